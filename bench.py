@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- leapfrog steps/sec of the fused WALNUTS/NUTS engine on the reference's headline
+workload (BASELINE.json: 100-D ill-conditioned Gaussian, kappa=1e4, fixedLeapFrog, M=10,
+H0=0.5, 100 iterations; SURVEY.md 8d cfg 2), with roofline and CPU-baseline legs.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one wn_run launch: `--iters` sampler iterations for `--chains` chains per GPU.
+Chains shard over GPUs with no data-path collective (weak scaling: per-GPU chains fixed); the
+only collective is the final gather of draws (reported separately as gather_ms) and the
+step-count/time reductions.
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 20251121            # SURVEY.md 8d master seed
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix (v_mfma_f64_16x16x4_f64: 256 CU x 4 SIMD x 32 flop/clk
+                              # x 2.4 GHz); checked on the box by tools/mfma_f64_rate.hip (profiles/)
+HBM_PEAK_GBS = 8000.0
+
+
+def make_dense_problem(D, kappa, C, seed, chain_offset=0):
+    """Sigma = Q diag(lam) Q', lam = logspace(0, log10 kappa, D); precision A = Q diag(1/lam) Q'
+    symmetrised; q0 ~ N(0, Sigma) per chain, keyed by 256-chain blocks of the GLOBAL chain id so
+    that a chain's start is the same however chains are sharded."""
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.normal(size=(D, D)))
+    lam = np.logspace(0.0, np.log10(kappa), D)
+    A = (Q * (1.0 / lam)) @ Q.T
+    A = 0.5 * (A + A.T)
+    S = Q * np.sqrt(lam)
+    q0 = np.empty((C, D))
+    c = 0
+    while c < C:
+        g = chain_offset + c
+        blk, off = divmod(g, 256)
+        z = np.random.default_rng([seed, 7, blk]).normal(size=(256, D))
+        n = min(256 - off, C - c)
+        q0[c:c + n] = z[off:off + n] @ S.T
+        c += n
+    return A, q0
+
+
+def _cpu_worker(args):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    A, q0, chain, iters, M, H0 = args
+    t0 = time.perf_counter()
+    o = ol.walnuts(ol.T_DENSEGAUSS, q0, integrator=ol.I_FIXED, tpar=A.ravel(), H0=H0, numIter=iters,
+                   M=M, seed=SEED, chain=chain)
+    dt = time.perf_counter() - t0
+    d = o["diagnostics"]
+    return float(d[:, 6].sum() + d[:, 7].sum()), dt
+
+
+def cpu_baseline(A, q0, iters, M, H0, budget_s=12.0):
+    """Time the CPU oracle (the validated C restatement of the reference's path) on the host
+    cores, one chain per process, on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    ol.build()
+    cores = os.cpu_count() or 1
+    # calibrate on one chain, one iteration
+    s1, t1 = _cpu_worker((A, q0[0], 0, 1, M, H0))
+    rate1 = s1 / max(t1, 1e-6)
+    per_iter = 540.0 / rate1 if rate1 > 0 else 1.0
+    n_it = int(max(1, min(iters, budget_s / max(per_iter, 1e-6))))
+    nchain = min(cores, q0.shape[0])
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(nchain) as pool:
+        res = pool.map(_cpu_worker, [(A, q0[c], c, n_it, M, H0) for c in range(nchain)])
+    wall = time.perf_counter() - t0
+    steps = sum(r[0] for r in res)
+    return {"value": steps / wall, "unit": "leapfrog steps/s", "cores": nchain, "kind": "port",
+            "sample": f"{nchain} chains x {n_it} iterations of the same workload, one chain per process "
+                      f"(oracle/libwalnuts_oracle.so, C restatement pinned to the Python reference)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--chains", type=int, default=4096, help="chains per GPU")
+    ap.add_argument("--iters", type=int, default=100, help="sampler iterations per launch")
+    ap.add_argument("--dim", type=int, default=100)
+    ap.add_argument("--kappa", type=float, default=1e4)
+    ap.add_argument("--M", type=int, default=10)
+    ap.add_argument("--H0", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch from a separate rocprofv3 --pmc pass (see profiles/)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    import walnuts_amd as wa
+    from walnuts_amd import _lib as L
+
+    C, D = args.chains, args.dim
+    offset = rank * C
+    A, q0 = make_dense_problem(D, args.kappa, C, SEED, chain_offset=offset)
+    eng = wa.Engine(D, C, integrator=L.I_FIXED, H0=args.H0, stepSizeRandScale=0.2, M=args.M,
+                    generated=L.G_Q0_SUMSQ, chain_offset=offset, device=dev.index)
+    eng.set_target(L.T_DENSEGAUSS, A)
+    q0d = torch.as_tensor(q0, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for w in range(args.warmup):
+        eng.run(q0d, SEED + 1000 + w, args.iters)
+    barrier()
+    t0 = time.perf_counter()
+    total_steps = torch.zeros((), dtype=torch.float64, device=dev)
+    kernel_ms = []
+    last = None
+    for k in range(args.steps):
+        samples, diag = eng.run(q0d, SEED + k, args.iters)
+        total_steps += diag[:, :, 6].sum() + diag[:, :, 7].sum()
+        kernel_ms.append(eng.last_run_ms())  # HIP events on the launch stream (synchronises)
+        last = samples
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(total_steps, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    steps_all = float(total_steps.item())
+
+    # final gather of draws to rank 0 (the only data collective; RCCL over xGMI), timed apart
+    gather_ms = 0.0
+    if world > 1:
+        torch.cuda.synchronize(dev)
+        g0 = time.perf_counter()
+        bufs = [torch.empty_like(last) for _ in range(world)] if rank == 0 else None
+        dist.gather(last, bufs, dst=0)
+        torch.cuda.synchronize(dev)
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    if rank == 0:
+        flop_per_step = 2.0 * D * D + 12.0 * D  # matvec + leapfrog updates + 2 dots
+        avg_ms = float(np.mean(kernel_ms))
+        steps_per_launch_rank0 = steps_all / world / args.steps
+        achieved = steps_per_launch_rank0 * flop_per_step / (avg_ms * 1e-3) / 1e12
+        out = {
+            "metric": "leapfrog steps/sec across chains, 100-D Gaussian",
+            "value": steps_all / elapsed,
+            "unit": "leapfrog steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{D}-D dense Gaussian kappa={args.kappa:g}, {C} chains/GPU, "
+                                   f"fixedLeapFrog, M={args.M}, H0={args.H0}, {args.iters} iterations/launch "
+                                   f"(SURVEY 8d cfg 2)",
+                       "chains_per_gpu": C, "dim": D, "iters_per_step": args.iters,
+                       "kernel": eng.kernel_name, "sharding": f"chains x{world}, no data-path collective"},
+            "leapfrog_steps_per_launch_per_gpu": steps_per_launch_rank0,
+            "kernel_ms_avg": avg_ms,
+            "gather_ms": gather_ms,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                         "traffic": args.traffic_bytes,
+                         "flop_per_leapfrog_step": flop_per_step},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(A, q0, args.iters, args.M, args.H0)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

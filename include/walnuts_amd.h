@@ -1,0 +1,144 @@
+/*
+ * walnuts_amd.h -- C ABI of the MI355X-native batched WALNUTS/NUTS engine.
+ *
+ * The reference (bob-carpenter/walnuts) has no FFI: its boundary is Python call signatures
+ * (SURVEY.md 8b).  This ABI is what sits *behind* Python functions of those shapes
+ * (walnuts_amd/WALNUTS.py mirrors WALNUTSpy/WALNUTS.py:111-129, walnuts_amd/walnuts.py mirrors
+ * walnuts/walnuts.py:362-373); each entry point cites the reference interface it replaces.
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions: plain C types only; every pointer named *_dev is device memory on the
+ * engine's GPU, owned by the caller; all functions return 0 on success or a negative
+ * WN_E_* code, never throw and never exit(); one engine per GPU, not thread-safe per engine,
+ * safe across engines.  All arithmetic is IEEE binary64 ("f64").
+ */
+#ifndef WALNUTS_AMD_H
+#define WALNUTS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WN_ABI_VERSION 1
+#define WN_NDIAG 24      /* diagnostics columns, WALNUTSpy/WALNUTS.py:670-693 */
+#define WN_TRACE_NSCAL 12 /* trace row = 12 scalars + q[D] + v[D] */
+
+/* error codes */
+enum {
+  WN_OK = 0,
+  WN_E_ARG = -1,         /* bad argument (the reference: ValueError / sys.exit on bad targets) */
+  WN_E_UNSUPPORTED = -2, /* configuration has no device kernel (yet) */
+  WN_E_HIP = -3,         /* HIP runtime error, see wn_last_error */
+  WN_E_NOTARGET = -4,    /* wn_set_target not called */
+  WN_E_ALLOC = -5
+};
+
+/* target plugin lpFun(q) -> [lp, grad]  (WALNUTSpy/targetDistr.py; adaptiveIntegrators.py passes
+ * it as `lpFun`).  On the device the plugin is an enum + parameter buffer. */
+enum {
+  WN_T_STDGAUSS = 0,   /* targetDistr.py:18-21 */
+  WN_T_FUNNEL10 = 1,   /* targetDistr.py:74-78 (D = 11) */
+  WN_T_DENSEGAUSS = 2, /* lp = -1/2 q'Aq, grad = -Aq; params = A row-major D*D (SURVEY.md 8d cfg 2/4) */
+  WN_T_DIAGGAUSS = 3,  /* params = diag(A), D (SURVEY.md 8d cfg 2 diagonal variant) */
+  WN_T_CORRGAUSS = 4,  /* targetDistr.py:25-31 (D = 2) */
+  WN_T_SMILE = 5,      /* targetDistr.py:34-38 (D = 2) */
+  WN_T_FUNNEL1 = 6,    /* targetDistr.py:88-93 (D = 2) */
+  WN_T_MODFUNNEL = 7   /* targetDistr.py:41-51 (D = 2) */
+};
+
+/* macro-step integrator plugin  integrator(q,v,g,Ham0,h,xi,lpFun,delta,auxPar)
+ * (WALNUTSpy/adaptiveIntegrators.py) */
+enum {
+  WN_I_FIXED = 0,     /* fixedLeapFrog    adaptiveIntegrators.py:49-59  */
+  WN_I_ADAPT_D = 1,   /* adaptLeapFrogD   adaptiveIntegrators.py:65-137 */
+  WN_I_ADAPT_R2P = 2  /* adaptLeapFrogR2P adaptiveIntegrators.py:361-475 */
+};
+
+/* generated(q): what is stored per draw (WALNUTS.py:113,164,695) */
+enum {
+  WN_G_IDENTITY = 0, /* lambda q: q */
+  WN_G_Q0_SUMSQ = 1, /* [q[0], sum(q*q)]  WALNUTSpy_examples/gaussian/mainGaussESS.py:29-30 */
+  WN_G_FIRSTK = 2    /* q[0:k]            WALNUTSpy_examples/funnel/mainFunnel.py:17-18 */
+};
+
+/* keyword arguments of WALNUTS(...) (WALNUTS.py:111-129) + integratorAuxPar
+ * (adaptiveIntegrators.py:36-44) as a flat struct. */
+typedef struct wn_config {
+  int32_t abi_version; /* WN_ABI_VERSION */
+  int32_t device;      /* HIP device ordinal */
+  int32_t dim;         /* D = q0.size */
+  int32_t n_chains;    /* chains resident on this engine */
+  int64_t chain_offset; /* global id of local chain 0; RNG is keyed by global id */
+  int32_t integrator;  /* WN_I_* */
+  int32_t M;           /* max doublings, WALNUTS.py:121 */
+  int32_t min_c;       /* integratorAuxPar.minC */
+  int32_t max_c;       /* integratorAuxPar.maxC */
+  double H0;           /* WALNUTS.py:115 */
+  double step_size_rand_scale; /* WALNUTS.py:116 */
+  double delta0;       /* WALNUTS.py:117 */
+  double r2p_prob0;    /* integratorAuxPar.R2Pprob0 */
+  int32_t generated;   /* WN_G_* */
+  int32_t gen_k;
+  int32_t warmup_iter; /* WALNUTS.py:120; must be 0 (adaptation is SURVEY.md 8f) */
+  int32_t waves_per_group; /* cooperative (MFMA) layout: waves sharing one 16-chain group; 0 = auto */
+} wn_config;
+
+typedef struct wn_engine wn_engine;
+
+/* Construct an engine on cfg->device; allocates the engine's own workspace. */
+int wn_create(const wn_config *cfg, wn_engine **out);
+
+/* Select the target plugin (replaces passing `lpFun`, WALNUTS.py:111).  params_dev: device
+ * buffer of n_params doubles (see WN_T_*), copied into engine-owned storage. */
+int wn_set_target(wn_engine *e, int32_t kind, const double *params_dev, size_t n_params);
+
+/* WALNUTS(lpFun, q0, ..., numIter) for all resident chains (WALNUTS.py:189-695).
+ *   q0_dev      [C][D]                chain-major initial positions
+ *   samples_dev [C][n_iter+1][dg]     row 0 = generated(q0)   (WALNUTS.py:164,695)
+ *   diag_dev    [C][n_iter][24]       (WALNUTS.py:670-693)
+ *   trace_dev   [C][trace_cap][12+2D] or NULL: one row per integrator call
+ *               {iter, doubling, xi, h, Ham0, lp, If, Ib, c, lwt, nEvalF, nEvalB, q', v'}
+ *   trace_n_dev [C] int32 or NULL: rows wanted per chain (may exceed trace_cap)
+ *   stream      hipStream_t (0 = default stream).  Asynchronous: returns after the launch. */
+int wn_run(wn_engine *e, const double *q0_dev, uint64_t seed, int32_t n_iter, double *samples_dev,
+           double *diag_dev, double *trace_dev, int32_t trace_cap, int32_t *trace_n_dev,
+           void *stream);
+
+/* One macro step for a batch of independent states -- the integrator plugin call
+ * integrator(q,v,g,Ham0,h,xi,lpFun,delta,auxPar) -> integratorReturn
+ * (adaptiveIntegrators.py:17-29,49,65,361).  Arrays are [B][D] / [B]; u_r2p_dev holds the
+ * uniform R2P consumes (adaptiveIntegrators.py:392).  iout_dev [B][5] = nEvalF,nEvalB,If,Ib,c;
+ * dout_dev [B][3] = lp, lwt, H1 (Hamiltonian of the returned state).  Uses cfg->integrator,
+ * delta0, min_c, max_c, r2p_prob0; B must equal cfg->n_chains. */
+int wn_integrator_step(wn_engine *e, const double *q_dev, const double *v_dev, const double *g_dev,
+                       const double *ham0_dev, const double *h_dev, const int32_t *xi_dev,
+                       const double *u_r2p_dev, double *q1_dev, double *v1_dev, double *g1_dev,
+                       int32_t *iout_dev, double *dout_dev, void *stream);
+
+/* lpFun(q) -> (lp, grad) for a batch: q_dev [B][D] -> lp_dev [B], grad_dev [B][D]. */
+int wn_lpfun(wn_engine *e, const double *q_dev, double *lp_dev, double *grad_dev, void *stream);
+
+/* Export the engine's random stream (wn_rng.h) so the oracle / the Python reference can be
+ * driven by the same randomness: u_dev [C][n_u] uniforms, z_dev [C][D] normals of iteration
+ * `iter` (1-based) for every resident chain.  Either pointer may be NULL. */
+int wn_rng_tape(wn_engine *e, uint64_t seed, int32_t iter, int32_t n_u, double *u_dev,
+                double *z_dev, void *stream);
+
+/* Kernel time of the last wn_run in milliseconds, measured with HIP events recorded on the
+ * launch stream (synchronises on the stop event). */
+int wn_last_run_ms(wn_engine *e, float *ms);
+
+/* Which kernel the engine dispatches to: "coop_mfma<NT,W>", "lane<DMAX>" ... (static string). */
+const char *wn_kernel_name(wn_engine *e);
+
+const char *wn_last_error(wn_engine *e); /* e may be NULL: last creation error */
+int wn_destroy(wn_engine *e);
+int wn_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,84 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every declared symbol, and the
+engine's chain state machine (walnuts_amd/csrc/wn_chain.h), instantiated on the host by
+tests/hostsim, reproduces the oracle on every golden configuration."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import hostsim_lib as hs
+import oracle_lib as ol
+import test_oracle_golden as tg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    from walnuts_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "walnuts_amd.h")).read()
+    declared = set(re.findall(r"\b(wn_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = _lib.lib()  # raises ImportError if the HIP library is not built (no fallback)
+    for s in declared:
+        assert hasattr(L, s), s
+    assert L.wn_abi_version() == _lib.WN_ABI_VERSION
+    assert C.sizeof(_lib.WnConfig) == 88
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import walnuts_amd as wa
+    with pytest.raises(wa.WalnutsError):
+        wa.Engine(3, 4)
+    from walnuts_amd import targetDistr as td
+    with pytest.raises(wa.WalnutsError):
+        wa.WALNUTS(td.stdGauss, np.zeros(3), warmupIter=0, numIter=2)
+
+
+def test_package_never_imports_oracle():
+    """The product path must not route through oracle/ or tests/hostsim."""
+    pkg = os.path.join(ROOT, "walnuts_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle_lib" not in txt and "walnuts_oracle" not in txt and "hostsim" not in txt, f
+
+
+@pytest.mark.parametrize("name", tg.CASES)
+def test_state_machine_on_host_matches_oracle(name):
+    c, ref = tg.load_case(name)
+    seed = int(tg.TR["seed"][0])
+    o = tg.run_oracle(c, ref, tape=False)
+    h = hs.walnuts(c["target"], c["q0"], integrator=c["integrator"], tpar=c["tpar"], H0=c["H0"],
+                   delta0=c["delta0"], numIter=c["numIter"], M=c["M"], minC=c["minC"], maxC=c["maxC"],
+                   generated=c["generated"], gen_k=c["gen_k"], seed=seed, chain0=c["chain"],
+                   trace_cap=len(ref["trace"]) + 8)
+    n = o["ncalls"]
+    assert int(h["trace_n"][0]) == n
+    tr = h["trace"][0, :n]
+    for col in (0, 1, 2, 6, 7, 8, 10, 11):
+        np.testing.assert_array_equal(tr[:, col], o["trace"][:, col], err_msg=f"col {col}")
+    tg.close(tr[:, 3:6], o["trace"][:, 3:6], rtol=1e-12, atol=1e-13)
+    tg.close(tr[:, 12:], o["trace"][:, 12:], rtol=1e-12, atol=1e-13)
+    tg.close(h["samples"][0], o["samples"], rtol=1e-12, atol=1e-13)
+    d, rd = h["diagnostics"][0], o["diagnostics"]
+    for col in (0, 1, 4, 5, 6, 7, 8, 9, 12, 13, 19, 20, 21, 22):
+        np.testing.assert_array_equal(d[:, col], rd[:, col], err_msg=f"diag col {col}")
+    tg.close(d, rd, rtol=1e-10, atol=1e-12)
+
+
+def test_state_machine_many_chains_host():
+    rng = np.random.default_rng(1)
+    q0 = rng.normal(size=(6, 10))
+    h = hs.walnuts(ol.T_STDGAUSS, q0, integrator=ol.I_ADAPT_R2P, H0=0.9, delta0=0.2, numIter=15, M=7,
+                   seed=99, chain0=500, generated=1)
+    for k in range(6):
+        o = ol.walnuts(ol.T_STDGAUSS, q0[k], integrator=ol.I_ADAPT_R2P, H0=0.9, delta0=0.2, numIter=15,
+                       M=7, seed=99, chain=500 + k, generated=1)
+        tg.close(h["samples"][k], o["samples"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_array_equal(h["diagnostics"][k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]])

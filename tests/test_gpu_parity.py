@@ -1,0 +1,276 @@
+"""GPU parity tests: the HIP engine, called through the C ABI, against
+  (1) the golden fixtures captured from the Python reference, and
+  (2) the CPU oracle on the same seeded inputs (the engine's RNG stream is replayed by the
+      oracle's independent Philox restatement).
+Tolerance for floating point: rtol 1e-6 (BASELINE.json north_star), integers exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TR = np.load(os.path.join(G, "walnuts_traces.npz"))
+KA = np.load(os.path.join(G, "integrator_kats.npz"))
+CASES = [str(x) for x in TR["case_names"]]
+SEED = int(TR["seed"][0])
+RTOL, ATOL = 1e-6, 1e-9
+INT_DIAG = (0, 1, 4, 5, 6, 7, 8, 9, 12, 13, 19, 20, 21, 22)
+
+
+@pytest.fixture(scope="module")
+def wa():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import walnuts_amd
+    return walnuts_amd
+
+
+def close(a, b, rtol=RTOL, atol=ATOL, what=""):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    with np.errstate(all="ignore"):
+        both_nan = np.isnan(a) & np.isnan(b)
+        same_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
+        ok = both_nan | same_inf | (np.abs(a - b) <= atol + rtol * np.abs(b))
+    assert ok.all(), f"{what}: {np.count_nonzero(~ok)} mismatches, first at {np.argwhere(~ok)[:4].tolist()}, " \
+                     f"a={a[~ok][:4]}, b={b[~ok][:4]}"
+
+
+def load_case(name):
+    p = name + "__"
+    cfg = TR[p + "cfg"]; par = TR[p + "par"]
+    c = dict(target=int(cfg[0]), integrator=int(cfg[1]), M=int(cfg[2]), numIter=int(cfg[3]),
+             minC=int(cfg[4]), maxC=int(cfg[5]), generated=int(cfg[6]), gen_k=int(cfg[7]),
+             chain=int(cfg[8]), H0=float(par[0]), s=float(par[1]), delta0=float(par[2]),
+             R2Pprob0=float(par[3]), q0=TR[p + "q0"],
+             tpar=TR[p + "tpar"] if (p + "tpar") in TR.files else None)
+    ref = {k: TR[p + k] for k in ("samples", "diagnostics", "trace", "n_u")}
+    return c, ref
+
+
+def run_engine(wa, c, q0, ncalls_hint, chain_offset):
+    q0 = np.atleast_2d(q0)
+    e = wa.Engine(q0.shape[1], q0.shape[0], integrator=c["integrator"], H0=c["H0"],
+                  stepSizeRandScale=c["s"], delta0=c["delta0"], M=c["M"], minC=c["minC"],
+                  maxC=c["maxC"], R2Pprob0=c["R2Pprob0"], generated=c["generated"], gen_k=c["gen_k"],
+                  chain_offset=chain_offset)
+    e.set_target(c["target"], c["tpar"])
+    s, d, tr, tn = e.run(q0, SEED, c["numIter"], trace_cap=ncalls_hint)
+    out = dict(samples=s.transpose(1, 2).cpu().numpy(), diagnostics=d.cpu().numpy(),
+               trace=tr.cpu().numpy(), trace_n=tn.cpu().numpy(), kernel=e.kernel_name)
+    e.close()
+    return out
+
+
+def compare_chain(out, k, ref_trace, ref_samples, ref_diag, what):
+    n = len(ref_trace)
+    assert out["trace_n"][k] == n, f"{what}: {out['trace_n'][k]} integrator calls, reference {n}"
+    tr = out["trace"][k, :n]
+    for col in (0, 2, 6, 7, 8, 10, 11):  # iter, xi, If, Ib, c, nEvalF, nEvalB
+        np.testing.assert_array_equal(tr[:, col], ref_trace[:, col], err_msg=f"{what} trace col {col}")
+    close(tr[:, 3:6], ref_trace[:, 3:6], what=what + " h/Ham0/lp")
+    close(tr[:, 9], ref_trace[:, 9], what=what + " lwt")
+    close(tr[:, 12:], ref_trace[:, 12:], what=what + " per-step (q,v)")
+    close(out["samples"][k], ref_samples, what=what + " samples")
+    d = out["diagnostics"][k]
+    for col in INT_DIAG:
+        np.testing.assert_array_equal(d[:, col], ref_diag[:, col], err_msg=f"{what} diag col {col}")
+    close(d, ref_diag, what=what + " diagnostics")
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_trace_through_c_abi(wa, name):
+    """Every integrator call of every reference fixture, reproduced by the HIP engine."""
+    c, ref = load_case(name)
+    out = run_engine(wa, c, c["q0"], len(ref["trace"]) + 8, c["chain"])
+    compare_chain(out, 0, ref["trace"], ref["samples"], ref["diagnostics"], name)
+
+
+def test_rng_tape_matches_oracle(wa):
+    e = wa.Engine(37, 5, chain_offset=1000)
+    u, z = e.rng_tape(SEED, 3, 50)
+    u = u.cpu().numpy(); z = z.cpu().numpy()
+    for c in range(5):
+        uo, zo = ol.rng_tape(SEED, 1000 + c, 3, 50, 37)
+        np.testing.assert_array_equal(u[c], uo)          # integer path: bit exact
+        np.testing.assert_allclose(z[c], zo, rtol=1e-14, atol=1e-15)  # libm vs ocml log/sincos
+    e.close()
+
+
+@pytest.mark.parametrize("i", range(int(KA["n"][0])))
+def test_integrator_kat_through_c_abi(wa, i):
+    p = f"k{i}__"
+    tk, kind, d, xi, minC, maxC = [int(x) for x in KA[p + "meta"]]
+    Ham0, h, delta, u = [float(x) for x in KA[p + "par"]]
+    tpar = KA["dense6_A"] if tk == ol.T_DENSEGAUSS else None
+    e = wa.Engine(d, 1, integrator=kind, delta0=delta, minC=minC, maxC=maxC)
+    e.set_target(tk, tpar)
+    q1, v1, g1, io, do = e.integrator_step(KA[p + "q"], KA[p + "v"], KA[p + "g"], [Ham0], [h], [xi], [u])
+    np.testing.assert_array_equal(io.cpu().numpy()[0], KA[p + "io"])
+    close(do.cpu().numpy()[0][:2], KA[p + "do"][:2], what="lp,lwt")
+    close(q1.cpu().numpy()[0], KA[p + "q1"], what="q"); close(v1.cpu().numpy()[0], KA[p + "v1"], what="v")
+    close(g1.cpu().numpy()[0], KA[p + "g1"], what="grad")
+    e.close()
+
+
+@pytest.mark.parametrize("tname", ["std3", "std100", "funnel", "dense6", "corr", "smile", "funnel1", "modfunnel"])
+def test_lpfun_through_c_abi(wa, tname):
+    tk, d = [int(x) for x in KA[f"lp__{tname}__kind"]]
+    Q = KA[f"lp__{tname}__q"]
+    tpar = KA["dense6_A"] if tk == ol.T_DENSEGAUSS else None
+    e = wa.Engine(d, Q.shape[0]).set_target(tk, tpar)
+    lp, g = e.lpfun(Q)
+    close(lp.cpu().numpy(), KA[f"lp__{tname}__lp"], rtol=1e-12, what="lp")
+    close(g.cpu().numpy(), KA[f"lp__{tname}__g"], rtol=1e-12, what="grad")
+    e.close()
+
+
+def dense_problem(D, kappa, C, seed):
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.normal(size=(D, D)))
+    lam = np.logspace(0, np.log10(kappa), D)
+    A = (Q * (1.0 / lam)) @ Q.T
+    A = 0.5 * (A + A.T)
+    q0 = rng.normal(size=(C, D)) @ (Q * np.sqrt(lam)).T
+    return A, q0
+
+
+BATCH = [
+    # name, target, D, integrator, kwargs, C, check chains
+    ("dense100_fixed", ol.T_DENSEGAUSS, 100, ol.I_FIXED, dict(H0=0.5, M=7, numIter=4), 48, (0, 17, 47)),
+    ("dense100_R2P", ol.T_DENSEGAUSS, 100, ol.I_ADAPT_R2P, dict(H0=1.2, delta0=0.3, M=5, numIter=3), 20, (0, 19)),
+    ("dense100_D", ol.T_DENSEGAUSS, 100, ol.I_ADAPT_D, dict(H0=1.2, delta0=0.3, M=5, numIter=3), 16, (3, 15)),
+    ("dense64_fixed", ol.T_DENSEGAUSS, 64, ol.I_FIXED, dict(H0=0.6, M=6, numIter=4), 33, (0, 32)),
+    ("dense128_fixed", ol.T_DENSEGAUSS, 128, ol.I_FIXED, dict(H0=0.6, M=6, numIter=3), 17, (16,)),
+    ("dense37_fixed", ol.T_DENSEGAUSS, 37, ol.I_FIXED, dict(H0=0.6, M=6, numIter=4), 16, (5,)),
+    ("std100_R2P", ol.T_STDGAUSS, 100, ol.I_ADAPT_R2P, dict(H0=1.4 * 100 ** -0.25, delta0=0.3, M=8, numIter=6), 40, (0, 39)),
+    ("diag200_fixed", ol.T_DIAGGAUSS, 200, ol.I_FIXED, dict(H0=0.7, M=6, numIter=4), 16, (9,)),
+    ("std10_fixed", ol.T_STDGAUSS, 10, ol.I_FIXED, dict(H0=0.9, M=8, numIter=8), 130, (0, 64, 129)),
+    ("funnel_R2P", ol.T_FUNNEL10, 11, ol.I_ADAPT_R2P, dict(H0=0.3, delta0=0.3, M=8, numIter=6), 100, (0, 63, 64, 99)),
+    ("funnel_D", ol.T_FUNNEL10, 11, ol.I_ADAPT_D, dict(H0=0.3, delta0=0.3, M=8, numIter=6), 70, (1, 69)),
+]
+
+
+@pytest.mark.parametrize("case", BATCH, ids=[b[0] for b in BATCH])
+def test_batch_matches_oracle(wa, case):
+    """Many chains in one launch (ragged chain counts, both layouts): selected chains must
+    reproduce the oracle's per-step (q, v) trajectory on the same seed."""
+    name, tk, D, ig, kw, C, check = case
+    rng = np.random.default_rng(42)
+    tpar = None
+    if tk == ol.T_DENSEGAUSS:
+        tpar, q0 = dense_problem(D, 1e4 if D >= 64 else 100.0, C, 5)
+        tpar = tpar.ravel()
+    elif tk == ol.T_DIAGGAUSS:
+        tpar = 1.0 / np.logspace(0, 3, D)
+        q0 = rng.normal(size=(C, D)) / np.sqrt(tpar)
+    elif tk == ol.T_FUNNEL10:
+        q0 = np.zeros((C, 11)); q0[:, 0] = 3.0 * rng.normal(size=C)
+        q0[:, 1:] = np.exp(0.5 * q0[:, :1]) * rng.normal(size=(C, 10))
+    else:
+        q0 = rng.normal(size=(C, D))
+    c = dict(target=tk, integrator=ig, H0=kw["H0"], s=0.2, delta0=kw.get("delta0", 0.05), M=kw["M"],
+             numIter=kw["numIter"], minC=0, maxC=10, R2Pprob0=2.0 / 3.0, generated=0, gen_k=0, tpar=tpar)
+    cap = 3 * (2 ** kw["M"]) * kw["numIter"] // 2
+    out = run_engine(wa, c, q0, cap, chain_offset=7000)
+    for k in check:
+        o = ol.walnuts(tk, q0[k], integrator=ig, tpar=tpar, H0=c["H0"], delta0=c["delta0"],
+                       numIter=c["numIter"], M=c["M"], seed=SEED, chain=7000 + k, trace_cap=cap)
+        assert o["ncalls"] <= cap
+        compare_chain(out, k, o["trace"], o["samples"], o["diagnostics"], f"{name} chain {k} [{out['kernel']}]")
+
+
+def test_sharding_invariance(wa):
+    """per-chain results do not depend on how chains are split over engines/GPUs."""
+    A, q0 = dense_problem(100, 1e4, 64, 11)
+    c = dict(target=ol.T_DENSEGAUSS, integrator=ol.I_FIXED, H0=0.5, s=0.2, delta0=0.05, M=6, numIter=3,
+             minC=0, maxC=10, R2Pprob0=2.0 / 3.0, generated=1, gen_k=0, tpar=A.ravel())
+    whole = run_engine(wa, c, q0, 8, chain_offset=0)
+    a = run_engine(wa, c, q0[:32], 8, chain_offset=0)
+    b = run_engine(wa, c, q0[32:], 8, chain_offset=32)
+    np.testing.assert_array_equal(whole["samples"], np.concatenate([a["samples"], b["samples"]]))
+    np.testing.assert_array_equal(whole["diagnostics"], np.concatenate([a["diagnostics"], b["diagnostics"]]))
+
+
+def test_time_reversal_of_integrators(wa):
+    """Invariant the reference's commented scaffold checks (adaptiveIntegrators.py:769-789):
+    integrating forward and then from (q', -v') returns to (q, -v) with If/Ib swapped."""
+    A, q0 = dense_problem(100, 1e4, 32, 3)
+    rng = np.random.default_rng(0)
+    v = rng.normal(size=q0.shape)
+    for kind in (ol.I_FIXED, ol.I_ADAPT_D):
+        e = wa.Engine(100, 32, integrator=kind, delta0=0.05).set_target(ol.T_DENSEGAUSS, A)
+        lp, g = e.lpfun(q0)
+        H0 = (-lp.cpu().numpy() + 0.5 * (v * v).sum(1))
+        h = np.full(32, 0.9); xi = np.ones(32, dtype=np.int32)
+        q1, v1, g1, io, do = e.integrator_step(q0, v, g, H0, h, xi)
+        q2, v2, g2, io2, do2 = e.integrator_step(q1, -v1, g1, do[:, 2], h, xi)
+        np.testing.assert_allclose(q2.cpu().numpy(), q0, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(v2.cpu().numpy(), -v, rtol=1e-9, atol=1e-10)
+        if kind == ol.I_ADAPT_D:
+            io = io.cpu().numpy(); io2 = io2.cpu().numpy()
+            np.testing.assert_array_equal(io[:, 2], io2[:, 3])  # If forward == Ib of the return trip
+        e.close()
+
+
+def test_full_size_properties(wa):
+    """BASELINE configs[1] at full size (100-D kappa=1e4, 1024 chains, fixedLeapFrog, M=10):
+    size-independent properties -- step accounting, energy-error sanity, stop codes, and the
+    exact invariant  #steps = sum over completed doublings of 2**i."""
+    A, q0 = dense_problem(100, 1e4, 1024, 20251121)
+    e = wa.Engine(100, 1024, integrator=ol.I_FIXED, H0=0.5, M=10, generated=1).set_target(ol.T_DENSEGAUSS, A)
+    s, d = e.run(q0, SEED, 6)
+    d = d.cpu().numpy(); s = s.cpu().numpy()
+    assert np.isfinite(d).all() and np.isfinite(s).all()
+    assert set(np.unique(d[:, :, 19]).astype(int)).issubset({0, 4, 5})
+    nd = d[:, :, 20].astype(int)  # doublings computed; each computes 2**i steps unless cut by a sub-U-turn
+    steps = d[:, :, 6]
+    full = d[:, :, 19] != 5
+    assert (steps[full] == (2 ** nd[full] - 1)).all()
+    assert (steps[~full] <= (2 ** nd[~full] - 1)).all() and (steps[~full] > 2 ** (nd[~full] - 1) - 1).all()
+    assert (d[:, :, 7] == 0).all()
+    assert d[:, :, 17].max() < 5.0  # orbit energy error stays O(1) at H0=0.5 (~1.25 max)
+    assert (d[:, :, 4] - d[:, :, 5] == steps).all()  # maxFint - maxBint = number of steps
+    # draws: second generated component is sum(q^2) of the first... check against recomputation
+    s2, d2 = e.run(q0, SEED, 6)
+    np.testing.assert_array_equal(s2.cpu().numpy(), s)  # deterministic
+    e.close()
+
+
+def test_error_paths(wa):
+    with pytest.raises(ValueError):
+        wa.Engine(3, 4, M=0)
+    with pytest.raises(NotImplementedError):
+        wa.Engine(3, 4, warmupIter=10)
+    e = wa.Engine(5, 4)
+    with pytest.raises(ValueError):
+        e.set_target(ol.T_FUNNEL10)
+    with pytest.raises(wa.WalnutsError):
+        e.run(np.zeros((4, 5)), 0, 1)  # no target yet
+    e.close()
+    with pytest.raises(NotImplementedError):
+        wa.Engine(3000, 4).set_target(ol.T_STDGAUSS)
+
+
+def test_walnuts_api_shapes(wa):
+    """Single-chain call returns exactly the reference's shapes (WALNUTS.py:163,180,724-727)."""
+    from walnuts_amd import adaptiveIntegrators as ai, targetDistr as td
+    s, d = wa.WALNUTS(td.stdGauss, np.zeros(7), integrator=ai.adaptLeapFrogR2P, numIter=12, warmupIter=0, M=6,
+                      H0=0.8, delta0=0.3, seed=5)
+    assert s.shape == (7, 13) and d.shape == (12, 24)
+    np.testing.assert_array_equal(s[:, 0], 0.0)
+    s2, d2 = wa.WALNUTS(td.stdGauss, np.zeros((3, 7)), generated=lambda q: np.array([q[0], sum(q * q)]),
+                        numIter=5, warmupIter=0, M=6, H0=0.8, seed=5)
+    assert s2.shape == (3, 2, 6) and d2.shape == (3, 5, 24)
+    lp, g = td.funnel10(np.arange(11) * 0.1)
+    lo, go = ol.lpfun(ol.T_FUNNEL10, np.arange(11) * 0.1)
+    np.testing.assert_allclose(lp, lo, rtol=1e-12); np.testing.assert_allclose(g, go, rtol=1e-12)
+    with pytest.raises(TypeError):
+        wa.WALNUTS(lambda q: [0.0, -q], np.zeros(3), warmupIter=0)
+    with pytest.raises(NotImplementedError):
+        wa.WALNUTS(td.stdGauss, np.zeros(3))  # default warmupIter=1000 needs adaptation

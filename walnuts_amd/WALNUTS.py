@@ -1,0 +1,88 @@
+"""WALNUTS(...) with the reference's signature (WALNUTSpy/WALNUTS.py:111-129), batched on the GPU.
+
+Differences a caller sees:
+  * lpFun / integrator are device descriptors (walnuts_amd.targetDistr / .adaptiveIntegrators);
+  * q0 may be (D,) -- one chain, returns exactly the reference's shapes -- or (C, D) for C
+    independent chains, returning arrays with a leading chain axis;
+  * randomness comes from the engine's counter-based stream keyed by (seed, chain, iteration)
+    instead of NumPy's global state; pass seed= and chain_offset=.
+"""
+import sys
+
+import numpy as np
+
+from . import _lib as L
+from . import adaptiveIntegrators as ai
+from .engine import Engine
+from .targetDistr import DeviceTarget
+
+
+class Generated:
+    """Device forms of the `generated` argument (WALNUTS.py:113)."""
+
+    def __init__(self, kind, k=0):
+        self.kind, self.k = kind, k
+
+
+identity = Generated(L.G_IDENTITY)
+q0_sumsq = Generated(L.G_Q0_SUMSQ)  # mainGaussESS.py:29-30  [q[0], sum(q*q)]
+
+
+def firstk(k):
+    return Generated(L.G_FIRSTK, k)  # mainFunnel.py:17-18
+
+
+def WALNUTS(lpFun, q0, generated=identity, integrator=ai.fixedLeapFrog, H0=0.2,
+            stepSizeRandScale=0.2, delta0=0.05, numIter=2000, warmupIter=1000, M=10,
+            igrAux=None, adaptH=True, adaptHtarget=0.8, adaptDelta=True, adaptDeltaTarget=0.6,
+            adaptDeltaQuantile=0.9, recordOrbitStats=False, *, seed=0, chain_offset=0, device=None,
+            return_torch=False, trace_cap=0):
+    if igrAux is None:
+        igrAux = ai.integratorAuxPar()
+    if not isinstance(lpFun, DeviceTarget):
+        raise TypeError("lpFun must be a walnuts_amd.targetDistr descriptor: a Python callable cannot "
+                        "run inside the fused GPU kernel")
+    if not isinstance(integrator, ai.DeviceIntegrator):
+        raise TypeError("integrator must be one of walnuts_amd.adaptiveIntegrators.{fixedLeapFrog,"
+                        "adaptLeapFrogD,adaptLeapFrogR2P}")
+    if warmupIter > 0 and (adaptH or adaptDelta):
+        # the reference sys.exit()s on bad adaptation targets (WALNUTS.py:140,146)
+        if adaptH and (adaptHtarget < 0.0 or adaptHtarget > 1.0):
+            sys.exit("bad adaptHtarget")
+        if adaptDelta and adaptDeltaTarget < 0.0:
+            sys.exit("bad adaptDeltaTarget")
+        raise NotImplementedError("warm-up adaptation of H/delta (WALNUTS.py:701-712) is not on the "
+                                  "device yet; pass warmupIter=0 (SURVEY.md 8f)")
+    if recordOrbitStats:
+        raise NotImplementedError("recordOrbitStats (WALNUTS.py:182-184) is not on the device yet")
+    host_gen = None
+    if not isinstance(generated, Generated):
+        if not callable(generated):
+            raise TypeError("generated must be callable or a walnuts_amd.WALNUTS.Generated")
+        host_gen, generated = generated, identity  # applied to the stored draws on the host
+    q0a = q0 if hasattr(q0, "data_ptr") else np.asarray(q0, dtype=np.float64)
+    single = q0a.ndim == 1
+    C, D = (1, q0a.shape[0]) if single else q0a.shape
+    lpFun.check_dim(D)
+    eng = Engine(D, C, integrator=integrator.kind, H0=H0, stepSizeRandScale=stepSizeRandScale,
+                 delta0=delta0, M=M, minC=igrAux.minC, maxC=igrAux.maxC, R2Pprob0=igrAux.R2Pprob0,
+                 generated=generated.kind, gen_k=generated.k, warmupIter=0,
+                 chain_offset=chain_offset, device=device)
+    eng.set_target(lpFun.kind, lpFun.params)
+    out = eng.run(q0a, seed, numIter, trace_cap=trace_cap)
+    samples, diag = out[0], out[1]
+    samples = samples.transpose(1, 2)  # [C, dg, numIter+1] as the reference's (dg, numIter+1)
+    if return_torch:
+        eng.torch.cuda.synchronize(eng.device)
+        res = (samples, diag) + tuple(out[2:])
+        eng.close()
+        return res
+    samples = samples.cpu().numpy(); diag = diag.cpu().numpy()
+    extra = tuple(t.cpu().numpy() for t in out[2:])
+    eng.close()
+    if host_gen is not None:
+        samples = np.stack([np.stack([np.asarray(host_gen(samples[c, :, i])) for i in range(numIter + 1)], axis=1)
+                            for c in range(C)])
+    if single:
+        return (samples[0], diag[0]) + tuple(x[0] for x in extra)
+    return (samples, diag) + extra

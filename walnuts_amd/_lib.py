@@ -1,0 +1,77 @@
+"""ctypes binding of libwalnuts_amd.so (the C ABI declared in include/walnuts_amd.h).
+
+There is no CPU fallback: if the HIP library is missing the import fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwalnuts_amd.so")
+
+WN_ABI_VERSION = 1
+NDIAG = 24
+TRACE_NSCAL = 12
+
+# enums of include/walnuts_amd.h
+T_STDGAUSS, T_FUNNEL10, T_DENSEGAUSS, T_DIAGGAUSS, T_CORRGAUSS, T_SMILE, T_FUNNEL1, T_MODFUNNEL = range(8)
+I_FIXED, I_ADAPT_D, I_ADAPT_R2P = range(3)
+G_IDENTITY, G_Q0_SUMSQ, G_FIRSTK = range(3)
+E_ARG, E_UNSUPPORTED, E_HIP, E_NOTARGET, E_ALLOC = -1, -2, -3, -4, -5
+
+
+class WnConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device", C.c_int32), ("dim", C.c_int32),
+        ("n_chains", C.c_int32), ("chain_offset", C.c_int64), ("integrator", C.c_int32),
+        ("M", C.c_int32), ("min_c", C.c_int32), ("max_c", C.c_int32),
+        ("H0", C.c_double), ("step_size_rand_scale", C.c_double), ("delta0", C.c_double),
+        ("r2p_prob0", C.c_double), ("generated", C.c_int32), ("gen_k", C.c_int32),
+        ("warmup_iter", C.c_int32), ("waves_per_group", C.c_int32),
+    ]
+
+
+# every symbol include/walnuts_amd.h declares
+SYMBOLS = ["wn_abi_version", "wn_create", "wn_set_target", "wn_run", "wn_integrator_step",
+           "wn_lpfun", "wn_rng_tape", "wn_last_run_ms", "wn_kernel_name", "wn_last_error",
+           "wn_destroy"]
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; raises ImportError (never falls back) when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the walnuts_amd engine is HIP-only and has no CPU fallback. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C walnuts_amd/csrc`.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.wn_abi_version.restype = C.c_int
+    L.wn_create.restype = C.c_int
+    L.wn_create.argtypes = [C.POINTER(WnConfig), C.POINTER(vp)]
+    L.wn_set_target.restype = C.c_int
+    L.wn_set_target.argtypes = [vp, C.c_int32, vp, C.c_size_t]
+    L.wn_run.restype = C.c_int
+    L.wn_run.argtypes = [vp, vp, C.c_uint64, C.c_int32, vp, vp, vp, C.c_int32, vp, vp]
+    L.wn_integrator_step.restype = C.c_int
+    L.wn_integrator_step.argtypes = [vp] * 14
+    L.wn_lpfun.restype = C.c_int
+    L.wn_lpfun.argtypes = [vp, vp, vp, vp, vp]
+    L.wn_rng_tape.restype = C.c_int
+    L.wn_rng_tape.argtypes = [vp, C.c_uint64, C.c_int32, C.c_int32, vp, vp, vp]
+    L.wn_last_run_ms.restype = C.c_int
+    L.wn_last_run_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.wn_kernel_name.restype = C.c_char_p
+    L.wn_kernel_name.argtypes = [vp]
+    L.wn_last_error.restype = C.c_char_p
+    L.wn_last_error.argtypes = [vp]
+    L.wn_destroy.restype = C.c_int
+    L.wn_destroy.argtypes = [vp]
+    if L.wn_abi_version() != WN_ABI_VERSION:
+        raise ImportError("libwalnuts_amd.so ABI version mismatch; rebuild it")
+    _lib = L
+    return L

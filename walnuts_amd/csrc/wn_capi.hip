@@ -1,0 +1,358 @@
+// wn_capi.hip -- the C ABI of include/walnuts_amd.h: engine object, kernel selection, launches.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/walnuts_amd.h"
+#include "wn_launch.h"
+#include "wn_policy_coop.h"  // CK_*
+
+using namespace wn;
+
+namespace wn {
+size_t lane_work_doubles(int dmax, int C, int M);
+size_t coop_work_doubles(int NT, int W, int C, int M);
+
+static int lane_dmax(int target, int D) {
+  switch (target) {
+    case T_STDGAUSS:
+    case T_DIAGGAUSS:
+      return D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : D <= 24 ? 24 : 0;
+    case T_DENSEGAUSS:
+      return D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : 0;
+    case T_FUNNEL10: return D == 11 ? 11 : 0;
+    case T_CORRGAUSS:
+    case T_SMILE:
+    case T_FUNNEL1:
+    case T_MODFUNNEL: return D == 2 ? 2 : 0;
+  }
+  return 0;
+}
+
+int choose_kernel(int target, int D, int waves_per_group, KernelChoice* kc) {
+  static char names[8][64];
+  static int slot = 0;
+  char* nm = names[(slot++) & 7];
+  int dm = lane_dmax(target, D);
+  if (dm) {
+    kc->layout = 0; kc->p0 = dm; kc->p1 = target; kc->W = 1;
+    snprintf(nm, 64, "wn_lane_kernel<DMAX=%d,target=%d>", dm, target);
+    kc->name = nm;
+    return 0;
+  }
+  if (target == T_DENSEGAUSS || target == T_DIAGGAUSS || target == T_STDGAUSS) {
+    const int W = waves_per_group ? waves_per_group : 4;
+    if (W != 4) return -1;
+    const int ks = (D + 3) / 4;
+    int KS = 0, NT = 0;
+    if (target == T_DENSEGAUSS) {
+      if (ks <= 16) { KS = 16; NT = 1; }
+      else if (ks <= 25) { KS = 25; NT = 2; }
+      else if (ks <= 32) { KS = 32; NT = 2; }
+    } else {
+      if (ks <= 16) { KS = 16; NT = 1; }
+      else if (ks <= 32) { KS = 32; NT = 2; }
+      else if (ks <= 64) { KS = 64; NT = 4; }
+    }
+    if (!KS) return -1;
+    kc->layout = 1; kc->p0 = KS; kc->p1 = (target == T_DENSEGAUSS) ? CK_DENSE : CK_DIAG; kc->W = W;
+    snprintf(nm, 64, "wn_coop_kernel<NT=%d,W=%d,KS=%d,%s>", NT, W, KS,
+             kc->p1 == CK_DENSE ? "dense" : "diag");
+    kc->name = nm;
+    return 0;
+  }
+  return -1;
+}
+
+size_t kernel_work_doubles(const KernelChoice& kc, int C, int M) {
+  if (kc.layout == 0) return lane_work_doubles(kc.p0, C, M);
+  const int NT = kc.p0 <= 16 ? 1 : kc.p0 <= 32 ? 2 : 4;
+  return coop_work_doubles(NT, kc.W, C, M);
+}
+
+// lpFun for a batch, one thread per chain (test/diagnostic entry; the samplers evaluate the
+// target inside their fused kernels)
+__global__ void wn_lpfun_kernel(int kind, int D, int B, const double* tpar, const double* q,
+                                double* lp, double* grad) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= B) return;
+  const double* x = q + (size_t)c * D;
+  double* g = grad + (size_t)c * D;
+  const double logC = 0.91893853320467274178, log3 = 1.09861228866810969140;
+  double r = 0.0;
+  switch (kind) {
+    case T_STDGAUSS:
+      for (int i = 0; i < D; ++i) { g[i] = -x[i]; r += x[i] * x[i]; }
+      r = -0.5 * r;
+      break;
+    case T_DIAGGAUSS:
+      for (int i = 0; i < D; ++i) { g[i] = -(tpar[i] * x[i]); r += x[i] * g[i]; }
+      r = 0.5 * r;
+      break;
+    case T_DENSEGAUSS:
+      for (int i = 0; i < D; ++i) {
+        double a = 0.0;
+        for (int j = 0; j < D; ++j) a += tpar[(size_t)i * D + j] * x[j];
+        g[i] = -a;
+        r += x[i] * g[i];
+      }
+      r = 0.5 * r;
+      break;
+    case T_FUNNEL10: {
+      double emq = exp(-x[0]), ss = 0.0;
+      for (int i = 1; i < 11; ++i) ss += x[i] * x[i];
+      g[0] = -5.0 - x[0] / 9.0 + 0.5 * emq * ss;
+      for (int i = 1; i < 11; ++i) g[i] = -x[i] * emq;
+      r = (0.5 * x[0] > 709.782712893384)
+              ? -INFINITY
+              : (-(x[0] * x[0]) / 18.0 - logC - log3) + (-0.5 * emq * ss - 10.0 * logC - 5.0 * x[0]);
+    } break;
+    case T_CORRGAUSS: {
+      const double rho = 0.5, tmp = 1.0 - rho * rho;
+      double rr = x[1] - rho * x[0];
+      g[0] = -(x[0] - rho * x[1]) / tmp; g[1] = -(x[1] - rho * x[0]) / tmp;
+      r = -0.5 * (x[0] * x[0]) - (0.5 / tmp) * (rr * rr);
+    } break;
+    case T_SMILE: {
+      double q0s = x[0] * x[0], rr = x[1] - q0s;
+      g[0] = -x[0] + 2.0 * x[0] * x[1] - 2.0 * (q0s * x[0]); g[1] = q0s - x[1];
+      r = -0.5 * q0s - 0.5 * (rr * rr);
+    } break;
+    case T_FUNNEL1: {
+      double emq = exp(-x[0]);
+      g[0] = -0.5 - x[0] / 9.0 + 0.5 * (x[1] * x[1]) * emq; g[1] = -x[1] * emq;
+      r = (0.5 * x[0] > 709.782712893384)
+              ? -INFINITY
+              : (-(x[0] * x[0]) / 18.0 - logC - log3) + (-0.5 * (x[1] * x[1]) * emq - logC - 0.5 * x[0]);
+    } break;
+    case T_MODFUNNEL: {
+      double t1 = exp(-3.0 * x[0]), t2 = 1.0 + t1, t3 = 1.0 / t2, t4 = x[1] * x[1];
+      g[0] = 1.5 * t1 * (t4 - t3) - x[0]; g[1] = -x[1] * t2;
+      r = -0.5 * (t2 * t4 + log(t3) + x[0] * x[0]);
+    } break;
+  }
+  lp[c] = r;
+}
+
+__global__ void wn_tape_kernel(uint64_t seed, uint32_t chain0, int C, int iter, int nu, int D,
+                               double* u, double* z) {
+  int c = blockIdx.x;
+  if (c >= C) return;
+  if (u)
+    for (int k = threadIdx.x; k < nu; k += blockDim.x)
+      u[(size_t)c * nu + k] = rng_uniform(seed, chain0 + c, (uint32_t)iter, (uint32_t)k);
+  if (z)
+    for (int j = threadIdx.x; j < D; j += blockDim.x)
+      z[(size_t)c * D + j] = rng_normal(seed, chain0 + c, (uint32_t)iter, (uint32_t)j);
+}
+
+__global__ void wn_fill_kernel(double* p, size_t n, double v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace wn
+
+struct wn_engine {
+  wn_config cfg;
+  int target = -1;
+  double* tpar = nullptr;
+  size_t ntpar = 0;
+  double* work = nullptr;
+  size_t work_doubles = 0;
+  KernelChoice kc{};
+  bool have_kc = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  std::string err;
+};
+
+static std::string g_create_err;
+
+#define HIPCHK(e, call)                                                        \
+  do {                                                                         \
+    hipError_t _r = (call);                                                    \
+    if (_r != hipSuccess) {                                                    \
+      (e)->err = std::string(#call) + ": " + hipGetErrorString(_r);            \
+      return WN_E_HIP;                                                         \
+    }                                                                          \
+  } while (0)
+
+extern "C" {
+
+int wn_abi_version(void) { return WN_ABI_VERSION; }
+
+const char* wn_last_error(wn_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+int wn_create(const wn_config* cfg, wn_engine** out) {
+  if (!cfg || !out) { g_create_err = "null argument"; return WN_E_ARG; }
+  *out = nullptr;
+  if (cfg->abi_version != WN_ABI_VERSION) { g_create_err = "abi_version mismatch"; return WN_E_ARG; }
+  // WALNUTS.py:140,146 sys.exit on bad tuning targets; the analogous argument checks here
+  if (cfg->dim < 1 || cfg->n_chains < 1) { g_create_err = "dim and n_chains must be >= 1"; return WN_E_ARG; }
+  if (cfg->M < 1 || cfg->M > MAX_M) { g_create_err = "M out of range [1,24]"; return WN_E_ARG; }
+  if (cfg->integrator < WN_I_FIXED || cfg->integrator > WN_I_ADAPT_R2P) { g_create_err = "unknown integrator"; return WN_E_ARG; }
+  if (cfg->min_c < 0 || cfg->max_c < cfg->min_c || cfg->max_c > 20) { g_create_err = "need 0 <= minC <= maxC <= 20"; return WN_E_ARG; }
+  if (!(cfg->H0 > 0.0) || !(cfg->delta0 > 0.0) || cfg->step_size_rand_scale < 0.0 || cfg->step_size_rand_scale >= 1.0) {
+    g_create_err = "need H0 > 0, delta0 > 0, 0 <= stepSizeRandScale < 1"; return WN_E_ARG;
+  }
+  if (!(cfg->r2p_prob0 > 0.0 && cfg->r2p_prob0 < 1.0)) { g_create_err = "R2Pprob0 must be in (0,1)"; return WN_E_ARG; }
+  if (cfg->warmup_iter != 0) { g_create_err = "warm-up adaptation (WALNUTS.py:701-712) is not implemented on the device yet: warmupIter must be 0"; return WN_E_UNSUPPORTED; }
+  if (cfg->generated < WN_G_IDENTITY || cfg->generated > WN_G_FIRSTK) { g_create_err = "unknown generated kind"; return WN_E_ARG; }
+  if (cfg->generated == WN_G_FIRSTK && (cfg->gen_k < 1 || cfg->gen_k > cfg->dim)) { g_create_err = "gen_k out of range"; return WN_E_ARG; }
+  wn_engine* e = new wn_engine();
+  e->cfg = *cfg;
+  hipError_t r = hipSetDevice(cfg->device);
+  if (r != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(r); delete e; return WN_E_HIP; }
+  r = hipEventCreate(&e->ev0);
+  if (r == hipSuccess) r = hipEventCreate(&e->ev1);
+  if (r != hipSuccess) { g_create_err = std::string("hipEventCreate: ") + hipGetErrorString(r); delete e; return WN_E_HIP; }
+  *out = e;
+  return WN_OK;
+}
+
+int wn_destroy(wn_engine* e) {
+  if (!e) return WN_OK;
+  hipSetDevice(e->cfg.device);
+  if (e->tpar) hipFree(e->tpar);
+  if (e->work) hipFree(e->work);
+  if (e->ev0) hipEventDestroy(e->ev0);
+  if (e->ev1) hipEventDestroy(e->ev1);
+  delete e;
+  return WN_OK;
+}
+
+int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n_params) {
+  if (!e) return WN_E_ARG;
+  const int D = e->cfg.dim;
+  size_t need = 0;
+  switch (kind) {
+    case WN_T_STDGAUSS: need = 0; break;
+    case WN_T_DIAGGAUSS: need = (size_t)D; break;
+    case WN_T_DENSEGAUSS: need = (size_t)D * D; break;
+    case WN_T_FUNNEL10: if (D != 11) { e->err = "funnel10 needs dim 11"; return WN_E_ARG; } break;
+    case WN_T_CORRGAUSS: case WN_T_SMILE: case WN_T_FUNNEL1: case WN_T_MODFUNNEL:
+      if (D != 2) { e->err = "target needs dim 2"; return WN_E_ARG; } break;
+    default: e->err = "unknown target kind"; return WN_E_ARG;
+  }
+  if (need && (n_params != need || !params_dev)) { e->err = "wrong parameter count for target"; return WN_E_ARG; }
+  KernelChoice kc;
+  if (choose_kernel(kind, D, e->cfg.waves_per_group, &kc)) {
+    e->err = "no device kernel for this (target, dim) yet";
+    return WN_E_UNSUPPORTED;
+  }
+  HIPCHK(e, hipSetDevice(e->cfg.device));
+  if (e->tpar) { hipFree(e->tpar); e->tpar = nullptr; }
+  if (e->work) { hipFree(e->work); e->work = nullptr; }
+  size_t nt = need ? need : (size_t)D;  // stdGauss runs as the diagonal target with a == 1
+  HIPCHK(e, hipMalloc((void**)&e->tpar, nt * sizeof(double)));
+  if (need) HIPCHK(e, hipMemcpy(e->tpar, params_dev, need * sizeof(double), hipMemcpyDeviceToDevice));
+  else {
+    hipLaunchKernelGGL(wn_fill_kernel, dim3((nt + 255) / 256), dim3(256), 0, 0, e->tpar, nt, 1.0);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipDeviceSynchronize());
+  }
+  e->ntpar = nt;
+  e->work_doubles = kernel_work_doubles(kc, e->cfg.n_chains, e->cfg.M);
+  HIPCHK(e, hipMalloc((void**)&e->work, e->work_doubles * sizeof(double)));
+  HIPCHK(e, hipMemset(e->work, 0, e->work_doubles * sizeof(double)));
+  e->kc = kc;
+  e->have_kc = true;
+  e->target = kind;
+  return WN_OK;
+}
+
+static void fill_params(const wn_engine* e, Params* p) {
+  memset(p, 0, sizeof(*p));
+  const wn_config& c = e->cfg;
+  p->D = c.dim; p->C = c.n_chains;
+  p->integrator = c.integrator; p->M = c.M; p->minC = c.min_c; p->maxC = c.max_c;
+  p->generated = c.generated; p->gen_k = c.gen_k;
+  p->dg = c.generated == WN_G_IDENTITY ? c.dim : c.generated == WN_G_Q0_SUMSQ ? 2 : c.gen_k;
+  p->H = c.H0; p->s = c.step_size_rand_scale; p->delta = c.delta0; p->R2Pprob0 = c.r2p_prob0;
+  p->logP = log(c.r2p_prob0); p->log1mP = log(1.0 - c.r2p_prob0);
+  p->wtSumThresh = exp(WN_LOGZERO + 1.0);  // constants.py:14
+  p->chain0 = (uint32_t)c.chain_offset;
+  p->work = e->work;
+  p->tpar = e->tpar;
+}
+
+static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
+  const bool adapt = e->cfg.integrator != WN_I_FIXED;
+  if (timed) HIPCHK(e, hipEventRecord(e->ev0, st));
+  hipError_t r = e->kc.layout == 0 ? launch_lane(e->kc, adapt, p, st) : launch_coop(e->kc, adapt, p, st);
+  if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
+  if (timed) { HIPCHK(e, hipEventRecord(e->ev1, st)); e->timed = true; }
+  return WN_OK;
+}
+
+int wn_run(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, double* samples_dev,
+           double* diag_dev, double* trace_dev, int32_t trace_cap, int32_t* trace_n_dev, void* stream) {
+  if (!e) return WN_E_ARG;
+  if (!e->have_kc) { e->err = "wn_set_target has not been called"; return WN_E_NOTARGET; }
+  if (!q0_dev || !samples_dev || !diag_dev || n_iter < 0) { e->err = "null buffer or negative n_iter"; return WN_E_ARG; }
+  if (trace_dev && (!trace_n_dev || trace_cap < 1)) { e->err = "trace needs trace_n_dev and trace_cap >= 1"; return WN_E_ARG; }
+  HIPCHK(e, hipSetDevice(e->cfg.device));
+  Params p;
+  fill_params(e, &p);
+  p.mode = MODE_SAMPLE;
+  p.numIter = n_iter; p.seed = seed;
+  p.q0 = q0_dev; p.samples = samples_dev; p.diag = diag_dev;
+  p.trace = trace_dev; p.trace_cap = trace_cap; p.trace_n = trace_n_dev;
+  return launch(e, p, (hipStream_t)stream, true);
+}
+
+int wn_integrator_step(wn_engine* e, const double* q_dev, const double* v_dev, const double* g_dev,
+                       const double* ham0_dev, const double* h_dev, const int32_t* xi_dev,
+                       const double* u_r2p_dev, double* q1_dev, double* v1_dev, double* g1_dev,
+                       int32_t* iout_dev, double* dout_dev, void* stream) {
+  if (!e) return WN_E_ARG;
+  if (!e->have_kc) { e->err = "wn_set_target has not been called"; return WN_E_NOTARGET; }
+  if (!q_dev || !v_dev || !g_dev || !ham0_dev || !h_dev || !xi_dev || !q1_dev || !v1_dev || !g1_dev || !iout_dev || !dout_dev ||
+      (e->cfg.integrator == WN_I_ADAPT_R2P && !u_r2p_dev)) { e->err = "null buffer"; return WN_E_ARG; }
+  HIPCHK(e, hipSetDevice(e->cfg.device));
+  Params p;
+  fill_params(e, &p);
+  p.mode = MODE_KAT;
+  p.numIter = 0;
+  p.kq = q_dev; p.kv = v_dev; p.kg = g_dev; p.kham0 = ham0_dev; p.kh = h_dev; p.kxi = xi_dev;
+  p.ku_r2p = u_r2p_dev; p.kq1 = q1_dev; p.kv1 = v1_dev; p.kg1 = g1_dev; p.kiout = iout_dev; p.kdout = dout_dev;
+  return launch(e, p, (hipStream_t)stream, false);
+}
+
+int wn_lpfun(wn_engine* e, const double* q_dev, double* lp_dev, double* grad_dev, void* stream) {
+  if (!e) return WN_E_ARG;
+  if (!e->have_kc) { e->err = "wn_set_target has not been called"; return WN_E_NOTARGET; }
+  if (!q_dev || !lp_dev || !grad_dev) { e->err = "null buffer"; return WN_E_ARG; }
+  HIPCHK(e, hipSetDevice(e->cfg.device));
+  const int B = e->cfg.n_chains;
+  hipLaunchKernelGGL(wn_lpfun_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, e->target,
+                     e->cfg.dim, B, e->tpar, q_dev, lp_dev, grad_dev);
+  HIPCHK(e, hipGetLastError());
+  return WN_OK;
+}
+
+int wn_rng_tape(wn_engine* e, uint64_t seed, int32_t iter, int32_t n_u, double* u_dev, double* z_dev,
+                void* stream) {
+  if (!e) return WN_E_ARG;
+  if (iter < 0 || n_u < 0) { e->err = "negative iter or n_u"; return WN_E_ARG; }
+  HIPCHK(e, hipSetDevice(e->cfg.device));
+  hipLaunchKernelGGL(wn_tape_kernel, dim3(e->cfg.n_chains), dim3(64), 0, (hipStream_t)stream, seed,
+                     (uint32_t)e->cfg.chain_offset, e->cfg.n_chains, iter, n_u, e->cfg.dim, u_dev, z_dev);
+  HIPCHK(e, hipGetLastError());
+  return WN_OK;
+}
+
+int wn_last_run_ms(wn_engine* e, float* ms) {
+  if (!e || !ms) return WN_E_ARG;
+  if (!e->timed) { e->err = "no timed run yet"; return WN_E_ARG; }
+  HIPCHK(e, hipEventSynchronize(e->ev1));
+  HIPCHK(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
+  return WN_OK;
+}
+
+const char* wn_kernel_name(wn_engine* e) { return (e && e->have_kc) ? e->kc.name : ""; }
+
+}  // extern "C"

@@ -1,0 +1,678 @@
+// wn_chain.h -- the per-chain WALNUTS/NUTS state machine, written once for every layout.
+//
+// The reference runs one chain as nested Python loops (WALNUTSpy/WALNUTS.py:189-695 calling an
+// integrator from adaptiveIntegrators.py).  On the GPU thousands of chains sit at different tree
+// depths, directions and refinement levels, so the loops are turned inside out: every chain is a
+// small state machine that advances by exactly ONE gradient evaluation ("tick") and then does its
+// own bookkeeping.  A tick is
+//
+//   A  (chain-local)  start iteration / macro step / micro pass if one is pending
+//   B  (uniform)      one leapfrog micro step on the work state + reduce {lp, KE, ...}
+//   C  (chain-local)  energy bookkeeping of the macro-step integrator; may finalise the step
+//   D  (uniform)      U-turn dot products for chains whose macro step finalised (+ reduce)
+//   E  (chain-local)  NUTS bookkeeping: weights, multinomial pick, sub-tree checks, doubling /
+//                     iteration end, draws + diagnostics output
+//
+// "uniform" phases are executed by every lane of a chain group together (they may contain
+// barriers in a cooperative layout); "chain-local" phases are plain divergent SIMT code in which
+// each lane keeps a replica of its chain's scalars.  The layout policy P says where the D-vectors
+// live (registers of one lane, registers of several lanes in MFMA C-layout, ...), how partial dot
+// products are reduced, and how the target gradient is evaluated.
+//
+// Reference semantics reproduced here are cited inline.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "wn_rng.h"
+
+namespace wn {
+
+enum { T_STDGAUSS = 0, T_FUNNEL10, T_DENSEGAUSS, T_DIAGGAUSS, T_CORRGAUSS, T_SMILE, T_FUNNEL1, T_MODFUNNEL };
+enum { I_FIXED = 0, I_ADAPT_D = 1, I_ADAPT_R2P = 2 };
+enum { G_IDENTITY = 0, G_Q0_SUMSQ = 1, G_FIRSTK = 2 };
+enum { MODE_SAMPLE = 0, MODE_KAT = 1 };
+enum { NDIAG = 24, TRACE_NSCAL = 12 };
+enum { MAX_M = 24 };
+
+// WALNUTSpy/constants.py:13-14
+#define WN_LOGZERO (-700.0)
+
+// kernel parameters: keyword arguments of WALNUTS(...) (WALNUTS.py:111-129) + buffers
+struct Params {
+  int D, C, mode;
+  int integrator, M, numIter, minC, maxC, generated, gen_k, dg;
+  double H, s, delta, R2Pprob0, logP, log1mP, wtSumThresh;
+  uint64_t seed;
+  uint32_t chain0;  // global id of local chain 0
+  const double* q0;  // [C][D]
+  double* samples;   // [C][numIter+1][dg]
+  double* diag;      // [C][numIter][24]
+  double* trace;     // [C][trace_cap][12+2D] or null
+  int trace_cap;
+  int* trace_n;   // [C] or null
+  double* work;   // layout-specific workspace (sub-tree endpoint slots, cold vectors)
+  const double* tpar;
+  // MODE_KAT (one macro step per chain; wn_integrator_step)
+  const double *kq, *kv, *kg, *kham0, *kh, *ku_r2p;
+  const int* kxi;
+  double *kq1, *kv1, *kg1, *kdout;
+  int* kiout;
+};
+
+#define WN_VFOR(e) _Pragma("unroll") for (int e = 0; e < P::NE; ++e)
+
+// cold vector ids (touched only at doubling boundaries)
+enum { COLD_QB = 0, COLD_VB, COLD_GB, COLD_QPL, COLD_GPL, COLD_N };
+
+template <class P, bool ADAPT>
+struct Engine {
+  using Vec = typename P::Vec;
+  P& p;
+  const Params& prm;
+
+  // ---- per-chain scalars (replicated in every lane that serves the chain) -------------------
+  int iter;
+  bool live;
+  uint32_t Bbits;
+  int i, xi, a, b, n, nleaf;
+  double H0, Ha, Hb, lp0;
+  double WoldSum, WnewSum, lwtSumf, lwtSumb, h2;
+  uint32_t ku;
+  uint32_t ublk;       // cached uniform block index
+  double ucache0, ucache1;
+  bool needKE, needGen;
+  double keinit_part, gen_part;
+  // diagnostics accumulators (WALNUTS.py:196-207, 660-693)
+  int nevalF, nevalB, L_, Lold_, NdS, NdC, maxFint, maxBint, stopCode;
+  double orbitLen_, orbitLenSam_, indexStat_, indexStatOld_, timeLenF_, timeLenB_;
+  bool bothEndsPassive;
+  int minIf, maxIf, minc, maxc, nneq, nzero, nused;
+  double minlw, maxlw, Hmin, Hmax;
+  bool Hnan;
+  // macro-step integrator state
+  enum { PH_FWD = 0, PH_FWD2 = 1, PH_BWD = 2 };
+  bool needMacro, needPass, fin, needIter, needDoubling, endIter;
+  int ph, c, im, nstep, If, Ib, cSim, maxTry, nEvF, nEvB, cret;
+  double h, hh, Ham0, HamPass0, lwtf, lwt, lpn, Hn, lpOut, HOut;
+  bool allfin;
+  uint32_t firemask;
+  int gen_iter;  // iteration whose deferred generated() row is pending
+
+  // ---- D-vectors ----------------------------------------------------------------------------
+  Vec qa, va, ga;  // active end of the orbit = start of the current macro step (v forward-time)
+  Vec qP, gP;      // current proposal and its gradient (becomes q_c, grad0 of the next iteration)
+  Vec ql, vl;      // first state of the current leaf pair (WALNUTS.py:438-439 / 525-526)
+  double lpP, lpPL;
+  // adaptive integrators only: work state of the running micro pass, and the accepted forward
+  // result while the backward passes run
+  struct Empty {};
+  typename P::template Opt<ADAPT> qw, vw, gw, qo, vo, go;
+
+  WN_HD Engine(P& p_, const Params& prm_) : p(p_), prm(prm_) {}
+
+  // ------------------------------------------------------------------------------------------
+  // random draws in the reference's call order
+  // ------------------------------------------------------------------------------------------
+  WN_HD double next_u() {
+    uint32_t blk = ku >> 1;
+    if (blk != ublk) {
+      Philox4 ph4 = philox4x32_10(blk, (uint32_t)iter, p.chain_global(), 0u, (uint32_t)prm.seed,
+                                  (uint32_t)(prm.seed >> 32));
+      ucache0 = u53(ph4.w[0], ph4.w[1]);
+      ucache1 = u53(ph4.w[2], ph4.w[3]);
+      ublk = blk;
+    }
+    double u = (ku & 1u) ? ucache1 : ucache0;
+    ku++;
+    return u;
+  }
+  // numpy legacy uniform(low, high) = low + (high-low)*U
+  WN_HD double draw_h() {
+    double low = prm.H * (1 - prm.s), high = prm.H * (1 + prm.s);
+    return low + (high - low) * next_u();
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // iteration start  (WALNUTS.py:196-276)
+  // ------------------------------------------------------------------------------------------
+  WN_HD void start_iteration() {
+    ku = 0;
+    ublk = 0xffffffffu;
+    Bbits = 0;
+    for (int k = 0; k < prm.M; ++k) {  // :216  B = floor(uniform(0,2,size=M))
+      double u = 0.0 + (2.0 - 0.0) * next_u();
+      if ((int)floor(u) != 0) Bbits |= (1u << k);
+    }
+    a = 0; b = 0; maxFint = 0; maxBint = 0;  // :230-233
+    double kp = 0.0;
+    double ztmp[P::NE];
+    // rolled on purpose: one copy of philox + Box-Muller in the code instead of NE (this runs
+    // once per iteration; the dynamic index costs a few scratch stores)
+#pragma unroll 1
+    for (int e = 0; e < P::NE; ++e)
+      ztmp[e] = p.valid(e) ? rng_normal(prm.seed, p.chain_global(), (uint32_t)iter, (uint32_t)p.gidx(e)) : 0.0;
+    WN_VFOR(e) {  // :236  v = normal(size=d); both ends start at (qc, v, grad0)  :239-253
+      double z = ztmp[e];
+      va.x[e] = z;
+      qa.x[e] = qP.x[e];
+      ga.x[e] = gP.x[e];
+      kp += z * z;
+    }
+    p.template cold_put<COLD_QB>(qa);
+    p.template cold_put<COLD_VB>(va);
+    p.template cold_put<COLD_GB>(ga);
+    keinit_part = kp;
+    needIter = false;
+    needKE = true;  // Hs[I0] = -f0 + 0.5*sum(v**2) (:256) completes at the next reduce
+    lp0 = lpP;
+    WoldSum = 1.0; WnewSum = 0.0; lwtSumb = 0.0; lwtSumf = 0.0;  // :260-264
+    stopCode = 0; bothEndsPassive = false;
+    nevalF = nevalB = 0; Lold_ = L_ = 0; orbitLen_ = orbitLenSam_ = 0.0; NdS = NdC = 0;
+    indexStat_ = indexStatOld_ = 0.0; timeLenF_ = timeLenB_ = 0.0;
+    minIf = minc = 1 << 30; maxIf = maxc = -(1 << 30); nneq = nzero = nused = 0;
+    minlw = INFINITY; maxlw = -INFINITY;
+    i = 0;
+    xi = (Bbits & 1u) ? -1 : 1;
+    start_doubling_common();
+  }
+
+  WN_HD void start_doubling_common() {  // :283-294
+    n = 0;
+    nleaf = 1 << i;
+    p.template cold_put<COLD_QPL>(qP);
+    p.template cold_put<COLD_GPL>(gP);
+    lpPL = lpP;
+    Lold_ = L_;
+    indexStatOld_ = indexStat_;
+    if (i > 0) WnewSum = 0.0;  // :390
+    needMacro = true;
+  }
+
+  WN_HD void start_doubling() {
+    needDoubling = false;
+    int nxi = ((Bbits >> i) & 1u) ? -1 : 1;  // :283
+    if (nxi != xi) {  // the other end of the orbit becomes the active one
+      Vec t;
+      p.template cold_get<COLD_QB>(t); p.template cold_put<COLD_QB>(qa); qa = t;
+      p.template cold_get<COLD_VB>(t); p.template cold_put<COLD_VB>(va); va = t;
+      p.template cold_get<COLD_GB>(t); p.template cold_put<COLD_GB>(ga); ga = t;
+      double th = Ha; Ha = Hb; Hb = th;
+      xi = nxi;
+    }
+    start_doubling_common();
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // macro step / micro pass setup
+  // ------------------------------------------------------------------------------------------
+  WN_HD void setup_macro() {
+    needMacro = false;
+    if (prm.mode == MODE_SAMPLE) {
+      if (i == 0) h = draw_h();                // :298
+      else if ((n & 1) == 0) { h = draw_h(); h2 = draw_h(); }  // :395 size=2, before the first step
+      else h = h2;
+    }
+    Ham0 = Ha;  // Hs[] of the neighbouring stored index = energy at the active end (:302,400,443,487,530)
+    nEvF = nEvB = 0;
+    if (ADAPT) {
+      ph = PH_FWD;
+      c = prm.minC;
+      If = prm.maxC;  // adaptiveIntegrators.py:68 / 364
+      needPass = true;
+    } else {
+      // fixedLeapFrog (adaptiveIntegrators.py:49-59) works in place on the active end
+      hh = h;
+      WN_VFOR(e) va.x[e] = (double)xi * va.x[e];  // vh = xi*v + ...
+    }
+  }
+
+  template <bool B_ = ADAPT>
+  WN_HD typename std::enable_if<B_>::type setup_pass() {
+    needPass = false;
+    nstep = 1 << c;
+    hh = h / (double)nstep;  // adaptiveIntegrators.py:70-71
+    im = 0;
+    if (ph == PH_BWD) {  // :112-118 from (qOut, -vOut, gOut), Hams[0] = H0b
+      WN_VFOR(e) { qw.x[e] = qo.x[e]; vw.x[e] = -vo.x[e]; gw.x[e] = go.x[e]; }
+      HamPass0 = HOut;
+    } else {  // :72-76 from (q, xi*v, g), Hams[0] = Ham0
+      WN_VFOR(e) { qw.x[e] = qa.x[e]; vw.x[e] = (double)xi * va.x[e]; gw.x[e] = ga.x[e]; }
+      HamPass0 = Ham0;
+    }
+    allfin = isfinite(HamPass0);
+  }
+  template <bool B_ = ADAPT>
+  WN_HD typename std::enable_if<!B_>::type setup_pass() {}
+
+  // references to the state the micro step works on
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_, Vec&>::type QW() { return qw; }
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_, Vec&>::type QW() { return qa; }
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_, Vec&>::type VW() { return vw; }
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_, Vec&>::type VW() { return va; }
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_, Vec&>::type GW() { return gw; }
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_, Vec&>::type GW() { return ga; }
+  // the finalised macro-step result (q', v' in integration orientation, grad')
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_, Vec&>::type QN() { return qo; }
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_, Vec&>::type QN() { return qa; }
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_, Vec&>::type VN() { return vo; }
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_, Vec&>::type VN() { return va; }
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_, Vec&>::type GN() { return go; }
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_, Vec&>::type GN() { return ga; }
+
+  // ------------------------------------------------------------------------------------------
+  // phase C: after one micro step (lp, ke known)
+  // ------------------------------------------------------------------------------------------
+  template <bool B_ = ADAPT>
+  WN_HD typename std::enable_if<B_>::type save_out(double lp, double Hi) {
+    WN_VFOR(e) { qo.x[e] = qw.x[e]; vo.x[e] = vw.x[e]; go.x[e] = gw.x[e]; }
+    lpOut = lp;
+    HOut = Hi;
+  }
+  template <bool B_ = ADAPT>
+  WN_HD typename std::enable_if<!B_>::type save_out(double, double) {}
+
+  WN_HD void start_bwd_or_finalize() {
+    if (maxTry >= prm.minC) {  // adaptiveIntegrators.py:107 / 440
+      ph = PH_BWD;
+      c = prm.minC;
+      needPass = true;
+    } else {
+      finalize_macro();
+    }
+  }
+
+  WN_HD void finalize_macro() {
+    fin = true;
+    lpn = ADAPT ? lpOut : lpn;
+    Hn = ADAPT ? HOut : Hn;
+    if (prm.integrator == I_ADAPT_D) {  // :135-137
+      cret = If;
+      lwt = (If != Ib) ? WN_LOGZERO : 0.0;
+    } else if (prm.integrator == I_ADAPT_R2P) {  // :466-475
+      double lwtb = WN_LOGZERO;
+      if (cSim == Ib) lwtb = prm.logP;
+      else if (cSim == Ib + 1) lwtb = prm.log1mP;
+      cret = cSim;
+      lwt = lwtb - lwtf;
+    } else {  // :57-59
+      cret = 0; If = 0; Ib = 0; lwt = 0.0;
+    }
+  }
+
+  WN_HD void after_micro(double lp, double ke) {
+    double Hi = -lp + 0.5 * ke;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
+    if (!ADAPT) {
+      nEvF = 1;
+      lpn = lp;
+      Hn = Hi;
+      finalize_macro();
+      return;
+    }
+    if (!isfinite(Hi)) allfin = false;
+    im++;
+    if (ph == PH_BWD) nEvB++; else nEvF++;
+    if (im < nstep) return;
+    // pass complete: all(isfinite(Hams)) and abs(Hams[0]-Hams[-1]) < delta   (:87-94)
+    bool ok = allfin && (fabs(HamPass0 - Hi) < prm.delta);
+    if (ph == PH_FWD) {
+      bool done = false;
+      if (ok) { If = c; done = true; }
+      else if (c < prm.maxC) { c++; needPass = true; }
+      else { If = prm.maxC; done = true; }  // Q5: last computed state is used silently
+      if (done) {
+        if (prm.integrator == I_ADAPT_R2P) {
+          double u = (prm.mode == MODE_KAT) ? prm.ku_r2p[p.chain_local()] : next_u();  // :392
+          if (u < prm.R2Pprob0) {  // :393-399, 430-433
+            cSim = If; save_out(lp, Hi);
+            maxTry = If - 1; Ib = If; lwtf = prm.logP;
+            start_bwd_or_finalize();
+          } else {  // :400-424 re-integrate at c = If+1
+            ph = PH_FWD2; c = If + 1; needPass = true;
+          }
+        } else {  // adaptLeapFrogD :96-111
+          cSim = If; save_out(lp, Hi);
+          maxTry = If - 1; Ib = If; lwtf = 0.0;
+          start_bwd_or_finalize();
+        }
+      }
+    } else if (ph == PH_FWD2) {  // :419-424, 434-437
+      cSim = If + 1; save_out(lp, Hi);
+      maxTry = prm.maxC; Ib = prm.maxC; lwtf = prm.log1mP;
+      start_bwd_or_finalize();
+    } else {  // PH_BWD :129-132 / 461-464
+      if (ok) { Ib = c; finalize_macro(); }
+      else if (c < maxTry) { c++; needPass = true; }
+      else finalize_macro();
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // which U-turn checks does a finalised step need?  check 0 = full orbit (passive end,
+  // WALNUTS.py:622), check j>=1 = sub-tree of 2**j leaves ending at this leaf (subTreePlan,
+  // WALNUTS.py:22-41: a check [s-2**j+1, s] fires after leaf s for every j with 2**j | s).
+  // ------------------------------------------------------------------------------------------
+  WN_HD int ctz_leaf() const {  // ctz(n+1) for odd n
+    return __builtin_ctz((unsigned)(n + 1));
+  }
+  WN_HD int nchecks() const {  // number of check indices to evaluate (0 = none)
+    if (!(live && fin) || prm.mode != MODE_SAMPLE) return 0;
+    int m = 0;
+    if (n == nleaf - 1) m = 1;
+    if (i >= 1 && (n & 1)) m = ctz_leaf() + 1;
+    return m;
+  }
+  WN_HD bool need_check(int j) const {
+    if (j == 0) return n == nleaf - 1;
+    return i >= 1 && (n & 1) && j <= ctz_leaf();
+  }
+  WN_HD void uturn_dots(const Vec& qo_, const Vec& vo_, double& d1, double& d2) {
+    double a1 = 0.0, a2 = 0.0;
+    WN_VFOR(e) {
+      double dq = QN().x[e] - qo_.x[e];
+      a1 += ((double)xi * VN().x[e]) * dq;
+      a2 += vo_.x[e] * dq;
+    }
+    d1 = a1; d2 = a2;
+  }
+  WN_HD static int slot_of_leaf(int m) { return m == 0 ? 0 : __builtin_ctz((unsigned)m); }
+
+  // ------------------------------------------------------------------------------------------
+  // phase E: NUTS bookkeeping after a finalised macro step (WALNUTS.py:296-648)
+  // ------------------------------------------------------------------------------------------
+  WN_HD void pick_state(int idx) {
+    WN_VFOR(e) { qP.x[e] = QN().x[e]; gP.x[e] = GN().x[e]; }
+    lpP = lpn;
+    L_ = idx;
+    indexStat_ = xi > 0 ? timeLenF_ : -timeLenB_;
+  }
+  WN_HD void revert_prop() {  // qProp = qPropLast (:599-601, 614-616)
+    p.template cold_get<COLD_QPL>(qP);
+    p.template cold_get<COLD_GPL>(gP);
+    lpP = lpPL;
+    L_ = Lold_;
+    indexStat_ = indexStatOld_;
+  }
+
+  WN_HD void trace_row() {
+    if (!prm.trace_n) return;
+    int cl = p.chain_local();
+    int row = ntrace++;
+    if (prm.trace && row < prm.trace_cap) {
+      double* r = prm.trace + ((size_t)cl * prm.trace_cap + row) * (TRACE_NSCAL + 2 * prm.D);
+      if (p.writer()) {
+        r[0] = iter; r[1] = i; r[2] = xi; r[3] = h; r[4] = Ham0; r[5] = lpn; r[6] = If; r[7] = Ib;
+        r[8] = cret; r[9] = lwt; r[10] = nEvF; r[11] = nEvB;
+      }
+      WN_VFOR(e) if (p.valid(e) && p.owner(e)) {
+        r[TRACE_NSCAL + p.gidx(e)] = QN().x[e];
+        r[TRACE_NSCAL + prm.D + p.gidx(e)] = (double)xi * VN().x[e];
+      }
+    }
+  }
+  int ntrace;
+
+  WN_HD void step_done() {
+    fin = false;
+    const bool first = (i == 0) || ((n & 1) == 0);
+    const int idx = xi > 0 ? b + 1 + n : a - 1 - n;
+    trace_row();
+    // intOut.v is in forward-time orientation (adaptiveIntegrators.py:57,135,473)
+    WN_VFOR(e) VN().x[e] = (double)xi * VN().x[e];
+    nevalF += nEvF; nevalB += nEvB;
+    // per-step records Hs/Ifs/Ibs/cs/lwts feed only min/max/mean diagnostics (:668-692)
+    nused++;
+    minIf = If < minIf ? If : minIf; maxIf = If > maxIf ? If : maxIf;
+    minc = cret < minc ? cret : minc; maxc = cret > maxc ? cret : maxc;
+    minlw = lwt < minlw ? lwt : minlw; maxlw = lwt > maxlw ? lwt : maxlw;
+    nneq += (If != Ib); nzero += (If == 0);
+    if (isnan(Hn)) Hnan = true;
+    Hmin = Hn < Hmin ? Hn : Hmin; Hmax = Hn > Hmax ? Hn : Hmax;
+    if (xi > 0) { maxFint = idx; timeLenF_ += h; } else { maxBint = idx; timeLenB_ += h; }
+    if (i == 0) orbitLen_ += h;  // :300 (before the integrator call)
+    if (!isfinite(Hn)) {         // :316-319, 414-417, 457-459 (Q3, Q4)
+      if (first) stopCode = 999;
+      endIter = true;
+      return;
+    }
+    if (i == 0) { if (xi > 0) lwtSumf = lwt; else lwtSumb = lwt; }             // :321 / 354
+    else if (first || xi > 0) { if (xi > 0) lwtSumf += lwt; else lwtSumb += lwt; }  // :420,507,550; Q2
+    const double lwtSum = xi > 0 ? lwtSumf : lwtSumb;
+    const double Wnew = exp(-Hn + H0 + lwtSum);
+    if (i == 0) {  // :322-328, 368-369: unconditional, no uniform
+      WnewSum = Wnew;
+      pick_state(idx);
+    } else {
+      WnewSum += Wnew;
+      // :426  the uniform is not drawn when the first clause is false
+      if (WnewSum > prm.wtSumThresh && next_u() < Wnew / WnewSum) pick_state(idx);
+      orbitLen_ += h;  // :432 / 471 / 519 / 561
+      if ((n & 1) == 0) {  // statePush (:431,518) -- only sub-tree left endpoints are ever read back
+        WN_VFOR(e) { ql.x[e] = QN().x[e]; vl.x[e] = VN().x[e]; }
+        if (i >= 2 && (n & 3) == 0) p.slot_store(slot_of_leaf(n), QN(), VN());
+      }
+    }
+    // the new state becomes the active end (qp/qm = intOut.q ...)
+    if (ADAPT) { WN_VFOR(e) { qa.x[e] = QN().x[e]; va.x[e] = VN().x[e]; ga.x[e] = GN().x[e]; } }
+    Ha = Hn;
+    bool sub = false;
+    if (i >= 1 && (n & 1)) {  // leaf pair + completed inner rows, post-order (:479,568,582-587)
+      uint32_t m = ((2u << ctz_leaf()) - 1u) & ~1u;  // checks 1..ctz(n+1)
+      sub = (firemask & m) != 0;
+    }
+    n++;
+    if (sub) doubling_end(true);
+    else if (n == nleaf) doubling_end(false);
+    else needMacro = true;
+  }
+
+  WN_HD void doubling_end(bool sub) {
+    indexStat_ = indexStat_ / (timeLenF_ + timeLenB_);  // :595 (Q6)
+    if (sub) {  // :597-605
+      revert_prop();
+      NdS = i; NdC = i + 1; stopCode = 5;
+      endIter = true;
+      return;
+    }
+    if (!(next_u() < WnewSum / WoldSum)) revert_prop();  // :613-616
+    const bool joined = (firemask & 1u) != 0;            // :622
+    bothEndsPassive = (lwtSumb < WN_LOGZERO + 1.0) && (lwtSumf < WN_LOGZERO + 1.0);  // :624
+    if (joined || bothEndsPassive) {  // :625-634
+      stopCode = joined ? 4 : -4;
+      NdS = NdC = i + 1;
+      orbitLenSam_ = orbitLen_;
+      endIter = true;
+      return;
+    }
+    WoldSum += WnewSum;  // :641-648
+    orbitLenSam_ = orbitLen_;
+    NdS = NdC = i + 1;
+    if (xi > 0) b += nleaf; else a -= nleaf;
+    i++;
+    if (i == prm.M) { endIter = true; return; }
+    needDoubling = true;
+  }
+
+  WN_HD void end_iteration() {  // :653-695
+    const int cl = p.chain_local();
+    if (p.writer()) {
+      double* d = prm.diag + ((size_t)cl * prm.numIter + (iter - 1)) * NDIAG;
+      d[0] = L_; d[1] = NdS; d[2] = orbitLen_; d[3] = orbitLenSam_; d[4] = maxFint; d[5] = maxBint;
+      d[6] = nevalF; d[7] = nevalB; d[8] = minIf; d[9] = maxIf; d[10] = minlw; d[11] = maxlw;
+      d[12] = bothEndsPassive ? 1.0 : 0.0;
+      d[13] = ((lwtSumb < WN_LOGZERO + 1.0) || (lwtSumf < WN_LOGZERO + 1.0)) ? 1.0 : 0.0;
+      d[14] = (double)nneq / (double)nused;
+      d[15] = prm.H;
+      d[16] = (double)nzero / (double)nused;
+      d[17] = Hnan ? NAN : (Hmax - Hmin);
+      d[18] = prm.delta; d[19] = (double)stopCode; d[20] = NdC; d[21] = minc; d[22] = maxc;
+      d[23] = indexStat_;
+    }
+    emit_generated(iter);  // samples[:,iterN] = generated(qc), qc = qProp
+    iter++;
+    endIter = false;
+    needMacro = false;
+    if (iter > prm.numIter) live = false;
+    else needIter = true;
+  }
+
+  WN_HD void emit_generated(int it) {
+    double* row = prm.samples + ((size_t)p.chain_local() * (prm.numIter + 1) + it) * prm.dg;
+    if (prm.generated == G_Q0_SUMSQ) {  // needs a reduction: completed at the next uniform phase
+      double s = 0.0;
+      WN_VFOR(e) s += qP.x[e] * qP.x[e];
+      gen_part = s;
+      needGen = true;
+      gen_iter = it;
+      WN_VFOR(e) if (p.valid(e) && p.owner(e) && p.gidx(e) == 0) row[0] = qP.x[e];
+    } else {
+      const int k = prm.generated == G_FIRSTK ? prm.gen_k : prm.D;
+      WN_VFOR(e) if (p.valid(e) && p.owner(e) && p.gidx(e) < k) row[p.gidx(e)] = qP.x[e];
+    }
+  }
+  WN_HD void finish_generated(double total) {
+    if (needGen) {
+      if (p.writer())
+        prm.samples[((size_t)p.chain_local() * (prm.numIter + 1) + gen_iter) * prm.dg + 1] = total;
+      needGen = false;
+      gen_part = 0.0;
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // the tick loop
+  // ------------------------------------------------------------------------------------------
+  WN_HD void run() {
+    const bool inrange = p.chain_local() < prm.C;
+    live = inrange;
+    needKE = needGen = needMacro = needPass = fin = needIter = needDoubling = endIter = false;
+    keinit_part = gen_part = 0.0;
+    ntrace = 0;
+    iter = 1;
+    Hnan = false; Hmin = INFINITY; Hmax = -INFINITY;
+    firemask = 0;
+    h = h2 = 0.0; xi = 1; i = 0; n = 0; nleaf = 1; a = b = 0;
+    lpn = Hn = lpOut = HOut = 0.0; H0 = Ha = Hb = 0.0;
+
+    // q_c = q0; f0, grad0 = lpFun(q0)  (WALNUTS.py:177,249)
+    const int cl = inrange ? p.chain_local() : 0;
+    {
+      const double* src = prm.mode == MODE_KAT ? prm.kq : prm.q0;
+      WN_VFOR(e) qP.x[e] = (p.valid(e) && inrange) ? src[(size_t)cl * prm.D + p.gidx(e)] : 0.0;
+    }
+    if (prm.mode == MODE_SAMPLE) {
+      double part[1];
+      p.grad(qP, gP, part[0]);
+      p.template reduce<1>(part);
+      lpP = p.lp_finish(part[0]);
+      if (live) {
+        emit_generated(0);  // samples[:,0] = generated(q0)  (:164)
+        if (prm.numIter < 1) live = false; else needIter = true;
+      }
+    } else if (live) {  // one macro step from a caller-supplied state
+      WN_VFOR(e) {
+        qa.x[e] = qP.x[e];
+        va.x[e] = p.valid(e) ? prm.kv[(size_t)cl * prm.D + p.gidx(e)] : 0.0;
+        ga.x[e] = p.valid(e) ? prm.kg[(size_t)cl * prm.D + p.gidx(e)] : 0.0;
+      }
+      Ha = prm.kham0[cl]; h = prm.kh[cl]; xi = prm.kxi[cl];
+      needMacro = true;
+    }
+
+    while (p.any(live || needGen)) {
+      // ---- A ----
+      if (live && needIter) start_iteration();
+      if (live && needDoubling) start_doubling();
+      if (live && needMacro) setup_macro();
+      if (ADAPT && live && needPass) setup_pass();
+      // ---- B: one leapfrog micro step on the work state ----
+      Vec& Q = QW(); Vec& V = VW(); Vec& G = GW();
+      const double hh2 = live ? 0.5 * hh : 0.0, hq = live ? hh : 0.0;
+      WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; Q.x[e] = Q.x[e] + hq * V.x[e]; }
+      double part[4];
+      p.grad(Q, G, part[0]);
+      double ke = 0.0;
+      WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; ke += V.x[e] * V.x[e]; }
+      part[1] = ke; part[2] = keinit_part; part[3] = gen_part;
+      p.template reduce<4>(part);
+      // ---- C ----
+      finish_generated(part[3]);
+      if (live) {
+        if (needKE) {  // Hs[I0] = -f0 + 0.5*sum(v**2)  (:256); multinomialLscale (:259)
+          H0 = -lp0 + 0.5 * part[2];
+          Ha = Hb = H0; Ham0 = H0;
+          if (ADAPT) { HamPass0 = H0; allfin = isfinite(H0); }
+          Hnan = isnan(H0); Hmin = Hmax = H0;
+          needKE = false; keinit_part = 0.0;
+        }
+        after_micro(p.lp_finish(part[0]), part[1]);
+      }
+      // ---- D: U-turn dot products, four checks per reduction ----
+      const int nchk = nchecks();
+      firemask = 0;
+      for (int j0 = 0; p.any(nchk > j0); j0 += 4) {
+        double dots[8];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = j0 + jj;
+          double d1 = 0.0, d2 = 0.0;
+          if (p.any(nchk > j)) {
+            const bool need = (nchk > j) && need_check(j);
+            if (need) {
+              // newer minus older; v' of the new state is xi * VN
+              if (j == 0) {
+                Vec qo_, vo_;
+                p.template cold_get<COLD_QB>(qo_); p.template cold_get<COLD_VB>(vo_);
+                uturn_dots(qo_, vo_, d1, d2);
+              } else if (j == 1) {
+                uturn_dots(ql, vl, d1, d2);
+              } else {
+                Vec qo_, vo_;
+                p.slot_load(slot_of_leaf(n + 1 - (1 << j)), qo_, vo_);
+                uturn_dots(qo_, vo_, d1, d2);
+              }
+            }
+          }
+          dots[2 * jj] = d1; dots[2 * jj + 1] = d2;
+        }
+        p.template reduce<8>(dots);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = j0 + jj;
+          // stopCondition (WALNUTS.py:95-97) with the older state on the side opposite to xi
+          if (nchk > j && need_check(j) &&
+              (((double)xi * dots[2 * jj] < 0.0) || ((double)xi * dots[2 * jj + 1] < 0.0)))
+            firemask |= (1u << j);
+        }
+      }
+      // ---- E ----
+      if (live && fin) {
+        if (prm.mode == MODE_SAMPLE) step_done();
+        else kat_done();
+        if (endIter) end_iteration();
+      }
+    }
+    if (prm.trace_n && inrange && p.writer()) prm.trace_n[p.chain_local()] = ntrace;
+  }
+
+  WN_HD void kat_done() {  // wn_integrator_step: return integratorReturn fields
+    const int cl = p.chain_local();
+    WN_VFOR(e) if (p.valid(e) && p.owner(e)) {
+      prm.kq1[(size_t)cl * prm.D + p.gidx(e)] = QN().x[e];
+      prm.kv1[(size_t)cl * prm.D + p.gidx(e)] = (double)xi * VN().x[e];
+      prm.kg1[(size_t)cl * prm.D + p.gidx(e)] = GN().x[e];
+    }
+    if (p.writer()) {
+      int* io = prm.kiout + (size_t)cl * 5;
+      io[0] = nEvF; io[1] = nEvB; io[2] = If; io[3] = Ib; io[4] = cret;
+      double* dd = prm.kdout + (size_t)cl * 3;
+      dd[0] = lpn; dd[1] = lwt; dd[2] = Hn;
+    }
+    fin = false;
+    live = false;
+  }
+};
+
+}  // namespace wn

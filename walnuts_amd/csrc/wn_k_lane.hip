@@ -1,0 +1,57 @@
+// wn_k_lane.hip -- kernels of the one-chain-per-lane layout (small D: funnel10, 2-D toy targets,
+// low-dimensional Gaussians).  One wavefront = 64 chains; no LDS, no barriers.
+#include "wn_launch.h"
+#include "wn_policy_lane.h"
+#include "wn_targets.h"
+
+namespace wn {
+
+template <int DMAX, class Tgt, bool ADAPT>
+__global__ __launch_bounds__(64) void wn_lane_kernel(Params prm) {
+  const int cl = blockIdx.x * 64 + threadIdx.x;
+  LanePolicy<DMAX, Tgt> p(prm, cl);
+  Engine<LanePolicy<DMAX, Tgt>, ADAPT> eng(p, prm);
+  eng.run();
+}
+
+template <int DMAX, class Tgt>
+static hipError_t go(bool adapt, const Params& prm, hipStream_t st) {
+  dim3 grid((prm.C + 63) / 64), block(64);
+  if (adapt) hipLaunchKernelGGL((wn_lane_kernel<DMAX, Tgt, true>), grid, block, 0, st, prm);
+  else hipLaunchKernelGGL((wn_lane_kernel<DMAX, Tgt, false>), grid, block, 0, st, prm);
+  return hipGetLastError();
+}
+
+size_t lane_work_doubles(int dmax, int C, int M) {
+  size_t cpad = ((size_t)C + 63) / 64 * 64;
+  return ((size_t)(M + 1) * 2 + COLD_N) * dmax * cpad;
+}
+
+hipError_t launch_lane(const KernelChoice& kc, bool adapt, const Params& prm, hipStream_t st) {
+  switch (kc.p1) {
+    case T_STDGAUSS:
+    case T_DIAGGAUSS:
+      switch (kc.p0) {
+        case 4: return go<4, TgtDiag<4>>(adapt, prm, st);
+        case 8: return go<8, TgtDiag<8>>(adapt, prm, st);
+        case 16: return go<16, TgtDiag<16>>(adapt, prm, st);
+        case 24: return go<24, TgtDiag<24>>(adapt, prm, st);
+      }
+      break;
+    case T_DENSEGAUSS:
+      switch (kc.p0) {
+        case 4: return go<4, TgtDense<4>>(adapt, prm, st);
+        case 8: return go<8, TgtDense<8>>(adapt, prm, st);
+        case 16: return go<16, TgtDense<16>>(adapt, prm, st);
+      }
+      break;
+    case T_FUNNEL10: return go<11, TgtFunnel10>(adapt, prm, st);
+    case T_CORRGAUSS: return go<2, TgtCorrGauss>(adapt, prm, st);
+    case T_SMILE: return go<2, TgtSmile>(adapt, prm, st);
+    case T_FUNNEL1: return go<2, TgtFunnel1>(adapt, prm, st);
+    case T_MODFUNNEL: return go<2, TgtModFunnel>(adapt, prm, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace wn

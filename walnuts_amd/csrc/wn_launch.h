@@ -1,0 +1,25 @@
+// wn_launch.h -- internal launcher interface between the C-ABI (wn_capi.hip) and the kernel
+// translation units (wn_k_lane.hip, wn_k_coop.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#include "wn_chain.h"
+
+namespace wn {
+
+struct KernelChoice {
+  int layout;  // 0 = lane, 1 = coop
+  int p0;      // lane: DMAX ; coop: NT
+  int p1;      // lane: target kind ; coop: CK_DENSE / CK_DIAG
+  int W;       // coop: waves per group
+  const char* name;
+};
+
+// returns 0 and fills `kc` if a kernel exists for (target, D)
+int choose_kernel(int target, int D, int waves_per_group, KernelChoice* kc);
+size_t kernel_work_doubles(const KernelChoice& kc, int C, int M);
+hipError_t launch_lane(const KernelChoice& kc, bool adapt, const Params& prm, hipStream_t st);
+hipError_t launch_coop(const KernelChoice& kc, bool adapt, const Params& prm, hipStream_t st);
+
+}  // namespace wn

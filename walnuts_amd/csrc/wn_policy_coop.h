@@ -1,0 +1,191 @@
+// wn_policy_coop.h -- cooperative MFMA layout for Gaussian targets at medium dimension
+// (dense precision matrix, D <= 64*NT), gfx950 only.
+//
+// One workgroup = one group of 16 chains x W wavefronts.  The 16 chains are the N dimension of
+// v_mfma_f64_16x16x4_f64; the D coordinates are split into 16-row tiles, NT tiles per wave.
+// Every D-vector (q, v, grad, ...) lives in registers in the MFMA C/D layout
+//
+//     lane l, register r of tile T  <->  coordinate 16*T + 4*r + (l>>4)  of chain (l & 15)
+//
+// which for the f64 MFMA is also exactly the B-operand layout of k-step s = 4*T + r (lane l
+// holds B[k = l>>4][n = l&15]).  So the batched gradient  G[D x 16] = (-A)[D x D] . Q[D x 16]  needs
+// no data reshuffle: each wave publishes its own 4*NT k-steps of Q to LDS (512 B contiguous per
+// k-step), reads all ceil(D/4) k-steps back as B fragments, and multiplies by its rows of -A, which
+// it keeps resident in registers as A fragments for the whole run (NT*ceil(D/4) doubles/lane).
+// Dot products are reduced lane -> (xor 16, xor 32) -> across waves through LDS; the per-chain
+// scalars are replicated in all 4*W lanes that serve a chain and stay bit-identical because every
+// replica reads the same reduced sums.
+//
+// LDS per workgroup: Q exchange 4*NT*W*512 B (16 KiB at NT=2,W=4) + 2 x 8 x W x 16 x 8 B reduction
+// buffers.  HBM traffic is only the sub-tree endpoint slots ([slot][q|v][wave][reg][lane], 512 B
+// coalesced per register) -- see DESIGN.md.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "wn_chain.h"
+#include "wn_policy_lane.h"  // EmptyVec
+
+namespace wn {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+enum { CK_DENSE = 0, CK_DIAG = 1 };
+
+template <int NT, int W, int KS, int TK>
+struct CoopPolicy {
+  static constexpr int NE = NT * 4;
+  static constexpr int KS_MAX = 4 * NT * W;  // k-steps of the padded dimension 16*NT*W
+  static constexpr int DPAD = 16 * NT * W;
+  static constexpr int NRED = 8;
+  static constexpr int LDS_Q = KS_MAX * 64;
+  static constexpr int LDS_RED = 2 * NRED * W * 16;
+  static constexpr int LDS_DOUBLES = LDS_Q + LDS_RED;
+  static_assert(KS <= KS_MAX, "k-steps exceed the padded dimension");
+  static constexpr int NA = (TK == CK_DENSE) ? NT * KS : 1;
+  struct Vec {
+    double x[NE];
+  };
+  template <bool B>
+  using Opt = typename std::conditional<B, Vec, EmptyVec>::type;
+
+  int D, lane, wave, cn, lg, cl, ksteps;
+  uint32_t cg;
+  double* ldsq;
+  double* ldsr;
+  double* slotbase;
+  int redpar;
+  double afrag[NA];  // -A fragments: afrag[t*KS+s] = -A[16*T+(l&15)][4*s+(l>>4)]
+  double adiag[NE];  // diagonal target: a[gidx(e)]
+  Vec cold[COLD_N];
+
+  static size_t work_doubles(int C, int M) {
+    size_t groups = ((size_t)C + 15) / 16;
+    return groups * (size_t)(M + 1) * 2 * W * NE * 64;
+  }
+
+  __device__ __forceinline__ CoopPolicy(const Params& prm, double* lds) {
+    D = prm.D;
+    lane = threadIdx.x & 63;
+    wave = threadIdx.x >> 6;
+    cn = lane & 15;
+    lg = lane >> 4;
+    cl = blockIdx.x * 16 + cn;
+    cg = prm.chain0 + (uint32_t)cl;
+    ksteps = (D + 3) >> 2;
+    ldsq = lds;
+    ldsr = lds + LDS_Q;
+    slotbase = prm.work + (size_t)blockIdx.x * (size_t)(prm.M + 1) * 2 * W * NE * 64;
+    redpar = 0;
+    if (TK == CK_DENSE) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int row = 16 * (wave * NT + t) + (lane & 15);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const int col = 4 * s + (lane >> 4);
+          afrag[t * KS + s] = (row < D && col < D) ? -prm.tpar[(size_t)row * D + col] : 0.0;
+        }
+      }
+    } else {
+      afrag[0] = 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) adiag[e] = (TK == CK_DIAG && valid(e)) ? prm.tpar[gidx(e)] : 0.0;
+  }
+
+  __device__ __forceinline__ int gidx(int e) const {
+    return 16 * (wave * NT + (e >> 2)) + 4 * (e & 3) + lg;
+  }
+  __device__ __forceinline__ bool valid(int e) const { return gidx(e) < D; }
+  __device__ __forceinline__ bool owner(int) const { return true; }
+  __device__ __forceinline__ bool writer() const { return wave == 0 && lg == 0; }
+  __device__ __forceinline__ int chain_local() const { return cl; }
+  __device__ __forceinline__ uint32_t chain_global() const { return cg; }
+  __device__ __forceinline__ bool any(bool b) const { return __any(b); }
+
+  // sum partials over the 4*W lanes that serve a chain; every replica gets the same bits
+  template <int N>
+  __device__ __forceinline__ void reduce(double* v) {
+    static_assert(N <= NRED, "reduce width");
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      double x = v[k];
+      x += __shfl_xor(x, 16);
+      x += __shfl_xor(x, 32);
+      v[k] = x;
+    }
+    if (W > 1) {
+      double* buf = ldsr + (redpar & 1) * (NRED * W * 16);
+      redpar++;
+      if (lg == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) buf[(k * W + wave) * 16 + cn] = v[k];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) s += buf[(k * W + w) * 16 + cn];
+        v[k] = s;
+      }
+    }
+  }
+
+  // grad = -A q for the 16 chains of the group; lp partial = sum_e q_e g_e (lp = 1/2 q.g)
+  __device__ __forceinline__ void grad(const Vec& q, Vec& g, double& lp_part) {
+    if (TK == CK_DENSE) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int s = 4 * (wave * NT + (e >> 2)) + (e & 3);
+        ldsq[s * 64 + lane] = q.x[e];
+      }
+      __syncthreads();
+      d4_t acc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const double bq = ldsq[s * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[t * KS + s], bq, acc[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g.x[t * 4 + r] = acc[t][r];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) g.x[e] = -(adiag[e] * q.x[e]);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) s += q.x[e] * g.x[e];
+    lp_part = s;
+  }
+  __device__ __forceinline__ double lp_finish(double r) const { return 0.5 * r; }
+
+  __device__ __forceinline__ double* slot_ptr(int slot, int which) const {
+    return slotbase + ((size_t)((slot * 2 + which) * W + wave) * NE) * 64 + lane;
+  }
+  __device__ __forceinline__ void slot_store(int slot, const Vec& q, const Vec& v) const {
+    double* pq = slot_ptr(slot, 0);
+    double* pv = slot_ptr(slot, 1);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { pq[e * 64] = q.x[e]; pv[e * 64] = v.x[e]; }
+  }
+  __device__ __forceinline__ void slot_load(int slot, Vec& q, Vec& v) const {
+    const double* pq = slot_ptr(slot, 0);
+    const double* pv = slot_ptr(slot, 1);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { q.x[e] = pq[e * 64]; v.x[e] = pv[e * 64]; }
+  }
+  template <int K>
+  __device__ __forceinline__ void cold_put(const Vec& x) { cold[K] = x; }
+  template <int K>
+  __device__ __forceinline__ void cold_get(Vec& x) const { x = cold[K]; }
+};
+
+}  // namespace wn

@@ -1,0 +1,83 @@
+// wn_policy_lane.h -- layout policy "one chain per lane": every D-vector of a chain lives in the
+// registers of one lane (D <= DMAX, small), so dot products are lane-local loops in the
+// reference's own left-to-right order and no reduction or barrier exists.  Sub-tree endpoint
+// slots and the cold vectors (passive orbit end, last proposal) are in global memory laid out
+// [vector][element][chain] so that the 64 lanes of a wave touch 512 contiguous bytes.
+#pragma once
+#include "wn_chain.h"
+
+namespace wn {
+
+struct EmptyVec {};
+
+template <int DMAX, class Tgt>
+struct LanePolicy {
+  static constexpr int NE = DMAX;
+  struct Vec {
+    double x[DMAX];
+  };
+  template <bool B>
+  using Opt = typename std::conditional<B, Vec, EmptyVec>::type;
+
+  int D, cl;
+  uint32_t cg;
+  size_t cstride;  // padded chain count
+  double* work;
+  const double* tpar;
+  int nslot;
+
+  // workspace doubles needed for C chains
+  static size_t work_doubles(int C, int M) {
+    size_t cpad = ((size_t)C + 63) / 64 * 64;
+    return ((size_t)(M + 1) * 2 + COLD_N) * DMAX * cpad;
+  }
+
+  WN_HD LanePolicy(const Params& prm, int chain_local)
+      : D(prm.D), cl(chain_local), cg(prm.chain0 + (uint32_t)chain_local),
+        cstride(((size_t)prm.C + 63) / 64 * 64), work(prm.work), tpar(prm.tpar), nslot(prm.M + 1) {}
+
+  WN_HD bool valid(int e) const { return e < D; }
+  WN_HD bool owner(int) const { return true; }
+  WN_HD int gidx(int e) const { return e; }
+  WN_HD bool writer() const { return true; }
+  WN_HD int chain_local() const { return cl; }
+  WN_HD uint32_t chain_global() const { return cg; }
+  WN_HD bool any(bool b) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __any(b);
+#else
+    return b;
+#endif
+  }
+  template <int N>
+  WN_HD void reduce(double*) const {}
+  WN_HD void grad(const Vec& q, Vec& g, double& lp) const { lp = Tgt::eval(q.x, g.x, D, tpar); }
+  WN_HD double lp_finish(double lp) const { return lp; }
+
+  WN_HD double* vec_ptr(int v, int e) const { return work + ((size_t)v * DMAX + e) * cstride + cl; }
+  WN_HD void slot_store(int slot, const Vec& q, const Vec& v) const {
+#pragma unroll
+    for (int e = 0; e < DMAX; ++e)
+      if (e < D) { *vec_ptr(2 * slot, e) = q.x[e]; *vec_ptr(2 * slot + 1, e) = v.x[e]; }
+  }
+  WN_HD void slot_load(int slot, Vec& q, Vec& v) const {
+#pragma unroll
+    for (int e = 0; e < DMAX; ++e) {
+      q.x[e] = e < D ? *vec_ptr(2 * slot, e) : 0.0;
+      v.x[e] = e < D ? *vec_ptr(2 * slot + 1, e) : 0.0;
+    }
+  }
+  template <int K>
+  WN_HD void cold_put(const Vec& x) const {
+#pragma unroll
+    for (int e = 0; e < DMAX; ++e)
+      if (e < D) *vec_ptr(2 * nslot + K, e) = x.x[e];
+  }
+  template <int K>
+  WN_HD void cold_get(Vec& x) const {
+#pragma unroll
+    for (int e = 0; e < DMAX; ++e) x.x[e] = e < D ? *vec_ptr(2 * nslot + K, e) : 0.0;
+  }
+};
+
+}  // namespace wn

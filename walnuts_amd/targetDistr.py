@@ -1,0 +1,59 @@
+"""Device forms of the reference's target plugins (WALNUTSpy/targetDistr.py).
+
+The reference passes a Python callable lpFun(q, hessian=False) -> [lp, grad]
+(targetDistr.py:18).  A Python callable cannot run inside a fused GPU kernel, so a target here
+is a descriptor (kind enum + parameter buffer) that the kernels evaluate in place; calling the
+descriptor evaluates it on the GPU through the same C ABI (wn_lpfun), keeping the reference's
+call shape for scripts that probe a target by hand.
+"""
+import numpy as np
+
+from . import _lib as L
+
+
+class DeviceTarget:
+    def __init__(self, name, kind, dim=None, params=None):
+        self.name, self.kind, self.dim, self.params = name, kind, dim, params
+
+    def check_dim(self, d):
+        if self.dim is not None and d != self.dim:
+            raise ValueError(f"target {self.name} needs dimension {self.dim}, got {d}")
+
+    def __call__(self, q, hessian=False):
+        """lpFun(q) -> [lp, grad], evaluated on the GPU."""
+        from .engine import Engine
+        if hessian:
+            raise NotImplementedError("Hessians are only used by integrators outside the hot path")
+        q = np.asarray(q, dtype=np.float64)
+        self.check_dim(q.size)
+        e = Engine(q.size, 1).set_target(self.kind, self.params)
+        lp, g = e.lpfun(q.reshape(1, -1))
+        out = [float(lp.cpu()[0]), g.cpu().numpy()[0]]
+        e.close()
+        return out
+
+    def __repr__(self):
+        return f"<walnuts_amd target {self.name}>"
+
+
+stdGauss = DeviceTarget("stdGauss", L.T_STDGAUSS)              # targetDistr.py:18-21
+corrGauss = DeviceTarget("corrGauss", L.T_CORRGAUSS, 2)        # targetDistr.py:25-31
+smileDistr = DeviceTarget("smileDistr", L.T_SMILE, 2)          # targetDistr.py:34-38
+modFunnel = DeviceTarget("modFunnel", L.T_MODFUNNEL, 2)        # targetDistr.py:41-51
+funnel10 = DeviceTarget("funnel10", L.T_FUNNEL10, 11)          # targetDistr.py:74-78
+funnel1 = DeviceTarget("funnel1", L.T_FUNNEL1, 2)              # targetDistr.py:88-93
+
+
+def denseGauss(A):
+    """lp = -1/2 q'Aq, grad = -Aq for a symmetric precision matrix A (cfg 2/4)."""
+    A = np.asarray(A, dtype=np.float64) if not hasattr(A, "data_ptr") else A
+    d = A.shape[0]
+    if A.shape != (d, d):
+        raise ValueError("A must be square")
+    return DeviceTarget(f"denseGauss{d}", L.T_DENSEGAUSS, d, A)
+
+
+def diagGauss(a):
+    """lp = -1/2 sum a_i q_i^2 (diagonal precision)."""
+    a = np.asarray(a, dtype=np.float64) if not hasattr(a, "data_ptr") else a
+    return DeviceTarget(f"diagGauss{a.shape[0]}", L.T_DIAGGAUSS, int(a.shape[0]), a)
