@@ -30,7 +30,7 @@ class Params(C.Structure):
         ("q0", dp), ("samples", dp), ("diag", dp), ("trace", dp), ("trace_cap", C.c_int),
         ("trace_n", ip), ("work", dp), ("tpar", dp),
         ("kq", dp), ("kv", dp), ("kg", dp), ("kham0", dp), ("kh", dp), ("ku_r2p", dp),
-        ("kxi", ip), ("kq1", dp), ("kv1", dp), ("kg1", dp), ("kdout", dp), ("kiout", ip),
+        ("kxi", ip), ("kq1", dp), ("kv1", dp), ("kg1", dp), ("kdout", dp), ("kiout", ip), ("stamps", C.c_void_p),
     ]
 
 

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Build a diagnostic variant of the library: tools/build_variant.sh <name> <extra hipcc flags...>
+# -> walnuts_amd/libwalnuts_amd_<name>.so (select it with WN_LIB=<name>)
+set -e
+NAME=$1; shift
+cd "$(dirname "$0")/../walnuts_amd/csrc"
+mkdir -p build_$NAME
+FLAGS="-O3 -std=c++17 -fPIC -fno-strict-aliasing --offload-arch=gfx950 -Wno-unused-result -Wno-unused-value $*"
+for f in wn_capi wn_k_lane wn_k_coop; do
+  ( /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o build_$NAME/$f.o ) &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libwalnuts_amd_$NAME.so build_$NAME/*.o
+echo built ../libwalnuts_amd_$NAME.so

@@ -6,7 +6,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwalnuts_amd.so")
+# WN_LIB=<name> selects a diagnostic build made by tools/build_variant.sh (profiling only)
+_VARIANT = os.environ.get("WN_LIB", "")
+LIB_PATH = os.path.join(_HERE, f"libwalnuts_amd_{_VARIANT}.so" if _VARIANT else "libwalnuts_amd.so")
 
 WN_ABI_VERSION = 1
 NDIAG = 24

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/walnuts_amd.h"
 #include "wn_launch.h"
@@ -301,6 +302,26 @@ int wn_run(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, do
   p.numIter = n_iter; p.seed = seed;
   p.q0 = q0_dev; p.samples = samples_dev; p.diag = diag_dev;
   p.trace = trace_dev; p.trace_cap = trace_cap; p.trace_n = trace_n_dev;
+#ifdef WN_STAMPS
+  {  // diagnostic build: per-phase cycle stamps, dumped to $WN_STAMPS_OUT after the run
+    static unsigned long long* sbuf = nullptr;
+    const size_t nw = (size_t)((p.C + 15) / 16) * 4 * 8;
+    if (!sbuf) hipMalloc((void**)&sbuf, nw * sizeof(unsigned long long));
+    hipMemset(sbuf, 0, nw * sizeof(unsigned long long));
+    p.stamps = sbuf;
+    int rc = launch(e, p, (hipStream_t)stream, true);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(nw);
+    hipMemcpy(h.data(), sbuf, nw * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double tot[8] = {0};
+    for (size_t w = 0; w < nw / 8; ++w) for (int k = 0; k < 8; ++k) tot[k] += (double)h[w * 8 + k];
+    const char* names[8] = {"A_setup", "B_leapfrog+grad", "B_ke+reduce4", "C_after_micro", "D_uturn", "E_bookkeeping", "ticks", "loop_head"};
+    fprintf(stderr, "[WN_STAMPS] per wave-tick cycles:");
+    for (int k = 0; k < 8; ++k) if (k != 6) fprintf(stderr, " %s=%.0f", names[k], tot[k] / tot[6]);
+    fprintf(stderr, " ticks/wave=%.0f\n", tot[6] / (nw / 8));
+    return rc;
+  }
+#endif
   return launch(e, p, (hipStream_t)stream, true);
 }
 

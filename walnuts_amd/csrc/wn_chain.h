@@ -60,16 +60,35 @@ struct Params {
   const int* kxi;
   double *kq1, *kv1, *kg1, *kdout;
   int* kiout;
+  unsigned long long* stamps;  // diagnostic builds (-DWN_STAMPS): [block][wave][8] cycles per phase
 };
+
+#if defined(WN_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define WN_STAMP(k)                                              \
+  do {                                                           \
+    unsigned long long _t = __builtin_readcyclecounter();        \
+    st_[k] += _t - st_last_;                                     \
+    st_last_ = _t;                                               \
+  } while (0)
+#else
+#define WN_STAMP(k) do {} while (0)
+#endif
 
 #define WN_VFOR(e) _Pragma("unroll") for (int e = 0; e < P::NE; ++e)
 
 // cold vector ids (touched only at doubling boundaries)
-enum { COLD_QB = 0, COLD_VB, COLD_GB, COLD_QPL, COLD_GPL, COLD_N };
+// QB/VB/GB: passive end of the orbit.  QP/GP: current proposal and its gradient (q_c, grad0 of the
+// next iteration); QPL/GPL: proposal before the current doubling (qPropLast).  The proposal set is
+// written on multinomial picks and read once per doubling/iteration, so layouts keep it off-chip.
+enum { COLD_QB = 0, COLD_VB, COLD_GB, COLD_QP, COLD_GP, COLD_QPL, COLD_GPL, COLD_N };
 
 template <class P, bool ADAPT>
 struct Engine {
   using Vec = typename P::Vec;
+  // U-turn checks 0 (full orbit), 1 (leaf pair) and 2..1+NLC (fast-cached sub-tree levels) have
+  // their left state on chip; deeper levels are fetched from the slot store in memory.
+  static constexpr int NFAST = 2 + P::NLC;
+  static constexpr int NPB = ADAPT ? 4 : 4 + 2 * NFAST;  // partials reduced after the micro step
   P& p;
   const Params& prm;
 
@@ -81,8 +100,8 @@ struct Engine {
   double H0, Ha, Hb, lp0;
   double WoldSum, WnewSum, lwtSumf, lwtSumb, h2;
   uint32_t ku;
-  uint32_t ublk;       // cached uniform block index
-  double ucache0, ucache1;
+  uint32_t ub0;   // first Philox block of the cached uniform window
+  double uc[8];   // uniforms 2*ub0 .. 2*ub0+7 of this (chain, iteration)
   bool needKE, needGen;
   double keinit_part, gen_part;
   // diagnostics accumulators (WALNUTS.py:196-207, 660-693)
@@ -103,7 +122,6 @@ struct Engine {
 
   // ---- D-vectors ----------------------------------------------------------------------------
   Vec qa, va, ga;  // active end of the orbit = start of the current macro step (v forward-time)
-  Vec qP, gP;      // current proposal and its gradient (becomes q_c, grad0 of the next iteration)
   Vec ql, vl;      // first state of the current leaf pair (WALNUTS.py:438-439 / 525-526)
   double lpP, lpPL;
   // adaptive integrators only: work state of the running micro pass, and the accepted forward
@@ -116,18 +134,31 @@ struct Engine {
   // ------------------------------------------------------------------------------------------
   // random draws in the reference's call order
   // ------------------------------------------------------------------------------------------
-  WN_HD double next_u() {
-    uint32_t blk = ku >> 1;
-    if (blk != ublk) {
-      Philox4 ph4 = philox4x32_10(blk, (uint32_t)iter, p.chain_global(), 0u, (uint32_t)prm.seed,
+  // The k-th uniform of (chain, iteration) is a pure function of k (wn_rng.h); a window of four
+  // Philox blocks is slid forward ONCE per tick, at one code site, so the draws themselves are
+  // register selects.  A tick consumes at most 5 uniforms (h pair, R2P, pick, accept) < 7.
+  WN_HD void rng_refill() {
+    const uint32_t nb = ku >> 1;
+#pragma unroll 1
+    while (p.any(live && ub0 != nb)) {
+      if (live && ub0 != nb) {
+        uc[0] = uc[2]; uc[1] = uc[3]; uc[2] = uc[4]; uc[3] = uc[5]; uc[4] = uc[6]; uc[5] = uc[7];
+        ub0++;
+        Philox4 r = philox4x32_10(ub0 + 3u, (uint32_t)iter, p.chain_global(), 0u, (uint32_t)prm.seed,
                                   (uint32_t)(prm.seed >> 32));
-      ucache0 = u53(ph4.w[0], ph4.w[1]);
-      ucache1 = u53(ph4.w[2], ph4.w[3]);
-      ublk = blk;
+        uc[6] = u53(r.w[0], r.w[1]);
+        uc[7] = u53(r.w[2], r.w[3]);
+      }
     }
-    double u = (ku & 1u) ? ucache1 : ucache0;
+  }
+  WN_HD double next_u() {
+    const uint32_t k = ku - 2u * ub0;
     ku++;
-    return u;
+    const double a01 = (k & 1u) ? uc[1] : uc[0], a23 = (k & 1u) ? uc[3] : uc[2];
+    const double a45 = (k & 1u) ? uc[5] : uc[4], a67 = (k & 1u) ? uc[7] : uc[6];
+    const double lo = (k & 2u) ? a23 : a01, hi = (k & 2u) ? a67 : a45;
+    const double u = (k & 4u) ? hi : lo;
+    return k < 8u ? u : NAN;  // outside the window: poison (cannot happen, see rng_refill)
   }
   // numpy legacy uniform(low, high) = low + (high-low)*U
   WN_HD double draw_h() {
@@ -139,13 +170,18 @@ struct Engine {
   // iteration start  (WALNUTS.py:196-276)
   // ------------------------------------------------------------------------------------------
   WN_HD void start_iteration() {
-    ku = 0;
-    ublk = 0xffffffffu;
     Bbits = 0;
-    for (int k = 0; k < prm.M; ++k) {  // :216  B = floor(uniform(0,2,size=M))
-      double u = 0.0 + (2.0 - 0.0) * next_u();
-      if ((int)floor(u) != 0) Bbits |= (1u << k);
+#pragma unroll 1
+    for (uint32_t blk = 0; 2u * blk < (uint32_t)prm.M; ++blk) {  // :216  B = floor(uniform(0,2,size=M))
+      Philox4 r = philox4x32_10(blk, (uint32_t)iter, p.chain_global(), 0u, (uint32_t)prm.seed,
+                                (uint32_t)(prm.seed >> 32));
+      const double u0 = 0.0 + (2.0 - 0.0) * u53(r.w[0], r.w[1]);
+      const double u1 = 0.0 + (2.0 - 0.0) * u53(r.w[2], r.w[3]);
+      if ((int)floor(u0) != 0) Bbits |= (1u << (2u * blk));
+      if (2u * blk + 1u < (uint32_t)prm.M && (int)floor(u1) != 0) Bbits |= (1u << (2u * blk + 1u));
     }
+    ku = (uint32_t)prm.M;
+    ub0 = (ku >> 1) - 4u;  // empty window: the refill that follows loads blocks ku/2 .. ku/2+3
     a = 0; b = 0; maxFint = 0; maxBint = 0;  // :230-233
     double kp = 0.0;
     double ztmp[P::NE];
@@ -157,10 +193,10 @@ struct Engine {
     WN_VFOR(e) {  // :236  v = normal(size=d); both ends start at (qc, v, grad0)  :239-253
       double z = ztmp[e];
       va.x[e] = z;
-      qa.x[e] = qP.x[e];
-      ga.x[e] = gP.x[e];
       kp += z * z;
     }
+    p.template cold_get<COLD_QP>(qa);
+    p.template cold_get<COLD_GP>(ga);
     p.template cold_put<COLD_QB>(qa);
     p.template cold_put<COLD_VB>(va);
     p.template cold_put<COLD_GB>(ga);
@@ -182,8 +218,11 @@ struct Engine {
   WN_HD void start_doubling_common() {  // :283-294
     n = 0;
     nleaf = 1 << i;
-    p.template cold_put<COLD_QPL>(qP);
-    p.template cold_put<COLD_GPL>(gP);
+    {  // qPropLast = qProp  (:292)
+      Vec t;
+      p.template cold_get<COLD_QP>(t); p.template cold_put<COLD_QPL>(t);
+      p.template cold_get<COLD_GP>(t); p.template cold_put<COLD_GPL>(t);
+    }
     lpPL = lpP;
     Lold_ = L_;
     indexStatOld_ = indexStat_;
@@ -273,6 +312,13 @@ struct Engine {
   }
   template <bool B_ = ADAPT>
   WN_HD typename std::enable_if<!B_>::type save_out(double, double) {}
+
+  template <bool B_ = ADAPT>
+  WN_HD typename std::enable_if<B_>::type zero_adapt() {
+    WN_VFOR(e) { qw.x[e] = vw.x[e] = gw.x[e] = qo.x[e] = vo.x[e] = go.x[e] = 0.0; }
+  }
+  template <bool B_ = ADAPT>
+  WN_HD typename std::enable_if<!B_>::type zero_adapt() {}
 
   WN_HD void start_bwd_or_finalize() {
     if (maxTry >= prm.minC) {  // adaptiveIntegrators.py:107 / 440
@@ -377,20 +423,52 @@ struct Engine {
     }
     d1 = a1; d2 = a2;
   }
+  // dots of the on-chip checks: 0 = passive orbit end, 1 = first state of the leaf pair,
+  // 2..NFAST-1 = fast-cached sub-tree left endpoints.  out[2*j], out[2*j+1].
+  WN_HD void fast_dots(double* out) {
+    const bool on = live && fin && prm.mode == MODE_SAMPLE;
+#pragma unroll
+    for (int j = 0; j < NFAST; ++j) {
+      double d1 = 0.0, d2 = 0.0;
+      if (on && need_check(j)) {
+        if (j == 0) {
+          Vec qo_, vo_;
+          p.template cold_get<COLD_QB>(qo_); p.template cold_get<COLD_VB>(vo_);
+          uturn_dots(qo_, vo_, d1, d2);
+        } else if (j == 1) {
+          uturn_dots(ql, vl, d1, d2);
+        } else {
+          Vec qo_, vo_;
+          p.lslot_load(j - 2, qo_, vo_);
+          uturn_dots(qo_, vo_, d1, d2);
+        }
+      }
+      out[2 * j] = d1; out[2 * j + 1] = d2;
+    }
+  }
+  WN_HD void fast_fire(const double* dots, int nchk) {
+#pragma unroll
+    for (int j = 0; j < NFAST; ++j)
+      if (nchk > j && need_check(j) &&
+          (((double)xi * dots[2 * j] < 0.0) || ((double)xi * dots[2 * j + 1] < 0.0)))
+        firemask |= (1u << j);
+  }
   WN_HD static int slot_of_leaf(int m) { return m == 0 ? 0 : __builtin_ctz((unsigned)m); }
 
   // ------------------------------------------------------------------------------------------
   // phase E: NUTS bookkeeping after a finalised macro step (WALNUTS.py:296-648)
   // ------------------------------------------------------------------------------------------
   WN_HD void pick_state(int idx) {
-    WN_VFOR(e) { qP.x[e] = QN().x[e]; gP.x[e] = GN().x[e]; }
+    p.template cold_put<COLD_QP>(QN());
+    p.template cold_put<COLD_GP>(GN());
     lpP = lpn;
     L_ = idx;
     indexStat_ = xi > 0 ? timeLenF_ : -timeLenB_;
   }
   WN_HD void revert_prop() {  // qProp = qPropLast (:599-601, 614-616)
-    p.template cold_get<COLD_QPL>(qP);
-    p.template cold_get<COLD_GPL>(gP);
+    Vec t;
+    p.template cold_get<COLD_QPL>(t); p.template cold_put<COLD_QP>(t);
+    p.template cold_get<COLD_GPL>(t); p.template cold_put<COLD_GP>(t);
     lpP = lpPL;
     L_ = Lold_;
     indexStat_ = indexStatOld_;
@@ -451,7 +529,16 @@ struct Engine {
       orbitLen_ += h;  // :432 / 471 / 519 / 561
       if ((n & 1) == 0) {  // statePush (:431,518) -- only sub-tree left endpoints are ever read back
         WN_VFOR(e) { ql.x[e] = QN().x[e]; vl.x[e] = VN().x[e]; }
-        if (i >= 2 && (n & 3) == 0) p.slot_store(slot_of_leaf(n), QN(), VN());
+        if (i >= 2 && (n & 3) == 0) {
+          // left endpoint of sub-trees of 2**j leaves for every j <= i with 2**j | n.  Checks
+          // 2..NFAST-1 read it back from the layout's fast cache (one copy per level, reused
+          // every 2**j leaves); deeper checks read the long-lived copy in slot ctz(n).
+#pragma unroll
+          for (int j = 2; j < NFAST; ++j)
+            if (j <= i && (n & ((1 << j) - 1)) == 0) p.lslot_store(j - 2, QN(), VN());
+          if (n == 0 ? (i >= NFAST) : (__builtin_ctz((unsigned)n) >= NFAST))
+            p.slot_store(slot_of_leaf(n), QN(), VN());
+        }
       }
     }
     // the new state becomes the active end (qp/qm = intOut.q ...)
@@ -520,6 +607,8 @@ struct Engine {
 
   WN_HD void emit_generated(int it) {
     double* row = prm.samples + ((size_t)p.chain_local() * (prm.numIter + 1) + it) * prm.dg;
+    Vec qP;
+    p.template cold_get<COLD_QP>(qP);
     if (prm.generated == G_Q0_SUMSQ) {  // needs a reduction: completed at the next uniform phase
       double s = 0.0;
       WN_VFOR(e) s += qP.x[e] * qP.x[e];
@@ -546,10 +635,26 @@ struct Engine {
   // ------------------------------------------------------------------------------------------
   WN_HD void run() {
     const bool inrange = p.chain_local() < prm.C;
+    // every scalar starts defined (reading an indeterminate value is UB even on dead paths)
+    Bbits = 0; lp0 = 0.0; WoldSum = 1.0; WnewSum = 0.0; lwtSumf = lwtSumb = 0.0;
+    gen_iter = 0; lpP = lpPL = 0.0;
+    nevalF = nevalB = L_ = Lold_ = NdS = NdC = maxFint = maxBint = stopCode = 0;
+    orbitLen_ = orbitLenSam_ = indexStat_ = indexStatOld_ = timeLenF_ = timeLenB_ = 0.0;
+    bothEndsPassive = false;
+    minIf = minc = 1 << 30; maxIf = maxc = -(1 << 30); nneq = nzero = nused = 0;
+    minlw = INFINITY; maxlw = -INFINITY;
+    ph = PH_FWD; c = im = nstep = If = Ib = cSim = maxTry = nEvF = nEvB = cret = 0;
+    hh = Ham0 = HamPass0 = lwtf = lwt = 0.0;
+    allfin = true;
+    WN_VFOR(e) { va.x[e] = 0.0; ga.x[e] = 0.0; ql.x[e] = 0.0; vl.x[e] = 0.0; }
+    zero_adapt();
     live = inrange;
     needKE = needGen = needMacro = needPass = fin = needIter = needDoubling = endIter = false;
     keinit_part = gen_part = 0.0;
     ntrace = 0;
+    ku = 0; ub0 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) uc[k] = 0.0;
     iter = 1;
     Hnan = false; Hmin = INFINITY; Hmax = -INFINITY;
     firemask = 0;
@@ -560,20 +665,24 @@ struct Engine {
     const int cl = inrange ? p.chain_local() : 0;
     {
       const double* src = prm.mode == MODE_KAT ? prm.kq : prm.q0;
-      WN_VFOR(e) qP.x[e] = (p.valid(e) && inrange) ? src[(size_t)cl * prm.D + p.gidx(e)] : 0.0;
+      WN_VFOR(e) qa.x[e] = (p.valid(e) && inrange) ? src[(size_t)cl * prm.D + p.gidx(e)] : 0.0;
     }
     if (prm.mode == MODE_SAMPLE) {
       double part[1];
-      p.grad(qP, gP, part[0]);
+      p.grad(qa, ga, part[0]);
       p.template reduce<1>(part);
       lpP = p.lp_finish(part[0]);
+#ifdef WN_DEBUG_PRINT
+      if (p.chain_local() == 0) printf("[dbg] init lpP=%g part0=%g\n", lpP, part[0]);
+#endif
+      p.template cold_put<COLD_QP>(qa);
+      p.template cold_put<COLD_GP>(ga);
       if (live) {
         emit_generated(0);  // samples[:,0] = generated(q0)  (:164)
         if (prm.numIter < 1) live = false; else needIter = true;
       }
     } else if (live) {  // one macro step from a caller-supplied state
       WN_VFOR(e) {
-        qa.x[e] = qP.x[e];
         va.x[e] = p.valid(e) ? prm.kv[(size_t)cl * prm.D + p.gidx(e)] : 0.0;
         ga.x[e] = p.valid(e) ? prm.kg[(size_t)cl * prm.D + p.gidx(e)] : 0.0;
       }
@@ -581,27 +690,46 @@ struct Engine {
       needMacro = true;
     }
 
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last_ = 0;
+    (void)st_; (void)st_last_;
+#if defined(WN_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    st_last_ = __builtin_readcyclecounter();
+#endif
     while (p.any(live || needGen)) {
+      WN_STAMP(7);
       // ---- A ----
       if (live && needIter) start_iteration();
+      rng_refill();
       if (live && needDoubling) start_doubling();
       if (live && needMacro) setup_macro();
       if (ADAPT && live && needPass) setup_pass();
       // ---- B: one leapfrog micro step on the work state ----
       Vec& Q = QW(); Vec& V = VW(); Vec& G = GW();
       const double hh2 = live ? 0.5 * hh : 0.0, hq = live ? hh : 0.0;
+      WN_STAMP(0);
       WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; Q.x[e] = Q.x[e] + hq * V.x[e]; }
-      double part[4];
+      double part[NPB > 2 * NFAST ? NPB : 2 * NFAST];
       p.grad(Q, G, part[0]);
+      WN_STAMP(1);
       double ke = 0.0;
       WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; ke += V.x[e] * V.x[e]; }
       part[1] = ke; part[2] = keinit_part; part[3] = gen_part;
-      p.template reduce<4>(part);
+      if (!ADAPT) {
+        // fixedLeapFrog finalises its macro step every tick, so the on-chip U-turn checks ride
+        // in the same reduction as the energies
+        fin = live;
+        fast_dots(part + 4);
+      }
+      p.template reduce<NPB>(part);
+      WN_STAMP(2);
       // ---- C ----
       finish_generated(part[3]);
       if (live) {
         if (needKE) {  // Hs[I0] = -f0 + 0.5*sum(v**2)  (:256); multinomialLscale (:259)
           H0 = -lp0 + 0.5 * part[2];
+#ifdef WN_DEBUG_PRINT
+          if (p.chain_local() == 0) printf("[dbg] needKE iter=%d lp0=%g lpP=%g ke=%g H0=%g\n", iter, lp0, lpP, part[2], H0);
+#endif
           Ha = Hb = H0; Ham0 = H0;
           if (ADAPT) { HamPass0 = H0; allfin = isfinite(H0); }
           Hnan = isnan(H0); Hmin = Hmax = H0;
@@ -609,30 +737,31 @@ struct Engine {
         }
         after_micro(p.lp_finish(part[0]), part[1]);
       }
-      // ---- D: U-turn dot products, four checks per reduction ----
+      WN_STAMP(3);
+      // ---- D: U-turn checks ----
       const int nchk = nchecks();
       firemask = 0;
-      for (int j0 = 0; p.any(nchk > j0); j0 += 4) {
+      if (ADAPT) {
+        if (p.any(nchk > 0)) {
+          fast_dots(part);
+          p.template reduce<2 * NFAST>(part);
+          fast_fire(part, nchk);
+        }
+      } else {
+        fast_fire(part + 4, nchk);
+      }
+      // deep sub-tree levels: left states come from the slot store, four checks per reduction
+      for (int j0 = NFAST; p.any(nchk > j0); j0 += 4) {
         double dots[8];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const int j = j0 + jj;
           double d1 = 0.0, d2 = 0.0;
           if (p.any(nchk > j)) {
-            const bool need = (nchk > j) && need_check(j);
-            if (need) {
-              // newer minus older; v' of the new state is xi * VN
-              if (j == 0) {
-                Vec qo_, vo_;
-                p.template cold_get<COLD_QB>(qo_); p.template cold_get<COLD_VB>(vo_);
-                uturn_dots(qo_, vo_, d1, d2);
-              } else if (j == 1) {
-                uturn_dots(ql, vl, d1, d2);
-              } else {
-                Vec qo_, vo_;
-                p.slot_load(slot_of_leaf(n + 1 - (1 << j)), qo_, vo_);
-                uturn_dots(qo_, vo_, d1, d2);
-              }
+            if ((nchk > j) && need_check(j)) {
+              Vec qo_, vo_;
+              p.slot_load(slot_of_leaf(n + 1 - (1 << j)), qo_, vo_);
+              uturn_dots(qo_, vo_, d1, d2);
             }
           }
           dots[2 * jj] = d1; dots[2 * jj + 1] = d2;
@@ -647,13 +776,22 @@ struct Engine {
             firemask |= (1u << j);
         }
       }
+      WN_STAMP(4);
       // ---- E ----
       if (live && fin) {
         if (prm.mode == MODE_SAMPLE) step_done();
         else kat_done();
         if (endIter) end_iteration();
       }
+      WN_STAMP(5);
+      st_[6] += 1;
     }
+#if defined(WN_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    if (prm.stamps && (threadIdx.x & 63) == 0) {
+      unsigned long long* o = prm.stamps + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8;
+      for (int k = 0; k < 8; ++k) o[k] = st_[k];
+    }
+#endif
     if (prm.trace_n && inrange && p.writer()) prm.trace_n[p.chain_local()] = ntrace;
   }
 

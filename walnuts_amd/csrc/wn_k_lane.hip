@@ -28,6 +28,13 @@ size_t lane_work_doubles(int dmax, int C, int M) {
 }
 
 hipError_t launch_lane(const KernelChoice& kc, bool adapt, const Params& prm, hipStream_t st) {
+#ifdef WN_NO_LANE  // diagnostic variant builds (tools/build_variant.sh) skip the lane kernels
+  return hipErrorInvalidValue;
+#else
+#ifdef WN_LANE_ONLY_FUNNEL
+  if (kc.p1 == T_FUNNEL10) return go<11, TgtFunnel10>(adapt, prm, st);
+  return hipErrorInvalidValue;
+#endif
   switch (kc.p1) {
     case T_STDGAUSS:
     case T_DIAGGAUSS:
@@ -52,6 +59,7 @@ hipError_t launch_lane(const KernelChoice& kc, bool adapt, const Params& prm, hi
     case T_MODFUNNEL: return go<2, TgtModFunnel>(adapt, prm, st);
   }
   return hipErrorInvalidValue;
+#endif
 }
 
 }  // namespace wn

@@ -36,10 +36,14 @@ struct CoopPolicy {
   static constexpr int NE = NT * 4;
   static constexpr int KS_MAX = 4 * NT * W;  // k-steps of the padded dimension 16*NT*W
   static constexpr int DPAD = 16 * NT * W;
-  static constexpr int NRED = 8;
+  // sub-tree levels 2..1+NLC keep their left endpoint (q, v) in LDS: [level][q|v][wave][reg][lane]
+  static constexpr int NLC = NT <= 2 ? 3 : 1;
+  static constexpr int NRED = 4 + 2 * (2 + NLC);
   static constexpr int LDS_Q = KS_MAX * 64;
   static constexpr int LDS_RED = 2 * NRED * W * 16;
-  static constexpr int LDS_DOUBLES = LDS_Q + LDS_RED;
+  static constexpr int LDS_CACHE = NLC * 2 * W * NE * 64;
+  static constexpr int LDS_DOUBLES = LDS_Q + LDS_RED + LDS_CACHE;
+  static_assert(LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget (160 KiB per CU)");
   static_assert(KS <= KS_MAX, "k-steps exceed the padded dimension");
   static constexpr int NA = (TK == CK_DENSE) ? NT * KS : 1;
   struct Vec {
@@ -52,15 +56,18 @@ struct CoopPolicy {
   uint32_t cg;
   double* ldsq;
   double* ldsr;
+  double* ldsc;
   double* slotbase;
   int redpar;
   double afrag[NA];  // -A fragments: afrag[t*KS+s] = -A[16*T+(l&15)][4*s+(l>>4)]
   double adiag[NE];  // diagonal target: a[gidx(e)]
-  Vec cold[COLD_N];
+  Vec cold[3];  // passive orbit end (q, v, grad): read at every doubling end, kept in registers
+  double* coldbase;  // proposal set QP/GP/QPL/GPL: in memory, [vec][wave][reg][lane]
 
+  static constexpr size_t GROUP_DOUBLES(int M) { return (size_t)((M + 1) * 2 + 4) * W * NE * 64; }
   static size_t work_doubles(int C, int M) {
     size_t groups = ((size_t)C + 15) / 16;
-    return groups * (size_t)(M + 1) * 2 * W * NE * 64;
+    return groups * GROUP_DOUBLES(M);
   }
 
   __device__ __forceinline__ CoopPolicy(const Params& prm, double* lds) {
@@ -74,7 +81,9 @@ struct CoopPolicy {
     ksteps = (D + 3) >> 2;
     ldsq = lds;
     ldsr = lds + LDS_Q;
-    slotbase = prm.work + (size_t)blockIdx.x * (size_t)(prm.M + 1) * 2 * W * NE * 64;
+    ldsc = lds + LDS_Q + LDS_RED;
+    slotbase = prm.work + (size_t)blockIdx.x * GROUP_DOUBLES(prm.M);
+    coldbase = slotbase + (size_t)(prm.M + 1) * 2 * W * NE * 64;
     redpar = 0;
     if (TK == CK_DENSE) {
 #pragma unroll
@@ -103,17 +112,27 @@ struct CoopPolicy {
   __device__ __forceinline__ uint32_t chain_global() const { return cg; }
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
 
+  // x[l] + x[l^16] + x[l^32] + x[l^48] in every lane, on the VALU (no LDS round trip):
+  // v_permlane16_swap exchanges odd rows of one operand with even rows of the other,
+  // v_permlane32_swap the upper half of one with the lower half of the other.
+  __device__ __forceinline__ static double rowsum4(double x) {
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    u2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    u2_t b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double y = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    lo = __double2loint(y); hi = __double2hiint(y);
+    a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  }
+
   // sum partials over the 4*W lanes that serve a chain; every replica gets the same bits
   template <int N>
   __device__ __forceinline__ void reduce(double* v) {
     static_assert(N <= NRED, "reduce width");
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-      double x = v[k];
-      x += __shfl_xor(x, 16);
-      x += __shfl_xor(x, 32);
-      v[k] = x;
-    }
+    for (int k = 0; k < N; ++k) v[k] = rowsum4(v[k]);
     if (W > 1) {
       double* buf = ldsr + (redpar & 1) * (NRED * W * 16);
       redpar++;
@@ -182,10 +201,41 @@ struct CoopPolicy {
 #pragma unroll
     for (int e = 0; e < NE; ++e) { q.x[e] = pq[e * 64]; v.x[e] = pv[e * 64]; }
   }
+  __device__ __forceinline__ double* lslot_ptr(int lev, int which) const {
+    return ldsc + ((size_t)((lev * 2 + which) * W + wave) * NE) * 64 + lane;
+  }
+  __device__ __forceinline__ void lslot_store(int lev, const Vec& q, const Vec& v) const {
+    double* pq = lslot_ptr(lev, 0);
+    double* pv = lslot_ptr(lev, 1);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { pq[e * 64] = q.x[e]; pv[e * 64] = v.x[e]; }
+  }
+  __device__ __forceinline__ void lslot_load(int lev, Vec& q, Vec& v) const {
+    const double* pq = lslot_ptr(lev, 0);
+    const double* pv = lslot_ptr(lev, 1);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { q.x[e] = pq[e * 64]; v.x[e] = pv[e * 64]; }
+  }
   template <int K>
-  __device__ __forceinline__ void cold_put(const Vec& x) { cold[K] = x; }
+  __device__ __forceinline__ void cold_put(const Vec& x) {
+    if (K <= COLD_GB) {
+      cold[K <= COLD_GB ? K : 0] = x;
+    } else {
+      double* pc = coldbase + ((size_t)((K - COLD_QP) * W + wave) * NE) * 64 + lane;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) pc[e * 64] = x.x[e];
+    }
+  }
   template <int K>
-  __device__ __forceinline__ void cold_get(Vec& x) const { x = cold[K]; }
+  __device__ __forceinline__ void cold_get(Vec& x) const {
+    if (K <= COLD_GB) {
+      x = cold[K <= COLD_GB ? K : 0];
+    } else {
+      const double* pc = coldbase + ((size_t)((K - COLD_QP) * W + wave) * NE) * 64 + lane;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) x.x[e] = pc[e * 64];
+    }
+  }
 };
 
 }  // namespace wn

@@ -13,6 +13,7 @@ struct EmptyVec {};
 template <int DMAX, class Tgt>
 struct LanePolicy {
   static constexpr int NE = DMAX;
+  static constexpr int NLC = 0;  // no fast cache: every sub-tree left endpoint lives in the slot store
   struct Vec {
     double x[DMAX];
   };
@@ -67,6 +68,8 @@ struct LanePolicy {
       v.x[e] = e < D ? *vec_ptr(2 * slot + 1, e) : 0.0;
     }
   }
+  WN_HD void lslot_store(int, const Vec&, const Vec&) const {}
+  WN_HD void lslot_load(int, Vec&, Vec&) const {}
   template <int K>
   WN_HD void cold_put(const Vec& x) const {
 #pragma unroll

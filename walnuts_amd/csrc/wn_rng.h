@@ -42,8 +42,10 @@ WN_HD Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, 
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    uint32_t hi0 = mulhi32(M0, c0), lo0 = M0 * c0;
-    uint32_t hi1 = mulhi32(M1, c2), lo1 = M1 * c2;
+    // one 32x32->64 multiply per product (v_mad_u64_u32 on gfx950) instead of mul_hi + mul_lo
+    const uint64_t p0 = (uint64_t)M0 * (uint64_t)c0, p1 = (uint64_t)M1 * (uint64_t)c2;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     uint32_t n0 = hi1 ^ c1 ^ k0;
     uint32_t n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;

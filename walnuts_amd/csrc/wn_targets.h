@@ -63,8 +63,8 @@ struct TgtFunnel10 {
     // sum_i [-(q_i/s)^2/2 - logC - log s], s = e^{q0/2}.  The reference evaluates log(s) with
     // s = np.exp(0.5*q0) (targetDistr.py:75): when that overflows its lp is -inf and the sampler
     // force-rejects (WALNUTS.py:316); keep that behaviour.
-    if (0.5 * q[0] > 709.782712893384) return -INFINITY;
-    return (-(q[0] * q[0]) / 18.0 - logC - log3) + (-0.5 * emq * ss - 10.0 * logC - 5.0 * q[0]);
+    const double lp = (-(q[0] * q[0]) / 18.0 - logC - log3) + (-0.5 * emq * ss - 10.0 * logC - 5.0 * q[0]);
+    return (0.5 * q[0] > 709.782712893384) ? -INFINITY : lp;
   }
 };
 
@@ -96,8 +96,8 @@ struct TgtFunnel1 {  // targetDistr.py:88-93
     const double emq = exp(-q[0]);
     g[0] = -0.5 - q[0] / 9.0 + 0.5 * (q[1] * q[1]) * emq;
     g[1] = -q[1] * emq;
-    if (0.5 * q[0] > 709.782712893384) return -INFINITY;  // log(np.exp(0.5*q0)) overflow, as above
-    return (-(q[0] * q[0]) / 18.0 - logC - log3) + (-0.5 * (q[1] * q[1]) * emq - logC - 0.5 * q[0]);
+    const double lp = (-(q[0] * q[0]) / 18.0 - logC - log3) + (-0.5 * (q[1] * q[1]) * emq - logC - 0.5 * q[0]);
+    return (0.5 * q[0] > 709.782712893384) ? -INFINITY : lp;  // log(np.exp(0.5*q0)) overflow, as above
   }
 };
 
