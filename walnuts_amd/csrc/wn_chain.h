@@ -502,10 +502,12 @@ struct Engine {
     nevalF += nEvF; nevalB += nEvB;
     // per-step records Hs/Ifs/Ibs/cs/lwts feed only min/max/mean diagnostics (:668-692)
     nused++;
-    minIf = If < minIf ? If : minIf; maxIf = If > maxIf ? If : maxIf;
-    minc = cret < minc ? cret : minc; maxc = cret > maxc ? cret : maxc;
-    minlw = lwt < minlw ? lwt : minlw; maxlw = lwt > maxlw ? lwt : maxlw;
-    nneq += (If != Ib); nzero += (If == 0);
+    if (ADAPT) {  // fixedLeapFrog: If = Ib = c = 0, lwt = 0 for every step
+      minIf = If < minIf ? If : minIf; maxIf = If > maxIf ? If : maxIf;
+      minc = cret < minc ? cret : minc; maxc = cret > maxc ? cret : maxc;
+      minlw = lwt < minlw ? lwt : minlw; maxlw = lwt > maxlw ? lwt : maxlw;
+      nneq += (If != Ib); nzero += (If == 0);
+    }
     if (isnan(Hn)) Hnan = true;
     Hmin = Hn < Hmin ? Hn : Hmin; Hmax = Hn > Hmax ? Hn : Hmax;
     if (xi > 0) { maxFint = idx; timeLenF_ += h; } else { maxBint = idx; timeLenB_ += h; }
@@ -587,14 +589,15 @@ struct Engine {
     if (p.writer()) {
       double* d = prm.diag + ((size_t)cl * prm.numIter + (iter - 1)) * NDIAG;
       d[0] = L_; d[1] = NdS; d[2] = orbitLen_; d[3] = orbitLenSam_; d[4] = maxFint; d[5] = maxBint;
-      d[6] = nevalF; d[7] = nevalB; d[8] = minIf; d[9] = maxIf; d[10] = minlw; d[11] = maxlw;
+      d[6] = nevalF; d[7] = nevalB;
+      d[8] = ADAPT ? minIf : 0; d[9] = ADAPT ? maxIf : 0; d[10] = ADAPT ? minlw : 0.0; d[11] = ADAPT ? maxlw : 0.0;
       d[12] = bothEndsPassive ? 1.0 : 0.0;
       d[13] = ((lwtSumb < WN_LOGZERO + 1.0) || (lwtSumf < WN_LOGZERO + 1.0)) ? 1.0 : 0.0;
-      d[14] = (double)nneq / (double)nused;
+      d[14] = ADAPT ? (double)nneq / (double)nused : 0.0;
       d[15] = prm.H;
-      d[16] = (double)nzero / (double)nused;
+      d[16] = ADAPT ? (double)nzero / (double)nused : 1.0;
       d[17] = Hnan ? NAN : (Hmax - Hmin);
-      d[18] = prm.delta; d[19] = (double)stopCode; d[20] = NdC; d[21] = minc; d[22] = maxc;
+      d[18] = prm.delta; d[19] = (double)stopCode; d[20] = NdC; d[21] = ADAPT ? minc : 0; d[22] = ADAPT ? maxc : 0;
       d[23] = indexStat_;
     }
     emit_generated(iter);  // samples[:,iterN] = generated(qc), qc = qProp

@@ -27,7 +27,7 @@ static hipError_t go(bool adapt, const Params& prm, hipStream_t st) {
 
 size_t coop_work_doubles(int NT, int W, int C, int M) {
   size_t groups = ((size_t)C + 15) / 16;
-  return groups * (size_t)((M + 1) * 2 + 4) * W * (NT * 4) * 64;
+  return groups * (size_t)((M + 1) * 2 + 5) * W * (NT * 4) * 64;
 }
 
 hipError_t launch_coop(const KernelChoice& kc, bool adapt, const Params& prm, hipStream_t st) {

@@ -37,12 +37,13 @@ struct CoopPolicy {
   static constexpr int KS_MAX = 4 * NT * W;  // k-steps of the padded dimension 16*NT*W
   static constexpr int DPAD = 16 * NT * W;
   // sub-tree levels 2..1+NLC keep their left endpoint (q, v) in LDS: [level][q|v][wave][reg][lane]
-  static constexpr int NLC = NT <= 2 ? 3 : 1;
+  static constexpr int NLC = NT <= 2 ? 3 : 0;
   static constexpr int NRED = 4 + 2 * (2 + NLC);
   static constexpr int LDS_Q = KS_MAX * 64;
   static constexpr int LDS_RED = 2 * NRED * W * 16;
   static constexpr int LDS_CACHE = NLC * 2 * W * NE * 64;
-  static constexpr int LDS_DOUBLES = LDS_Q + LDS_RED + LDS_CACHE;
+  static constexpr int LDS_COLD = 2 * W * NE * 64;  // passive orbit end (q, v), read at every doubling end
+  static constexpr int LDS_DOUBLES = LDS_Q + LDS_RED + LDS_CACHE + LDS_COLD;
   static_assert(LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget (160 KiB per CU)");
   static_assert(KS <= KS_MAX, "k-steps exceed the padded dimension");
   static constexpr int NA = (TK == CK_DENSE) ? NT * KS : 1;
@@ -61,10 +62,10 @@ struct CoopPolicy {
   int redpar;
   double afrag[NA];  // -A fragments: afrag[t*KS+s] = -A[16*T+(l&15)][4*s+(l>>4)]
   double adiag[NE];  // diagonal target: a[gidx(e)]
-  Vec cold[3];  // passive orbit end (q, v, grad): read at every doubling end, kept in registers
-  double* coldbase;  // proposal set QP/GP/QPL/GPL: in memory, [vec][wave][reg][lane]
+  double* ldscold;   // QB, VB in LDS: [q|v][wave][reg][lane]
+  double* coldbase;  // GB and the proposal set QP/GP/QPL/GPL: in memory, [vec][wave][reg][lane]
 
-  static constexpr size_t GROUP_DOUBLES(int M) { return (size_t)((M + 1) * 2 + 4) * W * NE * 64; }
+  static constexpr size_t GROUP_DOUBLES(int M) { return (size_t)((M + 1) * 2 + 5) * W * NE * 64; }
   static size_t work_doubles(int C, int M) {
     size_t groups = ((size_t)C + 15) / 16;
     return groups * GROUP_DOUBLES(M);
@@ -82,6 +83,7 @@ struct CoopPolicy {
     ldsq = lds;
     ldsr = lds + LDS_Q;
     ldsc = lds + LDS_Q + LDS_RED;
+    ldscold = ldsc + LDS_CACHE;
     slotbase = prm.work + (size_t)blockIdx.x * GROUP_DOUBLES(prm.M);
     coldbase = slotbase + (size_t)(prm.M + 1) * 2 * W * NE * 64;
     redpar = 0;
@@ -217,24 +219,21 @@ struct CoopPolicy {
     for (int e = 0; e < NE; ++e) { q.x[e] = pq[e * 64]; v.x[e] = pv[e * 64]; }
   }
   template <int K>
+  __device__ __forceinline__ double* cold_ptr() const {
+    if (K == COLD_QB || K == COLD_VB) return ldscold + ((size_t)(K * W + wave) * NE) * 64 + lane;
+    return coldbase + ((size_t)((K - COLD_GB) * W + wave) * NE) * 64 + lane;
+  }
+  template <int K>
   __device__ __forceinline__ void cold_put(const Vec& x) {
-    if (K <= COLD_GB) {
-      cold[K <= COLD_GB ? K : 0] = x;
-    } else {
-      double* pc = coldbase + ((size_t)((K - COLD_QP) * W + wave) * NE) * 64 + lane;
+    double* pc = cold_ptr<K>();
 #pragma unroll
-      for (int e = 0; e < NE; ++e) pc[e * 64] = x.x[e];
-    }
+    for (int e = 0; e < NE; ++e) pc[e * 64] = x.x[e];
   }
   template <int K>
   __device__ __forceinline__ void cold_get(Vec& x) const {
-    if (K <= COLD_GB) {
-      x = cold[K <= COLD_GB ? K : 0];
-    } else {
-      const double* pc = coldbase + ((size_t)((K - COLD_QP) * W + wave) * NE) * 64 + lane;
+    const double* pc = cold_ptr<K>();
 #pragma unroll
-      for (int e = 0; e < NE; ++e) x.x[e] = pc[e * 64];
-    }
+    for (int e = 0; e < NE; ++e) x.x[e] = pc[e * 64];
   }
 };
 

@@ -68,8 +68,15 @@ WN_HD double rng_uniform(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t 
   return (k & 1u) ? u53(p.w[2], p.w[3]) : u53(p.w[0], p.w[1]);
 }
 
-// j-th momentum normal of (chain, iter)
-WN_HD double rng_normal(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t j) {
+// j-th momentum normal of (chain, iter).  Deliberately NOT inlined on the device: it is called
+// once per element per iteration, and inlining log/sincos into the sampler's hot loop inflates its
+// register allocation; as a real call only the rare call site pays.
+#if defined(__HIPCC__)
+#define WN_HD_NOINLINE __host__ __device__ __attribute__((noinline)) inline
+#else
+#define WN_HD_NOINLINE inline
+#endif
+WN_HD_NOINLINE double rng_normal(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t j) {
   Philox4 p = philox4x32_10(j >> 1, iter, chain, 1u, (uint32_t)seed, (uint32_t)(seed >> 32));
   uint64_t x0 = ((uint64_t)p.w[1] << 32) | p.w[0];
   double u1 = ((double)(x0 >> 12) + 0.5) * 0x1.0p-52;
