@@ -77,10 +77,11 @@ struct Params {
 #define WN_VFOR(e) _Pragma("unroll") for (int e = 0; e < P::NE; ++e)
 
 // cold vector ids (touched only at doubling boundaries)
-// QB/VB/GB: passive end of the orbit.  QP/GP: current proposal and its gradient (q_c, grad0 of the
-// next iteration); QPL/GPL: proposal before the current doubling (qPropLast).  The proposal set is
-// written on multinomial picks and read once per doubling/iteration, so layouts keep it off-chip.
-enum { COLD_QB = 0, COLD_VB, COLD_GB, COLD_QP, COLD_GP, COLD_QPL, COLD_GPL, COLD_N };
+// QB/VB/GB: passive end of the orbit.  The proposal (q_c-to-be and its gradient) and the proposal
+// before the current doubling (qPropLast, WALNUTS.py:292) live in two off-chip buffers that are
+// never copied: `ip` names the buffer holding qProp, `ipl` the one holding qPropLast; the first
+// pick of a doubling moves to the other buffer, a revert (WALNUTS.py:599,616) just sets ip = ipl.
+enum { COLD_QB = 0, COLD_VB, COLD_GB, COLD_N };
 
 template <class P, bool ADAPT>
 struct Engine {
@@ -124,6 +125,7 @@ struct Engine {
   Vec qa, va, ga;  // active end of the orbit = start of the current macro step (v forward-time)
   Vec ql, vl;      // first state of the current leaf pair (WALNUTS.py:438-439 / 525-526)
   double lpP, lpPL;
+  int ip, ipl;
   // adaptive integrators only: work state of the running micro pass, and the accepted forward
   // result while the backward passes run
   struct Empty {};
@@ -195,8 +197,7 @@ struct Engine {
       va.x[e] = z;
       kp += z * z;
     }
-    p.template cold_get<COLD_QP>(qa);
-    p.template cold_get<COLD_GP>(ga);
+    p.prop_get(ip, qa, ga);
     p.template cold_put<COLD_QB>(qa);
     p.template cold_put<COLD_VB>(va);
     p.template cold_put<COLD_GB>(ga);
@@ -218,11 +219,7 @@ struct Engine {
   WN_HD void start_doubling_common() {  // :283-294
     n = 0;
     nleaf = 1 << i;
-    {  // qPropLast = qProp  (:292)
-      Vec t;
-      p.template cold_get<COLD_QP>(t); p.template cold_put<COLD_QPL>(t);
-      p.template cold_get<COLD_GP>(t); p.template cold_put<COLD_GPL>(t);
-    }
+    ipl = ip;  // qPropLast = qProp  (:292)
     lpPL = lpP;
     Lold_ = L_;
     indexStatOld_ = indexStat_;
@@ -459,16 +456,14 @@ struct Engine {
   // phase E: NUTS bookkeeping after a finalised macro step (WALNUTS.py:296-648)
   // ------------------------------------------------------------------------------------------
   WN_HD void pick_state(int idx) {
-    p.template cold_put<COLD_QP>(QN());
-    p.template cold_put<COLD_GP>(GN());
+    if (ip == ipl) ip ^= 1;  // keep qPropLast intact
+    p.prop_put(ip, QN(), GN());
     lpP = lpn;
     L_ = idx;
     indexStat_ = xi > 0 ? timeLenF_ : -timeLenB_;
   }
   WN_HD void revert_prop() {  // qProp = qPropLast (:599-601, 614-616)
-    Vec t;
-    p.template cold_get<COLD_QPL>(t); p.template cold_put<COLD_QP>(t);
-    p.template cold_get<COLD_GPL>(t); p.template cold_put<COLD_GP>(t);
+    ip = ipl;
     lpP = lpPL;
     L_ = Lold_;
     indexStat_ = indexStatOld_;
@@ -610,8 +605,8 @@ struct Engine {
 
   WN_HD void emit_generated(int it) {
     double* row = prm.samples + ((size_t)p.chain_local() * (prm.numIter + 1) + it) * prm.dg;
-    Vec qP;
-    p.template cold_get<COLD_QP>(qP);
+    Vec qP, gP_;
+    p.prop_get(ip, qP, gP_);
     if (prm.generated == G_Q0_SUMSQ) {  // needs a reduction: completed at the next uniform phase
       double s = 0.0;
       WN_VFOR(e) s += qP.x[e] * qP.x[e];
@@ -640,7 +635,7 @@ struct Engine {
     const bool inrange = p.chain_local() < prm.C;
     // every scalar starts defined (reading an indeterminate value is UB even on dead paths)
     Bbits = 0; lp0 = 0.0; WoldSum = 1.0; WnewSum = 0.0; lwtSumf = lwtSumb = 0.0;
-    gen_iter = 0; lpP = lpPL = 0.0;
+    gen_iter = 0; lpP = lpPL = 0.0; ip = ipl = 0;
     nevalF = nevalB = L_ = Lold_ = NdS = NdC = maxFint = maxBint = stopCode = 0;
     orbitLen_ = orbitLenSam_ = indexStat_ = indexStatOld_ = timeLenF_ = timeLenB_ = 0.0;
     bothEndsPassive = false;
@@ -678,8 +673,7 @@ struct Engine {
 #ifdef WN_DEBUG_PRINT
       if (p.chain_local() == 0) printf("[dbg] init lpP=%g part0=%g\n", lpP, part[0]);
 #endif
-      p.template cold_put<COLD_QP>(qa);
-      p.template cold_put<COLD_GP>(ga);
+      p.prop_put(ip, qa, ga);
       if (live) {
         emit_generated(0);  // samples[:,0] = generated(q0)  (:164)
         if (prm.numIter < 1) live = false; else needIter = true;

@@ -24,7 +24,7 @@ static hipError_t go(bool adapt, const Params& prm, hipStream_t st) {
 
 size_t lane_work_doubles(int dmax, int C, int M) {
   size_t cpad = ((size_t)C + 63) / 64 * 64;
-  return ((size_t)(M + 1) * 2 + COLD_N) * dmax * cpad;
+  return ((size_t)(M + 1) * 2 + COLD_N + 4) * dmax * cpad;
 }
 
 hipError_t launch_lane(const KernelChoice& kc, bool adapt, const Params& prm, hipStream_t st) {

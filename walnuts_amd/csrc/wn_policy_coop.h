@@ -221,7 +221,20 @@ struct CoopPolicy {
   template <int K>
   __device__ __forceinline__ double* cold_ptr() const {
     if (K == COLD_QB || K == COLD_VB) return ldscold + ((size_t)(K * W + wave) * NE) * 64 + lane;
-    return coldbase + ((size_t)((K - COLD_GB) * W + wave) * NE) * 64 + lane;
+    return coldbase + ((size_t)wave * NE) * 64 + lane;  // COLD_GB
+  }
+  // proposal buffers which = 0/1: (q, grad), in memory after GB
+  __device__ __forceinline__ void prop_put(int which, const Vec& q, const Vec& g) const {
+    double* pq = coldbase + ((size_t)((1 + 2 * which) * W + wave) * NE) * 64 + lane;
+    double* pg = pq + (size_t)W * NE * 64;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { pq[e * 64] = q.x[e]; pg[e * 64] = g.x[e]; }
+  }
+  __device__ __forceinline__ void prop_get(int which, Vec& q, Vec& g) const {
+    const double* pq = coldbase + ((size_t)((1 + 2 * which) * W + wave) * NE) * 64 + lane;
+    const double* pg = pq + (size_t)W * NE * 64;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { q.x[e] = pq[e * 64]; g.x[e] = pg[e * 64]; }
   }
   template <int K>
   __device__ __forceinline__ void cold_put(const Vec& x) {

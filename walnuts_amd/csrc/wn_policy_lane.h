@@ -30,7 +30,7 @@ struct LanePolicy {
   // workspace doubles needed for C chains
   static size_t work_doubles(int C, int M) {
     size_t cpad = ((size_t)C + 63) / 64 * 64;
-    return ((size_t)(M + 1) * 2 + COLD_N) * DMAX * cpad;
+    return ((size_t)(M + 1) * 2 + COLD_N + 4) * DMAX * cpad;
   }
 
   WN_HD LanePolicy(const Params& prm, int chain_local)
@@ -66,6 +66,22 @@ struct LanePolicy {
     for (int e = 0; e < DMAX; ++e) {
       q.x[e] = e < D ? *vec_ptr(2 * slot, e) : 0.0;
       v.x[e] = e < D ? *vec_ptr(2 * slot + 1, e) : 0.0;
+    }
+  }
+  // proposal buffers which = 0/1: (q, grad)
+  WN_HD void prop_put(int which, const Vec& q, const Vec& g) const {
+#pragma unroll
+    for (int e = 0; e < DMAX; ++e)
+      if (e < D) {
+        *vec_ptr(2 * nslot + COLD_N + 2 * which, e) = q.x[e];
+        *vec_ptr(2 * nslot + COLD_N + 2 * which + 1, e) = g.x[e];
+      }
+  }
+  WN_HD void prop_get(int which, Vec& q, Vec& g) const {
+#pragma unroll
+    for (int e = 0; e < DMAX; ++e) {
+      q.x[e] = e < D ? *vec_ptr(2 * nslot + COLD_N + 2 * which, e) : 0.0;
+      g.x[e] = e < D ? *vec_ptr(2 * nslot + COLD_N + 2 * which + 1, e) : 0.0;
     }
   }
   WN_HD void lslot_store(int, const Vec&, const Vec&) const {}
