@@ -160,11 +160,12 @@ def main():
 
     # final gather of draws to rank 0 (the only data collective; RCCL over xGMI), timed apart
     gather_ms = 0.0
+    draws = last
     if world > 1:
+        from walnuts_amd.dist import gather_draws
         torch.cuda.synchronize(dev)
         g0 = time.perf_counter()
-        bufs = [torch.empty_like(last) for _ in range(world)] if rank == 0 else None
-        dist.gather(last, bufs, dst=0)
+        draws = gather_draws(last, dst=0)
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - g0) * 1e3
 
@@ -199,6 +200,19 @@ def main():
                          "traffic": args.traffic_bytes,
                          "flop_per_leapfrog_step": flop_per_step},
         }
+        # ESS/sec of gen(q) = [q[0], sum(q*q)] (mainGaussESS.py:29-30) over all chains of the last
+        # launch; rank-normalised split bulk ESS (walnuts_amd/ess.py), host side, outside the timing
+        try:
+            from walnuts_amd.ess import ess
+            dr = draws.cpu().numpy()
+            e0, e1 = ess(dr[:, 1:, 0]), ess(dr[:, 1:, 1])
+            per_launch_s = elapsed / args.steps
+            out["ess_per_sec"] = {"q0": e0 / per_launch_s, "sum_q2": e1 / per_launch_s,
+                                  "ess_q0": e0, "ess_sum_q2": e1,
+                                  "draws": int(dr.shape[0] * (dr.shape[1] - 1)),
+                                  "method": "rank-normalised split bulk ESS over all chains of one launch"}
+        except Exception as ex:  # the throughput line must not depend on the ESS estimator
+            out["ess_per_sec"] = {"error": repr(ex)}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -1,0 +1,89 @@
+"""Host-side logic without a GPU: ESS estimator, sharding helpers (2-process gloo), bench
+problem construction."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_ess_on_ar1_series():
+    from walnuts_amd.ess import ess
+    rng = np.random.default_rng(0)
+    for phi in (0.0, 0.5, 0.9):
+        m, n = 8, 4000
+        x = np.zeros((m, n)); e = rng.normal(size=(m, n))
+        x[:, 0] = e[:, 0] / np.sqrt(1 - phi ** 2)
+        for t in range(1, n):
+            x[:, t] = phi * x[:, t - 1] + e[:, t]
+        want = m * n * (1 - phi) / (1 + phi)
+        got = ess(x)
+        assert 0.8 * want < got < 1.25 * want, (phi, got, want)
+    # anticorrelated draws (what NUTS produces on Gaussians) exceed the number of draws
+    x = np.zeros((4, 2000)); e = rng.normal(size=(4, 2000))
+    for t in range(1, 2000):
+        x[:, t] = -0.4 * x[:, t - 1] + e[:, t]
+    assert ess(x) > 4 * 2000
+
+
+def test_shard_range_partitions():
+    from walnuts_amd.dist import shard_range
+    for total in (1, 7, 4096, 8192 + 5):
+        for world in (1, 2, 3, 8):
+            r = [shard_range(total, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_bench_problem_is_sharding_invariant():
+    sys.path.insert(0, ROOT)
+    from bench import make_dense_problem
+    A, q = make_dense_problem(20, 1e4, 700, 5)
+    A2, qa = make_dense_problem(20, 1e4, 300, 5, chain_offset=0)
+    A3, qb = make_dense_problem(20, 1e4, 400, 5, chain_offset=300)
+    np.testing.assert_array_equal(A, A2); np.testing.assert_array_equal(A, A3)
+    np.testing.assert_array_equal(q, np.concatenate([qa, qb]))
+    ev = np.linalg.eigvalsh(A)
+    assert abs(ev.max() / ev.min() - 1e4) / 1e4 < 1e-6
+
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    from walnuts_amd.dist import shard_range, gather_draws, total_steps
+    from bench import make_dense_problem
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    total = 37
+    lo, hi = shard_range(total, rank, world)
+    A, q0 = make_dense_problem(6, 100.0, hi - lo, 11, chain_offset=lo)
+    # stand-in for per-rank draws: a deterministic function of the GLOBAL chain id and q0
+    draws = torch.tensor(q0[:, :2] + np.arange(lo, hi)[:, None])
+    diag = torch.zeros(hi - lo, 3, 24, dtype=torch.float64); diag[..., 6] = 5.0; diag[..., 7] = 1.0
+    out = gather_draws(draws, dst=0)
+    steps = total_steps(diag)
+    if rank == 0:
+        A1, qall = make_dense_problem(6, 100.0, total, 11)
+        want = qall[:, :2] + np.arange(total)[:, None]
+        assert out.shape == (total, 2) and np.array_equal(out.numpy(), want), "gather mismatch"
+        assert steps == total * 3 * 6.0, steps
+        print("OK")
+    dist.destroy_process_group()
+''')
+
+
+def test_two_process_gloo_sharding_and_gather(tmp_path):
+    """N > 1 path on CPU: contiguous sharding keyed by global chain id + the final gather."""
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29731", str(script)],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr

@@ -305,7 +305,7 @@ int wn_run(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, do
 #ifdef WN_STAMPS
   {  // diagnostic build: per-phase cycle stamps, dumped to $WN_STAMPS_OUT after the run
     static unsigned long long* sbuf = nullptr;
-    const size_t nw = (size_t)((p.C + 15) / 16) * 4 * 8;
+    const size_t nw = (size_t)((p.C + 15) / 16) * 4 * 16;
     if (!sbuf) hipMalloc((void**)&sbuf, nw * sizeof(unsigned long long));
     hipMemset(sbuf, 0, nw * sizeof(unsigned long long));
     p.stamps = sbuf;
@@ -313,12 +313,13 @@ int wn_run(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, do
     hipDeviceSynchronize();
     std::vector<unsigned long long> h(nw);
     hipMemcpy(h.data(), sbuf, nw * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    double tot[8] = {0};
-    for (size_t w = 0; w < nw / 8; ++w) for (int k = 0; k < 8; ++k) tot[k] += (double)h[w * 8 + k];
-    const char* names[8] = {"A_setup", "B_leapfrog+grad", "B_ke+reduce4", "C_after_micro", "D_uturn", "E_bookkeeping", "ticks", "loop_head"};
+    double tot[16] = {0};
+    for (size_t w = 0; w < nw / 16; ++w) for (int k = 0; k < 16; ++k) tot[k] += (double)h[w * 16 + k];
+    const char* names[16] = {"A_setup", "B_leapfrog+grad", "B_ke+reduce", "C_after_micro", "D_uturn", "E_rest", "ticks", "loop_head",
+                             "E_to_exp", "E_pick+stores", "E_doubling_end", "", "", "", "", ""};
     fprintf(stderr, "[WN_STAMPS] per wave-tick cycles:");
-    for (int k = 0; k < 8; ++k) if (k != 6) fprintf(stderr, " %s=%.0f", names[k], tot[k] / tot[6]);
-    fprintf(stderr, " ticks/wave=%.0f\n", tot[6] / (nw / 8));
+    for (int k = 0; k < 11; ++k) if (k != 6) fprintf(stderr, " %s=%.0f", names[k], tot[k] / tot[6]);
+    fprintf(stderr, " ticks/wave=%.0f\n", tot[6] / (nw / 16));
     return rc;
   }
 #endif

@@ -64,11 +64,15 @@ struct Params {
 };
 
 #if defined(WN_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
-#define WN_STAMP(k)                                              \
-  do {                                                           \
-    unsigned long long _t = __builtin_readcyclecounter();        \
-    st_[k] += _t - st_last_;                                     \
-    st_last_ = _t;                                               \
+#define WN_STAMP(k)                                                                   \
+  do {                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    unsigned long long _t;                                                            \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" \
+                 : "=s"(_t)::"memory");                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    st_[k] += _t - st_last_;                                                          \
+    st_last_ = _t;                                                                    \
   } while (0)
 #else
 #define WN_STAMP(k) do {} while (0)
@@ -486,6 +490,7 @@ struct Engine {
     }
   }
   int ntrace;
+  unsigned long long st_[16], st_last_;  // diagnostic builds only (-DWN_STAMPS)
 
   WN_HD void step_done() {
     fin = false;
@@ -516,6 +521,7 @@ struct Engine {
     else if (first || xi > 0) { if (xi > 0) lwtSumf += lwt; else lwtSumb += lwt; }  // :420,507,550; Q2
     const double lwtSum = xi > 0 ? lwtSumf : lwtSumb;
     const double Wnew = exp(-Hn + H0 + lwtSum);
+    WN_STAMP(8);
     if (i == 0) {  // :322-328, 368-369: unconditional, no uniform
       WnewSum = Wnew;
       pick_state(idx);
@@ -538,6 +544,7 @@ struct Engine {
         }
       }
     }
+    WN_STAMP(9);
     // the new state becomes the active end (qp/qm = intOut.q ...)
     if (ADAPT) { WN_VFOR(e) { qa.x[e] = QN().x[e]; va.x[e] = VN().x[e]; ga.x[e] = GN().x[e]; } }
     Ha = Hn;
@@ -550,6 +557,7 @@ struct Engine {
     if (sub) doubling_end(true);
     else if (n == nleaf) doubling_end(false);
     else needMacro = true;
+    WN_STAMP(10);
   }
 
   WN_HD void doubling_end(bool sub) {
@@ -581,21 +589,26 @@ struct Engine {
 
   WN_HD void end_iteration() {  // :653-695
     const int cl = p.chain_local();
-    if (p.writer()) {
-      double* d = prm.diag + ((size_t)cl * prm.numIter + (iter - 1)) * NDIAG;
-      d[0] = L_; d[1] = NdS; d[2] = orbitLen_; d[3] = orbitLenSam_; d[4] = maxFint; d[5] = maxBint;
-      d[6] = nevalF; d[7] = nevalB;
-      d[8] = ADAPT ? minIf : 0; d[9] = ADAPT ? maxIf : 0; d[10] = ADAPT ? minlw : 0.0; d[11] = ADAPT ? maxlw : 0.0;
-      d[12] = bothEndsPassive ? 1.0 : 0.0;
-      d[13] = ((lwtSumb < WN_LOGZERO + 1.0) || (lwtSumf < WN_LOGZERO + 1.0)) ? 1.0 : 0.0;
-      d[14] = ADAPT ? (double)nneq / (double)nused : 0.0;
-      d[15] = prm.H;
-      d[16] = ADAPT ? (double)nzero / (double)nused : 1.0;
-      d[17] = Hnan ? NAN : (Hmax - Hmin);
-      d[18] = prm.delta; d[19] = (double)stopCode; d[20] = NdC; d[21] = ADAPT ? minc : 0; d[22] = ADAPT ? maxc : 0;
-      d[23] = indexStat_;
-    }
-    emit_generated(iter);  // samples[:,iterN] = generated(qc), qc = qProp
+#ifndef WN_ABL_NOGEN
+    emit_generated(iter);  // samples[:,iterN] = generated(qc), qc = qProp  (loads before the stores below)
+#endif
+    double d[NDIAG];
+    d[0] = L_; d[1] = NdS; d[2] = orbitLen_; d[3] = orbitLenSam_; d[4] = maxFint; d[5] = maxBint;
+    d[6] = nevalF; d[7] = nevalB;
+    d[8] = ADAPT ? minIf : 0; d[9] = ADAPT ? maxIf : 0; d[10] = ADAPT ? minlw : 0.0; d[11] = ADAPT ? maxlw : 0.0;
+    d[12] = bothEndsPassive ? 1.0 : 0.0;
+    d[13] = ((lwtSumb < WN_LOGZERO + 1.0) || (lwtSumf < WN_LOGZERO + 1.0)) ? 1.0 : 0.0;
+    d[14] = ADAPT ? (double)nneq / (double)nused : 0.0;
+    d[15] = prm.H;
+    d[16] = ADAPT ? (double)nzero / (double)nused : 1.0;
+    d[17] = Hnan ? NAN : (Hmax - Hmin);
+    d[18] = prm.delta; d[19] = (double)stopCode; d[20] = NdC; d[21] = ADAPT ? minc : 0; d[22] = ADAPT ? maxc : 0;
+    d[23] = indexStat_;
+#if defined(WN_ABL_DIAGSAME)
+    p.diag_store(prm.diag + (size_t)cl * NDIAG, d);
+#elif !defined(WN_ABL_NODIAG)
+    p.diag_store(prm.diag + ((size_t)cl * prm.numIter + (iter - 1)) * NDIAG, d);
+#endif
     iter++;
     endIter = false;
     needMacro = false;
@@ -687,8 +700,9 @@ struct Engine {
       needMacro = true;
     }
 
-    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last_ = 0;
-    (void)st_; (void)st_last_;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) st_[k] = 0;
+    st_last_ = 0;
 #if defined(WN_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
     st_last_ = __builtin_readcyclecounter();
 #endif
@@ -785,8 +799,8 @@ struct Engine {
     }
 #if defined(WN_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
     if (prm.stamps && (threadIdx.x & 63) == 0) {
-      unsigned long long* o = prm.stamps + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8;
-      for (int k = 0; k < 8; ++k) o[k] = st_[k];
+      unsigned long long* o = prm.stamps + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
+      for (int k = 0; k < 16; ++k) o[k] = st_[k];
     }
 #endif
     if (prm.trace_n && inrange && p.writer()) prm.trace_n[p.chain_local()] = ntrace;

@@ -223,6 +223,21 @@ struct CoopPolicy {
     if (K == COLD_QB || K == COLD_VB) return ldscold + ((size_t)(K * W + wave) * NE) * 64 + lane;
     return coldbase + ((size_t)wave * NE) * 64 + lane;  // COLD_GB
   }
+  // one diagnostics row = 24 doubles = three 64-B lines.  Partial-line stores to 16 different rows
+  // serialise in the memory system (~17 us per row set measured), so the four replicas of a chain
+  // in wave 0 each write 16 B of the same line in ONE instruction: three full-line stores per row.
+  __device__ __forceinline__ void diag_store(double* row, const double* d) const {
+    if (wave == 0) {
+      typedef double d2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        d2_t v;
+        v[0] = lg == 0 ? d[8 * k] : lg == 1 ? d[8 * k + 2] : lg == 2 ? d[8 * k + 4] : d[8 * k + 6];
+        v[1] = lg == 0 ? d[8 * k + 1] : lg == 1 ? d[8 * k + 3] : lg == 2 ? d[8 * k + 5] : d[8 * k + 7];
+        *reinterpret_cast<d2_t*>(row + 8 * k + 2 * lg) = v;
+      }
+    }
+  }
   // proposal buffers which = 0/1: (q, grad), in memory after GB
   __device__ __forceinline__ void prop_put(int which, const Vec& q, const Vec& g) const {
     double* pq = coldbase + ((size_t)((1 + 2 * which) * W + wave) * NE) * 64 + lane;

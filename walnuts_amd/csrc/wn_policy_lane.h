@@ -68,6 +68,10 @@ struct LanePolicy {
       v.x[e] = e < D ? *vec_ptr(2 * slot + 1, e) : 0.0;
     }
   }
+  WN_HD void diag_store(double* row, const double* d) const {
+#pragma unroll
+    for (int k = 0; k < NDIAG; ++k) row[k] = d[k];
+  }
   // proposal buffers which = 0/1: (q, grad)
   WN_HD void prop_put(int which, const Vec& q, const Vec& g) const {
 #pragma unroll
