@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--kappa", type=float, default=1e4)
     ap.add_argument("--M", type=int, default=10)
     ap.add_argument("--H0", type=float, default=0.5)
+    ap.add_argument("--workload", default="gauss100", choices=["gauss100", "funnel"],
+                    help="gauss100 = BASELINE configs[1] family (headline); funnel = configs[2] "
+                         "(funnel10, adaptLeapFrogR2P, M=12, H0=0.3, delta0=0.3; SURVEY 8d cfg 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (see profiles/)")
@@ -106,6 +109,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.workload == "funnel":
+        return main_funnel(args)
     C, D = args.chains, args.dim
     offset = rank * C
     A, q0 = make_dense_problem(D, args.kappa, C, SEED, chain_offset=offset)
@@ -219,6 +224,53 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_funnel(args):
+    """SURVEY 8d cfg 3: funnel10 (D=11), adaptLeapFrogR2P, M=12, H0=0.3, delta0=0.3, warmupIter=0,
+    q0[0]~N(0,9), q0[1:]~N(0,e^{q0[0]}); metric = gradient evaluations (nevalF+nevalB) per second.
+    Roofline per SURVEY 8d: HBM, 48*D = 528 B per gradient evaluation (unfused streaming figure)."""
+    import torch
+    torch.cuda.set_device(0)
+    import walnuts_amd as wa
+    from walnuts_amd import _lib as L
+    C = args.chains
+    iters = args.iters
+    rng = np.random.default_rng([SEED, 3])
+    q0 = np.zeros((C, 11)); q0[:, 0] = 3.0 * rng.normal(size=C)
+    q0[:, 1:] = np.exp(0.5 * q0[:, :1]) * rng.normal(size=(C, 10))
+    eng = wa.Engine(11, C, integrator=L.I_ADAPT_R2P, H0=0.3, delta0=0.3, M=12, generated=L.G_FIRSTK, gen_k=2)
+    eng.set_target(L.T_FUNNEL10)
+    q0d = torch.as_tensor(q0, device="cuda")
+    for w in range(args.warmup):
+        eng.run(q0d, SEED + 1000 + w, iters)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tot = 0.0; kms = []; mx = []
+    for k in range(args.steps):
+        s, d = eng.run(q0d, SEED + k, iters)
+        per_chain = (d[:, :, 6] + d[:, :, 7]).sum(1)
+        tot += float(per_chain.sum().item())
+        mx.append(float(per_chain.max().item()))
+        kms.append(eng.last_run_ms())
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ach = tot / args.steps * 528.0 / (np.mean(kms) * 1e-3) / 1e9
+    print(json.dumps({"metric": "gradient evaluations/sec across chains, funnel10 (adaptLeapFrogR2P)",
+                      "value": tot / el, "unit": "gradient evaluations/s", "n_gpus": 1, "steps": args.steps,
+                      "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+                      "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": f"funnel10 D=11, {C} chains, adaptLeapFrogR2P, M=12, H0=0.3, delta0=0.3, "
+                                             f"{iters} iterations/launch (SURVEY 8d cfg 3)", "kernel": eng.kernel_name},
+                      "kernel_ms_avg": float(np.mean(kms)),
+                      # every lane advances one gradient evaluation per tick; a launch lasts as long as
+                      # its busiest chain, so mean/max evaluations per chain is the lane occupancy
+                      "busiest_chain_evals": float(np.mean(mx)),
+                      "lane_occupancy": tot / args.steps / C / float(np.mean(mx)),
+                      "tick_us": float(np.mean(kms)) * 1e3 / float(np.mean(mx)),
+                      "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                   "bytes_per_gradient_evaluation": 528.0}}), flush=True)
 
 
 if __name__ == "__main__":

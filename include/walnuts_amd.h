@@ -46,7 +46,11 @@ enum {
   WN_T_CORRGAUSS = 4,  /* targetDistr.py:25-31 (D = 2) */
   WN_T_SMILE = 5,      /* targetDistr.py:34-38 (D = 2) */
   WN_T_FUNNEL1 = 6,    /* targetDistr.py:88-93 (D = 2) */
-  WN_T_MODFUNNEL = 7   /* targetDistr.py:41-51 (D = 2) */
+  WN_T_MODFUNNEL = 7,  /* targetDistr.py:41-51 (D = 2) */
+  /* (lpdf, grad) pairs of test/targets.py, used with walnuts() (walnuts/walnuts.py:362);
+   * wn_ext_orbit / wn_lpfun only */
+  WN_T_TT_CORRNORMAL = 8, /* test/targets.py:9-15 (D = 2; note its grad[0] = -q0 + rho*q1) */
+  WN_T_TT_FUNNEL = 9      /* test/targets.py:23-29 (any D >= 2; no log-scale term) */
 };
 
 /* macro-step integrator plugin  integrator(q,v,g,Ham0,h,xi,lpFun,delta,auxPar)
@@ -120,6 +124,27 @@ int wn_integrator_step(wn_engine *e, const double *q_dev, const double *v_dev, c
 
 /* lpFun(q) -> (lp, grad) for a batch: q_dev [B][D] -> lp_dev [B], grad_dev [B][D]. */
 int wn_lpfun(wn_engine *e, const double *q_dev, double *lp_dev, double *grad_dev, void *stream);
+
+/* Stand-alone lpFun for any WN_T_* kind (no engine): logp(theta) / grad(theta) of the
+ * (logp, grad) callable pair that walnuts() takes (walnuts/walnuts.py:379-380). */
+int wn_lpfun_kind(int32_t device, int32_t target_kind, const double *tpar_dev, int32_t dim, int32_t B,
+                  const double *q_dev, double *lp_dev, double *grad_dev, void *stream);
+
+/* extend_orbit(...) of the pseudocode-faithful variant (walnuts/walnuts.py:211-276) for B
+ * independent chains: from (theta, rho) take n_macro macro steps; per macro step find the stable
+ * micro-step count (stable_steps, :144-182), pick ell = {ell//2, ell, 2*ell}[lottery] (the host
+ * draws `lottery` with the caller's Generator, :194), integrate (leapfrog, :74-95), find the
+ * reverse stable count and accumulate the log weight (:264-271).
+ *   theta_dev, rho_dev [B][D]; inv_mass_dev [D]; lottery_dev [B][n_macro] in {0,1,2};
+ *   weight0_dev [B] log weight of the starting state;
+ *   orbit_dev [B][n_macro][2][D] new states (theta, rho) in integration order;
+ *   logw_dev [B][n_macro]; ell_dev [B][n_macro][3] = ell_stable, ell, ell_stable_next (may be NULL).
+ * Stand-alone (no engine): tpar_dev as in wn_set_target, may be NULL for parameter-free targets. */
+int wn_ext_orbit(int32_t device, int32_t target_kind, const double *tpar_dev, int32_t dim, int32_t B,
+                 const double *theta_dev, const double *rho_dev, const double *inv_mass_dev,
+                 double macro_step, double max_error, int32_t n_macro, const int32_t *lottery_dev,
+                 const double *weight0_dev, double *orbit_dev, double *logw_dev, int32_t *ell_dev,
+                 void *stream);
 
 /* Export the engine's random stream (wn_rng.h) so the oracle / the Python reference can be
  * driven by the same randomness: u_dev [C][n_u] uniforms, z_dev [C][D] normals of iteration

@@ -82,3 +82,25 @@ def test_state_machine_many_chains_host():
                        M=7, seed=99, chain=500 + k, generated=1)
         tg.close(h["samples"][k], o["samples"], rtol=1e-12, atol=1e-13)
         np.testing.assert_array_equal(h["diagnostics"][k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]])
+
+
+def test_walnuts_argument_errors_match_reference():
+    """ValueError cases of walnuts_step (walnuts/walnuts.py:309-320) are raised before any device work."""
+    import walnuts_amd as wa
+    from walnuts_amd import targets as tt
+    rng = np.random.default_rng(0)
+    sn = (tt.standard_normal_lpdf, tt.standard_normal_grad)
+    for theta, im, ms, depth, err in [
+        (np.zeros((2, 2)), np.ones(2), 1.0, 5, 0.1),
+        (np.zeros(2), np.ones((2, 1)), 1.0, 5, 0.1),
+        (np.zeros(2), np.ones(3), 1.0, 5, 0.1),
+        (np.zeros(2), np.ones(2), 0.0, 5, 0.1),
+        (np.zeros(2), np.ones(2), 1.0, 0, 0.1),
+        (np.zeros(2), np.ones(2), 1.0, 5, -1.0),
+    ]:
+        with pytest.raises(ValueError):
+            wa.walnuts_step(rng, theta, *sn, im, ms, depth, err)
+    with pytest.raises(TypeError):
+        wa.walnuts_step(rng, np.zeros(2), lambda q: 0.0, lambda q: -q, np.ones(2), 1.0, 5, 0.1)
+    with pytest.raises(ValueError):
+        wa.walnuts_step(rng, np.zeros(2), tt.standard_normal_lpdf, tt.funnel_grad, np.ones(2), 1.0, 5, 0.1)

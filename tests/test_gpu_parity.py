@@ -278,3 +278,35 @@ def test_walnuts_api_shapes(wa):
         wa.WALNUTS(lambda q: [0.0, -q], np.zeros(3), warmupIter=0)
     with pytest.raises(NotImplementedError):
         wa.WALNUTS(td.stdGauss, np.zeros(3))  # default warmupIter=1000 needs adaptation
+
+
+WD = np.load(os.path.join(G, "walnuts_draws.npz"))
+
+
+@pytest.mark.parametrize("seed", [123, 124, 125, 126])
+def test_walnuts_config1_draws_match_reference(wa, seed):
+    """BASELINE configs[0]: 10-D standard normal, 1000 draws via walnuts() with test/test.py's
+    parameters; the caller's Generator is consumed exactly as the reference does, so the draws
+    (and the stream position afterwards) reproduce the reference run."""
+    from walnuts_amd import targets as tt
+    rng = np.random.default_rng(seed)
+    d = wa.walnuts(rng, np.zeros(10), tt.standard_normal_lpdf, tt.standard_normal_grad, np.ones(10),
+                   2.0, 10, 0.1, 0, 1000)
+    assert d.shape == (1000, 10)
+    close(d, WD[f"std10_seed{seed}"], rtol=1e-6, atol=1e-9, what="draws")
+    assert rng.uniform() == WD[f"std10_seed{seed}_next_uniform"][0]
+
+
+def test_walnuts_other_targets_match_reference(wa):
+    from walnuts_amd import targets as tt
+    rng = np.random.default_rng(7)
+    d = wa.walnuts(rng, np.array([0.5, 0.1, -0.2]), tt.funnel_lpdf, tt.funnel_grad, np.array([1.0, 2.0, 0.5]),
+                   1.5, 8, 0.2, 20, 150)
+    close(d, WD["funnel3_seed7"], what="funnel"); assert rng.uniform() == WD["funnel3_seed7_next_uniform"][0]
+    rng = np.random.default_rng(8)
+    d = wa.walnuts(rng, np.array([1.0, 0.0]), tt.correlated_normal_lpdf, tt.correlated_normal_grad, np.ones(2),
+                   1.8, 8, 0.1, 0, 200)
+    close(d, WD["corr2_seed8"], what="corr"); assert rng.uniform() == WD["corr2_seed8_next_uniform"][0]
+    rng = np.random.default_rng(9)
+    d = wa.walnuts(rng, np.array([0.3, -0.2]), tt.rosenbrock_lpdf, tt.rosenbrock_grad, np.ones(2), 1.0, 8, 0.1, 0, 200)
+    close(d, WD["rosen2_seed9"], what="rosenbrock"); assert rng.uniform() == WD["rosen2_seed9_next_uniform"][0]

@@ -5,9 +5,10 @@ targetDistr): the same call shapes, executed by hand-written gfx950 HIP kernels 
 (include/walnuts_amd.h).  There is no CPU fallback.
 """
 from . import _lib
-from . import adaptiveIntegrators, targetDistr
+from . import adaptiveIntegrators, targetDistr, targets
+from .walnuts import walnuts, walnuts_step
 from .WALNUTS import WALNUTS, Generated, identity, q0_sumsq, firstk
 from .engine import Engine, WalnutsError
 
-__all__ = ["WALNUTS", "Engine", "WalnutsError", "adaptiveIntegrators", "targetDistr", "Generated",
+__all__ = ["WALNUTS", "walnuts", "walnuts_step", "targets", "Engine", "WalnutsError", "adaptiveIntegrators", "targetDistr", "Generated",
            "identity", "q0_sumsq", "firstk"]

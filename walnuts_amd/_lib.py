@@ -34,7 +34,7 @@ class WnConfig(C.Structure):
 
 # every symbol include/walnuts_amd.h declares
 SYMBOLS = ["wn_abi_version", "wn_create", "wn_set_target", "wn_run", "wn_integrator_step",
-           "wn_lpfun", "wn_rng_tape", "wn_last_run_ms", "wn_kernel_name", "wn_last_error",
+           "wn_lpfun", "wn_lpfun_kind", "wn_ext_orbit", "wn_rng_tape", "wn_last_run_ms", "wn_kernel_name", "wn_last_error",
            "wn_destroy"]
 
 _lib = None
@@ -63,6 +63,11 @@ def lib():
     L.wn_integrator_step.argtypes = [vp] * 14
     L.wn_lpfun.restype = C.c_int
     L.wn_lpfun.argtypes = [vp, vp, vp, vp, vp]
+    L.wn_lpfun_kind.restype = C.c_int
+    L.wn_lpfun_kind.argtypes = [C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
+    L.wn_ext_orbit.restype = C.c_int
+    L.wn_ext_orbit.argtypes = [C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, vp, C.c_double,
+                               C.c_double, C.c_int32, vp, vp, vp, vp, vp, vp]
     L.wn_rng_tape.restype = C.c_int
     L.wn_rng_tape.argtypes = [vp, C.c_uint64, C.c_int32, C.c_int32, vp, vp, vp]
     L.wn_last_run_ms.restype = C.c_int
