@@ -120,14 +120,19 @@ def main():
 
     import torch
     import torch.distributed as dist
+    backend = os.environ.get("WN_DIST_BACKEND", "nccl")  # "gloo" lets two ranks share one GPU in tests
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where collectives run
 
     import walnuts_amd as wa
     from walnuts_amd import _lib as L
@@ -156,7 +161,8 @@ def main():
         last = samples
     barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    total_steps = total_steps.to(cdev).reshape(1)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(total_steps, op=dist.ReduceOp.SUM)
@@ -170,7 +176,7 @@ def main():
         from walnuts_amd.dist import gather_draws
         torch.cuda.synchronize(dev)
         g0 = time.perf_counter()
-        draws = gather_draws(last, dst=0)
+        draws = gather_draws(last.to(cdev), dst=0)
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - g0) * 1e3
 

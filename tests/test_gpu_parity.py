@@ -310,3 +310,26 @@ def test_walnuts_other_targets_match_reference(wa):
     rng = np.random.default_rng(9)
     d = wa.walnuts(rng, np.array([0.3, -0.2]), tt.rosenbrock_lpdf, tt.rosenbrock_grad, np.ones(2), 1.0, 8, 0.1, 0, 200)
     close(d, WD["rosen2_seed9"], what="rosenbrock"); assert rng.uniform() == WD["rosen2_seed9_next_uniform"][0]
+
+
+def test_bench_two_ranks_sharing_one_gpu():
+    """bench.py's N > 1 path (sharding by chain_offset, MAX-time / SUM-steps reductions, final
+    gather) with two ranks on the one GPU of this box; collectives over gloo because RCCL refuses
+    two ranks on one device.  The 8-GPU RCCL run is the driver's."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WN_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29741", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+           "--warmup", "0", "--chains", "256", "--iters", "5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["ess_per_sec"]["draws"] == 2 * 256 * 5
+    # the same 512 chains in one process give the same number of leapfrog steps (sharding invariance)
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--chains", "512",
+                         "--iters", "5", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+    o1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    assert o1["leapfrog_steps_per_launch_per_gpu"] == 2 * out["leapfrog_steps_per_launch_per_gpu"]

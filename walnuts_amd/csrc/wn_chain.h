@@ -86,6 +86,10 @@ struct Params {
 // never copied: `ip` names the buffer holding qProp, `ipl` the one holding qPropLast; the first
 // pick of a doubling moves to the other buffer, a revert (WALNUTS.py:599,616) just sets ip = ipl.
 enum { COLD_QB = 0, COLD_VB, COLD_GB, COLD_N };
+// "warm" vectors: touched once per macro step, not per micro step -- first state of the current leaf
+// pair (WALNUTS.py:438-439) and, for the adaptive integrators, the accepted forward result while the
+// backward passes run (adaptiveIntegrators.py:96-99).  The layout decides registers vs LDS.
+enum { WARM_QL = 0, WARM_VL, WARM_QO, WARM_VO, WARM_GO, WARM_N };
 
 template <class P, bool ADAPT>
 struct Engine {
@@ -120,20 +124,18 @@ struct Engine {
   enum { PH_FWD = 0, PH_FWD2 = 1, PH_BWD = 2 };
   bool needMacro, needPass, fin, needIter, needDoubling, endIter;
   int ph, c, im, nstep, If, Ib, cSim, maxTry, nEvF, nEvB, cret;
-  double h, hh, Ham0, HamPass0, lwtf, lwt, lpn, Hn, lpOut, HOut;
-  bool allfin;
+  double h, hh, Ham0, HamPass0, lwtf, lwt, lpn, Hn, lpOut, HOut, lpCur, HCur;
+  bool allfin, inPass;
   uint32_t firemask;
   int gen_iter;  // iteration whose deferred generated() row is pending
 
   // ---- D-vectors ----------------------------------------------------------------------------
   Vec qa, va, ga;  // active end of the orbit = start of the current macro step (v forward-time)
-  Vec ql, vl;      // first state of the current leaf pair (WALNUTS.py:438-439 / 525-526)
   double lpP, lpPL;
   int ip, ipl;
-  // adaptive integrators only: work state of the running micro pass, and the accepted forward
-  // result while the backward passes run
-  struct Empty {};
-  typename P::template Opt<ADAPT> qw, vw, gw, qo, vo, go;
+  // adaptive integrators only: work state of the running micro pass (the accepted forward result
+  // is parked in the layout's warm storage while the backward passes run)
+  typename P::template Opt<ADAPT> qw, vw, gw;
 
   WN_HD Engine(P& p_, const Params& prm_) : p(p_), prm(prm_) {}
 
@@ -276,7 +278,8 @@ struct Engine {
     hh = h / (double)nstep;  // adaptiveIntegrators.py:70-71
     im = 0;
     if (ph == PH_BWD) {  // :112-118 from (qOut, -vOut, gOut), Hams[0] = H0b
-      WN_VFOR(e) { qw.x[e] = qo.x[e]; vw.x[e] = -vo.x[e]; gw.x[e] = go.x[e]; }
+      p.template warm_get<WARM_QO>(qw); p.template warm_get<WARM_VO>(vw); p.template warm_get<WARM_GO>(gw);
+      WN_VFOR(e) vw.x[e] = -vw.x[e];
       HamPass0 = HOut;
     } else {  // :72-76 from (q, xi*v, g), Hams[0] = Ham0
       WN_VFOR(e) { qw.x[e] = qa.x[e]; vw.x[e] = (double)xi * va.x[e]; gw.x[e] = ga.x[e]; }
@@ -295,11 +298,11 @@ struct Engine {
   template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_, Vec&>::type GW() { return gw; }
   template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_, Vec&>::type GW() { return ga; }
   // the finalised macro-step result (q', v' in integration orientation, grad')
-  template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_, Vec&>::type QN() { return qo; }
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_, Vec&>::type QN() { return qw; }
   template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_, Vec&>::type QN() { return qa; }
-  template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_, Vec&>::type VN() { return vo; }
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_, Vec&>::type VN() { return vw; }
   template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_, Vec&>::type VN() { return va; }
-  template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_, Vec&>::type GN() { return go; }
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_, Vec&>::type GN() { return gw; }
   template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_, Vec&>::type GN() { return ga; }
 
   // ------------------------------------------------------------------------------------------
@@ -307,7 +310,7 @@ struct Engine {
   // ------------------------------------------------------------------------------------------
   template <bool B_ = ADAPT>
   WN_HD typename std::enable_if<B_>::type save_out(double lp, double Hi) {
-    WN_VFOR(e) { qo.x[e] = qw.x[e]; vo.x[e] = vw.x[e]; go.x[e] = gw.x[e]; }
+    p.template warm_put<WARM_QO>(qw); p.template warm_put<WARM_VO>(vw); p.template warm_put<WARM_GO>(gw);
     lpOut = lp;
     HOut = Hi;
   }
@@ -316,7 +319,7 @@ struct Engine {
 
   template <bool B_ = ADAPT>
   WN_HD typename std::enable_if<B_>::type zero_adapt() {
-    WN_VFOR(e) { qw.x[e] = vw.x[e] = gw.x[e] = qo.x[e] = vo.x[e] = go.x[e] = 0.0; }
+    WN_VFOR(e) { qw.x[e] = vw.x[e] = gw.x[e] = 0.0; }
   }
   template <bool B_ = ADAPT>
   WN_HD typename std::enable_if<!B_>::type zero_adapt() {}
@@ -331,8 +334,17 @@ struct Engine {
     }
   }
 
+  template <bool B_ = ADAPT>
+  WN_HD typename std::enable_if<B_>::type restore_out() {
+    // the backward passes overwrote the work state: bring the accepted forward result back
+    p.template warm_get<WARM_QO>(qw); p.template warm_get<WARM_VO>(vw); p.template warm_get<WARM_GO>(gw);
+  }
+  template <bool B_ = ADAPT>
+  WN_HD typename std::enable_if<!B_>::type restore_out() {}
+
   WN_HD void finalize_macro() {
     fin = true;
+    if (ADAPT && ph == PH_BWD) restore_out();
     lpn = ADAPT ? lpOut : lpn;
     Hn = ADAPT ? HOut : Hn;
     if (prm.integrator == I_ADAPT_D) {  // :135-137
@@ -349,19 +361,26 @@ struct Engine {
     }
   }
 
-  WN_HD void after_micro(double lp, double ke) {
-    double Hi = -lp + 0.5 * ke;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
-    if (!ADAPT) {
-      nEvF = 1;
-      lpn = lp;
-      Hn = Hi;
-      finalize_macro();
-      return;
-    }
+  // energy bookkeeping of ONE micro step (adaptiveIntegrators.py:79-84): cheap, so several micro
+  // steps of a long pass can run back to back before the heavier per-pass / per-step logic
+  WN_HD void micro_account(double lp, double ke) {
+    const double Hi = -lp + 0.5 * ke;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
+    lpCur = lp; HCur = Hi;
     if (!isfinite(Hi)) allfin = false;
     im++;
     if (ph == PH_BWD) nEvB++; else nEvF++;
-    if (im < nstep) return;
+    inPass = im < nstep;
+  }
+
+  WN_HD void after_micro(double lp, double ke) {  // fixedLeapFrog: the macro step is one micro step
+    nEvF = 1;
+    lpn = lp;
+    Hn = -lp + 0.5 * ke;
+    finalize_macro();
+  }
+
+  WN_HD void pass_end() {
+    const double lp = lpCur, Hi = HCur;
     // pass complete: all(isfinite(Hams)) and abs(Hams[0]-Hams[-1]) < delta   (:87-94)
     bool ok = allfin && (fabs(HamPass0 - Hi) < prm.delta);
     if (ph == PH_FWD) {
@@ -437,7 +456,9 @@ struct Engine {
           p.template cold_get<COLD_QB>(qo_); p.template cold_get<COLD_VB>(vo_);
           uturn_dots(qo_, vo_, d1, d2);
         } else if (j == 1) {
-          uturn_dots(ql, vl, d1, d2);
+          Vec qo_, vo_;
+          p.template warm_get<WARM_QL>(qo_); p.template warm_get<WARM_VL>(vo_);
+          uturn_dots(qo_, vo_, d1, d2);
         } else {
           Vec qo_, vo_;
           p.lslot_load(j - 2, qo_, vo_);
@@ -531,7 +552,7 @@ struct Engine {
       if (WnewSum > prm.wtSumThresh && next_u() < Wnew / WnewSum) pick_state(idx);
       orbitLen_ += h;  // :432 / 471 / 519 / 561
       if ((n & 1) == 0) {  // statePush (:431,518) -- only sub-tree left endpoints are ever read back
-        WN_VFOR(e) { ql.x[e] = QN().x[e]; vl.x[e] = VN().x[e]; }
+        p.template warm_put<WARM_QL>(QN()); p.template warm_put<WARM_VL>(VN());
         if (i >= 2 && (n & 3) == 0) {
           // left endpoint of sub-trees of 2**j leaves for every j <= i with 2**j | n.  Checks
           // 2..NFAST-1 read it back from the layout's fast cache (one copy per level, reused
@@ -655,9 +676,9 @@ struct Engine {
     minIf = minc = 1 << 30; maxIf = maxc = -(1 << 30); nneq = nzero = nused = 0;
     minlw = INFINITY; maxlw = -INFINITY;
     ph = PH_FWD; c = im = nstep = If = Ib = cSim = maxTry = nEvF = nEvB = cret = 0;
-    hh = Ham0 = HamPass0 = lwtf = lwt = 0.0;
-    allfin = true;
-    WN_VFOR(e) { va.x[e] = 0.0; ga.x[e] = 0.0; ql.x[e] = 0.0; vl.x[e] = 0.0; }
+    hh = Ham0 = HamPass0 = lwtf = lwt = lpCur = HCur = 0.0;
+    allfin = true; inPass = false;
+    WN_VFOR(e) { va.x[e] = 0.0; ga.x[e] = 0.0; }
     zero_adapt();
     live = inrange;
     needKE = needGen = needMacro = needPass = fin = needIter = needDoubling = endIter = false;
@@ -714,39 +735,47 @@ struct Engine {
       if (live && needDoubling) start_doubling();
       if (live && needMacro) setup_macro();
       if (ADAPT && live && needPass) setup_pass();
-      // ---- B: one leapfrog micro step on the work state ----
+      // ---- B: one leapfrog micro step on the work state (adaptive integrators: up to 16 of them
+      // back to back while at least half of the live chains are still inside a micro pass, so the
+      // per-step bookkeeping below is not paid once per micro step of a 2**c-step pass) ----
       Vec& Q = QW(); Vec& V = VW(); Vec& G = GW();
-      const double hh2 = live ? 0.5 * hh : 0.0, hq = live ? hh : 0.0;
-      WN_STAMP(0);
-      WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; Q.x[e] = Q.x[e] + hq * V.x[e]; }
       double part[NPB > 2 * NFAST ? NPB : 2 * NFAST];
-      p.grad(Q, G, part[0]);
-      WN_STAMP(1);
-      double ke = 0.0;
-      WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; ke += V.x[e] * V.x[e]; }
-      part[1] = ke; part[2] = keinit_part; part[3] = gen_part;
-      if (!ADAPT) {
-        // fixedLeapFrog finalises its macro step every tick, so the on-chip U-turn checks ride
-        // in the same reduction as the energies
-        fin = live;
-        fast_dots(part + 4);
-      }
-      p.template reduce<NPB>(part);
-      WN_STAMP(2);
-      // ---- C ----
-      finish_generated(part[3]);
-      if (live) {
-        if (needKE) {  // Hs[I0] = -f0 + 0.5*sum(v**2)  (:256); multinomialLscale (:259)
-          H0 = -lp0 + 0.5 * part[2];
-#ifdef WN_DEBUG_PRINT
-          if (p.chain_local() == 0) printf("[dbg] needKE iter=%d lp0=%g lpP=%g ke=%g H0=%g\n", iter, lp0, lpP, part[2], H0);
-#endif
-          Ha = Hb = H0; Ham0 = H0;
-          if (ADAPT) { HamPass0 = H0; allfin = isfinite(H0); }
-          Hnan = isnan(H0); Hmin = Hmax = H0;
-          needKE = false; keinit_part = 0.0;
+      WN_STAMP(0);
+      int kin = 0;
+      do {
+        const bool act = live && (kin == 0 || inPass);
+        const double hh2 = act ? 0.5 * hh : 0.0, hq = act ? hh : 0.0;
+        WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; Q.x[e] = Q.x[e] + hq * V.x[e]; }
+        p.grad(Q, G, part[0]);
+        WN_STAMP(1);
+        double ke = 0.0;
+        WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; ke += V.x[e] * V.x[e]; }
+        part[1] = ke; part[2] = keinit_part; part[3] = gen_part;
+        if (!ADAPT) {
+          // fixedLeapFrog finalises its macro step every tick, so the on-chip U-turn checks ride
+          // in the same reduction as the energies
+          fin = live;
+          fast_dots(part + 4);
         }
-        after_micro(p.lp_finish(part[0]), part[1]);
+        p.template reduce<NPB>(part);
+        WN_STAMP(2);
+        finish_generated(part[3]);
+        if (act) {
+          if (needKE) {  // Hs[I0] = -f0 + 0.5*sum(v**2)  (:256); multinomialLscale (:259)
+            H0 = -lp0 + 0.5 * part[2];
+            Ha = Hb = H0; Ham0 = H0;
+            if (ADAPT) { HamPass0 = H0; allfin = isfinite(H0); }
+            Hnan = isnan(H0); Hmin = Hmax = H0;
+            needKE = false; keinit_part = 0.0;
+          }
+          if (ADAPT) micro_account(p.lp_finish(part[0]), part[1]);
+        }
+        kin++;
+      } while (ADAPT && kin < 16 && p.majority(live && inPass, live));
+      // ---- C ----
+      if (live) {
+        if (!ADAPT) after_micro(p.lp_finish(part[0]), part[1]);
+        else if (!inPass) pass_end();
       }
       WN_STAMP(3);
       // ---- D: U-turn checks ----

@@ -8,8 +8,9 @@ namespace wn {
 
 template <int DMAX, class Tgt, bool ADAPT>
 __global__ __launch_bounds__(64) void wn_lane_kernel(Params prm) {
+  __shared__ double lds[LanePolicy<DMAX, Tgt>::WARM_DOUBLES];
   const int cl = blockIdx.x * 64 + threadIdx.x;
-  LanePolicy<DMAX, Tgt> p(prm, cl);
+  LanePolicy<DMAX, Tgt> p(prm, cl, lds);
   Engine<LanePolicy<DMAX, Tgt>, ADAPT> eng(p, prm);
   eng.run();
 }

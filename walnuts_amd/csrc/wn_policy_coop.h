@@ -62,6 +62,7 @@ struct CoopPolicy {
   int redpar;
   double afrag[NA];  // -A fragments: afrag[t*KS+s] = -A[16*T+(l&15)][4*s+(l>>4)]
   double adiag[NE];  // diagonal target: a[gidx(e)]
+  Vec warm[WARM_N];  // leaf-pair state / adaptive forward result: registers (unused ones vanish)
   double* ldscold;   // QB, VB in LDS: [q|v][wave][reg][lane]
   double* coldbase;  // GB and the proposal set QP/GP/QPL/GPL: in memory, [vec][wave][reg][lane]
 
@@ -113,6 +114,10 @@ struct CoopPolicy {
   __device__ __forceinline__ int chain_local() const { return cl; }
   __device__ __forceinline__ uint32_t chain_global() const { return cg; }
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
+  __device__ __forceinline__ bool majority(bool a, bool of) const {
+    const int na = __popcll(__ballot(a)), no = __popcll(__ballot(of));
+    return na > 0 && 2 * na >= no;
+  }
 
   // x[l] + x[l^16] + x[l^32] + x[l^48] in every lane, on the VALU (no LDS round trip):
   // v_permlane16_swap exchanges odd rows of one operand with even rows of the other,
@@ -218,6 +223,10 @@ struct CoopPolicy {
 #pragma unroll
     for (int e = 0; e < NE; ++e) { q.x[e] = pq[e * 64]; v.x[e] = pv[e * 64]; }
   }
+  template <int K>
+  __device__ __forceinline__ void warm_put(const Vec& x) { warm[K] = x; }
+  template <int K>
+  __device__ __forceinline__ void warm_get(Vec& x) const { x = warm[K]; }
   template <int K>
   __device__ __forceinline__ double* cold_ptr() const {
     if (K == COLD_QB || K == COLD_VB) return ldscold + ((size_t)(K * W + wave) * NE) * 64 + lane;

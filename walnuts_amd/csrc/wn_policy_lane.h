@@ -20,6 +20,13 @@ struct LanePolicy {
   template <bool B>
   using Opt = typename std::conditional<B, Vec, EmptyVec>::type;
 
+  // warm vectors: LDS on the device ([vector][element][lane], conflict-free), an array on the host
+  static constexpr int WARM_DOUBLES = WARM_N * DMAX * 64;
+#if defined(__HIP_DEVICE_COMPILE__)
+  double* wbase;  // lds + lane
+#else
+  double wstore[WARM_N * DMAX];
+#endif
   int D, cl;
   uint32_t cg;
   size_t cstride;  // padded chain count
@@ -33,8 +40,12 @@ struct LanePolicy {
     return ((size_t)(M + 1) * 2 + COLD_N + 4) * DMAX * cpad;
   }
 
-  WN_HD LanePolicy(const Params& prm, int chain_local)
-      : D(prm.D), cl(chain_local), cg(prm.chain0 + (uint32_t)chain_local),
+  WN_HD LanePolicy(const Params& prm, int chain_local, double* lds = nullptr)
+      :
+#if defined(__HIP_DEVICE_COMPILE__)
+        wbase(lds + (threadIdx.x & 63)),
+#endif
+        D(prm.D), cl(chain_local), cg(prm.chain0 + (uint32_t)chain_local),
         cstride(((size_t)prm.C + 63) / 64 * 64), work(prm.work), tpar(prm.tpar), nslot(prm.M + 1) {}
 
   WN_HD bool valid(int e) const { return e < D; }
@@ -48,6 +59,15 @@ struct LanePolicy {
     return __any(b);
 #else
     return b;
+#endif
+  }
+  // at least half of the lanes in `of` satisfy `a` (and at least one does)
+  WN_HD bool majority(bool a, bool of) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int na = __popcll(__ballot(a)), no = __popcll(__ballot(of));
+    return na > 0 && 2 * na >= no;
+#else
+    return a && of;
 #endif
   }
   template <int N>
@@ -86,6 +106,28 @@ struct LanePolicy {
     for (int e = 0; e < DMAX; ++e) {
       q.x[e] = e < D ? *vec_ptr(2 * nslot + COLD_N + 2 * which, e) : 0.0;
       g.x[e] = e < D ? *vec_ptr(2 * nslot + COLD_N + 2 * which + 1, e) : 0.0;
+    }
+  }
+  template <int K>
+  WN_HD void warm_put(const Vec& x) {
+#pragma unroll
+    for (int e = 0; e < DMAX; ++e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      wbase[(K * DMAX + e) * 64] = x.x[e];
+#else
+      wstore[K * DMAX + e] = x.x[e];
+#endif
+    }
+  }
+  template <int K>
+  WN_HD void warm_get(Vec& x) const {
+#pragma unroll
+    for (int e = 0; e < DMAX; ++e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      x.x[e] = wbase[(K * DMAX + e) * 64];
+#else
+      x.x[e] = wstore[K * DMAX + e];
+#endif
     }
   }
   WN_HD void lslot_store(int, const Vec&, const Vec&) const {}
