@@ -181,6 +181,15 @@ def main():
         gather_ms = (time.perf_counter() - g0) * 1e3
 
     if rank == 0:
+        traffic = args.traffic_bytes
+        if traffic is None:  # PMC traffic of this exact workload, measured in a separate rocprofv3 pass
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+                w = tj["workload"]
+                if (w["dim"], w["chains"], w["iters"]) == (D, C, args.iters) and w["kernel"] == eng.kernel_name:
+                    traffic = tj["bytes_per_launch"]
+            except Exception:
+                traffic = None
         flop_per_step = 2.0 * D * D + 12.0 * D  # matvec + leapfrog updates + 2 dots
         avg_ms = float(np.mean(kernel_ms))
         steps_per_launch_rank0 = steps_all / world / args.steps
@@ -208,7 +217,7 @@ def main():
             "gather_ms": gather_ms,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": args.traffic_bytes,
+                         "traffic": traffic,
                          "flop_per_leapfrog_step": flop_per_step},
         }
         # ESS/sec of gen(q) = [q[0], sum(q*q)] (mainGaussESS.py:29-30) over all chains of the last

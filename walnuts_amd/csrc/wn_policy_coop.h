@@ -193,20 +193,26 @@ struct CoopPolicy {
   }
   __device__ __forceinline__ double lp_finish(double r) const { return 0.5 * r; }
 
-  __device__ __forceinline__ double* slot_ptr(int slot, int which) const {
-    return slotbase + ((size_t)((slot * 2 + which) * W + wave) * NE) * 64 + lane;
+  // Memory-resident vectors are laid out [vector][chain][wave][reg][lane>>4]: the four replicas of a
+  // chain write 32 contiguous bytes per register and 256 contiguous bytes (four whole lines) per
+  // wave, so a store by ONE chain (a multinomial pick, an endpoint push) dirties whole lines only;
+  // with [reg][lane] order the same store scattered 8-byte pieces over 32 lines (measured 672 B of
+  // HBM writes per leapfrog step, profiles/r01).
+  static constexpr int VEC_DOUBLES = 16 * W * NE * 4;  // one vector of the 16-chain group
+  __device__ __forceinline__ double* gvec_ptr(double* base, int vec) const {
+    return base + (size_t)vec * VEC_DOUBLES + ((size_t)(cn * W + wave) * NE) * 4 + lg;
   }
   __device__ __forceinline__ void slot_store(int slot, const Vec& q, const Vec& v) const {
-    double* pq = slot_ptr(slot, 0);
-    double* pv = slot_ptr(slot, 1);
+    double* pq = gvec_ptr(slotbase, slot * 2);
+    double* pv = gvec_ptr(slotbase, slot * 2 + 1);
 #pragma unroll
-    for (int e = 0; e < NE; ++e) { pq[e * 64] = q.x[e]; pv[e * 64] = v.x[e]; }
+    for (int e = 0; e < NE; ++e) { pq[e * 4] = q.x[e]; pv[e * 4] = v.x[e]; }
   }
   __device__ __forceinline__ void slot_load(int slot, Vec& q, Vec& v) const {
-    const double* pq = slot_ptr(slot, 0);
-    const double* pv = slot_ptr(slot, 1);
+    const double* pq = gvec_ptr(slotbase, slot * 2);
+    const double* pv = gvec_ptr(slotbase, slot * 2 + 1);
 #pragma unroll
-    for (int e = 0; e < NE; ++e) { q.x[e] = pq[e * 64]; v.x[e] = pv[e * 64]; }
+    for (int e = 0; e < NE; ++e) { q.x[e] = pq[e * 4]; v.x[e] = pv[e * 4]; }
   }
   __device__ __forceinline__ double* lslot_ptr(int lev, int which) const {
     return ldsc + ((size_t)((lev * 2 + which) * W + wave) * NE) * 64 + lane;
@@ -229,8 +235,7 @@ struct CoopPolicy {
   __device__ __forceinline__ void warm_get(Vec& x) const { x = warm[K]; }
   template <int K>
   __device__ __forceinline__ double* cold_ptr() const {
-    if (K == COLD_QB || K == COLD_VB) return ldscold + ((size_t)(K * W + wave) * NE) * 64 + lane;
-    return coldbase + ((size_t)wave * NE) * 64 + lane;  // COLD_GB
+    return ldscold + ((size_t)(K * W + wave) * NE) * 64 + lane;  // COLD_QB / COLD_VB
   }
   // one diagnostics row = 24 doubles = three 64-B lines.  Partial-line stores to 16 different rows
   // serialise in the memory system (~17 us per row set measured), so the four replicas of a chain
@@ -249,28 +254,40 @@ struct CoopPolicy {
   }
   // proposal buffers which = 0/1: (q, grad), in memory after GB
   __device__ __forceinline__ void prop_put(int which, const Vec& q, const Vec& g) const {
-    double* pq = coldbase + ((size_t)((1 + 2 * which) * W + wave) * NE) * 64 + lane;
-    double* pg = pq + (size_t)W * NE * 64;
+    double* pq = gvec_ptr(coldbase, 1 + 2 * which);
+    double* pg = gvec_ptr(coldbase, 2 + 2 * which);
 #pragma unroll
-    for (int e = 0; e < NE; ++e) { pq[e * 64] = q.x[e]; pg[e * 64] = g.x[e]; }
+    for (int e = 0; e < NE; ++e) { pq[e * 4] = q.x[e]; pg[e * 4] = g.x[e]; }
   }
   __device__ __forceinline__ void prop_get(int which, Vec& q, Vec& g) const {
-    const double* pq = coldbase + ((size_t)((1 + 2 * which) * W + wave) * NE) * 64 + lane;
-    const double* pg = pq + (size_t)W * NE * 64;
+    const double* pq = gvec_ptr(coldbase, 1 + 2 * which);
+    const double* pg = gvec_ptr(coldbase, 2 + 2 * which);
 #pragma unroll
-    for (int e = 0; e < NE; ++e) { q.x[e] = pq[e * 64]; g.x[e] = pg[e * 64]; }
+    for (int e = 0; e < NE; ++e) { q.x[e] = pq[e * 4]; g.x[e] = pg[e * 4]; }
   }
   template <int K>
   __device__ __forceinline__ void cold_put(const Vec& x) {
-    double* pc = cold_ptr<K>();
+    if (K == COLD_GB) {
+      double* pc = gvec_ptr(coldbase, 0);
 #pragma unroll
-    for (int e = 0; e < NE; ++e) pc[e * 64] = x.x[e];
+      for (int e = 0; e < NE; ++e) pc[e * 4] = x.x[e];
+    } else {
+      double* pc = cold_ptr<K>();
+#pragma unroll
+      for (int e = 0; e < NE; ++e) pc[e * 64] = x.x[e];
+    }
   }
   template <int K>
   __device__ __forceinline__ void cold_get(Vec& x) const {
-    const double* pc = cold_ptr<K>();
+    if (K == COLD_GB) {
+      const double* pc = gvec_ptr(coldbase, 0);
 #pragma unroll
-    for (int e = 0; e < NE; ++e) x.x[e] = pc[e * 64];
+      for (int e = 0; e < NE; ++e) x.x[e] = pc[e * 4];
+    } else {
+      const double* pc = cold_ptr<K>();
+#pragma unroll
+      for (int e = 0; e < NE; ++e) x.x[e] = pc[e * 64];
+    }
   }
 };
 
