@@ -460,6 +460,111 @@ static void ss_reset(state_store *s) { /* :79-80 */
 }
 
 /* ------------------------------------------------------------------------------------------
+ * P2quantile      WALNUTSpy/P2quantile.py:16-86   (Jain & Chlamtac 1985)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  long npush;
+  double p;
+  double x[5]; /* first five values (:43-44) */
+  double q[5]; /* zeros until the 5th push, then the sorted x (self.q = self.x aliases, :47-48) */
+  long n[5];
+  double npp[5];
+} p2q;
+
+static void p2_init(p2q *s, double prob) { /* :17-27 */
+  s->npush = 0;
+  s->p = prob;
+  for (int i = 0; i < 5; ++i) { s->x[i] = 0.0; s->q[i] = 0.0; s->n[i] = i + 1; }
+  s->npp[0] = 1.0; s->npp[1] = 1.0 + 2.0 * prob; s->npp[2] = 1.0 + 4.0 * prob;
+  s->npp[3] = 3.0 + 2.0 * prob; s->npp[4] = 5.0;
+}
+static double p2_quantile(const p2q *s) { return s->q[2]; } /* :28-29 */
+
+static double dsign(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : (x == 0 ? 0.0 : NAN)); }
+
+static void p2_push(p2q *s, double xi) { /* pushCore :41-86 */
+  s->npush += 1;
+  if (s->npush <= 5) s->x[s->npush - 1] = xi;
+  if (s->npush == 5) { /* :46-48 np.sort, q = x */
+    for (int a = 0; a < 5; ++a) s->q[a] = s->x[a];
+    for (int a = 1; a < 5; ++a) {
+      double v = s->q[a];
+      int b = a - 1;
+      /* np.sort puts NaN last */
+      while (b >= 0 && (s->q[b] > v || (isnan(s->q[b]) && !isnan(v)))) { s->q[b + 1] = s->q[b]; --b; }
+      s->q[b + 1] = v;
+    }
+  } else if (s->npush > 5) {
+    int k; /* findInterval :31-38; returns None when no branch matches (xi == q[4] or NaN) */
+    if (xi < s->q[0]) k = 0;
+    else if (xi > s->q[4]) k = 5;
+    else {
+      k = -1;
+      for (int i = 0; i < 4; ++i)
+        if (xi < s->q[i + 1]) { k = i + 1; break; }
+    }
+    if (k == 0) { s->q[0] = xi; k = 1; }
+    else if (k == 5) { s->q[4] = xi; k = 4; }
+    /* self.n[k:5] += 1 ; k None -> n[None:5] = every marker (:61) */
+    for (int i = (k < 0 ? 0 : k); i < 5; ++i) s->n[i] += 1;
+    double nn = (double)s->npush, pp = s->p;
+    s->npp[0] = 1.0;
+    s->npp[1] = 0.5 * (nn - 1) * pp + 1.0;
+    s->npp[2] = (nn - 1) * pp + 1.0;
+    s->npp[3] = (nn - 1) * (1 + pp) / 2.0 + 1;
+    s->npp[4] = nn;
+    for (int i = 2; i < 5; ++i) { /* :71-86 */
+      long ni = s->n[i - 1], nip = s->n[i], nim = s->n[i - 2];
+      double di = s->npp[i - 1] - (double)ni;
+      if ((di >= 1.0 && nip - ni > 1) || (di <= -1.0 && nim - ni < -1)) {
+        long d = (long)dsign(di);
+        double qi = s->q[i - 1];
+        double qip = qi + ((double)d / (double)(nip - nim)) *
+                              ((double)(ni - nim + d) * (s->q[i] - qi) / (double)(nip - ni) +
+                               (double)(nip - ni - d) * (qi - s->q[i - 2]) / (double)(ni - nim));
+        if (s->q[i - 2] < qip && qip < s->q[i]) s->q[i - 1] = qip;
+        else s->q[i - 1] = qi + (double)d * (s->q[i + d - 1] - qi) / (double)(s->n[i + d - 1] - s->n[i - 1]);
+        s->n[i - 1] += d;
+      }
+    }
+  }
+}
+
+void wno_p2quantile(double prob, int n, const double *xs, double *q_after) {
+  p2q s;
+  p2_init(&s, prob);
+  for (int i = 0; i < n; ++i) { p2_push(&s, xs[i]); q_after[i] = p2_quantile(&s); }
+}
+
+/* np.quantile(a[0:n], q), method='linear': virtual index (n-1)*q, neighbours floor/floor+1,
+ * _lerp(a, b, t) = a + (b-a)*t, replaced by b - (b-a)*(1-t) where t >= 0.5; NaN if any NaN. */
+static int cmp_double(const void *x, const void *y) {
+  double a = *(const double *)x, b = *(const double *)y;
+  if (isnan(a)) return isnan(b) ? 0 : 1;
+  if (isnan(b)) return -1;
+  return a < b ? -1 : (a > b ? 1 : 0);
+}
+double wno_np_quantile(const double *a, int n, double q) {
+  double *t = (double *)malloc(sizeof(double) * (size_t)n);
+  memcpy(t, a, sizeof(double) * (size_t)n);
+  qsort(t, (size_t)n, sizeof(double), cmp_double);
+  double res;
+  if (isnan(t[n - 1])) {
+    res = NAN;
+  } else {
+    double vi = (double)(n - 1) * q;
+    long prev = (long)floor(vi), next = prev + 1;
+    double gamma = vi - (double)prev;
+    if (vi >= (double)(n - 1)) { prev = n - 1; next = n - 1; gamma = vi - (-1.0); }
+    if (vi < 0) { prev = 0; next = 0; gamma = vi - 0.0; }
+    double A = t[prev], B = t[next], d = B - A;
+    res = (gamma >= 0.5) ? (B - d * (1 - gamma)) : (A + d * gamma);
+  }
+  free(t);
+  return res;
+}
+
+/* ------------------------------------------------------------------------------------------
  * random stream as the sampler sees it (Q1: one global stream, data-dependent order)
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
@@ -543,6 +648,8 @@ typedef struct {
   double *work;
   int ntrace;
   int iterN, idoubl;
+  void *igrQ; /* p2q* */
+  int warm;
 } sampler_ctx;
 
 static void call_integrator(sampler_ctx *S, const double *q, const double *v, const double *g,
@@ -551,6 +658,9 @@ static void call_integrator(sampler_ctx *S, const double *q, const double *v, co
   const wno_config *c = S->cfg;
   integrator_impl(c->integrator, &S->t, q, v, g, Ham0, h, xi, delta, c->minC, c->maxC,
                   c->R2Pprob0, next_unif, &S->rng, q1, v1, g1, r, S->work);
+  /* if(warmup and adaptH): igrConstQ.push(np.log(intOut.igrConst))  WALNUTS.py:313,347,411,454,498,541
+     (right after Hs/Ifs/... are recorded and before the non-finite check; nothing in between reads it) */
+  if (S->warm) p2_push((p2q *)S->igrQ, log(r->igrConst));
   if (c->trace && S->ntrace < c->trace_cap) {
     int d = c->d;
     double *row = c->trace + (size_t)S->ntrace * (WNO_TRACE_NSCAL + 2 * d);
@@ -566,7 +676,13 @@ static void call_integrator(sampler_ctx *S, const double *q, const double *v, co
 int wno_walnuts(const wno_config *cfg, const double *q0, double *samples, double *diag,
                 int *n_u_used) {
   const int d = cfg->d, M = cfg->M, numIter = cfg->numIter;
-  if (cfg->warmupIter != 0) return -10; /* adaptation (WALNUTS.py:701-712) not restated yet */
+  if (cfg->warmupIter < 0) return -10;
+  /* :139-147 (the reference sys.exit()s on bad targets) */
+  if (cfg->adaptH && (cfg->adaptHtarget < 0.0 || cfg->adaptHtarget > 1.0)) return -13;
+  if (cfg->adaptDelta && cfg->adaptDeltaTarget < 0.0) return -14;
+  p2q igrConstQ;
+  p2_init(&igrConstQ, 1.0 - cfg->adaptHtarget); /* :141 */
+  double *energyErrorInfFacs = (double *)calloc((size_t)(cfg->warmupIter > 0 ? cfg->warmupIter : 1), sizeof(double)); /* :147 */
   if (M < 1 || M > 24 || d < 1) return -11;
   const int dg = wno_gen_dim(cfg);
   if (dg < 1) return -12;
@@ -610,6 +726,8 @@ int wno_walnuts(const wno_config *cfg, const double *q0, double *samples, double
   S.rng.cfg = cfg; S.rng.iter = 0; S.rng.k = 0; S.rng.overflow = 0;
   S.work = (double *)calloc((size_t)8 * d, sizeof(double));
   S.ntrace = 0;
+  S.igrQ = &igrConstQ;
+  S.warm = 0;
 
   memcpy(qc, q0, sizeof(double) * d); /* :177 */
   generated(cfg, q0, samples);        /* :164 samples[:,0] = generated(q0) */
@@ -618,6 +736,8 @@ int wno_walnuts(const wno_config *cfg, const double *q0, double *samples, double
     S.rng.iter = (uint32_t)iterN;
     S.rng.k = 0;
     S.iterN = iterN;
+    const int warmup = iterN <= cfg->warmupIter; /* :209 */
+    S.warm = warmup && cfg->adaptH;          /* igrConstQ.push(...) at every integrator call :313 */
     int nevalF = 0, nevalB = 0, Lold_ = 0, L_ = 0;
     double orbitLen_ = 0.0, orbitLenSam_ = 0.0;
     int NdoublSampled_ = 0, NdoublComputed_ = 0;
@@ -898,6 +1018,14 @@ int wno_walnuts(const wno_config *cfg, const double *q0, double *samples, double
 
     generated(cfg, qc, samples + (size_t)iterN * dg); /* :695 */
     if (n_u_used) n_u_used[iterN - 1] = (int)S.rng.k;
+
+    if (warmup) { /* :701-712 */
+      if (cfg->adaptDelta) energyErrorInfFacs[iterN - 1] = orbitEnergyError / delta;
+      if (cfg->adaptDelta && iterN > 10)
+        delta = cfg->adaptDeltaTarget / wno_np_quantile(energyErrorInfFacs, iterN, cfg->adaptDeltaQuantile);
+      if (cfg->adaptH && igrConstQ.npush > 10)
+        H = pow(delta, 1.0 / 3.0) * exp(p2_quantile(&igrConstQ));
+    }
   }
   if (S.rng.overflow) rc = -30;
 
@@ -908,5 +1036,6 @@ done:
   free(Hs); free(Ifs); free(Ibs); free(cs); free(lwts);
   free(buf);
   free(S.work);
+  free(energyErrorInfFacs);
   return rc < 0 ? rc : S.ntrace;
 }

@@ -69,12 +69,18 @@ typedef struct {
   double stepSizeRandScale; /* WALNUTS.py:116 */
   double delta0;            /* WALNUTS.py:117 */
   int numIter;              /* WALNUTS.py:119 */
-  int warmupIter;           /* WALNUTS.py:120 (must be 0: adaptation is SURVEY 8f, not restated yet) */
+  int warmupIter;           /* WALNUTS.py:120 */
   int M;                    /* WALNUTS.py:121 */
   int minC, maxC;           /* adaptiveIntegrators.py:37 */
   double R2Pprob0;          /* adaptiveIntegrators.py:37 */
   int generated;
   int gen_k;
+  /* warm-up adaptation, WALNUTS.py:123-127, 139-147, 313, 701-712 (+ P2quantile.py) */
+  int adaptH;
+  double adaptHtarget;
+  int adaptDelta;
+  double adaptDeltaTarget;
+  double adaptDeltaQuantile;
   /* rng */
   int rng_mode;
   uint64_t seed;
@@ -113,6 +119,13 @@ int wno_integrator(int integrator, int target, int d, const double *tpar, const 
  * NULL): [numIter] number of uniforms consumed per iteration. */
 int wno_walnuts(const wno_config *cfg, const double *q0, double *samples, double *diag,
                 int *n_u_used);
+
+/* P2quantile (WALNUTSpy/P2quantile.py:16-86): push xs[0..n-1], return quantile() after each push */
+void wno_p2quantile(double prob, int n, const double *xs, double *q_after);
+
+/* np.quantile(a[0:n], q), method "linear" (numpy/lib/_function_base_impl.py), used by
+ * WALNUTS.py:706 */
+double wno_np_quantile(const double *a, int n, double q);
 
 /* engine RNG, restated independently of walnuts_amd/csrc/wn_rng.h (DESIGN.md "RNG"). */
 void wno_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

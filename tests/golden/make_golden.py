@@ -165,10 +165,10 @@ def main():
     cases = []
 
     def add(name, target_kind, lpFun, q0, integ, tpar=None, generated=ol.G_IDENTITY, gen_k=0,
-            genfn=None, minC=0, maxC=10, **kw):
+            genfn=None, minC=0, maxC=10, warm=None, **kw):
         cases.append(dict(name=name, target=target_kind, lpFun=lpFun, q0=np.asarray(q0, float),
                           integ=integ, tpar=tpar, generated=generated, gen_k=gen_k, genfn=genfn,
-                          minC=minC, maxC=maxC, kw=kw))
+                          minC=minC, maxC=maxC, warm=warm or {}, kw=kw))
 
     for ig in ("fixed", "D", "R2P"):
         add(f"std3_{ig}", ol.T_STDGAUSS, td.stdGauss, rng.normal(size=3), ig,
@@ -204,6 +204,20 @@ def main():
         H0=0.1, numIter=20, M=3)
     add("std3_R2P_M2", ol.T_STDGAUSS, td.stdGauss, rng.normal(size=3), "R2P",
         H0=0.2, delta0=0.3, numIter=20, M=2)
+    # warm-up adaptation of H and delta (WALNUTS.py:701-712 + P2quantile.py), SURVEY.md 8f rank 1
+    add("corr_R2P_warm", ol.T_CORRGAUSS, td.corrGauss, np.array([1.0, 0.0]), "R2P",
+        H0=0.2, delta0=0.05, numIter=70, M=7, warm=dict(warmupIter=45))
+    add("funnel_R2P_warm", ol.T_FUNNEL10, td.funnel10,
+        np.r_[0.7, np.exp(0.35) * rng.normal(size=10)], "R2P", H0=0.3, delta0=0.3, numIter=50, M=8,
+        warm=dict(warmupIter=35, adaptDeltaTarget=0.6))
+    add("std3_fixed_warm", ol.T_STDGAUSS, td.stdGauss, rng.normal(size=3), "fixed",
+        H0=0.3, delta0=0.05, numIter=45, M=7, warm=dict(warmupIter=30, adaptHtarget=0.7))
+    A8w, S8w = dense_precision(8, 100.0, 3)
+    add("dense8_D_warm", ol.T_DENSEGAUSS, make_dense(A8w), S8w @ rng.normal(size=8), "D",
+        tpar=A8w.ravel(), H0=0.4, delta0=0.1, numIter=40, M=7,
+        warm=dict(warmupIter=25, adaptDelta=False))
+    add("std4_D_warm_noH", ol.T_STDGAUSS, td.stdGauss, rng.normal(size=4), "D",
+        H0=0.8, delta0=0.2, numIter=40, M=6, warm=dict(warmupIter=30, adaptH=False, adaptDeltaQuantile=0.8))
     add("corr_R2P", ol.T_CORRGAUSS, td.corrGauss, np.array([1.0, 0.0]), "R2P",
         H0=0.7, delta0=0.1, numIter=25, M=7)
     add("smile_D", ol.T_SMILE, td.smileDistr, np.array([0.3, -0.2]), "D",
@@ -218,8 +232,14 @@ def main():
         aux = ai.integratorAuxPar(minC=c["minC"], maxC=c["maxC"])
         kw = dict(c["kw"])
         kw.setdefault("delta0", 0.05)
+        wk = dict(warmupIter=0, adaptH=True, adaptHtarget=0.8, adaptDelta=True, adaptDeltaTarget=0.6,
+                  adaptDeltaQuantile=0.9)  # WALNUTS.py:120-127 defaults (warm-up off unless asked)
+        wk.update(c["warm"])
         res = run_reference(c["lpFun"], c["q0"], fn, chain=chain, generated=c["genfn"],
-                            warmupIter=0, igrAux=aux, **kw)
+                            igrAux=aux, **wk, **kw)
+        out[c["name"] + "__warm"] = np.array([wk["warmupIter"], float(wk["adaptH"]), wk["adaptHtarget"],
+                                              float(wk["adaptDelta"]), wk["adaptDeltaTarget"],
+                                              wk["adaptDeltaQuantile"]])
         pre = c["name"] + "__"
         out[pre + "cfg"] = np.array([c["target"], kind, kw["M"], kw["numIter"], c["minC"],
                                      c["maxC"], c["generated"], c["gen_k"], chain], dtype=np.int64)
@@ -311,6 +331,23 @@ def main():
     for i, (a, r) in enumerate(sc):
         g1[f"stop__{i}__args"] = np.array(a)
         g1[f"stop__{i}__res"] = np.array([int(r)])
+    # G5: P2quantile push/quantile sequences and np.quantile values (for 8f rank 1)
+    import P2quantile as P2
+    for k, prob in enumerate((0.2, 0.5, 0.9)):
+        xs = krng.normal(size=300) * np.exp(krng.normal(size=300))
+        f = P2.P2quantile(prob)
+        qs = []
+        for x in xs:
+            f.push(x); qs.append(f.quantile())
+        g1[f"p2__{k}__prob"] = np.array([prob]); g1[f"p2__{k}__x"] = xs; g1[f"p2__{k}__q"] = np.array(qs)
+    qv = []
+    for n in (1, 2, 3, 11, 12, 50, 333):
+        for q in (0.9, 0.8, 0.5):
+            a = krng.normal(size=n) ** 2
+            qv.append((a, q, float(np.quantile(a, q))))
+    g1["quant__n"] = np.array([len(qv)])
+    for i, (a, q, r) in enumerate(qv):
+        g1[f"quant__{i}__a"] = a; g1[f"quant__{i}__qr"] = np.array([q, r])
     np.savez_compressed(os.path.join(HERE, "integrator_kats.npz"), **g1)
     print("wrote", len(cases), "trace cases,", len(kats), "integrator KATs")
 

@@ -30,6 +30,8 @@ class WnoConfig(C.Structure):
         ("numIter", C.c_int), ("warmupIter", C.c_int), ("M", C.c_int),
         ("minC", C.c_int), ("maxC", C.c_int), ("R2Pprob0", C.c_double),
         ("generated", C.c_int), ("gen_k", C.c_int),
+        ("adaptH", C.c_int), ("adaptHtarget", C.c_double), ("adaptDelta", C.c_int),
+        ("adaptDeltaTarget", C.c_double), ("adaptDeltaQuantile", C.c_double),
         ("rng_mode", C.c_int), ("seed", C.c_uint64), ("chain", C.c_uint32),
         ("tape_u", c_double_p), ("tape_u_stride", C.c_int), ("tape_z", c_double_p),
         ("trace", c_double_p), ("trace_cap", C.c_int),
@@ -76,6 +78,10 @@ def lib():
         L.wno_rng_tape.restype = None
         L.wno_rng_tape.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, c_double_p,
                                    C.c_int, c_double_p]
+        L.wno_p2quantile.restype = None
+        L.wno_p2quantile.argtypes = [C.c_double, C.c_int, c_double_p, c_double_p]
+        L.wno_np_quantile.restype = C.c_double
+        L.wno_np_quantile.argtypes = [c_double_p, C.c_int, C.c_double]
         L.wno_version.restype = C.c_char_p
         _lib = L
     return _lib
@@ -139,10 +145,22 @@ def integrator(kind, target, q, v, g, Ham0, h, xi, delta, tpar=None, minC=0, max
                 Ib=int(io[3]), c=int(io[4]), lp=do[0], lwt=do[1], igrConst=do[2])
 
 
+def p2quantile(prob, xs):
+    xs = _f64(xs); out = np.empty_like(xs)
+    lib().wno_p2quantile(prob, xs.size, _dp(xs), _dp(out))
+    return out
+
+
+def np_quantile(a, q):
+    a = _f64(a)
+    return lib().wno_np_quantile(_dp(a), a.size, q)
+
+
 def walnuts(target, q0, integrator=I_FIXED, tpar=None, H0=0.2, stepSizeRandScale=0.2, delta0=0.05,
             numIter=10, warmupIter=0, M=10, minC=0, maxC=10, R2Pprob0=2.0 / 3.0,
             generated=G_IDENTITY, gen_k=0, seed=0, chain=0, tape_u=None, tape_z=None,
-            trace_cap=0):
+            trace_cap=0, adaptH=True, adaptHtarget=0.8, adaptDelta=True, adaptDeltaTarget=0.6,
+            adaptDeltaQuantile=0.9):
     """One chain of the oracle's WALNUTS.  Returns dict(samples (dg,numIter+1), diagnostics
     (numIter,24), trace (ncalls, 12+2d), n_u (numIter,))."""
     q0 = _f64(q0); d = q0.size
@@ -155,6 +173,8 @@ def walnuts(target, q0, integrator=I_FIXED, tpar=None, H0=0.2, stepSizeRandScale
     cfg.numIter = numIter; cfg.warmupIter = warmupIter; cfg.M = M
     cfg.minC = minC; cfg.maxC = maxC; cfg.R2Pprob0 = R2Pprob0
     cfg.generated = generated; cfg.gen_k = gen_k
+    cfg.adaptH = int(adaptH); cfg.adaptHtarget = adaptHtarget; cfg.adaptDelta = int(adaptDelta)
+    cfg.adaptDeltaTarget = adaptDeltaTarget; cfg.adaptDeltaQuantile = adaptDeltaQuantile
     cfg.seed = seed; cfg.chain = chain
     if tape_u is not None:
         tu = _f64(tape_u); tz = _f64(tape_z)
