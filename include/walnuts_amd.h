@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 1
+#define WN_ABI_VERSION 2
 #define WN_NDIAG 24      /* diagnostics columns, WALNUTSpy/WALNUTS.py:670-693 */
 #define WN_TRACE_NSCAL 12 /* trace row = 12 scalars + q[D] + v[D] */
 
@@ -86,8 +86,13 @@ typedef struct wn_config {
   double r2p_prob0;    /* integratorAuxPar.R2Pprob0 */
   int32_t generated;   /* WN_G_* */
   int32_t gen_k;
-  int32_t warmup_iter; /* WALNUTS.py:120; must be 0 (adaptation is SURVEY.md 8f) */
+  int32_t warmup_iter; /* WALNUTS.py:120: iterations 1..warmup_iter adapt H and delta (:701-712) */
   int32_t waves_per_group; /* cooperative (MFMA) layout: waves sharing one 16-chain group; 0 = auto */
+  int32_t adapt_h;         /* WALNUTS.py:123 adaptH */
+  int32_t adapt_delta;     /* WALNUTS.py:125 adaptDelta */
+  double adapt_h_target;       /* WALNUTS.py:124 adaptHtarget: P2 quantile 1-target of log igrConst */
+  double adapt_delta_target;   /* WALNUTS.py:126 */
+  double adapt_delta_quantile; /* WALNUTS.py:127 */
 } wn_config;
 
 typedef struct wn_engine wn_engine;

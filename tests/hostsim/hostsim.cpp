@@ -18,12 +18,13 @@ template <int DMAX, class Tgt>
 static void run_all(const Params& prm) {
   for (int c = 0; c < prm.C; ++c) {
     LanePolicy<DMAX, Tgt> p(prm, c);
+    const bool warm = prm.warmupIter > 0;
     if (prm.integrator == I_FIXED) {
-      Engine<LanePolicy<DMAX, Tgt>, false> e(p, prm);
-      e.run();
+      if (warm) { Engine<LanePolicy<DMAX, Tgt>, false, true> e(p, prm); e.run(); }
+      else { Engine<LanePolicy<DMAX, Tgt>, false, false> e(p, prm); e.run(); }
     } else {
-      Engine<LanePolicy<DMAX, Tgt>, true> e(p, prm);
-      e.run();
+      if (warm) { Engine<LanePolicy<DMAX, Tgt>, true, true> e(p, prm); e.run(); }
+      else { Engine<LanePolicy<DMAX, Tgt>, true, false> e(p, prm); e.run(); }
     }
   }
 }

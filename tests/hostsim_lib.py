@@ -30,7 +30,10 @@ class Params(C.Structure):
         ("q0", dp), ("samples", dp), ("diag", dp), ("trace", dp), ("trace_cap", C.c_int),
         ("trace_n", ip), ("work", dp), ("tpar", dp),
         ("kq", dp), ("kv", dp), ("kg", dp), ("kham0", dp), ("kh", dp), ("ku_r2p", dp),
-        ("kxi", ip), ("kq1", dp), ("kv1", dp), ("kg1", dp), ("kdout", dp), ("kiout", ip), ("stamps", C.c_void_p),
+        ("kxi", ip), ("kq1", dp), ("kv1", dp), ("kg1", dp), ("kdout", dp), ("kiout", ip),
+        ("warmupIter", C.c_int), ("adaptH", C.c_int), ("adaptDelta", C.c_int),
+        ("adaptHtarget", C.c_double), ("adaptDeltaTarget", C.c_double), ("adaptDeltaQuantile", C.c_double),
+        ("facs", dp), ("stamps", C.c_void_p),
     ]
 
 
@@ -61,7 +64,8 @@ def _p(a, t=dp):
 
 def walnuts(target, q0, integrator=0, tpar=None, H0=0.2, stepSizeRandScale=0.2, delta0=0.05,
             numIter=10, M=10, minC=0, maxC=10, R2Pprob0=2.0 / 3.0, generated=0, gen_k=0, seed=0,
-            chain0=0, trace_cap=0):
+            chain0=0, trace_cap=0, warmupIter=0, adaptH=True, adaptHtarget=0.8, adaptDelta=True,
+            adaptDeltaTarget=0.6, adaptDeltaQuantile=0.9):
     q0 = np.ascontiguousarray(np.atleast_2d(np.asarray(q0, float)))
     Cn, D = q0.shape
     prm = Params()
@@ -82,6 +86,11 @@ def walnuts(target, q0, integrator=0, tpar=None, H0=0.2, stepSizeRandScale=0.2, 
     prm.q0 = _p(q0); prm.samples = _p(samples); prm.diag = _p(diag)
     prm.trace = _p(trace); prm.trace_cap = trace_cap; prm.trace_n = _p(tn, ip)
     prm.tpar = _p(tp)
+    prm.warmupIter = warmupIter; prm.adaptH = int(adaptH); prm.adaptDelta = int(adaptDelta)
+    prm.adaptHtarget = adaptHtarget; prm.adaptDeltaTarget = adaptDeltaTarget
+    prm.adaptDeltaQuantile = adaptDeltaQuantile
+    facs = np.zeros((Cn, 2, max(warmupIter, 1)))
+    prm.facs = _p(facs)
     rc = lib().hostsim_run(C.byref(prm), target)
     if rc:
         raise RuntimeError(f"hostsim rc={rc}")

@@ -24,7 +24,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(L, s), s
     assert L.wn_abi_version() == _lib.WN_ABI_VERSION
-    assert C.sizeof(_lib.WnConfig) == 88
+    assert C.sizeof(_lib.WnConfig) == 120
 
 
 def test_no_gpu_means_loud_failure():
@@ -57,19 +57,24 @@ def test_state_machine_on_host_matches_oracle(name):
     h = hs.walnuts(c["target"], c["q0"], integrator=c["integrator"], tpar=c["tpar"], H0=c["H0"],
                    delta0=c["delta0"], numIter=c["numIter"], M=c["M"], minC=c["minC"], maxC=c["maxC"],
                    generated=c["generated"], gen_k=c["gen_k"], seed=seed, chain0=c["chain"],
-                   trace_cap=len(ref["trace"]) + 8)
+                   trace_cap=len(ref["trace"]) + 8, warmupIter=c["warmupIter"], adaptH=c["adaptH"],
+                   adaptHtarget=c["adaptHtarget"], adaptDelta=c["adaptDelta"],
+                   adaptDeltaTarget=c["adaptDeltaTarget"], adaptDeltaQuantile=c["adaptDeltaQuantile"])
     n = o["ncalls"]
     assert int(h["trace_n"][0]) == n
     tr = h["trace"][0, :n]
     for col in (0, 1, 2, 6, 7, 8, 10, 11):
         np.testing.assert_array_equal(tr[:, col], o["trace"][:, col], err_msg=f"col {col}")
-    tg.close(tr[:, 3:6], o["trace"][:, 3:6], rtol=1e-12, atol=1e-13)
-    tg.close(tr[:, 12:], o["trace"][:, 12:], rtol=1e-12, atol=1e-13)
-    tg.close(h["samples"][0], o["samples"], rtol=1e-12, atol=1e-13)
+    # the engine's funnel log-density is algebraically simplified (last-bit differences from the
+    # oracle's literal scipy form); with warm-up those feed the adapted step size and are amplified
+    rt, at = (1e-7, 1e-9) if (c["warmupIter"] > 0 and c["target"] in tg.EXP_TARGETS) else (1e-12, 1e-13)
+    tg.close(tr[:, 3:6], o["trace"][:, 3:6], rtol=rt, atol=at)
+    tg.close(tr[:, 12:], o["trace"][:, 12:], rtol=rt, atol=at)
+    tg.close(h["samples"][0], o["samples"], rtol=rt, atol=at)
     d, rd = h["diagnostics"][0], o["diagnostics"]
     for col in (0, 1, 4, 5, 6, 7, 8, 9, 12, 13, 19, 20, 21, 22):
         np.testing.assert_array_equal(d[:, col], rd[:, col], err_msg=f"diag col {col}")
-    tg.close(d, rd, rtol=1e-10, atol=1e-12)
+    tg.close(d, rd, rtol=max(rt, 1e-10), atol=max(at, 1e-12))
 
 
 def test_state_machine_many_chains_host():

@@ -49,6 +49,9 @@ def load_case(name):
              chain=int(cfg[8]), H0=float(par[0]), s=float(par[1]), delta0=float(par[2]),
              R2Pprob0=float(par[3]), q0=TR[p + "q0"],
              tpar=TR[p + "tpar"] if (p + "tpar") in TR.files else None)
+    w = TR[p + "warm"] if (p + "warm") in TR.files else np.array([0, 1, 0.8, 1, 0.6, 0.9])
+    c.update(warmupIter=int(w[0]), adaptH=bool(w[1]), adaptHtarget=float(w[2]), adaptDelta=bool(w[3]),
+             adaptDeltaTarget=float(w[4]), adaptDeltaQuantile=float(w[5]))
     ref = {k: TR[p + k] for k in ("samples", "diagnostics", "trace", "n_u")}
     return c, ref
 
@@ -58,7 +61,10 @@ def run_engine(wa, c, q0, ncalls_hint, chain_offset):
     e = wa.Engine(q0.shape[1], q0.shape[0], integrator=c["integrator"], H0=c["H0"],
                   stepSizeRandScale=c["s"], delta0=c["delta0"], M=c["M"], minC=c["minC"],
                   maxC=c["maxC"], R2Pprob0=c["R2Pprob0"], generated=c["generated"], gen_k=c["gen_k"],
-                  chain_offset=chain_offset)
+                  chain_offset=chain_offset, warmupIter=c.get("warmupIter", 0), adaptH=c.get("adaptH", True),
+                  adaptHtarget=c.get("adaptHtarget", 0.8), adaptDelta=c.get("adaptDelta", True),
+                  adaptDeltaTarget=c.get("adaptDeltaTarget", 0.6),
+                  adaptDeltaQuantile=c.get("adaptDeltaQuantile", 0.9))
     e.set_target(c["target"], c["tpar"])
     s, d, tr, tn = e.run(q0, SEED, c["numIter"], trace_cap=ncalls_hint)
     out = dict(samples=s.transpose(1, 2).cpu().numpy(), diagnostics=d.cpu().numpy(),
@@ -185,6 +191,25 @@ def test_batch_matches_oracle(wa, case):
         compare_chain(out, k, o["trace"], o["samples"], o["diagnostics"], f"{name} chain {k} [{out['kernel']}]")
 
 
+def test_warmup_batch_matches_oracle(wa):
+    """Warm-up adaptation in a batched launch (coop and lane layouts): H (col 15) and delta (col 18)
+    per iteration and the draws agree with the oracle chain by chain."""
+    rng = np.random.default_rng(5)
+    for tk, D, ig, C, kw in [(ol.T_STDGAUSS, 40, ol.I_ADAPT_R2P, 20, dict(H0=0.4, delta0=0.1, M=6)),
+                             (ol.T_STDGAUSS, 6, ol.I_FIXED, 70, dict(H0=0.3, delta0=0.05, M=6)),
+                             (ol.T_FUNNEL10, 11, ol.I_ADAPT_D, 66, dict(H0=0.3, delta0=0.3, M=7))]:
+        q0 = rng.normal(size=(C, D))
+        c = dict(target=tk, integrator=ig, H0=kw["H0"], s=0.2, delta0=kw["delta0"], M=kw["M"], numIter=30,
+                 minC=0, maxC=10, R2Pprob0=2.0 / 3.0, generated=0, gen_k=0, tpar=None, warmupIter=20)
+        out = run_engine(wa, c, q0, 4, chain_offset=300)
+        for k in (0, C - 1):
+            o = ol.walnuts(tk, q0[k], integrator=ig, H0=c["H0"], delta0=c["delta0"], numIter=30, M=c["M"],
+                           seed=SEED, chain=300 + k, warmupIter=20)
+            close(out["diagnostics"][k][:, [15, 18]], o["diagnostics"][:, [15, 18]], what=f"H/delta {tk} chain {k}")
+            np.testing.assert_array_equal(out["diagnostics"][k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]])
+            close(out["samples"][k], o["samples"], what=f"samples {tk} chain {k}")
+
+
 def test_sharding_invariance(wa):
     """per-chain results do not depend on how chains are split over engines/GPUs."""
     A, q0 = dense_problem(100, 1e4, 64, 11)
@@ -249,8 +274,8 @@ def test_full_size_properties(wa):
 def test_error_paths(wa):
     with pytest.raises(ValueError):
         wa.Engine(3, 4, M=0)
-    with pytest.raises(NotImplementedError):
-        wa.Engine(3, 4, warmupIter=10)
+    with pytest.raises(ValueError):
+        wa.Engine(3, 4, warmupIter=10, adaptHtarget=1.5)  # the reference: sys.exit("bad adaptHtarget")
     e = wa.Engine(5, 4)
     with pytest.raises(ValueError):
         e.set_target(ol.T_FUNNEL10)
@@ -276,8 +301,13 @@ def test_walnuts_api_shapes(wa):
     np.testing.assert_allclose(lp, lo, rtol=1e-12); np.testing.assert_allclose(g, go, rtol=1e-12)
     with pytest.raises(TypeError):
         wa.WALNUTS(lambda q: [0.0, -q], np.zeros(3), warmupIter=0)
-    with pytest.raises(NotImplementedError):
-        wa.WALNUTS(td.stdGauss, np.zeros(3))  # default warmupIter=1000 needs adaptation
+    with pytest.raises(SystemExit):
+        wa.WALNUTS(td.stdGauss, np.zeros(3), adaptHtarget=2.0)  # WALNUTS.py:140
+    # the reference's defaults (warmupIter=1000, adaptH, adaptDelta; WALNUTS.py:119-127) run as they are
+    s3, d3 = wa.WALNUTS(td.corrGauss, np.array([1.0, 0.0]), integrator=ai.adaptLeapFrogR2P, numIter=1200, seed=3)
+    assert s3.shape == (2, 1201) and d3.shape == (1200, 24)
+    assert (d3[1000:, 15] == d3[1000, 15]).all() and (d3[1000:, 18] == d3[1000, 18]).all()  # frozen after warm-up
+    assert d3[0, 15] == 0.2 and d3[999, 15] != 0.2 and abs(s3[:, 1000:].mean()) < 0.3
 
 
 WD = np.load(os.path.join(G, "walnuts_draws.npz"))

@@ -6,6 +6,7 @@ Differences a caller sees:
     independent chains, returning arrays with a leading chain axis;
   * randomness comes from the engine's counter-based stream keyed by (seed, chain, iteration)
     instead of NumPy's global state; pass seed= and chain_offset=.
+Warm-up adaptation of H and delta (WALNUTS.py:701-712, P2quantile.py) runs per chain on the device.
 """
 import sys
 
@@ -45,14 +46,11 @@ def WALNUTS(lpFun, q0, generated=identity, integrator=ai.fixedLeapFrog, H0=0.2,
     if not isinstance(integrator, ai.DeviceIntegrator):
         raise TypeError("integrator must be one of walnuts_amd.adaptiveIntegrators.{fixedLeapFrog,"
                         "adaptLeapFrogD,adaptLeapFrogR2P}")
-    if warmupIter > 0 and (adaptH or adaptDelta):
-        # the reference sys.exit()s on bad adaptation targets (WALNUTS.py:140,146)
-        if adaptH and (adaptHtarget < 0.0 or adaptHtarget > 1.0):
-            sys.exit("bad adaptHtarget")
-        if adaptDelta and adaptDeltaTarget < 0.0:
-            sys.exit("bad adaptDeltaTarget")
-        raise NotImplementedError("warm-up adaptation of H/delta (WALNUTS.py:701-712) is not on the "
-                                  "device yet; pass warmupIter=0 (SURVEY.md 8f)")
+    # the reference sys.exit()s on bad adaptation targets whatever warmupIter is (WALNUTS.py:140,146)
+    if adaptH and (adaptHtarget < 0.0 or adaptHtarget > 1.0):
+        sys.exit("bad adaptHtarget")
+    if adaptDelta and adaptDeltaTarget < 0.0:
+        sys.exit("bad adaptDeltaTarget")
     if recordOrbitStats:
         raise NotImplementedError("recordOrbitStats (WALNUTS.py:182-184) is not on the device yet")
     host_gen = None
@@ -66,8 +64,10 @@ def WALNUTS(lpFun, q0, generated=identity, integrator=ai.fixedLeapFrog, H0=0.2,
     lpFun.check_dim(D)
     eng = Engine(D, C, integrator=integrator.kind, H0=H0, stepSizeRandScale=stepSizeRandScale,
                  delta0=delta0, M=M, minC=igrAux.minC, maxC=igrAux.maxC, R2Pprob0=igrAux.R2Pprob0,
-                 generated=generated.kind, gen_k=generated.k, warmupIter=0,
-                 chain_offset=chain_offset, device=device)
+                 generated=generated.kind, gen_k=generated.k, warmupIter=warmupIter,
+                 chain_offset=chain_offset, device=device, adaptH=adaptH, adaptHtarget=adaptHtarget,
+                 adaptDelta=adaptDelta, adaptDeltaTarget=adaptDeltaTarget,
+                 adaptDeltaQuantile=adaptDeltaQuantile)
     eng.set_target(lpFun.kind, lpFun.params)
     out = eng.run(q0a, seed, numIter, trace_cap=trace_cap)
     samples, diag = out[0], out[1]

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _VARIANT = os.environ.get("WN_LIB", "")
 LIB_PATH = os.path.join(_HERE, f"libwalnuts_amd_{_VARIANT}.so" if _VARIANT else "libwalnuts_amd.so")
 
-WN_ABI_VERSION = 1
+WN_ABI_VERSION = 2
 NDIAG = 24
 TRACE_NSCAL = 12
 
@@ -29,6 +29,8 @@ class WnConfig(C.Structure):
         ("H0", C.c_double), ("step_size_rand_scale", C.c_double), ("delta0", C.c_double),
         ("r2p_prob0", C.c_double), ("generated", C.c_int32), ("gen_k", C.c_int32),
         ("warmup_iter", C.c_int32), ("waves_per_group", C.c_int32),
+        ("adapt_h", C.c_int32), ("adapt_delta", C.c_int32), ("adapt_h_target", C.c_double),
+        ("adapt_delta_target", C.c_double), ("adapt_delta_quantile", C.c_double),
     ]
 
 

@@ -261,6 +261,7 @@ struct wn_engine {
   size_t ntpar = 0;
   double* work = nullptr;
   size_t work_doubles = 0;
+  double* facs = nullptr;  // warm-up: sorted energyErrorInfFacs, [C][2][warmupIter]
   KernelChoice kc{};
   bool have_kc = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -298,7 +299,12 @@ int wn_create(const wn_config* cfg, wn_engine** out) {
     g_create_err = "need H0 > 0, delta0 > 0, 0 <= stepSizeRandScale < 1"; return WN_E_ARG;
   }
   if (!(cfg->r2p_prob0 > 0.0 && cfg->r2p_prob0 < 1.0)) { g_create_err = "R2Pprob0 must be in (0,1)"; return WN_E_ARG; }
-  if (cfg->warmup_iter != 0) { g_create_err = "warm-up adaptation (WALNUTS.py:701-712) is not implemented on the device yet: warmupIter must be 0"; return WN_E_UNSUPPORTED; }
+  if (cfg->warmup_iter < 0) { g_create_err = "warmupIter must be >= 0"; return WN_E_ARG; }
+  if (cfg->warmup_iter > 0) {  // WALNUTS.py:140,146 sys.exit("bad adaptHtarget") / ("bad adaptDeltaTarget")
+    if (cfg->adapt_h && (cfg->adapt_h_target < 0.0 || cfg->adapt_h_target > 1.0)) { g_create_err = "bad adaptHtarget"; return WN_E_ARG; }
+    if (cfg->adapt_delta && cfg->adapt_delta_target < 0.0) { g_create_err = "bad adaptDeltaTarget"; return WN_E_ARG; }
+    if (cfg->adapt_delta && !(cfg->adapt_delta_quantile >= 0.0 && cfg->adapt_delta_quantile <= 1.0)) { g_create_err = "adaptDeltaQuantile must be in [0,1]"; return WN_E_ARG; }
+  }
   if (cfg->generated < WN_G_IDENTITY || cfg->generated > WN_G_FIRSTK) { g_create_err = "unknown generated kind"; return WN_E_ARG; }
   if (cfg->generated == WN_G_FIRSTK && (cfg->gen_k < 1 || cfg->gen_k > cfg->dim)) { g_create_err = "gen_k out of range"; return WN_E_ARG; }
   wn_engine* e = new wn_engine();
@@ -317,6 +323,7 @@ int wn_destroy(wn_engine* e) {
   hipSetDevice(e->cfg.device);
   if (e->tpar) hipFree(e->tpar);
   if (e->work) hipFree(e->work);
+  if (e->facs) hipFree(e->facs);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   delete e;
@@ -376,12 +383,17 @@ static void fill_params(const wn_engine* e, Params* p) {
   p->chain0 = (uint32_t)c.chain_offset;
   p->work = e->work;
   p->tpar = e->tpar;
+  p->adaptH = c.adapt_h; p->adaptDelta = c.adapt_delta;
+  p->adaptHtarget = c.adapt_h_target; p->adaptDeltaTarget = c.adapt_delta_target;
+  p->adaptDeltaQuantile = c.adapt_delta_quantile;
+  p->facs = e->facs;
 }
 
 static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
   const bool adapt = e->cfg.integrator != WN_I_FIXED;
   if (timed) HIPCHK(e, hipEventRecord(e->ev0, st));
-  hipError_t r = e->kc.layout == 0 ? launch_lane(e->kc, adapt, p, st) : launch_coop(e->kc, adapt, p, st);
+  const bool warm = p.warmupIter > 0;
+  hipError_t r = e->kc.layout == 0 ? launch_lane(e->kc, adapt, warm, p, st) : launch_coop(e->kc, adapt, warm, p, st);
   if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
   if (timed) { HIPCHK(e, hipEventRecord(e->ev1, st)); e->timed = true; }
   return WN_OK;
@@ -398,6 +410,13 @@ int wn_run(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, do
   fill_params(e, &p);
   p.mode = MODE_SAMPLE;
   p.numIter = n_iter; p.seed = seed;
+  p.warmupIter = e->cfg.warmup_iter;
+  if (p.warmupIter > 0 && (e->cfg.adapt_h || e->cfg.adapt_delta)) {
+    if (!e->facs) HIPCHK(e, hipMalloc((void**)&e->facs, (size_t)e->cfg.n_chains * 2 * p.warmupIter * sizeof(double)));
+    p.facs = e->facs;
+  } else {
+    p.warmupIter = 0;  // nothing adapts: the plain kernels are exact
+  }
   p.q0 = q0_dev; p.samples = samples_dev; p.diag = diag_dev;
   p.trace = trace_dev; p.trace_cap = trace_cap; p.trace_n = trace_n_dev;
 #ifdef WN_STAMPS

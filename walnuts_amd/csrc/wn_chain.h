@@ -60,6 +60,10 @@ struct Params {
   const int* kxi;
   double *kq1, *kv1, *kg1, *kdout;
   int* kiout;
+  // warm-up adaptation (WALNUTS.py:120-127, 701-712)
+  int warmupIter, adaptH, adaptDelta;
+  double adaptHtarget, adaptDeltaTarget, adaptDeltaQuantile;
+  double* facs;  // [C][2][warmupIter] sorted energyErrorInfFacs, double-buffered
   unsigned long long* stamps;  // diagnostic builds (-DWN_STAMPS): [block][wave][8] cycles per phase
 };
 
@@ -91,7 +95,7 @@ enum { COLD_QB = 0, COLD_VB, COLD_GB, COLD_N };
 // backward passes run (adaptiveIntegrators.py:96-99).  The layout decides registers vs LDS.
 enum { WARM_QL = 0, WARM_VL, WARM_QO, WARM_VO, WARM_GO, WARM_N };
 
-template <class P, bool ADAPT>
+template <class P, bool ADAPT, bool WARM = false>
 struct Engine {
   using Vec = typename P::Vec;
   // U-turn checks 0 (full orbit), 1 (leaf pair) and 2..1+NLC (fast-cached sub-tree levels) have
@@ -133,6 +137,11 @@ struct Engine {
   Vec qa, va, ga;  // active end of the orbit = start of the current macro step (v forward-time)
   double lpP, lpPL;
   int ip, ipl;
+  double Hc, dc;  // big step size H and tolerance delta of this chain (adapted during warm-up)
+  // warm-up only: P2 quantile of log(igrConst) (P2quantile.py), energy-step statistics
+  int p2n, p2m[5];
+  double p2q[5], Hprev, madv, igrOut;
+  bool madnan;
   // adaptive integrators only: work state of the running micro pass (the accepted forward result
   // is parked in the layout's warm storage while the backward passes run)
   typename P::template Opt<ADAPT> qw, vw, gw;
@@ -170,7 +179,7 @@ struct Engine {
   }
   // numpy legacy uniform(low, high) = low + (high-low)*U
   WN_HD double draw_h() {
-    double low = prm.H * (1 - prm.s), high = prm.H * (1 + prm.s);
+    double low = Hc * (1 - prm.s), high = Hc * (1 + prm.s);
     return low + (high - low) * next_u();
   }
 
@@ -286,6 +295,7 @@ struct Engine {
       HamPass0 = Ham0;
     }
     allfin = isfinite(HamPass0);
+    if (WARM) { Hprev = HamPass0; madv = -INFINITY; madnan = false; }
   }
   template <bool B_ = ADAPT>
   WN_HD typename std::enable_if<!B_>::type setup_pass() {}
@@ -311,6 +321,7 @@ struct Engine {
   template <bool B_ = ADAPT>
   WN_HD typename std::enable_if<B_>::type save_out(double lp, double Hi) {
     p.template warm_put<WARM_QO>(qw); p.template warm_put<WARM_VO>(vw); p.template warm_put<WARM_GO>(gw);
+    if (WARM) igrOut = hh * pow(madnan ? NAN : madv, -1.0 / 3.0);  // :101 / :399 / :424
     lpOut = lp;
     HOut = Hi;
   }
@@ -366,6 +377,11 @@ struct Engine {
   WN_HD void micro_account(double lp, double ke) {
     const double Hi = -lp + 0.5 * ke;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
     lpCur = lp; HCur = Hi;
+    if (WARM) {  // np.max(np.abs(np.diff(Hams))) of the running pass (adaptiveIntegrators.py:101)
+      const double df = fabs(Hi - Hprev);
+      if (isnan(df)) madnan = true; else madv = df > madv ? df : madv;
+      Hprev = Hi;
+    }
     if (!isfinite(Hi)) allfin = false;
     im++;
     if (ph == PH_BWD) nEvB++; else nEvF++;
@@ -382,7 +398,7 @@ struct Engine {
   WN_HD void pass_end() {
     const double lp = lpCur, Hi = HCur;
     // pass complete: all(isfinite(Hams)) and abs(Hams[0]-Hams[-1]) < delta   (:87-94)
-    bool ok = allfin && (fabs(HamPass0 - Hi) < prm.delta);
+    bool ok = allfin && (fabs(HamPass0 - Hi) < dc);
     if (ph == PH_FWD) {
       bool done = false;
       if (ok) { If = c; done = true; }
@@ -518,6 +534,10 @@ struct Engine {
     const bool first = (i == 0) || ((n & 1) == 0);
     const int idx = xi > 0 ? b + 1 + n : a - 1 - n;
     trace_row();
+    if (WARM && iter <= prm.warmupIter && prm.adaptH) {  // igrConstQ.push(np.log(intOut.igrConst)) :313
+      const double igr = ADAPT ? igrOut : h * pow(fmax(1.0e-10, fabs(Ham0 - Hn)), -1.0 / 3.0);  // ai.py:59
+      p2_push(log(igr));
+    }
     // intOut.v is in forward-time orientation (adaptiveIntegrators.py:57,135,473)
     WN_VFOR(e) VN().x[e] = (double)xi * VN().x[e];
     nevalF += nEvF; nevalB += nEvB;
@@ -608,6 +628,97 @@ struct Engine {
     needDoubling = true;
   }
 
+  // ------------------------------------------------------------------------------------------
+  // warm-up adaptation (WALNUTS.py:701-712).  P2quantile.py:41-86 on registers (every replica
+  // of a chain runs it identically); the exact quantile of energyErrorInfFacs[0:iterN]
+  // (np.quantile, method "linear") reads a sorted copy in memory that only the writer lane
+  // extends, into the other half of a double buffer, so readers never race with the insertion.
+  // ------------------------------------------------------------------------------------------
+  WN_HD static bool p2_after(double a, double b) { return a > b || (isnan(a) && !isnan(b)); }  // np.sort order
+  WN_HD void p2_cswap(int i, int j) {
+    if (p2_after(p2q[i], p2q[j])) { double t = p2q[i]; p2q[i] = p2q[j]; p2q[j] = t; }
+  }
+  WN_HD void p2_push(double xi) {
+    p2n++;
+    if (p2n <= 5) {  // self.x[npush-1] = xi; (quantile() is not read before npush > 10)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) if (j == p2n - 1) p2q[j] = xi;
+      if (p2n == 5) {  // np.sort (9-comparator network), self.q = self.x
+        p2_cswap(0, 1); p2_cswap(3, 4); p2_cswap(2, 4); p2_cswap(2, 3); p2_cswap(0, 3);
+        p2_cswap(0, 2); p2_cswap(1, 4); p2_cswap(1, 3); p2_cswap(1, 2);
+      }
+      return;
+    }
+    int k;  // findInterval :31-38 (None when xi == q[4] or xi is NaN -> every marker moves)
+    if (xi < p2q[0]) k = 0;
+    else if (xi > p2q[4]) k = 5;
+    else k = xi < p2q[1] ? 1 : xi < p2q[2] ? 2 : xi < p2q[3] ? 3 : xi < p2q[4] ? 4 : -1;
+    if (k == 0) { p2q[0] = xi; k = 1; }
+    else if (k == 5) { p2q[4] = xi; k = 4; }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) if (j >= k) p2m[j] += 1;  // self.n[k:5] += 1
+    const double nn = (double)p2n, pp = 1.0 - prm.adaptHtarget;
+    const double npp[5] = {1.0, 0.5 * (nn - 1) * pp + 1.0, (nn - 1) * pp + 1.0, (nn - 1) * (1 + pp) / 2.0 + 1, nn};
+#pragma unroll
+    for (int i = 2; i < 5; ++i) {  // :71-86
+      const int ni = p2m[i - 1], nip = p2m[i], nim = p2m[i - 2];
+      const double di = npp[i - 1] - (double)ni;
+      if ((di >= 1.0 && nip - ni > 1) || (di <= -1.0 && nim - ni < -1)) {
+        const int d = di > 0 ? 1 : -1;
+        const double qi = p2q[i - 1];
+        const double qip = qi + ((double)d / (double)(nip - nim)) *
+                                    ((double)(ni - nim + d) * (p2q[i] - qi) / (double)(nip - ni) +
+                                     (double)(nip - ni - d) * (qi - p2q[i - 2]) / (double)(ni - nim));
+        if (p2q[i - 2] < qip && qip < p2q[i]) p2q[i - 1] = qip;
+        else {
+          const double qn = d > 0 ? p2q[i] : p2q[i - 2];
+          const int mn = d > 0 ? p2m[i] : p2m[i - 2];
+          p2q[i - 1] = qi + (double)d * (qn - qi) / (double)(mn - p2m[i - 1]);
+        }
+        p2m[i - 1] += d;
+      }
+    }
+  }
+
+  WN_HD void adapt_update(double orbitEnergyError) {
+    if (prm.adaptDelta) {
+      const int n0 = iter - 1;  // values stored so far
+      const size_t W_ = (size_t)prm.warmupIter;
+      const double* cur = prm.facs + ((size_t)p.chain_local() * 2 + (size_t)(n0 & 1)) * W_;
+      double* nxt = prm.facs + ((size_t)p.chain_local() * 2 + (size_t)((n0 + 1) & 1)) * W_;
+      const double x = orbitEnergyError / dc;  // :704
+      // position of x in the sorted array (NaNs sort last): number of elements that stay before it
+      int lo = 0, hi = n0;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const double a = cur[mid];
+        if (p2_after(x, a) || x == a) lo = mid + 1; else hi = mid;  // a <= x (NaN-last order)
+      }
+      const int pos = lo, n = n0 + 1;
+      if (iter > 10) {  // :705-707  delta = adaptDeltaTarget / np.quantile(facs[0:iterN], q)
+        auto elem = [&](int r) -> double { return r < pos ? cur[r] : (r == pos ? x : cur[r - 1]); };
+        double res;
+        if (isnan(elem(n - 1))) res = NAN;
+        else {
+          const double vi = (double)(n - 1) * prm.adaptDeltaQuantile;
+          int prev = (int)floor(vi), next = prev + 1;
+          double gamma = vi - (double)prev;
+          if (vi >= (double)(n - 1)) { prev = n - 1; next = n - 1; gamma = vi + 1.0; }
+          if (vi < 0) { prev = 0; next = 0; gamma = vi; }
+          const double A = elem(prev), B = elem(next), dba = B - A;
+          res = gamma >= 0.5 ? (B - dba * (1 - gamma)) : (A + dba * gamma);
+        }
+        dc = prm.adaptDeltaTarget / res;
+      }
+      if (p.writer()) {  // extend the sorted copy into the other buffer
+        for (int r = 0; r < pos; ++r) nxt[r] = cur[r];
+        nxt[pos] = x;
+        for (int r = pos; r < n0; ++r) nxt[r + 1] = cur[r];
+      }
+    }
+    if (prm.adaptH && p2n > 10) Hc = pow(dc, 1.0 / 3.0) * exp(p2q[2]);  // :711-712
+  }
+
   WN_HD void end_iteration() {  // :653-695
     const int cl = p.chain_local();
 #ifndef WN_ABL_NOGEN
@@ -620,11 +731,12 @@ struct Engine {
     d[12] = bothEndsPassive ? 1.0 : 0.0;
     d[13] = ((lwtSumb < WN_LOGZERO + 1.0) || (lwtSumf < WN_LOGZERO + 1.0)) ? 1.0 : 0.0;
     d[14] = ADAPT ? (double)nneq / (double)nused : 0.0;
-    d[15] = prm.H;
+    d[15] = Hc;
     d[16] = ADAPT ? (double)nzero / (double)nused : 1.0;
     d[17] = Hnan ? NAN : (Hmax - Hmin);
-    d[18] = prm.delta; d[19] = (double)stopCode; d[20] = NdC; d[21] = ADAPT ? minc : 0; d[22] = ADAPT ? maxc : 0;
+    d[18] = dc; d[19] = (double)stopCode; d[20] = NdC; d[21] = ADAPT ? minc : 0; d[22] = ADAPT ? maxc : 0;
     d[23] = indexStat_;
+    if (WARM && iter <= prm.warmupIter) adapt_update(d[17]);
 #if defined(WN_ABL_DIAGSAME)
     p.diag_store(prm.diag + (size_t)cl * NDIAG, d);
 #elif !defined(WN_ABL_NODIAG)
@@ -670,6 +782,10 @@ struct Engine {
     // every scalar starts defined (reading an indeterminate value is UB even on dead paths)
     Bbits = 0; lp0 = 0.0; WoldSum = 1.0; WnewSum = 0.0; lwtSumf = lwtSumb = 0.0;
     gen_iter = 0; lpP = lpPL = 0.0; ip = ipl = 0;
+    Hc = prm.H; dc = prm.delta;
+    p2n = 0; Hprev = madv = igrOut = 0.0; madnan = false;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { p2q[k] = 0.0; p2m[k] = k + 1; }
     nevalF = nevalB = L_ = Lold_ = NdS = NdC = maxFint = maxBint = stopCode = 0;
     orbitLen_ = orbitLenSam_ = indexStat_ = indexStatOld_ = timeLenF_ = timeLenB_ = 0.0;
     bothEndsPassive = false;
@@ -764,7 +880,7 @@ struct Engine {
           if (needKE) {  // Hs[I0] = -f0 + 0.5*sum(v**2)  (:256); multinomialLscale (:259)
             H0 = -lp0 + 0.5 * part[2];
             Ha = Hb = H0; Ham0 = H0;
-            if (ADAPT) { HamPass0 = H0; allfin = isfinite(H0); }
+            if (ADAPT) { HamPass0 = H0; allfin = isfinite(H0); if (WARM) Hprev = H0; }
             Hnan = isnan(H0); Hmin = Hmax = H0;
             needKE = false; keinit_part = 0.0;
           }

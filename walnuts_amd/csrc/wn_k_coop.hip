@@ -6,22 +6,27 @@
 
 namespace wn {
 
-template <int NT, int W, int KS, int TK, bool ADAPT>
+template <int NT, int W, int KS, int TK, bool ADAPT, bool WARM>
 __global__ __launch_bounds__(W * 64) void wn_coop_kernel(Params prm) {
   __shared__ double lds[CoopPolicy<NT, W, KS, TK>::LDS_DOUBLES];
   CoopPolicy<NT, W, KS, TK> p(prm, lds);
-  Engine<CoopPolicy<NT, W, KS, TK>, ADAPT> eng(p, prm);
+  Engine<CoopPolicy<NT, W, KS, TK>, ADAPT, WARM> eng(p, prm);
   eng.run();
 }
 
 template <int NT, int W, int KS, int TK>
-static hipError_t go(bool adapt, const Params& prm, hipStream_t st) {
+static hipError_t go(bool adapt, bool warm, const Params& prm, hipStream_t st) {
   dim3 grid((prm.C + 15) / 16), block(W * 64);
 #ifndef WN_ONLY_FIXED
-  if (adapt) hipLaunchKernelGGL((wn_coop_kernel<NT, W, KS, TK, true>), grid, block, 0, st, prm);
+  if (warm) {
+    if (adapt) hipLaunchKernelGGL((wn_coop_kernel<NT, W, KS, TK, true, true>), grid, block, 0, st, prm);
+    else hipLaunchKernelGGL((wn_coop_kernel<NT, W, KS, TK, false, true>), grid, block, 0, st, prm);
+    return hipGetLastError();
+  }
+  if (adapt) hipLaunchKernelGGL((wn_coop_kernel<NT, W, KS, TK, true, false>), grid, block, 0, st, prm);
   else
 #endif
-    hipLaunchKernelGGL((wn_coop_kernel<NT, W, KS, TK, false>), grid, block, 0, st, prm);
+    hipLaunchKernelGGL((wn_coop_kernel<NT, W, KS, TK, false, false>), grid, block, 0, st, prm);
   return hipGetLastError();
 }
 
@@ -30,20 +35,20 @@ size_t coop_work_doubles(int NT, int W, int C, int M) {
   return groups * (size_t)((M + 1) * 2 + 5) * W * (NT * 4) * 64;
 }
 
-hipError_t launch_coop(const KernelChoice& kc, bool adapt, const Params& prm, hipStream_t st) {
+hipError_t launch_coop(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st) {
   if (kc.W != 4) return hipErrorInvalidValue;
   // p0 = k-steps (= ceil(D/4) rounded up to an instantiated value)
 #ifdef WN_ONLY_MAIN
-  if (kc.p1 == CK_DENSE && kc.p0 == 25) return go<2, 4, 25, CK_DENSE>(adapt, prm, st);
+  if (kc.p1 == CK_DENSE && kc.p0 == 25) return go<2, 4, 25, CK_DENSE>(adapt, warm, prm, st);
 #else
   if (kc.p1 == CK_DENSE) {
-    if (kc.p0 == 16) return go<1, 4, 16, CK_DENSE>(adapt, prm, st);
-    if (kc.p0 == 25) return go<2, 4, 25, CK_DENSE>(adapt, prm, st);
-    if (kc.p0 == 32) return go<2, 4, 32, CK_DENSE>(adapt, prm, st);
+    if (kc.p0 == 16) return go<1, 4, 16, CK_DENSE>(adapt, warm, prm, st);
+    if (kc.p0 == 25) return go<2, 4, 25, CK_DENSE>(adapt, warm, prm, st);
+    if (kc.p0 == 32) return go<2, 4, 32, CK_DENSE>(adapt, warm, prm, st);
   } else {
-    if (kc.p0 == 16) return go<1, 4, 16, CK_DIAG>(adapt, prm, st);
-    if (kc.p0 == 32) return go<2, 4, 32, CK_DIAG>(adapt, prm, st);
-    if (kc.p0 == 64) return go<4, 4, 64, CK_DIAG>(adapt, prm, st);
+    if (kc.p0 == 16) return go<1, 4, 16, CK_DIAG>(adapt, warm, prm, st);
+    if (kc.p0 == 32) return go<2, 4, 32, CK_DIAG>(adapt, warm, prm, st);
+    if (kc.p0 == 64) return go<4, 4, 64, CK_DIAG>(adapt, warm, prm, st);
   }
 #endif
   return hipErrorInvalidValue;

@@ -19,7 +19,7 @@ struct KernelChoice {
 // returns 0 and fills `kc` if a kernel exists for (target, D)
 int choose_kernel(int target, int D, int waves_per_group, KernelChoice* kc);
 size_t kernel_work_doubles(const KernelChoice& kc, int C, int M);
-hipError_t launch_lane(const KernelChoice& kc, bool adapt, const Params& prm, hipStream_t st);
-hipError_t launch_coop(const KernelChoice& kc, bool adapt, const Params& prm, hipStream_t st);
+hipError_t launch_lane(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st);
+hipError_t launch_coop(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st);
 
 }  // namespace wn

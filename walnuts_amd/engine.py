@@ -25,7 +25,8 @@ class Engine:
 
     def __init__(self, dim, n_chains, integrator=L.I_FIXED, H0=0.2, stepSizeRandScale=0.2,
                  delta0=0.05, M=10, minC=0, maxC=10, R2Pprob0=2.0 / 3.0, generated=L.G_IDENTITY,
-                 gen_k=0, warmupIter=0, chain_offset=0, device=None, waves_per_group=0):
+                 gen_k=0, warmupIter=0, chain_offset=0, device=None, waves_per_group=0, adaptH=True,
+                 adaptHtarget=0.8, adaptDelta=True, adaptDeltaTarget=0.6, adaptDeltaQuantile=0.9):
         torch = _torch()
         self.torch = torch
         self.lib = L.lib()
@@ -39,6 +40,9 @@ class Engine:
         cfg.delta0 = float(delta0); cfg.r2p_prob0 = float(R2Pprob0)
         cfg.generated = int(generated); cfg.gen_k = int(gen_k); cfg.warmup_iter = int(warmupIter)
         cfg.waves_per_group = int(waves_per_group)
+        cfg.adapt_h = int(bool(adaptH)); cfg.adapt_delta = int(bool(adaptDelta))
+        cfg.adapt_h_target = float(adaptHtarget); cfg.adapt_delta_target = float(adaptDeltaTarget)
+        cfg.adapt_delta_quantile = float(adaptDeltaQuantile)
         self.cfg = cfg
         self.dim, self.n_chains = int(dim), int(n_chains)
         self.dg = {L.G_IDENTITY: self.dim, L.G_Q0_SUMSQ: 2, L.G_FIRSTK: int(gen_k)}[int(generated)]
