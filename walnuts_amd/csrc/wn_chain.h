@@ -82,6 +82,10 @@ struct Params {
 #define WN_STAMP(k) do {} while (0)
 #endif
 
+#ifndef WN_ALIGN_LOG2
+#define WN_ALIGN_LOG2 3
+#endif
+
 #define WN_VFOR(e) _Pragma("unroll") for (int e = 0; e < P::NE; ++e)
 
 // cold vector ids (touched only at doubling boundaries)
@@ -466,7 +470,7 @@ struct Engine {
 #pragma unroll
     for (int j = 0; j < NFAST; ++j) {
       double d1 = 0.0, d2 = 0.0;
-      if (on && need_check(j)) {
+      if (p.any(on && need_check(j)) && on && need_check(j)) {
         if (j == 0) {
           Vec qo_, vo_;
           p.template cold_get<COLD_QB>(qo_); p.template cold_get<COLD_VB>(vo_);
@@ -843,10 +847,19 @@ struct Engine {
 #if defined(WN_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
     st_last_ = __builtin_readcyclecounter();
 #endif
+    // fixedLeapFrog: every macro step is one tick, so leaf n of doubling i of an iteration that
+    // starts at tick T0 runs at tick T0 + 2**i - 1 + n.  Starting iterations only at T0 = 1 (mod
+    // 2**ALIGN_LOG2) makes the leaf parity, the sub-tree check schedule (levels 1..ALIGN_LOG2) and the
+    // doubling ends of ALL chains of a group functions of the tick count alone: the expensive
+    // divergent paths run on a few tick phases for everybody instead of on most ticks for somebody.
+    // Costs (2**ALIGN_LOG2 - 1)/2 idle ticks per iteration; changes no chain's arithmetic.
+    constexpr uint32_t ALIGN_MASK = ADAPT ? 0u : ((1u << WN_ALIGN_LOG2) - 1u);
+    uint32_t T = 0;
     while (p.any(live || needGen)) {
       WN_STAMP(7);
       // ---- A ----
-      if (live && needIter) start_iteration();
+      if (live && needIter && (prm.mode != MODE_SAMPLE || (T & ALIGN_MASK) == (1u & ALIGN_MASK))) start_iteration();
+      T++;
       rng_refill();
       if (live && needDoubling) start_doubling();
       if (live && needMacro) setup_macro();
@@ -859,7 +872,7 @@ struct Engine {
       WN_STAMP(0);
       int kin = 0;
       do {
-        const bool act = live && (kin == 0 || inPass);
+        const bool act = live && !needIter && (kin == 0 || inPass);
         const double hh2 = act ? 0.5 * hh : 0.0, hq = act ? hh : 0.0;
         WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; Q.x[e] = Q.x[e] + hq * V.x[e]; }
         p.grad(Q, G, part[0]);
@@ -870,10 +883,18 @@ struct Engine {
         if (!ADAPT) {
           // fixedLeapFrog finalises its macro step every tick, so the on-chip U-turn checks ride
           // in the same reduction as the energies
-          fin = live;
-          fast_dots(part + 4);
+          fin = act;
+          if (p.any(nchecks() > 0)) {
+            fast_dots(part + 4);
+            p.template reduce<NPB>(part);
+          } else {  // no chain of the group is at a check leaf on this tick
+#pragma unroll
+            for (int k = 4; k < NPB; ++k) part[k] = 0.0;
+            p.template reduce<4>(part);
+          }
+        } else {
+          p.template reduce<NPB>(part);
         }
-        p.template reduce<NPB>(part);
         WN_STAMP(2);
         finish_generated(part[3]);
         if (act) {
@@ -889,7 +910,7 @@ struct Engine {
         kin++;
       } while (ADAPT && kin < 16 && p.majority(live && inPass, live));
       // ---- C ----
-      if (live) {
+      if (live && !needIter) {
         if (!ADAPT) after_micro(p.lp_finish(part[0]), part[1]);
         else if (!inPass) pass_end();
       }
