@@ -262,6 +262,7 @@ typedef struct {
 /* One pass of 2**c micro steps from (q, vv0, g) (adaptiveIntegrators.py:70-84 / 112-126).
  * On return qq,vv,gg hold the end state, *fnew the last lp; returns all(isfinite(Hams));
  * *maxErr = abs(Hams[0]-Hams[-1]); *maxAbsDiff = max(abs(diff(Hams))); *Hlast = Hams[-1]. */
+static int g_yoshida = 0; /* set by integrator_impl for adaptYoshidaD (single-threaded test tool) */
 static int micro_pass(const lpctx *t, int c, double h, const double *q, const double *vv0,
                       const double *g, double Ham0, double *qq, double *vv, double *gg,
                       double *vh, double *fnew, double *hh_out, double *maxErr,
@@ -276,12 +277,25 @@ static int micro_pass(const lpctx *t, int c, double h, const double *q, const do
   double prev = Ham0, mad = -INFINITY;
   int madnan = 0;
   for (long i = 1; i <= nstep; ++i) {
+    if (g_yoshida) { /* adaptiveIntegrators.py:143-144,157-173: three leapfrog sub-steps */
+      const double firstLast = 1.351207191959658, middle = -1.702414383919315;
+      for (int sub = 0; sub < 3; ++sub) {
+        const double w = (sub == 1) ? middle : firstLast;
+        const double a = 0.5 * w * hh, bq = w * hh; /* 0.5*firstLast*hh ; firstLast*hh */
+        for (int k = 0; k < d; ++k) vh[k] = vv[k] + a * gg[k];
+        for (int k = 0; k < d; ++k) qq[k] = qq[k] + bq * vh[k];
+        wno_lpfun(t->target, d, t->tpar, qq, fnew, gg);
+        (*nEval)++;
+        for (int k = 0; k < d; ++k) vv[k] = vh[k] + a * gg[k];
+      }
+    } else {
     double hh2 = 0.5 * hh;
     for (int k = 0; k < d; ++k) vh[k] = vv[k] + hh2 * gg[k];
     for (int k = 0; k < d; ++k) qq[k] = qq[k] + hh * vh[k];
     wno_lpfun(t->target, d, t->tpar, qq, fnew, gg);
     (*nEval)++;
     for (int k = 0; k < d; ++k) vv[k] = vh[k] + hh2 * gg[k];
+    }
     double Hi = -(*fnew) + 0.5 * seqdot(d, vv, vv);
     if (!isfinite(Hi)) allfin = 0;
     double df = fabs(Hi - prev);
@@ -320,6 +334,8 @@ static void integrator_impl(int kind, const lpctx *t, const double *q, const dou
     return;
   }
 
+  g_yoshida = (kind == WNO_I_ADAPT_YOSHIDA);
+  if (kind == WNO_I_ADAPT_YOSHIDA) kind = WNO_I_ADAPT_D; /* same search/weight logic, :146-240 */
   /* forward search  adaptiveIntegrators.py:67-94 (D) / 363-389 (R2P) */
   int nEvalF = 0, nEvalB = 0;
   int If = maxC;

@@ -40,7 +40,8 @@ enum {
 enum {
   WNO_I_FIXED = 0, /* adaptiveIntegrators.py:49-59  fixedLeapFrog   */
   WNO_I_ADAPT_D = 1, /* adaptiveIntegrators.py:65-137 adaptLeapFrogD  */
-  WNO_I_ADAPT_R2P = 2 /* adaptiveIntegrators.py:361-475 adaptLeapFrogR2P */
+  WNO_I_ADAPT_R2P = 2, /* adaptiveIntegrators.py:361-475 adaptLeapFrogR2P */
+  WNO_I_ADAPT_YOSHIDA = 3 /* adaptiveIntegrators.py:142-240 adaptYoshidaD (4th order, 3 gradients per micro step) */
 };
 
 /* generated() kinds: what is stored per draw */

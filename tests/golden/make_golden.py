@@ -152,7 +152,7 @@ def dense_precision(d, kappa, seed):
 
 
 INTEGRATORS = {"fixed": (ai.fixedLeapFrog, ol.I_FIXED), "D": (ai.adaptLeapFrogD, ol.I_ADAPT_D),
-               "R2P": (ai.adaptLeapFrogR2P, ol.I_ADAPT_R2P)}
+               "R2P": (ai.adaptLeapFrogR2P, ol.I_ADAPT_R2P), "Y": (ai.adaptYoshidaD, ol.I_ADAPT_YOSHIDA)}
 
 
 def gen_q0_sumsq(q):
@@ -218,6 +218,12 @@ def main():
         warm=dict(warmupIter=25, adaptDelta=False))
     add("std4_D_warm_noH", ol.T_STDGAUSS, td.stdGauss, rng.normal(size=4), "D",
         H0=0.8, delta0=0.2, numIter=40, M=6, warm=dict(warmupIter=30, adaptH=False, adaptDeltaQuantile=0.8))
+    # adaptYoshidaD (adaptiveIntegrators.py:142-240), SURVEY.md 8f rank 2
+    add("std3_Y", ol.T_STDGAUSS, td.stdGauss, rng.normal(size=3), "Y", H0=1.5, delta0=0.01, numIter=25, M=6)
+    add("funnel_Y", ol.T_FUNNEL10, td.funnel10, np.r_[0.4, np.exp(0.2) * rng.normal(size=10)], "Y",
+        H0=0.5, delta0=0.05, numIter=15, M=6)
+    add("dense8_Y_warm", ol.T_DENSEGAUSS, make_dense(A8w), S8w @ rng.normal(size=8), "Y",
+        tpar=A8w.ravel(), H0=0.8, delta0=0.05, numIter=30, M=6, warm=dict(warmupIter=20))
     add("corr_R2P", ol.T_CORRGAUSS, td.corrGauss, np.array([1.0, 0.0]), "R2P",
         H0=0.7, delta0=0.1, numIter=25, M=7)
     add("smile_D", ol.T_SMILE, td.smileDistr, np.array([0.3, -0.2]), "D",
@@ -265,7 +271,7 @@ def main():
                ("funnel", ol.T_FUNNEL10, td.funnel10, None, 11),
                ("dense6", ol.T_DENSEGAUSS, make_dense(A6), A6.ravel(), 6)]
     for tname, tk, lpF, tpar, d in targets:
-        for ig in ("fixed", "D", "R2P"):
+        for ig in ("fixed", "D", "R2P", "Y"):
             fn, kind = INTEGRATORS[ig]
             for rep in range(6):
                 q = krng.normal(size=d)

@@ -45,7 +45,7 @@ def WALNUTS(lpFun, q0, generated=identity, integrator=ai.fixedLeapFrog, H0=0.2,
                         "run inside the fused GPU kernel")
     if not isinstance(integrator, ai.DeviceIntegrator):
         raise TypeError("integrator must be one of walnuts_amd.adaptiveIntegrators.{fixedLeapFrog,"
-                        "adaptLeapFrogD,adaptLeapFrogR2P}")
+                        "adaptLeapFrogD,adaptLeapFrogR2P,adaptYoshidaD}")
     # the reference sys.exit()s on bad adaptation targets whatever warmupIter is (WALNUTS.py:140,146)
     if adaptH and (adaptHtarget < 0.0 or adaptHtarget > 1.0):
         sys.exit("bad adaptHtarget")

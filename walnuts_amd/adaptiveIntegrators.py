@@ -61,3 +61,4 @@ class DeviceIntegrator:
 fixedLeapFrog = DeviceIntegrator("fixedLeapFrog", L.I_FIXED)            # adaptiveIntegrators.py:49
 adaptLeapFrogD = DeviceIntegrator("adaptLeapFrogD", L.I_ADAPT_D)        # adaptiveIntegrators.py:65
 adaptLeapFrogR2P = DeviceIntegrator("adaptLeapFrogR2P", L.I_ADAPT_R2P)  # adaptiveIntegrators.py:361
+adaptYoshidaD = DeviceIntegrator("adaptYoshidaD", L.I_ADAPT_YOSHIDA)    # adaptiveIntegrators.py:142

@@ -293,7 +293,7 @@ int wn_create(const wn_config* cfg, wn_engine** out) {
   // WALNUTS.py:140,146 sys.exit on bad tuning targets; the analogous argument checks here
   if (cfg->dim < 1 || cfg->n_chains < 1) { g_create_err = "dim and n_chains must be >= 1"; return WN_E_ARG; }
   if (cfg->M < 1 || cfg->M > MAX_M) { g_create_err = "M out of range [1,24]"; return WN_E_ARG; }
-  if (cfg->integrator < WN_I_FIXED || cfg->integrator > WN_I_ADAPT_R2P) { g_create_err = "unknown integrator"; return WN_E_ARG; }
+  if (cfg->integrator < WN_I_FIXED || cfg->integrator > WN_I_ADAPT_YOSHIDA) { g_create_err = "unknown integrator"; return WN_E_ARG; }
   if (cfg->min_c < 0 || cfg->max_c < cfg->min_c || cfg->max_c > 20) { g_create_err = "need 0 <= minC <= maxC <= 20"; return WN_E_ARG; }
   if (!(cfg->H0 > 0.0) || !(cfg->delta0 > 0.0) || cfg->step_size_rand_scale < 0.0 || cfg->step_size_rand_scale >= 1.0) {
     g_create_err = "need H0 > 0, delta0 > 0, 0 <= stepSizeRandScale < 1"; return WN_E_ARG;

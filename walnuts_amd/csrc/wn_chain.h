@@ -31,7 +31,7 @@
 namespace wn {
 
 enum { T_STDGAUSS = 0, T_FUNNEL10, T_DENSEGAUSS, T_DIAGGAUSS, T_CORRGAUSS, T_SMILE, T_FUNNEL1, T_MODFUNNEL };
-enum { I_FIXED = 0, I_ADAPT_D = 1, I_ADAPT_R2P = 2 };
+enum { I_FIXED = 0, I_ADAPT_D = 1, I_ADAPT_R2P = 2, I_ADAPT_YOSHIDA = 3 };
 enum { G_IDENTITY = 0, G_Q0_SUMSQ = 1, G_FIRSTK = 2 };
 enum { MODE_SAMPLE = 0, MODE_KAT = 1 };
 enum { NDIAG = 24, TRACE_NSCAL = 12 };
@@ -132,6 +132,7 @@ struct Engine {
   enum { PH_FWD = 0, PH_FWD2 = 1, PH_BWD = 2 };
   bool needMacro, needPass, fin, needIter, needDoubling, endIter;
   int ph, c, im, nstep, If, Ib, cSim, maxTry, nEvF, nEvB, cret;
+  int sub;  // adaptYoshidaD: leapfrog sub-step 0..2 inside the current micro step
   double h, hh, Ham0, HamPass0, lwtf, lwt, lpn, Hn, lpOut, HOut, lpCur, HCur;
   bool allfin, inPass;
   uint32_t firemask;
@@ -287,6 +288,7 @@ struct Engine {
   template <bool B_ = ADAPT>
   WN_HD typename std::enable_if<B_>::type setup_pass() {
     needPass = false;
+    sub = 0;
     nstep = 1 << c;
     hh = h / (double)nstep;  // adaptiveIntegrators.py:70-71
     im = 0;
@@ -362,7 +364,7 @@ struct Engine {
     if (ADAPT && ph == PH_BWD) restore_out();
     lpn = ADAPT ? lpOut : lpn;
     Hn = ADAPT ? HOut : Hn;
-    if (prm.integrator == I_ADAPT_D) {  // :135-137
+    if (prm.integrator == I_ADAPT_D || prm.integrator == I_ADAPT_YOSHIDA) {  // :135-137 / :238-240
       cret = If;
       lwt = (If != Ib) ? WN_LOGZERO : 0.0;
     } else if (prm.integrator == I_ADAPT_R2P) {  // :466-475
@@ -379,6 +381,13 @@ struct Engine {
   // energy bookkeeping of ONE micro step (adaptiveIntegrators.py:79-84): cheap, so several micro
   // steps of a long pass can run back to back before the heavier per-pass / per-step logic
   WN_HD void micro_account(double lp, double ke) {
+    if (prm.integrator == I_ADAPT_YOSHIDA && sub < 2) {  // adaptiveIntegrators.py:157-167: not yet a full step
+      sub++;
+      if (ph == PH_BWD) nEvB++; else nEvF++;
+      inPass = true;
+      return;
+    }
+    sub = 0;
     const double Hi = -lp + 0.5 * ke;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
     lpCur = lp; HCur = Hi;
     if (WARM) {  // np.max(np.abs(np.diff(Hams))) of the running pass (adaptiveIntegrators.py:101)
@@ -795,7 +804,7 @@ struct Engine {
     bothEndsPassive = false;
     minIf = minc = 1 << 30; maxIf = maxc = -(1 << 30); nneq = nzero = nused = 0;
     minlw = INFINITY; maxlw = -INFINITY;
-    ph = PH_FWD; c = im = nstep = If = Ib = cSim = maxTry = nEvF = nEvB = cret = 0;
+    ph = PH_FWD; c = im = nstep = If = Ib = cSim = maxTry = nEvF = nEvB = cret = 0; sub = 0;
     hh = Ham0 = HamPass0 = lwtf = lwt = lpCur = HCur = 0.0;
     allfin = true; inPass = false;
     WN_VFOR(e) { va.x[e] = 0.0; ga.x[e] = 0.0; }
@@ -873,7 +882,12 @@ struct Engine {
       int kin = 0;
       do {
         const bool act = live && !needIter && (kin == 0 || inPass);
-        const double hh2 = act ? 0.5 * hh : 0.0, hq = act ? hh : 0.0;
+        double hh2 = act ? 0.5 * hh : 0.0, hq = act ? hh : 0.0;
+        if (ADAPT && prm.integrator == I_ADAPT_YOSHIDA && act) {
+          // 4th-order composition (adaptiveIntegrators.py:143-144): sub-steps firstLast, middle, firstLast
+          const double w = sub == 1 ? -1.702414383919315 : 1.351207191959658;
+          hh2 = 0.5 * w * hh; hq = w * hh;
+        }
         WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; Q.x[e] = Q.x[e] + hq * V.x[e]; }
         p.grad(Q, G, part[0]);
         WN_STAMP(1);
