@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--workload", default="gauss100", choices=["gauss100", "funnel"],
                     help="gauss100 = BASELINE configs[1] family (headline); funnel = configs[2] "
                          "(funnel10, adaptLeapFrogR2P, M=12, H0=0.3, delta0=0.3; SURVEY 8d cfg 3)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the SURVEY 8d side measurements (C=1024, diagonal-precision variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (see profiles/)")
@@ -233,6 +235,32 @@ def main():
                                   "method": "rank-normalised split bulk ESS over all chains of one launch"}
         except Exception as ex:  # the throughput line must not depend on the ESS estimator
             out["ess_per_sec"] = {"error": repr(ex)}
+        if world == 1 and not args.no_extras and args.workload == "gauss100":
+            # SURVEY 8d cfg 2 side numbers, one launch each, outside the timed region:
+            # BASELINE configs[1]'s chain count (1024) and the diagonal-precision variant (HBM-style target)
+            extras = {}
+            try:
+                e2 = wa.Engine(D, 1024, integrator=L.I_FIXED, H0=args.H0, stepSizeRandScale=0.2, M=args.M,
+                               generated=L.G_Q0_SUMSQ, device=dev.index).set_target(L.T_DENSEGAUSS, A)
+                e2.run(q0d[:1024], SEED + 77, args.iters)
+                s2, d2 = e2.run(q0d[:1024], SEED, args.iters)
+                st = float((d2[:, :, 6].sum() + d2[:, :, 7].sum()).item())
+                extras["dense_1024_chains"] = {"value": st / (e2.last_run_ms() * 1e-3), "unit": "leapfrog steps/s"}
+                e2.close()
+                lam = np.logspace(0.0, np.log10(args.kappa), D)
+                e3 = wa.Engine(D, C, integrator=L.I_FIXED, H0=args.H0, stepSizeRandScale=0.2, M=args.M,
+                               generated=L.G_Q0_SUMSQ, device=dev.index).set_target(L.T_DIAGGAUSS, 1.0 / lam)
+                qd = torch.as_tensor(np.random.default_rng([SEED, 9]).normal(size=(C, D)) * np.sqrt(lam), device=dev)
+                e3.run(qd, SEED + 77, args.iters)
+                s3, d3 = e3.run(qd, SEED, args.iters)
+                st = float((d3[:, :, 6].sum() + d3[:, :, 7].sum()).item())
+                ms3 = e3.last_run_ms()
+                extras["diag_variant"] = {"value": st / (ms3 * 1e-3), "unit": "leapfrog steps/s", "kernel": e3.kernel_name,
+                                          "hbm_roofline_GBps_at_48D_bytes_per_step": st * 48.0 * D / (ms3 * 1e-3) / 1e9}
+                e3.close()
+            except Exception as ex:
+                extras["error"] = repr(ex)
+            out["extras"] = extras
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
