@@ -117,6 +117,13 @@ int wn_run(wn_engine *e, const double *q0_dev, uint64_t seed, int32_t n_iter, do
            double *diag_dev, double *trace_dev, int32_t trace_cap, int32_t *trace_n_dev,
            void *stream);
 
+/* wn_run with recordOrbitStats=True (WALNUTS.py:128,182-184,724-725): additionally fills
+ * orbit_min_dev / orbit_max_dev [C][n_iter][dg] with the per-iteration minimum / maximum of
+ * generated(q) over the states of the orbit.  generated must be WN_G_IDENTITY or WN_G_FIRSTK. */
+int wn_run_orbit_stats(wn_engine *e, const double *q0_dev, uint64_t seed, int32_t n_iter,
+                       double *samples_dev, double *diag_dev, double *orbit_min_dev,
+                       double *orbit_max_dev, void *stream);
+
 /* One macro step for a batch of independent states -- the integrator plugin call
  * integrator(q,v,g,Ham0,h,xi,lpFun,delta,auxPar) -> integratorReturn
  * (adaptiveIntegrators.py:17-29,49,65,361).  Arrays are [B][D] / [B]; u_r2p_dev holds the

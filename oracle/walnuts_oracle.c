@@ -636,6 +636,24 @@ static void generated(const wno_config *cfg, const double *q, double *out) {
   }
 }
 
+/* orbitMin/orbitMax update: np.minimum / np.maximum (nan-propagating), WALNUTS.py:332-333 etc. */
+static void orbit_stats(const wno_config *cfg, int iterN, const double *q, int init) {
+  if (!cfg->orbitMin) return;
+  const int dg = wno_gen_dim(cfg);
+  double tmp[1024];
+  double *g = dg <= 1024 ? tmp : (double *)malloc(sizeof(double) * dg);
+  generated(cfg, q, g);
+  double *mn = cfg->orbitMin + (size_t)(iterN - 1) * dg, *mx = cfg->orbitMax + (size_t)(iterN - 1) * dg;
+  for (int k = 0; k < dg; ++k) {
+    if (init) { mn[k] = g[k]; mx[k] = g[k]; }
+    else {
+      mn[k] = (isnan(g[k]) || isnan(mn[k])) ? NAN : (g[k] < mn[k] ? g[k] : mn[k]);
+      mx[k] = (isnan(g[k]) || isnan(mx[k])) ? NAN : (g[k] > mx[k] ? g[k] : mx[k]);
+    }
+  }
+  if (g != tmp) free(g);
+}
+
 /* np.min / np.max over a slice (nan-propagating) */
 static double np_max(const double *x, int lo, int hi) {
   double m = x[lo];
@@ -780,6 +798,7 @@ int wno_walnuts(const wno_config *cfg, const double *q0, double *samples, double
     double WoldSum = 1.0, WnewSum = 0.0;
     double lwtSumb = 0.0, lwtSumf = 0.0; /* :263-264 */
     int forcedReject = 0, bothEndsPassive = 0, stopCode = 0;
+    orbit_stats(cfg, iterN, qc, 1); /* :274-276 */
 
     for (int i = 0; i < M; ++i) { /* :281 */
       S.idoubl = i;
@@ -810,6 +829,7 @@ int wno_walnuts(const wno_config *cfg, const double *q0, double *samples, double
           memcpy(qProp, qp, sizeof(double) * d); /* :326 */
           L_ = 1;
           indexStat_ = timeLenF_;
+          orbit_stats(cfg, iterN, qp, 0); /* :331-333 */
           WoldSum = 1.0; WnewSum = Wnew; /* :368-369 */
         } else { /* :335-361 */
           call_integrator(&S, qm, vm, gm, Hs[I0], HLoc, xi, delta, q1, v1, g1, &r);
@@ -826,6 +846,7 @@ int wno_walnuts(const wno_config *cfg, const double *q0, double *samples, double
           memcpy(qProp, qm, sizeof(double) * d);
           L_ = -1;
           indexStat_ = -timeLenB_;
+          orbit_stats(cfg, iterN, qm, 0); /* :364-366 */
           WoldSum = 1.0; WnewSum = Wnew;
         }
       } else { /* :381 */
@@ -861,6 +882,7 @@ int wno_walnuts(const wno_config *cfg, const double *q0, double *samples, double
               }
               if (ss_push(&st, i1, qm, vm, gm)) { rc = -20; goto done; } /* :431 */
               orbitLen_ += HLoc1[0];
+              orbit_stats(cfg, iterN, qm, 0); /* :434-436 */
               memcpy(qtmp, qm, sizeof(double) * d); /* :438-439 */
               memcpy(vtmp, vm, sizeof(double) * d);
               int i2 = p1; /* :442 */
@@ -883,6 +905,7 @@ int wno_walnuts(const wno_config *cfg, const double *q0, double *samples, double
               }
               if (ss_push(&st, i2, qm, vm, gm)) { rc = -20; goto done; } /* :470 */
               orbitLen_ += HLoc1[1];
+              orbit_stats(cfg, iterN, qm, 0); /* :474-476 */
               if (wno_stopcondition(d, qm, vm, qtmp, vtmp)) { expandFurther = 0; break; } /* :479 */
             } else { /* :485-570 forward */
               int i1 = p0;
@@ -905,6 +928,7 @@ int wno_walnuts(const wno_config *cfg, const double *q0, double *samples, double
               }
               if (ss_push(&st, i1, qp, vp, gp)) { rc = -20; goto done; } /* :518 */
               orbitLen_ += HLoc1[0];
+              orbit_stats(cfg, iterN, qp, 0); /* :521-523 */
               memcpy(qtmp, qp, sizeof(double) * d); /* :525-526 */
               memcpy(vtmp, vp, sizeof(double) * d);
               int i2 = p1; /* :529 */
@@ -927,6 +951,7 @@ int wno_walnuts(const wno_config *cfg, const double *q0, double *samples, double
               }
               if (ss_push(&st, i2, qp, vp, gp)) { rc = -20; goto done; } /* :560 */
               orbitLen_ += HLoc1[1];
+              orbit_stats(cfg, iterN, qp, 0); /* :564-566 */
               if (wno_stopcondition(d, qtmp, vtmp, qp, vp)) { expandFurther = 0; break; } /* :568 */
             }
           } else { /* :572-587 inner row */

@@ -89,6 +89,10 @@ typedef struct {
   const double *tape_u; /* [numIter][tape_u_stride] uniforms in call order, per iteration */
   int tape_u_stride;
   const double *tape_z; /* [numIter][d] standard normals, per iteration */
+  /* recordOrbitStats (WALNUTS.py:128,182-184,274-276,331-333,...): per-iteration min / max of
+   * generated(q) over the orbit states; [numIter][dg] each, or NULL */
+  double *orbitMin;
+  double *orbitMax;
   /* optional per-integrator-call trace */
   double *trace; /* [trace_cap][WNO_TRACE_NSCAL + 2*d] */
   int trace_cap;

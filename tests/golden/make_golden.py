@@ -97,7 +97,8 @@ def run_reference(lpFun, q0, integrator, seed=SEED, chain=0, generated=None, **k
         args = dict(kw)
         if generated is not None:
             args["generated"] = generated
-        samples, diag = wn.WALNUTS(lpFun, q0.copy(), integrator=logged, **args)
+        ret = wn.WALNUTS(lpFun, q0.copy(), integrator=logged, **args)
+        samples, diag = ret[0], ret[1]
     finally:
         np.random.uniform, np.random.normal = saved
     numIter = kw["numIter"]
@@ -106,8 +107,10 @@ def run_reference(lpFun, q0, integrator, seed=SEED, chain=0, generated=None, **k
     for i, u in enumerate(tape.u_used):
         tu[i, :len(u)] = u
     tz = np.array(tape.z_used)
-    return dict(samples=samples, diagnostics=diag, trace=np.array(trace), tape_u=tu, tape_z=tz,
-                n_u=nu)
+    res = dict(samples=samples, diagnostics=diag, trace=np.array(trace), tape_u=tu, tape_z=tz, n_u=nu)
+    if len(ret) == 4:
+        res["orbitMin"], res["orbitMax"] = ret[2], ret[3]
+    return res
 
 
 # ---- targets that are not in the reference, as reference-convention callables
@@ -218,6 +221,12 @@ def main():
         warm=dict(warmupIter=25, adaptDelta=False))
     add("std4_D_warm_noH", ol.T_STDGAUSS, td.stdGauss, rng.normal(size=4), "D",
         H0=0.8, delta0=0.2, numIter=40, M=6, warm=dict(warmupIter=30, adaptH=False, adaptDeltaQuantile=0.8))
+    # recordOrbitStats (WALNUTS.py:182-184, 331-333), SURVEY.md 8f rank 3
+    add("funnel_R2P_orbit", ol.T_FUNNEL10, td.funnel10, np.r_[-1.0, np.exp(-0.5) * rng.normal(size=10)], "R2P",
+        H0=0.3, delta0=0.3, numIter=20, M=8, generated=ol.G_FIRSTK, gen_k=2,
+        genfn=lambda q: np.array([q[0], q[1]]), recordOrbitStats=True)
+    add("std3_fixed_orbit", ol.T_STDGAUSS, td.stdGauss, rng.normal(size=3), "fixed",
+        H0=0.6, numIter=25, M=7, recordOrbitStats=True)
     # adaptYoshidaD (adaptiveIntegrators.py:142-240), SURVEY.md 8f rank 2
     add("std3_Y", ol.T_STDGAUSS, td.stdGauss, rng.normal(size=3), "Y", H0=1.5, delta0=0.01, numIter=25, M=6)
     add("funnel_Y", ol.T_FUNNEL10, td.funnel10, np.r_[0.4, np.exp(0.2) * rng.normal(size=10)], "Y",
@@ -253,8 +262,9 @@ def main():
         out[pre + "q0"] = c["q0"]
         if c["tpar"] is not None:
             out[pre + "tpar"] = np.asarray(c["tpar"], float)
-        for k in ("samples", "diagnostics", "trace", "tape_u", "tape_z", "n_u"):
-            out[pre + k] = res[k]
+        for k in ("samples", "diagnostics", "trace", "tape_u", "tape_z", "n_u", "orbitMin", "orbitMax"):
+            if k in res:
+                out[pre + k] = res[k]
         d6 = res["diagnostics"]
         print(f"{c['name']:22s} calls={len(res['trace']):5d} evals={int(d6[:,6].sum()+d6[:,7].sum()):6d} "
               f"stop={sorted(set(d6[:,19].astype(int)))} depth~{d6[:,20].mean():.2f}")

@@ -33,7 +33,7 @@ class Params(C.Structure):
         ("kxi", ip), ("kq1", dp), ("kv1", dp), ("kg1", dp), ("kdout", dp), ("kiout", ip),
         ("warmupIter", C.c_int), ("adaptH", C.c_int), ("adaptDelta", C.c_int),
         ("adaptHtarget", C.c_double), ("adaptDeltaTarget", C.c_double), ("adaptDeltaQuantile", C.c_double),
-        ("facs", dp), ("stamps", C.c_void_p),
+        ("facs", dp), ("omin", dp), ("omax", dp), ("stamps", C.c_void_p),
     ]
 
 
@@ -65,7 +65,7 @@ def _p(a, t=dp):
 def walnuts(target, q0, integrator=0, tpar=None, H0=0.2, stepSizeRandScale=0.2, delta0=0.05,
             numIter=10, M=10, minC=0, maxC=10, R2Pprob0=2.0 / 3.0, generated=0, gen_k=0, seed=0,
             chain0=0, trace_cap=0, warmupIter=0, adaptH=True, adaptHtarget=0.8, adaptDelta=True,
-            adaptDeltaTarget=0.6, adaptDeltaQuantile=0.9):
+            adaptDeltaTarget=0.6, adaptDeltaQuantile=0.9, recordOrbitStats=False):
     q0 = np.ascontiguousarray(np.atleast_2d(np.asarray(q0, float)))
     Cn, D = q0.shape
     prm = Params()
@@ -91,7 +91,14 @@ def walnuts(target, q0, integrator=0, tpar=None, H0=0.2, stepSizeRandScale=0.2, 
     prm.adaptDeltaQuantile = adaptDeltaQuantile
     facs = np.zeros((Cn, 2, max(warmupIter, 1)))
     prm.facs = _p(facs)
+    omin = omax = None
+    if recordOrbitStats:
+        omin = np.zeros((Cn, numIter, dg)); omax = np.zeros((Cn, numIter, dg))
+        prm.omin = _p(omin); prm.omax = _p(omax)
     rc = lib().hostsim_run(C.byref(prm), target)
     if rc:
         raise RuntimeError(f"hostsim rc={rc}")
+    if recordOrbitStats:
+        return dict(samples=samples.transpose(0, 2, 1).copy(), diagnostics=diag, trace=trace, trace_n=tn,
+                    orbitMin=omin.transpose(0, 2, 1).copy(), orbitMax=omax.transpose(0, 2, 1).copy())
     return dict(samples=samples.transpose(0, 2, 1).copy(), diagnostics=diag, trace=trace, trace_n=tn)

@@ -34,6 +34,7 @@ class WnoConfig(C.Structure):
         ("adaptDeltaTarget", C.c_double), ("adaptDeltaQuantile", C.c_double),
         ("rng_mode", C.c_int), ("seed", C.c_uint64), ("chain", C.c_uint32),
         ("tape_u", c_double_p), ("tape_u_stride", C.c_int), ("tape_z", c_double_p),
+        ("orbitMin", c_double_p), ("orbitMax", c_double_p),
         ("trace", c_double_p), ("trace_cap", C.c_int),
     ]
 
@@ -160,7 +161,7 @@ def walnuts(target, q0, integrator=I_FIXED, tpar=None, H0=0.2, stepSizeRandScale
             numIter=10, warmupIter=0, M=10, minC=0, maxC=10, R2Pprob0=2.0 / 3.0,
             generated=G_IDENTITY, gen_k=0, seed=0, chain=0, tape_u=None, tape_z=None,
             trace_cap=0, adaptH=True, adaptHtarget=0.8, adaptDelta=True, adaptDeltaTarget=0.6,
-            adaptDeltaQuantile=0.9):
+            adaptDeltaQuantile=0.9, recordOrbitStats=False):
     """One chain of the oracle's WALNUTS.  Returns dict(samples (dg,numIter+1), diagnostics
     (numIter,24), trace (ncalls, 12+2d), n_u (numIter,))."""
     q0 = _f64(q0); d = q0.size
@@ -187,6 +188,10 @@ def walnuts(target, q0, integrator=I_FIXED, tpar=None, H0=0.2, stepSizeRandScale
     tr = np.zeros((max(trace_cap, 1), ncol)) if trace_cap else None
     cfg.trace = _dp(tr); cfg.trace_cap = trace_cap
     dg = lib().wno_gen_dim(C.byref(cfg))
+    omin = omax = None
+    if recordOrbitStats:
+        omin = np.zeros((numIter, dg)); omax = np.zeros((numIter, dg))
+        cfg.orbitMin = _dp(omin); cfg.orbitMax = _dp(omax)
     samples = np.zeros((numIter + 1, dg)); diag = np.zeros((numIter, NDIAG))
     nu = np.zeros(numIter, dtype=np.int32)
     rc = lib().wno_walnuts(C.byref(cfg), _dp(q0), _dp(samples), _dp(diag),
@@ -194,6 +199,8 @@ def walnuts(target, q0, integrator=I_FIXED, tpar=None, H0=0.2, stepSizeRandScale
     if rc < 0:
         raise RuntimeError(f"wno_walnuts rc={rc}")
     out = dict(samples=samples.T.copy(), diagnostics=diag, n_u=nu, ncalls=rc)
+    if recordOrbitStats:
+        out["orbitMin"] = omin.T.copy(); out["orbitMax"] = omax.T.copy()
     if tr is not None:
         out["trace"] = tr[:min(rc, trace_cap)]
     return out

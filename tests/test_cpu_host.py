@@ -59,7 +59,11 @@ def test_state_machine_on_host_matches_oracle(name):
                    generated=c["generated"], gen_k=c["gen_k"], seed=seed, chain0=c["chain"],
                    trace_cap=len(ref["trace"]) + 8, warmupIter=c["warmupIter"], adaptH=c["adaptH"],
                    adaptHtarget=c["adaptHtarget"], adaptDelta=c["adaptDelta"],
-                   adaptDeltaTarget=c["adaptDeltaTarget"], adaptDeltaQuantile=c["adaptDeltaQuantile"])
+                   adaptDeltaTarget=c["adaptDeltaTarget"], adaptDeltaQuantile=c["adaptDeltaQuantile"],
+                   recordOrbitStats="orbitMin" in ref)
+    if "orbitMin" in ref:
+        tg.close(h["orbitMin"][0], o["orbitMin"], rtol=1e-12, atol=1e-13)
+        tg.close(h["orbitMax"][0], o["orbitMax"], rtol=1e-12, atol=1e-13)
     n = o["ncalls"]
     assert int(h["trace_n"][0]) == n
     tr = h["trace"][0, :n]

@@ -53,6 +53,8 @@ def load_case(name):
     c.update(warmupIter=int(w[0]), adaptH=bool(w[1]), adaptHtarget=float(w[2]), adaptDelta=bool(w[3]),
              adaptDeltaTarget=float(w[4]), adaptDeltaQuantile=float(w[5]))
     ref = {k: TR[p + k] for k in ("samples", "diagnostics", "trace", "n_u")}
+    if (p + "orbitMin") in TR.files:
+        ref["orbitMin"] = TR[p + "orbitMin"]; ref["orbitMax"] = TR[p + "orbitMax"]
     return c, ref
 
 
@@ -95,6 +97,27 @@ def test_golden_trace_through_c_abi(wa, name):
     c, ref = load_case(name)
     out = run_engine(wa, c, c["q0"], len(ref["trace"]) + 8, c["chain"])
     compare_chain(out, 0, ref["trace"], ref["samples"], ref["diagnostics"], name)
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if n.endswith("_orbit")])
+def test_record_orbit_stats_matches_reference(wa, name):
+    """recordOrbitStats=True (WALNUTS.py:182-184, 724-725): per-iteration min/max of generated(q)."""
+    c, ref = load_case(name)
+    e = wa.Engine(c["q0"].size, 1, integrator=c["integrator"], H0=c["H0"], stepSizeRandScale=c["s"], delta0=c["delta0"],
+                  M=c["M"], minC=c["minC"], maxC=c["maxC"], R2Pprob0=c["R2Pprob0"], generated=c["generated"],
+                  gen_k=c["gen_k"], chain_offset=c["chain"])
+    e.set_target(c["target"], c["tpar"])
+    s, d, omin, omax = e.run_orbit_stats(c["q0"][None], SEED, c["numIter"])
+    close(omin.cpu().numpy()[0].T, ref["orbitMin"], what="orbitMin")
+    close(omax.cpu().numpy()[0].T, ref["orbitMax"], what="orbitMax")
+    close(s.cpu().numpy()[0].T, ref["samples"], what="samples")
+    e.close()
+    from walnuts_amd import adaptiveIntegrators as ai, targetDistr as td
+    if name == "std3_fixed_orbit":  # the 4-tuple return of the Python mirror
+        r = wa.WALNUTS(td.stdGauss, c["q0"], integrator=ai.fixedLeapFrog, H0=c["H0"], numIter=c["numIter"], warmupIter=0,
+                       M=c["M"], recordOrbitStats=True, seed=SEED, chain_offset=c["chain"])
+        assert len(r) == 4 and r[2].shape == (3, c["numIter"])
+        close(r[2], ref["orbitMin"], what="orbitMin via WALNUTS()")
 
 
 def test_rng_tape_matches_oracle(wa):

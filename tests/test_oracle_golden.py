@@ -42,6 +42,8 @@ def load_case(name):
     c.update(warmupIter=int(w[0]), adaptH=bool(w[1]), adaptHtarget=float(w[2]), adaptDelta=bool(w[3]),
              adaptDeltaTarget=float(w[4]), adaptDeltaQuantile=float(w[5]))
     ref = {k: TR[p + k] for k in ("samples", "diagnostics", "trace", "tape_u", "tape_z", "n_u")}
+    if (p + "orbitMin") in TR.files:
+        ref["orbitMin"] = TR[p + "orbitMin"]; ref["orbitMax"] = TR[p + "orbitMax"]
     return c, ref
 
 
@@ -52,7 +54,7 @@ def run_oracle(c, ref, tape=True):
               generated=c["generated"], gen_k=c["gen_k"], trace_cap=len(ref["trace"]) + 8,
               warmupIter=c["warmupIter"], adaptH=c["adaptH"], adaptHtarget=c["adaptHtarget"],
               adaptDelta=c["adaptDelta"], adaptDeltaTarget=c["adaptDeltaTarget"],
-              adaptDeltaQuantile=c["adaptDeltaQuantile"])
+              adaptDeltaQuantile=c["adaptDeltaQuantile"], recordOrbitStats="orbitMin" in ref)
     if tape:
         tu = np.nan_to_num(ref["tape_u"], nan=0.5)
         kw.update(tape_u=tu, tape_z=ref["tape_z"])
@@ -86,6 +88,9 @@ def test_walnuts_trace_matches_reference(name, tape):
         np.testing.assert_array_equal(tr[:, 12:], rt[:, 12:])  # per-step (q, v)
         np.testing.assert_array_equal(out["samples"], ref["samples"])
         np.testing.assert_array_equal(tr[:, 3:6], rt[:, 3:6])
+    if "orbitMin" in ref:
+        close(out["orbitMin"], ref["orbitMin"], rtol=1e-9, atol=1e-11)
+        close(out["orbitMax"], ref["orbitMax"], rtol=1e-9, atol=1e-11)
     d, rd = out["diagnostics"], ref["diagnostics"]
     for col in (0, 1, 4, 5, 6, 7, 8, 9, 12, 13, 19, 20, 21, 22):
         np.testing.assert_array_equal(d[:, col], rd[:, col], err_msg=f"diag col {col}")

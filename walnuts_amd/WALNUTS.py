@@ -51,8 +51,6 @@ def WALNUTS(lpFun, q0, generated=identity, integrator=ai.fixedLeapFrog, H0=0.2,
         sys.exit("bad adaptHtarget")
     if adaptDelta and adaptDeltaTarget < 0.0:
         sys.exit("bad adaptDeltaTarget")
-    if recordOrbitStats:
-        raise NotImplementedError("recordOrbitStats (WALNUTS.py:182-184) is not on the device yet")
     host_gen = None
     if not isinstance(generated, Generated):
         if not callable(generated):
@@ -69,7 +67,13 @@ def WALNUTS(lpFun, q0, generated=identity, integrator=ai.fixedLeapFrog, H0=0.2,
                  adaptDelta=adaptDelta, adaptDeltaTarget=adaptDeltaTarget,
                  adaptDeltaQuantile=adaptDeltaQuantile)
     eng.set_target(lpFun.kind, lpFun.params)
-    out = eng.run(q0a, seed, numIter, trace_cap=trace_cap)
+    if recordOrbitStats:
+        if host_gen is not None or generated.kind == L.G_Q0_SUMSQ:
+            raise NotImplementedError("recordOrbitStats needs generated = identity or firstk(k) on the device")
+        samples, diag, omin, omax = eng.run_orbit_stats(q0a, seed, numIter)
+        out = (samples, diag, omin.transpose(1, 2), omax.transpose(1, 2))  # (dg, numIter) per chain (WALNUTS.py:183-184)
+    else:
+        out = eng.run(q0a, seed, numIter, trace_cap=trace_cap)
     samples, diag = out[0], out[1]
     samples = samples.transpose(1, 2)  # [C, dg, numIter+1] as the reference's (dg, numIter+1)
     if return_torch:

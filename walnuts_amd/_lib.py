@@ -35,7 +35,7 @@ class WnConfig(C.Structure):
 
 
 # every symbol include/walnuts_amd.h declares
-SYMBOLS = ["wn_abi_version", "wn_create", "wn_set_target", "wn_run", "wn_integrator_step",
+SYMBOLS = ["wn_abi_version", "wn_create", "wn_set_target", "wn_run", "wn_run_orbit_stats", "wn_integrator_step",
            "wn_lpfun", "wn_lpfun_kind", "wn_ext_orbit", "wn_rng_tape", "wn_last_run_ms", "wn_kernel_name", "wn_last_error",
            "wn_destroy"]
 
@@ -61,6 +61,8 @@ def lib():
     L.wn_set_target.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     L.wn_run.restype = C.c_int
     L.wn_run.argtypes = [vp, vp, C.c_uint64, C.c_int32, vp, vp, vp, C.c_int32, vp, vp]
+    L.wn_run_orbit_stats.restype = C.c_int
+    L.wn_run_orbit_stats.argtypes = [vp, vp, C.c_uint64, C.c_int32, vp, vp, vp, vp, vp]
     L.wn_integrator_step.restype = C.c_int
     L.wn_integrator_step.argtypes = [vp] * 14
     L.wn_lpfun.restype = C.c_int

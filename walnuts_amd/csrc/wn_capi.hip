@@ -364,6 +364,8 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
   e->work_doubles = kernel_work_doubles(kc, e->cfg.n_chains, e->cfg.M);
   HIPCHK(e, hipMalloc((void**)&e->work, e->work_doubles * sizeof(double)));
   HIPCHK(e, hipMemset(e->work, 0, e->work_doubles * sizeof(double)));
+  if (e->cfg.warmup_iter > 0 && !e->facs)
+    HIPCHK(e, hipMalloc((void**)&e->facs, (size_t)e->cfg.n_chains * 2 * e->cfg.warmup_iter * sizeof(double)));
   e->kc = kc;
   e->have_kc = true;
   e->target = kind;
@@ -412,8 +414,7 @@ int wn_run(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, do
   p.numIter = n_iter; p.seed = seed;
   p.warmupIter = e->cfg.warmup_iter;
   if (p.warmupIter > 0 && (e->cfg.adapt_h || e->cfg.adapt_delta)) {
-    if (!e->facs) HIPCHK(e, hipMalloc((void**)&e->facs, (size_t)e->cfg.n_chains * 2 * p.warmupIter * sizeof(double)));
-    p.facs = e->facs;
+    p.facs = e->facs;  // allocated in wn_set_target (no allocation on the launch path)
   } else {
     p.warmupIter = 0;  // nothing adapts: the plain kernels are exact
   }
@@ -440,6 +441,23 @@ int wn_run(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, do
     return rc;
   }
 #endif
+  return launch(e, p, (hipStream_t)stream, true);
+}
+
+int wn_run_orbit_stats(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, double* samples_dev,
+                       double* diag_dev, double* orbit_min_dev, double* orbit_max_dev, void* stream) {
+  if (!e) return WN_E_ARG;
+  if (!e->have_kc) { e->err = "wn_set_target has not been called"; return WN_E_NOTARGET; }
+  if (!q0_dev || !samples_dev || !diag_dev || !orbit_min_dev || !orbit_max_dev || n_iter < 0) { e->err = "null buffer or negative n_iter"; return WN_E_ARG; }
+  if (e->cfg.generated == WN_G_Q0_SUMSQ) { e->err = "recordOrbitStats supports generated = identity / first-k"; return WN_E_UNSUPPORTED; }
+  HIPCHK(e, hipSetDevice(e->cfg.device));
+  Params p;
+  fill_params(e, &p);
+  p.mode = MODE_SAMPLE;
+  p.numIter = n_iter; p.seed = seed;
+  p.warmupIter = (e->cfg.warmup_iter > 0 && (e->cfg.adapt_h || e->cfg.adapt_delta)) ? e->cfg.warmup_iter : 0;
+  p.q0 = q0_dev; p.samples = samples_dev; p.diag = diag_dev;
+  p.omin = orbit_min_dev; p.omax = orbit_max_dev;
   return launch(e, p, (hipStream_t)stream, true);
 }
 

@@ -64,6 +64,9 @@ struct Params {
   int warmupIter, adaptH, adaptDelta;
   double adaptHtarget, adaptDeltaTarget, adaptDeltaQuantile;
   double* facs;  // [C][2][warmupIter] sorted energyErrorInfFacs, double-buffered
+  // recordOrbitStats (WALNUTS.py:128,182-184): [C][numIter][dg] min / max of generated(q) over the
+  // orbit states of each iteration, or null (generated = identity / first-k only)
+  double *omin, *omax;
   unsigned long long* stamps;  // diagnostic builds (-DWN_STAMPS): [block][wave][8] cycles per phase
 };
 
@@ -218,6 +221,7 @@ struct Engine {
       kp += z * z;
     }
     p.prop_get(ip, qa, ga);
+    orbit_stats(qa, true);
     p.template cold_put<COLD_QB>(qa);
     p.template cold_put<COLD_VB>(va);
     p.template cold_put<COLD_GB>(ga);
@@ -509,6 +513,25 @@ struct Engine {
   // ------------------------------------------------------------------------------------------
   // phase E: NUTS bookkeeping after a finalised macro step (WALNUTS.py:296-648)
   // ------------------------------------------------------------------------------------------
+  // orbitMin/orbitMax[:,iterN-1] = np.minimum/np.maximum(..., generated(q))  (WALNUTS.py:274-276,
+  // 331-333, 364-366, 434-436, ...): every lane updates the elements it owns, in memory
+  WN_HD void orbit_stats(const Vec& q, bool init) {
+    if (!prm.omin) return;
+    const int k = prm.generated == G_FIRSTK ? prm.gen_k : prm.D;
+    const size_t row = ((size_t)p.chain_local() * prm.numIter + (iter - 1)) * prm.dg;
+    WN_VFOR(e) if (p.valid(e) && p.owner(e) && p.gidx(e) < k) {
+      double* mn = prm.omin + row + p.gidx(e);
+      double* mx = prm.omax + row + p.gidx(e);
+      const double x = q.x[e];
+      if (init) { *mn = x; *mx = x; }
+      else {
+        const double a = *mn, b = *mx;
+        *mn = (isnan(x) || isnan(a)) ? NAN : (x < a ? x : a);
+        *mx = (isnan(x) || isnan(b)) ? NAN : (x > b ? x : b);
+      }
+    }
+  }
+
   WN_HD void pick_state(int idx) {
     if (ip == ipl) ip ^= 1;  // keep qPropLast intact
     p.prop_put(ip, QN(), GN());
@@ -576,6 +599,7 @@ struct Engine {
     const double lwtSum = xi > 0 ? lwtSumf : lwtSumb;
     const double Wnew = exp(-Hn + H0 + lwtSum);
     WN_STAMP(8);
+    orbit_stats(QN(), false);
     if (i == 0) {  // :322-328, 368-369: unconditional, no uniform
       WnewSum = Wnew;
       pick_state(idx);
@@ -734,9 +758,7 @@ struct Engine {
 
   WN_HD void end_iteration() {  // :653-695
     const int cl = p.chain_local();
-#ifndef WN_ABL_NOGEN
     emit_generated(iter);  // samples[:,iterN] = generated(qc), qc = qProp  (loads before the stores below)
-#endif
     double d[NDIAG];
     d[0] = L_; d[1] = NdS; d[2] = orbitLen_; d[3] = orbitLenSam_; d[4] = maxFint; d[5] = maxBint;
     d[6] = nevalF; d[7] = nevalB;
@@ -750,11 +772,7 @@ struct Engine {
     d[18] = dc; d[19] = (double)stopCode; d[20] = NdC; d[21] = ADAPT ? minc : 0; d[22] = ADAPT ? maxc : 0;
     d[23] = indexStat_;
     if (WARM && iter <= prm.warmupIter) adapt_update(d[17]);
-#if defined(WN_ABL_DIAGSAME)
-    p.diag_store(prm.diag + (size_t)cl * NDIAG, d);
-#elif !defined(WN_ABL_NODIAG)
     p.diag_store(prm.diag + ((size_t)cl * prm.numIter + (iter - 1)) * NDIAG, d);
-#endif
     iter++;
     endIter = false;
     needMacro = false;
@@ -833,9 +851,6 @@ struct Engine {
       p.grad(qa, ga, part[0]);
       p.template reduce<1>(part);
       lpP = p.lp_finish(part[0]);
-#ifdef WN_DEBUG_PRINT
-      if (p.chain_local() == 0) printf("[dbg] init lpP=%g part0=%g\n", lpP, part[0]);
-#endif
       p.prop_put(ip, qa, ga);
       if (live) {
         emit_generated(0);  // samples[:,0] = generated(q0)  (:164)

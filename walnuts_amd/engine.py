@@ -101,6 +101,20 @@ class Engine:
         self._keep = [q0]
         return (samples, diag, trace, tn) if trace_cap else (samples, diag)
 
+    def run_orbit_stats(self, q0, seed, n_iter):
+        """run() with recordOrbitStats: returns samples, diag, orbit_min, orbit_max ([C, n_iter, dg])."""
+        torch = self.torch
+        q0 = self._dev(q0).reshape(self.n_chains, self.dim)
+        samples = torch.zeros((self.n_chains, n_iter + 1, self.dg), dtype=torch.float64, device=self.device)
+        diag = torch.zeros((self.n_chains, n_iter, L.NDIAG), dtype=torch.float64, device=self.device)
+        omin = torch.zeros((self.n_chains, n_iter, self.dg), dtype=torch.float64, device=self.device)
+        omax = torch.zeros_like(omin)
+        P = lambda t: C.c_void_p(t.data_ptr())
+        self._check(self.lib.wn_run_orbit_stats(self.h, P(q0), C.c_uint64(int(seed)), int(n_iter), P(samples),
+                                                P(diag), P(omin), P(omax), self._stream()))
+        self._keep = [q0]
+        return samples, diag, omin, omax
+
     def last_run_ms(self):
         ms = C.c_float()
         self._check(self.lib.wn_last_run_ms(self.h, C.byref(ms)))
