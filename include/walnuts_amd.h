@@ -50,7 +50,10 @@ enum {
   /* (lpdf, grad) pairs of test/targets.py, used with walnuts() (walnuts/walnuts.py:362);
    * wn_ext_orbit / wn_lpfun only */
   WN_T_TT_CORRNORMAL = 8, /* test/targets.py:9-15 (D = 2; note its grad[0] = -q0 + rho*q1) */
-  WN_T_TT_FUNNEL = 9      /* test/targets.py:23-29 (any D >= 2; no log-scale term) */
+  WN_T_TT_FUNNEL = 9,     /* test/targets.py:23-29 (any D >= 2; no log-scale term) */
+  /* lpFun evaluated by the CALLER (targetDistr.py:18 `lpFun(q) -> [lp, grad]` as a batched callable
+   * on device buffers): wn_split_begin / wn_split_tick below; D <= 1024 */
+  WN_T_EXTERNAL = 10
 };
 
 /* macro-step integrator plugin  integrator(q,v,g,Ham0,h,xi,lpFun,delta,auxPar)
@@ -120,6 +123,30 @@ int wn_run(wn_engine *e, const double *q0_dev, uint64_t seed, int32_t n_iter, do
 /* wn_run with recordOrbitStats=True (WALNUTS.py:128,182-184,724-725): additionally fills
  * orbit_min_dev / orbit_max_dev [C][n_iter][dg] with the per-iteration minimum / maximum of
  * generated(q) over the states of the orbit.  generated must be WN_G_IDENTITY or WN_G_FIRSTK. */
+/* ---- caller-evaluated target (WN_T_EXTERNAL) ----------------------------------------------------
+ * The reference calls lpFun(q) once per leapfrog step of one chain (adaptiveIntegrators.py:53,78);
+ * here every chain advances by one gradient evaluation per wn_split_tick and the caller evaluates
+ * its target for ALL chains in between:
+ *
+ *   wn_split_ld(e, &ld);                                  // row stride of the exchange buffers
+ *   wn_split_begin(e, q0, seed, n_iter, samples, diag, q_eval, grad, lp, stream);
+ *   do {
+ *     lp[c], grad[c][0:D] = lpFun(q_eval[c][0:D]) for every chain c   (caller, on the same stream)
+ *     wn_split_tick(e, stream);
+ *     every so often: wn_split_done(e, &n_done, stream);  // synchronises
+ *   } while (n_done < n_chains);
+ *
+ * q_eval_dev / grad_dev are caller-owned [n_chains][ld] doubles, lp_dev [n_chains]; they must stay
+ * valid until the run has finished.  A NaN / -inf lp is a per-chain event as in the reference
+ * (mainSW.py:24-26, WALNUTS.py:316-319).  Rows of finished chains keep their last position; their
+ * lp / grad are ignored. */
+int wn_split_ld(wn_engine *e, int32_t *ld);
+int wn_split_begin(wn_engine *e, const double *q0_dev, uint64_t seed, int32_t n_iter,
+                   double *samples_dev, double *diag_dev, double *q_eval_dev,
+                   const double *grad_dev, const double *lp_dev, void *stream);
+int wn_split_tick(wn_engine *e, void *stream);
+int wn_split_done(wn_engine *e, int32_t *n_done, void *stream);
+
 int wn_run_orbit_stats(wn_engine *e, const double *q0_dev, uint64_t seed, int32_t n_iter,
                        double *samples_dev, double *diag_dev, double *orbit_min_dev,
                        double *orbit_max_dev, void *stream);

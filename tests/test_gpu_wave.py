@@ -1,0 +1,137 @@
+"""GPU parity tests of the one-chain-per-wavefront layout (wn_policy_wave.h):
+  * persistent kernels for large std / diagonal Gaussians (256 < D <= 1024),
+  * split mode with the batched FP64-MFMA gradient kernel (dense Gaussian, 128 < D <= 1024,
+    SURVEY.md 8d cfg 4),
+  * split mode with a caller-evaluated target (WN_T_EXTERNAL): the reference's lpFun plugin as a
+    batched device callable or as a per-chain host callable.
+Same bar as test_gpu_parity.py: per-step (q, v) trajectories against the CPU oracle on the same
+seed, rtol 1e-6, integers exact."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from test_gpu_parity import SEED, close, compare_chain, dense_problem, run_engine, wa  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+WAVE = [
+    # name, target, D, integrator, kwargs, C, check chains
+    ("std300_fixed_wave", ol.T_STDGAUSS, 300, ol.I_FIXED, dict(H0=1.4 * 300 ** -0.25, M=7, numIter=4), 5, (0, 4)),
+    ("diag600_R2P_wave", ol.T_DIAGGAUSS, 600, ol.I_ADAPT_R2P, dict(H0=0.9, delta0=0.3, M=6, numIter=3), 3, (0, 2)),
+    ("diag1000_D_wave", ol.T_DIAGGAUSS, 1000, ol.I_ADAPT_D, dict(H0=0.9, delta0=0.3, M=5, numIter=3), 2, (1,)),
+    ("std1024_fixed_wave", ol.T_STDGAUSS, 1024, ol.I_FIXED, dict(H0=1.4 * 1024 ** -0.25, M=6, numIter=3), 2, (0, 1)),
+    ("diag400_yoshida_wave", ol.T_DIAGGAUSS, 400, ol.I_ADAPT_YOSHIDA, dict(H0=1.2, delta0=0.1, M=5, numIter=3), 2, (0,)),
+    ("dense200_fixed_split", ol.T_DENSEGAUSS, 200, ol.I_FIXED, dict(H0=0.5, M=6, numIter=3), 70, (0, 63, 64, 69)),
+    ("dense300_R2P_split", ol.T_DENSEGAUSS, 300, ol.I_ADAPT_R2P, dict(H0=1.2, delta0=0.3, M=5, numIter=3), 6, (0, 5)),
+    ("dense520_D_split", ol.T_DENSEGAUSS, 520, ol.I_ADAPT_D, dict(H0=1.2, delta0=0.3, M=4, numIter=2), 3, (2,)),
+    ("dense1000_fixed_split", ol.T_DENSEGAUSS, 1000, ol.I_FIXED, dict(H0=0.5, M=5, numIter=2), 5, (0, 4)),
+]
+
+
+@pytest.mark.parametrize("case", WAVE, ids=[b[0] for b in WAVE])
+def test_wave_layout_matches_oracle(wa, case):
+    name, tk, D, ig, kw, C, check = case
+    rng = np.random.default_rng(43)
+    tpar = None
+    if tk == ol.T_DENSEGAUSS:
+        tpar, q0 = dense_problem(D, 100.0 if D >= 1000 else 1e4, C, 6)
+        tpar = tpar.ravel()
+    elif tk == ol.T_DIAGGAUSS:
+        tpar = 1.0 / np.logspace(0, 3, D)
+        q0 = rng.normal(size=(C, D)) / np.sqrt(tpar)
+    else:
+        q0 = rng.normal(size=(C, D))
+    c = dict(target=tk, integrator=ig, H0=kw["H0"], s=0.2, delta0=kw.get("delta0", 0.05), M=kw["M"],
+             numIter=kw["numIter"], minC=0, maxC=10, R2Pprob0=2.0 / 3.0, generated=0, gen_k=0, tpar=tpar)
+    cap = 3 * (2 ** kw["M"]) * kw["numIter"] // 2
+    out = run_engine(wa, c, q0, cap, chain_offset=9000)
+    assert ("wave" in out["kernel"]) or ("split" in out["kernel"]), out["kernel"]
+    for k in check:
+        o = ol.walnuts(tk, q0[k], integrator=ig, tpar=tpar, H0=c["H0"], delta0=c["delta0"],
+                       numIter=c["numIter"], M=c["M"], seed=SEED, chain=9000 + k, trace_cap=cap)
+        assert o["ncalls"] <= cap
+        compare_chain(out, k, o["trace"], o["samples"], o["diagnostics"], f"{name} chain {k} [{out['kernel']}]")
+
+
+def test_wave_warmup_and_generated(wa):
+    """Warm-up adaptation and generated = [q0, sum q^2] in the wave layout."""
+    rng = np.random.default_rng(8)
+    D, C = 320, 3
+    q0 = rng.normal(size=(C, D))
+    c = dict(target=ol.T_STDGAUSS, integrator=ol.I_ADAPT_R2P, H0=0.5, s=0.2, delta0=0.1, M=6, numIter=24,
+             minC=0, maxC=10, R2Pprob0=2.0 / 3.0, generated=ol.G_Q0_SUMSQ, gen_k=0, tpar=None, warmupIter=16)
+    out = run_engine(wa, c, q0, 4, chain_offset=50)
+    assert "wave" in out["kernel"]
+    for k in (0, 2):
+        o = ol.walnuts(ol.T_STDGAUSS, q0[k], integrator=ol.I_ADAPT_R2P, H0=0.5, delta0=0.1, numIter=24, M=6, seed=SEED,
+                       chain=50 + k, warmupIter=16, generated=ol.G_Q0_SUMSQ)
+        close(out["diagnostics"][k][:, [15, 18]], o["diagnostics"][:, [15, 18]], what=f"H/delta chain {k}")
+        np.testing.assert_array_equal(out["diagnostics"][k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]])
+        close(out["samples"][k], o["samples"], what=f"samples chain {k}")
+
+
+def test_split_dense_full_size_properties(wa):
+    """SURVEY.md 8d cfg 4 shape (D = 1000, kappa = 100, fixedLeapFrog, M = 10) at a reduced chain
+    count: size-independent properties -- every chain finishes, step counts are consistent with the
+    tree depths, energy errors are bounded, sharding the chains does not change any draw."""
+    D, C = 1000, 96
+    A, q0 = dense_problem(D, 100.0, C, 11)
+    def run(qs, off):
+        e = wa.Engine(D, qs.shape[0], integrator=ol.I_FIXED, H0=0.5, M=10, generated=ol.G_Q0_SUMSQ, chain_offset=off)
+        e.set_target(ol.T_DENSEGAUSS, A.ravel())
+        s, d = e.run(qs, SEED, 3)
+        s = s.cpu().numpy(); d = d.cpu().numpy(); ms = e.last_run_ms(); e.close()
+        return s, d, ms
+    s, d, ms = run(q0, 0)
+    assert np.isfinite(s).all() and np.isfinite(d).all()
+    steps = d[:, :, 6] + d[:, :, 7]
+    assert (steps >= 1).all() and (steps <= 2 ** 10 - 1).all()
+    np.testing.assert_array_equal(steps, 2.0 ** d[:, :, 20] - 1)  # fixedLeapFrog: 2^NdoublComputed - 1 gradient calls
+    assert (d[:, :, 17] < 5.0).all()  # orbit energy error stays bounded (stable step size)
+    s2, d2, _ = run(q0[64:], 64)
+    np.testing.assert_array_equal(s2, s[64:])
+    np.testing.assert_array_equal(d2, d[64:])
+
+
+def test_external_batched_callable_matches_fused_target(wa):
+    """WN_T_EXTERNAL with a batched torch callable for stdGauss reproduces the fused kernel."""
+    import torch
+    from walnuts_amd import adaptiveIntegrators as ai, targetDistr as td
+    rng = np.random.default_rng(3)
+    q0 = rng.normal(size=(9, 10))
+    kw = dict(integrator=ai.adaptLeapFrogR2P, H0=0.9, delta0=0.3, numIter=12, warmupIter=0, M=7, seed=SEED, chain_offset=40)
+    s0, d0 = wa.WALNUTS(td.stdGauss, q0, **kw)
+    calls = [0]
+    def fn(q):
+        calls[0] += 1
+        assert q.is_cuda and q.shape == (9, 10)
+        return -0.5 * (q * q).sum(dim=1), -q
+    s1, d1 = wa.WALNUTS(td.batched(fn, dim=10), q0, **kw)
+    assert calls[0] >= (d0[:, :, 6] + d0[:, :, 7]).sum(axis=1).max()
+    close(s1, s0, what="samples external vs fused")
+    np.testing.assert_array_equal(d1[:, :, [6, 7, 19, 20]], d0[:, :, [6, 7, 19, 20]])
+
+
+def test_external_host_callable_is_the_reference_plugin_contract(wa):
+    """A plain per-chain callable lpFun(q) -> [lp, grad] (targetDistr.py:18) drives the sampler: with
+    the oracle's funnel10 as that callable the chains must reproduce the oracle's own run."""
+    from walnuts_amd import adaptiveIntegrators as ai
+    rng = np.random.default_rng(4)
+    C = 3
+    q0 = np.zeros((C, 11)); q0[:, 0] = rng.normal(size=C)
+    q0[:, 1:] = np.exp(0.5 * q0[:, :1]) * rng.normal(size=(C, 10))
+    def lpFun(q, hessian=False):
+        lp, g = ol.lpfun(ol.T_FUNNEL10, q)
+        return [lp, g]
+    s, d = wa.WALNUTS(lpFun, q0, integrator=ai.adaptLeapFrogR2P, H0=0.3, delta0=0.3, numIter=5, warmupIter=0, M=7,
+                      seed=SEED, chain_offset=77)
+    for k in range(C):
+        o = ol.walnuts(ol.T_FUNNEL10, q0[k], integrator=ol.I_ADAPT_R2P, H0=0.3, delta0=0.3, numIter=5, M=7, seed=SEED,
+                       chain=77 + k)
+        close(s[k], o["samples"], what=f"host-callable funnel chain {k}")
+        np.testing.assert_array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]])
+        close(d[k], o["diagnostics"], what=f"diagnostics chain {k}")
+    # NaN from the callable is a per-chain event (mainSW.py:24-26), never an abort
+    def bad(q, hessian=False):
+        return [float("nan"), np.zeros_like(q)] if q[0] > 1e300 else lpFun(q)
+    wa.WALNUTS(bad, q0[0], integrator=ai.fixedLeapFrog, H0=0.3, numIter=2, warmupIter=0, M=4, seed=1)

@@ -1,7 +1,10 @@
 """WALNUTS(...) with the reference's signature (WALNUTSpy/WALNUTS.py:111-129), batched on the GPU.
 
 Differences a caller sees:
-  * lpFun / integrator are device descriptors (walnuts_amd.targetDistr / .adaptiveIntegrators);
+  * lpFun is a device descriptor (walnuts_amd.targetDistr: fused in the kernel), a
+    targetDistr.batched(fn) device callable evaluated for all chains between chain-kernel launches,
+    or any reference-style host callable lpFun(q) -> [lp, grad] (slow: one host call per chain and
+    gradient evaluation); integrator is a device descriptor (walnuts_amd.adaptiveIntegrators);
   * q0 may be (D,) -- one chain, returns exactly the reference's shapes -- or (C, D) for C
     independent chains, returning arrays with a leading chain axis;
   * randomness comes from the engine's counter-based stream keyed by (seed, chain, iteration)
@@ -15,7 +18,7 @@ import numpy as np
 from . import _lib as L
 from . import adaptiveIntegrators as ai
 from .engine import Engine
-from .targetDistr import DeviceTarget
+from .targetDistr import BatchedTarget, DeviceTarget, host_callable
 
 
 class Generated:
@@ -40,9 +43,10 @@ def WALNUTS(lpFun, q0, generated=identity, integrator=ai.fixedLeapFrog, H0=0.2,
             return_torch=False, trace_cap=0):
     if igrAux is None:
         igrAux = ai.integratorAuxPar()
-    if not isinstance(lpFun, DeviceTarget):
-        raise TypeError("lpFun must be a walnuts_amd.targetDistr descriptor: a Python callable cannot "
-                        "run inside the fused GPU kernel")
+    if not isinstance(lpFun, (DeviceTarget, BatchedTarget)):
+        if not callable(lpFun):
+            raise TypeError("lpFun must be a walnuts_amd.targetDistr descriptor or a callable lpFun(q) -> [lp, grad]")
+        lpFun = host_callable(lpFun)  # the reference's plugin contract, evaluated on the host
     if not isinstance(integrator, ai.DeviceIntegrator):
         raise TypeError("integrator must be one of walnuts_amd.adaptiveIntegrators.{fixedLeapFrog,"
                         "adaptLeapFrogD,adaptLeapFrogR2P,adaptYoshidaD}")
@@ -66,13 +70,19 @@ def WALNUTS(lpFun, q0, generated=identity, integrator=ai.fixedLeapFrog, H0=0.2,
                  chain_offset=chain_offset, device=device, adaptH=adaptH, adaptHtarget=adaptHtarget,
                  adaptDelta=adaptDelta, adaptDeltaTarget=adaptDeltaTarget,
                  adaptDeltaQuantile=adaptDeltaQuantile)
-    eng.set_target(lpFun.kind, lpFun.params)
-    if recordOrbitStats:
+    if isinstance(lpFun, BatchedTarget):
+        if recordOrbitStats or trace_cap:
+            raise NotImplementedError("recordOrbitStats / trace need a device target descriptor")
+        eng.set_target(L.T_EXTERNAL)
+        out = eng.run_external(q0a, seed, numIter, lpFun.fn)
+    elif recordOrbitStats:
+        eng.set_target(lpFun.kind, lpFun.params)
         if host_gen is not None or generated.kind == L.G_Q0_SUMSQ:
             raise NotImplementedError("recordOrbitStats needs generated = identity or firstk(k) on the device")
         samples, diag, omin, omax = eng.run_orbit_stats(q0a, seed, numIter)
         out = (samples, diag, omin.transpose(1, 2), omax.transpose(1, 2))  # (dg, numIter) per chain (WALNUTS.py:183-184)
     else:
+        eng.set_target(lpFun.kind, lpFun.params)
         out = eng.run(q0a, seed, numIter, trace_cap=trace_cap)
     samples, diag = out[0], out[1]
     samples = samples.transpose(1, 2)  # [C, dg, numIter+1] as the reference's (dg, numIter+1)

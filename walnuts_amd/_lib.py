@@ -16,6 +16,7 @@ TRACE_NSCAL = 12
 
 # enums of include/walnuts_amd.h
 T_STDGAUSS, T_FUNNEL10, T_DENSEGAUSS, T_DIAGGAUSS, T_CORRGAUSS, T_SMILE, T_FUNNEL1, T_MODFUNNEL = range(8)
+T_EXTERNAL = 10
 I_FIXED, I_ADAPT_D, I_ADAPT_R2P, I_ADAPT_YOSHIDA = range(4)
 G_IDENTITY, G_Q0_SUMSQ, G_FIRSTK = range(3)
 E_ARG, E_UNSUPPORTED, E_HIP, E_NOTARGET, E_ALLOC = -1, -2, -3, -4, -5
@@ -35,7 +36,7 @@ class WnConfig(C.Structure):
 
 
 # every symbol include/walnuts_amd.h declares
-SYMBOLS = ["wn_abi_version", "wn_create", "wn_set_target", "wn_run", "wn_run_orbit_stats", "wn_integrator_step",
+SYMBOLS = ["wn_abi_version", "wn_create", "wn_set_target", "wn_run", "wn_run_orbit_stats", "wn_split_ld", "wn_split_begin", "wn_split_tick", "wn_split_done", "wn_integrator_step",
            "wn_lpfun", "wn_lpfun_kind", "wn_ext_orbit", "wn_rng_tape", "wn_last_run_ms", "wn_kernel_name", "wn_last_error",
            "wn_destroy"]
 
@@ -63,6 +64,14 @@ def lib():
     L.wn_run.argtypes = [vp, vp, C.c_uint64, C.c_int32, vp, vp, vp, C.c_int32, vp, vp]
     L.wn_run_orbit_stats.restype = C.c_int
     L.wn_run_orbit_stats.argtypes = [vp, vp, C.c_uint64, C.c_int32, vp, vp, vp, vp, vp]
+    L.wn_split_begin.restype = C.c_int
+    L.wn_split_begin.argtypes = [vp, vp, C.c_uint64, C.c_int32, vp, vp, vp, vp, vp, vp]
+    L.wn_split_ld.restype = C.c_int
+    L.wn_split_ld.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.wn_split_tick.restype = C.c_int
+    L.wn_split_tick.argtypes = [vp, vp]
+    L.wn_split_done.restype = C.c_int
+    L.wn_split_done.argtypes = [vp, C.POINTER(C.c_int32), vp]
     L.wn_integrator_step.restype = C.c_int
     L.wn_integrator_step.argtypes = [vp] * 14
     L.wn_lpfun.restype = C.c_int

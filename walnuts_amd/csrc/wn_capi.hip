@@ -9,6 +9,7 @@
 #include "../../include/walnuts_amd.h"
 #include "wn_launch.h"
 #include "wn_policy_coop.h"  // CK_*
+#include "wn_policy_wave.h"  // EXT_*
 
 using namespace wn;
 
@@ -43,6 +44,14 @@ int choose_kernel(int target, int D, int waves_per_group, KernelChoice* kc) {
     kc->name = nm;
     return 0;
   }
+  if (target == WN_T_EXTERNAL) {  // caller-evaluated (logp, grad): split mode
+    if (D > 1024) return -1;
+    const int NE = D <= 512 ? 8 : 16;
+    kc->layout = 3; kc->p0 = NE; kc->p1 = EXT_LP; kc->W = 1;
+    snprintf(nm, 64, "wn_split_tick_kernel<NE=%d,external>", NE);
+    kc->name = nm;
+    return 0;
+  }
   if (target == T_DENSEGAUSS || target == T_DIAGGAUSS || target == T_STDGAUSS) {
     const int W = waves_per_group ? waves_per_group : 4;
     if (W != 4) return -1;
@@ -57,6 +66,21 @@ int choose_kernel(int target, int D, int waves_per_group, KernelChoice* kc) {
       else if (ks <= 32) { KS = 32; NT = 2; }
       else if (ks <= 64) { KS = 64; NT = 4; }
     }
+    if (!KS && D <= 1024) {
+      // one chain per wavefront (wn_policy_wave.h): fused std / diagonal Gaussian, or the dense
+      // Gaussian with its gradient from the batched MFMA kernel between chain-kernel launches
+      const int NE = D <= 512 ? 8 : 16;
+      kc->W = 1; kc->p0 = NE;
+      if (target == T_DENSEGAUSS) {
+        kc->layout = 3; kc->p1 = EXT_HALF_QG;
+        snprintf(nm, 64, "wn_split_tick_kernel<NE=%d,dense>+wn_dense_grad_kernel", NE);
+      } else {
+        kc->layout = 2; kc->p1 = T_DIAGGAUSS;
+        snprintf(nm, 64, "wn_wave_kernel<NE=%d,diag>", NE);
+      }
+      kc->name = nm;
+      return 0;
+    }
     if (!KS) return -1;
     kc->layout = 1; kc->p0 = KS; kc->p1 = (target == T_DENSEGAUSS) ? CK_DENSE : CK_DIAG; kc->W = W;
     snprintf(nm, 64, "wn_coop_kernel<NT=%d,W=%d,KS=%d,%s>", NT, W, KS,
@@ -69,6 +93,8 @@ int choose_kernel(int target, int D, int waves_per_group, KernelChoice* kc) {
 
 size_t kernel_work_doubles(const KernelChoice& kc, int C, int M) {
   if (kc.layout == 0) return lane_work_doubles(kc.p0, C, M);
+  if (kc.layout == 2) return wave_work_doubles(kc.p0, C, M);
+  if (kc.layout == 3) return split_work_doubles(kc.p0, C, M);
   const int NT = kc.p0 <= 16 ? 1 : kc.p0 <= 32 ? 2 : 4;
   return coop_work_doubles(NT, kc.W, C, M);
 }
@@ -262,6 +288,14 @@ struct wn_engine {
   double* work = nullptr;
   size_t work_doubles = 0;
   double* facs = nullptr;  // warm-up: sorted energyErrorInfFacs, [C][2][warmupIter]
+  // split mode (layout 3): zero-padded precision matrix [DP][DP], position / gradient / log-density
+  // exchange buffers [Cpad][DP], [Cpad], finished-chain counter, parameters of the run in flight
+  double *apad = nullptr, *xq = nullptr, *xg = nullptr;
+  int* sp_done = nullptr;
+  int DP = 0, Cpad = 0;
+  Params sp_prm{};
+  bool sp_active = false;
+  long long sp_ticks = 0;
   KernelChoice kc{};
   bool have_kc = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -324,6 +358,10 @@ int wn_destroy(wn_engine* e) {
   if (e->tpar) hipFree(e->tpar);
   if (e->work) hipFree(e->work);
   if (e->facs) hipFree(e->facs);
+  if (e->apad) hipFree(e->apad);
+  if (e->xq) hipFree(e->xq);
+  if (e->xg) hipFree(e->xg);
+  if (e->sp_done) hipFree(e->sp_done);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   delete e;
@@ -336,6 +374,7 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
   size_t need = 0;
   switch (kind) {
     case WN_T_STDGAUSS: need = 0; break;
+    case WN_T_EXTERNAL: need = 0; break;
     case WN_T_DIAGGAUSS: need = (size_t)D; break;
     case WN_T_DENSEGAUSS: need = (size_t)D * D; break;
     case WN_T_FUNNEL10: if (D != 11) { e->err = "funnel10 needs dim 11"; return WN_E_ARG; } break;
@@ -366,6 +405,26 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
   HIPCHK(e, hipMemset(e->work, 0, e->work_doubles * sizeof(double)));
   if (e->cfg.warmup_iter > 0 && !e->facs)
     HIPCHK(e, hipMalloc((void**)&e->facs, (size_t)e->cfg.n_chains * 2 * e->cfg.warmup_iter * sizeof(double)));
+  if (e->apad) { hipFree(e->apad); e->apad = nullptr; }
+  if (e->xq) { hipFree(e->xq); e->xq = nullptr; }
+  if (e->xg) { hipFree(e->xg); e->xg = nullptr; }
+  e->sp_active = false;
+  if (kc.layout == 3) {
+    e->DP = 64 * kc.p0;
+    e->Cpad = (e->cfg.n_chains + 63) / 64 * 64;
+    const size_t nx = (size_t)e->Cpad * e->DP;
+    if (!e->sp_done) HIPCHK(e, hipMalloc((void**)&e->sp_done, 64));
+    if (kind == WN_T_DENSEGAUSS) {
+      HIPCHK(e, hipMalloc((void**)&e->xq, nx * sizeof(double)));
+      HIPCHK(e, hipMalloc((void**)&e->xg, nx * sizeof(double)));
+      HIPCHK(e, hipMemset(e->xq, 0, nx * sizeof(double)));
+      HIPCHK(e, hipMemset(e->xg, 0, nx * sizeof(double)));
+      HIPCHK(e, hipMalloc((void**)&e->apad, (size_t)e->DP * e->DP * sizeof(double)));
+      HIPCHK(e, hipMemset(e->apad, 0, (size_t)e->DP * e->DP * sizeof(double)));
+      HIPCHK(e, hipMemcpy2D(e->apad, (size_t)e->DP * sizeof(double), params_dev, (size_t)D * sizeof(double),
+                            (size_t)D * sizeof(double), (size_t)D, hipMemcpyDeviceToDevice));
+    }
+  }
   e->kc = kc;
   e->have_kc = true;
   e->target = kind;
@@ -391,11 +450,43 @@ static void fill_params(const wn_engine* e, Params* p) {
   p->facs = e->facs;
 }
 
+// split mode with the built-in dense-Gaussian gradient: begin, then {batched -A q, one tick of every
+// chain} until every chain has finished.  The host polls the finished-chain counter once per batch
+// of ticks; a launch whose chains have all finished is a few microseconds of early exits.
+static int run_split_dense(wn_engine* e, Params p, hipStream_t st, bool adapt, bool warm) {
+  if (p.mode != MODE_SAMPLE) { e->err = "wn_integrator_step is not available in split mode"; return WN_E_UNSUPPORTED; }
+  p.xq = e->xq; p.xg = e->xg; p.xlp = nullptr; p.sp_done = e->sp_done;
+  HIPCHK(e, hipMemsetAsync(e->sp_done, 0, 64, st));
+  hipError_t r = launch_split_begin(e->kc, adapt, warm, p, st);
+  if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
+  int done = 0;
+  e->sp_ticks = 0;
+  while (done < p.C) {
+    for (int k = 0; k < 64; ++k) {
+      r = launch_dense_grad(e->apad, e->xq, e->xg, e->DP, p.D, e->Cpad, e->sp_done, p.C, st);
+      if (r == hipSuccess) r = launch_split_tick(e->kc, adapt, warm, p, st);
+      if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
+    }
+    e->sp_ticks += 64;
+    HIPCHK(e, hipMemcpyAsync(&done, e->sp_done, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+  }
+  return WN_OK;
+}
+
 static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
   const bool adapt = e->cfg.integrator != WN_I_FIXED;
   if (timed) HIPCHK(e, hipEventRecord(e->ev0, st));
   const bool warm = p.warmupIter > 0;
-  hipError_t r = e->kc.layout == 0 ? launch_lane(e->kc, adapt, warm, p, st) : launch_coop(e->kc, adapt, warm, p, st);
+  if (e->kc.layout == 3) {
+    if (e->kc.p1 != EXT_HALF_QG) { e->err = "external target: drive the run with wn_split_begin / wn_split_tick"; return WN_E_UNSUPPORTED; }
+    int rc = run_split_dense(e, p, st, adapt, warm);
+    if (rc) return rc;
+    if (timed) { HIPCHK(e, hipEventRecord(e->ev1, st)); e->timed = true; }
+    return WN_OK;
+  }
+  hipError_t r = e->kc.layout == 0 ? launch_lane(e->kc, adapt, warm, p, st)
+               : e->kc.layout == 1 ? launch_coop(e->kc, adapt, warm, p, st) : launch_wave(e->kc, adapt, warm, p, st);
   if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
   if (timed) { HIPCHK(e, hipEventRecord(e->ev1, st)); e->timed = true; }
   return WN_OK;
@@ -461,6 +552,59 @@ int wn_run_orbit_stats(wn_engine* e, const double* q0_dev, uint64_t seed, int32_
   return launch(e, p, (hipStream_t)stream, true);
 }
 
+// ---- caller-evaluated target (WN_T_EXTERNAL): the reference's lpFun plugin as a batched callable ----
+int wn_split_begin(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, double* samples_dev,
+                   double* diag_dev, double* q_eval_dev, const double* grad_dev, const double* lp_dev, void* stream) {
+  if (!e) return WN_E_ARG;
+  if (!e->have_kc) { e->err = "wn_set_target has not been called"; return WN_E_NOTARGET; }
+  if (e->kc.layout != 3 || e->kc.p1 != EXT_LP) { e->err = "wn_split_begin needs the WN_T_EXTERNAL target"; return WN_E_ARG; }
+  if (!q0_dev || !samples_dev || !diag_dev || !q_eval_dev || !grad_dev || !lp_dev || n_iter < 0) { e->err = "null buffer or negative n_iter"; return WN_E_ARG; }
+  HIPCHK(e, hipSetDevice(e->cfg.device));
+  Params p;
+  fill_params(e, &p);
+  p.mode = MODE_SAMPLE;
+  p.numIter = n_iter; p.seed = seed;
+  p.warmupIter = (e->cfg.warmup_iter > 0 && (e->cfg.adapt_h || e->cfg.adapt_delta)) ? e->cfg.warmup_iter : 0;
+  p.q0 = q0_dev; p.samples = samples_dev; p.diag = diag_dev;
+  p.xq = q_eval_dev; p.xg = const_cast<double*>(grad_dev); p.xlp = lp_dev; p.sp_done = e->sp_done;
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(e, hipMemsetAsync(e->sp_done, 0, 64, st));
+  hipError_t r = launch_split_begin(e->kc, e->cfg.integrator != WN_I_FIXED, p.warmupIter > 0, p, st);
+  if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
+  e->sp_prm = p;
+  e->sp_active = true;
+  e->sp_ticks = 0;
+  return WN_OK;
+}
+
+int wn_split_ld(wn_engine* e, int32_t* ld) {
+  if (!e || !ld) return WN_E_ARG;
+  if (!e->have_kc || e->kc.layout != 3) { e->err = "wn_split_ld needs a split-mode target"; return WN_E_ARG; }
+  *ld = e->DP;
+  return WN_OK;
+}
+
+int wn_split_tick(wn_engine* e, void* stream) {
+  if (!e) return WN_E_ARG;
+  if (!e->sp_active) { e->err = "wn_split_begin has not been called"; return WN_E_ARG; }
+  HIPCHK(e, hipSetDevice(e->cfg.device));
+  hipError_t r = launch_split_tick(e->kc, e->cfg.integrator != WN_I_FIXED, e->sp_prm.warmupIter > 0, e->sp_prm, (hipStream_t)stream);
+  if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
+  e->sp_ticks++;
+  return WN_OK;
+}
+
+int wn_split_done(wn_engine* e, int32_t* n_done, void* stream) {
+  if (!e || !n_done) return WN_E_ARG;
+  if (!e->sp_active) { e->err = "wn_split_begin has not been called"; return WN_E_ARG; }
+  HIPCHK(e, hipSetDevice(e->cfg.device));
+  int done = 0;
+  HIPCHK(e, hipMemcpyAsync(&done, e->sp_done, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
+  *n_done = done;
+  return WN_OK;
+}
+
 int wn_integrator_step(wn_engine* e, const double* q_dev, const double* v_dev, const double* g_dev,
                        const double* ham0_dev, const double* h_dev, const int32_t* xi_dev,
                        const double* u_r2p_dev, double* q1_dev, double* v1_dev, double* g1_dev,
@@ -483,6 +627,7 @@ int wn_lpfun(wn_engine* e, const double* q_dev, double* lp_dev, double* grad_dev
   if (!e) return WN_E_ARG;
   if (!e->have_kc) { e->err = "wn_set_target has not been called"; return WN_E_NOTARGET; }
   if (!q_dev || !lp_dev || !grad_dev) { e->err = "null buffer"; return WN_E_ARG; }
+  if (e->target == WN_T_EXTERNAL) { e->err = "the external target is evaluated by the caller"; return WN_E_UNSUPPORTED; }
   HIPCHK(e, hipSetDevice(e->cfg.device));
   const int B = e->cfg.n_chains;
   hipLaunchKernelGGL(wn_lpfun_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, e->target,

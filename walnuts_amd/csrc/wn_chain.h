@@ -67,6 +67,11 @@ struct Params {
   // recordOrbitStats (WALNUTS.py:128,182-184): [C][numIter][dg] min / max of generated(q) over the
   // orbit states of each iteration, or null (generated = identity / first-k only)
   double *omin, *omax;
+  // split mode (Engine::split_tick): position out / gradient in [C][DP], log density in [C] or
+  // null, number of finished chains
+  double *xq, *xg;
+  const double* xlp;
+  int* sp_done;
   unsigned long long* stamps;  // diagnostic builds (-DWN_STAMPS): [block][wave][8] cycles per phase
 };
 
@@ -102,8 +107,52 @@ enum { COLD_QB = 0, COLD_VB, COLD_GB, COLD_N };
 // backward passes run (adaptiveIntegrators.py:96-99).  The layout decides registers vs LDS.
 enum { WARM_QL = 0, WARM_VL, WARM_QO, WARM_VO, WARM_GO, WARM_N };
 
+// ---- per-chain scalars (replicated in every lane that serves the chain) ---------------------
+// A plain struct so that the split-mode kernels (gradient evaluated outside the chain kernel) can
+// park a chain between launches with one struct copy.
+struct alignas(16) ChainScalars {
+  double H0, Ha, Hb, lp0;
+  double WoldSum, WnewSum, lwtSumf, lwtSumb, h2;
+  double uc[8];   // uniforms 2*ub0 .. 2*ub0+7 of this (chain, iteration)
+  double keinit_part, gen_part;
+  // diagnostics accumulators (WALNUTS.py:196-207, 660-693)
+  double orbitLen_, orbitLenSam_, indexStat_, indexStatOld_, timeLenF_, timeLenB_;
+  double minlw, maxlw, Hmin, Hmax;
+  // macro-step integrator state
+  double h, hh, Ham0, HamPass0, lwtf, lwt, lpn, Hn, lpOut, HOut, lpCur, HCur;
+  double lpP, lpPL;
+  double Hc, dc;  // big step size H and tolerance delta of this chain (adapted during warm-up)
+  // warm-up only: P2 quantile of log(igrConst) (P2quantile.py), energy-step statistics
+  double p2q[5], Hprev, madv, igrOut;
+  double sp_hh2;  // split mode: half-step factor of the micro step in flight
+  int iter;
+  uint32_t Bbits;
+  int i, xi, a, b, n, nleaf;
+  uint32_t ku;
+  uint32_t ub0;   // first Philox block of the cached uniform window
+  int nevalF, nevalB, L_, Lold_, NdS, NdC, maxFint, maxBint, stopCode;
+  int minIf, maxIf, minc, maxc, nneq, nzero, nused;
+  enum { PH_FWD = 0, PH_FWD2 = 1, PH_BWD = 2 };
+  int ph, c, im, nstep, If, Ib, cSim, maxTry, nEvF, nEvB, cret;
+  int sub;  // adaptYoshidaD: leapfrog sub-step 0..2 inside the current micro step
+  uint32_t firemask;
+  int gen_iter;  // iteration whose deferred generated() row is pending
+  int ip, ipl;
+  int p2n, p2m[5];
+  int ntrace;
+  int sp_stage;  // split mode: 0 = waiting for grad(q0), 1 = running, 2 = finished
+  bool live;
+  bool needKE, needGen;
+  bool bothEndsPassive;
+  bool Hnan;
+  bool needMacro, needPass, fin, needIter, needDoubling, endIter;
+  bool allfin, inPass;
+  bool madnan;
+  bool sp_act;  // split mode: the micro step in flight belongs to an active chain
+};
+
 template <class P, bool ADAPT, bool WARM = false>
-struct Engine {
+struct Engine : ChainScalars {
   using Vec = typename P::Vec;
   // U-turn checks 0 (full orbit), 1 (leaf pair) and 2..1+NLC (fast-cached sub-tree levels) have
   // their left state on chip; deeper levels are fetched from the slot store in memory.
@@ -112,44 +161,8 @@ struct Engine {
   P& p;
   const Params& prm;
 
-  // ---- per-chain scalars (replicated in every lane that serves the chain) -------------------
-  int iter;
-  bool live;
-  uint32_t Bbits;
-  int i, xi, a, b, n, nleaf;
-  double H0, Ha, Hb, lp0;
-  double WoldSum, WnewSum, lwtSumf, lwtSumb, h2;
-  uint32_t ku;
-  uint32_t ub0;   // first Philox block of the cached uniform window
-  double uc[8];   // uniforms 2*ub0 .. 2*ub0+7 of this (chain, iteration)
-  bool needKE, needGen;
-  double keinit_part, gen_part;
-  // diagnostics accumulators (WALNUTS.py:196-207, 660-693)
-  int nevalF, nevalB, L_, Lold_, NdS, NdC, maxFint, maxBint, stopCode;
-  double orbitLen_, orbitLenSam_, indexStat_, indexStatOld_, timeLenF_, timeLenB_;
-  bool bothEndsPassive;
-  int minIf, maxIf, minc, maxc, nneq, nzero, nused;
-  double minlw, maxlw, Hmin, Hmax;
-  bool Hnan;
-  // macro-step integrator state
-  enum { PH_FWD = 0, PH_FWD2 = 1, PH_BWD = 2 };
-  bool needMacro, needPass, fin, needIter, needDoubling, endIter;
-  int ph, c, im, nstep, If, Ib, cSim, maxTry, nEvF, nEvB, cret;
-  int sub;  // adaptYoshidaD: leapfrog sub-step 0..2 inside the current micro step
-  double h, hh, Ham0, HamPass0, lwtf, lwt, lpn, Hn, lpOut, HOut, lpCur, HCur;
-  bool allfin, inPass;
-  uint32_t firemask;
-  int gen_iter;  // iteration whose deferred generated() row is pending
-
   // ---- D-vectors ----------------------------------------------------------------------------
   Vec qa, va, ga;  // active end of the orbit = start of the current macro step (v forward-time)
-  double lpP, lpPL;
-  int ip, ipl;
-  double Hc, dc;  // big step size H and tolerance delta of this chain (adapted during warm-up)
-  // warm-up only: P2 quantile of log(igrConst) (P2quantile.py), energy-step statistics
-  int p2n, p2m[5];
-  double p2q[5], Hprev, madv, igrOut;
-  bool madnan;
   // adaptive integrators only: work state of the running micro pass (the accepted forward result
   // is parked in the layout's warm storage while the backward passes run)
   typename P::template Opt<ADAPT> qw, vw, gw;
@@ -562,7 +575,6 @@ struct Engine {
       }
     }
   }
-  int ntrace;
   unsigned long long st_[16], st_last_;  // diagnostic builds only (-DWN_STAMPS)
 
   WN_HD void step_done() {
@@ -805,11 +817,7 @@ struct Engine {
     }
   }
 
-  // ------------------------------------------------------------------------------------------
-  // the tick loop
-  // ------------------------------------------------------------------------------------------
-  WN_HD void run() {
-    const bool inrange = p.chain_local() < prm.C;
+  WN_HD void init_scalars(bool inrange) {
     // every scalar starts defined (reading an indeterminate value is UB even on dead paths)
     Bbits = 0; lp0 = 0.0; WoldSum = 1.0; WnewSum = 0.0; lwtSumf = lwtSumb = 0.0;
     gen_iter = 0; lpP = lpPL = 0.0; ip = ipl = 0;
@@ -839,6 +847,178 @@ struct Engine {
     firemask = 0;
     h = h2 = 0.0; xi = 1; i = 0; n = 0; nleaf = 1; a = b = 0;
     lpn = Hn = lpOut = HOut = 0.0; H0 = Ha = Hb = 0.0;
+    sp_stage = 0; sp_hh2 = 0.0; sp_act = false;
+  }
+
+
+  // ------------------------------------------------------------------------------------------
+  // split mode: the gradient is evaluated OUTSIDE the chain kernel -- by a batched MFMA GEMM for
+  // dense Gaussians too large to keep A on chip, or by the caller's own batched (logp, grad) on
+  // device tensors (the reference's lpFun plugin, targetDistr.py:18).  One launch of the tick kernel
+  // runs, for every chain, the part of tick t that follows p.grad() in run() and the part of tick
+  // t+1 that precedes it; between launches a chain is parked in memory (P::park / P::unpark).
+  // Same arithmetic and same draw order as run(); only one micro step per tick.
+  // ------------------------------------------------------------------------------------------
+  WN_HD void split_begin() {
+    const bool inrange = p.chain_local() < prm.C;
+    init_scalars(inrange);
+    const int cl = inrange ? p.chain_local() : 0;
+    WN_VFOR(e) qa.x[e] = (p.valid(e) && inrange) ? prm.q0[(size_t)cl * prm.D + p.gidx(e)] : 0.0;
+    p.ext_put_q(qa);  // grad(q0) is evaluated next
+    park();
+  }
+  WN_HD void park() {
+    p.park_scalars(static_cast<const ChainScalars&>(*this));
+    p.template park_vec<0>(qa); p.template park_vec<1>(va); p.template park_vec<2>(ga);
+    park_adapt();
+  }
+  WN_HD void unpark() {
+    p.template unpark_vec<0>(qa); p.template unpark_vec<1>(va); p.template unpark_vec<2>(ga);
+    unpark_adapt();
+  }
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_>::type park_adapt() {
+    p.template park_vec<3>(qw); p.template park_vec<4>(vw); p.template park_vec<5>(gw);
+  }
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_>::type park_adapt() {}
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_>::type unpark_adapt() {
+    p.template unpark_vec<3>(qw); p.template unpark_vec<4>(vw); p.template unpark_vec<5>(gw);
+  }
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_>::type unpark_adapt() {}
+
+  // returns true while the chain still needs ticks
+  WN_HD bool split_tick() {
+    p.unpark_scalars(static_cast<ChainScalars&>(*this));
+    if (sp_stage == 2) return false;
+    unpark();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) st_[k] = 0;
+    st_last_ = 0;
+    Vec& Q = QW(); Vec& V = VW(); Vec& G = GW();
+    double part[NPB > 2 * NFAST ? NPB : 2 * NFAST];
+    if (sp_stage == 0) {  // f0, grad0 = lpFun(q0)  (WALNUTS.py:177,249)
+      p.ext_get(qa, ga, part[0]);
+      p.template reduce<1>(part);
+      lpP = p.lp_finish(part[0]);
+      p.prop_put(ip, qa, ga);
+      if (live) {
+        emit_generated(0);  // samples[:,0] = generated(q0)  (:164)
+        if (prm.numIter < 1) live = false; else needIter = true;
+      }
+      sp_stage = 1;
+    } else {
+      // ---- B, second half ----
+      const bool act = sp_act;
+      const double hh2 = sp_hh2;
+      p.ext_get(Q, G, part[0]);
+      double ke = 0.0;
+      WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; ke += V.x[e] * V.x[e]; }
+      part[1] = ke; part[2] = keinit_part; part[3] = gen_part;
+      if (!ADAPT) {
+        fin = act;
+        if (p.any(nchecks() > 0)) {
+          fast_dots(part + 4);
+          p.template reduce<NPB>(part);
+        } else {
+#pragma unroll
+          for (int k = 4; k < NPB; ++k) part[k] = 0.0;
+          p.template reduce<4>(part);
+        }
+      } else {
+        p.template reduce<NPB>(part);
+      }
+      finish_generated(part[3]);
+      if (act) {
+        if (needKE) {  // Hs[I0] = -f0 + 0.5*sum(v**2)  (:256); multinomialLscale (:259)
+          H0 = -lp0 + 0.5 * part[2];
+          Ha = Hb = H0; Ham0 = H0;
+          if (ADAPT) { HamPass0 = H0; allfin = isfinite(H0); if (WARM) Hprev = H0; }
+          Hnan = isnan(H0); Hmin = Hmax = H0;
+          needKE = false; keinit_part = 0.0;
+        }
+        if (ADAPT) micro_account(p.lp_finish(part[0]), part[1]);
+      }
+      // ---- C ----
+      if (live && !needIter) {
+        if (!ADAPT) after_micro(p.lp_finish(part[0]), part[1]);
+        else if (!inPass) pass_end();
+      }
+      // ---- D: U-turn checks ----
+      const int nchk = nchecks();
+      firemask = 0;
+      if (ADAPT) {
+        if (p.any(nchk > 0)) {
+          fast_dots(part);
+          p.template reduce<2 * NFAST>(part);
+          fast_fire(part, nchk);
+        }
+      } else {
+        fast_fire(part + 4, nchk);
+      }
+      for (int j0 = NFAST; p.any(nchk > j0); j0 += 4) {
+        double dots[8];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = j0 + jj;
+          double d1 = 0.0, d2 = 0.0;
+          if (p.any(nchk > j)) {
+            if ((nchk > j) && need_check(j)) {
+              Vec qo_, vo_;
+              p.slot_load(slot_of_leaf(n + 1 - (1 << j)), qo_, vo_);
+              uturn_dots(qo_, vo_, d1, d2);
+            }
+          }
+          dots[2 * jj] = d1; dots[2 * jj + 1] = d2;
+        }
+        p.template reduce<8>(dots);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = j0 + jj;
+          if (nchk > j && need_check(j) &&
+              (((double)xi * dots[2 * jj] < 0.0) || ((double)xi * dots[2 * jj + 1] < 0.0)))
+            firemask |= (1u << j);
+        }
+      }
+      // ---- E ----
+      if (live && fin) {
+        step_done();
+        if (endIter) end_iteration();
+      }
+    }
+    if (!p.any(live || needGen)) {
+      sp_stage = 2;
+      if (prm.trace_n && p.chain_local() < prm.C && p.writer()) prm.trace_n[p.chain_local()] = ntrace;
+      p.park_scalars(static_cast<const ChainScalars&>(*this));
+      return false;
+    }
+    // ---- A of the next tick ----
+    if (live && needIter) start_iteration();
+    rng_refill();
+    if (live && needDoubling) start_doubling();
+    if (live && needMacro) setup_macro();
+    if (ADAPT && live && needPass) setup_pass();
+    // ---- B, first half: kick + drift; the position goes out for the gradient ----
+    {
+      Vec& Q2 = QW(); Vec& V2 = VW(); Vec& G2 = GW();
+      const bool act = live && !needIter;
+      double hh2 = act ? 0.5 * hh : 0.0, hq = act ? hh : 0.0;
+      if (ADAPT && prm.integrator == I_ADAPT_YOSHIDA && act) {
+        const double w = sub == 1 ? -1.702414383919315 : 1.351207191959658;
+        hh2 = 0.5 * w * hh; hq = w * hh;
+      }
+      WN_VFOR(e) { V2.x[e] = V2.x[e] + hh2 * G2.x[e]; Q2.x[e] = Q2.x[e] + hq * V2.x[e]; }
+      p.ext_put_q(Q2);
+      sp_act = act; sp_hh2 = hh2;
+    }
+    park();
+    return true;
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // the tick loop
+  // ------------------------------------------------------------------------------------------
+  WN_HD void run() {
+    const bool inrange = p.chain_local() < prm.C;
+    init_scalars(inrange);
 
     // q_c = q0; f0, grad0 = lpFun(q0)  (WALNUTS.py:177,249)
     const int cl = inrange ? p.chain_local() : 0;
@@ -877,7 +1057,7 @@ struct Engine {
     // doubling ends of ALL chains of a group functions of the tick count alone: the expensive
     // divergent paths run on a few tick phases for everybody instead of on most ticks for somebody.
     // Costs (2**ALIGN_LOG2 - 1)/2 idle ticks per iteration; changes no chain's arithmetic.
-    constexpr uint32_t ALIGN_MASK = ADAPT ? 0u : ((1u << WN_ALIGN_LOG2) - 1u);
+    constexpr uint32_t ALIGN_MASK = ADAPT ? 0u : ((1u << P::ALIGN_LOG2) - 1u);
     uint32_t T = 0;
     while (p.any(live || needGen)) {
       WN_STAMP(7);

@@ -9,9 +9,9 @@
 namespace wn {
 
 struct KernelChoice {
-  int layout;  // 0 = lane, 1 = coop
-  int p0;      // lane: DMAX ; coop: NT
-  int p1;      // lane: target kind ; coop: CK_DENSE / CK_DIAG
+  int layout;  // 0 = lane, 1 = coop, 2 = wave (persistent), 3 = wave split (gradient outside the chain kernel)
+  int p0;      // lane: DMAX ; coop: k-steps ; wave: NE
+  int p1;      // lane: target kind ; coop: CK_DENSE / CK_DIAG ; wave: target kind ; split: EXT_*
   int W;       // coop: waves per group
   const char* name;
 };
@@ -21,5 +21,12 @@ int choose_kernel(int target, int D, int waves_per_group, KernelChoice* kc);
 size_t kernel_work_doubles(const KernelChoice& kc, int C, int M);
 hipError_t launch_lane(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st);
 hipError_t launch_coop(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st);
+hipError_t launch_wave(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st);
+hipError_t launch_split_begin(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st);
+hipError_t launch_split_tick(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st);
+hipError_t launch_dense_grad(const double* A, const double* xq, double* xg, int DP, int D, int Cpad, const int* done, int C,
+                             hipStream_t st);
+size_t wave_work_doubles(int NE, int C, int M);
+size_t split_work_doubles(int NE, int C, int M);
 
 }  // namespace wn

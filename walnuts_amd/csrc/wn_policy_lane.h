@@ -13,6 +13,7 @@ struct EmptyVec {};
 template <int DMAX, class Tgt>
 struct LanePolicy {
   static constexpr int NE = DMAX;
+  static constexpr int ALIGN_LOG2 = WN_ALIGN_LOG2;  // iteration-start alignment (wn_chain.h run())
   static constexpr int NLC = 0;  // no fast cache: every sub-tree left endpoint lives in the slot store
   struct Vec {
     double x[DMAX];

@@ -1,0 +1,191 @@
+// wn_policy_wave.h -- layout policy "one chain per wavefront": the D-vectors of a chain are striped
+// over the 64 lanes of one wave (element e*64 + lane in register e, D <= 64*NE), every lane keeps a
+// replica of the chain's scalars, dot products are DPP / permlane all-reduces that return the same
+// bits in every lane, and nothing needs LDS or a barrier.  This is the layout for large D
+// (100 < D <= 1024) where the state of a chain no longer fits one lane or one MFMA group:
+//
+//   * fused, HBM-bound targets (std / diagonal Gaussian, StockWatson): Engine::run() in one
+//     persistent kernel, Tgt::grad evaluated in the wave;
+//   * split mode (Engine::split_tick): the gradient comes from outside the chain kernel -- the
+//     batched FP64-MFMA GEMM of wn_k_wave.hip for dense Gaussians whose precision matrix cannot
+//     stay on chip (D = 1000, SURVEY.md 8d cfg 4), or the caller's own batched (logp, grad) on
+//     device tensors (the reference's lpFun plugin).  A chain is parked in memory between launches.
+//
+// Every memory-resident vector of a chain is [vector][DP] with DP = 64*NE, element e*64+lane, so a
+// wave load/store of one register touches 512 contiguous bytes.
+#pragma once
+#include "wn_chain.h"
+
+namespace wn {
+
+struct EmptyVecW {};
+
+enum { EXT_NONE = 0, EXT_HALF_QG = 1, EXT_LP = 2 };
+
+// lp = -1/2 sum a_i q_i^2, grad = -a_i q_i  (stdGauss, targetDistr.py:18-21, is a == 1)
+template <int NE>
+struct WTgtDiag {
+  static constexpr int EXT = EXT_NONE;
+  double a[NE];
+  __device__ __forceinline__ void init(const Params& prm, int lane) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) a[e] = (e * 64 + lane) < prm.D ? prm.tpar[e * 64 + lane] : 0.0;
+  }
+  __device__ __forceinline__ double grad(const double* q, double* g) const {
+    double s = 0.0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { g[e] = -(a[e] * q[e]); s += q[e] * g[e]; }
+    return s;
+  }
+  __device__ __forceinline__ static double lp_finish(double r) { return 0.5 * r; }
+};
+
+// gradient supplied from outside the chain kernel; lp = 1/2 q.g (Gaussian) or supplied too
+template <int NE, int EXT_>
+struct WTgtExt {
+  static constexpr int EXT = EXT_;
+  __device__ __forceinline__ void init(const Params&, int) {}
+  __device__ __forceinline__ double grad(const double*, double*) const { return 0.0; }
+  __device__ __forceinline__ static double lp_finish(double r) { return EXT_ == EXT_HALF_QG ? 0.5 * r : r; }
+};
+
+template <int NE_, class Tgt>
+struct WavePolicy {
+  static constexpr int NE = NE_;
+  static constexpr int DP = 64 * NE_;
+  static constexpr int NLC = 0;         // every sub-tree left endpoint lives in the slot store
+  static constexpr int ALIGN_LOG2 = 0;  // chains do not share a wave: nothing to align
+  struct Vec {
+    double x[NE_];
+  };
+  template <bool B>
+  using Opt = typename std::conditional<B, Vec, EmptyVecW>::type;
+  enum { NPARK = 6 };
+
+  int D, cl, lane;
+  uint32_t cg;
+  int nslot;
+  double* vbase;     // this chain's vectors: [2*nslot + COLD_N + 4 + WARM_N + NPARK][DP]
+  ChainScalars* sc;  // this chain's parked scalars
+  double *xq, *xg;   // split mode: position out / gradient in, [C][DP]
+  const double* xlp; // split mode, EXT_LP: log density in, [C]
+  Tgt tgt;
+
+  __host__ __device__ static size_t nvec(int M) { return (size_t)(M + 1) * 2 + COLD_N + 4 + WARM_N + NPARK; }
+  __host__ __device__ static size_t scalar_doubles() { return (sizeof(ChainScalars) + 63) / 64 * 8; }
+  // workspace doubles for C chains: vectors, then parked scalars
+  static size_t work_doubles(int C, int M) { return (size_t)C * (nvec(M) * DP + scalar_doubles()); }
+
+  __device__ WavePolicy(const Params& prm, int chain_local)
+      : D(prm.D), cl(chain_local), lane(threadIdx.x & 63), cg(prm.chain0 + (uint32_t)chain_local), nslot(prm.M + 1) {
+    const int c = chain_local < prm.C ? chain_local : 0;
+    vbase = prm.work + (size_t)c * nvec(prm.M) * DP + lane;
+    sc = reinterpret_cast<ChainScalars*>(prm.work + (size_t)prm.C * nvec(prm.M) * DP + (size_t)c * scalar_doubles());
+    xq = prm.xq ? prm.xq + (size_t)c * DP + lane : nullptr;
+    xg = prm.xg ? prm.xg + (size_t)c * DP + lane : nullptr;
+    xlp = prm.xlp ? prm.xlp + c : nullptr;
+    tgt.init(prm, lane);
+  }
+
+  __device__ __forceinline__ bool valid(int e) const { return e * 64 + lane < D; }
+  __device__ __forceinline__ bool owner(int) const { return true; }
+  __device__ __forceinline__ int gidx(int e) const { return e * 64 + lane; }
+  __device__ __forceinline__ bool writer() const { return lane == 0; }
+  __device__ __forceinline__ int chain_local() const { return cl; }
+  __device__ __forceinline__ uint32_t chain_global() const { return cg; }
+  // the scalars are replicated: every lane votes the same, and the vote makes the branch scalar
+  __device__ __forceinline__ bool any(bool b) const { return __any(b); }
+  __device__ __forceinline__ bool majority(bool a, bool) const { return __any(a); }
+
+  template <int CTRL>
+  __device__ __forceinline__ static double dpp(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+  }
+  // sum over the 64 lanes, same bits everywhere: xor-1, xor-2 inside quads, mirrored halves and rows
+  // (every exchange is symmetric, so both partners add the same two numbers), then across rows
+  __device__ __forceinline__ static double wavesum(double x) {
+    x += dpp<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += dpp<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += dpp<0x141>(x);  // row_half_mirror
+    x += dpp<0x140>(x);  // row_mirror
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    u2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    u2_t b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double y = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    lo = __double2loint(y); hi = __double2hiint(y);
+    a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  }
+  template <int N>
+  __device__ __forceinline__ void reduce(double* v) const {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = wavesum(v[k]);
+  }
+
+  __device__ __forceinline__ void grad(const Vec& q, Vec& g, double& lp_part) const { lp_part = tgt.grad(q.x, g.x); }
+  __device__ __forceinline__ double lp_finish(double r) const { return Tgt::lp_finish(r); }
+
+  // ---- memory-resident vectors ------------------------------------------------------------------
+  __device__ __forceinline__ double* vp(int v) const { return vbase + (size_t)v * DP; }
+  __device__ __forceinline__ void vput(int v, const Vec& x) const {
+    double* d = vp(v);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) d[e * 64] = x.x[e];
+  }
+  __device__ __forceinline__ void vget(int v, Vec& x) const {
+    const double* s = vp(v);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) x.x[e] = s[e * 64];
+  }
+  __device__ __forceinline__ void slot_store(int slot, const Vec& q, const Vec& v) const { vput(2 * slot, q); vput(2 * slot + 1, v); }
+  __device__ __forceinline__ void slot_load(int slot, Vec& q, Vec& v) const { vget(2 * slot, q); vget(2 * slot + 1, v); }
+  __device__ __forceinline__ void lslot_store(int, const Vec&, const Vec&) const {}
+  __device__ __forceinline__ void lslot_load(int, Vec&, Vec&) const {}
+  template <int K> __device__ __forceinline__ void cold_put(const Vec& x) const { vput(2 * nslot + K, x); }
+  template <int K> __device__ __forceinline__ void cold_get(Vec& x) const { vget(2 * nslot + K, x); }
+  __device__ __forceinline__ void prop_put(int which, const Vec& q, const Vec& g) const {
+    vput(2 * nslot + COLD_N + 2 * which, q); vput(2 * nslot + COLD_N + 2 * which + 1, g);
+  }
+  __device__ __forceinline__ void prop_get(int which, Vec& q, Vec& g) const {
+    vget(2 * nslot + COLD_N + 2 * which, q); vget(2 * nslot + COLD_N + 2 * which + 1, g);
+  }
+  template <int K> __device__ __forceinline__ void warm_put(const Vec& x) const { vput(2 * nslot + COLD_N + 4 + K, x); }
+  template <int K> __device__ __forceinline__ void warm_get(Vec& x) const { vget(2 * nslot + COLD_N + 4 + K, x); }
+  // one 192-byte row: lane k < 24 stores d[k]
+  __device__ __forceinline__ void diag_store(double* row, const double* d) const {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < NDIAG; ++k) v = lane == k ? d[k] : v;
+    if (lane < NDIAG) row[lane] = v;
+  }
+
+  // ---- split mode ---------------------------------------------------------------------------------
+  template <int K> __device__ __forceinline__ void park_vec(const Vec& x) const { vput(2 * nslot + COLD_N + 4 + WARM_N + K, x); }
+  template <int K> __device__ __forceinline__ void unpark_vec(Vec& x) const { vget(2 * nslot + COLD_N + 4 + WARM_N + K, x); }
+  __device__ __forceinline__ void park_scalars(const ChainScalars& s) const { if (lane == 0) *sc = s; }
+  __device__ __forceinline__ void unpark_scalars(ChainScalars& s) const { s = *sc; }
+  __device__ __forceinline__ void ext_put_q(const Vec& q) const {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) xq[e * 64] = q.x[e];  // the padding beyond D stays zero (vectors are zero there)
+  }
+  // gradient (and log density) of the position sent out by the previous launch
+  __device__ __forceinline__ void ext_get(const Vec& q, Vec& g, double& lp_part) const {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) g.x[e] = valid(e) ? xg[e * 64] : 0.0;
+    if (Tgt::EXT == EXT_LP) {
+      lp_part = lane == 0 ? *xlp : 0.0;
+    } else {
+      double s = 0.0;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) s += q.x[e] * g.x[e];
+      lp_part = s;
+    }
+  }
+};
+
+}  // namespace wn

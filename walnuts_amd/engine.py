@@ -115,6 +115,38 @@ class Engine:
         self._keep = [q0]
         return samples, diag, omin, omax
 
+    def run_external(self, q0, seed, n_iter, fn, poll=32):
+        """Run with a caller-evaluated target (WN_T_EXTERNAL): `fn(q)` takes the positions of all
+        chains as a device tensor view [C, D] and returns (lp [C], grad [C, D]) device tensors --
+        the reference's lpFun plugin (targetDistr.py:18) as a batched callable.  Every chain
+        advances by one gradient evaluation per call of fn."""
+        torch = self.torch
+        q0 = self._dev(q0).reshape(self.n_chains, self.dim)
+        samples = torch.zeros((self.n_chains, n_iter + 1, self.dg), dtype=torch.float64, device=self.device)
+        diag = torch.zeros((self.n_chains, n_iter, L.NDIAG), dtype=torch.float64, device=self.device)
+        ld = C.c_int32()
+        self._check(self.lib.wn_split_ld(self.h, C.byref(ld)))
+        xq = torch.zeros((self.n_chains, ld.value), dtype=torch.float64, device=self.device)
+        xg = torch.zeros_like(xq)
+        xlp = torch.zeros(self.n_chains, dtype=torch.float64, device=self.device)
+        P = lambda t: C.c_void_p(t.data_ptr())
+        self._check(self.lib.wn_split_begin(self.h, P(q0), C.c_uint64(int(seed)), int(n_iter), P(samples), P(diag),
+                                            P(xq), P(xg), P(xlp), self._stream()))
+        qview, gview = xq[:, :self.dim], xg[:, :self.dim]
+        done = C.c_int32(0)
+        ticks = 0
+        while done.value < self.n_chains:
+            for _ in range(poll):
+                lp, g = fn(qview)
+                xlp.copy_(torch.as_tensor(lp, dtype=torch.float64, device=self.device).reshape(self.n_chains))
+                gview.copy_(torch.as_tensor(g, dtype=torch.float64, device=self.device).reshape(self.n_chains, self.dim))
+                self._check(self.lib.wn_split_tick(self.h, self._stream()))
+            ticks += poll
+            self._check(self.lib.wn_split_done(self.h, C.byref(done), self._stream()))
+        self.ext_ticks = ticks
+        self._keep = [q0, xq, xg, xlp]
+        return samples, diag
+
     def last_run_ms(self):
         ms = C.c_float()
         self._check(self.lib.wn_last_run_ms(self.h, C.byref(ms)))

@@ -36,6 +36,40 @@ class DeviceTarget:
         return f"<walnuts_amd target {self.name}>"
 
 
+class BatchedTarget:
+    """The lpFun plugin evaluated by the caller for ALL chains at once, between launches of the
+    chain kernel (include/walnuts_amd.h, WN_T_EXTERNAL): `fn(q)` gets the positions as a device
+    tensor view [C, D] (float64, row stride >= D) and returns (lp [C], grad [C, D])."""
+
+    def __init__(self, fn, dim=None, name="batched"):
+        self.fn, self.dim, self.name = fn, dim, name
+
+    def check_dim(self, d):
+        if self.dim is not None and d != self.dim:
+            raise ValueError(f"target {self.name} needs dimension {self.dim}, got {d}")
+
+
+def batched(fn, dim=None):
+    return BatchedTarget(fn, dim)
+
+
+def host_callable(lpFun):
+    """Wrap a reference-style per-chain host callable lpFun(q) -> [lp, grad] (targetDistr.py:18):
+    positions go to the host, lpFun runs once per chain, results go back.  Keeps the reference's
+    plugin contract exactly; the speed is the host callable's."""
+
+    def fn(qv):
+        import torch
+        q = qv.cpu().numpy()
+        lp = np.empty(q.shape[0]); g = np.empty_like(q)
+        for c in range(q.shape[0]):
+            r = lpFun(q[c].copy())
+            lp[c] = r[0]; g[c] = np.asarray(r[1], dtype=np.float64)
+        return torch.as_tensor(lp, device=qv.device), torch.as_tensor(g, device=qv.device)
+
+    return BatchedTarget(fn, None, getattr(lpFun, "__name__", "host_callable"))
+
+
 stdGauss = DeviceTarget("stdGauss", L.T_STDGAUSS)              # targetDistr.py:18-21
 corrGauss = DeviceTarget("corrGauss", L.T_CORRGAUSS, 2)        # targetDistr.py:25-31
 smileDistr = DeviceTarget("smileDistr", L.T_SMILE, 2)          # targetDistr.py:34-38
