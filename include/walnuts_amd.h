@@ -53,7 +53,11 @@ enum {
   WN_T_TT_FUNNEL = 9,     /* test/targets.py:23-29 (any D >= 2; no log-scale term) */
   /* lpFun evaluated by the CALLER (targetDistr.py:18 `lpFun(q) -> [lp, grad]` as a batched callable
    * on device buffers): wn_split_begin / wn_split_tick below; D <= 1024 */
-  WN_T_EXTERNAL = 10
+  WN_T_EXTERNAL = 10,
+  /* StockWatson stochastic volatility, WALNUTSpy_examples/StockWatson/sw_innov.stan:7-51 as
+   * bridgestan's log_density_gradient evaluates it (mainSW.py:22): params = [T, y[1..T]], D = 3T,
+   * T <= 256 (BASELINE.json config 5: T = 252, D = 756) */
+  WN_T_STOCKWATSON = 11
 };
 
 /* macro-step integrator plugin  integrator(q,v,g,Ham0,h,xi,lpFun,delta,auxPar)

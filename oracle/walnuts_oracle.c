@@ -206,6 +206,81 @@ int wno_lpfun(int target, int d, const double *tpar, const double *q, double *lp
       grad[1] = -y * t2;
       return 0;
     }
+    case WNO_T_STOCKWATSON: {
+      /* WALNUTSpy_examples/StockWatson/sw_innov.stan:7-51 through bridgestan's
+       * log_density_gradient (mainSW.py:22): all parameters unconstrained (no Jacobian), constants
+       * dropped (propto).  bridgestan / Stan are absent from the reference tree and from this image
+       * (no version pinned): PARITY UNPINNED for this target -- the restatement follows
+       * the Stan program line by line and is checked against finite differences and an independent
+       * NumPy restatement in tests/.  tpar = [T, y[1..T]];  d = 3T.
+       * Parameter order (sw_innov.stan:7-14): tSigma, z1, zinn[T-2], x1, xinn[T-1], tau1, tauinn[T-1]. */
+      const int T = (int)tpar[0];
+      const double *y = tpar + 1;
+      if (T < 3 || d != 3 * T) return -2;
+      const double tS = q[0];
+      const double *zin = q + 1;      /* zin[0] = z1, zin[j] = zinn[j], j = 1..T-2 */
+      const double *xin = q + T;      /* xin[0] = x1, xin[j] = xinn[j], j = 1..T-1 */
+      const double *tin = q + 2 * T;  /* tin[0] = tau1, tin[j] = tauinn[j], j = 1..T-1 */
+      const double sigma = exp(-0.5 * tS); /* :24 */
+      const double gpri = exp(tS);         /* :25 */
+      double *z = (double *)malloc(sizeof(double) * (size_t)(8 * T));
+      if (!z) return -3;
+      double *x = z + T, *tau = x + T, *ez = tau + T, *a = ez + T, *b = a + T, *c = b + T, *A = c + T;
+      z[1] = zin[0]; /* :27-28 (1-based arrays as in the Stan program) */
+      for (int t = 2; t <= T - 1; ++t) z[t] = z[t - 1] + sigma * zin[t - 1];
+      double *x1b = x - 1; /* x1b[t], t = 1..T */
+      x1b[1] = xin[0];     /* :30-31 */
+      for (int t = 2; t <= T; ++t) x1b[t] = x1b[t - 1] + sigma * xin[t - 1];
+      double *tau1b = tau - 1;
+      tau1b[1] = tin[0]; /* :33-34 */
+      for (int t = 2; t <= T; ++t) {
+        ez[t - 1] = exp(0.5 * z[t - 1]);
+        tau1b[t] = tau1b[t - 1] + ez[t - 1] * tin[t - 1];
+      }
+      double r = 5.0 * tS - 0.5 * gpri; /* :40 */
+      double sz = 0.0, sx = 0.0, st = 0.0;
+      for (int j = 1; j <= T - 2; ++j) sz += zin[j] * zin[j]; /* :44-46 normal(0,1), constants dropped */
+      for (int j = 1; j <= T - 1; ++j) sx += xin[j] * xin[j];
+      for (int j = 1; j <= T - 1; ++j) st += tin[j] * tin[j];
+      r += -0.5 * sz - 0.5 * sx - 0.5 * st;
+      double *a1 = a - 1, *b1 = b - 1;
+      double so = 0.0;
+      for (int t = 1; t <= T; ++t) { /* :47-49  y[t] ~ normal(tau[t], exp(0.5*x[t])) */
+        const double w = exp(-x1b[t]), res = y[t - 1] - tau1b[t];
+        so += -0.5 * x1b[t] - 0.5 * (res * res) * w;
+        a1[t] = res * w;                      /* d/dtau[t] */
+        b1[t] = -0.5 + 0.5 * (res * res) * w; /* d/dx[t] */
+      }
+      r += so;
+      *lp = r;
+      /* reverse sweep */
+      double *A1 = A - 1; /* A1[s] = sum_{t >= s} a[t] */
+      double acc = 0.0;
+      for (int t = T; t >= 1; --t) { acc += a1[t]; A1[t] = acc; }
+      grad[2 * T] = A1[1]; /* tau1 */
+      for (int s = 2; s <= T; ++s) {
+        grad[2 * T + s - 1] = ez[s - 1] * A1[s] - tin[s - 1];  /* tauinn[s-1] */
+        c[s - 1] = 0.5 * ez[s - 1] * tin[s - 1] * A1[s];      /* d/dz[s-1] */
+      }
+      double dsig = 0.0; /* sum over states of (dL/dstate) * (state - first state) / sigma-chain */
+      acc = 0.0;
+      for (int k = T - 1; k >= 1; --k) { /* z[k] = z1 + sigma * sum_{j<k} zinn[j] */
+        if (k <= T - 2) grad[1 + k] = sigma * acc - zin[k]; /* zinn[k] feeds z[k+1..T-1] */
+        acc += c[k];
+        dsig += c[k] * (z[k] - z[1]);
+      }
+      grad[1] = acc; /* z1 */
+      acc = 0.0;
+      for (int t = T; t >= 1; --t) { /* x[t] = x1 + sigma * sum_{j<t} xinn[j] */
+        if (t <= T - 1) grad[T + t] = sigma * acc - xin[t]; /* xinn[t] feeds x[t+1..T] */
+        acc += b1[t];
+        dsig += b1[t] * (x1b[t] - x1b[1]);
+      }
+      grad[T] = acc; /* x1 */
+      grad[0] = 5.0 - 0.5 * gpri - 0.5 * dsig; /* dsigma/dtSigma = -sigma/2 */
+      free(z);
+      return 0;
+    }
     default:
       return -1;
   }

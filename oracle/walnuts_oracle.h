@@ -33,7 +33,9 @@ enum {
   WNO_T_CORRGAUSS = 4,   /* targetDistr.py:25-31 */
   WNO_T_SMILE = 5,       /* targetDistr.py:34-38 */
   WNO_T_FUNNEL1 = 6,     /* targetDistr.py:88-93 */
-  WNO_T_MODFUNNEL = 7    /* targetDistr.py:41-51 */
+  WNO_T_MODFUNNEL = 7,   /* targetDistr.py:41-51 */
+  /* 8, 9: test/targets.py pairs (walnuts() variant); 10: caller-evaluated target of the product ABI */
+  WNO_T_STOCKWATSON = 11 /* WALNUTSpy_examples/StockWatson/sw_innov.stan:7-51; tpar = [T, y[T]], d = 3T */
 };
 
 /* integrator kinds */

@@ -135,3 +135,54 @@ def test_external_host_callable_is_the_reference_plugin_contract(wa):
     def bad(q, hessian=False):
         return [float("nan"), np.zeros_like(q)] if q[0] > 1e300 else lpFun(q)
     wa.WALNUTS(bad, q0[0], integrator=ai.fixedLeapFrog, H0=0.3, numIter=2, warmupIter=0, M=4, seed=1)
+
+
+# ---- StockWatson (BASELINE.json config 5) -----------------------------------------------------------
+import os  # noqa: E402
+
+_SW = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stockwatson_data.npz"))
+SW_T = int(_SW["T"][0])
+SW_TPAR = np.concatenate([[float(SW_T)], _SW["y"]])
+
+
+def test_stockwatson_lpfun_through_c_abi(wa):
+    """wn_lpfun (scalar device form) against the oracle at random points."""
+    rng = np.random.default_rng(0)
+    B, D = 5, 3 * SW_T
+    q = 0.4 * rng.normal(size=(B, D))
+    e = wa.Engine(D, B).set_target(ol.T_STOCKWATSON, SW_TPAR)
+    lp, g = e.lpfun(q)
+    lp = lp.cpu().numpy(); g = g.cpu().numpy(); e.close()
+    for b in range(B):
+        rl, rg = ol.lpfun(ol.T_STOCKWATSON, q[b], SW_TPAR)
+        close(lp[b], rl, rtol=1e-10, what="SW lp")
+        close(g[b], rg, rtol=1e-9, atol=1e-9, what="SW grad")
+
+
+@pytest.mark.parametrize("ig,kw", [(ol.I_FIXED, dict(H0=0.002, M=6, numIter=3)),
+                                   (ol.I_ADAPT_D, dict(H0=0.1, delta0=0.3, M=5, numIter=3, minC=3)),
+                                   (ol.I_ADAPT_R2P, dict(H0=0.1, delta0=0.3, M=5, numIter=3, minC=3))],
+                         ids=["fixed", "adaptD_minC3", "R2P_minC3"])
+def test_stockwatson_matches_oracle(wa, ig, kw):
+    """mainSW.py:41-80 settings on the fused wave kernel: per-step (q, v) against the oracle."""
+    rng = np.random.default_rng(12)
+    D, C = 3 * SW_T, 3
+    q0 = 0.1 * rng.normal(size=(C, D))
+    q0[0] = 0.0  # mainSW.py's initq.npy is not in the reference tree: q0 = 0 (SURVEY.md 8d cfg 5)
+    c = dict(target=ol.T_STOCKWATSON, integrator=ig, H0=kw["H0"], s=0.2, delta0=kw.get("delta0", 0.05), M=kw["M"],
+             numIter=kw["numIter"], minC=kw.get("minC", 0), maxC=10, R2Pprob0=2.0 / 3.0, generated=0, gen_k=0, tpar=SW_TPAR)
+    cap = 40 * (2 ** kw["M"]) * kw["numIter"]
+    out = run_engine(wa, c, q0, cap, chain_offset=500)
+    assert "stockwatson" in out["kernel"]
+    for k in (0, C - 1):
+        o = ol.walnuts(ol.T_STOCKWATSON, q0[k], integrator=ig, tpar=SW_TPAR, H0=c["H0"], delta0=c["delta0"],
+                       numIter=c["numIter"], M=c["M"], minC=c["minC"], seed=SEED, chain=500 + k, trace_cap=cap)
+        assert o["ncalls"] <= cap
+        compare_chain(out, k, o["trace"], o["samples"], o["diagnostics"], f"SW chain {k}")
+
+
+def test_stockwatson_python_api(wa):
+    from walnuts_amd import adaptiveIntegrators as ai, targetDistr as td
+    s, d = wa.WALNUTS(td.stockWatson(_SW["y"]), np.zeros((2, 3 * SW_T)), integrator=ai.adaptLeapFrogD, H0=0.1, delta0=0.3,
+                      numIter=4, warmupIter=0, M=6, igrAux=ai.integratorAuxPar(minC=3), seed=3)
+    assert s.shape == (2, 3 * SW_T, 5) and np.isfinite(s).all() and (d[:, :, 21] >= 3).all()

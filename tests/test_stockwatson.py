@@ -1,0 +1,70 @@
+"""StockWatson stochastic-volatility target (BASELINE.json config 5, sw_innov.stan): the oracle's C
+restatement against an independent NumPy restatement of the Stan program and its complex-step
+gradient.  bridgestan / Stan are not available: parity for this target is pinned
+by these checks only ("parity unpinned" against the reference's own numbers)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+SW = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stockwatson_data.npz"))
+T = int(SW["T"][0]); Y = SW["y"]
+TPAR = np.concatenate([[float(T)], Y])
+
+
+def sw_lp(q, y=Y):
+    """sw_innov.stan:7-51 with NumPy cumsums (works for complex q: complex-step derivative)."""
+    T = y.size
+    tS, z1, zinn = q[0], q[1], q[2:T]
+    x1, xinn = q[T], q[T + 1:2 * T]
+    tau1, tauinn = q[2 * T], q[2 * T + 1:3 * T]
+    sigma = np.exp(-0.5 * tS)
+    z = z1 + np.concatenate([[0.0], np.cumsum(sigma * zinn)])            # z[1..T-1]
+    x = x1 + np.concatenate([[0.0], np.cumsum(sigma * xinn)])            # x[1..T]
+    tau = tau1 + np.concatenate([[0.0], np.cumsum(np.exp(0.5 * z) * tauinn)])  # tau[1..T]
+    lp = 5.0 * tS - 0.5 * np.exp(tS)
+    lp = lp - 0.5 * np.sum(zinn * zinn) - 0.5 * np.sum(xinn * xinn) - 0.5 * np.sum(tauinn * tauinn)
+    return lp + np.sum(-0.5 * x - 0.5 * (y - tau) ** 2 * np.exp(-x))
+
+
+def sw_grad_complex_step(q):
+    g = np.empty(q.size)
+    for j in range(q.size):
+        qc = q.astype(complex); qc[j] += 1e-30j
+        g[j] = sw_lp(qc).imag / 1e-30
+    return g
+
+
+@pytest.mark.parametrize("seed,scale", [(0, 0.0), (1, 0.1), (2, 0.5), (3, 1.0)])
+def test_oracle_stockwatson_matches_numpy_restatement(seed, scale):
+    rng = np.random.default_rng(seed)
+    q = scale * rng.normal(size=3 * T)
+    lp, g = ol.lpfun(ol.T_STOCKWATSON, q, TPAR)
+    ref = sw_lp(q)
+    assert abs(lp - ref) <= 1e-11 * max(1.0, abs(ref))
+    gref = sw_grad_complex_step(q)
+    np.testing.assert_allclose(g, gref, rtol=1e-10, atol=1e-10 * np.abs(gref).max())
+
+
+def test_oracle_stockwatson_finite_differences():
+    rng = np.random.default_rng(7)
+    q = 0.3 * rng.normal(size=3 * T)
+    lp, g = ol.lpfun(ol.T_STOCKWATSON, q, TPAR)
+    for j in (0, 1, 2, T - 1, T, T + 1, 2 * T - 1, 2 * T, 2 * T + 1, 3 * T - 1):
+        h = 1e-6
+        qp = q.copy(); qp[j] += h
+        qm = q.copy(); qm[j] -= h
+        fd = (ol.lpfun(ol.T_STOCKWATSON, qp, TPAR)[0] - ol.lpfun(ol.T_STOCKWATSON, qm, TPAR)[0]) / (2 * h)
+        assert abs(fd - g[j]) <= 1e-5 * max(1.0, abs(g[j])), (j, fd, g[j])
+
+
+def test_oracle_stockwatson_sampler_runs():
+    """mainSW.py:41-80 settings (adaptLeapFrogD, minC=3, H0=0.1, delta=0.3) from q0 = 0, few iterations."""
+    o = ol.walnuts(ol.T_STOCKWATSON, np.zeros(3 * T), integrator=ol.I_ADAPT_D, tpar=TPAR, H0=0.1, delta0=0.3,
+                   numIter=3, M=6, minC=3, seed=5)
+    assert np.isfinite(o["samples"]).all()
+    assert (o["diagnostics"][:, 21] >= 3).all()  # min c >= minC
+    with pytest.raises(ValueError):  # d must be 3T
+        ol.lpfun(ol.T_STOCKWATSON, np.zeros(5), TPAR)

@@ -44,6 +44,13 @@ int choose_kernel(int target, int D, int waves_per_group, KernelChoice* kc) {
     kc->name = nm;
     return 0;
   }
+  if (target == WN_T_STOCKWATSON) {
+    if (D > 768 || D % 3) return -1;
+    kc->layout = 2; kc->p0 = 12; kc->p1 = T_STOCKWATSON; kc->W = 1;
+    snprintf(nm, 64, "wn_wave_kernel<NE=12,stockwatson>");
+    kc->name = nm;
+    return 0;
+  }
   if (target == WN_T_EXTERNAL) {  // caller-evaluated (logp, grad): split mode
     if (D > 1024) return -1;
     const int NE = D <= 512 ? 8 : 16;
@@ -172,11 +179,59 @@ __device__ double wn_target_eval(int kind, int D, const double* tpar, const doub
   return r;
 }
 
+// sw_innov.stan:7-51, scalar form (wn_lpfun only; the sampler evaluates WTgtStockWatson in the wave kernel)
+__device__ double wn_stockwatson_eval(const double* tpar, const double* x, double* g) {
+  double r = 0.0;
+  {
+      const int T = (int)tpar[0];
+      const double* y = tpar + 1;
+      const double tS = x[0], sigma = exp(-0.5 * tS), gpri = exp(tS);
+      const double *zin = x + 1, *xin = x + T, *tin = x + 2 * T;
+      double z[257], xs[257], ez[257], a[258], b[258];
+      z[1] = zin[0];
+      for (int t = 2; t <= T - 1; ++t) z[t] = z[t - 1] + sigma * zin[t - 1];
+      xs[1] = xin[0];
+      for (int t = 2; t <= T; ++t) xs[t] = xs[t - 1] + sigma * xin[t - 1];
+      double tau = tin[0];
+      r = 5.0 * tS - 0.5 * gpri;
+      for (int j = 1; j <= T - 2; ++j) r += -0.5 * zin[j] * zin[j];
+      for (int j = 1; j <= T - 1; ++j) r += -0.5 * xin[j] * xin[j] - 0.5 * tin[j] * tin[j];
+      for (int t = 1; t <= T; ++t) {
+        if (t >= 2) { ez[t - 1] = exp(0.5 * z[t - 1]); tau += ez[t - 1] * tin[t - 1]; }
+        const double w = exp(-xs[t]), res = y[t - 1] - tau;
+        r += -0.5 * xs[t] - 0.5 * (res * res) * w;
+        a[t] = res * w; b[t] = -0.5 + 0.5 * (res * res) * w;
+      }
+      double acc = 0.0, cacc = 0.0, dsig = 0.0;
+      a[T + 1] = 0.0;
+      for (int t = T; t >= 1; --t) a[t] += a[t + 1];  // A[t] = sum_{t' >= t} a[t']
+      g[2 * T] = a[1];
+      // c[k] = 1/2 ez[k] tauinn[k] A[k+1], k = T-1 .. 1
+      for (int k = T - 1; k >= 1; --k) {
+        g[2 * T + k] = ez[k] * a[k + 1] - tin[k];
+        const double c = 0.5 * ez[k] * tin[k] * a[k + 1];
+        if (k <= T - 2) g[1 + k] = sigma * cacc - zin[k];
+        cacc += c;
+        dsig += c * (z[k] - z[1]);
+      }
+      g[1] = cacc;
+      for (int t = T; t >= 1; --t) {
+        if (t <= T - 1) g[T + t] = sigma * acc - xin[t];
+        acc += b[t];
+        dsig += b[t] * (xs[t] - xs[1]);
+      }
+      g[T] = acc;
+      g[0] = 5.0 - 0.5 * gpri - 0.5 * dsig;
+  }
+  return r;
+}
+
 __global__ void wn_lpfun_kernel(int kind, int D, int B, const double* tpar, const double* q,
                                 double* lp, double* grad) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= B) return;
-  lp[c] = wn_target_eval(kind, D, tpar, q + (size_t)c * D, grad + (size_t)c * D);
+  lp[c] = kind == T_STOCKWATSON ? wn_stockwatson_eval(tpar, q + (size_t)c * D, grad + (size_t)c * D)
+                                : wn_target_eval(kind, D, tpar, q + (size_t)c * D, grad + (size_t)c * D);
 }
 
 // ---- walnuts/walnuts.py variant: extend_orbit for B chains, one thread per chain -----------------
@@ -375,6 +430,10 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
   switch (kind) {
     case WN_T_STDGAUSS: need = 0; break;
     case WN_T_EXTERNAL: need = 0; break;
+    case WN_T_STOCKWATSON:
+      if (D % 3 || D < 9 || D > 768) { e->err = "StockWatson needs dim = 3T, 3 <= T <= 256"; return WN_E_ARG; }
+      need = (size_t)D / 3 + 1;
+      break;
     case WN_T_DIAGGAUSS: need = (size_t)D; break;
     case WN_T_DENSEGAUSS: need = (size_t)D * D; break;
     case WN_T_FUNNEL10: if (D != 11) { e->err = "funnel10 needs dim 11"; return WN_E_ARG; } break;

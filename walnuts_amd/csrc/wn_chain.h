@@ -30,7 +30,7 @@
 
 namespace wn {
 
-enum { T_STDGAUSS = 0, T_FUNNEL10, T_DENSEGAUSS, T_DIAGGAUSS, T_CORRGAUSS, T_SMILE, T_FUNNEL1, T_MODFUNNEL };
+enum { T_STDGAUSS = 0, T_FUNNEL10, T_DENSEGAUSS, T_DIAGGAUSS, T_CORRGAUSS, T_SMILE, T_FUNNEL1, T_MODFUNNEL, T_STOCKWATSON = 11 };
 enum { I_FIXED = 0, I_ADAPT_D = 1, I_ADAPT_R2P = 2, I_ADAPT_YOSHIDA = 3 };
 enum { G_IDENTITY = 0, G_Q0_SUMSQ = 1, G_FIRSTK = 2 };
 enum { MODE_SAMPLE = 0, MODE_KAT = 1 };
@@ -868,6 +868,10 @@ struct Engine : ChainScalars {
     park();
   }
   WN_HD void park() {
+    // keinit_part / gen_part are per-lane PARTIAL sums, not replicated scalars: park their totals
+    // (the next reduce then adds the total in one lane to zeros: the same bits)
+    keinit_part = p.park_partial(keinit_part);
+    gen_part = p.park_partial(gen_part);
     p.park_scalars(static_cast<const ChainScalars&>(*this));
     p.template park_vec<0>(qa); p.template park_vec<1>(va); p.template park_vec<2>(ga);
     park_adapt();
@@ -889,6 +893,8 @@ struct Engine : ChainScalars {
   WN_HD bool split_tick() {
     p.unpark_scalars(static_cast<ChainScalars&>(*this));
     if (sp_stage == 2) return false;
+    keinit_part = p.unpark_partial(keinit_part);
+    gen_part = p.unpark_partial(gen_part);
     unpark();
 #pragma unroll
     for (int k = 0; k < 16; ++k) st_[k] = 0;

@@ -65,13 +65,17 @@ __global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __rest
     }
     fa0 = na0; fa1 = na1; fb0 = nb0; fb1 = nb1;
   }
-  // C/D layout: lane l holds rows 4*(l/16) + 0..3 (output index), column l%16 (chain)
-  double* o0 = xg + (size_t)(c0 + r) * DP + d0 + kq;
+  // C/D layout of v_mfma_f64_16x16x4_f64: register r of lane l holds row 4*r + l/16 (output index),
+  // column l%16 (chain)
+  double* o0 = xg + (size_t)(c0 + r) * DP + d0 + (lane >> 4);
   double* o1 = o0 + (size_t)16 * DP;
-  *(d4_t*)(o0) = -acc00;
-  *(d4_t*)(o1) = -acc01;
-  *(d4_t*)(o0 + 16) = -acc10;
-  *(d4_t*)(o1 + 16) = -acc11;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    o0[4 * j] = -acc00[j];
+    o1[4 * j] = -acc01[j];
+    o0[16 + 4 * j] = -acc10[j];
+    o1[16 + 4 * j] = -acc11[j];
+  }
 }
 
 template <int NE, int EXT>

@@ -1,5 +1,5 @@
 // wn_k_wave.hip -- persistent kernels of the one-chain-per-wavefront layout (wn_policy_wave.h) for
-// fused, HBM-bound targets with 256 < D <= 1024 (std / diagonal Gaussian).  One workgroup = one
+// fused, HBM-bound targets with 256 < D <= 1024 (std / diagonal Gaussian, StockWatson).  One workgroup = one
 // wave = one chain; no LDS, no barriers.
 #include "wn_launch.h"
 #include "wn_policy_wave.h"
@@ -8,7 +8,8 @@ namespace wn {
 
 template <int NE, class Tgt, bool ADAPT, bool WARM>
 __global__ __launch_bounds__(64) void wn_wave_kernel(Params prm) {
-  WavePolicy<NE, Tgt> p(prm, blockIdx.x);
+  __shared__ double lds[Tgt::LDS_DOUBLES > 0 ? Tgt::LDS_DOUBLES : 1];
+  WavePolicy<NE, Tgt> p(prm, blockIdx.x, lds);
   Engine<WavePolicy<NE, Tgt>, ADAPT, WARM> eng(p, prm);
   eng.run();
 }
@@ -27,6 +28,7 @@ static hipError_t go(bool adapt, bool warm, const Params& prm, hipStream_t st) {
 }
 
 size_t wave_work_doubles(int NE, int C, int M) {
+  if (NE == 12) return WavePolicy<12, WTgtDiag<12>>::work_doubles(C, M);
   return NE <= 8 ? WavePolicy<8, WTgtDiag<8>>::work_doubles(C, M) : WavePolicy<16, WTgtDiag<16>>::work_doubles(C, M);
 }
 
@@ -35,6 +37,7 @@ hipError_t launch_wave(const KernelChoice& kc, bool adapt, bool warm, const Para
     if (kc.p0 == 8) return go<8, WTgtDiag<8>>(adapt, warm, prm, st);
     if (kc.p0 == 16) return go<16, WTgtDiag<16>>(adapt, warm, prm, st);
   }
+  if (kc.p1 == T_STOCKWATSON && kc.p0 == 12) return go<12, WTgtStockWatson<12>>(adapt, warm, prm, st);
   return hipErrorInvalidValue;
 }
 

@@ -27,11 +27,12 @@ template <int NE>
 struct WTgtDiag {
   static constexpr int EXT = EXT_NONE;
   double a[NE];
-  __device__ __forceinline__ void init(const Params& prm, int lane) {
+  static constexpr int LDS_DOUBLES = 0;
+  __device__ __forceinline__ void init(const Params& prm, int lane, double*) {
 #pragma unroll
     for (int e = 0; e < NE; ++e) a[e] = (e * 64 + lane) < prm.D ? prm.tpar[e * 64 + lane] : 0.0;
   }
-  __device__ __forceinline__ double grad(const double* q, double* g) const {
+  __device__ __forceinline__ double grad(const double* q, double* g, int) const {
     double s = 0.0;
 #pragma unroll
     for (int e = 0; e < NE; ++e) { g[e] = -(a[e] * q[e]); s += q[e] * g[e]; }
@@ -44,9 +45,190 @@ struct WTgtDiag {
 template <int NE, int EXT_>
 struct WTgtExt {
   static constexpr int EXT = EXT_;
-  __device__ __forceinline__ void init(const Params&, int) {}
-  __device__ __forceinline__ double grad(const double*, double*) const { return 0.0; }
+  static constexpr int LDS_DOUBLES = 0;
+  __device__ __forceinline__ void init(const Params&, int, double*) {}
+  __device__ __forceinline__ double grad(const double*, double*, int) const { return 0.0; }
   __device__ __forceinline__ static double lp_finish(double r) { return EXT_ == EXT_HALF_QG ? 0.5 * r : r; }
+};
+
+
+// StockWatson stochastic volatility (BASELINE.json config 5; WALNUTSpy_examples/StockWatson/
+// sw_innov.stan:7-51 as bridgestan's log_density_gradient would evaluate it: unconstrained
+// parameters, constants dropped).  D = 3T, parameter order tSigma, z1, zinn[T-2], x1, xinn[T-1],
+// tau1, tauinn[T-1]; tpar = [T, y[1..T]], T <= 256.
+//
+// The three latent series are cumulative sums over time, so the gradient is evaluated in a
+// time-major mapping -- lane l owns t = 4l+1 .. 4l+4 of every series -- reached from the striped
+// register layout through a 6 KB LDS transpose; forward (z, x, tau) and backward (adjoint) sums are
+// lane-local runs of four plus wave-level Hillis-Steele scans of the lane totals.
+template <int NE>
+struct WTgtStockWatson {
+  static constexpr int EXT = EXT_NONE;
+  static constexpr int TPL = 4;              // time points per lane
+  static constexpr int LDS_DOUBLES = 64 * NE;
+  int T;
+  double y[TPL];
+  double* lds;
+  __device__ __forceinline__ void init(const Params& prm, int lane, double* lds_) {
+    T = (int)prm.tpar[0];
+    lds = lds_;
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) { const int t = TPL * lane + k + 1; y[k] = t <= T ? prm.tpar[t] : 0.0; }
+  }
+  __device__ __forceinline__ static double lp_finish(double r) { return r; }
+  __device__ __forceinline__ static double shup(double v, int d, int lane) {
+    const double o = __shfl_up(v, d);
+    return lane >= d ? o : 0.0;
+  }
+  __device__ __forceinline__ static double shdn(double v, int d, int lane) {
+    const double o = __shfl_down(v, d);
+    return lane + d < 64 ? o : 0.0;
+  }
+  // sum of the totals of all lower / higher lanes
+  __device__ __forceinline__ static double excl_below(double tot, int lane) {
+    double v = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v += shup(v, d, lane);
+    return shup(v, 1, lane);
+  }
+  __device__ __forceinline__ static double excl_above(double tot, int lane) {
+    double v = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v += shdn(v, d, lane);
+    return shdn(v, 1, lane);
+  }
+  __device__ __forceinline__ double grad(const double* q, double* g, int lane) const {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) lds[e * 64 + lane] = q[e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const double tS = lds[0];
+    const double sigma = exp(-0.5 * tS), gpri = exp(tS);
+    double uz[TPL], ux[TPL], tin[TPL], z[TPL], x[TPL], tau[TPL];
+    const int t0 = TPL * lane + 1;  // first time point of this lane (1-based)
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) {
+      const int t = t0 + k;
+      // raw parameters of the three blocks at time t (first entry of a block = initial state)
+      const double rz = t <= T - 1 ? lds[t] : 0.0;           // z1 | zinn[t-1]
+      const double rx = t <= T ? lds[T + t - 1] : 0.0;       // x1 | xinn[t-1]
+      tin[k] = t <= T ? lds[2 * T + t - 1] : 0.0;            // tau1 | tauinn[t-1]
+      uz[k] = t == 1 ? rz : sigma * rz;
+      ux[k] = t == 1 ? rx : sigma * rx;
+    }
+    // z[t], x[t]: inclusive sums over time (sw_innov.stan:27-31)
+    double run = 0.0;
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) { run += uz[k]; z[k] = run; }
+    double base = excl_below(run, lane);
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) z[k] += base;
+    run = 0.0;
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) { run += ux[k]; x[k] = run; }
+    base = excl_below(run, lane);
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) x[k] += base;
+    // tau[t] = tau[t-1] + exp(z[t-1]/2) * tauinn[t-1]  (:33-34): needs z one step back
+    double zprev[TPL], ezp[TPL];
+    zprev[0] = shup(z[TPL - 1], 1, lane);
+#pragma unroll
+    for (int k = 1; k < TPL; ++k) zprev[k] = z[k - 1];
+    run = 0.0;
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) {
+      const int t = t0 + k;
+      ezp[k] = (t >= 2 && t <= T) ? exp(0.5 * zprev[k]) : 0.0;
+      run += t == 1 ? tin[k] : ezp[k] * tin[k];
+      tau[k] = run;
+    }
+    base = excl_below(run, lane);
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) tau[k] += base;
+    // log density (:40-49) and the adjoints of tau[t], x[t]
+    double lp = 0.0, a[TPL], b[TPL];
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) {
+      const int t = t0 + k;
+      const bool on = t <= T;
+      const double w = exp(-x[k]), res = y[k] - tau[k];
+      const double rt = (t >= 2 && on) ? tin[k] : 0.0;
+      lp += on ? (-0.5 * x[k] - 0.5 * (res * res) * w) : 0.0;
+      lp += -0.5 * (rt * rt);
+      a[k] = on ? res * w : 0.0;
+      b[k] = on ? (-0.5 + 0.5 * (res * res) * w) : 0.0;
+    }
+    // innovation priors of z and x (:44-45) on the raw parameters
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) {
+      const int t = t0 + k;
+      const double rz = (t >= 2 && t <= T - 1) ? lds[t] : 0.0;
+      const double rx = (t >= 2 && t <= T) ? lds[T + t - 1] : 0.0;
+      lp += -0.5 * (rz * rz) - 0.5 * (rx * rx);
+    }
+    if (lane == 0) lp += 5.0 * tS - 0.5 * gpri;
+    // backward: A[t] = sum_{t' >= t} a[t'], B[t] = sum_{t' >= t} b[t']
+    double A[TPL], B[TPL];
+    run = 0.0;
+#pragma unroll
+    for (int k = TPL - 1; k >= 0; --k) { run += a[k]; A[k] = run; }
+    base = excl_above(run, lane);
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) A[k] += base;
+    run = 0.0;
+#pragma unroll
+    for (int k = TPL - 1; k >= 0; --k) { run += b[k]; B[k] = run; }
+    base = excl_above(run, lane);
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) B[k] += base;
+    // cc[t] = d/dz[t-1] = 1/2 exp(z[t-1]/2) tauinn[t-1] A[t]  (t = 2..T); CS[t] = sum_{t' > t} cc[t']
+    double cc[TPL], CS[TPL], dsig = 0.0;
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) {
+      const int t = t0 + k;
+      cc[k] = (t >= 2 && t <= T) ? 0.5 * ezp[k] * tin[k] * A[k] : 0.0;
+    }
+    run = 0.0;
+#pragma unroll
+    for (int k = TPL - 1; k >= 0; --k) { CS[k] = run; run += cc[k]; }
+    base = excl_above(run, lane);
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) CS[k] += base;
+    const double z1 = __shfl(z[0], 0), x1 = __shfl(x[0], 0);
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) {
+      const int t = t0 + k;
+      if (t >= 2 && t <= T) dsig += cc[k] * (zprev[k] - z1);
+      if (t <= T) dsig += b[k] * (x[k] - x1);
+    }
+    dsig = wavesum_(dsig);
+    __builtin_amdgcn_wave_barrier();
+    // gradients back to the parameter order, through the LDS transpose
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) {
+      const int t = t0 + k;
+      if (t <= T - 1) lds[t] = t == 1 ? CS[k] : sigma * CS[k] - lds[t];
+      if (t <= T) {
+        const double rx = lds[T + t - 1];
+        lds[T + t - 1] = t == 1 ? B[k] : sigma * B[k] - rx;
+        lds[2 * T + t - 1] = t == 1 ? A[k] : ezp[k] * A[k] - tin[k];
+      }
+    }
+    if (lane == 0) lds[0] = 5.0 - 0.5 * gpri - 0.5 * dsig;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+    for (int e = 0; e < NE; ++e) g[e] = (e * 64 + lane) < 3 * T ? lds[e * 64 + lane] : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    return lp;
+  }
+  __device__ __forceinline__ static double wavesum_(double x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+    return x;
+  }
 };
 
 template <int NE_, class Tgt>
@@ -76,7 +258,7 @@ struct WavePolicy {
   // workspace doubles for C chains: vectors, then parked scalars
   static size_t work_doubles(int C, int M) { return (size_t)C * (nvec(M) * DP + scalar_doubles()); }
 
-  __device__ WavePolicy(const Params& prm, int chain_local)
+  __device__ WavePolicy(const Params& prm, int chain_local, double* lds = nullptr)
       : D(prm.D), cl(chain_local), lane(threadIdx.x & 63), cg(prm.chain0 + (uint32_t)chain_local), nslot(prm.M + 1) {
     const int c = chain_local < prm.C ? chain_local : 0;
     vbase = prm.work + (size_t)c * nvec(prm.M) * DP + lane;
@@ -84,7 +266,7 @@ struct WavePolicy {
     xq = prm.xq ? prm.xq + (size_t)c * DP + lane : nullptr;
     xg = prm.xg ? prm.xg + (size_t)c * DP + lane : nullptr;
     xlp = prm.xlp ? prm.xlp + c : nullptr;
-    tgt.init(prm, lane);
+    tgt.init(prm, lane, lds);
   }
 
   __device__ __forceinline__ bool valid(int e) const { return e * 64 + lane < D; }
@@ -127,7 +309,7 @@ struct WavePolicy {
     for (int k = 0; k < N; ++k) v[k] = wavesum(v[k]);
   }
 
-  __device__ __forceinline__ void grad(const Vec& q, Vec& g, double& lp_part) const { lp_part = tgt.grad(q.x, g.x); }
+  __device__ __forceinline__ void grad(const Vec& q, Vec& g, double& lp_part) const { lp_part = tgt.grad(q.x, g.x, lane); }
   __device__ __forceinline__ double lp_finish(double r) const { return Tgt::lp_finish(r); }
 
   // ---- memory-resident vectors ------------------------------------------------------------------
@@ -167,6 +349,8 @@ struct WavePolicy {
   // ---- split mode ---------------------------------------------------------------------------------
   template <int K> __device__ __forceinline__ void park_vec(const Vec& x) const { vput(2 * nslot + COLD_N + 4 + WARM_N + K, x); }
   template <int K> __device__ __forceinline__ void unpark_vec(Vec& x) const { vget(2 * nslot + COLD_N + 4 + WARM_N + K, x); }
+  __device__ __forceinline__ double park_partial(double x) const { return wavesum(x); }
+  __device__ __forceinline__ double unpark_partial(double x) const { return lane == 0 ? x : 0.0; }
   __device__ __forceinline__ void park_scalars(const ChainScalars& s) const { if (lane == 0) *sc = s; }
   __device__ __forceinline__ void unpark_scalars(ChainScalars& s) const { s = *sc; }
   __device__ __forceinline__ void ext_put_q(const Vec& q) const {

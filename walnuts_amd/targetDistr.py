@@ -91,3 +91,14 @@ def diagGauss(a):
     """lp = -1/2 sum a_i q_i^2 (diagonal precision)."""
     a = np.asarray(a, dtype=np.float64) if not hasattr(a, "data_ptr") else a
     return DeviceTarget(f"diagGauss{a.shape[0]}", L.T_DIAGGAUSS, int(a.shape[0]), a)
+
+
+def stockWatson(y):
+    """StockWatson stochastic-volatility model of WALNUTSpy_examples/StockWatson/sw_innov.stan as
+    mainSW.py:15-26 evaluates it through bridgestan (unconstrained parameters, D = 3T, T <= 256);
+    `y` is the observation vector of swdata.json."""
+    y = np.asarray(y, dtype=np.float64)
+    T = int(y.shape[0])
+    if not 3 <= T <= 256:
+        raise ValueError("StockWatson needs 3 <= T <= 256")
+    return DeviceTarget(f"stockWatson{T}", L.T_STOCKWATSON, 3 * T, np.concatenate([[float(T)], y]))
