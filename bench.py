@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--kappa", type=float, default=1e4)
     ap.add_argument("--M", type=int, default=10)
     ap.add_argument("--H0", type=float, default=0.5)
-    ap.add_argument("--workload", default="gauss100", choices=["gauss100", "funnel"],
+    ap.add_argument("--workload", default="gauss100", choices=["gauss100", "funnel", "dense1000", "stockwatson"],
                     help="gauss100 = BASELINE configs[1] family (headline); funnel = configs[2] "
                          "(funnel10, adaptLeapFrogR2P, M=12, H0=0.3, delta0=0.3; SURVEY 8d cfg 3)")
     ap.add_argument("--no-extras", action="store_true",
@@ -113,6 +113,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.workload == "funnel":
         return main_funnel(args)
+    if args.workload == "stockwatson":
+        return main_stockwatson(args)
+    if args.workload == "dense1000":  # SURVEY 8d cfg 4: one GPU's shard (1024 chains) of the 8192-chain job
+        args.dim, args.kappa, args.no_extras = 1000, 100.0, True
+        if args.chains == 4096:
+            args.chains = 1024
+        if args.iters == 100:
+            args.iters = 50
     C, D = args.chains, args.dim
     offset = rank * C
     A, q0 = make_dense_problem(D, args.kappa, C, SEED, chain_offset=offset)
@@ -211,7 +219,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{D}-D dense Gaussian kappa={args.kappa:g}, {C} chains/GPU, "
                                    f"fixedLeapFrog, M={args.M}, H0={args.H0}, {args.iters} iterations/launch "
-                                   f"(SURVEY 8d cfg 2)",
+                                   f"(SURVEY 8d cfg {4 if D >= 1000 else 2})",
                        "chains_per_gpu": C, "dim": D, "iters_per_step": args.iters,
                        "kernel": eng.kernel_name, "sharding": f"chains x{world}, no data-path collective"},
             "leapfrog_steps_per_launch_per_gpu": steps_per_launch_rank0,
@@ -314,6 +322,52 @@ def main_funnel(args):
                       "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": ach / HBM_PEAK_GBS, "traffic": None,
                                    "bytes_per_gradient_evaluation": 528.0}}), flush=True)
+
+
+def main_stockwatson(args):
+    """SURVEY 8d cfg 5: StockWatson (D = 756), one GPU's shard of the 2048-chain job, the first of
+    mainSW.py:41-80's three runs (adaptLeapFrogD, minC=3, H0=0.1, delta0=0.3, M=14), q0 = 0.
+    Metric = gradient evaluations/s; roofline per SURVEY 8d: HBM, 48*D bytes per evaluation."""
+    import torch
+    torch.cuda.set_device(0)
+    import walnuts_amd as wa
+    from walnuts_amd import _lib as L
+    sw = np.load(os.path.join(ROOT, "tests", "golden", "stockwatson_data.npz"))
+    T = int(sw["T"][0]); D = 3 * T
+    C = 256 if args.chains == 4096 else args.chains
+    iters = 20 if args.iters == 100 else args.iters
+    eng = wa.Engine(D, C, integrator=L.I_ADAPT_D, H0=0.1, delta0=0.3, M=14, minC=3, generated=L.G_FIRSTK, gen_k=2)
+    eng.set_target(L.T_STOCKWATSON, np.concatenate([[float(T)], sw["y"]]))
+    q0d = torch.zeros((C, D), dtype=torch.float64, device="cuda")
+    for w in range(args.warmup):
+        eng.run(q0d, SEED + 1000 + w, iters)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tot = 0.0; kms = []; mx = []
+    for k in range(args.steps):
+        s, d = eng.run(q0d, SEED + k, iters)
+        per_chain = (d[:, :, 6] + d[:, :, 7]).sum(1)
+        tot += float(per_chain.sum().item())
+        mx.append(float(per_chain.max().item()))
+        kms.append(eng.last_run_ms())
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    bpe = 48.0 * D
+    ach = tot / args.steps * bpe / (np.mean(kms) * 1e-3) / 1e9
+    print(json.dumps({"metric": "gradient evaluations/sec across chains, StockWatson (adaptLeapFrogD)",
+                      "value": tot / el, "unit": "gradient evaluations/s", "n_gpus": 1, "steps": args.steps,
+                      "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+                      "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": f"StockWatson D={D}, {C} chains, adaptLeapFrogD minC=3, M=14, H0=0.1, "
+                                             f"delta0=0.3, q0=0, {iters} iterations/launch (SURVEY 8d cfg 5)",
+                                 "kernel": eng.kernel_name},
+                      "kernel_ms_avg": float(np.mean(kms)),
+                      "busiest_chain_evals": float(np.mean(mx)),
+                      "chain_occupancy": tot / args.steps / C / float(np.mean(mx)),
+                      "tick_us": float(np.mean(kms)) * 1e3 / float(np.mean(mx)),
+                      "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                   "bytes_per_gradient_evaluation": bpe}}), flush=True)
 
 
 if __name__ == "__main__":

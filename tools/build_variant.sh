@@ -6,7 +6,7 @@ NAME=$1; shift
 cd "$(dirname "$0")/../walnuts_amd/csrc"
 mkdir -p build_$NAME
 FLAGS="-O3 -std=c++17 -fPIC -fno-strict-aliasing --offload-arch=gfx950 -Wno-unused-result -Wno-unused-value $*"
-for f in wn_capi wn_k_lane wn_k_coop; do
+for f in wn_capi wn_k_lane wn_k_coop wn_k_wave wn_k_split wn_k_gemm; do
   ( /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o build_$NAME/$f.o ) &
 done
 wait

@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -520,6 +521,12 @@ static int run_split_dense(wn_engine* e, Params p, hipStream_t st, bool adapt, b
   if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
   int done = 0;
   e->sp_ticks = 0;
+#if defined(WN_STAMPS) || defined(WN_SPAN)
+  static unsigned long long* sbuf = nullptr;
+  if (!sbuf) hipMalloc((void**)&sbuf, (size_t)p.C * 16 * sizeof(unsigned long long));
+  hipMemset(sbuf, 0, (size_t)p.C * 16 * sizeof(unsigned long long));
+  p.stamps = sbuf;
+#endif
   while (done < p.C) {
     for (int k = 0; k < 64; ++k) {
       r = launch_dense_grad(e->apad, e->xq, e->xg, e->DP, p.D, e->Cpad, e->sp_done, p.C, st);
@@ -530,6 +537,41 @@ static int run_split_dense(wn_engine* e, Params p, hipStream_t st, bool adapt, b
     HIPCHK(e, hipMemcpyAsync(&done, e->sp_done, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));
   }
+#if defined(WN_STAMPS) || defined(WN_SPAN)
+  {
+    std::vector<unsigned long long> h((size_t)p.C * 16);
+    hipMemcpy(h.data(), sbuf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double tot[16] = {0};
+#ifdef WN_STAMPS
+    for (int c = 0; c < p.C; ++c) for (int k = 0; k < 16; ++k) tot[k] += (double)h[(size_t)c * 16 + k];
+    const char* names[16] = {"unpark", "grad_in+kick", "reduce", "C", "D_deep", "E_rest", "ticks", "A", "E_to_exp", "E_pick+stores",
+                             "E_doubling_end", "B_pre+park", "fast_dots", "", "", ""};
+    fprintf(stderr, "[WN_STAMPS split] 100 MHz ticks per chain-tick:");
+    for (int k = 0; k < 13; ++k) if (k != 6) fprintf(stderr, " %s=%.1f", names[k], tot[k] / tot[6]);
+    fprintf(stderr, " ticks/chain=%.0f\n", tot[6] / p.C);
+#endif
+    unsigned long long s0 = ~0ull, s1 = 0, e0 = ~0ull, e1 = 0; double dur = 0;
+    for (int c = 0; c < p.C; ++c) {
+      const unsigned long long a = h[(size_t)c * 16 + 13], b = h[(size_t)c * 16 + 14];
+      if (!a) continue;
+      if (a < s0) s0 = a; if (a > s1) s1 = a; if (b < e0) e0 = b; if (b > e1) e1 = b; dur += (double)(b - a);
+    }
+    {
+      std::vector<long long> st, en;
+      for (int c = 0; c < p.C; ++c) if (h[(size_t)c * 16 + 13]) { st.push_back((long long)(h[(size_t)c * 16 + 13] - s0)); en.push_back((long long)(h[(size_t)c * 16 + 14] - s0)); }
+      std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
+      fprintf(stderr, "[WN_SPAN] start percentiles (10 ns):");
+      for (int q = 0; q <= 10; ++q) fprintf(stderr, " %lld", st[(st.size() - 1) * q / 10]);
+      fprintf(stderr, "\n[WN_SPAN] end percentiles (10 ns):");
+      for (int q = 0; q <= 10; ++q) fprintf(stderr, " %lld", en[(en.size() - 1) * q / 10]);
+      fprintf(stderr, "\n[WN_SPAN] XCD-0 blocks (b%%8==0) start-end: ");
+      for (int c = 0; c < p.C; c += 8) fprintf(stderr, " b%d:%lld-%lld", c, (long long)(h[(size_t)c * 16 + 13] - s0), (long long)(h[(size_t)c * 16 + 14] - s0));
+      fprintf(stderr, "\n");
+    }
+    fprintf(stderr, "[WN_STAMPS split] launch 100, wall clock in 10 ns units: first start..last start %llu, first end..last end %llu, "
+            "first start..last end %llu, mean wave duration %.0f\n", s1 - s0, e1 - e0, e1 - s0, dur / p.C);
+  }
+#endif
   return WN_OK;
 }
 

@@ -110,45 +110,54 @@ enum { WARM_QL = 0, WARM_VL, WARM_QO, WARM_VO, WARM_GO, WARM_N };
 // ---- per-chain scalars (replicated in every lane that serves the chain) ---------------------
 // A plain struct so that the split-mode kernels (gradient evaluated outside the chain kernel) can
 // park a chain between launches with one struct copy.
+// Declared through a field list so that parking can copy member by member: an aggregate struct copy
+// left the arrays (and whatever shared their memcpy chunks) in scratch / LDS, and scratch-using waves
+// are admitted only 64 per XCD on this stack -- the split tick kernel then ran in four rounds.
+#define WN_CS_FIELDS(X, XA)                                                                      \
+  X(double, H0) X(double, Ha) X(double, Hb) X(double, lp0)                                       \
+  X(double, WoldSum) X(double, WnewSum) X(double, lwtSumf) X(double, lwtSumb) X(double, h2)      \
+  XA(double, uc, 8) /* uniforms 2*ub0 .. 2*ub0+7 of this (chain, iteration) */                   \
+  X(double, keinit_part) X(double, gen_part)                                                     \
+  /* diagnostics accumulators (WALNUTS.py:196-207, 660-693) */                                   \
+  X(double, orbitLen_) X(double, orbitLenSam_) X(double, indexStat_) X(double, indexStatOld_)    \
+  X(double, timeLenF_) X(double, timeLenB_)                                                      \
+  X(double, minlw) X(double, maxlw) X(double, Hmin) X(double, Hmax)                              \
+  /* macro-step integrator state */                                                              \
+  X(double, h) X(double, hh) X(double, Ham0) X(double, HamPass0) X(double, lwtf) X(double, lwt)  \
+  X(double, lpn) X(double, Hn) X(double, lpOut) X(double, HOut) X(double, lpCur) X(double, HCur) \
+  X(double, lpP) X(double, lpPL)                                                                 \
+  X(double, Hc) X(double, dc) /* step size H and tolerance delta of this chain (warm-up adapts) */ \
+  /* warm-up only: P2 quantile of log(igrConst) (P2quantile.py), energy-step statistics */       \
+  XA(double, p2q, 5) X(double, Hprev) X(double, madv) X(double, igrOut)                          \
+  X(double, sp_hh2) /* split mode: half-step factor of the micro step in flight */               \
+  X(int, iter) X(uint32_t, Bbits)                                                                \
+  X(int, i) X(int, xi) X(int, a) X(int, b) X(int, n) X(int, nleaf)                               \
+  X(uint32_t, ku) X(uint32_t, ub0) /* ub0: first Philox block of the cached uniform window */    \
+  X(int, nevalF) X(int, nevalB) X(int, L_) X(int, Lold_) X(int, NdS) X(int, NdC)                 \
+  X(int, maxFint) X(int, maxBint) X(int, stopCode)                                               \
+  X(int, minIf) X(int, maxIf) X(int, minc) X(int, maxc) X(int, nneq) X(int, nzero) X(int, nused) \
+  X(int, ph) X(int, c) X(int, im) X(int, nstep) X(int, If) X(int, Ib) X(int, cSim) X(int, maxTry) \
+  X(int, nEvF) X(int, nEvB) X(int, cret)                                                         \
+  X(int, sub) /* adaptYoshidaD: leapfrog sub-step 0..2 inside the current micro step */          \
+  X(uint32_t, firemask)                                                                          \
+  X(int, gen_iter) /* iteration whose deferred generated() row is pending */                     \
+  X(int, ip) X(int, ipl) X(int, p2n) XA(int, p2m, 5) X(int, ntrace)                              \
+  X(int, sp_stage) /* split mode: 0 = waiting for grad(q0), 1 = running, 2 = finished */         \
+  X(bool, live) X(bool, needKE) X(bool, needGen) X(bool, bothEndsPassive) X(bool, Hnan)          \
+  X(bool, needMacro) X(bool, needPass) X(bool, fin) X(bool, needIter) X(bool, needDoubling)      \
+  X(bool, endIter) X(bool, allfin) X(bool, inPass) X(bool, madnan)                               \
+  X(bool, sp_act) /* split mode: the micro step in flight belongs to an active chain */
+
+#define WN_CS_DECL(T, N) T N;
+#define WN_CS_DECLA(T, N, K) T N[K];
+#define WN_CS_COPY(T, N) d_.N = s_.N;
+#define WN_CS_COPYA(T, N, K) _Pragma("unroll") for (int k_ = 0; k_ < K; ++k_) d_.N[k_] = s_.N[k_];
+
 struct alignas(16) ChainScalars {
-  double H0, Ha, Hb, lp0;
-  double WoldSum, WnewSum, lwtSumf, lwtSumb, h2;
-  double uc[8];   // uniforms 2*ub0 .. 2*ub0+7 of this (chain, iteration)
-  double keinit_part, gen_part;
-  // diagnostics accumulators (WALNUTS.py:196-207, 660-693)
-  double orbitLen_, orbitLenSam_, indexStat_, indexStatOld_, timeLenF_, timeLenB_;
-  double minlw, maxlw, Hmin, Hmax;
-  // macro-step integrator state
-  double h, hh, Ham0, HamPass0, lwtf, lwt, lpn, Hn, lpOut, HOut, lpCur, HCur;
-  double lpP, lpPL;
-  double Hc, dc;  // big step size H and tolerance delta of this chain (adapted during warm-up)
-  // warm-up only: P2 quantile of log(igrConst) (P2quantile.py), energy-step statistics
-  double p2q[5], Hprev, madv, igrOut;
-  double sp_hh2;  // split mode: half-step factor of the micro step in flight
-  int iter;
-  uint32_t Bbits;
-  int i, xi, a, b, n, nleaf;
-  uint32_t ku;
-  uint32_t ub0;   // first Philox block of the cached uniform window
-  int nevalF, nevalB, L_, Lold_, NdS, NdC, maxFint, maxBint, stopCode;
-  int minIf, maxIf, minc, maxc, nneq, nzero, nused;
   enum { PH_FWD = 0, PH_FWD2 = 1, PH_BWD = 2 };
-  int ph, c, im, nstep, If, Ib, cSim, maxTry, nEvF, nEvB, cret;
-  int sub;  // adaptYoshidaD: leapfrog sub-step 0..2 inside the current micro step
-  uint32_t firemask;
-  int gen_iter;  // iteration whose deferred generated() row is pending
-  int ip, ipl;
-  int p2n, p2m[5];
-  int ntrace;
-  int sp_stage;  // split mode: 0 = waiting for grad(q0), 1 = running, 2 = finished
-  bool live;
-  bool needKE, needGen;
-  bool bothEndsPassive;
-  bool Hnan;
-  bool needMacro, needPass, fin, needIter, needDoubling, endIter;
-  bool allfin, inPass;
-  bool madnan;
-  bool sp_act;  // split mode: the micro step in flight belongs to an active chain
+  WN_CS_FIELDS(WN_CS_DECL, WN_CS_DECLA)
+  // member-by-member copy (see above)
+  WN_HD static void copy(ChainScalars& d_, const ChainScalars& s_) { WN_CS_FIELDS(WN_CS_COPY, WN_CS_COPYA) }
 };
 
 template <class P, bool ADAPT, bool WARM = false>
@@ -225,9 +234,13 @@ struct Engine : ChainScalars {
     double ztmp[P::NE];
     // rolled on purpose: one copy of philox + Box-Muller in the code instead of NE (this runs
     // once per iteration; the dynamic index costs a few scratch stores)
+    if (P::NE > 8) {
 #pragma unroll 1
-    for (int e = 0; e < P::NE; ++e)
-      ztmp[e] = p.valid(e) ? rng_normal(prm.seed, p.chain_global(), (uint32_t)iter, (uint32_t)p.gidx(e)) : 0.0;
+      for (int e = 0; e < P::NE; ++e)
+        ztmp[e] = p.valid(e) ? rng_normal(prm.seed, p.chain_global(), (uint32_t)iter, (uint32_t)p.gidx(e)) : 0.0;
+    } else {  // few registers per vector: no dynamic index, no scratch
+      WN_VFOR(e) ztmp[e] = p.valid(e) ? rng_normal(prm.seed, p.chain_global(), (uint32_t)iter, (uint32_t)p.gidx(e)) : 0.0;
+    }
     WN_VFOR(e) {  // :236  v = normal(size=d); both ends start at (qc, v, grad0)  :239-253
       double z = ztmp[e];
       va.x[e] = z;
@@ -867,25 +880,38 @@ struct Engine : ChainScalars {
     p.ext_put_q(qa);  // grad(q0) is evaluated next
     park();
   }
+  // Homes between launches: the work position (qa for fixedLeapFrog, qw otherwise) IS the row of the
+  // exchange buffer the gradient kernel reads, and the gradient of an active chain arrives in the
+  // other exchange buffer, so neither is parked; everything else goes to the chain's park slots.
   WN_HD void park() {
     // keinit_part / gen_part are per-lane PARTIAL sums, not replicated scalars: park their totals
     // (the next reduce then adds the total in one lane to zeros: the same bits)
     keinit_part = p.park_partial(keinit_part);
     gen_part = p.park_partial(gen_part);
     p.park_scalars(static_cast<const ChainScalars&>(*this));
-    p.template park_vec<0>(qa); p.template park_vec<1>(va); p.template park_vec<2>(ga);
+    p.template park_vec<1>(va);
+    if (ADAPT) { p.template park_vec<0>(qa); p.template park_vec<2>(ga); }
+    else if (!sp_act) p.template park_vec<2>(ga);
     park_adapt();
   }
   WN_HD void unpark() {
-    p.template unpark_vec<0>(qa); p.template unpark_vec<1>(va); p.template unpark_vec<2>(ga);
+    p.template unpark_vec<1>(va);
+    if (ADAPT) { p.template unpark_vec<0>(qa); p.template unpark_vec<2>(ga); }
+    else {
+      p.ext_get_q(qa);
+      if (!sp_act) p.template unpark_vec<2>(ga);
+    }
     unpark_adapt();
   }
   template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_>::type park_adapt() {
-    p.template park_vec<3>(qw); p.template park_vec<4>(vw); p.template park_vec<5>(gw);
+    p.template park_vec<4>(vw);
+    if (!sp_act) p.template park_vec<5>(gw);
   }
   template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_>::type park_adapt() {}
   template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_>::type unpark_adapt() {
-    p.template unpark_vec<3>(qw); p.template unpark_vec<4>(vw); p.template unpark_vec<5>(gw);
+    p.ext_get_q(qw);
+    p.template unpark_vec<4>(vw);
+    if (!sp_act) p.template unpark_vec<5>(gw);
   }
   template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_>::type unpark_adapt() {}
 
@@ -899,6 +925,10 @@ struct Engine : ChainScalars {
 #pragma unroll
     for (int k = 0; k < 16; ++k) st_[k] = 0;
     st_last_ = 0;
+#if defined(WN_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    st_last_ = p.t_start;
+#endif
+    WN_STAMP(0);
     Vec& Q = QW(); Vec& V = VW(); Vec& G = GW();
     double part[NPB > 2 * NFAST ? NPB : 2 * NFAST];
     if (sp_stage == 0) {  // f0, grad0 = lpFun(q0)  (WALNUTS.py:177,249)
@@ -919,10 +949,12 @@ struct Engine : ChainScalars {
       double ke = 0.0;
       WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; ke += V.x[e] * V.x[e]; }
       part[1] = ke; part[2] = keinit_part; part[3] = gen_part;
+      WN_STAMP(1);
       if (!ADAPT) {
         fin = act;
         if (p.any(nchecks() > 0)) {
           fast_dots(part + 4);
+          WN_STAMP(12);
           p.template reduce<NPB>(part);
         } else {
 #pragma unroll
@@ -932,6 +964,7 @@ struct Engine : ChainScalars {
       } else {
         p.template reduce<NPB>(part);
       }
+      WN_STAMP(2);
       finish_generated(part[3]);
       if (act) {
         if (needKE) {  // Hs[I0] = -f0 + 0.5*sum(v**2)  (:256); multinomialLscale (:259)
@@ -948,6 +981,7 @@ struct Engine : ChainScalars {
         if (!ADAPT) after_micro(p.lp_finish(part[0]), part[1]);
         else if (!inPass) pass_end();
       }
+      WN_STAMP(3);
       // ---- D: U-turn checks ----
       const int nchk = nchecks();
       firemask = 0;
@@ -984,11 +1018,13 @@ struct Engine : ChainScalars {
             firemask |= (1u << j);
         }
       }
+      WN_STAMP(4);
       // ---- E ----
       if (live && fin) {
         step_done();
         if (endIter) end_iteration();
       }
+      WN_STAMP(5);
     }
     if (!p.any(live || needGen)) {
       sp_stage = 2;
@@ -1002,6 +1038,7 @@ struct Engine : ChainScalars {
     if (live && needDoubling) start_doubling();
     if (live && needMacro) setup_macro();
     if (ADAPT && live && needPass) setup_pass();
+    WN_STAMP(7);
     // ---- B, first half: kick + drift; the position goes out for the gradient ----
     {
       Vec& Q2 = QW(); Vec& V2 = VW(); Vec& G2 = GW();
@@ -1016,6 +1053,15 @@ struct Engine : ChainScalars {
       sp_act = act; sp_hh2 = hh2;
     }
     park();
+    WN_STAMP(11);
+    st_[6] += 1;
+#if defined(WN_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    if (prm.stamps && p.writer()) {
+      unsigned long long* o = prm.stamps + (size_t)p.chain_local() * 16;
+      for (int k = 0; k < 13; ++k) o[k] += st_[k];
+      if (o[6] == 100) { o[13] = p.t_real; o[14] = __builtin_amdgcn_s_memrealtime(); }  // wall clock (100 MHz) of launch 100
+    }
+#endif
     return true;
   }
 

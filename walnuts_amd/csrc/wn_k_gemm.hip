@@ -1,0 +1,104 @@
+// wn_k_gemm.hip -- the batched dense-Gaussian gradient of split mode (wn_k_split.hip):
+//   xg[c][d] = -sum_k A[d][k] xq[c][k]      (A symmetric, zero-padded to DP x DP; xq, xg [Cpad][DP])
+// as v_mfma_f64_16x16x4_f64 with M = output index d, N = chain, K = k.  Built with
+// -mllvm -amdgpu-mfma-vgpr-form (Makefile): with accumulators homed in AGPRs the compiler moved all
+// 128 of them through VGPRs on every trip of the k-loop.
+#include "wn_launch.h"
+
+namespace wn {
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// Workgroup = 4 waves = one 64 x 64 output tile.  Every wave accumulates the WHOLE tile (16 MFMA
+// tiles, 64 accumulator doubles per lane) over its own quarter of k, so each operand element is
+// loaded once per workgroup and one 16-byte fragment load feeds eight MFMAs (with a 32 x 32 wave
+// tile the vector-memory path, 64 B/clk/CU, was as busy as the matrix pipe).  Both operands are read
+// "along k": lane l loads row l%16, k0 + 2*(l/16) .. +1, which serve two k-steps (the sum over k does
+// not care which k sits in which MFMA slot as long as A and B agree).  Two register sets alternate,
+// the set not being multiplied is in flight.  The four partial tiles meet in LDS at the end, each
+// wave finishing and storing a quarter.
+#define WN_GEMM_LOAD(SET, KOFF)                                                    \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                \
+    fa##SET[i_] = *(const d2_t*)(ap + i_ * rs + (KOFF));                            \
+    fb##SET[i_] = *(const d2_t*)(bp + i_ * rs + (KOFF));                            \
+  }
+#define WN_GEMM_MUL(SET)                                                           \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                  \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                  \
+  _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                  \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa##SET[i_][s_], fb##SET[j_][s_], acc[i_][j_], 0, 0, 0);
+
+__global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __restrict__ A, const double* __restrict__ xq,
+                                                            double* __restrict__ xg, int DP, int Kr, int tiles_d,
+                                                            int tiles_c, const int* done, int C) {
+  if (*done >= C) return;  // every chain has finished: nothing reads the result
+  __shared__ double red[4 * 48 * 64];  // [owner wave][partial accumulator of a contributor][lane]
+  const int T = tiles_d * tiles_c, per = (T + 7) / 8;
+  // consecutive blocks go to different XCDs: give each XCD a contiguous range of tiles (same chains,
+  // neighbouring rows of A) so its L2 sees each operand row once
+  const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || t >= T) return;
+  const int ct = t / tiles_d, dt = t % tiles_d;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int d0 = dt * 64, c0 = ct * 64;
+  const int r = lane & 15;
+  // this wave's k-range [wave*Kq, (wave+1)*Kq): a multiple of 16 long; beyond Kr both operands are zero
+  const int Kq = ((Kr + 3) / 4 + 15) / 16 * 16;
+  const double* ap = A + (size_t)(d0 + r) * DP + wave * Kq + 2 * (lane >> 4);   // + i * 16 rows
+  const double* bp = xq + (size_t)(c0 + r) * DP + wave * Kq + 2 * (lane >> 4);  // + j * 16 rows
+  const size_t rs = (size_t)16 * DP;
+  d4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (d4_t){0, 0, 0, 0};
+  d2_t fa0[4], fb0[4], fa1[4], fb1[4];
+  WN_GEMM_LOAD(0, 0);
+  for (int k = 0; k < Kq; k += 16) {
+    WN_GEMM_LOAD(1, k + 8);
+    WN_GEMM_MUL(0);
+    WN_GEMM_LOAD(0, (k + 16 < Kq ? k + 16 : k));
+    WN_GEMM_MUL(1);
+  }
+  // wave w finishes the tiles with d-block i == w: the other waves hand it their partials
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i != wave) {
+      const int slot = wave < i ? wave : wave - 1;  // 0..2 among the three contributors of owner i
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[((i * 48) + (slot * 16 + j * 4 + q)) * 64 + lane] = acc[i][j][q];
+    }
+  }
+  __syncthreads();
+  // C/D layout of v_mfma_f64_16x16x4_f64: register q of lane l holds row 4*q + l/16 (output index),
+  // column l%16 (chain)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i == wave) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double* o = xg + (size_t)(c0 + 16 * j + r) * DP + d0 + 16 * i + (lane >> 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          double v = acc[i][j][q];
+#pragma unroll
+          for (int sl = 0; sl < 3; ++sl) v += red[((i * 48) + (sl * 16 + j * 4 + q)) * 64 + lane];
+          o[4 * q] = -v;
+        }
+      }
+    }
+  }
+}
+
+hipError_t launch_dense_grad(const double* A, const double* xq, double* xg, int DP, int D, int Cpad, const int* done, int C,
+                             hipStream_t st) {
+  const int tiles_d = DP / 64, tiles_c = Cpad / 64, T = tiles_d * tiles_c, per = (T + 7) / 8;
+  const int Kr = (D + 15) / 16 * 16;
+  hipLaunchKernelGGL(wn_dense_grad_kernel, dim3(8 * per), dim3(256), 0, st, A, xq, xg, DP, Kr, tiles_d, tiles_c, done, C);
+  return hipGetLastError();
+}
+
+}  // namespace wn

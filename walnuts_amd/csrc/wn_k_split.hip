@@ -8,79 +8,41 @@
 
 namespace wn {
 
-template <int NE, int EXT, bool ADAPT, bool WARM>
-__global__ __launch_bounds__(64) void wn_split_begin_kernel(Params prm) {
-  using P = WavePolicy<NE, WTgtExt<NE, EXT>>;
-  P p(prm, blockIdx.x);
+// DPW = DP / 64 (8 or 16); every chain is served by a workgroup of SPLIT_W waves, DPW/SPLIT_W registers per vector
+constexpr int SPLIT_W = 2;
+
+template <int DPW, int EXT, bool ADAPT, bool WARM>
+__global__ __launch_bounds__(64 * SPLIT_W) void wn_split_begin_kernel(Params prm) {
+  using P = WavePolicy<DPW / SPLIT_W, WTgtExt<DPW / SPLIT_W, EXT>, SPLIT_W>;
+  __shared__ double lds[P::LDS_DOUBLES > 0 ? P::LDS_DOUBLES : 1];
+  P p(prm, blockIdx.x, lds);
   Engine<P, ADAPT, WARM> eng(p, prm);
   eng.split_begin();
 }
 
-template <int NE, int EXT, bool ADAPT, bool WARM>
-__global__ __launch_bounds__(64) void wn_split_tick_kernel(Params prm) {
-  using P = WavePolicy<NE, WTgtExt<NE, EXT>>;
-  P p(prm, blockIdx.x);
+template <int DPW, int EXT, bool ADAPT, bool WARM>
+__global__ __launch_bounds__(64 * SPLIT_W) void wn_split_tick_kernel(Params prm) {
+  using P = WavePolicy<DPW / SPLIT_W, WTgtExt<DPW / SPLIT_W, EXT>, SPLIT_W>;
+  __shared__ double lds[P::LDS_DOUBLES > 0 ? P::LDS_DOUBLES : 1];
+  P p(prm, blockIdx.x, lds);
   Engine<P, ADAPT, WARM> eng(p, prm);
+#ifdef WN_SPAN  // diagnostic build: wall-clock start / end of every workgroup of launch 100
+  const unsigned long long span0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const bool was_done = p.sc->sp_stage == 2;
   const bool more = eng.split_tick();
-  if (!more && !was_done && (threadIdx.x & 63) == 0) atomicAdd(prm.sp_done, 1);
-}
-
-// grad = -A q for every chain: xg[c][d] = -sum_k A[d][k] xq[c][k]   (A symmetric, zero-padded to
-// DP x DP; xq, xg are [Cpad][DP] with zero padding).  v_mfma_f64_16x16x4_f64 with M = output index d,
-// N = chain, K = k.  Both operands are read "along k": lane l loads 32 contiguous bytes
-// row (l%16), k0 + 4*(l/16) .. +3, which serve four k-steps (the sum over k does not care which k
-// sits in which MFMA slot as long as A and B agree).  Workgroup tile 64 x 64, wave tile 32 x 32.
-typedef double d4_t __attribute__((ext_vector_type(4)));
-
-__global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __restrict__ A, const double* __restrict__ xq,
-                                                            double* __restrict__ xg, int DP, int Kr, int tiles_d,
-                                                            int tiles_c, const int* done, int C) {
-  if (*done >= C) return;  // every chain has finished: nothing reads the result
-  const int T = tiles_d * tiles_c, per = (T + 7) / 8;
-  // consecutive blocks go to different XCDs: give each XCD a contiguous range of tiles (same chains,
-  // neighbouring rows of A) so its L2 sees each operand row once
-  const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= per || t >= T) return;
-  const int ct = t / tiles_d, dt = t % tiles_d;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int d0 = dt * 64 + (wave & 1) * 32, c0 = ct * 64 + (wave >> 1) * 32;
-  const int r = lane & 15, kq = 4 * (lane >> 4);
-  const double* a0 = A + (size_t)(d0 + r) * DP + kq;
-  const double* a1 = a0 + (size_t)16 * DP;
-  const double* b0 = xq + (size_t)(c0 + r) * DP + kq;
-  const double* b1 = b0 + (size_t)16 * DP;
-  d4_t acc00 = {0, 0, 0, 0}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
-  d4_t fa0 = *(const d4_t*)a0, fa1 = *(const d4_t*)a1, fb0 = *(const d4_t*)b0, fb1 = *(const d4_t*)b1;
-  for (int k0 = 0; k0 < Kr; k0 += 16) {
-    const int kn = k0 + 16 < Kr ? k0 + 16 : k0;  // prefetch the next k-block while this one multiplies
-    const d4_t na0 = *(const d4_t*)(a0 + kn), na1 = *(const d4_t*)(a1 + kn);
-    const d4_t nb0 = *(const d4_t*)(b0 + kn), nb1 = *(const d4_t*)(b1 + kn);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[s], fb0[s], acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[s], fb1[s], acc01, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[s], fb0[s], acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[s], fb1[s], acc11, 0, 0, 0);
-    }
-    fa0 = na0; fa1 = na1; fb0 = nb0; fb1 = nb1;
+  if (!more && !was_done && threadIdx.x == 0) atomicAdd(prm.sp_done, 1);
+#ifdef WN_SPAN
+  if (prm.stamps && threadIdx.x == 0) {
+    unsigned long long* o = prm.stamps + (size_t)blockIdx.x * 16;
+    if (o[6]++ == 100) { o[13] = span0; o[14] = __builtin_amdgcn_s_memrealtime(); }
   }
-  // C/D layout of v_mfma_f64_16x16x4_f64: register r of lane l holds row 4*r + l/16 (output index),
-  // column l%16 (chain)
-  double* o0 = xg + (size_t)(c0 + r) * DP + d0 + (lane >> 4);
-  double* o1 = o0 + (size_t)16 * DP;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    o0[4 * j] = -acc00[j];
-    o1[4 * j] = -acc01[j];
-    o0[16 + 4 * j] = -acc10[j];
-    o1[16 + 4 * j] = -acc11[j];
-  }
+#endif
 }
 
 template <int NE, int EXT>
 static hipError_t go_begin(bool adapt, bool warm, const Params& prm, hipStream_t st) {
-  dim3 grid(prm.C), block(64);
+  dim3 grid(prm.C), block(64 * SPLIT_W);
   if (warm) {
     if (adapt) hipLaunchKernelGGL((wn_split_begin_kernel<NE, EXT, true, true>), grid, block, 0, st, prm);
     else hipLaunchKernelGGL((wn_split_begin_kernel<NE, EXT, false, true>), grid, block, 0, st, prm);
@@ -92,7 +54,7 @@ static hipError_t go_begin(bool adapt, bool warm, const Params& prm, hipStream_t
 }
 template <int NE, int EXT>
 static hipError_t go_tick(bool adapt, bool warm, const Params& prm, hipStream_t st) {
-  dim3 grid(prm.C), block(64);
+  dim3 grid(prm.C), block(64 * SPLIT_W);
   if (warm) {
     if (adapt) hipLaunchKernelGGL((wn_split_tick_kernel<NE, EXT, true, true>), grid, block, 0, st, prm);
     else hipLaunchKernelGGL((wn_split_tick_kernel<NE, EXT, false, true>), grid, block, 0, st, prm);
@@ -128,12 +90,4 @@ hipError_t launch_split_tick(const KernelChoice& kc, bool adapt, bool warm, cons
   }
   return hipErrorInvalidValue;
 }
-hipError_t launch_dense_grad(const double* A, const double* xq, double* xg, int DP, int D, int Cpad, const int* done, int C,
-                             hipStream_t st) {
-  const int tiles_d = DP / 64, tiles_c = Cpad / 64, T = tiles_d * tiles_c, per = (T + 7) / 8;
-  const int Kr = (D + 15) / 16 * 16;
-  hipLaunchKernelGGL(wn_dense_grad_kernel, dim3(8 * per), dim3(256), 0, st, A, xq, xg, DP, Kr, tiles_d, tiles_c, done, C);
-  return hipGetLastError();
-}
-
 }  // namespace wn

@@ -23,14 +23,14 @@ struct EmptyVecW {};
 enum { EXT_NONE = 0, EXT_HALF_QG = 1, EXT_LP = 2 };
 
 // lp = -1/2 sum a_i q_i^2, grad = -a_i q_i  (stdGauss, targetDistr.py:18-21, is a == 1)
-template <int NE>
+template <int NE, int ES = 64>
 struct WTgtDiag {
   static constexpr int EXT = EXT_NONE;
   double a[NE];
   static constexpr int LDS_DOUBLES = 0;
-  __device__ __forceinline__ void init(const Params& prm, int lane, double*) {
+  __device__ __forceinline__ void init(const Params& prm, int l0, double*) {
 #pragma unroll
-    for (int e = 0; e < NE; ++e) a[e] = (e * 64 + lane) < prm.D ? prm.tpar[e * 64 + lane] : 0.0;
+    for (int e = 0; e < NE; ++e) a[e] = (e * ES + l0) < prm.D ? prm.tpar[e * ES + l0] : 0.0;
   }
   __device__ __forceinline__ double grad(const double* q, double* g, int) const {
     double s = 0.0;
@@ -231,12 +231,18 @@ struct WTgtStockWatson {
   }
 };
 
-template <int NE_, class Tgt>
+// W waves (one workgroup) serve a chain: register e of wave w, lane l holds element (e*W + w)*64 + l.
+template <int NE_, class Tgt, int W_ = 1>
 struct WavePolicy {
   static constexpr int NE = NE_;
-  static constexpr int DP = 64 * NE_;
+  static constexpr int W = W_;
+  static constexpr int ES = 64 * W_;    // element stride between registers
+  static constexpr int DP = ES * NE_;
   static constexpr int NLC = 0;         // every sub-tree left endpoint lives in the slot store
   static constexpr int ALIGN_LOG2 = 0;  // chains do not share a wave: nothing to align
+  static constexpr int NRED = 8;        // widest reduction (wn_chain.h NPB)
+  static constexpr int LDS_DOUBLES = Tgt::LDS_DOUBLES + (W_ > 1 ? 2 * NRED * W_ : 0);
+  static_assert(W_ == 1 || Tgt::LDS_DOUBLES == 0, "LDS targets are single-wave");
   struct Vec {
     double x[NE_];
   };
@@ -244,9 +250,12 @@ struct WavePolicy {
   using Opt = typename std::conditional<B, Vec, EmptyVecW>::type;
   enum { NPARK = 6 };
 
-  int D, cl, lane;
+  int D, cl, lane, wave, l0;
+  unsigned long long t_start, t_real;  // diagnostic builds (-DWN_STAMPS)
   uint32_t cg;
   int nslot;
+  int redpar;
+  double* ldsr;      // cross-wave reduction buffers [2][NRED][W]
   double* vbase;     // this chain's vectors: [2*nslot + COLD_N + 4 + WARM_N + NPARK][DP]
   ChainScalars* sc;  // this chain's parked scalars
   double *xq, *xg;   // split mode: position out / gradient in, [C][DP]
@@ -259,23 +268,32 @@ struct WavePolicy {
   static size_t work_doubles(int C, int M) { return (size_t)C * (nvec(M) * DP + scalar_doubles()); }
 
   __device__ WavePolicy(const Params& prm, int chain_local, double* lds = nullptr)
-      : D(prm.D), cl(chain_local), lane(threadIdx.x & 63), cg(prm.chain0 + (uint32_t)chain_local), nslot(prm.M + 1) {
+      : D(prm.D), cl(chain_local), lane(threadIdx.x & 63), wave(W_ > 1 ? (int)(threadIdx.x >> 6) : 0),
+        cg(prm.chain0 + (uint32_t)chain_local), nslot(prm.M + 1), redpar(0) {
+    t_start = 0; t_real = 0;
+#if defined(WN_STAMPS)
+    t_real = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_start)::"memory");
+#endif
+    l0 = wave * 64 + lane;
+    ldsr = lds + Tgt::LDS_DOUBLES;
     const int c = chain_local < prm.C ? chain_local : 0;
-    vbase = prm.work + (size_t)c * nvec(prm.M) * DP + lane;
+    vbase = prm.work + (size_t)c * nvec(prm.M) * DP + l0;
     sc = reinterpret_cast<ChainScalars*>(prm.work + (size_t)prm.C * nvec(prm.M) * DP + (size_t)c * scalar_doubles());
-    xq = prm.xq ? prm.xq + (size_t)c * DP + lane : nullptr;
-    xg = prm.xg ? prm.xg + (size_t)c * DP + lane : nullptr;
+    xq = prm.xq ? prm.xq + (size_t)c * DP + l0 : nullptr;
+    xg = prm.xg ? prm.xg + (size_t)c * DP + l0 : nullptr;
     xlp = prm.xlp ? prm.xlp + c : nullptr;
-    tgt.init(prm, lane, lds);
+    tgt.init(prm, l0, lds);
   }
 
-  __device__ __forceinline__ bool valid(int e) const { return e * 64 + lane < D; }
+  __device__ __forceinline__ bool valid(int e) const { return e * ES + l0 < D; }
   __device__ __forceinline__ bool owner(int) const { return true; }
-  __device__ __forceinline__ int gidx(int e) const { return e * 64 + lane; }
-  __device__ __forceinline__ bool writer() const { return lane == 0; }
+  __device__ __forceinline__ int gidx(int e) const { return e * ES + l0; }
+  __device__ __forceinline__ bool writer() const { return l0 == 0; }
   __device__ __forceinline__ int chain_local() const { return cl; }
   __device__ __forceinline__ uint32_t chain_global() const { return cg; }
-  // the scalars are replicated: every lane votes the same, and the vote makes the branch scalar
+  // the scalars are replicated: every lane of every wave votes the same, and the vote makes the
+  // branch scalar
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
   __device__ __forceinline__ bool majority(bool a, bool) const { return __any(a); }
 
@@ -303,10 +321,30 @@ struct WavePolicy {
     b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
     return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
   }
+  // sum over all lanes serving the chain; every replica gets the same bits.  Two buffers alternate:
+  // a wave can reuse a buffer only after the barrier of the next reduction, behind which every wave
+  // has finished reading it.
   template <int N>
-  __device__ __forceinline__ void reduce(double* v) const {
+  __device__ __forceinline__ void reduce(double* v) {
+    static_assert(N <= NRED, "reduce width");
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] = wavesum(v[k]);
+    if (W_ > 1) {
+      double* buf = ldsr + (redpar & 1) * (NRED * W_);
+      redpar++;
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) buf[k * W_ + wave] = v[k];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < W_; ++w) s += buf[k * W_ + w];
+        v[k] = s;
+      }
+    }
   }
 
   __device__ __forceinline__ void grad(const Vec& q, Vec& g, double& lp_part) const { lp_part = tgt.grad(q.x, g.x, lane); }
@@ -317,12 +355,12 @@ struct WavePolicy {
   __device__ __forceinline__ void vput(int v, const Vec& x) const {
     double* d = vp(v);
 #pragma unroll
-    for (int e = 0; e < NE; ++e) d[e * 64] = x.x[e];
+    for (int e = 0; e < NE; ++e) d[e * ES] = x.x[e];
   }
   __device__ __forceinline__ void vget(int v, Vec& x) const {
     const double* s = vp(v);
 #pragma unroll
-    for (int e = 0; e < NE; ++e) x.x[e] = s[e * 64];
+    for (int e = 0; e < NE; ++e) x.x[e] = s[e * ES];
   }
   __device__ __forceinline__ void slot_store(int slot, const Vec& q, const Vec& v) const { vput(2 * slot, q); vput(2 * slot + 1, v); }
   __device__ __forceinline__ void slot_load(int slot, Vec& q, Vec& v) const { vget(2 * slot, q); vget(2 * slot + 1, v); }
@@ -342,27 +380,31 @@ struct WavePolicy {
   __device__ __forceinline__ void diag_store(double* row, const double* d) const {
     double v = 0.0;
 #pragma unroll
-    for (int k = 0; k < NDIAG; ++k) v = lane == k ? d[k] : v;
-    if (lane < NDIAG) row[lane] = v;
+    for (int k = 0; k < NDIAG; ++k) v = l0 == k ? d[k] : v;
+    if (l0 < NDIAG) row[l0] = v;
   }
 
   // ---- split mode ---------------------------------------------------------------------------------
   template <int K> __device__ __forceinline__ void park_vec(const Vec& x) const { vput(2 * nslot + COLD_N + 4 + WARM_N + K, x); }
   template <int K> __device__ __forceinline__ void unpark_vec(Vec& x) const { vget(2 * nslot + COLD_N + 4 + WARM_N + K, x); }
-  __device__ __forceinline__ double park_partial(double x) const { return wavesum(x); }
-  __device__ __forceinline__ double unpark_partial(double x) const { return lane == 0 ? x : 0.0; }
-  __device__ __forceinline__ void park_scalars(const ChainScalars& s) const { if (lane == 0) *sc = s; }
-  __device__ __forceinline__ void unpark_scalars(ChainScalars& s) const { s = *sc; }
+  __device__ __forceinline__ double park_partial(double x) { double v[1] = {x}; reduce<1>(v); return v[0]; }
+  __device__ __forceinline__ double unpark_partial(double x) const { return l0 == 0 ? x : 0.0; }
+  __device__ __forceinline__ void park_scalars(const ChainScalars& s) const { if (l0 == 0) ChainScalars::copy(*sc, s); }
+  __device__ __forceinline__ void unpark_scalars(ChainScalars& s) const { ChainScalars::copy(s, *sc); }
   __device__ __forceinline__ void ext_put_q(const Vec& q) const {
 #pragma unroll
-    for (int e = 0; e < NE; ++e) xq[e * 64] = q.x[e];  // the padding beyond D stays zero (vectors are zero there)
+    for (int e = 0; e < NE; ++e) xq[e * ES] = q.x[e];  // the padding beyond D stays zero (vectors are zero there)
+  }
+  __device__ __forceinline__ void ext_get_q(Vec& q) const {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) q.x[e] = xq[e * ES];
   }
   // gradient (and log density) of the position sent out by the previous launch
   __device__ __forceinline__ void ext_get(const Vec& q, Vec& g, double& lp_part) const {
 #pragma unroll
-    for (int e = 0; e < NE; ++e) g.x[e] = valid(e) ? xg[e * 64] : 0.0;
+    for (int e = 0; e < NE; ++e) g.x[e] = valid(e) ? xg[e * ES] : 0.0;
     if (Tgt::EXT == EXT_LP) {
-      lp_part = lane == 0 ? *xlp : 0.0;
+      lp_part = l0 == 0 ? *xlp : 0.0;
     } else {
       double s = 0.0;
 #pragma unroll
