@@ -66,7 +66,8 @@ enum {
   WN_I_FIXED = 0,     /* fixedLeapFrog    adaptiveIntegrators.py:49-59  */
   WN_I_ADAPT_D = 1,   /* adaptLeapFrogD   adaptiveIntegrators.py:65-137 */
   WN_I_ADAPT_R2P = 2, /* adaptLeapFrogR2P adaptiveIntegrators.py:361-475 */
-  WN_I_ADAPT_YOSHIDA = 3 /* adaptYoshidaD  adaptiveIntegrators.py:142-240 */
+  WN_I_ADAPT_YOSHIDA = 3, /* adaptYoshidaD  adaptiveIntegrators.py:142-240 */
+  WN_I_ADAPT_FLOWD = 4    /* adaptLeapFrogFlowD adaptiveIntegrators.py:246-356 (lane / wave / split layouts) */
 };
 
 /* generated(q): what is stored per draw (WALNUTS.py:113,164,695) */

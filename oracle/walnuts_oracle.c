@@ -338,6 +338,20 @@ typedef struct {
  * On return qq,vv,gg hold the end state, *fnew the last lp; returns all(isfinite(Hams));
  * *maxErr = abs(Hams[0]-Hams[-1]); *maxAbsDiff = max(abs(diff(Hams))); *Hlast = Hams[-1]. */
 static int g_yoshida = 0; /* set by integrator_impl for adaptYoshidaD (single-threaded test tool) */
+static int g_flow = 0;    /* set by integrator_impl for adaptLeapFrogFlowD */
+/* np.max(np.abs(a - b)) over d elements (NaN-propagating) */
+static double np_max_absdiff(int d, const double *a, const double *b) {
+  double m = -INFINITY;
+  int nan = 0;
+  for (int k = 0; k < d; ++k) {
+    double x = fabs(a[k] - b[k]);
+    if (isnan(x)) nan = 1;
+    else if (x > m) m = x;
+  }
+  return nan ? NAN : m;
+}
+/* Python's builtin max(err, x): x if x > err else err */
+static double py_max(double err, double x) { return x > err ? x : err; }
 static int micro_pass(const lpctx *t, int c, double h, const double *q, const double *vv0,
                       const double *g, double Ham0, double *qq, double *vv, double *gg,
                       double *vh, double *fnew, double *hh_out, double *maxErr,
@@ -351,6 +365,8 @@ static int micro_pass(const lpctx *t, int c, double h, const double *q, const do
   int allfin = isfinite(Ham0) ? 1 : 0;
   double prev = Ham0, mad = -INFINITY;
   int madnan = 0;
+  double flow_max = -INFINITY;
+  int flow_nan = 0;
   for (long i = 1; i <= nstep; ++i) {
     if (g_yoshida) { /* adaptiveIntegrators.py:143-144,157-173: three leapfrog sub-steps */
       const double firstLast = 1.351207191959658, middle = -1.702414383919315;
@@ -363,6 +379,34 @@ static int micro_pass(const lpctx *t, int c, double h, const double *q, const do
         (*nEval)++;
         for (int k = 0; k < d; ++k) vv[k] = vh[k] + a * gg[k];
       }
+    } else if (g_flow) { /* adaptLeapFrogFlowD, adaptiveIntegrators.py:262-290 (forward) / 319-343 (backward) */
+      double *qold = (double *)malloc(sizeof(double) * (size_t)(6 * d));
+      double *gold = qold + d, *vold = gold + d, *qMid = vold + d, *gMid = qMid + d, *tmp = gMid + d;
+      double hh2 = 0.5 * hh, fMid;
+      for (int k = 0; k < d; ++k) vh[k] = vv[k] + hh2 * gg[k];                     /* :263 */
+      memcpy(qold, qq, sizeof(double) * d); memcpy(gold, gg, sizeof(double) * d);  /* :264-266 */
+      memcpy(vold, vv, sizeof(double) * d);
+      for (int k = 0; k < d; ++k) qq[k] = qq[k] + hh * vh[k];                      /* :267 */
+      wno_lpfun(t->target, d, t->tpar, qq, fnew, gg);                              /* :268 */
+      (*nEval)++;
+      for (int k = 0; k < d; ++k) vv[k] = vh[k] + hh2 * gg[k];                     /* :270 */
+      for (int k = 0; k < d; ++k) qMid[k] = 0.5 * (qq[k] + qold[k]) + (hh / 8.0) * (vold[k] - vv[k]); /* :272 */
+      wno_lpfun(t->target, d, t->tpar, qMid, &fMid, gMid);                         /* :273 */
+      (*nEval)++;
+      const double hh_sq = hh * hh, h6 = hh / 6.0;
+      for (int k = 0; k < d; ++k)                                                  /* :276 qf */
+        tmp[k] = qold[k] + hh * vold[k] + hh_sq * ((1.0 / 6.0) * gold[k] + (1.0 / 3.0) * gMid[k]);
+      double err = np_max_absdiff(d, tmp, qq);                                     /* :277 */
+      for (int k = 0; k < d; ++k) tmp[k] = vold[k] + h6 * (gold[k] + gg[k] + 4.0 * gMid[k]); /* :279 vf */
+      err = py_max(err, np_max_absdiff(d, tmp, vv));                               /* :280 */
+      for (int k = 0; k < d; ++k)                                                  /* :282 qb */
+        tmp[k] = qq[k] - hh * vv[k] + hh_sq * ((1.0 / 6.0) * gg[k] + (1.0 / 3.0) * gMid[k]);
+      err = py_max(err, np_max_absdiff(d, tmp, qold));                             /* :283 */
+      for (int k = 0; k < d; ++k) tmp[k] = -(-vv[k] + h6 * (gold[k] + gg[k] + 4.0 * gMid[k])); /* :285 vb */
+      err = py_max(err, np_max_absdiff(d, tmp, vold));                             /* :287 */
+      if (isnan(err)) flow_nan = 1; /* maxErr = np.max(Errs)  :294 */
+      else if (err > flow_max) flow_max = err;
+      free(qold);
     } else {
     double hh2 = 0.5 * hh;
     for (int k = 0; k < d; ++k) vh[k] = vv[k] + hh2 * gg[k];
@@ -379,7 +423,7 @@ static int micro_pass(const lpctx *t, int c, double h, const double *q, const do
     prev = Hi;
   }
   *hh_out = hh;
-  *maxErr = fabs(Ham0 - prev);
+  *maxErr = g_flow ? (flow_nan ? NAN : flow_max) : fabs(Ham0 - prev);
   *maxAbsDiff = madnan ? NAN : mad;
   *Hlast = prev;
   return allfin;
@@ -411,6 +455,11 @@ static void integrator_impl(int kind, const lpctx *t, const double *q, const dou
 
   g_yoshida = (kind == WNO_I_ADAPT_YOSHIDA);
   if (kind == WNO_I_ADAPT_YOSHIDA) kind = WNO_I_ADAPT_D; /* same search/weight logic, :146-240 */
+  g_flow = (kind == WNO_I_ADAPT_FLOWD);
+  if (kind == WNO_I_ADAPT_FLOWD) { /* :246-356: the search of adaptLeapFrogD with c = 0..maxC (minC is ignored) */
+    kind = WNO_I_ADAPT_D;
+    minC = 0;
+  }
   /* forward search  adaptiveIntegrators.py:67-94 (D) / 363-389 (R2P) */
   int nEvalF = 0, nEvalB = 0;
   int If = maxC;

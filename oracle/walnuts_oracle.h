@@ -43,7 +43,8 @@ enum {
   WNO_I_FIXED = 0, /* adaptiveIntegrators.py:49-59  fixedLeapFrog   */
   WNO_I_ADAPT_D = 1, /* adaptiveIntegrators.py:65-137 adaptLeapFrogD  */
   WNO_I_ADAPT_R2P = 2, /* adaptiveIntegrators.py:361-475 adaptLeapFrogR2P */
-  WNO_I_ADAPT_YOSHIDA = 3 /* adaptiveIntegrators.py:142-240 adaptYoshidaD (4th order, 3 gradients per micro step) */
+  WNO_I_ADAPT_YOSHIDA = 3, /* adaptiveIntegrators.py:142-240 adaptYoshidaD (4th order, 3 gradients per micro step) */
+  WNO_I_ADAPT_FLOWD = 4    /* adaptiveIntegrators.py:246-356 adaptLeapFrogFlowD (flow-error criterion, 2 gradients per micro step) */
 };
 
 /* generated() kinds: what is stored per draw */

@@ -155,7 +155,8 @@ def dense_precision(d, kappa, seed):
 
 
 INTEGRATORS = {"fixed": (ai.fixedLeapFrog, ol.I_FIXED), "D": (ai.adaptLeapFrogD, ol.I_ADAPT_D),
-               "R2P": (ai.adaptLeapFrogR2P, ol.I_ADAPT_R2P), "Y": (ai.adaptYoshidaD, ol.I_ADAPT_YOSHIDA)}
+               "R2P": (ai.adaptLeapFrogR2P, ol.I_ADAPT_R2P), "Y": (ai.adaptYoshidaD, ol.I_ADAPT_YOSHIDA),
+               "F": (ai.adaptLeapFrogFlowD, ol.I_ADAPT_FLOWD)}
 
 
 def gen_q0_sumsq(q):
@@ -241,6 +242,13 @@ def main():
         H0=0.6, delta0=0.2, numIter=25, M=7)
     add("modfunnel_fixed", ol.T_MODFUNNEL, td.modFunnel, np.array([0.2, 0.4]), "fixed",
         H0=0.3, numIter=25, M=7)
+    # adaptLeapFrogFlowD (adaptiveIntegrators.py:246-356), SURVEY.md 8f rank 2 (appended: earlier cases keep their draws)
+    add("std3_F", ol.T_STDGAUSS, td.stdGauss, rng.normal(size=3), "F", H0=1.2, delta0=0.01, numIter=25, M=6)
+    add("funnel_F", ol.T_FUNNEL10, td.funnel10, np.r_[0.3, np.exp(0.15) * rng.normal(size=10)], "F",
+        H0=0.4, delta0=0.02, numIter=15, M=6)
+    add("smile_F", ol.T_SMILE, td.smileDistr, np.array([0.4, -0.1]), "F", H0=0.6, delta0=0.005, numIter=25, M=7)
+    add("dense8_F_warm", ol.T_DENSEGAUSS, make_dense(A8w), S8w @ rng.normal(size=8), "F",
+        tpar=A8w.ravel(), H0=0.8, delta0=0.02, numIter=30, M=6, warm=dict(warmupIter=20))
 
     for chain, c in enumerate(cases):
         fn, kind = INTEGRATORS[c["integ"]]
@@ -280,36 +288,43 @@ def main():
     targets = [("std3", ol.T_STDGAUSS, td.stdGauss, None, 3), ("std100", ol.T_STDGAUSS, td.stdGauss, None, 100),
                ("funnel", ol.T_FUNNEL10, td.funnel10, None, 11),
                ("dense6", ol.T_DENSEGAUSS, make_dense(A6), A6.ravel(), 6)]
+    def one_kat(tname, tk, lpF, d, ig, rep, krng):
+        fn, kind = INTEGRATORS[ig]
+        q = krng.normal(size=d)
+        if tname == "funnel":
+            q[0] = krng.normal() * 2.0
+            q[1:] *= np.exp(0.5 * q[0])
+        v = krng.normal(size=d)
+        lp0, g = lpF(q)
+        g = np.asarray(g, float)
+        Ham0 = -lp0 + 0.5 * sum(v * v)
+        h = float(krng.uniform(0.2, 1.5))
+        xi = 1 if rep % 2 == 0 else -1
+        delta = float(krng.choice([0.3, 0.05, 1e-3]))
+        u = float(krng.uniform())
+        minC = 0 if rep < 4 else 2
+        aux = ai.integratorAuxPar(minC=minC, maxC=10 if rep != 3 else 3)
+        saved = np.random.uniform
+        np.random.uniform = lambda *a, **k: np.float64(u)
+        try:
+            o = fn(q, v, g, Ham0, h, xi, lpF, delta, aux)
+        finally:
+            np.random.uniform = saved
+        kats.append(dict(t=tname, tk=tk, kind=kind, d=d, q=q, v=v, g=g, Ham0=Ham0, h=h,
+                         xi=xi, delta=delta, u=u, minC=aux.minC, maxC=aux.maxC,
+                         q1=np.asarray(o.q, float), v1=np.asarray(o.v, float),
+                         g1=np.asarray(o.grad, float),
+                         io=np.array([o.nEvalF, o.nEvalB, o.If, o.Ib, o.c]),
+                         do=np.array([o.lp, o.lwt, o.igrConst])))
+
     for tname, tk, lpF, tpar, d in targets:
         for ig in ("fixed", "D", "R2P", "Y"):
-            fn, kind = INTEGRATORS[ig]
             for rep in range(6):
-                q = krng.normal(size=d)
-                if tname == "funnel":
-                    q[0] = krng.normal() * 2.0
-                    q[1:] *= np.exp(0.5 * q[0])
-                v = krng.normal(size=d)
-                lp0, g = lpF(q)
-                g = np.asarray(g, float)
-                Ham0 = -lp0 + 0.5 * sum(v * v)
-                h = float(krng.uniform(0.2, 1.5))
-                xi = 1 if rep % 2 == 0 else -1
-                delta = float(krng.choice([0.3, 0.05, 1e-3]))
-                u = float(krng.uniform())
-                minC = 0 if rep < 4 else 2
-                aux = ai.integratorAuxPar(minC=minC, maxC=10 if rep != 3 else 3)
-                saved = np.random.uniform
-                np.random.uniform = lambda *a, **k: np.float64(u)
-                try:
-                    o = fn(q, v, g, Ham0, h, xi, lpF, delta, aux)
-                finally:
-                    np.random.uniform = saved
-                kats.append(dict(t=tname, tk=tk, kind=kind, d=d, q=q, v=v, g=g, Ham0=Ham0, h=h,
-                                 xi=xi, delta=delta, u=u, minC=aux.minC, maxC=aux.maxC,
-                                 q1=np.asarray(o.q, float), v1=np.asarray(o.v, float),
-                                 g1=np.asarray(o.grad, float),
-                                 io=np.array([o.nEvalF, o.nEvalB, o.If, o.Ib, o.c]),
-                                 do=np.array([o.lp, o.lwt, o.igrConst])))
+                one_kat(tname, tk, lpF, d, ig, rep, krng)
+    frng = np.random.default_rng(23)  # FlowD KATs from their own stream: the earlier ones keep their values
+    for tname, tk, lpF, tpar, d in targets:
+        for rep in range(6):
+            one_kat(tname, tk, lpF, d, "F", rep, frng)
     g1["n"] = np.array([len(kats)])
     g1["dense6_A"] = A6.ravel()
     for i, k in enumerate(kats):

@@ -19,7 +19,10 @@ static void run_all(const Params& prm) {
   for (int c = 0; c < prm.C; ++c) {
     LanePolicy<DMAX, Tgt> p(prm, c);
     const bool warm = prm.warmupIter > 0;
-    if (prm.integrator == I_FIXED) {
+    if (prm.integrator == I_ADAPT_FLOWD) {
+      if (warm) { Engine<LanePolicy<DMAX, Tgt>, true, true, true> e(p, prm); e.run(); }
+      else { Engine<LanePolicy<DMAX, Tgt>, true, false, true> e(p, prm); e.run(); }
+    } else if (prm.integrator == I_FIXED) {
       if (warm) { Engine<LanePolicy<DMAX, Tgt>, false, true> e(p, prm); e.run(); }
       else { Engine<LanePolicy<DMAX, Tgt>, false, false> e(p, prm); e.run(); }
     } else {

@@ -323,7 +323,13 @@ def test_walnuts_api_shapes(wa):
     lo, go = ol.lpfun(ol.T_FUNNEL10, np.arange(11) * 0.1)
     np.testing.assert_allclose(lp, lo, rtol=1e-12); np.testing.assert_allclose(g, go, rtol=1e-12)
     with pytest.raises(TypeError):
-        wa.WALNUTS(lambda q: [0.0, -q], np.zeros(3), warmupIter=0)
+        wa.WALNUTS("stdGauss", np.zeros(3), warmupIter=0)  # neither a descriptor nor a callable
+    with pytest.raises(TypeError):
+        wa.WALNUTS(td.stdGauss, np.zeros(3), integrator=lambda *a: None, warmupIter=0)  # integrators are descriptors
+    # a plain callable lpFun(q) -> [lp, grad] is the reference's plugin contract: it runs (split mode, host-evaluated)
+    s4, d4 = wa.WALNUTS(lambda q: [-0.5 * float(q @ q), -q], np.zeros(3), warmupIter=0, numIter=4, M=4, H0=0.8, seed=2)
+    s5, d5 = wa.WALNUTS(td.stdGauss, np.zeros(3), warmupIter=0, numIter=4, M=4, H0=0.8, seed=2)
+    close(s4, s5, what="host callable vs fused stdGauss")
     with pytest.raises(SystemExit):
         wa.WALNUTS(td.stdGauss, np.zeros(3), adaptHtarget=2.0)  # WALNUTS.py:140
     # the reference's defaults (warmupIter=1000, adaptH, adaptDelta; WALNUTS.py:119-127) run as they are

@@ -25,6 +25,12 @@ WAVE = [
     ("dense300_R2P_split", ol.T_DENSEGAUSS, 300, ol.I_ADAPT_R2P, dict(H0=1.2, delta0=0.3, M=5, numIter=3), 6, (0, 5)),
     ("dense520_D_split", ol.T_DENSEGAUSS, 520, ol.I_ADAPT_D, dict(H0=1.2, delta0=0.3, M=4, numIter=2), 3, (2,)),
     ("dense1000_fixed_split", ol.T_DENSEGAUSS, 1000, ol.I_FIXED, dict(H0=0.5, M=5, numIter=2), 5, (0, 4)),
+    # adaptLeapFrogFlowD (adaptiveIntegrators.py:246-356) has no cooperative-layout kernel: Gaussians beyond the
+    # lane layout run one chain per wavefront, dense ones in split mode (two exchanges per micro step)
+    ("std60_F_wave", ol.T_STDGAUSS, 60, ol.I_ADAPT_FLOWD, dict(H0=1.2, delta0=0.02, M=5, numIter=3), 3, (0, 2)),
+    ("diag300_F_wave", ol.T_DIAGGAUSS, 300, ol.I_ADAPT_FLOWD, dict(H0=0.9, delta0=0.05, M=5, numIter=3), 3, (1,)),
+    ("dense40_F_split", ol.T_DENSEGAUSS, 40, ol.I_ADAPT_FLOWD, dict(H0=1.0, delta0=0.05, M=5, numIter=3), 5, (0, 4)),
+    ("dense200_F_split", ol.T_DENSEGAUSS, 200, ol.I_ADAPT_FLOWD, dict(H0=1.0, delta0=0.05, M=4, numIter=2), 3, (2,)),
 ]
 
 
@@ -161,8 +167,9 @@ def test_stockwatson_lpfun_through_c_abi(wa):
 
 @pytest.mark.parametrize("ig,kw", [(ol.I_FIXED, dict(H0=0.002, M=6, numIter=3)),
                                    (ol.I_ADAPT_D, dict(H0=0.1, delta0=0.3, M=5, numIter=3, minC=3)),
-                                   (ol.I_ADAPT_R2P, dict(H0=0.1, delta0=0.3, M=5, numIter=3, minC=3))],
-                         ids=["fixed", "adaptD_minC3", "R2P_minC3"])
+                                   (ol.I_ADAPT_R2P, dict(H0=0.1, delta0=0.3, M=5, numIter=3, minC=3)),
+                                   (ol.I_ADAPT_FLOWD, dict(H0=0.05, delta0=0.01, M=4, numIter=2))],
+                         ids=["fixed", "adaptD_minC3", "R2P_minC3", "flowD"])
 def test_stockwatson_matches_oracle(wa, ig, kw):
     """mainSW.py:41-80 settings on the fused wave kernel: per-step (q, v) against the oracle."""
     rng = np.random.default_rng(12)

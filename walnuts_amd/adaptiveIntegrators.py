@@ -62,3 +62,4 @@ fixedLeapFrog = DeviceIntegrator("fixedLeapFrog", L.I_FIXED)            # adapti
 adaptLeapFrogD = DeviceIntegrator("adaptLeapFrogD", L.I_ADAPT_D)        # adaptiveIntegrators.py:65
 adaptLeapFrogR2P = DeviceIntegrator("adaptLeapFrogR2P", L.I_ADAPT_R2P)  # adaptiveIntegrators.py:361
 adaptYoshidaD = DeviceIntegrator("adaptYoshidaD", L.I_ADAPT_YOSHIDA)    # adaptiveIntegrators.py:142
+adaptLeapFrogFlowD = DeviceIntegrator("adaptLeapFrogFlowD", L.I_ADAPT_FLOWD)  # adaptiveIntegrators.py:246

@@ -34,7 +34,8 @@ static int lane_dmax(int target, int D) {
   return 0;
 }
 
-int choose_kernel(int target, int D, int waves_per_group, KernelChoice* kc) {
+int choose_kernel(int target, int D, int waves_per_group, int integrator, KernelChoice* kc) {
+  const bool flow = integrator == I_ADAPT_FLOWD;  // no cooperative-layout kernels: its gradient holds barriers
   static char names[8][64];
   static int slot = 0;
   char* nm = names[(slot++) & 7];
@@ -65,7 +66,8 @@ int choose_kernel(int target, int D, int waves_per_group, KernelChoice* kc) {
     if (W != 4) return -1;
     const int ks = (D + 3) / 4;
     int KS = 0, NT = 0;
-    if (target == T_DENSEGAUSS) {
+    if (flow) {
+    } else if (target == T_DENSEGAUSS) {
       if (ks <= 16) { KS = 16; NT = 1; }
       else if (ks <= 25) { KS = 25; NT = 2; }
       else if (ks <= 32) { KS = 32; NT = 2; }
@@ -383,7 +385,7 @@ int wn_create(const wn_config* cfg, wn_engine** out) {
   // WALNUTS.py:140,146 sys.exit on bad tuning targets; the analogous argument checks here
   if (cfg->dim < 1 || cfg->n_chains < 1) { g_create_err = "dim and n_chains must be >= 1"; return WN_E_ARG; }
   if (cfg->M < 1 || cfg->M > MAX_M) { g_create_err = "M out of range [1,24]"; return WN_E_ARG; }
-  if (cfg->integrator < WN_I_FIXED || cfg->integrator > WN_I_ADAPT_YOSHIDA) { g_create_err = "unknown integrator"; return WN_E_ARG; }
+  if (cfg->integrator < WN_I_FIXED || cfg->integrator > WN_I_ADAPT_FLOWD) { g_create_err = "unknown integrator"; return WN_E_ARG; }
   if (cfg->min_c < 0 || cfg->max_c < cfg->min_c || cfg->max_c > 20) { g_create_err = "need 0 <= minC <= maxC <= 20"; return WN_E_ARG; }
   if (!(cfg->H0 > 0.0) || !(cfg->delta0 > 0.0) || cfg->step_size_rand_scale < 0.0 || cfg->step_size_rand_scale >= 1.0) {
     g_create_err = "need H0 > 0, delta0 > 0, 0 <= stepSizeRandScale < 1"; return WN_E_ARG;
@@ -444,7 +446,7 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
   }
   if (need && (n_params != need || !params_dev)) { e->err = "wrong parameter count for target"; return WN_E_ARG; }
   KernelChoice kc;
-  if (choose_kernel(kind, D, e->cfg.waves_per_group, &kc)) {
+  if (choose_kernel(kind, D, e->cfg.waves_per_group, e->cfg.integrator, &kc)) {
     e->err = "no device kernel for this (target, dim) yet";
     return WN_E_UNSUPPORTED;
   }
@@ -513,7 +515,7 @@ static void fill_params(const wn_engine* e, Params* p) {
 // split mode with the built-in dense-Gaussian gradient: begin, then {batched -A q, one tick of every
 // chain} until every chain has finished.  The host polls the finished-chain counter once per batch
 // of ticks; a launch whose chains have all finished is a few microseconds of early exits.
-static int run_split_dense(wn_engine* e, Params p, hipStream_t st, bool adapt, bool warm) {
+static int run_split_dense(wn_engine* e, Params p, hipStream_t st, int adapt, bool warm) {
   if (p.mode != MODE_SAMPLE) { e->err = "wn_integrator_step is not available in split mode"; return WN_E_UNSUPPORTED; }
   p.xq = e->xq; p.xg = e->xg; p.xlp = nullptr; p.sp_done = e->sp_done;
   HIPCHK(e, hipMemsetAsync(e->sp_done, 0, 64, st));
@@ -576,7 +578,7 @@ static int run_split_dense(wn_engine* e, Params p, hipStream_t st, bool adapt, b
 }
 
 static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
-  const bool adapt = e->cfg.integrator != WN_I_FIXED;
+  const int adapt = e->cfg.integrator == WN_I_FIXED ? 0 : e->cfg.integrator == WN_I_ADAPT_FLOWD ? 2 : 1;
   if (timed) HIPCHK(e, hipEventRecord(e->ev0, st));
   const bool warm = p.warmupIter > 0;
   if (e->kc.layout == 3) {
@@ -670,7 +672,7 @@ int wn_split_begin(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_
   p.xq = q_eval_dev; p.xg = const_cast<double*>(grad_dev); p.xlp = lp_dev; p.sp_done = e->sp_done;
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(e, hipMemsetAsync(e->sp_done, 0, 64, st));
-  hipError_t r = launch_split_begin(e->kc, e->cfg.integrator != WN_I_FIXED, p.warmupIter > 0, p, st);
+  hipError_t r = launch_split_begin(e->kc, e->cfg.integrator == WN_I_FIXED ? 0 : e->cfg.integrator == WN_I_ADAPT_FLOWD ? 2 : 1, p.warmupIter > 0, p, st);
   if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
   e->sp_prm = p;
   e->sp_active = true;
@@ -689,7 +691,7 @@ int wn_split_tick(wn_engine* e, void* stream) {
   if (!e) return WN_E_ARG;
   if (!e->sp_active) { e->err = "wn_split_begin has not been called"; return WN_E_ARG; }
   HIPCHK(e, hipSetDevice(e->cfg.device));
-  hipError_t r = launch_split_tick(e->kc, e->cfg.integrator != WN_I_FIXED, e->sp_prm.warmupIter > 0, e->sp_prm, (hipStream_t)stream);
+  hipError_t r = launch_split_tick(e->kc, e->cfg.integrator == WN_I_FIXED ? 0 : e->cfg.integrator == WN_I_ADAPT_FLOWD ? 2 : 1, e->sp_prm.warmupIter > 0, e->sp_prm, (hipStream_t)stream);
   if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
   e->sp_ticks++;
   return WN_OK;

@@ -31,7 +31,7 @@
 namespace wn {
 
 enum { T_STDGAUSS = 0, T_FUNNEL10, T_DENSEGAUSS, T_DIAGGAUSS, T_CORRGAUSS, T_SMILE, T_FUNNEL1, T_MODFUNNEL, T_STOCKWATSON = 11 };
-enum { I_FIXED = 0, I_ADAPT_D = 1, I_ADAPT_R2P = 2, I_ADAPT_YOSHIDA = 3 };
+enum { I_FIXED = 0, I_ADAPT_D = 1, I_ADAPT_R2P = 2, I_ADAPT_YOSHIDA = 3, I_ADAPT_FLOWD = 4 };
 enum { G_IDENTITY = 0, G_Q0_SUMSQ = 1, G_FIRSTK = 2 };
 enum { MODE_SAMPLE = 0, MODE_KAT = 1 };
 enum { NDIAG = 24, TRACE_NSCAL = 12 };
@@ -130,6 +130,8 @@ enum { WARM_QL = 0, WARM_VL, WARM_QO, WARM_VO, WARM_GO, WARM_N };
   /* warm-up only: P2 quantile of log(igrConst) (P2quantile.py), energy-step statistics */       \
   XA(double, p2q, 5) X(double, Hprev) X(double, madv) X(double, igrOut)                          \
   X(double, sp_hh2) /* split mode: half-step factor of the micro step in flight */               \
+  /* adaptLeapFrogFlowD: lp / kinetic energy of the leapfrog half of the micro step, running max flow error */ \
+  X(double, flp) X(double, fke) X(double, ferr_max)                                              \
   X(int, iter) X(uint32_t, Bbits)                                                                \
   X(int, i) X(int, xi) X(int, a) X(int, b) X(int, n) X(int, nleaf)                               \
   X(uint32_t, ku) X(uint32_t, ub0) /* ub0: first Philox block of the cached uniform window */    \
@@ -145,8 +147,9 @@ enum { WARM_QL = 0, WARM_VL, WARM_QO, WARM_VO, WARM_GO, WARM_N };
   X(int, sp_stage) /* split mode: 0 = waiting for grad(q0), 1 = running, 2 = finished */         \
   X(bool, live) X(bool, needKE) X(bool, needGen) X(bool, bothEndsPassive) X(bool, Hnan)          \
   X(bool, needMacro) X(bool, needPass) X(bool, fin) X(bool, needIter) X(bool, needDoubling)      \
-  X(bool, endIter) X(bool, allfin) X(bool, inPass) X(bool, madnan)                               \
-  X(bool, sp_act) /* split mode: the micro step in flight belongs to an active chain */
+  X(bool, endIter) X(bool, allfin) X(bool, inPass) X(bool, madnan) X(bool, ferr_nan)             \
+  X(bool, sp_act) /* split mode: the micro step in flight belongs to an active chain */          \
+  X(bool, sp_mid) /* split mode, adaptLeapFrogFlowD: the evaluation in flight is the midpoint one */
 
 #define WN_CS_DECL(T, N) T N;
 #define WN_CS_DECLA(T, N, K) T N[K];
@@ -160,8 +163,12 @@ struct alignas(16) ChainScalars {
   WN_HD static void copy(ChainScalars& d_, const ChainScalars& s_) { WN_CS_FIELDS(WN_CS_COPY, WN_CS_COPYA) }
 };
 
-template <class P, bool ADAPT, bool WARM = false>
+// FLOW: adaptLeapFrogFlowD (adaptiveIntegrators.py:246-356) -- the search of adaptLeapFrogD with
+// c = 0..maxC, two gradient evaluations per micro step (new position, then the midpoint of
+// adaptiveIntegrators.py:272) and the flow-error criterion max(Errs) < delta (:294).  Implies ADAPT.
+template <class P, bool ADAPT, bool WARM = false, bool FLOW = false>
 struct Engine : ChainScalars {
+  static_assert(!FLOW || ADAPT, "FLOW implies ADAPT");
   using Vec = typename P::Vec;
   // U-turn checks 0 (full orbit), 1 (leaf pair) and 2..1+NLC (fast-cached sub-tree levels) have
   // their left state on chip; deeper levels are fetched from the slot store in memory.
@@ -175,6 +182,8 @@ struct Engine : ChainScalars {
   // adaptive integrators only: work state of the running micro pass (the accepted forward result
   // is parked in the layout's warm storage while the backward passes run)
   typename P::template Opt<ADAPT> qw, vw, gw;
+  // adaptLeapFrogFlowD only: state before the leapfrog half of the micro step (qold, vold, gold)
+  typename P::template Opt<FLOW> qo2, vo2, go2;
 
   WN_HD Engine(P& p_, const Params& prm_) : p(p_), prm(prm_) {}
 
@@ -305,7 +314,7 @@ struct Engine : ChainScalars {
     nEvF = nEvB = 0;
     if (ADAPT) {
       ph = PH_FWD;
-      c = prm.minC;
+      c = cmin();
       If = prm.maxC;  // adaptiveIntegrators.py:68 / 364
       needPass = true;
     } else {
@@ -332,6 +341,7 @@ struct Engine : ChainScalars {
     }
     allfin = isfinite(HamPass0);
     if (WARM) { Hprev = HamPass0; madv = -INFINITY; madnan = false; }
+    if (FLOW) { ferr_max = -INFINITY; ferr_nan = false; }
   }
   template <bool B_ = ADAPT>
   WN_HD typename std::enable_if<!B_>::type setup_pass() {}
@@ -370,11 +380,16 @@ struct Engine : ChainScalars {
   }
   template <bool B_ = ADAPT>
   WN_HD typename std::enable_if<!B_>::type zero_adapt() {}
+  template <bool B_ = FLOW>
+  WN_HD typename std::enable_if<B_>::type zero_flow() { WN_VFOR(e) { qo2.x[e] = vo2.x[e] = go2.x[e] = 0.0; } }
+  template <bool B_ = FLOW>
+  WN_HD typename std::enable_if<!B_>::type zero_flow() {}
 
+  WN_HD int cmin() const { return FLOW ? 0 : prm.minC; }  // adaptiveIntegrators.py:250,303: range(0, ...)
   WN_HD void start_bwd_or_finalize() {
-    if (maxTry >= prm.minC) {  // adaptiveIntegrators.py:107 / 440
+    if (maxTry >= cmin()) {  // adaptiveIntegrators.py:107 / 440 / 300
       ph = PH_BWD;
-      c = prm.minC;
+      c = cmin();
       needPass = true;
     } else {
       finalize_macro();
@@ -394,7 +409,7 @@ struct Engine : ChainScalars {
     if (ADAPT && ph == PH_BWD) restore_out();
     lpn = ADAPT ? lpOut : lpn;
     Hn = ADAPT ? HOut : Hn;
-    if (prm.integrator == I_ADAPT_D || prm.integrator == I_ADAPT_YOSHIDA) {  // :135-137 / :238-240
+    if (prm.integrator == I_ADAPT_D || prm.integrator == I_ADAPT_YOSHIDA || prm.integrator == I_ADAPT_FLOWD) {  // :135-137 / :238-240 / :354-356
       cret = If;
       lwt = (If != Ib) ? WN_LOGZERO : 0.0;
     } else if (prm.integrator == I_ADAPT_R2P) {  // :466-475
@@ -417,9 +432,22 @@ struct Engine : ChainScalars {
       inPass = true;
       return;
     }
+    if (FLOW) {
+      if (sub == 0) {  // leapfrog half done: Hams[i] needs nothing more, but the step is not complete
+        sub = 1;
+        flp = lp; fke = ke;
+        if (ph == PH_BWD) nEvB++; else nEvF++;
+        inPass = true;
+        return;
+      }
+    }
+    // adaptLeapFrogFlowD: the midpoint evaluation only feeds the error estimate (flow_account).
+    // (Select form on purpose: reassigning the by-value parameters here was miscompiled by hipcc 7.2
+    // in the StockWatson wave kernel -- lpCur came out 0 while Hi was right)
+    const double lpS = (FLOW && sub == 1) ? flp : lp, keS = (FLOW && sub == 1) ? fke : ke;
     sub = 0;
-    const double Hi = -lp + 0.5 * ke;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
-    lpCur = lp; HCur = Hi;
+    const double Hi = -lpS + 0.5 * keS;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
+    lpCur = lpS; HCur = Hi;
     if (WARM) {  // np.max(np.abs(np.diff(Hams))) of the running pass (adaptiveIntegrators.py:101)
       const double df = fabs(Hi - Hprev);
       if (isnan(df)) madnan = true; else madv = df > madv ? df : madv;
@@ -431,6 +459,57 @@ struct Engine : ChainScalars {
     inPass = im < nstep;
   }
 
+  // ---- adaptLeapFrogFlowD: midpoint evaluation and flow errors (adaptiveIntegrators.py:272-288) ----
+  // position whose gradient this tick needs: the new position (leapfrog half) or
+  // qMid = 0.5*(qq+qold) + (hh/8)*(vold-vv)  (:272)
+  template <bool B_ = FLOW>
+  WN_HD typename std::enable_if<B_>::type flow_begin(bool act, bool& mid, double& hh2, double& hq) {
+    mid = act && sub == 1;
+    if (act && sub == 0) { WN_VFOR(e) { qo2.x[e] = qw.x[e]; vo2.x[e] = vw.x[e]; go2.x[e] = gw.x[e]; } }  // :264-266
+    if (mid) { hh2 = 0.0; hq = 0.0; }
+  }
+  template <bool B_ = FLOW>
+  WN_HD typename std::enable_if<!B_>::type flow_begin(bool, bool& mid, double&, double&) { mid = false; }
+  template <bool B_ = FLOW>
+  WN_HD typename std::enable_if<B_>::type flow_point(bool mid, Vec& x) {
+    const double h8 = hh / 8.0;
+    WN_VFOR(e) x.x[e] = mid ? (0.5 * (qw.x[e] + qo2.x[e]) + h8 * (vo2.x[e] - vw.x[e])) : qw.x[e];
+  }
+  template <bool B_ = FLOW>
+  WN_HD typename std::enable_if<!B_>::type flow_point(bool, Vec&) {}
+  // the four errors of :276-287 as local (max, #NaN) pairs; gm = gradient at qMid
+  template <bool B_ = FLOW>
+  WN_HD typename std::enable_if<B_>::type flow_errors(const Vec& gm, double* em, double* en) {
+    const double hsq = hh * hh, h6 = hh / 6.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { em[k] = -INFINITY; en[k] = 0.0; }
+    WN_VFOR(e) {
+      const double s4 = go2.x[e] + gw.x[e] + 4.0 * gm.x[e];
+      const double d0 = fabs((qo2.x[e] + hh * vo2.x[e] + hsq * ((1.0 / 6.0) * go2.x[e] + (1.0 / 3.0) * gm.x[e])) - qw.x[e]);  // qf - qq
+      const double d1 = fabs((vo2.x[e] + h6 * s4) - vw.x[e]);                                                                // vf - vv
+      const double d2 = fabs((qw.x[e] - hh * vw.x[e] + hsq * ((1.0 / 6.0) * gw.x[e] + (1.0 / 3.0) * gm.x[e])) - qo2.x[e]);  // qb - qold
+      const double d3 = fabs(-(-vw.x[e] + h6 * s4) - vo2.x[e]);                                                              // vb - vold
+      const double dd[4] = {d0, d1, d2, d3};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (isnan(dd[k])) en[k] += 1.0; else em[k] = dd[k] > em[k] ? dd[k] : em[k];
+      }
+    }
+  }
+  template <bool B_ = FLOW>
+  WN_HD typename std::enable_if<!B_>::type flow_errors(const Vec&, double*, double*) {}
+  // err = np.max(..); err = max(err, np.max(..)) x3 (Python's max: x if x > err else err); Errs[i-1] = err;
+  // maxErr = np.max(Errs)  (:277-288, 294)
+  WN_HD void flow_account(const double* em, const double* en) {
+    double err = en[0] > 0.0 ? NAN : em[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const double x = en[k] > 0.0 ? NAN : em[k];
+      err = x > err ? x : err;
+    }
+    if (isnan(err)) ferr_nan = true; else ferr_max = err > ferr_max ? err : ferr_max;
+  }
+
   WN_HD void after_micro(double lp, double ke) {  // fixedLeapFrog: the macro step is one micro step
     nEvF = 1;
     lpn = lp;
@@ -440,8 +519,9 @@ struct Engine : ChainScalars {
 
   WN_HD void pass_end() {
     const double lp = lpCur, Hi = HCur;
-    // pass complete: all(isfinite(Hams)) and abs(Hams[0]-Hams[-1]) < delta   (:87-94)
-    bool ok = allfin && (fabs(HamPass0 - Hi) < dc);
+    // pass complete: all(isfinite(Hams)) and abs(Hams[0]-Hams[-1]) < delta   (:87-94);
+    // adaptLeapFrogFlowD: ... and np.max(Errs) < delta  (:294-297)
+    bool ok = allfin && (FLOW ? (!ferr_nan && ferr_max < dc) : (fabs(HamPass0 - Hi) < dc));
     if (ph == PH_FWD) {
       bool done = false;
       if (ok) { If = c; done = true; }
@@ -860,7 +940,9 @@ struct Engine : ChainScalars {
     firemask = 0;
     h = h2 = 0.0; xi = 1; i = 0; n = 0; nleaf = 1; a = b = 0;
     lpn = Hn = lpOut = HOut = 0.0; H0 = Ha = Hb = 0.0;
-    sp_stage = 0; sp_hh2 = 0.0; sp_act = false;
+    sp_stage = 0; sp_hh2 = 0.0; sp_act = false; sp_mid = false;
+    flp = fke = 0.0; ferr_max = -INFINITY; ferr_nan = false;
+    zero_flow();
   }
 
 
@@ -905,13 +987,24 @@ struct Engine : ChainScalars {
   }
   template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_>::type park_adapt() {
     p.template park_vec<4>(vw);
-    if (!sp_act) p.template park_vec<5>(gw);
+    if (FLOW || !sp_act) p.template park_vec<5>(gw);
+    park_flow();
   }
+  // adaptLeapFrogFlowD: the exchange buffers carry the midpoint on every other tick, so the work
+  // position and gradient are parked like everything else, with the pre-step state
+  template <bool B_ = FLOW> WN_HD typename std::enable_if<B_>::type park_flow() {
+    p.template park_vec<3>(qw); p.template park_vec<6>(qo2); p.template park_vec<7>(vo2); p.template park_vec<8>(go2);
+  }
+  template <bool B_ = FLOW> WN_HD typename std::enable_if<!B_>::type park_flow() {}
+  template <bool B_ = FLOW> WN_HD typename std::enable_if<B_>::type unpark_flow() {
+    p.template unpark_vec<3>(qw); p.template unpark_vec<6>(qo2); p.template unpark_vec<7>(vo2); p.template unpark_vec<8>(go2);
+  }
+  template <bool B_ = FLOW> WN_HD typename std::enable_if<!B_>::type unpark_flow() { p.ext_get_q(qw); }
   template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_>::type park_adapt() {}
   template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_>::type unpark_adapt() {
-    p.ext_get_q(qw);
+    unpark_flow();
     p.template unpark_vec<4>(vw);
-    if (!sp_act) p.template unpark_vec<5>(gw);
+    if (FLOW || !sp_act) p.template unpark_vec<5>(gw);
   }
   template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_>::type unpark_adapt() {}
 
@@ -945,7 +1038,16 @@ struct Engine : ChainScalars {
       // ---- B, second half ----
       const bool act = sp_act;
       const double hh2 = sp_hh2;
-      p.ext_get(Q, G, part[0]);
+      const bool mid = FLOW && sp_mid;
+      double em[4], en[4];
+      if constexpr (FLOW) {
+        Vec gout;
+        p.ext_get(Q, gout, part[0]);
+        if (p.any(mid)) flow_errors(gout, em, en);
+        WN_VFOR(e) G.x[e] = mid ? G.x[e] : gout.x[e];
+      } else {
+        p.ext_get(Q, G, part[0]);
+      }
       double ke = 0.0;
       WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; ke += V.x[e] * V.x[e]; }
       part[1] = ke; part[2] = keinit_part; part[3] = gen_part;
@@ -965,6 +1067,11 @@ struct Engine : ChainScalars {
         p.template reduce<NPB>(part);
       }
       WN_STAMP(2);
+      if constexpr (FLOW) if (p.any(mid)) {
+        p.template reduce_max<4>(em);
+        p.template reduce<4>(en);
+        if (mid) flow_account(em, en);
+      }
       finish_generated(part[3]);
       if (act) {
         if (needKE) {  // Hs[I0] = -f0 + 0.5*sum(v**2)  (:256); multinomialLscale (:259)
@@ -1048,9 +1155,17 @@ struct Engine : ChainScalars {
         const double w = sub == 1 ? -1.702414383919315 : 1.351207191959658;
         hh2 = 0.5 * w * hh; hq = w * hh;
       }
+      bool mid;
+      flow_begin(act, mid, hh2, hq);
       WN_VFOR(e) { V2.x[e] = V2.x[e] + hh2 * G2.x[e]; Q2.x[e] = Q2.x[e] + hq * V2.x[e]; }
-      p.ext_put_q(Q2);
-      sp_act = act; sp_hh2 = hh2;
+      if constexpr (FLOW) {
+        Vec xin;
+        flow_point(mid, xin);
+        p.ext_put_q(xin);
+      } else {
+        p.ext_put_q(Q2);
+      }
+      sp_act = act; sp_hh2 = hh2; sp_mid = mid;
     }
     park();
     WN_STAMP(11);
@@ -1135,8 +1250,19 @@ struct Engine : ChainScalars {
           const double w = sub == 1 ? -1.702414383919315 : 1.351207191959658;
           hh2 = 0.5 * w * hh; hq = w * hh;
         }
+        bool mid;
+        flow_begin(act, mid, hh2, hq);
         WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; Q.x[e] = Q.x[e] + hq * V.x[e]; }
-        p.grad(Q, G, part[0]);
+        double em[4], en[4];
+        if constexpr (FLOW) {
+          Vec xin, gout;
+          flow_point(mid, xin);
+          p.grad(xin, gout, part[0]);
+          if (p.any(mid)) flow_errors(gout, em, en);
+          WN_VFOR(e) G.x[e] = mid ? G.x[e] : gout.x[e];
+        } else {
+          p.grad(Q, G, part[0]);
+        }
         WN_STAMP(1);
         double ke = 0.0;
         WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; ke += V.x[e] * V.x[e]; }
@@ -1157,6 +1283,11 @@ struct Engine : ChainScalars {
           p.template reduce<NPB>(part);
         }
         WN_STAMP(2);
+        if constexpr (FLOW) if (p.any(mid)) {
+          p.template reduce_max<4>(em);
+          p.template reduce<4>(en);
+          if (mid) flow_account(em, en);
+        }
         finish_generated(part[3]);
         if (act) {
           if (needKE) {  // Hs[I0] = -f0 + 0.5*sum(v**2)  (:256); multinomialLscale (:259)

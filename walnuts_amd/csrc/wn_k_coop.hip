@@ -35,8 +35,9 @@ size_t coop_work_doubles(int NT, int W, int C, int M) {
   return groups * (size_t)((M + 1) * 2 + 5) * W * (NT * 4) * 64;
 }
 
-hipError_t launch_coop(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st) {
-  if (kc.W != 4) return hipErrorInvalidValue;
+hipError_t launch_coop(const KernelChoice& kc, int adapt_, bool warm, const Params& prm, hipStream_t st) {
+  if (kc.W != 4 || adapt_ == 2) return hipErrorInvalidValue;  // adaptLeapFrogFlowD runs in the lane / wave layouts
+  const bool adapt = adapt_ != 0;
   // p0 = k-steps (= ceil(D/4) rounded up to an instantiated value)
 #ifdef WN_ONLY_MAIN
   if (kc.p1 == CK_DENSE && kc.p0 == 25) return go<2, 4, 25, CK_DENSE>(adapt, warm, prm, st);

@@ -6,18 +6,23 @@
 
 namespace wn {
 
-template <int DMAX, class Tgt, bool ADAPT, bool WARM>
+template <int DMAX, class Tgt, bool ADAPT, bool WARM, bool FLOW = false>
 __global__ __launch_bounds__(64) void wn_lane_kernel(Params prm) {
   __shared__ double lds[LanePolicy<DMAX, Tgt>::WARM_DOUBLES];
   const int cl = blockIdx.x * 64 + threadIdx.x;
   LanePolicy<DMAX, Tgt> p(prm, cl, lds);
-  Engine<LanePolicy<DMAX, Tgt>, ADAPT, WARM> eng(p, prm);
+  Engine<LanePolicy<DMAX, Tgt>, ADAPT, WARM, FLOW> eng(p, prm);
   eng.run();
 }
 
 template <int DMAX, class Tgt>
-static hipError_t go(bool adapt, bool warm, const Params& prm, hipStream_t st) {
+static hipError_t go(int adapt, bool warm, const Params& prm, hipStream_t st) {
   dim3 grid((prm.C + 63) / 64), block(64);
+  if (adapt == 2) {  // adaptLeapFrogFlowD
+    if (warm) hipLaunchKernelGGL((wn_lane_kernel<DMAX, Tgt, true, true, true>), grid, block, 0, st, prm);
+    else hipLaunchKernelGGL((wn_lane_kernel<DMAX, Tgt, true, false, true>), grid, block, 0, st, prm);
+    return hipGetLastError();
+  }
   if (warm) {
     if (adapt) hipLaunchKernelGGL((wn_lane_kernel<DMAX, Tgt, true, true>), grid, block, 0, st, prm);
     else hipLaunchKernelGGL((wn_lane_kernel<DMAX, Tgt, false, true>), grid, block, 0, st, prm);
@@ -33,7 +38,7 @@ size_t lane_work_doubles(int dmax, int C, int M) {
   return ((size_t)(M + 1) * 2 + COLD_N + 4) * dmax * cpad;
 }
 
-hipError_t launch_lane(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st) {
+hipError_t launch_lane(const KernelChoice& kc, int adapt, bool warm, const Params& prm, hipStream_t st) {
 #ifdef WN_NO_LANE  // diagnostic variant builds (tools/build_variant.sh) skip the lane kernels
   return hipErrorInvalidValue;
 #else

@@ -11,21 +11,21 @@ namespace wn {
 // DPW = DP / 64 (8 or 16); every chain is served by a workgroup of SPLIT_W waves, DPW/SPLIT_W registers per vector
 constexpr int SPLIT_W = 2;
 
-template <int DPW, int EXT, bool ADAPT, bool WARM>
+template <int DPW, int EXT, bool ADAPT, bool WARM, bool FLOW = false>
 __global__ __launch_bounds__(64 * SPLIT_W) void wn_split_begin_kernel(Params prm) {
   using P = WavePolicy<DPW / SPLIT_W, WTgtExt<DPW / SPLIT_W, EXT>, SPLIT_W>;
   __shared__ double lds[P::LDS_DOUBLES > 0 ? P::LDS_DOUBLES : 1];
   P p(prm, blockIdx.x, lds);
-  Engine<P, ADAPT, WARM> eng(p, prm);
+  Engine<P, ADAPT, WARM, FLOW> eng(p, prm);
   eng.split_begin();
 }
 
-template <int DPW, int EXT, bool ADAPT, bool WARM>
+template <int DPW, int EXT, bool ADAPT, bool WARM, bool FLOW = false>
 __global__ __launch_bounds__(64 * SPLIT_W) void wn_split_tick_kernel(Params prm) {
   using P = WavePolicy<DPW / SPLIT_W, WTgtExt<DPW / SPLIT_W, EXT>, SPLIT_W>;
   __shared__ double lds[P::LDS_DOUBLES > 0 ? P::LDS_DOUBLES : 1];
   P p(prm, blockIdx.x, lds);
-  Engine<P, ADAPT, WARM> eng(p, prm);
+  Engine<P, ADAPT, WARM, FLOW> eng(p, prm);
 #ifdef WN_SPAN  // diagnostic build: wall-clock start / end of every workgroup of launch 100
   const unsigned long long span0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -41,8 +41,13 @@ __global__ __launch_bounds__(64 * SPLIT_W) void wn_split_tick_kernel(Params prm)
 }
 
 template <int NE, int EXT>
-static hipError_t go_begin(bool adapt, bool warm, const Params& prm, hipStream_t st) {
+static hipError_t go_begin(int adapt, bool warm, const Params& prm, hipStream_t st) {
   dim3 grid(prm.C), block(64 * SPLIT_W);
+  if (adapt == 2) {  // adaptLeapFrogFlowD
+    if (warm) hipLaunchKernelGGL((wn_split_begin_kernel<NE, EXT, true, true, true>), grid, block, 0, st, prm);
+    else hipLaunchKernelGGL((wn_split_begin_kernel<NE, EXT, true, false, true>), grid, block, 0, st, prm);
+    return hipGetLastError();
+  }
   if (warm) {
     if (adapt) hipLaunchKernelGGL((wn_split_begin_kernel<NE, EXT, true, true>), grid, block, 0, st, prm);
     else hipLaunchKernelGGL((wn_split_begin_kernel<NE, EXT, false, true>), grid, block, 0, st, prm);
@@ -53,8 +58,13 @@ static hipError_t go_begin(bool adapt, bool warm, const Params& prm, hipStream_t
   return hipGetLastError();
 }
 template <int NE, int EXT>
-static hipError_t go_tick(bool adapt, bool warm, const Params& prm, hipStream_t st) {
+static hipError_t go_tick(int adapt, bool warm, const Params& prm, hipStream_t st) {
   dim3 grid(prm.C), block(64 * SPLIT_W);
+  if (adapt == 2) {  // adaptLeapFrogFlowD
+    if (warm) hipLaunchKernelGGL((wn_split_tick_kernel<NE, EXT, true, true, true>), grid, block, 0, st, prm);
+    else hipLaunchKernelGGL((wn_split_tick_kernel<NE, EXT, true, false, true>), grid, block, 0, st, prm);
+    return hipGetLastError();
+  }
   if (warm) {
     if (adapt) hipLaunchKernelGGL((wn_split_tick_kernel<NE, EXT, true, true>), grid, block, 0, st, prm);
     else hipLaunchKernelGGL((wn_split_tick_kernel<NE, EXT, false, true>), grid, block, 0, st, prm);
@@ -70,7 +80,7 @@ size_t split_work_doubles(int NE, int C, int M) {
 }
 
 // kc.p0 = NE (8 or 16), kc.p1 = EXT_HALF_QG (dense Gaussian through the GEMM) or EXT_LP (caller)
-hipError_t launch_split_begin(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st) {
+hipError_t launch_split_begin(const KernelChoice& kc, int adapt, bool warm, const Params& prm, hipStream_t st) {
   if (kc.p1 == EXT_HALF_QG) {
     if (kc.p0 == 8) return go_begin<8, EXT_HALF_QG>(adapt, warm, prm, st);
     if (kc.p0 == 16) return go_begin<16, EXT_HALF_QG>(adapt, warm, prm, st);
@@ -80,7 +90,7 @@ hipError_t launch_split_begin(const KernelChoice& kc, bool adapt, bool warm, con
   }
   return hipErrorInvalidValue;
 }
-hipError_t launch_split_tick(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st) {
+hipError_t launch_split_tick(const KernelChoice& kc, int adapt, bool warm, const Params& prm, hipStream_t st) {
   if (kc.p1 == EXT_HALF_QG) {
     if (kc.p0 == 8) return go_tick<8, EXT_HALF_QG>(adapt, warm, prm, st);
     if (kc.p0 == 16) return go_tick<16, EXT_HALF_QG>(adapt, warm, prm, st);

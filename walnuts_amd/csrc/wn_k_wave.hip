@@ -6,17 +6,22 @@
 
 namespace wn {
 
-template <int NE, class Tgt, bool ADAPT, bool WARM>
+template <int NE, class Tgt, bool ADAPT, bool WARM, bool FLOW = false>
 __global__ __launch_bounds__(64) void wn_wave_kernel(Params prm) {
   __shared__ double lds[Tgt::LDS_DOUBLES > 0 ? Tgt::LDS_DOUBLES : 1];
   WavePolicy<NE, Tgt> p(prm, blockIdx.x, lds);
-  Engine<WavePolicy<NE, Tgt>, ADAPT, WARM> eng(p, prm);
+  Engine<WavePolicy<NE, Tgt>, ADAPT, WARM, FLOW> eng(p, prm);
   eng.run();
 }
 
 template <int NE, class Tgt>
-static hipError_t go(bool adapt, bool warm, const Params& prm, hipStream_t st) {
+static hipError_t go(int adapt, bool warm, const Params& prm, hipStream_t st) {
   dim3 grid(prm.C), block(64);
+  if (adapt == 2) {  // adaptLeapFrogFlowD
+    if (warm) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, true, true>), grid, block, 0, st, prm);
+    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false, true>), grid, block, 0, st, prm);
+    return hipGetLastError();
+  }
   if (warm) {
     if (adapt) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, true>), grid, block, 0, st, prm);
     else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, false, true>), grid, block, 0, st, prm);
@@ -32,7 +37,7 @@ size_t wave_work_doubles(int NE, int C, int M) {
   return NE <= 8 ? WavePolicy<8, WTgtDiag<8>>::work_doubles(C, M) : WavePolicy<16, WTgtDiag<16>>::work_doubles(C, M);
 }
 
-hipError_t launch_wave(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st) {
+hipError_t launch_wave(const KernelChoice& kc, int adapt, bool warm, const Params& prm, hipStream_t st) {
   if (kc.p1 == T_DIAGGAUSS || kc.p1 == T_STDGAUSS) {
     if (kc.p0 == 8) return go<8, WTgtDiag<8>>(adapt, warm, prm, st);
     if (kc.p0 == 16) return go<16, WTgtDiag<16>>(adapt, warm, prm, st);

@@ -17,13 +17,13 @@ struct KernelChoice {
 };
 
 // returns 0 and fills `kc` if a kernel exists for (target, D)
-int choose_kernel(int target, int D, int waves_per_group, KernelChoice* kc);
+int choose_kernel(int target, int D, int waves_per_group, int integrator, KernelChoice* kc);
 size_t kernel_work_doubles(const KernelChoice& kc, int C, int M);
-hipError_t launch_lane(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st);
-hipError_t launch_coop(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st);
-hipError_t launch_wave(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st);
-hipError_t launch_split_begin(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st);
-hipError_t launch_split_tick(const KernelChoice& kc, bool adapt, bool warm, const Params& prm, hipStream_t st);
+hipError_t launch_lane(const KernelChoice& kc, int adapt /* 0 fixed, 1 adaptive, 2 adaptLeapFrogFlowD */, bool warm, const Params& prm, hipStream_t st);
+hipError_t launch_coop(const KernelChoice& kc, int adapt /* 0 fixed, 1 adaptive, 2 adaptLeapFrogFlowD */, bool warm, const Params& prm, hipStream_t st);
+hipError_t launch_wave(const KernelChoice& kc, int adapt /* 0 fixed, 1 adaptive, 2 adaptLeapFrogFlowD */, bool warm, const Params& prm, hipStream_t st);
+hipError_t launch_split_begin(const KernelChoice& kc, int adapt /* 0 fixed, 1 adaptive, 2 adaptLeapFrogFlowD */, bool warm, const Params& prm, hipStream_t st);
+hipError_t launch_split_tick(const KernelChoice& kc, int adapt /* 0 fixed, 1 adaptive, 2 adaptLeapFrogFlowD */, bool warm, const Params& prm, hipStream_t st);
 hipError_t launch_dense_grad(const double* A, const double* xq, double* xg, int DP, int D, int Cpad, const int* done, int C,
                              hipStream_t st);
 size_t wave_work_doubles(int NE, int C, int M);

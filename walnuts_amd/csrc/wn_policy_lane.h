@@ -73,6 +73,8 @@ struct LanePolicy {
   }
   template <int N>
   WN_HD void reduce(double*) const {}
+  template <int N>
+  WN_HD void reduce_max(double*) const {}
   WN_HD void grad(const Vec& q, Vec& g, double& lp) const { lp = Tgt::eval(q.x, g.x, D, tpar); }
   WN_HD double lp_finish(double lp) const { return lp; }
 

@@ -248,7 +248,7 @@ struct WavePolicy {
   };
   template <bool B>
   using Opt = typename std::conditional<B, Vec, EmptyVecW>::type;
-  enum { NPARK = 6 };
+  enum { NPARK = 9 };
 
   int D, cl, lane, wave, l0;
   unsigned long long t_start, t_real;  // diagnostic builds (-DWN_STAMPS)
@@ -342,6 +342,39 @@ struct WavePolicy {
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < W_; ++w) s += buf[k * W_ + w];
+        v[k] = s;
+      }
+    }
+  }
+
+  // max over all lanes serving the chain (NaN-free inputs; max is exact, so every replica agrees)
+  __device__ __forceinline__ static double wavemax(double x) {
+    x = fmax(x, dpp<0xB1>(x));
+    x = fmax(x, dpp<0x4E>(x));
+    x = fmax(x, dpp<0x141>(x));
+    x = fmax(x, dpp<0x140>(x));
+#pragma unroll
+    for (int d = 16; d < 64; d <<= 1) x = fmax(x, __shfl_xor(x, d));
+    return x;
+  }
+  template <int N>
+  __device__ __forceinline__ void reduce_max(double* v) {
+    static_assert(N <= NRED, "reduce width");
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = wavemax(v[k]);
+    if (W_ > 1) {
+      double* buf = ldsr + (redpar & 1) * (NRED * W_);
+      redpar++;
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) buf[k * W_ + wave] = v[k];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        double s = buf[k * W_];
+#pragma unroll
+        for (int w = 1; w < W_; ++w) s = fmax(s, buf[k * W_ + w]);
         v[k] = s;
       }
     }
