@@ -21,23 +21,29 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
         for r in csv.DictReader(fh):
             print(f"{r.get('Name','?')[:70]:70s} calls={r.get('Calls')} total_ns={r.get('TotalDurationNs')} "
                   f"avg_ns={r.get('AverageNs')} pct={r.get('Percentage')}")
-print("== sampler-kernel dispatches (kernel trace) ==")
+print("== sampler-kernel dispatches (kernel trace), grouped by kernel ==")
+grp = {}
 for r in rows("trace/**/*kernel_trace.csv"):
     if "wn_" in r.get("Kernel_Name", ""):
         dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-        print(f"{r['Kernel_Name'][:60]} dur_ms={dur/1e6:.3f} vgpr={r.get('VGPR_Count')} accum={r.get('Accum_VGPR_Count')} "
-              f"sgpr={r.get('SGPR_Count')} lds={r.get('LDS_Block_Size')} scratch={r.get('Scratch_Size')} "
-              f"grid={r.get('Grid_Size')} wg={r.get('Workgroup_Size')}")
-print("== PMC counters, sampler-kernel dispatches (one line per dispatch) ==")
+        g = grp.setdefault(r["Kernel_Name"][:70], dict(n=0, tot=0, r=r))
+        g["n"] += 1; g["tot"] += dur
+for k, g in grp.items():
+    r = g["r"]
+    print(f"{k} calls={g['n']} avg_us={g['tot']/g['n']/1e3:.2f} total_ms={g['tot']/1e6:.3f} vgpr={r.get('VGPR_Count')} "
+          f"accum={r.get('Accum_VGPR_Count')} sgpr={r.get('SGPR_Count')} lds={r.get('LDS_Block_Size')} "
+          f"scratch={r.get('Scratch_Size')} wg={r.get('Workgroup_Size')}")
+print("== PMC counters per dispatch, grouped by kernel (mean over dispatches) ==")
 acc = {}
+names = {}
 for r in rows("pmc_*/**/*counter_collection.csv"):
     if "wn_" not in r.get("Kernel_Name", ""):
         continue
-    key = (r["Dispatch_Id"], r["Counter_Name"])
+    key = (r["Kernel_Name"][:50], r["Dispatch_Id"], r["Counter_Name"])
     acc[key] = acc.get(key, 0.0) + float(r["Counter_Value"])
 byname = {}
-for (d, n), v in acc.items():
-    byname.setdefault(n, []).append(v)
-for n in sorted(byname):
-    vals = byname[n]
-    print(f"{n:28s} n={len(vals)} mean={sum(vals)/len(vals):.6g} last={vals[-1]:.6g}")
+for (k, d, n), v in acc.items():
+    byname.setdefault((k, n), []).append(v)
+for (k, n) in sorted(byname):
+    vals = byname[(k, n)]
+    print(f"{k:50s} {n:28s} n={len(vals)} mean={sum(vals)/len(vals):.6g}")
