@@ -193,3 +193,13 @@ def test_stockwatson_python_api(wa):
     s, d = wa.WALNUTS(td.stockWatson(_SW["y"]), np.zeros((2, 3 * SW_T)), integrator=ai.adaptLeapFrogD, H0=0.1, delta0=0.3,
                       numIter=4, warmupIter=0, M=6, igrAux=ai.integratorAuxPar(minC=3), seed=3)
     assert s.shape == (2, 3 * SW_T, 5) and np.isfinite(s).all() and (d[:, :, 21] >= 3).all()
+    # generated = param_constrain(q, include_tp=True) (mainSW.py:28-29): 3T parameters + sigma, gpri, z, x, tau
+    s2, d2 = wa.WALNUTS(td.stockWatson(_SW["y"]), np.zeros(3 * SW_T), generated=td.stockWatsonConstrain(_SW["y"]),
+                        integrator=ai.adaptLeapFrogD, H0=0.1, delta0=0.3, numIter=3, warmupIter=0, M=5,
+                        igrAux=ai.integratorAuxPar(minC=3), seed=3)
+    T = SW_T
+    assert s2.shape == (3 * T + 2 + (T - 1) + 2 * T, 4)
+    q = s2[:3 * T, 3]
+    np.testing.assert_allclose(s2[3 * T, 3], np.exp(-0.5 * q[0]))
+    x = q[T] + np.concatenate([[0.0], np.cumsum(np.exp(-0.5 * q[0]) * q[T + 1:2 * T])])
+    np.testing.assert_allclose(s2[3 * T + 2 + (T - 1):3 * T + 2 + (T - 1) + T, 3], x, rtol=1e-12, atol=1e-12)

@@ -529,7 +529,12 @@ static int run_split_dense(wn_engine* e, Params p, hipStream_t st, int adapt, bo
   hipMemset(sbuf, 0, (size_t)p.C * 16 * sizeof(unsigned long long));
   p.stamps = sbuf;
 #endif
+  // every chain needs at most numIter * (2^M - 1) macro steps of at most 3 * 2^(maxC+2) gradient
+  // evaluations (forward search, R2P re-integration, backward search; x3 Yoshida, x2 FlowD)
+  const double cap = 64.0 + 1.05 * (double)p.numIter * (double)(1u << p.M) *
+                                (adapt ? 9.0 * (double)(1u << (p.maxC + 2)) : 1.0);
   while (done < p.C) {
+    if ((double)e->sp_ticks > cap) { e->err = "split run exceeded its tick bound (internal error)"; return WN_E_HIP; }
     for (int k = 0; k < 64; ++k) {
       r = launch_dense_grad(e->apad, e->xq, e->xg, e->DP, p.D, e->Cpad, e->sp_done, p.C, st);
       if (r == hipSuccess) r = launch_split_tick(e->kc, adapt, warm, p, st);

@@ -976,14 +976,17 @@ struct Engine : ChainScalars {
     else if (!sp_act) p.template park_vec<2>(ga);
     park_adapt();
   }
-  WN_HD void unpark() {
+  // Loads that do not depend on the parked scalars are issued BEFORE the scalars are read, so a tick
+  // starts with one memory round trip, not two; the rest follows once sp_act is known.
+  WN_HD void unpark_early() {
     p.template unpark_vec<1>(va);
     if (ADAPT) { p.template unpark_vec<0>(qa); p.template unpark_vec<2>(ga); }
-    else {
-      p.ext_get_q(qa);
-      if (!sp_act) p.template unpark_vec<2>(ga);
-    }
-    unpark_adapt();
+    else p.ext_get_q(qa);
+    unpark_adapt_early();
+  }
+  WN_HD void unpark_late() {
+    if (!ADAPT) { if (!sp_act) p.template unpark_vec<2>(ga); }
+    unpark_adapt_late();
   }
   template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_>::type park_adapt() {
     p.template park_vec<4>(vw);
@@ -1001,20 +1004,26 @@ struct Engine : ChainScalars {
   }
   template <bool B_ = FLOW> WN_HD typename std::enable_if<!B_>::type unpark_flow() { p.ext_get_q(qw); }
   template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_>::type park_adapt() {}
-  template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_>::type unpark_adapt() {
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_>::type unpark_adapt_early() {
     unpark_flow();
     p.template unpark_vec<4>(vw);
+  }
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_>::type unpark_adapt_early() {}
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<B_>::type unpark_adapt_late() {
     if (FLOW || !sp_act) p.template unpark_vec<5>(gw);
   }
-  template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_>::type unpark_adapt() {}
+  template <bool B_ = ADAPT> WN_HD typename std::enable_if<!B_>::type unpark_adapt_late() {}
 
   // returns true while the chain still needs ticks
   WN_HD bool split_tick() {
+    unpark_early();
+    Vec gin;  // the gradient that arrived for the position sent out by the previous launch
+    p.ext_load_g(gin);
     p.unpark_scalars(static_cast<ChainScalars&>(*this));
     if (sp_stage == 2) return false;
     keinit_part = p.unpark_partial(keinit_part);
     gen_part = p.unpark_partial(gen_part);
-    unpark();
+    unpark_late();
 #pragma unroll
     for (int k = 0; k < 16; ++k) st_[k] = 0;
     st_last_ = 0;
@@ -1025,7 +1034,8 @@ struct Engine : ChainScalars {
     Vec& Q = QW(); Vec& V = VW(); Vec& G = GW();
     double part[NPB > 2 * NFAST ? NPB : 2 * NFAST];
     if (sp_stage == 0) {  // f0, grad0 = lpFun(q0)  (WALNUTS.py:177,249)
-      p.ext_get(qa, ga, part[0]);
+      WN_VFOR(e) ga.x[e] = gin.x[e];
+      p.ext_lp(qa, ga, part[0]);
       p.template reduce<1>(part);
       lpP = p.lp_finish(part[0]);
       p.prop_put(ip, qa, ga);
@@ -1041,12 +1051,12 @@ struct Engine : ChainScalars {
       const bool mid = FLOW && sp_mid;
       double em[4], en[4];
       if constexpr (FLOW) {
-        Vec gout;
-        p.ext_get(Q, gout, part[0]);
-        if (p.any(mid)) flow_errors(gout, em, en);
-        WN_VFOR(e) G.x[e] = mid ? G.x[e] : gout.x[e];
+        p.ext_lp(Q, gin, part[0]);
+        if (p.any(mid)) flow_errors(gin, em, en);
+        WN_VFOR(e) G.x[e] = mid ? G.x[e] : gin.x[e];
       } else {
-        p.ext_get(Q, G, part[0]);
+        WN_VFOR(e) G.x[e] = gin.x[e];
+        p.ext_lp(Q, G, part[0]);
       }
       double ke = 0.0;
       WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; ke += V.x[e] * V.x[e]; }

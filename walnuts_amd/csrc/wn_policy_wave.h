@@ -433,9 +433,11 @@ struct WavePolicy {
     for (int e = 0; e < NE; ++e) q.x[e] = xq[e * ES];
   }
   // gradient (and log density) of the position sent out by the previous launch
-  __device__ __forceinline__ void ext_get(const Vec& q, Vec& g, double& lp_part) const {
+  __device__ __forceinline__ void ext_load_g(Vec& g) const {
 #pragma unroll
     for (int e = 0; e < NE; ++e) g.x[e] = valid(e) ? xg[e * ES] : 0.0;
+  }
+  __device__ __forceinline__ void ext_lp(const Vec& q, const Vec& g, double& lp_part) const {
     if (Tgt::EXT == EXT_LP) {
       lp_part = l0 == 0 ? *xlp : 0.0;
     } else {

@@ -135,7 +135,11 @@ class Engine:
         qview, gview = xq[:, :self.dim], xg[:, :self.dim]
         done = C.c_int32(0)
         ticks = 0
+        adaptive = self.cfg.integrator != L.I_FIXED
+        cap = 64 + 1.05 * n_iter * (1 << self.cfg.M) * (9.0 * (1 << (self.cfg.max_c + 2)) if adaptive else 1.0)
         while done.value < self.n_chains:
+            if ticks > cap:
+                raise WalnutsError("external-target run exceeded its tick bound (internal error)")
             for _ in range(poll):
                 lp, g = fn(qview)
                 xlp.copy_(torch.as_tensor(lp, dtype=torch.float64, device=self.device).reshape(self.n_chains))

@@ -102,3 +102,32 @@ def stockWatson(y):
     if not 3 <= T <= 256:
         raise ValueError("StockWatson needs 3 <= T <= 256")
     return DeviceTarget(f"stockWatson{T}", L.T_STOCKWATSON, 3 * T, np.concatenate([[float(T)], y]))
+
+
+def stockWatsonConstrain(y):
+    """Host form of mainSW.py:28-29 `generatedInnov(q) = param_constrain(q, include_tp=True)` for
+    sw_innov.stan: the 3T unconstrained parameters followed by the transformed parameters in
+    declaration order (sigma, gpri, z[T-1], x[T], tau[T]; sw_innov.stan:17-35).  Pass it as
+    `generated=`: identity draws are stored on the device and the transform is applied to each stored
+    draw on the host, once per iteration, as in the reference."""
+    T = int(np.asarray(y).shape[0])
+
+    def gen(q):
+        q = np.asarray(q, dtype=np.float64)
+        tS, z1, zinn = q[0], q[1], q[2:T]
+        x1, xinn = q[T], q[T + 1:2 * T]
+        tau1, tauinn = q[2 * T], q[2 * T + 1:3 * T]
+        sigma, gpri = np.exp(-0.5 * tS), np.exp(tS)
+        z = np.empty(T - 1); x = np.empty(T); tau = np.empty(T)
+        z[0] = z1
+        for t in range(1, T - 1):
+            z[t] = z[t - 1] + sigma * zinn[t - 1]
+        x[0] = x1
+        for t in range(1, T):
+            x[t] = x[t - 1] + sigma * xinn[t - 1]
+        tau[0] = tau1
+        for t in range(1, T):
+            tau[t] = tau[t - 1] + np.exp(0.5 * z[t - 1]) * tauinn[t - 1]
+        return np.concatenate([q, [sigma, gpri], z, x, tau])
+
+    return gen
