@@ -66,7 +66,7 @@ def run_engine(wa, c, q0, ncalls_hint, chain_offset):
                   chain_offset=chain_offset, warmupIter=c.get("warmupIter", 0), adaptH=c.get("adaptH", True),
                   adaptHtarget=c.get("adaptHtarget", 0.8), adaptDelta=c.get("adaptDelta", True),
                   adaptDeltaTarget=c.get("adaptDeltaTarget", 0.6),
-                  adaptDeltaQuantile=c.get("adaptDeltaQuantile", 0.9))
+                  adaptDeltaQuantile=c.get("adaptDeltaQuantile", 0.9), waves_per_group=c.get("waves_per_group", 0))
     e.set_target(c["target"], c["tpar"])
     s, d, tr, tn = e.run(q0, SEED, c["numIter"], trace_cap=ncalls_hint)
     out = dict(samples=s.transpose(1, 2).cpu().numpy(), diagnostics=d.cpu().numpy(),

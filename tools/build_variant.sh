@@ -6,8 +6,13 @@ NAME=$1; shift
 cd "$(dirname "$0")/../walnuts_amd/csrc"
 mkdir -p build_$NAME
 FLAGS="-O3 -std=c++17 -fPIC -fno-strict-aliasing --offload-arch=gfx950 -Wno-unused-result -Wno-unused-value $*"
+BASE="-O3 -std=c++17 -fPIC -fno-strict-aliasing --offload-arch=gfx950 -Wno-unused-result -Wno-unused-value"
+# PLAIN="wn_k_split wn_k_wave" compiles those translation units without the extra flags
 for f in wn_capi wn_k_lane wn_k_coop wn_k_wave wn_k_split wn_k_gemm; do
-  ( /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o build_$NAME/$f.o ) &
+  FL="$FLAGS"
+  case " ${PLAIN:-} " in *" $f "*) FL="$BASE";; esac
+  [ $f = wn_k_gemm ] && FL="$FL -mllvm -amdgpu-mfma-vgpr-form"
+  ( /opt/rocm/bin/hipcc $FL -c $f.hip -o build_$NAME/$f.o ) &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libwalnuts_amd_$NAME.so build_$NAME/*.o

@@ -6,28 +6,29 @@
 
 namespace wn {
 
-template <int NE, class Tgt, bool ADAPT, bool WARM, bool FLOW = false>
-__global__ __launch_bounds__(64) void wn_wave_kernel(Params prm) {
-  __shared__ double lds[Tgt::LDS_DOUBLES > 0 ? Tgt::LDS_DOUBLES : 1];
-  WavePolicy<NE, Tgt> p(prm, blockIdx.x, lds);
-  Engine<WavePolicy<NE, Tgt>, ADAPT, WARM, FLOW> eng(p, prm);
+template <int NE, class Tgt, bool ADAPT, bool WARM, bool FLOW = false, int W = 1>
+__global__ __launch_bounds__(64 * W) void wn_wave_kernel(Params prm) {
+  using P = WavePolicy<NE, Tgt, W>;
+  __shared__ double lds[P::LDS_DOUBLES > 0 ? P::LDS_DOUBLES : 1];
+  P p(prm, blockIdx.x, lds);
+  Engine<P, ADAPT, WARM, FLOW> eng(p, prm);
   eng.run();
 }
 
-template <int NE, class Tgt>
+template <int NE, class Tgt, int W = 1>
 static hipError_t go(int adapt, bool warm, const Params& prm, hipStream_t st) {
-  dim3 grid(prm.C), block(64);
+  dim3 grid(prm.C), block(64 * W);
   if (adapt == 2) {  // adaptLeapFrogFlowD
-    if (warm) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, true, true>), grid, block, 0, st, prm);
-    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false, true>), grid, block, 0, st, prm);
+    if (warm) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, true, true, W>), grid, block, 0, st, prm);
+    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false, true, W>), grid, block, 0, st, prm);
     return hipGetLastError();
   }
   if (warm) {
-    if (adapt) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, true>), grid, block, 0, st, prm);
-    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, false, true>), grid, block, 0, st, prm);
+    if (adapt) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, true, false, W>), grid, block, 0, st, prm);
+    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, false, true, false, W>), grid, block, 0, st, prm);
   } else {
-    if (adapt) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false>), grid, block, 0, st, prm);
-    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, false, false>), grid, block, 0, st, prm);
+    if (adapt) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false, false, W>), grid, block, 0, st, prm);
+    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, false, false, false, W>), grid, block, 0, st, prm);
   }
   return hipGetLastError();
 }
@@ -42,6 +43,8 @@ hipError_t launch_wave(const KernelChoice& kc, int adapt, bool warm, const Param
     if (kc.p0 == 8) return go<8, WTgtDiag<8>>(adapt, warm, prm, st);
     if (kc.p0 == 16) return go<16, WTgtDiag<16>>(adapt, warm, prm, st);
   }
+  // (four waves per chain were tried for StockWatson: 4.43 -> 4.08 us per tick at 256 chains, 2.2x slower
+  //  at 1024 -- the tick is scalar bookkeeping and f64 exp, not vector work; not kept)
   if (kc.p1 == T_STOCKWATSON && kc.p0 == 12) return go<12, WTgtStockWatson<12>>(adapt, warm, prm, st);
   return hipErrorInvalidValue;
 }

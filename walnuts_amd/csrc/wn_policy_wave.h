@@ -242,7 +242,6 @@ struct WavePolicy {
   static constexpr int ALIGN_LOG2 = 0;  // chains do not share a wave: nothing to align
   static constexpr int NRED = 8;        // widest reduction (wn_chain.h NPB)
   static constexpr int LDS_DOUBLES = Tgt::LDS_DOUBLES + (W_ > 1 ? 2 * NRED * W_ : 0);
-  static_assert(W_ == 1 || Tgt::LDS_DOUBLES == 0, "LDS targets are single-wave");
   struct Vec {
     double x[NE_];
   };
