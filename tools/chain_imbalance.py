@@ -1,3 +1,5 @@
+"""Diagnostic: spread of leapfrog steps per chain in the headline workload (a launch lasts as long as its
+slowest 16-chain group; measured mean/max = 0.91)."""
 import sys, numpy as np
 sys.path.insert(0, ".")
 import torch, walnuts_amd as wa
