@@ -76,6 +76,31 @@ def test_wave_warmup_and_generated(wa):
         close(out["samples"][k], o["samples"], what=f"samples chain {k}")
 
 
+def test_split_warmup_generated_and_orbit_stats(wa):
+    """Split mode (dense 200-D) with warm-up adaptation, generated = [q0, sum q^2] (a deferred reduction that is
+    parked between launches) and recordOrbitStats, chain by chain against the oracle."""
+    D, C = 200, 4
+    A, q0 = dense_problem(D, 1e3, C, 21)
+    c = dict(target=ol.T_DENSEGAUSS, integrator=ol.I_ADAPT_D, H0=0.6, s=0.2, delta0=0.2, M=5, numIter=16,
+             minC=0, maxC=10, R2Pprob0=2.0 / 3.0, generated=ol.G_Q0_SUMSQ, gen_k=0, tpar=A.ravel(), warmupIter=12)
+    out = run_engine(wa, c, q0, 4, chain_offset=60)
+    assert "split" in out["kernel"]
+    for k in (0, 3):
+        o = ol.walnuts(ol.T_DENSEGAUSS, q0[k], integrator=ol.I_ADAPT_D, tpar=A.ravel(), H0=0.6, delta0=0.2, numIter=16, M=5,
+                       seed=SEED, chain=60 + k, warmupIter=12, generated=ol.G_Q0_SUMSQ)
+        close(out["diagnostics"][k][:, [15, 18]], o["diagnostics"][:, [15, 18]], what=f"H/delta chain {k}")
+        np.testing.assert_array_equal(out["diagnostics"][k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]])
+        close(out["samples"][k], o["samples"], what=f"samples chain {k}")
+    e = wa.Engine(D, C, integrator=ol.I_FIXED, H0=0.5, M=5, generated=ol.G_FIRSTK, gen_k=3, chain_offset=60)
+    e.set_target(ol.T_DENSEGAUSS, A.ravel())
+    s, d, omin, omax = e.run_orbit_stats(q0, SEED, 4)
+    omin = omin.cpu().numpy(); omax = omax.cpu().numpy(); e.close()
+    o = ol.walnuts(ol.T_DENSEGAUSS, q0[2], integrator=ol.I_FIXED, tpar=A.ravel(), H0=0.5, numIter=4, M=5, seed=SEED,
+                   chain=62, generated=ol.G_FIRSTK, gen_k=3, recordOrbitStats=True)
+    close(omin[2].T, o["orbitMin"], what="orbitMin split")
+    close(omax[2].T, o["orbitMax"], what="orbitMax split")
+
+
 def test_split_dense_full_size_properties(wa):
     """SURVEY.md 8d cfg 4 shape (D = 1000, kappa = 100, fixedLeapFrog, M = 10) at a reduced chain
     count: size-independent properties -- every chain finishes, step counts are consistent with the
