@@ -40,6 +40,14 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, Kernel
   static int slot = 0;
   char* nm = names[(slot++) & 7];
   int dm = lane_dmax(target, D);
+  if (target == T_FUNNEL10 && integrator != I_FIXED && waves_per_group != 64) {
+    // adaptive integrators on the funnel: per-chain work is wildly uneven, one chain per wave (see WTgtFunnel10);
+    // waves_per_group = 64 asks for the one-chain-per-lane kernel
+    kc->layout = 2; kc->p0 = 1; kc->p1 = T_FUNNEL10; kc->W = 1;
+    snprintf(nm, 64, "wn_wave_kernel<NE=1,funnel10>");
+    kc->name = nm;
+    return 0;
+  }
   if (dm) {
     kc->layout = 0; kc->p0 = dm; kc->p1 = target; kc->W = 1;
     snprintf(nm, 64, "wn_lane_kernel<DMAX=%d,target=%d>", dm, target);

@@ -1074,7 +1074,8 @@ struct Engine : ChainScalars {
           p.template reduce<4>(part);
         }
       } else {
-        p.template reduce<NPB>(part);
+        if (p.any(needKE || needGen)) p.template reduce<NPB>(part);
+        else p.template reduce<2>(part);
       }
       WN_STAMP(2);
       if constexpr (FLOW) if (p.any(mid)) {
@@ -1290,7 +1291,9 @@ struct Engine : ChainScalars {
             p.template reduce<4>(part);
           }
         } else {
-          p.template reduce<NPB>(part);
+          // the initial kinetic energy / deferred generated() sum ride along only when one is pending
+          if (p.any(needKE || needGen)) p.template reduce<NPB>(part);
+          else p.template reduce<2>(part);
         }
         WN_STAMP(2);
         if constexpr (FLOW) if (p.any(mid)) {

@@ -34,6 +34,7 @@ static hipError_t go(int adapt, bool warm, const Params& prm, hipStream_t st) {
 }
 
 size_t wave_work_doubles(int NE, int C, int M) {
+  if (NE == 1) return WavePolicy<1, WTgtFunnel10>::work_doubles(C, M);
   if (NE == 12) return WavePolicy<12, WTgtDiag<12>>::work_doubles(C, M);
   return NE <= 8 ? WavePolicy<8, WTgtDiag<8>>::work_doubles(C, M) : WavePolicy<16, WTgtDiag<16>>::work_doubles(C, M);
 }
@@ -43,6 +44,7 @@ hipError_t launch_wave(const KernelChoice& kc, int adapt, bool warm, const Param
     if (kc.p0 == 8) return go<8, WTgtDiag<8>>(adapt, warm, prm, st);
     if (kc.p0 == 16) return go<16, WTgtDiag<16>>(adapt, warm, prm, st);
   }
+  if (kc.p1 == T_FUNNEL10 && kc.p0 == 1) return go<1, WTgtFunnel10>(adapt, warm, prm, st);
   // (four waves per chain were tried for StockWatson: 4.43 -> 4.08 us per tick at 256 chains, 2.2x slower
   //  at 1024 -- the tick is scalar bookkeeping and f64 exp, not vector work; not kept)
   if (kc.p1 == T_STOCKWATSON && kc.p0 == 12) return go<12, WTgtStockWatson<12>>(adapt, warm, prm, st);

@@ -20,6 +20,32 @@ namespace wn {
 
 struct EmptyVecW {};
 
+template <int CTRL>
+__device__ __forceinline__ double wn_dpp(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes, same bits everywhere: xor-1, xor-2 inside quads, mirrored halves and rows
+// (every exchange is symmetric, so both partners add the same two numbers), then across rows
+__device__ __forceinline__ double wn_wavesum(double x) {
+  x += wn_dpp<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += wn_dpp<0x4E>(x);   // quad_perm [2,3,0,1]
+  x += wn_dpp<0x141>(x);  // row_half_mirror
+  x += wn_dpp<0x140>(x);  // row_mirror
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  u2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  u2_t b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double y = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  lo = __double2loint(y); hi = __double2hiint(y);
+  a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
+
 enum { EXT_NONE = 0, EXT_HALF_QG = 1, EXT_LP = 2 };
 
 // lp = -1/2 sum a_i q_i^2, grad = -a_i q_i  (stdGauss, targetDistr.py:18-21, is a == 1)
@@ -231,6 +257,30 @@ struct WTgtStockWatson {
   }
 };
 
+// funnel10 (targetDistr.py:74-78) for one chain per wave: lane i < 11 holds q_i.  Chains of a funnel
+// run need wildly different numbers of gradient evaluations (the neck), and a wave that hosts 64
+// chains lasts as long as its busiest one (measured lane occupancy 4 %); one chain per wave lets every
+// chain run at its own pace and the dispatcher balance the rest.
+struct WTgtFunnel10 {
+  static constexpr int EXT = EXT_NONE;
+  static constexpr int LDS_DOUBLES = 0;
+  __device__ __forceinline__ void init(const Params&, int, double*) {}
+  __device__ __forceinline__ static double lp_finish(double r) { return r; }
+  __device__ __forceinline__ double grad(const double* q, double* g, int lane) const {
+    const double logC = 0.91893853320467274178;  // log(sqrt(2 pi))
+    const double log3 = 1.09861228866810969140;
+    const double q0 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(q[0])),
+                                       __builtin_amdgcn_readfirstlane(__double2loint(q[0])));  // lane 0 holds q_0
+    const double emq = exp(-q0);
+    const double ss = wn_wavesum((lane >= 1 && lane < 11) ? q[0] * q[0] : 0.0);
+    g[0] = lane == 0 ? (-5.0 - q0 / 9.0 + 0.5 * emq * ss) : (lane < 11 ? -q[0] * emq : 0.0);
+    const double lp = (-(q0 * q0) / 18.0 - logC - log3) + (-0.5 * emq * ss - 10.0 * logC - 5.0 * q0);
+    // s = np.exp(0.5*q0) overflowing makes the reference's lp -inf (targetDistr.py:75, WALNUTS.py:316)
+    const double r = (0.5 * q0 > 709.782712893384) ? -INFINITY : lp;
+    return lane == 0 ? r : 0.0;
+  }
+};
+
 // W waves (one workgroup) serve a chain: register e of wave w, lane l holds element (e*W + w)*64 + l.
 template <int NE_, class Tgt, int W_ = 1>
 struct WavePolicy {
@@ -296,30 +346,6 @@ struct WavePolicy {
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
   __device__ __forceinline__ bool majority(bool a, bool) const { return __any(a); }
 
-  template <int CTRL>
-  __device__ __forceinline__ static double dpp(double x) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-  }
-  // sum over the 64 lanes, same bits everywhere: xor-1, xor-2 inside quads, mirrored halves and rows
-  // (every exchange is symmetric, so both partners add the same two numbers), then across rows
-  __device__ __forceinline__ static double wavesum(double x) {
-    x += dpp<0xB1>(x);   // quad_perm [1,0,3,2]
-    x += dpp<0x4E>(x);   // quad_perm [2,3,0,1]
-    x += dpp<0x141>(x);  // row_half_mirror
-    x += dpp<0x140>(x);  // row_mirror
-    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-    unsigned lo = __double2loint(x), hi = __double2hiint(x);
-    u2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    u2_t b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    const double y = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-    lo = __double2loint(y); hi = __double2hiint(y);
-    a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-  }
   // sum over all lanes serving the chain; every replica gets the same bits.  Two buffers alternate:
   // a wave can reuse a buffer only after the barrier of the next reduction, behind which every wave
   // has finished reading it.
@@ -327,7 +353,7 @@ struct WavePolicy {
   __device__ __forceinline__ void reduce(double* v) {
     static_assert(N <= NRED, "reduce width");
 #pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = wavesum(v[k]);
+    for (int k = 0; k < N; ++k) v[k] = wn_wavesum(v[k]);
     if (W_ > 1) {
       double* buf = ldsr + (redpar & 1) * (NRED * W_);
       redpar++;
@@ -348,10 +374,10 @@ struct WavePolicy {
 
   // max over all lanes serving the chain (NaN-free inputs; max is exact, so every replica agrees)
   __device__ __forceinline__ static double wavemax(double x) {
-    x = fmax(x, dpp<0xB1>(x));
-    x = fmax(x, dpp<0x4E>(x));
-    x = fmax(x, dpp<0x141>(x));
-    x = fmax(x, dpp<0x140>(x));
+    x = fmax(x, wn_dpp<0xB1>(x));
+    x = fmax(x, wn_dpp<0x4E>(x));
+    x = fmax(x, wn_dpp<0x141>(x));
+    x = fmax(x, wn_dpp<0x140>(x));
 #pragma unroll
     for (int d = 16; d < 64; d <<= 1) x = fmax(x, __shfl_xor(x, d));
     return x;
