@@ -268,6 +268,12 @@ def main():
                 e3.close()
             except Exception as ex:
                 extras["error"] = repr(ex)
+            # the other BASELINE configs, one short launch each (outside the timed region; the full lines
+            # are `--workload funnel | dense1000 | stockwatson`)
+            try:
+                extras["other_configs"] = side_configs(wa, L, torch, dev)
+            except Exception as ex:
+                extras["other_configs"] = {"error": repr(ex)}
             out["extras"] = extras
         if cpu is not None:
             out["cpu_baseline"] = cpu
@@ -275,6 +281,43 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def side_configs(wa, L, torch, dev):
+    """One launch each of BASELINE configs 3, 4 (one GPU's shard) and 5 (one GPU's shard)."""
+    res = {}
+    rng = np.random.default_rng([SEED, 3])
+    C = 4096
+    q0 = np.zeros((C, 11)); q0[:, 0] = 3.0 * rng.normal(size=C)
+    q0[:, 1:] = np.exp(0.5 * q0[:, :1]) * rng.normal(size=(C, 10))
+    e = wa.Engine(11, C, integrator=L.I_ADAPT_R2P, H0=0.3, delta0=0.3, M=12, generated=L.G_FIRSTK, gen_k=2,
+                  device=dev.index).set_target(L.T_FUNNEL10)
+    e.run(torch.as_tensor(q0, device=dev), SEED + 1, 2)  # untimed first launch (code load)
+    s, d = e.run(torch.as_tensor(q0, device=dev), SEED, 30)
+    ev = float((d[:, :, 6] + d[:, :, 7]).sum().item())
+    res["cfg3_funnel10_R2P_4096_chains"] = {"value": ev / (e.last_run_ms() * 1e-3), "unit": "gradient evaluations/s",
+                                            "kernel": e.kernel_name}
+    e.close()
+    A, q1 = make_dense_problem(1000, 100.0, 1024, SEED)
+    e = wa.Engine(1000, 1024, integrator=L.I_FIXED, H0=0.5, M=10, generated=L.G_Q0_SUMSQ, device=dev.index)
+    e.set_target(L.T_DENSEGAUSS, A)
+    e.run(torch.as_tensor(q1, device=dev), SEED + 1, 2)
+    s, d = e.run(torch.as_tensor(q1, device=dev), SEED, 30)
+    st = float((d[:, :, 6] + d[:, :, 7]).sum().item()); ms = e.last_run_ms()
+    res["cfg4_dense1000_1024_chains"] = {"value": st / (ms * 1e-3), "unit": "leapfrog steps/s", "kernel": e.kernel_name,
+                                         "fp64_mfma_frac": st * (2.0e6 + 12.0e3) / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+    e.close()
+    sw = np.load(os.path.join(ROOT, "tests", "golden", "stockwatson_data.npz"))
+    T = int(sw["T"][0])
+    e = wa.Engine(3 * T, 256, integrator=L.I_ADAPT_D, H0=0.1, delta0=0.3, M=14, minC=3, generated=L.G_FIRSTK, gen_k=2,
+                  device=dev.index).set_target(L.T_STOCKWATSON, np.concatenate([[float(T)], sw["y"]]))
+    e.run(torch.zeros((256, 3 * T), dtype=torch.float64, device=dev), SEED + 1, 1)
+    s, d = e.run(torch.zeros((256, 3 * T), dtype=torch.float64, device=dev), SEED, 10)
+    ev = float((d[:, :, 6] + d[:, :, 7]).sum().item())
+    res["cfg5_stockwatson_adaptD_256_chains"] = {"value": ev / (e.last_run_ms() * 1e-3), "unit": "gradient evaluations/s",
+                                                 "kernel": e.kernel_name}
+    e.close()
+    return res
 
 
 def main_funnel(args):
