@@ -320,97 +320,128 @@ def side_configs(wa, L, torch, dev):
     return res
 
 
+def _dist_setup():
+    """One process per GPU (torch.distributed.run env); returns rank, world, device, collective device, dist."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("WN_DIST_BACKEND", "nccl")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    return rank, world, dev, (dev if backend == "nccl" else torch.device("cpu")), dist
+
+
+def _run_evals_workload(args, make_engine, q0_of, metric, workload, bytes_per_eval):
+    """Common driver of the gradient-evaluation workloads (configs 3 and 5): chains shard over ranks with no
+    data-path collective; barrier + synchronize around exactly `steps` launches; max time over ranks."""
+    import torch
+    rank, world, dev, cdev, dist = _dist_setup()
+    eng, C = make_engine(rank, dev)
+    q0d = torch.as_tensor(q0_of(rank, C), device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for w in range(args.warmup):
+        eng.run(q0d, SEED + 1000 + w, args.iters)
+    barrier()
+    t0 = time.perf_counter()
+    tot = 0.0; kms = []; mx = []
+    for k in range(args.steps):
+        s, d = eng.run(q0d, SEED + k, args.iters)
+        per_chain = (d[:, :, 6] + d[:, :, 7]).sum(1)
+        tot += float(per_chain.sum().item())
+        mx.append(float(per_chain.max().item()))
+        kms.append(eng.last_run_ms())
+    barrier()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el, tot], dtype=torch.float64, device=cdev)
+    if world > 1:
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        el, tot_all = float(tmax[0].item()), float(t[1].item())
+    else:
+        tot_all = tot
+    if rank == 0:
+        ach = tot / args.steps * bytes_per_eval / (np.mean(kms) * 1e-3) / 1e9  # rank 0's kernel
+        print(json.dumps({"metric": metric, "value": tot_all / el, "unit": "gradient evaluations/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                          "data": "synthetic",
+                          "config": {"workload": workload(C), "kernel": eng.kernel_name, "chains_per_gpu": C,
+                                     "sharding": f"chains x{world}, no data-path collective"},
+                          "kernel_ms_avg": float(np.mean(kms)),
+                          # a launch lasts as long as its busiest chain (that chain's evaluations are sequential)
+                          "busiest_chain_evals": float(np.mean(mx)),
+                          "chain_occupancy": tot / args.steps / C / float(np.mean(mx)),
+                          "tick_us": float(np.mean(kms)) * 1e3 / float(np.mean(mx)),
+                          "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                       "bytes_per_gradient_evaluation": bytes_per_eval}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main_funnel(args):
     """SURVEY 8d cfg 3: funnel10 (D=11), adaptLeapFrogR2P, M=12, H0=0.3, delta0=0.3, warmupIter=0,
     q0[0]~N(0,9), q0[1:]~N(0,e^{q0[0]}); metric = gradient evaluations (nevalF+nevalB) per second.
     Roofline per SURVEY 8d: HBM, 48*D = 528 B per gradient evaluation (unfused streaming figure)."""
-    import torch
-    torch.cuda.set_device(0)
     import walnuts_amd as wa
     from walnuts_amd import _lib as L
-    C = args.chains
-    iters = args.iters
-    rng = np.random.default_rng([SEED, 3])
-    q0 = np.zeros((C, 11)); q0[:, 0] = 3.0 * rng.normal(size=C)
-    q0[:, 1:] = np.exp(0.5 * q0[:, :1]) * rng.normal(size=(C, 10))
-    eng = wa.Engine(11, C, integrator=L.I_ADAPT_R2P, H0=0.3, delta0=0.3, M=12, generated=L.G_FIRSTK, gen_k=2)
-    eng.set_target(L.T_FUNNEL10)
-    q0d = torch.as_tensor(q0, device="cuda")
-    for w in range(args.warmup):
-        eng.run(q0d, SEED + 1000 + w, iters)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    tot = 0.0; kms = []; mx = []
-    for k in range(args.steps):
-        s, d = eng.run(q0d, SEED + k, iters)
-        per_chain = (d[:, :, 6] + d[:, :, 7]).sum(1)
-        tot += float(per_chain.sum().item())
-        mx.append(float(per_chain.max().item()))
-        kms.append(eng.last_run_ms())
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    ach = tot / args.steps * 528.0 / (np.mean(kms) * 1e-3) / 1e9
-    print(json.dumps({"metric": "gradient evaluations/sec across chains, funnel10 (adaptLeapFrogR2P)",
-                      "value": tot / el, "unit": "gradient evaluations/s", "n_gpus": 1, "steps": args.steps,
-                      "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
-                      "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                      "config": {"workload": f"funnel10 D=11, {C} chains, adaptLeapFrogR2P, M=12, H0=0.3, delta0=0.3, "
-                                             f"{iters} iterations/launch (SURVEY 8d cfg 3)", "kernel": eng.kernel_name},
-                      "kernel_ms_avg": float(np.mean(kms)),
-                      # every lane advances one gradient evaluation per tick; a launch lasts as long as
-                      # its busiest chain, so mean/max evaluations per chain is the lane occupancy
-                      "busiest_chain_evals": float(np.mean(mx)),
-                      "lane_occupancy": tot / args.steps / C / float(np.mean(mx)),
-                      "tick_us": float(np.mean(kms)) * 1e3 / float(np.mean(mx)),
-                      "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                                   "bytes_per_gradient_evaluation": 528.0}}), flush=True)
+
+    def make_engine(rank, dev):
+        C = args.chains
+        e = wa.Engine(11, C, integrator=L.I_ADAPT_R2P, H0=0.3, delta0=0.3, M=12, generated=L.G_FIRSTK, gen_k=2,
+                      chain_offset=rank * C, device=dev.index)
+        return e.set_target(L.T_FUNNEL10), C
+
+    def q0_of(rank, C):
+        rng = np.random.default_rng([SEED, 3, rank])
+        q0 = np.zeros((C, 11)); q0[:, 0] = 3.0 * rng.normal(size=C)
+        q0[:, 1:] = np.exp(0.5 * q0[:, :1]) * rng.normal(size=(C, 10))
+        return q0
+
+    _run_evals_workload(args, make_engine, q0_of, "gradient evaluations/sec across chains, funnel10 (adaptLeapFrogR2P)",
+                        lambda C: f"funnel10 D=11, {C} chains/GPU, adaptLeapFrogR2P, M=12, H0=0.3, delta0=0.3, "
+                                  f"{args.iters} iterations/launch (SURVEY 8d cfg 3)", 528.0)
 
 
 def main_stockwatson(args):
-    """SURVEY 8d cfg 5: StockWatson (D = 756), one GPU's shard of the 2048-chain job, the first of
+    """SURVEY 8d cfg 5: StockWatson (D = 756), one GPU's shard of the 2048-chain job per rank, the first of
     mainSW.py:41-80's three runs (adaptLeapFrogD, minC=3, H0=0.1, delta0=0.3, M=14), q0 = 0.
     Metric = gradient evaluations/s; roofline per SURVEY 8d: HBM, 48*D bytes per evaluation."""
-    import torch
-    torch.cuda.set_device(0)
     import walnuts_amd as wa
     from walnuts_amd import _lib as L
     sw = np.load(os.path.join(ROOT, "tests", "golden", "stockwatson_data.npz"))
     T = int(sw["T"][0]); D = 3 * T
-    C = 256 if args.chains == 4096 else args.chains
-    iters = 20 if args.iters == 100 else args.iters
-    eng = wa.Engine(D, C, integrator=L.I_ADAPT_D, H0=0.1, delta0=0.3, M=14, minC=3, generated=L.G_FIRSTK, gen_k=2)
-    eng.set_target(L.T_STOCKWATSON, np.concatenate([[float(T)], sw["y"]]))
-    q0d = torch.zeros((C, D), dtype=torch.float64, device="cuda")
-    for w in range(args.warmup):
-        eng.run(q0d, SEED + 1000 + w, iters)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    tot = 0.0; kms = []; mx = []
-    for k in range(args.steps):
-        s, d = eng.run(q0d, SEED + k, iters)
-        per_chain = (d[:, :, 6] + d[:, :, 7]).sum(1)
-        tot += float(per_chain.sum().item())
-        mx.append(float(per_chain.max().item()))
-        kms.append(eng.last_run_ms())
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    bpe = 48.0 * D
-    ach = tot / args.steps * bpe / (np.mean(kms) * 1e-3) / 1e9
-    print(json.dumps({"metric": "gradient evaluations/sec across chains, StockWatson (adaptLeapFrogD)",
-                      "value": tot / el, "unit": "gradient evaluations/s", "n_gpus": 1, "steps": args.steps,
-                      "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
-                      "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                      "config": {"workload": f"StockWatson D={D}, {C} chains, adaptLeapFrogD minC=3, M=14, H0=0.1, "
-                                             f"delta0=0.3, q0=0, {iters} iterations/launch (SURVEY 8d cfg 5)",
-                                 "kernel": eng.kernel_name},
-                      "kernel_ms_avg": float(np.mean(kms)),
-                      "busiest_chain_evals": float(np.mean(mx)),
-                      "chain_occupancy": tot / args.steps / C / float(np.mean(mx)),
-                      "tick_us": float(np.mean(kms)) * 1e3 / float(np.mean(mx)),
-                      "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                                   "bytes_per_gradient_evaluation": bpe}}), flush=True)
+    if args.chains == 4096:
+        args.chains = 256
+    if args.iters == 100:
+        args.iters = 20
+
+    def make_engine(rank, dev):
+        C = args.chains
+        e = wa.Engine(D, C, integrator=L.I_ADAPT_D, H0=0.1, delta0=0.3, M=14, minC=3, generated=L.G_FIRSTK, gen_k=2,
+                      chain_offset=rank * C, device=dev.index)
+        return e.set_target(L.T_STOCKWATSON, np.concatenate([[float(T)], sw["y"]])), C
+
+    _run_evals_workload(args, make_engine, lambda rank, C: np.zeros((C, D)),
+                        "gradient evaluations/sec across chains, StockWatson (adaptLeapFrogD)",
+                        lambda C: f"StockWatson D={D}, {C} chains/GPU, adaptLeapFrogD minC=3, M=14, H0=0.1, delta0=0.3, "
+                                  f"q0=0, {args.iters} iterations/launch (SURVEY 8d cfg 5)", 48.0 * D)
 
 
 if __name__ == "__main__":

@@ -392,3 +392,14 @@ def test_bench_two_ranks_sharing_one_gpu():
                          "--iters", "5", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
     o1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
     assert o1["leapfrog_steps_per_launch_per_gpu"] == 2 * out["leapfrog_steps_per_launch_per_gpu"]
+    # the other workloads shard the same way (configs 3, 4, 5)
+    for port, extra in ((29743, ["--workload", "funnel", "--chains", "64", "--iters", "3"]),
+                        (29745, ["--workload", "dense1000", "--chains", "64", "--iters", "2", "--no-cpu-baseline"]),
+                        (29747, ["--workload", "stockwatson", "--chains", "8", "--iters", "2"])):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+               "--warmup", "0"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert o["n_gpus"] == 2 and o["value"] > 0 and o["roofline"]["frac"] > 0, o
