@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--workload", default="gauss100", choices=["gauss100", "funnel", "dense1000", "stockwatson"],
                     help="gauss100 = BASELINE configs[1] family (headline); funnel = configs[2] "
                          "(funnel10, adaptLeapFrogR2P, M=12, H0=0.3, delta0=0.3; SURVEY 8d cfg 3)")
+    ap.add_argument("--sw-run", default="D", choices=["D", "fixed", "R2P"],
+                    help="stockwatson workload: which of mainSW.py:41-80's three runs (adaptLeapFrogD minC=3 H0=0.1 | "
+                         "fixedLeapFrog H0=0.002 | adaptLeapFrogR2P minC=3 H0=0.1)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the SURVEY 8d side measurements (C=1024, diagonal-precision variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -432,15 +435,18 @@ def main_stockwatson(args):
     if args.iters == 100:
         args.iters = 20
 
+    ig, H0, minC, name = {"D": (L.I_ADAPT_D, 0.1, 3, "adaptLeapFrogD minC=3"), "fixed": (L.I_FIXED, 0.002, 0, "fixedLeapFrog"),
+                          "R2P": (L.I_ADAPT_R2P, 0.1, 3, "adaptLeapFrogR2P minC=3")}[args.sw_run]
+
     def make_engine(rank, dev):
         C = args.chains
-        e = wa.Engine(D, C, integrator=L.I_ADAPT_D, H0=0.1, delta0=0.3, M=14, minC=3, generated=L.G_FIRSTK, gen_k=2,
+        e = wa.Engine(D, C, integrator=ig, H0=H0, delta0=0.3, M=14, minC=minC, generated=L.G_FIRSTK, gen_k=2,
                       chain_offset=rank * C, device=dev.index)
         return e.set_target(L.T_STOCKWATSON, np.concatenate([[float(T)], sw["y"]])), C
 
     _run_evals_workload(args, make_engine, lambda rank, C: np.zeros((C, D)),
-                        "gradient evaluations/sec across chains, StockWatson (adaptLeapFrogD)",
-                        lambda C: f"StockWatson D={D}, {C} chains/GPU, adaptLeapFrogD minC=3, M=14, H0=0.1, delta0=0.3, "
+                        f"gradient evaluations/sec across chains, StockWatson ({name.split()[0]})",
+                        lambda C: f"StockWatson D={D}, {C} chains/GPU, {name}, M=14, H0={H0}, delta0=0.3, "
                                   f"q0=0, {args.iters} iterations/launch (SURVEY 8d cfg 5)", 48.0 * D)
 
 
