@@ -37,7 +37,10 @@ struct CoopPolicy {
   static constexpr int KS_MAX = 4 * NT * W;  // k-steps of the padded dimension 16*NT*W
   static constexpr int DPAD = 16 * NT * W;
   // sub-tree levels 2..1+NLC keep their left endpoint (q, v) in LDS: [level][q|v][wave][reg][lane]
-  static constexpr int NLC = NT <= 2 ? 3 : 0;
+#ifndef WN_COOP_NLC
+#define WN_COOP_NLC 3
+#endif
+  static constexpr int NLC = NT <= 2 ? WN_COOP_NLC : 0;
   static constexpr int ALIGN_LOG2 = WN_ALIGN_LOG2;  // iteration-start alignment (wn_chain.h run())
   static constexpr int NRED = 4 + 2 * (2 + NLC);
   static constexpr int LDS_Q = KS_MAX * 64;
