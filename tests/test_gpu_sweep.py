@@ -1,0 +1,84 @@
+"""GPU sweep over dimensions at the seams between layouts (lane / coop / wave / split) and over all five
+integrators: two iterations of three chains each, draws and step counts against the oracle."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from test_gpu_parity import SEED, close, dense_problem, wa  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+DIMS_DIAG = [1, 4, 5, 24, 25, 64, 65, 128, 129, 256, 257, 512, 513, 1024]
+DIMS_DENSE = [2, 16, 17, 64, 100, 101, 128, 129, 500]
+INTEG = [ol.I_FIXED, ol.I_ADAPT_D, ol.I_ADAPT_R2P, ol.I_ADAPT_YOSHIDA, ol.I_ADAPT_FLOWD]
+
+
+def _run(wa, tk, D, ig, tpar, q0, M=4, numIter=2):
+    e = wa.Engine(D, q0.shape[0], integrator=ig, H0=0.7, delta0=0.2, M=M, chain_offset=11)
+    e.set_target(tk, tpar)
+    s, d = e.run(q0, SEED, numIter)
+    s = s.transpose(1, 2).cpu().numpy(); d = d.cpu().numpy(); name = e.kernel_name; e.close()
+    for k in (0, q0.shape[0] - 1):
+        o = ol.walnuts(tk, q0[k], integrator=ig, tpar=tpar, H0=0.7, delta0=0.2, numIter=numIter, M=M, seed=SEED, chain=11 + k)
+        np.testing.assert_array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]], err_msg=f"{name} D={D} ig={ig}")
+        close(s[k], o["samples"], what=f"{name} D={D} ig={ig} chain {k}")
+
+
+@pytest.mark.parametrize("D", DIMS_DIAG)
+def test_diag_gaussian_every_layout_seam(wa, D):
+    rng = np.random.default_rng(D)
+    a = 1.0 / np.logspace(0, 1.5, D)
+    q0 = rng.normal(size=(3, D)) / np.sqrt(a)
+    for ig in INTEG:
+        _run(wa, ol.T_DIAGGAUSS, D, ig, a, q0)
+
+
+@pytest.mark.parametrize("D", DIMS_DENSE)
+def test_dense_gaussian_every_layout_seam(wa, D):
+    A, q0 = dense_problem(D, 30.0, 3, 100 + D)
+    for ig in INTEG:
+        _run(wa, ol.T_DENSEGAUSS, D, ig, A.ravel(), q0)
+
+
+def test_unsupported_sizes_fail_loudly(wa):
+    with pytest.raises(NotImplementedError):
+        wa.Engine(1025, 2).set_target(ol.T_STDGAUSS)
+    with pytest.raises(NotImplementedError):
+        wa.Engine(1030, 2).set_target(ol.T_DENSEGAUSS, np.eye(1030).ravel())
+    with pytest.raises(ValueError):
+        wa.Engine(12, 2).set_target(ol.T_FUNNEL10)
+
+
+@pytest.mark.parametrize("C", [1, 63, 64, 65, 129])
+def test_split_ragged_chain_counts(wa, C):
+    """The gradient kernel works on 64-chain tiles; chain counts around the tile edges."""
+    D = 140
+    A, q0 = dense_problem(D, 30.0, C, 7)
+    e = wa.Engine(D, C, integrator=ol.I_FIXED, H0=0.7, M=5, chain_offset=3).set_target(ol.T_DENSEGAUSS, A.ravel())
+    s, d = e.run(q0, SEED, 2)
+    s = s.transpose(1, 2).cpu().numpy(); d = d.cpu().numpy(); e.close()
+    for k in sorted({0, C // 2, C - 1}):
+        o = ol.walnuts(ol.T_DENSEGAUSS, q0[k], integrator=ol.I_FIXED, tpar=A.ravel(), H0=0.7, numIter=2, M=5, seed=SEED, chain=3 + k)
+        np.testing.assert_array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]])
+        close(s[k], o["samples"], what=f"C={C} chain {k}")
+
+
+@pytest.mark.parametrize("layout", ["wave", "split"])
+def test_deep_trees_in_wave_and_split(wa, layout):
+    """M = 10 with a small step size: orbits of up to 1023 steps exercise every slot level of the memory-resident
+    sub-tree store (the one-chain-per-wave layouts cache none on chip)."""
+    D = 300 if layout == "wave" else 150
+    rng = np.random.default_rng(2)
+    if layout == "wave":
+        tk, tpar = ol.T_DIAGGAUSS, np.ones(D); q0 = rng.normal(size=(2, D))
+    else:
+        tk = ol.T_DENSEGAUSS; A, q0 = dense_problem(D, 4.0, 2, 9); tpar = A.ravel()
+    e = wa.Engine(D, 2, integrator=ol.I_FIXED, H0=0.01, M=10, chain_offset=5).set_target(tk, tpar)
+    assert layout in e.kernel_name
+    s, d = e.run(q0, SEED, 2)
+    s = s.transpose(1, 2).cpu().numpy(); d = d.cpu().numpy(); e.close()
+    assert d[:, :, 20].max() >= 9  # deep doublings were reached
+    for k in (0, 1):
+        o = ol.walnuts(tk, q0[k], integrator=ol.I_FIXED, tpar=tpar, H0=0.01, numIter=2, M=10, seed=SEED, chain=5 + k)
+        np.testing.assert_array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]])
+        close(s[k], o["samples"], what=f"{layout} chain {k}")
