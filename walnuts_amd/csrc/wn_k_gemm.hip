@@ -3,6 +3,8 @@
 // as v_mfma_f64_16x16x4_f64 with M = output index d, N = chain, K = k.  Built with
 // -mllvm -amdgpu-mfma-vgpr-form (Makefile): with accumulators homed in AGPRs the compiler moved all
 // 128 of them through VGPRs on every trip of the k-loop.
+#include <stdlib.h>
+
 #include "wn_launch.h"
 
 namespace wn {
@@ -19,21 +21,23 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // the set not being multiplied is in flight.  The four partial tiles meet in LDS at the end, each
 // wave finishing and storing a quarter.
 #define WN_GEMM_LOAD(SET, KOFF)                                                    \
-  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                \
-    fa##SET[i_] = *(const d2_t*)(ap + i_ * rs + (KOFF));                            \
-    fb##SET[i_] = *(const d2_t*)(bp + i_ * rs + (KOFF));                            \
-  }
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) fa##SET[i_] = *(const d2_t*)(ap + i_ * rs + (KOFF));   \
+  _Pragma("unroll") for (int j_ = 0; j_ < NJ; ++j_) fb##SET[j_] = *(const d2_t*)(bp + j_ * rs + (KOFF));
 #define WN_GEMM_MUL(SET)                                                           \
   _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                  \
   _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                  \
-  _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                  \
+  _Pragma("unroll") for (int j_ = 0; j_ < NJ; ++j_)                                 \
     acc[i_][j_] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa##SET[i_][s_], fb##SET[j_][s_], acc[i_][j_], 0, 0, 0);
 
+// NJ = 16-chain blocks per tile: 4 (64 x 64 tiles), or 2 (64 x 32 tiles) when 64 x 64 tiles would leave
+// CUs without a workgroup (measured, 1024 chains: D = 1000 44 vs 55 us -- the wider tile's register reuse
+// wins once every CU has one; D = 300 15.6 vs 11.3 us -- 128 wide tiles fill half the chip).
+template <int NJ>
 __global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __restrict__ A, const double* __restrict__ xq,
                                                             double* __restrict__ xg, int DP, int Kr, int tiles_d,
                                                             int tiles_c, const int* done, int C) {
   if (*done >= C) return;  // every chain has finished: nothing reads the result
-  __shared__ double red[4 * 48 * 64];  // [owner wave][partial accumulator of a contributor][lane]
+  __shared__ double red[4 * 3 * 4 * NJ * 64];  // [owner wave][partial accumulator of a contributor][lane]
   const int T = tiles_d * tiles_c, per = (T + 7) / 8;
   // consecutive blocks go to different XCDs: give each XCD a contiguous range of tiles (same chains,
   // neighbouring rows of A) so its L2 sees each operand row once
@@ -41,19 +45,19 @@ __global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __rest
   if ((int)(blockIdx.x >> 3) >= per || t >= T) return;
   const int ct = t / tiles_d, dt = t % tiles_d;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int d0 = dt * 64, c0 = ct * 64;
+  const int d0 = dt * 64, c0 = ct * 16 * NJ;
   const int r = lane & 15;
   // this wave's k-range [wave*Kq, (wave+1)*Kq): a multiple of 16 long; beyond Kr both operands are zero
   const int Kq = ((Kr + 3) / 4 + 15) / 16 * 16;
   const double* ap = A + (size_t)(d0 + r) * DP + wave * Kq + 2 * (lane >> 4);   // + i * 16 rows
   const double* bp = xq + (size_t)(c0 + r) * DP + wave * Kq + 2 * (lane >> 4);  // + j * 16 rows
   const size_t rs = (size_t)16 * DP;
-  d4_t acc[4][4];
+  d4_t acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (d4_t){0, 0, 0, 0};
-  d2_t fa0[4], fb0[4], fa1[4], fb1[4];
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (d4_t){0, 0, 0, 0};
+  d2_t fa0[4], fb0[NJ], fa1[4], fb1[NJ];
   WN_GEMM_LOAD(0, 0);
   for (int k = 0; k < Kq; k += 16) {
     WN_GEMM_LOAD(1, k + 8);
@@ -67,9 +71,9 @@ __global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __rest
     if (i != wave) {
       const int slot = wave < i ? wave : wave - 1;  // 0..2 among the three contributors of owner i
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) red[((i * 48) + (slot * 16 + j * 4 + q)) * 64 + lane] = acc[i][j][q];
+        for (int q = 0; q < 4; ++q) red[((i * 3 + slot) * 4 * NJ + j * 4 + q) * 64 + lane] = acc[i][j][q];
     }
   }
   __syncthreads();
@@ -79,13 +83,13 @@ __global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __rest
   for (int i = 0; i < 4; ++i) {
     if (i == wave) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         double* o = xg + (size_t)(c0 + 16 * j + r) * DP + d0 + 16 * i + (lane >> 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           double v = acc[i][j][q];
 #pragma unroll
-          for (int sl = 0; sl < 3; ++sl) v += red[((i * 48) + (sl * 16 + j * 4 + q)) * 64 + lane];
+          for (int sl = 0; sl < 3; ++sl) v += red[((i * 3 + sl) * 4 * NJ + j * 4 + q) * 64 + lane];
           o[4 * q] = -v;
         }
       }
@@ -95,9 +99,17 @@ __global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __rest
 
 hipError_t launch_dense_grad(const double* A, const double* xq, double* xg, int DP, int D, int Cpad, const int* done, int C,
                              hipStream_t st) {
-  const int tiles_d = DP / 64, tiles_c = Cpad / 64, T = tiles_d * tiles_c, per = (T + 7) / 8;
   const int Kr = (D + 15) / 16 * 16;
-  hipLaunchKernelGGL(wn_dense_grad_kernel, dim3(8 * per), dim3(256), 0, st, A, xq, xg, DP, Kr, tiles_d, tiles_c, done, C);
+  const int tiles_d = DP / 64;
+  static const int narrow_env = getenv("WN_GEMM_NJ") ? atoi(getenv("WN_GEMM_NJ")) : 0;  // diagnostic override
+  const bool narrow = narrow_env ? narrow_env == 2 : (tiles_d * (Cpad / 64) < 256);
+  if (narrow) {
+    const int tiles_c = Cpad / 32, T = tiles_d * tiles_c, per = (T + 7) / 8;
+    hipLaunchKernelGGL(wn_dense_grad_kernel<2>, dim3(8 * per), dim3(256), 0, st, A, xq, xg, DP, Kr, tiles_d, tiles_c, done, C);
+  } else {
+    const int tiles_c = Cpad / 64, T = tiles_d * tiles_c, per = (T + 7) / 8;
+    hipLaunchKernelGGL(wn_dense_grad_kernel<4>, dim3(8 * per), dim3(256), 0, st, A, xq, xg, DP, Kr, tiles_d, tiles_c, done, C);
+  }
   return hipGetLastError();
 }
 
