@@ -82,3 +82,22 @@ def test_deep_trees_in_wave_and_split(wa, layout):
         o = ol.walnuts(tk, q0[k], integrator=ol.I_FIXED, tpar=tpar, H0=0.01, numIter=2, M=10, seed=SEED, chain=5 + k)
         np.testing.assert_array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]])
         close(s[k], o["samples"], what=f"{layout} chain {k}")
+
+
+def test_headline_config_full_size_spot_check(wa):
+    """BASELINE config 2 at its full size (4096 chains, 100-D kappa = 1e4 dense Gaussian, fixedLeapFrog, M = 10, H0 = 0.5):
+    32 chains spread over the launch, three iterations each, against the oracle chain by chain."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_dense_problem, SEED as BSEED
+    C, D = 4096, 100
+    A, q0 = make_dense_problem(D, 1e4, C, BSEED)
+    e = wa.Engine(D, C, integrator=ol.I_FIXED, H0=0.5, M=10).set_target(ol.T_DENSEGAUSS, A)
+    s, d = e.run(q0, BSEED, 3)
+    s = s.transpose(1, 2).cpu().numpy(); d = d.cpu().numpy(); e.close()
+    rng = np.random.default_rng(0)
+    for k in sorted(set(rng.integers(0, C, size=30).tolist() + [0, C - 1])):
+        o = ol.walnuts(ol.T_DENSEGAUSS, q0[k], integrator=ol.I_FIXED, tpar=A.ravel(), H0=0.5, numIter=3, M=10, seed=BSEED, chain=k)
+        np.testing.assert_array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]], err_msg=f"chain {k}")
+        close(s[k], o["samples"], what=f"chain {k}")
+        close(d[k], o["diagnostics"], what=f"diagnostics chain {k}")
