@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 2
+#define WN_ABI_VERSION 3
 #define WN_NDIAG 24      /* diagnostics columns, WALNUTSpy/WALNUTS.py:670-693 */
 #define WN_TRACE_NSCAL 12 /* trace row = 12 scalars + q[D] + v[D] */
 
@@ -160,7 +160,7 @@ int wn_run_orbit_stats(wn_engine *e, const double *q0_dev, uint64_t seed, int32_
  * integrator(q,v,g,Ham0,h,xi,lpFun,delta,auxPar) -> integratorReturn
  * (adaptiveIntegrators.py:17-29,49,65,361).  Arrays are [B][D] / [B]; u_r2p_dev holds the
  * uniform R2P consumes (adaptiveIntegrators.py:392).  iout_dev [B][5] = nEvalF,nEvalB,If,Ib,c;
- * dout_dev [B][3] = lp, lwt, H1 (Hamiltonian of the returned state).  Uses cfg->integrator,
+ * dout_dev [B][4] = lp, lwt, H1 (Hamiltonian of the returned state), igrConst.  Uses cfg->integrator,
  * delta0, min_c, max_c, r2p_prob0; B must equal cfg->n_chains. */
 int wn_integrator_step(wn_engine *e, const double *q_dev, const double *v_dev, const double *g_dev,
                        const double *ham0_dev, const double *h_dev, const int32_t *xi_dev,

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _VARIANT = os.environ.get("WN_LIB", "")
 LIB_PATH = os.path.join(_HERE, f"libwalnuts_amd_{_VARIANT}.so" if _VARIANT else "libwalnuts_amd.so")
 
-WN_ABI_VERSION = 2
+WN_ABI_VERSION = 3
 NDIAG = 24
 TRACE_NSCAL = 12
 

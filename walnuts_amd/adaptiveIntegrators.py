@@ -44,11 +44,7 @@ class DeviceIntegrator:
                    R2Pprob0=auxPar.R2Pprob0).set_target(lpFun.kind, lpFun.params)
         q1, v1, g1, io, do = e.integrator_step(q, v, g, [Ham0], [h], [xi], [u_r2p])
         io = io.cpu().numpy()[0]; do = do.cpu().numpy()[0]
-        H1 = do[2]
-        if self.kind == L.I_FIXED:  # adaptiveIntegrators.py:59
-            igr = h * max(1.0e-10, abs(Ham0 - H1)) ** (-1.0 / 3.0)
-        else:
-            igr = float("nan")  # only used by warm-up adaptation
+        igr = float(do[3])  # adaptiveIntegrators.py:59 / 101 / 399 / 424 / 300
         out = integratorReturn(q1.cpu().numpy()[0], v1.cpu().numpy()[0], float(do[0]), g1.cpu().numpy()[0],
                                int(io[0]), int(io[1]), int(io[2]), int(io[3]), int(io[4]), float(do[1]), igr)
         e.close()

@@ -735,6 +735,8 @@ int wn_integrator_step(wn_engine* e, const double* q_dev, const double* v_dev, c
   fill_params(e, &p);
   p.mode = MODE_KAT;
   p.numIter = 0;
+  p.warmupIter = 1;  // the instantiation that tracks igrConst; no adaptation runs in this mode
+  if (!p.facs) p.adaptDelta = 0;
   p.kq = q_dev; p.kv = v_dev; p.kg = g_dev; p.kham0 = ham0_dev; p.kh = h_dev; p.kxi = xi_dev;
   p.ku_r2p = u_r2p_dev; p.kq1 = q1_dev; p.kv1 = v1_dev; p.kg1 = g1_dev; p.kiout = iout_dev; p.kdout = dout_dev;
   return launch(e, p, (hipStream_t)stream, false);

@@ -1387,8 +1387,11 @@ struct Engine : ChainScalars {
     if (p.writer()) {
       int* io = prm.kiout + (size_t)cl * 5;
       io[0] = nEvF; io[1] = nEvB; io[2] = If; io[3] = Ib; io[4] = cret;
-      double* dd = prm.kdout + (size_t)cl * 3;
+      double* dd = prm.kdout + (size_t)cl * 4;
       dd[0] = lpn; dd[1] = lwt; dd[2] = Hn;
+      // igrConst (adaptiveIntegrators.py:59 / 101 / 399 / 424 / 300); the adaptive form needs the WARM
+      // instantiation, which tracks max|diff(Hams)| of the accepted pass
+      dd[3] = ADAPT ? (WARM ? igrOut : NAN) : h * pow(fmax(1.0e-10, fabs(Ham0 - Hn)), -1.0 / 3.0);
     }
     fin = false;
     live = false;

@@ -165,7 +165,7 @@ class Engine:
         u = self._dev(u_r2p if u_r2p is not None else np.zeros(B)).reshape(B)
         q1 = torch.empty_like(q); v1 = torch.empty_like(q); g1 = torch.empty_like(q)
         io = torch.zeros((B, 5), dtype=torch.int32, device=self.device)
-        do = torch.zeros((B, 3), dtype=torch.float64, device=self.device)
+        do = torch.zeros((B, 4), dtype=torch.float64, device=self.device)
         P = lambda t: C.c_void_p(t.data_ptr())
         self._check(self.lib.wn_integrator_step(self.h, P(q), P(v), P(g), P(Ham0), P(h), P(xi), P(u),
                                                 P(q1), P(v1), P(g1), P(io), P(do), self._stream()))
