@@ -8,7 +8,7 @@ from test_gpu_parity import SEED, close, dense_problem, wa  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
-DIMS_DIAG = [1, 4, 5, 24, 25, 64, 65, 128, 129, 256, 257, 512, 513, 1024]
+DIMS_DIAG = [1, 4, 5, 24, 25, 64, 65, 128, 129, 256, 257, 512, 513, 1024, 1025, 2048, 4096]
 DIMS_DENSE = [2, 16, 17, 64, 100, 101, 128, 129, 500]
 INTEG = [ol.I_FIXED, ol.I_ADAPT_D, ol.I_ADAPT_R2P, ol.I_ADAPT_YOSHIDA, ol.I_ADAPT_FLOWD]
 
@@ -42,7 +42,7 @@ def test_dense_gaussian_every_layout_seam(wa, D):
 
 def test_unsupported_sizes_fail_loudly(wa):
     with pytest.raises(NotImplementedError):
-        wa.Engine(1025, 2).set_target(ol.T_STDGAUSS)
+        wa.Engine(4097, 2).set_target(ol.T_STDGAUSS)
     with pytest.raises(NotImplementedError):
         wa.Engine(1030, 2).set_target(ol.T_DENSEGAUSS, np.eye(1030).ravel())
     with pytest.raises(ValueError):

@@ -84,6 +84,14 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, Kernel
       else if (ks <= 32) { KS = 32; NT = 2; }
       else if (ks <= 64) { KS = 64; NT = 4; }
     }
+    if (!KS && D > 1024 && D <= 4096 && target != T_DENSEGAUSS) {
+      // std / diagonal Gaussian, 1024 < D <= 4096: four waves per chain (the reference's Gaussian scaling
+      // scripts go on to 2^18, which needs vectors streamed from memory instead of held in registers: next)
+      kc->layout = 2; kc->p0 = 64; kc->p1 = T_DIAGGAUSS; kc->W = 4;
+      snprintf(nm, 64, "wn_wave_kernel<NE=16,W=4,diag>");
+      kc->name = nm;
+      return 0;
+    }
     if (!KS && D <= 1024) {
       // one chain per wavefront (wn_policy_wave.h): fused std / diagonal Gaussian, or the dense
       // Gaussian with its gradient from the batched MFMA kernel between chain-kernel launches

@@ -34,6 +34,7 @@ static hipError_t go(int adapt, bool warm, const Params& prm, hipStream_t st) {
 }
 
 size_t wave_work_doubles(int NE, int C, int M) {
+  if (NE == 64) return WavePolicy<16, WTgtDiag<16, 256>, 4>::work_doubles(C, M);  // four waves per chain, D <= 4096
   if (NE == 1) return WavePolicy<1, WTgtFunnel10>::work_doubles(C, M);
   if (NE == 12) return WavePolicy<12, WTgtDiag<12>>::work_doubles(C, M);
   return NE <= 8 ? WavePolicy<8, WTgtDiag<8>>::work_doubles(C, M) : WavePolicy<16, WTgtDiag<16>>::work_doubles(C, M);
@@ -43,6 +44,7 @@ hipError_t launch_wave(const KernelChoice& kc, int adapt, bool warm, const Param
   if (kc.p1 == T_DIAGGAUSS || kc.p1 == T_STDGAUSS) {
     if (kc.p0 == 8) return go<8, WTgtDiag<8>>(adapt, warm, prm, st);
     if (kc.p0 == 16) return go<16, WTgtDiag<16>>(adapt, warm, prm, st);
+    if (kc.p0 == 64) return go<16, WTgtDiag<16, 256>, 4>(adapt, warm, prm, st);  // DP / 64 = 64: four waves per chain
   }
   if (kc.p1 == T_FUNNEL10 && kc.p0 == 1) return go<1, WTgtFunnel10>(adapt, warm, prm, st);
   // (four waves per chain were tried for StockWatson: 4.43 -> 4.08 us per tick at 256 chains, 2.2x slower
