@@ -143,6 +143,22 @@ def test_external_batched_callable_matches_fused_target(wa):
     np.testing.assert_array_equal(d1[:, :, [6, 7, 19, 20]], d0[:, :, [6, 7, 19, 20]])
 
 
+def test_funnel10rescaled_batched_target(wa):
+    """targetDistr.funnel10rescaled (targetDistr.py:81-86) is a batched device callable: the same chain through
+    the host-callable path with the formula written in NumPy gives the same draws."""
+    from walnuts_amd import adaptiveIntegrators as ai, targetDistr as td
+    S = np.ones(11); S[0] = 3.0
+    def ref(q, hessian=False):
+        lp, g = ol.lpfun(ol.T_FUNNEL10, S * q)
+        return [lp, S * g]
+    q0 = np.random.default_rng(6).normal(size=(2, 11)) * 0.3
+    kw = dict(integrator=ai.adaptLeapFrogD, H0=0.3, delta0=0.1, numIter=6, warmupIter=0, M=6, seed=9)
+    s1, d1 = wa.WALNUTS(td.funnel10rescaled, q0, **kw)
+    s2, d2 = wa.WALNUTS(ref, q0, **kw)
+    close(s1, s2, what="funnel10rescaled torch vs numpy callable")
+    np.testing.assert_array_equal(d1[:, :, [6, 7, 19, 20]], d2[:, :, [6, 7, 19, 20]])
+
+
 def test_external_host_callable_is_the_reference_plugin_contract(wa):
     """A plain per-chain callable lpFun(q) -> [lp, grad] (targetDistr.py:18) drives the sampler: with
     the oracle's funnel10 as that callable the chains must reproduce the oracle's own run."""

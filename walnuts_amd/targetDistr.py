@@ -78,6 +78,30 @@ funnel10 = DeviceTarget("funnel10", L.T_FUNNEL10, 11)          # targetDistr.py:
 funnel1 = DeviceTarget("funnel1", L.T_FUNNEL1, 2)              # targetDistr.py:88-93
 
 
+modFunnelH = modFunnel  # targetDistr.py:53-54 with hessian=False (Hessians are used by integrators outside the path)
+
+
+def _funnel10rescaled(q):
+    """targetDistr.py:81-86: funnel10 in the coordinates qb = S*q, S = (3, 1, ..., 1); batched torch form
+    (split mode: evaluated for all chains between chain-kernel launches)."""
+    import math
+    import torch
+    S = torch.ones(11, dtype=q.dtype, device=q.device); S[0] = 3.0
+    qb = q * S
+    q0 = qb[:, 0]
+    emq = torch.exp(-q0)
+    ss = (qb[:, 1:] * qb[:, 1:]).sum(dim=1)
+    logC = 0.5 * math.log(2.0 * math.pi)
+    lp = (-(q0 * q0) / 18.0 - logC - math.log(3.0)) + (-0.5 * emq * ss - 10.0 * logC - 5.0 * q0)
+    g = torch.empty_like(qb)
+    g[:, 0] = -5.0 - q0 / 9.0 + 0.5 * emq * ss
+    g[:, 1:] = -qb[:, 1:] * emq[:, None]
+    return lp, g * S
+
+
+funnel10rescaled = BatchedTarget(_funnel10rescaled, 11, "funnel10rescaled")  # targetDistr.py:81-86
+
+
 def denseGauss(A):
     """lp = -1/2 q'Aq, grad = -Aq for a symmetric precision matrix A (cfg 2/4)."""
     A = np.asarray(A, dtype=np.float64) if not hasattr(A, "data_ptr") else A
