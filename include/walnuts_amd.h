@@ -39,10 +39,10 @@ enum {
 /* target plugin lpFun(q) -> [lp, grad]  (WALNUTSpy/targetDistr.py; adaptiveIntegrators.py passes
  * it as `lpFun`).  On the device the plugin is an enum + parameter buffer. */
 enum {
-  WN_T_STDGAUSS = 0,   /* targetDistr.py:18-21 (D <= 4096) */
+  WN_T_STDGAUSS = 0,   /* targetDistr.py:18-21 (D <= 262144; beyond 4096: n_chains * ceil(D/4096) <= 256) */
   WN_T_FUNNEL10 = 1,   /* targetDistr.py:74-78 (D = 11) */
   WN_T_DENSEGAUSS = 2, /* lp = -1/2 q'Aq, grad = -Aq; params = A row-major D*D, D <= 1024 (SURVEY.md 8d cfg 2/4) */
-  WN_T_DIAGGAUSS = 3,  /* params = diag(A), D <= 4096 (SURVEY.md 8d cfg 2 diagonal variant) */
+  WN_T_DIAGGAUSS = 3,  /* params = diag(A), D <= 262144 as for WN_T_STDGAUSS (SURVEY.md 8d cfg 2 diagonal variant) */
   WN_T_CORRGAUSS = 4,  /* targetDistr.py:25-31 (D = 2) */
   WN_T_SMILE = 5,      /* targetDistr.py:34-38 (D = 2) */
   WN_T_FUNNEL1 = 6,    /* targetDistr.py:88-93 (D = 2) */

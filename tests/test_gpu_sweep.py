@@ -42,7 +42,9 @@ def test_dense_gaussian_every_layout_seam(wa, D):
 
 def test_unsupported_sizes_fail_loudly(wa):
     with pytest.raises(NotImplementedError):
-        wa.Engine(4097, 2).set_target(ol.T_STDGAUSS)
+        wa.Engine(262145, 1).set_target(ol.T_STDGAUSS)
+    with pytest.raises(NotImplementedError):  # the cluster of a chain must be resident: n_chains * ceil(D/4096) <= CUs
+        wa.Engine(100000, 64).set_target(ol.T_STDGAUSS)
     with pytest.raises(NotImplementedError):
         wa.Engine(1030, 2).set_target(ol.T_DENSEGAUSS, np.eye(1030).ravel())
     with pytest.raises(ValueError):
@@ -101,3 +103,21 @@ def test_headline_config_full_size_spot_check(wa):
         np.testing.assert_array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]], err_msg=f"chain {k}")
         close(s[k], o["samples"], what=f"chain {k}")
         close(d[k], o["diagnostics"], what=f"diagnostics chain {k}")
+
+
+@pytest.mark.parametrize("D,ig", [(5000, ol.I_FIXED), (9000, ol.I_ADAPT_R2P), (20000, ol.I_ADAPT_D), (70000, ol.I_FIXED)])
+def test_cluster_layout_huge_gaussians(wa, D, ig):
+    """D > 4096 (the reference's Gaussian scaling scripts go to 2^18): a cluster of ceil(D/4096) workgroups per
+    chain, vectors in registers, reductions across workgroups through global memory."""
+    rng = np.random.default_rng(D)
+    q0 = rng.normal(size=(2, D))
+    H0 = 1.4 * D ** -0.25
+    e = wa.Engine(D, 2, integrator=ig, H0=H0, delta0=0.3, M=5, generated=ol.G_Q0_SUMSQ, chain_offset=21).set_target(ol.T_STDGAUSS)
+    assert "cluster" in e.kernel_name
+    s, d = e.run(q0, SEED, 3)
+    s = s.transpose(1, 2).cpu().numpy(); d = d.cpu().numpy(); e.close()
+    for k in (0, 1):
+        o = ol.walnuts(ol.T_STDGAUSS, q0[k], integrator=ig, H0=H0, delta0=0.3, numIter=3, M=5, seed=SEED, chain=21 + k,
+                       generated=ol.G_Q0_SUMSQ)
+        np.testing.assert_array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]])
+        close(s[k], o["samples"], what=f"D={D} chain {k}")

@@ -35,6 +35,7 @@ static int lane_dmax(int target, int D) {
 }
 
 int choose_kernel(int target, int D, int waves_per_group, int integrator, KernelChoice* kc) {
+  kc->G = 1;
   const bool flow = integrator == I_ADAPT_FLOWD;  // no cooperative-layout kernels: its gradient holds barriers
   static char names[8][64];
   static int slot = 0;
@@ -84,9 +85,17 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, Kernel
       else if (ks <= 32) { KS = 32; NT = 2; }
       else if (ks <= 64) { KS = 64; NT = 4; }
     }
+    if (!KS && D > 4096 && D <= 64 * 4096 && target != T_DENSEGAUSS) {
+      // std / diagonal Gaussian up to D = 2^18 (the range of the reference's Gaussian scaling scripts,
+      // mainGaussESS.py:20): a cluster of ceil(D/4096) workgroups per chain keeps the chain's vectors in
+      // registers; only the partial sums of the reductions cross workgroups
+      kc->layout = 2; kc->p0 = 64; kc->p1 = T_DIAGGAUSS; kc->W = 4; kc->G = (D + 4095) / 4096;
+      snprintf(nm, 64, "wn_wave_kernel<NE=16,W=4,diag,cluster=%d>", kc->G);
+      kc->name = nm;
+      return 0;
+    }
     if (!KS && D > 1024 && D <= 4096 && target != T_DENSEGAUSS) {
-      // std / diagonal Gaussian, 1024 < D <= 4096: four waves per chain (the reference's Gaussian scaling
-      // scripts go on to 2^18, which needs vectors streamed from memory instead of held in registers: next)
+      // std / diagonal Gaussian, 1024 < D <= 4096: four waves per chain
       kc->layout = 2; kc->p0 = 64; kc->p1 = T_DIAGGAUSS; kc->W = 4;
       snprintf(nm, 64, "wn_wave_kernel<NE=16,W=4,diag>");
       kc->name = nm;
@@ -119,7 +128,7 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, Kernel
 
 size_t kernel_work_doubles(const KernelChoice& kc, int C, int M) {
   if (kc.layout == 0) return lane_work_doubles(kc.p0, C, M);
-  if (kc.layout == 2) return wave_work_doubles(kc.p0, C, M);
+  if (kc.layout == 2) return wave_work_doubles(kc.p0, C, M, kc.G);
   if (kc.layout == 3) return split_work_doubles(kc.p0, C, M);
   const int NT = kc.p0 <= 16 ? 1 : kc.p0 <= 32 ? 2 : 4;
   return coop_work_doubles(NT, kc.W, C, M);
@@ -366,6 +375,9 @@ struct wn_engine {
   // exchange buffers [Cpad][DP], [Cpad], finished-chain counter, parameters of the run in flight
   double *apad = nullptr, *xq = nullptr, *xg = nullptr;
   int* sp_done = nullptr;
+  // cluster layout: partial sums [C][2][G][8], arrival counters [C] followed by the abort flag
+  double* cl_red = nullptr;
+  unsigned* cl_cnt = nullptr;
   int DP = 0, Cpad = 0;
   Params sp_prm{};
   bool sp_active = false;
@@ -436,6 +448,8 @@ int wn_destroy(wn_engine* e) {
   if (e->xq) hipFree(e->xq);
   if (e->xg) hipFree(e->xg);
   if (e->sp_done) hipFree(e->sp_done);
+  if (e->cl_red) hipFree(e->cl_red);
+  if (e->cl_cnt) hipFree(e->cl_cnt);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   delete e;
@@ -481,12 +495,27 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
   e->work_doubles = kernel_work_doubles(kc, e->cfg.n_chains, e->cfg.M);
   HIPCHK(e, hipMalloc((void**)&e->work, e->work_doubles * sizeof(double)));
   HIPCHK(e, hipMemset(e->work, 0, e->work_doubles * sizeof(double)));
-  if (e->cfg.warmup_iter > 0 && !e->facs)
-    HIPCHK(e, hipMalloc((void**)&e->facs, (size_t)e->cfg.n_chains * 2 * e->cfg.warmup_iter * sizeof(double)));
+  if (e->facs) { hipFree(e->facs); e->facs = nullptr; }
+  if (e->cfg.warmup_iter > 0)  // one sorted copy per chain (per workgroup of a cluster: every replica keeps its own)
+    HIPCHK(e, hipMalloc((void**)&e->facs, (size_t)e->cfg.n_chains * kc.G * 2 * e->cfg.warmup_iter * sizeof(double)));
   if (e->apad) { hipFree(e->apad); e->apad = nullptr; }
   if (e->xq) { hipFree(e->xq); e->xq = nullptr; }
   if (e->xg) { hipFree(e->xg); e->xg = nullptr; }
   e->sp_active = false;
+  if (e->cl_red) { hipFree(e->cl_red); e->cl_red = nullptr; }
+  if (e->cl_cnt) { hipFree(e->cl_cnt); e->cl_cnt = nullptr; }
+  if (kc.G > 1) {
+    // every workgroup of a chain spins on its siblings: the whole grid must be resident (one 4-wave
+    // workgroup of 512-register waves per CU)
+    hipDeviceProp_t prop;
+    HIPCHK(e, hipGetDeviceProperties(&prop, e->cfg.device));
+    if ((long long)e->cfg.n_chains * kc.G > prop.multiProcessorCount) {
+      e->err = "cluster layout: n_chains * ceil(dim / 4096) must not exceed the number of CUs; run fewer chains per call";
+      return WN_E_UNSUPPORTED;
+    }
+    HIPCHK(e, hipMalloc((void**)&e->cl_red, (size_t)e->cfg.n_chains * 2 * kc.G * 8 * sizeof(double)));
+    HIPCHK(e, hipMalloc((void**)&e->cl_cnt, ((size_t)e->cfg.n_chains + 16) * sizeof(unsigned)));
+  }
   if (kc.layout == 3) {
     e->DP = 64 * kc.p0;
     e->Cpad = (e->cfg.n_chains + 63) / 64 * 64;
@@ -609,10 +638,22 @@ static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
     if (timed) { HIPCHK(e, hipEventRecord(e->ev1, st)); e->timed = true; }
     return WN_OK;
   }
-  hipError_t r = e->kc.layout == 0 ? launch_lane(e->kc, adapt, warm, p, st)
-               : e->kc.layout == 1 ? launch_coop(e->kc, adapt, warm, p, st) : launch_wave(e->kc, adapt, warm, p, st);
+  Params pc = p;
+  if (e->kc.G > 1) {
+    pc.cl_g = e->kc.G; pc.cl_red = e->cl_red; pc.cl_cnt = e->cl_cnt; pc.cl_abort = (int*)(e->cl_cnt + e->cfg.n_chains);
+    HIPCHK(e, hipMemsetAsync(e->cl_cnt, 0, ((size_t)e->cfg.n_chains + 16) * sizeof(unsigned), st));
+  }
+  const Params& p_ = pc;
+  hipError_t r = e->kc.layout == 0 ? launch_lane(e->kc, adapt, warm, p_, st)
+               : e->kc.layout == 1 ? launch_coop(e->kc, adapt, warm, p_, st) : launch_wave(e->kc, adapt, warm, p_, st);
   if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
   if (timed) { HIPCHK(e, hipEventRecord(e->ev1, st)); e->timed = true; }
+  if (e->kc.G > 1) {  // a cluster run reports a spin that gave up instead of returning unreduced sums
+    int ab = 0;
+    HIPCHK(e, hipMemcpyAsync(&ab, pc.cl_abort, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    if (ab) { e->err = "cluster layout: a cross-workgroup reduction timed out (workgroups not co-resident?)"; return WN_E_HIP; }
+  }
   return WN_OK;
 }
 

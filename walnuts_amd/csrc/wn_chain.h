@@ -72,6 +72,11 @@ struct Params {
   double *xq, *xg;
   const double* xlp;
   int* sp_done;
+  // cluster layout (several workgroups per chain): workgroups per chain, partials, arrival counters, abort flag
+  int cl_g;
+  double* cl_red;
+  unsigned* cl_cnt;
+  int* cl_abort;
   unsigned long long* stamps;  // diagnostic builds (-DWN_STAMPS): [block][wave][8] cycles per phase
 };
 
@@ -826,8 +831,8 @@ struct Engine : ChainScalars {
     if (prm.adaptDelta) {
       const int n0 = iter - 1;  // values stored so far
       const size_t W_ = (size_t)prm.warmupIter;
-      const double* cur = prm.facs + ((size_t)p.chain_local() * 2 + (size_t)(n0 & 1)) * W_;
-      double* nxt = prm.facs + ((size_t)p.chain_local() * 2 + (size_t)((n0 + 1) & 1)) * W_;
+      const double* cur = prm.facs + ((size_t)p.facs_slot() * 2 + (size_t)(n0 & 1)) * W_;
+      double* nxt = prm.facs + ((size_t)p.facs_slot() * 2 + (size_t)((n0 + 1) & 1)) * W_;
       const double x = orbitEnergyError / dc;  // :704
       // position of x in the sorted array (NaNs sort last): number of elements that stay before it
       int lo = 0, hi = n0;
@@ -852,7 +857,7 @@ struct Engine : ChainScalars {
         }
         dc = prm.adaptDeltaTarget / res;
       }
-      if (p.writer()) {  // extend the sorted copy into the other buffer
+      if (p.wg_writer()) {  // extend the sorted copy into the other buffer
         for (int r = 0; r < pos; ++r) nxt[r] = cur[r];
         nxt[pos] = x;
         for (int r = pos; r < n0; ++r) nxt[r + 1] = cur[r];

@@ -6,35 +6,35 @@
 
 namespace wn {
 
-template <int NE, class Tgt, bool ADAPT, bool WARM, bool FLOW = false, int W = 1>
+template <int NE, class Tgt, bool ADAPT, bool WARM, bool FLOW = false, int W = 1, bool CL = false>
 __global__ __launch_bounds__(64 * W) void wn_wave_kernel(Params prm) {
-  using P = WavePolicy<NE, Tgt, W>;
+  using P = WavePolicy<NE, Tgt, W, CL>;
   __shared__ double lds[P::LDS_DOUBLES > 0 ? P::LDS_DOUBLES : 1];
   P p(prm, blockIdx.x, lds);
   Engine<P, ADAPT, WARM, FLOW> eng(p, prm);
   eng.run();
 }
 
-template <int NE, class Tgt, int W = 1>
+template <int NE, class Tgt, int W = 1, bool CL = false>
 static hipError_t go(int adapt, bool warm, const Params& prm, hipStream_t st) {
-  dim3 grid(prm.C), block(64 * W);
+  dim3 grid(CL ? prm.C * prm.cl_g : prm.C), block(64 * W);
   if (adapt == 2) {  // adaptLeapFrogFlowD
-    if (warm) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, true, true, W>), grid, block, 0, st, prm);
-    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false, true, W>), grid, block, 0, st, prm);
+    if (warm) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, true, true, W, CL>), grid, block, 0, st, prm);
+    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false, true, W, CL>), grid, block, 0, st, prm);
     return hipGetLastError();
   }
   if (warm) {
-    if (adapt) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, true, false, W>), grid, block, 0, st, prm);
-    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, false, true, false, W>), grid, block, 0, st, prm);
+    if (adapt) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, true, false, W, CL>), grid, block, 0, st, prm);
+    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, false, true, false, W, CL>), grid, block, 0, st, prm);
   } else {
-    if (adapt) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false, false, W>), grid, block, 0, st, prm);
-    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, false, false, false, W>), grid, block, 0, st, prm);
+    if (adapt) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false, false, W, CL>), grid, block, 0, st, prm);
+    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, false, false, false, W, CL>), grid, block, 0, st, prm);
   }
   return hipGetLastError();
 }
 
-size_t wave_work_doubles(int NE, int C, int M) {
-  if (NE == 64) return WavePolicy<16, WTgtDiag<16, 256>, 4>::work_doubles(C, M);  // four waves per chain, D <= 4096
+size_t wave_work_doubles(int NE, int C, int M, int G) {
+  if (NE == 64) return WavePolicy<16, WTgtDiag<16, 256>, 4>::work_doubles(C, M, G);  // four waves per workgroup, D <= 4096 * G
   if (NE == 1) return WavePolicy<1, WTgtFunnel10>::work_doubles(C, M);
   if (NE == 12) return WavePolicy<12, WTgtDiag<12>>::work_doubles(C, M);
   return NE <= 8 ? WavePolicy<8, WTgtDiag<8>>::work_doubles(C, M) : WavePolicy<16, WTgtDiag<16>>::work_doubles(C, M);
@@ -44,6 +44,7 @@ hipError_t launch_wave(const KernelChoice& kc, int adapt, bool warm, const Param
   if (kc.p1 == T_DIAGGAUSS || kc.p1 == T_STDGAUSS) {
     if (kc.p0 == 8) return go<8, WTgtDiag<8>>(adapt, warm, prm, st);
     if (kc.p0 == 16) return go<16, WTgtDiag<16>>(adapt, warm, prm, st);
+    if (kc.p0 == 64 && kc.G > 1) return go<16, WTgtDiag<16, 256>, 4, true>(adapt, warm, prm, st);  // cluster of workgroups per chain
     if (kc.p0 == 64) return go<16, WTgtDiag<16, 256>, 4>(adapt, warm, prm, st);  // DP / 64 = 64: four waves per chain
   }
   if (kc.p1 == T_FUNNEL10 && kc.p0 == 1) return go<1, WTgtFunnel10>(adapt, warm, prm, st);

@@ -13,6 +13,7 @@ struct KernelChoice {
   int p0;      // lane: DMAX ; coop: k-steps ; wave: NE
   int p1;      // lane: target kind ; coop: CK_DENSE / CK_DIAG ; wave: target kind ; split: EXT_*
   int W;       // coop: waves per group
+  int G;       // wave layout: workgroups per chain (cluster), 1 otherwise
   const char* name;
 };
 
@@ -26,7 +27,7 @@ hipError_t launch_split_begin(const KernelChoice& kc, int adapt /* 0 fixed, 1 ad
 hipError_t launch_split_tick(const KernelChoice& kc, int adapt /* 0 fixed, 1 adaptive, 2 adaptLeapFrogFlowD */, bool warm, const Params& prm, hipStream_t st);
 hipError_t launch_dense_grad(const double* A, const double* xq, double* xg, int DP, int D, int Cpad, const int* done, int C,
                              hipStream_t st);
-size_t wave_work_doubles(int NE, int C, int M);
+size_t wave_work_doubles(int NE, int C, int M, int G);
 size_t split_work_doubles(int NE, int C, int M);
 
 }  // namespace wn

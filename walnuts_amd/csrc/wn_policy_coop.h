@@ -115,6 +115,8 @@ struct CoopPolicy {
   __device__ __forceinline__ bool valid(int e) const { return gidx(e) < D; }
   __device__ __forceinline__ bool owner(int) const { return true; }
   __device__ __forceinline__ bool writer() const { return wave == 0 && lg == 0; }
+  __device__ __forceinline__ bool wg_writer() const { return wave == 0 && lg == 0; }
+  __device__ __forceinline__ int facs_slot() const { return cl; }
   __device__ __forceinline__ int chain_local() const { return cl; }
   __device__ __forceinline__ uint32_t chain_global() const { return cg; }
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }

@@ -53,6 +53,8 @@ struct LanePolicy {
   WN_HD bool owner(int) const { return true; }
   WN_HD int gidx(int e) const { return e; }
   WN_HD bool writer() const { return true; }
+  WN_HD bool wg_writer() const { return true; }
+  WN_HD int facs_slot() const { return cl; }
   WN_HD int chain_local() const { return cl; }
   WN_HD uint32_t chain_global() const { return cg; }
   WN_HD bool any(bool b) const {

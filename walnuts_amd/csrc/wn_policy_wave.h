@@ -282,7 +282,11 @@ struct WTgtFunnel10 {
 };
 
 // W waves (one workgroup) serve a chain: register e of wave w, lane l holds element (e*W + w)*64 + l.
-template <int NE_, class Tgt, int W_ = 1>
+// CL_: a CLUSTER of workgroups serves a chain -- workgroup `slice` of G holds elements [slice*DP, (slice+1)*DP)
+// in its registers, every workgroup replicates the chain's scalars, and the only exchange is the sum / max
+// of the per-workgroup partials through global memory (cl_exchange).  All G workgroups of a chain must be
+// resident (the launcher checks the grid against the chip) and every spin is bounded.
+template <int NE_, class Tgt, int W_ = 1, bool CL_ = false>
 struct WavePolicy {
   static constexpr int NE = NE_;
   static constexpr int W = W_;
@@ -291,7 +295,8 @@ struct WavePolicy {
   static constexpr int NLC = 0;         // every sub-tree left endpoint lives in the slot store
   static constexpr int ALIGN_LOG2 = 0;  // chains do not share a wave: nothing to align
   static constexpr int NRED = 8;        // widest reduction (wn_chain.h NPB)
-  static constexpr int LDS_DOUBLES = Tgt::LDS_DOUBLES + (W_ > 1 ? 2 * NRED * W_ : 0);
+  static_assert(!CL_ || W_ > 1, "the cluster exchange hands results to the waves through the reduction LDS");
+  static constexpr int LDS_DOUBLES = Tgt::LDS_DOUBLES + (W_ > 1 ? 2 * NRED * W_ : 0) + (CL_ ? NRED + 1 : 0);
   struct Vec {
     double x[NE_];
   };
@@ -300,6 +305,13 @@ struct WavePolicy {
   enum { NPARK = 9 };
 
   int D, cl, lane, wave, l0;
+  int G, slice, goff;      // cluster: workgroups per chain, this one's index, its first element
+  size_t vstride;          // doubles between consecutive vectors of a chain
+  double* cred;            // cluster: partials [chain][2][G][NRED]
+  unsigned* ccnt;          // cluster: arrival counter per chain
+  int* cabort;             // cluster: set when a bounded spin gave up
+  unsigned epoch;
+  bool aborted;
   unsigned long long t_start, t_real;  // diagnostic builds (-DWN_STAMPS)
   uint32_t cg;
   int nslot;
@@ -314,37 +326,90 @@ struct WavePolicy {
   __host__ __device__ static size_t nvec(int M) { return (size_t)(M + 1) * 2 + COLD_N + 4 + WARM_N + NPARK; }
   __host__ __device__ static size_t scalar_doubles() { return (sizeof(ChainScalars) + 63) / 64 * 8; }
   // workspace doubles for C chains: vectors, then parked scalars
-  static size_t work_doubles(int C, int M) { return (size_t)C * (nvec(M) * DP + scalar_doubles()); }
+  static size_t work_doubles(int C, int M, int G = 1) { return (size_t)C * (nvec(M) * DP * G + scalar_doubles()); }
 
-  __device__ WavePolicy(const Params& prm, int chain_local, double* lds = nullptr)
-      : D(prm.D), cl(chain_local), lane(threadIdx.x & 63), wave(W_ > 1 ? (int)(threadIdx.x >> 6) : 0),
-        cg(prm.chain0 + (uint32_t)chain_local), nslot(prm.M + 1), redpar(0) {
+  __device__ WavePolicy(const Params& prm, int block, double* lds = nullptr)
+      : D(prm.D), lane(threadIdx.x & 63), wave(W_ > 1 ? (int)(threadIdx.x >> 6) : 0), nslot(prm.M + 1), redpar(0) {
     t_start = 0; t_real = 0;
 #if defined(WN_STAMPS)
     t_real = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_start)::"memory");
 #endif
+    G = CL_ ? prm.cl_g : 1;
+    cl = CL_ ? block / G : block;
+    slice = CL_ ? block % G : 0;
+    goff = slice * DP;
+    cg = prm.chain0 + (uint32_t)cl;
+    vstride = (size_t)DP * G;
+    cred = prm.cl_red; ccnt = prm.cl_cnt; cabort = prm.cl_abort;
+    epoch = 0; aborted = false;
     l0 = wave * 64 + lane;
     ldsr = lds + Tgt::LDS_DOUBLES;
-    const int c = chain_local < prm.C ? chain_local : 0;
-    vbase = prm.work + (size_t)c * nvec(prm.M) * DP + l0;
-    sc = reinterpret_cast<ChainScalars*>(prm.work + (size_t)prm.C * nvec(prm.M) * DP + (size_t)c * scalar_doubles());
+    const int c = cl < prm.C ? cl : 0;
+    vbase = prm.work + (size_t)c * nvec(prm.M) * vstride + goff + l0;
+    sc = reinterpret_cast<ChainScalars*>(prm.work + (size_t)prm.C * nvec(prm.M) * vstride + (size_t)c * scalar_doubles());
     xq = prm.xq ? prm.xq + (size_t)c * DP + l0 : nullptr;
     xg = prm.xg ? prm.xg + (size_t)c * DP + l0 : nullptr;
     xlp = prm.xlp ? prm.xlp + c : nullptr;
-    tgt.init(prm, l0, lds);
+    tgt.init(prm, goff + l0, lds);
   }
 
-  __device__ __forceinline__ bool valid(int e) const { return e * ES + l0 < D; }
+  __device__ __forceinline__ bool valid(int e) const { return goff + e * ES + l0 < D; }
   __device__ __forceinline__ bool owner(int) const { return true; }
-  __device__ __forceinline__ int gidx(int e) const { return e * ES + l0; }
-  __device__ __forceinline__ bool writer() const { return l0 == 0; }
+  __device__ __forceinline__ int gidx(int e) const { return goff + e * ES + l0; }
+  __device__ __forceinline__ bool writer() const { return l0 == 0 && slice == 0; }
+  // per-workgroup writer and slot of per-chain scratch that every replica recomputes (warm-up quantile store)
+  __device__ __forceinline__ bool wg_writer() const { return l0 == 0; }
+  __device__ __forceinline__ int facs_slot() const { return cl * G + slice; }
   __device__ __forceinline__ int chain_local() const { return cl; }
   __device__ __forceinline__ uint32_t chain_global() const { return cg; }
   // the scalars are replicated: every lane of every wave votes the same, and the vote makes the
   // branch scalar
-  __device__ __forceinline__ bool any(bool b) const { return __any(b); }
-  __device__ __forceinline__ bool majority(bool a, bool) const { return __any(a); }
+  __device__ __forceinline__ bool any(bool b) const { return (CL_ && aborted) ? false : __any(b); }
+  __device__ __forceinline__ bool majority(bool a, bool) const { return any(a); }
+
+  // Cluster step of a reduction: this workgroup's N partials go to global memory (agent-scope 8-byte
+  // stores), one arrival is counted, everybody polls the counter (relaxed agent-scope loads, s_sleep,
+  // bounded), then wave 0 sums / maxes the G partials lane-parallel -- the same order in every workgroup,
+  // so all replicas of the chain get the same bits -- and hands them to the other waves through LDS.
+  // Two parity buffers: a workgroup can overwrite parity p only after the next reduction's wait, which
+  // everybody passes only after having read parity p.
+  template <int N, bool MAXOP>
+  __device__ __forceinline__ void cl_exchange(double* v) {
+    epoch++;
+    double* slot = cred + ((size_t)cl * 2 + (epoch & 1u)) * (size_t)G * NRED;
+    if (l0 == 0) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) __hip_atomic_store(slot + (size_t)slice * NRED + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(ccnt + cl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wave == 0) {
+      const unsigned target = epoch * (unsigned)G;
+      unsigned spins = 0;
+      bool bad = false;
+      while (__hip_atomic_load(ccnt + cl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 22) || __hip_atomic_load(cabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { bad = true; break; }
+      }
+      if (bad) __hip_atomic_store(cabort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      double* lbuf = ldsr + 2 * NRED * W_;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        double x = MAXOP ? -INFINITY : 0.0;
+        if (lane < G && !bad) x = __hip_atomic_load(slot + (size_t)lane * NRED + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = MAXOP ? wavemax(x) : wn_wavesum(x);
+        if (lane == 0) lbuf[k] = x;
+      }
+      if (lane == 0) lbuf[NRED] = bad ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const double* lbuf = ldsr + 2 * NRED * W_;
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = lbuf[k];
+    if (lbuf[NRED] != 0.0) aborted = true;
+    __syncthreads();
+  }
 
   // sum over all lanes serving the chain; every replica gets the same bits.  Two buffers alternate:
   // a wave can reuse a buffer only after the barrier of the next reduction, behind which every wave
@@ -370,6 +435,7 @@ struct WavePolicy {
         v[k] = s;
       }
     }
+    if (CL_) cl_exchange<N, false>(v);
   }
 
   // max over all lanes serving the chain (NaN-free inputs; max is exact, so every replica agrees)
@@ -403,13 +469,14 @@ struct WavePolicy {
         v[k] = s;
       }
     }
+    if (CL_) cl_exchange<N, true>(v);
   }
 
   __device__ __forceinline__ void grad(const Vec& q, Vec& g, double& lp_part) const { lp_part = tgt.grad(q.x, g.x, lane); }
   __device__ __forceinline__ double lp_finish(double r) const { return Tgt::lp_finish(r); }
 
   // ---- memory-resident vectors ------------------------------------------------------------------
-  __device__ __forceinline__ double* vp(int v) const { return vbase + (size_t)v * DP; }
+  __device__ __forceinline__ double* vp(int v) const { return vbase + (size_t)v * vstride; }
   __device__ __forceinline__ void vput(int v, const Vec& x) const {
     double* d = vp(v);
 #pragma unroll
@@ -439,14 +506,14 @@ struct WavePolicy {
     double v = 0.0;
 #pragma unroll
     for (int k = 0; k < NDIAG; ++k) v = l0 == k ? d[k] : v;
-    if (l0 < NDIAG) row[l0] = v;
+    if (l0 < NDIAG && slice == 0) row[l0] = v;
   }
 
   // ---- split mode ---------------------------------------------------------------------------------
   template <int K> __device__ __forceinline__ void park_vec(const Vec& x) const { vput(2 * nslot + COLD_N + 4 + WARM_N + K, x); }
   template <int K> __device__ __forceinline__ void unpark_vec(Vec& x) const { vget(2 * nslot + COLD_N + 4 + WARM_N + K, x); }
   __device__ __forceinline__ double park_partial(double x) { double v[1] = {x}; reduce<1>(v); return v[0]; }
-  __device__ __forceinline__ double unpark_partial(double x) const { return l0 == 0 ? x : 0.0; }
+  __device__ __forceinline__ double unpark_partial(double x) const { return (l0 == 0 && slice == 0) ? x : 0.0; }
   __device__ __forceinline__ void park_scalars(const ChainScalars& s) const { if (l0 == 0) ChainScalars::copy(*sc, s); }
   __device__ __forceinline__ void unpark_scalars(ChainScalars& s) const { ChainScalars::copy(s, *sc); }
   __device__ __forceinline__ void ext_put_q(const Vec& q) const {
