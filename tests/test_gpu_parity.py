@@ -307,7 +307,7 @@ def test_error_paths(wa):
         e.run(np.zeros((4, 5)), 0, 1)  # no target yet
     e.close()
     with pytest.raises(NotImplementedError):
-        wa.Engine(3000, 4).set_target(ol.T_STDGAUSS)
+        wa.Engine(3000, 4).set_target(ol.T_DENSEGAUSS, np.eye(3000).ravel())  # dense Gaussians stop at D = 1024
 
 
 def test_walnuts_api_shapes(wa):
