@@ -121,3 +121,15 @@ def test_cluster_layout_huge_gaussians(wa, D, ig):
                        generated=ol.G_Q0_SUMSQ)
         np.testing.assert_array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]])
         close(s[k], o["samples"], what=f"D={D} chain {k}")
+
+
+def test_gaussian_scaling_script_call_shape(wa):
+    """The call of WALNUTSpy_examples/gaussian/mainGaussESS.py:74-80 at a dimension of its upper range."""
+    from walnuts_amd import adaptiveIntegrators as ai, targetDistr as td
+    d = 2 ** 16
+    q0 = np.random.default_rng(0).normal(size=d)
+    for integ in (ai.fixedLeapFrog, ai.adaptLeapFrogR2P):
+        samples, diagnostics = wa.WALNUTS(td.stdGauss, q0, generated=wa.q0_sumsq, integrator=integ, M=10,
+                                          H0=1.4 * d ** -0.25, numIter=6, warmupIter=0, seed=5)
+        assert samples.shape == (2, 7) and diagnostics.shape == (6, 24)
+        assert abs(samples[1, 1:].mean() / d - 1.0) < 0.02  # sum q^2 ~ chi2_d
