@@ -20,6 +20,10 @@ namespace wn {
 
 struct EmptyVecW {};
 
+#ifndef WN_CL_SLEEP
+#define WN_CL_SLEEP 8  // 64-cycle units between polls of a cluster's arrival counter
+#endif
+
 template <int CTRL>
 __device__ __forceinline__ double wn_dpp(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
@@ -389,7 +393,7 @@ struct WavePolicy {
       unsigned spins = 0;
       bool bad = false;
       while (__hip_atomic_load(ccnt + cl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(WN_CL_SLEEP);
         if (++spins > (1u << 22) || __hip_atomic_load(cabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { bad = true; break; }
       }
       if (bad) __hip_atomic_store(cabort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
