@@ -133,3 +133,15 @@ def test_gaussian_scaling_script_call_shape(wa):
                                           H0=1.4 * d ** -0.25, numIter=6, warmupIter=0, seed=5)
         assert samples.shape == (2, 7) and diagnostics.shape == (6, 24)
         assert abs(samples[1, 1:].mean() / d - 1.0) < 0.02  # sum q^2 ~ chi2_d
+
+
+def test_cluster_chunks_more_chains_than_fit(wa):
+    """C * ceil(D/4096) > 256: WALNUTS() runs the chains in consecutive launches; same draws as one chain at a time."""
+    from walnuts_amd import adaptiveIntegrators as ai, targetDistr as td
+    D, C = 140000, 9  # 35 workgroups per chain: 7 chains per launch
+    q0 = np.random.default_rng(3).normal(size=(C, D))
+    kw = dict(generated=wa.q0_sumsq, integrator=ai.fixedLeapFrog, M=4, H0=1.4 * D ** -0.25, numIter=3, warmupIter=0, seed=8)
+    s, d = wa.WALNUTS(td.stdGauss, q0, **kw)
+    assert s.shape == (C, 2, 4) and d.shape == (C, 3, 24)
+    s1, d1 = wa.WALNUTS(td.stdGauss, q0[8], chain_offset=8, **kw)
+    np.testing.assert_array_equal(s[8], s1); np.testing.assert_array_equal(d[8], d1)

@@ -64,6 +64,21 @@ def WALNUTS(lpFun, q0, generated=identity, integrator=ai.fixedLeapFrog, H0=0.2,
     single = q0a.ndim == 1
     C, D = (1, q0a.shape[0]) if single else q0a.shape
     lpFun.check_dim(D)
+    # Beyond D = 4096 a chain occupies a cluster of ceil(D/4096) workgroups that must all be resident (256 CUs):
+    # more chains than fit run in consecutive launches; the RNG is keyed by the global chain id, so the
+    # result does not depend on the split.
+    if isinstance(lpFun, DeviceTarget) and lpFun.kind in (L.T_STDGAUSS, L.T_DIAGGAUSS) and D > 4096 and not single:
+        per = max(1, 256 // (-(-D // 4096)))
+        if C > per:
+            kw = dict(generated=host_gen if host_gen is not None else generated, integrator=integrator, H0=H0,
+                      stepSizeRandScale=stepSizeRandScale, delta0=delta0, numIter=numIter, warmupIter=warmupIter, M=M,
+                      igrAux=igrAux, adaptH=adaptH, adaptHtarget=adaptHtarget, adaptDelta=adaptDelta,
+                      adaptDeltaTarget=adaptDeltaTarget, adaptDeltaQuantile=adaptDeltaQuantile,
+                      recordOrbitStats=recordOrbitStats, seed=seed, device=device, return_torch=return_torch,
+                      trace_cap=trace_cap)
+            parts = [WALNUTS(lpFun, q0a[lo:lo + per], chain_offset=chain_offset + lo, **kw) for lo in range(0, C, per)]
+            import torch as _t
+            return tuple((_t.cat(list(x)) if return_torch else np.concatenate(list(x))) for x in zip(*parts))
     eng = Engine(D, C, integrator=integrator.kind, H0=H0, stepSizeRandScale=stepSizeRandScale,
                  delta0=delta0, M=M, minC=igrAux.minC, maxC=igrAux.maxC, R2Pprob0=igrAux.R2Pprob0,
                  generated=generated.kind, gen_k=generated.k, warmupIter=warmupIter,
