@@ -145,3 +145,20 @@ def test_cluster_chunks_more_chains_than_fit(wa):
     assert s.shape == (C, 2, 4) and d.shape == (C, 3, 24)
     s1, d1 = wa.WALNUTS(td.stdGauss, q0[8], chain_offset=8, **kw)
     np.testing.assert_array_equal(s[8], s1); np.testing.assert_array_equal(d[8], d1)
+
+
+def test_cluster_layout_warmup(wa):
+    """Warm-up adaptation in the cluster layout: every workgroup of a chain keeps its own sorted quantile store."""
+    D = 9000
+    q0 = np.random.default_rng(4).normal(size=(2, D))
+    H0 = 1.4 * D ** -0.25
+    e = wa.Engine(D, 2, integrator=ol.I_ADAPT_R2P, H0=H0, delta0=0.3, M=5, generated=ol.G_Q0_SUMSQ, chain_offset=2,
+                  warmupIter=12).set_target(ol.T_STDGAUSS)
+    s, d = e.run(q0, SEED, 16)
+    s = s.transpose(1, 2).cpu().numpy(); d = d.cpu().numpy(); e.close()
+    for k in (0, 1):
+        o = ol.walnuts(ol.T_STDGAUSS, q0[k], integrator=ol.I_ADAPT_R2P, H0=H0, delta0=0.3, numIter=16, M=5, seed=SEED,
+                       chain=2 + k, generated=ol.G_Q0_SUMSQ, warmupIter=12)
+        close(d[k][:, [15, 18]], o["diagnostics"][:, [15, 18]], what=f"H/delta chain {k}")
+        np.testing.assert_array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]])
+        close(s[k], o["samples"], what=f"chain {k}")
