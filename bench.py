@@ -404,6 +404,8 @@ def main_funnel(args):
     Roofline per SURVEY 8d: HBM, 48*D = 528 B per gradient evaluation (unfused streaming figure)."""
     import walnuts_amd as wa
     from walnuts_amd import _lib as L
+    if args.iters == 100:
+        args.iters = 300  # SURVEY 8d cfg 3
 
     def make_engine(rank, dev):
         C = args.chains
