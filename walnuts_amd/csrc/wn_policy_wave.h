@@ -50,6 +50,41 @@ __device__ __forceinline__ double wn_wavesum(double x) {
 }
 
 
+template <int CTRL>
+__device__ __forceinline__ double wn_dpp0(double x) {  // out-of-row sources read as zero
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wn_readlane(double x, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+// inclusive prefix sum over the 64 lanes: row_shr 1,2,4,8 inside each row of 16 (DPP: no LDS round trip per
+// step, unlike a shuffle-based Hillis-Steele scan), then the totals of the lower rows through v_readlane
+__device__ __forceinline__ double wn_scan_up(double x, int lane) {
+  x += wn_dpp0<0x111>(x);
+  x += wn_dpp0<0x112>(x);
+  x += wn_dpp0<0x114>(x);
+  x += wn_dpp0<0x118>(x);
+  const double t0 = wn_readlane(x, 15), t1 = wn_readlane(x, 31), t2 = wn_readlane(x, 47);
+  const int row = lane >> 4;
+  const double add = row == 0 ? 0.0 : row == 1 ? t0 : row == 2 ? t0 + t1 : (t0 + t1) + t2;
+  return x + add;
+}
+// inclusive suffix sum (lane l gets the sum over lanes >= l)
+__device__ __forceinline__ double wn_scan_down(double x, int lane) {
+  x += wn_dpp0<0x101>(x);  // row_shl:1
+  x += wn_dpp0<0x102>(x);
+  x += wn_dpp0<0x104>(x);
+  x += wn_dpp0<0x108>(x);
+  const double t1 = wn_readlane(x, 16), t2 = wn_readlane(x, 32), t3 = wn_readlane(x, 48);
+  const int row = lane >> 4;
+  const double add = row == 3 ? 0.0 : row == 2 ? t3 : row == 1 ? t2 + t3 : t1 + (t2 + t3);
+  return x + add;
+}
+
+
 enum { EXT_NONE = 0, EXT_HALF_QG = 1, EXT_LP = 2 };
 
 // lp = -1/2 sum a_i q_i^2, grad = -a_i q_i  (stdGauss, targetDistr.py:18-21, is a == 1)
@@ -90,7 +125,7 @@ struct WTgtExt {
 // The three latent series are cumulative sums over time, so the gradient is evaluated in a
 // time-major mapping -- lane l owns t = 4l+1 .. 4l+4 of every series -- reached from the striped
 // register layout through a 6 KB LDS transpose; forward (z, x, tau) and backward (adjoint) sums are
-// lane-local runs of four plus wave-level Hillis-Steele scans of the lane totals.
+// lane-local runs of four plus DPP wave scans of the lane totals (wn_scan_up / wn_scan_down).
 template <int NE>
 struct WTgtStockWatson {
   static constexpr int EXT = EXT_NONE;
@@ -114,19 +149,9 @@ struct WTgtStockWatson {
     const double o = __shfl_down(v, d);
     return lane + d < 64 ? o : 0.0;
   }
-  // sum of the totals of all lower / higher lanes
-  __device__ __forceinline__ static double excl_below(double tot, int lane) {
-    double v = tot;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) v += shup(v, d, lane);
-    return shup(v, 1, lane);
-  }
-  __device__ __forceinline__ static double excl_above(double tot, int lane) {
-    double v = tot;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) v += shdn(v, d, lane);
-    return shdn(v, 1, lane);
-  }
+  // sum of the totals of all lower / higher lanes: shift by one lane, then an inclusive DPP scan
+  __device__ __forceinline__ static double excl_below(double tot, int lane) { return wn_scan_up(shup(tot, 1, lane), lane); }
+  __device__ __forceinline__ static double excl_above(double tot, int lane) { return wn_scan_down(shdn(tot, 1, lane), lane); }
   __device__ __forceinline__ double grad(const double* q, double* g, int lane) const {
 #pragma unroll
     for (int e = 0; e < NE; ++e) lds[e * 64 + lane] = q[e];
@@ -225,14 +250,14 @@ struct WTgtStockWatson {
     base = excl_above(run, lane);
 #pragma unroll
     for (int k = 0; k < TPL; ++k) CS[k] += base;
-    const double z1 = __shfl(z[0], 0), x1 = __shfl(x[0], 0);
+    const double z1 = wn_readlane(z[0], 0), x1 = wn_readlane(x[0], 0);
 #pragma unroll
     for (int k = 0; k < TPL; ++k) {
       const int t = t0 + k;
       if (t >= 2 && t <= T) dsig += cc[k] * (zprev[k] - z1);
       if (t <= T) dsig += b[k] * (x[k] - x1);
     }
-    dsig = wavesum_(dsig);
+    dsig = wn_wavesum(dsig);
     __builtin_amdgcn_wave_barrier();
     // gradients back to the parameter order, through the LDS transpose
 #pragma unroll
