@@ -1,6 +1,7 @@
 // wn_capi.hip -- the C ABI of include/walnuts_amd.h: engine object, kernel selection, launches.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -75,7 +76,8 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, Kernel
     if (W != 4) return -1;
     const int ks = (D + 3) / 4;
     int KS = 0, NT = 0;
-    if (flow) {
+    static const bool force_wave = getenv("WN_FORCE_WAVE") != nullptr;  // diagnostic: std / diagonal on the wave layout
+    if (flow || (force_wave && target != T_DENSEGAUSS)) {
     } else if (target == T_DENSEGAUSS) {
       if (ks <= 16) { KS = 16; NT = 1; }
       else if (ks <= 25) { KS = 25; NT = 2; }
@@ -83,7 +85,9 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, Kernel
     } else {
       if (ks <= 16) { KS = 16; NT = 1; }
       else if (ks <= 32) { KS = 32; NT = 2; }
-      else if (ks <= 64) { KS = 64; NT = 4; }
+      // 129 <= D <= 256: four tiles per wave fit the register file only for fixedLeapFrog; the adaptive
+      // kernels spill and run 5.5x slower than one chain per wavefront (std 256-D R2P: 6.7e7 vs 3.6e8 evals/s)
+      else if (ks <= 64 && integrator == I_FIXED) { KS = 64; NT = 4; }
     }
     if (!KS && D > 4096 && D <= 64 * 4096 && target != T_DENSEGAUSS) {
       // std / diagonal Gaussian up to D = 2^18 (the range of the reference's Gaussian scaling scripts,
