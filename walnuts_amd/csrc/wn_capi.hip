@@ -41,7 +41,17 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, Kernel
   static char names[8][64];
   static int slot = 0;
   char* nm = names[(slot++) & 7];
+  static const bool force_wave = getenv("WN_FORCE_WAVE") != nullptr;  // diagnostic: std / diagonal Gaussians on the wave layout
   int dm = lane_dmax(target, D);
+  if (force_wave && (target == T_STDGAUSS || target == T_DIAGGAUSS)) dm = 0;
+  // Gaussians leave the one-chain-per-lane layout except for D <= 4 with fixedLeapFrog: the 16-chain MFMA
+  // group kernel is 2-5x faster from D = 10 up and for every adaptive integrator (measured, 4096 chains:
+  // std 16-D fixed 5.4e8 vs 2.4e8, R2P 5.1e8 vs 9.5e7; dense 16-D fixed 7.7e8 vs 1.9e8 evals/s) -- its tick
+  // alignment keeps 16 chains in step, while 64 chains in one wave pay each other's divergent paths
+  static const bool lane_gauss = getenv("WN_LANE_GAUSS") != nullptr;  // diagnostic: the old choice
+  if (!lane_gauss && (target == T_STDGAUSS || target == T_DIAGGAUSS || target == T_DENSEGAUSS) &&
+      !(D <= 4 && integrator == I_FIXED) && !(target == T_DENSEGAUSS && integrator == I_ADAPT_FLOWD))
+    dm = 0;  // (adaptLeapFrogFlowD has no MFMA-group kernel: std / diagonal go one chain per wave, small dense stay per lane)
   if (target == T_FUNNEL10 && integrator != I_FIXED && waves_per_group != 64) {
     // adaptive integrators on the funnel: per-chain work is wildly uneven, one chain per wave (see WTgtFunnel10);
     // waves_per_group = 64 asks for the one-chain-per-lane kernel
@@ -76,7 +86,6 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, Kernel
     if (W != 4) return -1;
     const int ks = (D + 3) / 4;
     int KS = 0, NT = 0;
-    static const bool force_wave = getenv("WN_FORCE_WAVE") != nullptr;  // diagnostic: std / diagonal on the wave layout
     if (flow || (force_wave && target != T_DENSEGAUSS)) {
     } else if (target == T_DENSEGAUSS) {
       if (ks <= 16) { KS = 16; NT = 1; }
