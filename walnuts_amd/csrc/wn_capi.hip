@@ -52,9 +52,10 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, Kernel
   if (!lane_gauss && (target == T_STDGAUSS || target == T_DIAGGAUSS || target == T_DENSEGAUSS) &&
       !(D <= 4 && integrator == I_FIXED) && !(target == T_DENSEGAUSS && integrator == I_ADAPT_FLOWD))
     dm = 0;  // (adaptLeapFrogFlowD has no MFMA-group kernel: std / diagonal go one chain per wave, small dense stay per lane)
-  if (target == T_FUNNEL10 && integrator != I_FIXED && waves_per_group != 64) {
-    // adaptive integrators on the funnel: per-chain work is wildly uneven, one chain per wave (see WTgtFunnel10);
-    // waves_per_group = 64 asks for the one-chain-per-lane kernel
+  if (target == T_FUNNEL10 && waves_per_group != 64) {
+    // per-chain work on the funnel is wildly uneven: one chain per wave (see WTgtFunnel10; measured at 4096 chains:
+    // R2P 7.1e7 vs 4.5e7, fixedLeapFrog 1.6e8 vs 1.2e8 evaluations/s); waves_per_group = 64 asks for the
+    // one-chain-per-lane kernel
     kc->layout = 2; kc->p0 = 1; kc->p1 = T_FUNNEL10; kc->W = 1;
     snprintf(nm, 64, "wn_wave_kernel<NE=1,funnel10>");
     kc->name = nm;
