@@ -96,7 +96,8 @@ typedef struct wn_config {
   int32_t generated;   /* WN_G_* */
   int32_t gen_k;
   int32_t warmup_iter; /* WALNUTS.py:120: iterations 1..warmup_iter adapt H and delta (:701-712) */
-  int32_t waves_per_group; /* cooperative (MFMA) layout: waves sharing one 16-chain group; 0 = auto */
+  int32_t waves_per_group; /* layout hint: 0 = auto (chosen from target, dim, integrator, n_chains); 4 = waves sharing
+                              one 16-chain MFMA group; 64 = one chain per lane where a lane kernel exists */
   int32_t adapt_h;         /* WALNUTS.py:123 adaptH */
   int32_t adapt_delta;     /* WALNUTS.py:125 adaptDelta */
   double adapt_h_target;       /* WALNUTS.py:124 adaptHtarget: P2 quantile 1-target of log igrConst */

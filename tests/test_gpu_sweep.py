@@ -162,3 +162,27 @@ def test_cluster_layout_warmup(wa):
         close(d[k][:, [15, 18]], o["diagnostics"][:, [15, 18]], what=f"H/delta chain {k}")
         np.testing.assert_array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]])
         close(s[k], o["samples"], what=f"chain {k}")
+
+
+@pytest.mark.parametrize("tk,D", [(ol.T_DIAGGAUSS, 5), (ol.T_DIAGGAUSS, 16), (ol.T_DIAGGAUSS, 24), (ol.T_DENSEGAUSS, 8), (ol.T_DENSEGAUSS, 16)])
+def test_lane_layout_on_request_and_by_chain_count(wa, tk, D):
+    """Small Gaussians run one chain per lane only when asked (waves_per_group = 64) or when there are enough
+    chains to fill the chip (>= 8192 with fixedLeapFrog); both choices give the oracle's draws."""
+    rng = np.random.default_rng(D)
+    if tk == ol.T_DENSEGAUSS:
+        A, q0 = dense_problem(D, 30.0, 70, 50 + D); tpar = A.ravel()
+    else:
+        tpar = 1.0 / np.logspace(0, 1.0, D); q0 = rng.normal(size=(70, D)) / np.sqrt(tpar)
+    for ig in (ol.I_FIXED, ol.I_ADAPT_R2P):
+        e = wa.Engine(D, 70, integrator=ig, H0=0.7, delta0=0.2, M=4, chain_offset=11, waves_per_group=64).set_target(tk, tpar)
+        assert "lane" in e.kernel_name
+        s, d = e.run(q0, SEED, 2)
+        s = s.transpose(1, 2).cpu().numpy(); d = d.cpu().numpy(); e.close()
+        for k in (0, 69):
+            o = ol.walnuts(tk, q0[k], integrator=ig, tpar=tpar, H0=0.7, delta0=0.2, numIter=2, M=4, seed=SEED, chain=11 + k)
+            np.testing.assert_array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]])
+            close(s[k], o["samples"], what=f"lane D={D} ig={ig} chain {k}")
+    big = wa.Engine(D, 8192, integrator=ol.I_FIXED, H0=0.7, M=4).set_target(tk, tpar)
+    small = wa.Engine(D, 4096, integrator=ol.I_FIXED, H0=0.7, M=4).set_target(tk, tpar)
+    assert "lane" in big.kernel_name and "coop" in small.kernel_name
+    big.close(); small.close()

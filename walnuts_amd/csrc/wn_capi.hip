@@ -35,7 +35,7 @@ static int lane_dmax(int target, int D) {
   return 0;
 }
 
-int choose_kernel(int target, int D, int waves_per_group, int integrator, KernelChoice* kc) {
+int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_chains, KernelChoice* kc) {
   kc->G = 1;
   const bool flow = integrator == I_ADAPT_FLOWD;  // no cooperative-layout kernels: its gradient holds barriers
   static char names[8][64];
@@ -44,14 +44,16 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, Kernel
   static const bool force_wave = getenv("WN_FORCE_WAVE") != nullptr;  // diagnostic: std / diagonal Gaussians on the wave layout
   int dm = lane_dmax(target, D);
   if (force_wave && (target == T_STDGAUSS || target == T_DIAGGAUSS)) dm = 0;
-  // Gaussians leave the one-chain-per-lane layout except for D <= 4 with fixedLeapFrog: the 16-chain MFMA
-  // group kernel is 2-5x faster from D = 10 up and for every adaptive integrator (measured, 4096 chains:
-  // std 16-D fixed 5.4e8 vs 2.4e8, R2P 5.1e8 vs 9.5e7; dense 16-D fixed 7.7e8 vs 1.9e8 evals/s) -- its tick
-  // alignment keeps 16 chains in step, while 64 chains in one wave pay each other's divergent paths
-  static const bool lane_gauss = getenv("WN_LANE_GAUSS") != nullptr;  // diagnostic: the old choice
-  if (!lane_gauss && (target == T_STDGAUSS || target == T_DIAGGAUSS || target == T_DENSEGAUSS) &&
-      !(D <= 4 && integrator == I_FIXED) && !(target == T_DENSEGAUSS && integrator == I_ADAPT_FLOWD))
-    dm = 0;  // (adaptLeapFrogFlowD has no MFMA-group kernel: std / diagonal go one chain per wave, small dense stay per lane)
+  // Gaussians small enough for one chain per lane use it only when there are chains to fill the chip's
+  // waves (64 per wave): at 4096 chains it occupies 64 of 1024 SIMDs and the 16-chain MFMA-group kernel is
+  // 2-5x faster (std 16-D: fixedLeapFrog 5.4e8 vs 2.4e8, R2P 5.1e8 vs 9.5e7 evals/s; dense 16-D 7.7e8 vs 1.9e8),
+  // while the lane kernel scales with the chain count (std 10-D fixedLeapFrog: 5.4e8 / 1.1e9 / 3.4e9 at 8k / 16k /
+  // 64k chains against a flat 5.2e8; R2P crosses at 16k).  adaptLeapFrogFlowD has no MFMA-group kernel.
+  static const bool lane_gauss = getenv("WN_LANE_GAUSS") != nullptr;  // diagnostic: always per lane
+  if (!lane_gauss && waves_per_group != 64 && (target == T_STDGAUSS || target == T_DIAGGAUSS || target == T_DENSEGAUSS) &&
+      !(D <= 4 && integrator == I_FIXED) && !(target == T_DENSEGAUSS && integrator == I_ADAPT_FLOWD) &&
+      n_chains < (integrator == I_FIXED ? 8192 : 16384))
+    dm = 0;
   if (target == T_FUNNEL10 && waves_per_group != 64) {
     // per-chain work on the funnel is wildly uneven: one chain per wave (see WTgtFunnel10; measured at 4096 chains:
     // R2P 7.1e7 vs 4.5e7, fixedLeapFrog 1.6e8 vs 1.2e8 evaluations/s); waves_per_group = 64 asks for the
@@ -83,7 +85,7 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, Kernel
     return 0;
   }
   if (target == T_DENSEGAUSS || target == T_DIAGGAUSS || target == T_STDGAUSS) {
-    const int W = waves_per_group ? waves_per_group : 4;
+    const int W = (waves_per_group && waves_per_group != 64) ? waves_per_group : 4;  // 64 = "one chain per lane if possible"
     if (W != 4) return -1;
     const int ks = (D + 3) / 4;
     int KS = 0, NT = 0;
@@ -490,7 +492,7 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
   }
   if (need && (n_params != need || !params_dev)) { e->err = "wrong parameter count for target"; return WN_E_ARG; }
   KernelChoice kc;
-  if (choose_kernel(kind, D, e->cfg.waves_per_group, e->cfg.integrator, &kc)) {
+  if (choose_kernel(kind, D, e->cfg.waves_per_group, e->cfg.integrator, e->cfg.n_chains, &kc)) {
     e->err = "no device kernel for this (target, dim) yet";
     return WN_E_UNSUPPORTED;
   }

@@ -18,7 +18,7 @@ struct KernelChoice {
 };
 
 // returns 0 and fills `kc` if a kernel exists for (target, D)
-int choose_kernel(int target, int D, int waves_per_group, int integrator, KernelChoice* kc);
+int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_chains, KernelChoice* kc);
 size_t kernel_work_doubles(const KernelChoice& kc, int C, int M);
 hipError_t launch_lane(const KernelChoice& kc, int adapt /* 0 fixed, 1 adaptive, 2 adaptLeapFrogFlowD */, bool warm, const Params& prm, hipStream_t st);
 hipError_t launch_coop(const KernelChoice& kc, int adapt /* 0 fixed, 1 adaptive, 2 adaptLeapFrogFlowD */, bool warm, const Params& prm, hipStream_t st);
