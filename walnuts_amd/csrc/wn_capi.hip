@@ -54,6 +54,15 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_
       !(D <= 4 && integrator == I_FIXED) && !(target == T_DENSEGAUSS && integrator == I_ADAPT_FLOWD) &&
       n_chains < (integrator == I_FIXED ? 8192 : 16384))
     dm = 0;
+  if ((target == T_CORRGAUSS || target == T_SMILE || target == T_FUNNEL1 || target == T_MODFUNNEL) && D == 2 &&
+      waves_per_group != 64 && !lane_gauss && integrator != I_FIXED && n_chains < 16384) {
+    // adaptive integrators with too few chains to fill the chip 64 per wave (4096 chains, R2P: 4.8e8 vs 3.8e8
+    // evals/s on corrGauss; with fixedLeapFrog the lane kernel wins, 9.2e8 vs 5.0e8)
+    kc->layout = 2; kc->p0 = 1; kc->p1 = target; kc->W = 1;
+    snprintf(nm, 64, "wn_wave_kernel<NE=1,target=%d>", target);
+    kc->name = nm;
+    return 0;
+  }
   if (target == T_FUNNEL10 && waves_per_group != 64) {
     // per-chain work on the funnel is wildly uneven: one chain per wave (see WTgtFunnel10; measured at 4096 chains:
     // R2P 7.1e7 vs 4.5e7, fixedLeapFrog 1.6e8 vs 1.2e8 evaluations/s); waves_per_group = 64 asks for the

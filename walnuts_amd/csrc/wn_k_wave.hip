@@ -48,6 +48,14 @@ hipError_t launch_wave(const KernelChoice& kc, int adapt, bool warm, const Param
     if (kc.p0 == 64) return go<16, WTgtDiag<16, 256>, 4>(adapt, warm, prm, st);  // DP / 64 = 64: four waves per chain
   }
   if (kc.p1 == T_FUNNEL10 && kc.p0 == 1) return go<1, WTgtFunnel10>(adapt, warm, prm, st);
+  if (kc.p0 == 1) {
+    switch (kc.p1) {
+      case T_CORRGAUSS: return go<1, WTgtPair<TgtCorrGauss>>(adapt, warm, prm, st);
+      case T_SMILE: return go<1, WTgtPair<TgtSmile>>(adapt, warm, prm, st);
+      case T_FUNNEL1: return go<1, WTgtPair<TgtFunnel1>>(adapt, warm, prm, st);
+      case T_MODFUNNEL: return go<1, WTgtPair<TgtModFunnel>>(adapt, warm, prm, st);
+    }
+  }
   // (four waves per chain were tried for StockWatson: 4.43 -> 4.08 us per tick at 256 chains, 2.2x slower
   //  at 1024 -- the tick is scalar bookkeeping and f64 exp, not vector work; not kept)
   if (kc.p1 == T_STOCKWATSON && kc.p0 == 12) return go<12, WTgtStockWatson<12>>(adapt, warm, prm, st);

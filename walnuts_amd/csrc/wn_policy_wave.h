@@ -15,6 +15,7 @@
 // wave load/store of one register touches 512 contiguous bytes.
 #pragma once
 #include "wn_chain.h"
+#include "wn_targets.h"
 
 namespace wn {
 
@@ -311,6 +312,24 @@ struct WTgtFunnel10 {
 };
 
 // W waves (one workgroup) serve a chain: register e of wave w, lane l holds element (e*W + w)*64 + l.
+// The 2-D toy targets of targetDistr.py (corrGauss, smileDistr, funnel1, modFunnel) for one chain per wave:
+// lanes 0 and 1 hold q_0, q_1; every lane evaluates the lane-layout target on the broadcast pair (the same
+// arithmetic, so the same bits) -- chosen when there are too few chains to fill the chip 64 per wave.
+template <class LaneTgt>
+struct WTgtPair {
+  static constexpr int EXT = EXT_NONE;
+  static constexpr int LDS_DOUBLES = 0;
+  __device__ __forceinline__ void init(const Params&, int, double*) {}
+  __device__ __forceinline__ static double lp_finish(double r) { return r; }
+  __device__ __forceinline__ double grad(const double* q, double* g, int lane) const {
+    const double qq[2] = {wn_readlane(q[0], 0), wn_readlane(q[0], 1)};
+    double gg[2];
+    const double lp = LaneTgt::eval(qq, gg, 2, nullptr);
+    g[0] = lane == 0 ? gg[0] : (lane == 1 ? gg[1] : 0.0);
+    return lane == 0 ? lp : 0.0;
+  }
+};
+
 // CL_: a CLUSTER of workgroups serves a chain -- workgroup `slice` of G holds elements [slice*DP, (slice+1)*DP)
 // in its registers, every workgroup replicates the chain's scalars, and the only exchange is the sum / max
 // of the per-workgroup partials through global memory (cl_exchange).  All G workgroups of a chain must be
