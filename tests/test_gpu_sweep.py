@@ -186,3 +186,14 @@ def test_lane_layout_on_request_and_by_chain_count(wa, tk, D):
     small = wa.Engine(D, 4096, integrator=ol.I_FIXED, H0=0.7, M=4).set_target(tk, tpar)
     assert "lane" in big.kernel_name and "coop" in small.kernel_name
     big.close(); small.close()
+
+
+def test_randomised_differential_fuzz():
+    """tools/fuzz_parity.py: random (target, D, integrator, M, step size, warm-up, generated, chain count) drawn
+    over every layout; step counts must equal the oracle's exactly, draws to rtol 1e-6 of their vector's scale."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "120", "11"], capture_output=True,
+                       text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "120 configurations, 0 mismatching chains" in r.stdout, r.stdout[-3000:]
