@@ -16,25 +16,28 @@ for it in range(n):
     tk = int(rng.choice([ol.T_STDGAUSS, ol.T_DIAGGAUSS, ol.T_DENSEGAUSS, ol.T_FUNNEL10, ol.T_CORRGAUSS, ol.T_SMILE,
                          ol.T_FUNNEL1, ol.T_MODFUNNEL, ol.T_STOCKWATSON], p=[.2, .2, .25, .1, .04, .04, .04, .04, .09]))
     ig = int(rng.integers(0, 5))
-    C = int(rng.choice([1, 3, 17, 70]))
-    M = int(rng.integers(2, 8))
+    C = int(rng.choice([1, 3, 17, 70, 8192], p=[.24, .24, .24, .24, .04]))
+    M = int(rng.integers(2, 8)) if rng.random() < 0.9 else int(rng.integers(8, 11))
     numIter = int(rng.integers(1, 6))
     warm = int(rng.choice([0, 0, 4]))
     tpar = None
     if tk in (ol.T_STDGAUSS, ol.T_DIAGGAUSS):
-        D = int(rng.choice([1, 2, 3, 7, 16, 30, 64, 100, 129, 200, 300, 700, 1500, 5000]))
+        D = int(rng.choice([1, 2, 3, 7, 16, 30, 64, 100, 129, 200, 300, 700, 1500, 5000, 20000]))
+        if D >= 5000: C = min(C, 3)
+        if C == 8192 and D > 100: C = 70
         if tk == ol.T_DIAGGAUSS:
             tpar = 1.0 / np.logspace(0, rng.uniform(0, 2), D)
         q0 = rng.normal(size=(C, D)) / (np.sqrt(tpar) if tpar is not None else 1.0)
         H0 = float(rng.uniform(0.3, 1.2)) * max(D, 4) ** -0.25
     elif tk == ol.T_DENSEGAUSS:
         D = int(rng.choice([2, 5, 16, 17, 40, 64, 100, 128, 129, 160, 300]))
+        if C == 8192 and D > 16: C = 70
         Q, _ = np.linalg.qr(rng.normal(size=(D, D))); lam = np.logspace(0, rng.uniform(0.5, 3), D)
         A = (Q * (1.0 / lam)) @ Q.T; A = 0.5 * (A + A.T); tpar = A.ravel()
         q0 = rng.normal(size=(C, D)) @ (Q * np.sqrt(lam)).T
         H0 = float(rng.uniform(0.3, 0.9))
     elif tk == ol.T_FUNNEL10:
-        D = 11; q0 = np.zeros((C, 11)); q0[:, 0] = 2.0 * rng.normal(size=C); q0[:, 1:] = np.exp(0.5 * q0[:, :1]) * rng.normal(size=(C, 10))
+        C = min(C, 70); D = 11; q0 = np.zeros((C, 11)); q0[:, 0] = 2.0 * rng.normal(size=C); q0[:, 1:] = np.exp(0.5 * q0[:, :1]) * rng.normal(size=(C, 10))
         H0 = float(rng.uniform(0.1, 0.5))
     elif tk == ol.T_STOCKWATSON:
         D = 3 * SWT; tpar = SWP; q0 = 0.1 * rng.normal(size=(C, D)); H0 = 0.002 if ig == 0 else 0.05; M = min(M, 4); C = min(C, 3); q0 = q0[:C]
