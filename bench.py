@@ -203,6 +203,9 @@ def main():
                     traffic = tj["bytes_per_launch"]
             except Exception:
                 traffic = None
+            if traffic is None and D == 1000 and "split" in eng.kernel_name:
+                bps = _side_traffic("dense1000", "bytes_per_leapfrog_step")
+                traffic = None if bps is None else bps * steps_all / world / args.steps
         flop_per_step = 2.0 * D * D + 12.0 * D  # matvec + leapfrog updates + 2 dots
         avg_ms = float(np.mean(kernel_ms))
         steps_per_launch_rank0 = steps_all / world / args.steps
@@ -344,7 +347,14 @@ def _dist_setup():
     return rank, world, dev, (dev if backend == "nccl" else torch.device("cpu")), dist
 
 
-def _run_evals_workload(args, make_engine, q0_of, metric, workload, bytes_per_eval):
+def _side_traffic(key, field):
+    try:
+        return float(json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_side.json")))[key][field])
+    except Exception:
+        return None
+
+
+def _run_evals_workload(args, make_engine, q0_of, metric, workload, bytes_per_eval, traffic_key=None):
     """Common driver of the gradient-evaluation workloads (configs 3 and 5): chains shard over ranks with no
     data-path collective; barrier + synchronize around exactly `steps` launches; max time over ranks."""
     import torch
@@ -391,7 +401,10 @@ def _run_evals_workload(args, make_engine, q0_of, metric, workload, bytes_per_ev
                           "chain_occupancy": tot / args.steps / C / float(np.mean(mx)),
                           "tick_us": float(np.mean(kms)) * 1e3 / float(np.mean(mx)),
                           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                       "frac": ach / HBM_PEAK_GBS,
+                                       # measured HBM bytes of one launch of rank 0 (PMC bytes per evaluation x evaluations)
+                                       "traffic": (None if traffic_key is None or _side_traffic(traffic_key, "bytes_per_gradient_evaluation") is None
+                                                   else _side_traffic(traffic_key, "bytes_per_gradient_evaluation") * tot / args.steps),
                                        "bytes_per_gradient_evaluation": bytes_per_eval}}), flush=True)
     if world > 1:
         dist.barrier()
@@ -421,7 +434,7 @@ def main_funnel(args):
 
     _run_evals_workload(args, make_engine, q0_of, "gradient evaluations/sec across chains, funnel10 (adaptLeapFrogR2P)",
                         lambda C: f"funnel10 D=11, {C} chains/GPU, adaptLeapFrogR2P, M=12, H0=0.3, delta0=0.3, "
-                                  f"{args.iters} iterations/launch (SURVEY 8d cfg 3)", 528.0)
+                                  f"{args.iters} iterations/launch (SURVEY 8d cfg 3)", 528.0, "funnel")
 
 
 def main_stockwatson(args):
@@ -449,7 +462,7 @@ def main_stockwatson(args):
     _run_evals_workload(args, make_engine, lambda rank, C: np.zeros((C, D)),
                         f"gradient evaluations/sec across chains, StockWatson ({name.split()[0]})",
                         lambda C: f"StockWatson D={D}, {C} chains/GPU, {name}, M=14, H0={H0}, delta0=0.3, "
-                                  f"q0=0, {args.iters} iterations/launch (SURVEY 8d cfg 5)", 48.0 * D)
+                                  f"q0=0, {args.iters} iterations/launch (SURVEY 8d cfg 5)", 48.0 * D, "stockwatson")
 
 
 if __name__ == "__main__":
