@@ -3,7 +3,7 @@
 workload (BASELINE.json: 100-D ill-conditioned Gaussian, kappa=1e4, fixedLeapFrog, M=10,
 H0=0.5, 100 iterations; SURVEY.md 8d cfg 2), with roofline and CPU-baseline legs.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W     (N > 1: starts one child process per GPU itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one wn_run launch: `--iters` sampler iterations for `--chains` chains per GPU.
@@ -87,6 +87,38 @@ def cpu_baseline(A, q0, iters, M, H0, budget_s=12.0):
                       f"(oracle/libwalnuts_oracle.so, C restatement pinned to the Python reference)"}
 
 
+def _self_launch(args):
+    """`python bench.py --gpus N` without torchrun: this process has not touched torch or HIP yet, so it
+    may start children.  Starts one fresh child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the
+    same command line), after one single-GPU child of the same workload whose value becomes the N = 1
+    reference of `weak_scaling_eff`; relays rank 0's JSON line and exits with the worst child's code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    if not args.no_n1_ref:
+        r = subprocess.run(argv + ["--gpus", "1", "--no-extras", "--no-cpu-baseline"], env=dict(base, WN_BENCH_CHILD="1"),
+                           stdout=subprocess.PIPE, text=True)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and lines:
+            base["WN_BENCH_N1_VALUE"] = repr(float(json.loads(lines[-1])["value"]))
+        else:
+            print(f"bench.py: the N=1 reference run failed (rc {r.returncode}); continuing without it", file=sys.stderr)
+    procs = []
+    for rank in range(n):
+        env = dict(base, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), WN_BENCH_CHILD="1")
+        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if rank == 0 else sys.stderr, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p_.wait() for p_ in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    sys.exit(max(abs(rc) for rc in rcs))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,12 +139,20 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the SURVEY 8d side measurements (C=1024, diagonal-precision variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-n1-ref", action="store_true",
+                    help="self-launched --gpus N > 1: skip the single-GPU run that weak_scaling_eff refers to")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (see profiles/)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            return _self_launch(args)  # never returns
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus and "WN_BENCH_CHILD" not in os.environ:
+        ap.error(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.workload == "funnel":
         return main_funnel(args)
@@ -132,20 +172,7 @@ def main():
         cpu = cpu_baseline(A, q0, args.iters, args.M, args.H0)  # forks workers: before any GPU init
 
     import torch
-    import torch.distributed as dist
-    backend = os.environ.get("WN_DIST_BACKEND", "nccl")  # "gloo" lets two ranks share one GPU in tests
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank % torch.cuda.device_count())
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", torch.cuda.current_device())
-    cdev = dev if backend == "nccl" else torch.device("cpu")  # where collectives run
+    rank, world, dev, cdev, dist = _dist_setup()
 
     import walnuts_amd as wa
     from walnuts_amd import _lib as L
@@ -176,11 +203,13 @@ def main():
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     total_steps = total_steps.to(cdev).reshape(1)
+    total_steps_rank = float(total_steps.item())
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(total_steps, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
     steps_all = float(total_steps.item())
+    scal = _scaling_fields(dist, world, cdev, steps_all / elapsed, float(np.mean(kernel_ms)), float(total_steps_rank))
 
     # final gather of draws to rank 0 (the only data collective; RCCL over xGMI), timed apart
     gather_ms = 0.0
@@ -231,6 +260,7 @@ def main():
             "leapfrog_steps_per_launch_per_gpu": steps_per_launch_rank0,
             "kernel_ms_avg": avg_ms,
             "gather_ms": gather_ms,
+            **scal,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": traffic,
@@ -333,6 +363,8 @@ def _dist_setup():
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     backend = os.environ.get("WN_DIST_BACKEND", "nccl")
+    if torch.cuda.device_count() < 1:
+        sys.exit("bench.py needs a ROCm GPU (the product has no CPU path)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -345,6 +377,24 @@ def _dist_setup():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
     return rank, world, dev, (dev if backend == "nccl" else torch.device("cpu")), dist
+
+
+def _scaling_fields(dist, world, cdev, value, kernel_ms_avg, units_rank):
+    """Per-rank kernel time and work (one small all_gather outside the timed region) and, when bench.py
+    launched the ranks itself, the weak-scaling efficiency against the single-GPU run of the same invocation."""
+    import torch
+    if world == 1:
+        return {}
+    mine = torch.tensor([kernel_ms_avg, units_rank], dtype=torch.float64, device=cdev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    out = {"per_rank_kernel_ms": [float(a[0].item()) for a in allr],
+           "per_rank_units": [float(a[1].item()) for a in allr]}
+    n1 = os.environ.get("WN_BENCH_N1_VALUE")
+    if n1:
+        out["n1_value_same_invocation"] = float(n1)
+        out["weak_scaling_eff"] = value / (world * float(n1))
+    return out
 
 
 def _side_traffic(key, field):
@@ -387,6 +437,7 @@ def _run_evals_workload(args, make_engine, q0_of, metric, workload, bytes_per_ev
         el, tot_all = float(tmax[0].item()), float(t[1].item())
     else:
         tot_all = tot
+    scal = _scaling_fields(dist, world, cdev, tot_all / el, float(np.mean(kms)), tot)
     if rank == 0:
         ach = tot / args.steps * bytes_per_eval / (np.mean(kms) * 1e-3) / 1e9  # rank 0's kernel
         print(json.dumps({"metric": metric, "value": tot_all / el, "unit": "gradient evaluations/s", "n_gpus": world,
@@ -395,7 +446,7 @@ def _run_evals_workload(args, make_engine, q0_of, metric, workload, bytes_per_ev
                           "data": "synthetic",
                           "config": {"workload": workload(C), "kernel": eng.kernel_name, "chains_per_gpu": C,
                                      "sharding": f"chains x{world}, no data-path collective"},
-                          "kernel_ms_avg": float(np.mean(kms)),
+                          "kernel_ms_avg": float(np.mean(kms)), **scal,
                           # a launch lasts as long as its busiest chain (that chain's evaluations are sequential)
                           "busiest_chain_evals": float(np.mean(mx)),
                           "chain_occupancy": tot / args.steps / C / float(np.mean(mx)),

@@ -373,34 +373,43 @@ def test_walnuts_other_targets_match_reference(wa):
 
 
 def test_bench_two_ranks_sharing_one_gpu():
-    """bench.py's N > 1 path (sharding by chain_offset, MAX-time / SUM-steps reductions, final
-    gather) with two ranks on the one GPU of this box; collectives over gloo because RCCL refuses
-    two ranks on one device.  The 8-GPU RCCL run is the driver's."""
+    """bench.py's N > 1 path (self-launch of one child per rank, sharding by chain_offset, MAX-time / SUM-steps
+    reductions, final gather) with two ranks on the one GPU of this box; collectives over gloo because RCCL
+    refuses two ranks on one device.  `python bench.py --gpus 2` with no launcher around it, and the driver's
+    torch.distributed.run form.  The 8-GPU RCCL run is the driver's."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, WN_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-           "127.0.0.1", "--master-port", "29741", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
-           "--warmup", "0", "--chains", "256", "--iters", "5"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    env = dict(os.environ, WN_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    bench = os.path.join(root, "bench.py")
+
+    def line(r):
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+    # self-launch: bench.py starts its own ranks (and the N = 1 reference run of weak_scaling_eff)
+    out = line(subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--chains", "256",
+                               "--iters", "5"], capture_output=True, text=True, timeout=900, env=env, cwd=root))
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["ess_per_sec"]["draws"] == 2 * 256 * 5
+    assert len(out["per_rank_kernel_ms"]) == 2 and out["gather_ms"] > 0
+    assert out["n1_value_same_invocation"] > 0 and out["weak_scaling_eff"] > 0
+    # the driver's form: torch.distributed.run around bench.py gives the same job
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29741", bench, "--gpus", "2", "--steps", "1",
+           "--warmup", "0", "--chains", "256", "--iters", "5"]
+    out2 = line(subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, MASTER_ADDR="127.0.0.1"), cwd=root))
+    assert out2["n_gpus"] == 2 and out2["leapfrog_steps_per_launch_per_gpu"] == out["leapfrog_steps_per_launch_per_gpu"]
     # the same 512 chains in one process give the same number of leapfrog steps (sharding invariance)
-    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--chains", "512",
-                         "--iters", "5", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
-    o1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
-    assert o1["leapfrog_steps_per_launch_per_gpu"] == 2 * out["leapfrog_steps_per_launch_per_gpu"]
+    o1 = line(subprocess.run([sys.executable, bench, "--steps", "1", "--warmup", "0", "--chains", "512", "--iters", "5",
+                              "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600, env=env, cwd=root))
+    assert o1["n_gpus"] == 1 and o1["leapfrog_steps_per_launch_per_gpu"] == 2 * out["leapfrog_steps_per_launch_per_gpu"]
     # the other workloads shard the same way (configs 3, 4, 5)
-    for port, extra in ((29743, ["--workload", "funnel", "--chains", "64", "--iters", "3"]),
-                        (29745, ["--workload", "dense1000", "--chains", "64", "--iters", "2", "--no-cpu-baseline"]),
-                        (29747, ["--workload", "stockwatson", "--chains", "8", "--iters", "2"])):
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-               "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
-               "--warmup", "0"] + extra
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for extra in (["--workload", "funnel", "--chains", "64", "--iters", "3"],
+                  ["--workload", "dense1000", "--chains", "64", "--iters", "2", "--no-cpu-baseline"],
+                  ["--workload", "stockwatson", "--chains", "8", "--iters", "2"]):
+        o = line(subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-n1-ref"] + extra,
+                                capture_output=True, text=True, timeout=600, env=env, cwd=root))
         assert o["n_gpus"] == 2 and o["value"] > 0 and o["roofline"]["frac"] > 0, o
+        assert len(o["per_rank_kernel_ms"]) == 2
