@@ -33,7 +33,7 @@ enum {
   WN_E_UNSUPPORTED = -2, /* configuration has no device kernel (yet) */
   WN_E_HIP = -3,         /* HIP runtime error, see wn_last_error */
   WN_E_NOTARGET = -4,    /* wn_set_target not called */
-  WN_E_ALLOC = -5
+  WN_E_ALLOC = -5        /* device memory exhausted (hipErrorOutOfMemory); the engine keeps no target */
 };
 
 /* target plugin lpFun(q) -> [lp, grad]  (WALNUTSpy/targetDistr.py; adaptiveIntegrators.py passes
@@ -84,7 +84,8 @@ typedef struct wn_config {
   int32_t device;      /* HIP device ordinal */
   int32_t dim;         /* D = q0.size */
   int32_t n_chains;    /* chains resident on this engine */
-  int64_t chain_offset; /* global id of local chain 0; RNG is keyed by global id */
+  int64_t chain_offset; /* global id of local chain 0; RNG is keyed by global id;
+                           0 <= chain_offset, chain_offset + n_chains <= 2^32 (ids are 32-bit) */
   int32_t integrator;  /* WN_I_* */
   int32_t M;           /* max doublings, WALNUTS.py:121 */
   int32_t min_c;       /* integratorAuxPar.minC */
@@ -126,9 +127,6 @@ int wn_run(wn_engine *e, const double *q0_dev, uint64_t seed, int32_t n_iter, do
            double *diag_dev, double *trace_dev, int32_t trace_cap, int32_t *trace_n_dev,
            void *stream);
 
-/* wn_run with recordOrbitStats=True (WALNUTS.py:128,182-184,724-725): additionally fills
- * orbit_min_dev / orbit_max_dev [C][n_iter][dg] with the per-iteration minimum / maximum of
- * generated(q) over the states of the orbit.  generated must be WN_G_IDENTITY or WN_G_FIRSTK. */
 /* ---- caller-evaluated target (WN_T_EXTERNAL) ----------------------------------------------------
  * The reference calls lpFun(q) once per leapfrog step of one chain (adaptiveIntegrators.py:53,78);
  * here every chain advances by one gradient evaluation per wn_split_tick and the caller evaluates
@@ -153,6 +151,9 @@ int wn_split_begin(wn_engine *e, const double *q0_dev, uint64_t seed, int32_t n_
 int wn_split_tick(wn_engine *e, void *stream);
 int wn_split_done(wn_engine *e, int32_t *n_done, void *stream);
 
+/* wn_run with recordOrbitStats=True (WALNUTS.py:128,182-184,724-725): additionally fills
+ * orbit_min_dev / orbit_max_dev [C][n_iter][dg] with the per-iteration minimum / maximum of
+ * generated(q) over the states of the orbit.  generated must be WN_G_IDENTITY or WN_G_FIRSTK. */
 int wn_run_orbit_stats(wn_engine *e, const double *q0_dev, uint64_t seed, int32_t n_iter,
                        double *samples_dev, double *diag_dev, double *orbit_min_dev,
                        double *orbit_max_dev, void *stream);
@@ -202,7 +203,9 @@ int wn_rng_tape(wn_engine *e, uint64_t seed, int32_t iter, int32_t n_u, double *
  * launch stream (synchronises on the stop event). */
 int wn_last_run_ms(wn_engine *e, float *ms);
 
-/* Which kernel the engine dispatches to: "coop_mfma<NT,W>", "lane<DMAX>" ... (static string). */
+/* Which kernel the engine dispatches to: "wn_coop_kernel<NT=2,W=4,KS=25,dense>", "wn_lane_kernel<DMAX=..>" ...
+ * The string is owned by the engine: valid until the next wn_set_target or wn_destroy of THIS engine;
+ * "" before the first successful wn_set_target. */
 const char *wn_kernel_name(wn_engine *e);
 
 const char *wn_last_error(wn_engine *e); /* e may be NULL: last creation error */

@@ -27,6 +27,21 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert C.sizeof(_lib.WnConfig) == 120
 
 
+def test_wn_create_rejects_chain_ids_beyond_32_bits():
+    """Argument checks run before any HIP call (no GPU needed): global chain ids are one 32-bit Philox word."""
+    from walnuts_amd import _lib
+    L = _lib.lib()
+    cfg = _lib.WnConfig()
+    cfg.abi_version = _lib.WN_ABI_VERSION
+    cfg.dim, cfg.n_chains, cfg.M, cfg.max_c = 3, 8, 5, 10
+    cfg.H0, cfg.delta0, cfg.step_size_rand_scale, cfg.r2p_prob0 = 0.2, 0.05, 0.2, 2.0 / 3.0
+    h = C.c_void_p()
+    for off in (2 ** 32 - 7, -1, 2 ** 40):
+        cfg.chain_offset = off
+        assert L.wn_create(C.byref(cfg), C.byref(h)) == _lib.E_ARG
+        assert b"chain_offset" in L.wn_last_error(None)
+
+
 def test_no_gpu_means_loud_failure():
     import torch
     if torch.cuda.is_available():

@@ -310,6 +310,41 @@ def test_error_paths(wa):
         wa.Engine(3000, 4).set_target(ol.T_DENSEGAUSS, np.eye(3000).ravel())  # dense Gaussians stop at D = 1024
 
 
+def test_kernel_names_are_per_engine_and_failed_set_target_leaves_no_target(wa):
+    """wn_kernel_name is engine-owned storage (it used to be a shared 8-entry ring), and a wn_set_target that
+    fails after the previous target was released leaves the engine without a target instead of the old kernel."""
+    first = wa.Engine(100, 16).set_target(ol.T_DENSEGAUSS, np.eye(100).ravel())
+    name0 = first.kernel_name
+    assert "coop" in name0 and "dense" in name0
+    others = [wa.Engine(11, 4, integrator=ol.I_ADAPT_R2P).set_target(ol.T_FUNNEL10) for _ in range(12)]
+    assert first.lib.wn_kernel_name(first.h).decode() == name0
+    assert all("funnel10" in o.kernel_name for o in others)
+    for o in others:
+        o.close()
+    with pytest.raises(ValueError):
+        first.set_target(ol.T_FUNNEL10)  # argument error: rejected before anything is touched, target kept
+    assert first.lib.wn_kernel_name(first.h).decode() == name0
+    s, d = first.run(np.zeros((16, 100)), 1, 1)
+    assert s.shape == (16, 2, 100)
+    first.close()
+    with pytest.raises(ValueError):
+        wa.Engine(3, 4, chain_offset=2 ** 32 - 2)  # global chain ids are 32-bit
+    wa.Engine(3, 4, chain_offset=2 ** 32 - 4).close()
+
+
+def test_host_generated_callable_with_return_torch(wa):
+    """A callable `generated` is applied to the stored draws whether numpy arrays or device tensors are returned."""
+    from walnuts_amd import adaptiveIntegrators as ai, targetDistr as td
+    gen = lambda q: np.array([q[0], np.sum(q * q), q[-1]])
+    q0 = np.random.default_rng(2).normal(size=(3, 6))
+    kw = dict(generated=gen, integrator=ai.fixedLeapFrog, H0=0.4, numIter=4, warmupIter=0, M=4, seed=3)
+    s, d = wa.WALNUTS(td.stdGauss, q0, **kw)
+    st, dt = wa.WALNUTS(td.stdGauss, q0, return_torch=True, **kw)
+    assert tuple(st.shape) == (3, 3, 5) and st.is_cuda
+    np.testing.assert_array_equal(st.cpu().numpy(), s)
+    np.testing.assert_array_equal(dt.cpu().numpy(), d)
+
+
 def test_walnuts_api_shapes(wa):
     """Single-chain call returns exactly the reference's shapes (WALNUTS.py:163,180,724-727)."""
     from walnuts_amd import adaptiveIntegrators as ai, targetDistr as td

@@ -103,6 +103,11 @@ def WALNUTS(lpFun, q0, generated=identity, integrator=ai.fixedLeapFrog, H0=0.2,
     samples = samples.transpose(1, 2)  # [C, dg, numIter+1] as the reference's (dg, numIter+1)
     if return_torch:
         eng.torch.cuda.synchronize(eng.device)
+        if host_gen is not None:  # a host callable sees host arrays; its results go back to the device
+            sh = samples.cpu().numpy()
+            sh = np.stack([np.stack([np.asarray(host_gen(sh[c, :, i])) for i in range(numIter + 1)], axis=1)
+                           for c in range(C)])
+            samples = eng.torch.as_tensor(sh, device=eng.device)
         res = (samples, diag) + tuple(out[2:])
         eng.close()
         return res

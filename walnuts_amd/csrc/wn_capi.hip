@@ -38,9 +38,8 @@ static int lane_dmax(int target, int D) {
 int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_chains, KernelChoice* kc) {
   kc->G = 1;
   const bool flow = integrator == I_ADAPT_FLOWD;  // no cooperative-layout kernels: its gradient holds barriers
-  static char names[8][64];
-  static int slot = 0;
-  char* nm = names[(slot++) & 7];
+  char* nm = kc->name;  // per-choice storage: the engine owns its kernel name
+  nm[0] = 0;
   static const bool force_wave = getenv("WN_FORCE_WAVE") != nullptr;  // diagnostic: std / diagonal Gaussians on the wave layout
   int dm = lane_dmax(target, D);
   if (force_wave && (target == T_STDGAUSS || target == T_DIAGGAUSS)) dm = 0;
@@ -59,8 +58,7 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_
     // adaptive integrators with too few chains to fill the chip 64 per wave (4096 chains, R2P: 4.8e8 vs 3.8e8
     // evals/s on corrGauss; with fixedLeapFrog the lane kernel wins, 9.2e8 vs 5.0e8)
     kc->layout = 2; kc->p0 = 1; kc->p1 = target; kc->W = 1;
-    snprintf(nm, 64, "wn_wave_kernel<NE=1,target=%d>", target);
-    kc->name = nm;
+    snprintf(nm, sizeof(kc->name), "wn_wave_kernel<NE=1,target=%d>", target);
     return 0;
   }
   if (target == T_FUNNEL10 && waves_per_group != 64) {
@@ -68,29 +66,25 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_
     // R2P 7.1e7 vs 4.5e7, fixedLeapFrog 1.6e8 vs 1.2e8 evaluations/s); waves_per_group = 64 asks for the
     // one-chain-per-lane kernel
     kc->layout = 2; kc->p0 = 1; kc->p1 = T_FUNNEL10; kc->W = 1;
-    snprintf(nm, 64, "wn_wave_kernel<NE=1,funnel10>");
-    kc->name = nm;
+    snprintf(nm, sizeof(kc->name), "wn_wave_kernel<NE=1,funnel10>");
     return 0;
   }
   if (dm) {
     kc->layout = 0; kc->p0 = dm; kc->p1 = target; kc->W = 1;
-    snprintf(nm, 64, "wn_lane_kernel<DMAX=%d,target=%d>", dm, target);
-    kc->name = nm;
+    snprintf(nm, sizeof(kc->name), "wn_lane_kernel<DMAX=%d,target=%d>", dm, target);
     return 0;
   }
   if (target == WN_T_STOCKWATSON) {
     if (D > 768 || D % 3) return -1;
     kc->layout = 2; kc->p0 = 12; kc->p1 = T_STOCKWATSON; kc->W = 1;
-    snprintf(nm, 64, "wn_wave_kernel<NE=12,stockwatson>");
-    kc->name = nm;
+    snprintf(nm, sizeof(kc->name), "wn_wave_kernel<NE=12,stockwatson>");
     return 0;
   }
   if (target == WN_T_EXTERNAL) {  // caller-evaluated (logp, grad): split mode
     if (D > 1024) return -1;
     const int NE = D <= 512 ? 8 : 16;
     kc->layout = 3; kc->p0 = NE; kc->p1 = EXT_LP; kc->W = 1;
-    snprintf(nm, 64, "wn_split_tick_kernel<NE=%d,external>", NE);
-    kc->name = nm;
+    snprintf(nm, sizeof(kc->name), "wn_split_tick_kernel<NE=%d,external>", NE);
     return 0;
   }
   if (target == T_DENSEGAUSS || target == T_DIAGGAUSS || target == T_STDGAUSS) {
@@ -115,16 +109,14 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_
       // mainGaussESS.py:20): a cluster of ceil(D/4096) workgroups per chain keeps the chain's vectors in
       // registers; only the partial sums of the reductions cross workgroups
       kc->layout = 2; kc->p0 = 64; kc->p1 = T_DIAGGAUSS; kc->W = 4; kc->G = (D + 4095) / 4096;
-      snprintf(nm, 64, "wn_wave_kernel<NE=16,W=4,diag,cluster=%d>", kc->G);
-      kc->name = nm;
-      return 0;
+      snprintf(nm, sizeof(kc->name), "wn_wave_kernel<NE=16,W=4,diag,cluster=%d>", kc->G);
+        return 0;
     }
     if (!KS && D > 1024 && D <= 4096 && target != T_DENSEGAUSS) {
       // std / diagonal Gaussian, 1024 < D <= 4096: four waves per chain
       kc->layout = 2; kc->p0 = 64; kc->p1 = T_DIAGGAUSS; kc->W = 4;
-      snprintf(nm, 64, "wn_wave_kernel<NE=16,W=4,diag>");
-      kc->name = nm;
-      return 0;
+      snprintf(nm, sizeof(kc->name), "wn_wave_kernel<NE=16,W=4,diag>");
+        return 0;
     }
     if (!KS && D <= 1024) {
       // one chain per wavefront (wn_policy_wave.h): fused std / diagonal Gaussian, or the dense
@@ -133,19 +125,17 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_
       kc->W = 1; kc->p0 = NE;
       if (target == T_DENSEGAUSS) {
         kc->layout = 3; kc->p1 = EXT_HALF_QG;
-        snprintf(nm, 64, "wn_split_tick_kernel<NE=%d,dense>+wn_dense_grad_kernel", NE);
+        snprintf(nm, sizeof(kc->name), "wn_split_tick_kernel<NE=%d,dense>+wn_dense_grad_kernel", NE);
       } else {
         kc->layout = 2; kc->p1 = T_DIAGGAUSS;
-        snprintf(nm, 64, "wn_wave_kernel<NE=%d,diag>", NE);
+        snprintf(nm, sizeof(kc->name), "wn_wave_kernel<NE=%d,diag>", NE);
       }
-      kc->name = nm;
-      return 0;
+        return 0;
     }
     if (!KS) return -1;
     kc->layout = 1; kc->p0 = KS; kc->p1 = (target == T_DENSEGAUSS) ? CK_DENSE : CK_DIAG; kc->W = W;
-    snprintf(nm, 64, "wn_coop_kernel<NT=%d,W=%d,KS=%d,%s>", NT, W, KS,
+    snprintf(nm, sizeof(kc->name), "wn_coop_kernel<NT=%d,W=%d,KS=%d,%s>", NT, W, KS,
              kc->p1 == CK_DENSE ? "dense" : "diag");
-    kc->name = nm;
     return 0;
   }
   return -1;
@@ -425,6 +415,18 @@ static std::string g_create_err;
     }                                                                          \
   } while (0)
 
+// device allocations: out-of-memory is the caller's problem to size (WN_E_ALLOC), anything else a HIP error
+#define HIPALLOC(e, ptr, bytes)                                                \
+  do {                                                                         \
+    hipError_t _r = hipMalloc((void**)&(ptr), (bytes));                        \
+    if (_r != hipSuccess) {                                                    \
+      (ptr) = nullptr;                                                         \
+      (void)hipGetLastError();                                                 \
+      (e)->err = std::string("hipMalloc(" #ptr ", ") + std::to_string((size_t)(bytes)) + " B): " + hipGetErrorString(_r); \
+      return _r == hipErrorOutOfMemory ? WN_E_ALLOC : WN_E_HIP;                \
+    }                                                                          \
+  } while (0)
+
 extern "C" {
 
 int wn_abi_version(void) { return WN_ABI_VERSION; }
@@ -437,6 +439,10 @@ int wn_create(const wn_config* cfg, wn_engine** out) {
   if (cfg->abi_version != WN_ABI_VERSION) { g_create_err = "abi_version mismatch"; return WN_E_ARG; }
   // WALNUTS.py:140,146 sys.exit on bad tuning targets; the analogous argument checks here
   if (cfg->dim < 1 || cfg->n_chains < 1) { g_create_err = "dim and n_chains must be >= 1"; return WN_E_ARG; }
+  // the random stream is keyed by a 32-bit global chain id (wn_rng.h: one Philox counter word)
+  if (cfg->chain_offset < 0 || (uint64_t)cfg->chain_offset + (uint64_t)cfg->n_chains > (1ull << 32)) {
+    g_create_err = "chain_offset + n_chains must stay within [0, 2^32) (global chain ids are 32-bit)"; return WN_E_ARG;
+  }
   if (cfg->M < 1 || cfg->M > MAX_M) { g_create_err = "M out of range [1,24]"; return WN_E_ARG; }
   if (cfg->integrator < WN_I_FIXED || cfg->integrator > WN_I_ADAPT_FLOWD) { g_create_err = "unknown integrator"; return WN_E_ARG; }
   if (cfg->min_c < 0 || cfg->max_c < cfg->min_c || cfg->max_c > 20) { g_create_err = "need 0 <= minC <= maxC <= 20"; return WN_E_ARG; }
@@ -506,10 +512,25 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
     return WN_E_UNSUPPORTED;
   }
   HIPCHK(e, hipSetDevice(e->cfg.device));
+  if (kc.G > 1) {
+    // every workgroup of a chain spins on its siblings: the whole grid must be resident (one 4-wave
+    // workgroup of 512-register waves per CU).  Checked before anything of the previous target is freed.
+    hipDeviceProp_t prop;
+    HIPCHK(e, hipGetDeviceProperties(&prop, e->cfg.device));
+    if ((long long)e->cfg.n_chains * kc.G > prop.multiProcessorCount) {
+      e->err = "cluster layout: n_chains * ceil(dim / 4096) must not exceed the number of CUs; run fewer chains per call";
+      return WN_E_UNSUPPORTED;
+    }
+  }
+  // from here on the previous target is gone: a failure below leaves the engine without a target
+  // (wn_run then returns WN_E_NOTARGET) instead of an old kernel on buffers sized for the new one
+  e->have_kc = false;
+  e->target = -1;
+  e->kc = KernelChoice{};
   if (e->tpar) { hipFree(e->tpar); e->tpar = nullptr; }
   if (e->work) { hipFree(e->work); e->work = nullptr; }
   size_t nt = need ? need : (size_t)D;  // stdGauss runs as the diagonal target with a == 1
-  HIPCHK(e, hipMalloc((void**)&e->tpar, nt * sizeof(double)));
+  HIPALLOC(e, e->tpar, nt * sizeof(double));
   if (need) HIPCHK(e, hipMemcpy(e->tpar, params_dev, need * sizeof(double), hipMemcpyDeviceToDevice));
   else {
     hipLaunchKernelGGL(wn_fill_kernel, dim3((nt + 255) / 256), dim3(256), 0, 0, e->tpar, nt, 1.0);
@@ -518,11 +539,11 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
   }
   e->ntpar = nt;
   e->work_doubles = kernel_work_doubles(kc, e->cfg.n_chains, e->cfg.M);
-  HIPCHK(e, hipMalloc((void**)&e->work, e->work_doubles * sizeof(double)));
+  HIPALLOC(e, e->work, e->work_doubles * sizeof(double));
   HIPCHK(e, hipMemset(e->work, 0, e->work_doubles * sizeof(double)));
   if (e->facs) { hipFree(e->facs); e->facs = nullptr; }
   if (e->cfg.warmup_iter > 0)  // one sorted copy per chain (per workgroup of a cluster: every replica keeps its own)
-    HIPCHK(e, hipMalloc((void**)&e->facs, (size_t)e->cfg.n_chains * kc.G * 2 * e->cfg.warmup_iter * sizeof(double)));
+    HIPALLOC(e, e->facs, (size_t)e->cfg.n_chains * kc.G * 2 * e->cfg.warmup_iter * sizeof(double));
   if (e->apad) { hipFree(e->apad); e->apad = nullptr; }
   if (e->xq) { hipFree(e->xq); e->xq = nullptr; }
   if (e->xg) { hipFree(e->xg); e->xg = nullptr; }
@@ -530,28 +551,20 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
   if (e->cl_red) { hipFree(e->cl_red); e->cl_red = nullptr; }
   if (e->cl_cnt) { hipFree(e->cl_cnt); e->cl_cnt = nullptr; }
   if (kc.G > 1) {
-    // every workgroup of a chain spins on its siblings: the whole grid must be resident (one 4-wave
-    // workgroup of 512-register waves per CU)
-    hipDeviceProp_t prop;
-    HIPCHK(e, hipGetDeviceProperties(&prop, e->cfg.device));
-    if ((long long)e->cfg.n_chains * kc.G > prop.multiProcessorCount) {
-      e->err = "cluster layout: n_chains * ceil(dim / 4096) must not exceed the number of CUs; run fewer chains per call";
-      return WN_E_UNSUPPORTED;
-    }
-    HIPCHK(e, hipMalloc((void**)&e->cl_red, (size_t)e->cfg.n_chains * 2 * kc.G * 8 * sizeof(double)));
-    HIPCHK(e, hipMalloc((void**)&e->cl_cnt, ((size_t)e->cfg.n_chains + 16) * sizeof(unsigned)));
+    HIPALLOC(e, e->cl_red, (size_t)e->cfg.n_chains * 2 * kc.G * 8 * sizeof(double));
+    HIPALLOC(e, e->cl_cnt, ((size_t)e->cfg.n_chains + 16) * sizeof(unsigned));
   }
   if (kc.layout == 3) {
     e->DP = 64 * kc.p0;
     e->Cpad = (e->cfg.n_chains + 63) / 64 * 64;
     const size_t nx = (size_t)e->Cpad * e->DP;
-    if (!e->sp_done) HIPCHK(e, hipMalloc((void**)&e->sp_done, 64));
+    if (!e->sp_done) HIPALLOC(e, e->sp_done, 64);
     if (kind == WN_T_DENSEGAUSS) {
-      HIPCHK(e, hipMalloc((void**)&e->xq, nx * sizeof(double)));
-      HIPCHK(e, hipMalloc((void**)&e->xg, nx * sizeof(double)));
+      HIPALLOC(e, e->xq, nx * sizeof(double));
+      HIPALLOC(e, e->xg, nx * sizeof(double));
       HIPCHK(e, hipMemset(e->xq, 0, nx * sizeof(double)));
       HIPCHK(e, hipMemset(e->xg, 0, nx * sizeof(double)));
-      HIPCHK(e, hipMalloc((void**)&e->apad, (size_t)e->DP * e->DP * sizeof(double)));
+      HIPALLOC(e, e->apad, (size_t)e->DP * e->DP * sizeof(double));
       HIPCHK(e, hipMemset(e->apad, 0, (size_t)e->DP * e->DP * sizeof(double)));
       HIPCHK(e, hipMemcpy2D(e->apad, (size_t)e->DP * sizeof(double), params_dev, (size_t)D * sizeof(double),
                             (size_t)D * sizeof(double), (size_t)D, hipMemcpyDeviceToDevice));
@@ -666,6 +679,7 @@ static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
   Params pc = p;
   if (e->kc.G > 1) {
     pc.cl_g = e->kc.G; pc.cl_red = e->cl_red; pc.cl_cnt = e->cl_cnt; pc.cl_abort = (int*)(e->cl_cnt + e->cfg.n_chains);
+    if (const char* dd = getenv("WN_DEBUG_CLUSTER_DROP")) pc.cl_debug_drop = atoi(dd);  // test hook: tests/test_gpu_wave.py
     HIPCHK(e, hipMemsetAsync(e->cl_cnt, 0, ((size_t)e->cfg.n_chains + 16) * sizeof(unsigned), st));
   }
   const Params& p_ = pc;
@@ -894,6 +908,6 @@ int wn_last_run_ms(wn_engine* e, float* ms) {
   return WN_OK;
 }
 
-const char* wn_kernel_name(wn_engine* e) { return (e && e->have_kc) ? e->kc.name : ""; }
+const char* wn_kernel_name(wn_engine* e) { return (e && e->have_kc) ? e->kc.name : ""; }  // engine-owned storage
 
 }  // extern "C"

@@ -77,6 +77,7 @@ struct Params {
   double* cl_red;
   unsigned* cl_cnt;
   int* cl_abort;
+  int cl_debug_drop;  // test hook (WN_DEBUG_CLUSTER_DROP): slice G-1 skips its arrival at this exchange (0 = never)
   unsigned long long* stamps;  // diagnostic builds (-DWN_STAMPS): [block][wave][8] cycles per phase
 };
 

@@ -14,7 +14,7 @@ struct KernelChoice {
   int p1;      // lane: target kind ; coop: CK_DENSE / CK_DIAG ; wave: target kind ; split: EXT_*
   int W;       // coop: waves per group
   int G;       // wave layout: workgroups per chain (cluster), 1 otherwise
-  const char* name;
+  char name[96];  // owned by the engine that holds this choice (no shared static storage)
 };
 
 // returns 0 and fills `kc` if a kernel exists for (target, D)

@@ -61,6 +61,8 @@ class Engine:
             msg = self.lib.wn_last_error(self.h).decode()
             if rc == L.E_UNSUPPORTED:
                 raise NotImplementedError(msg)
+            if rc == L.E_ALLOC:
+                raise MemoryError(msg)
             raise ValueError(msg) if rc == L.E_ARG else WalnutsError(f"rc={rc}: {msg}")
 
     def _dev(self, a, dtype=None):
