@@ -39,7 +39,9 @@ hipError_t launch_coop(const KernelChoice& kc, int adapt_, bool warm, const Para
   if (kc.W != 4 || adapt_ == 2) return hipErrorInvalidValue;  // adaptLeapFrogFlowD runs in the lane / wave layouts
   const bool adapt = adapt_ != 0;
   // p0 = k-steps (= ceil(D/4) rounded up to an instantiated value)
-#ifdef WN_ONLY_MAIN
+#ifdef WN_EXP_W8  // experiment: eight waves per group, one 16-row tile each (two waves per SIMD)
+  if (kc.p1 == CK_DENSE && kc.p0 == 25) return go<1, 8, 25, CK_DENSE>(adapt, warm, prm, st);
+#elif defined(WN_ONLY_MAIN)
   if (kc.p1 == CK_DENSE && kc.p0 == 25) return go<2, 4, 25, CK_DENSE>(adapt, warm, prm, st);
 #else
   if (kc.p1 == CK_DENSE) {
