@@ -1,0 +1,167 @@
+// fastsim.cpp -- CPU run of the role-split headline path's bookkeeper (walnuts_amd/csrc/wn_fast.h,
+// FastBook) with a scalar stand-in for the T waves of wn_k_fast.hip: same command / partial-sum
+// protocol, same two-tick lag, one chain at a time, plain loops for the vectors.
+//
+// TEST TOOL ONLY (see hostsim.cpp): checks the issue / retire automaton against the oracle in a
+// container without a GPU.  Never loaded by the walnuts_amd package.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "wn_fast.h"
+
+using namespace wn;
+using namespace wn::fast;
+
+namespace {
+
+struct TSim {  // what the four T waves hold for ONE chain
+  int D, M, NLC;
+  const Params* prm;
+  int cl;
+  std::vector<double> q, v, g, qb, vb, VL, zn;
+  std::vector<double> qhist[2];
+  std::vector<double> prop[2];
+  std::vector<std::vector<double>> lq, lv, sq, sv;  // LDS-cached levels, memory slots
+  double sums[4 + 2 * (MAX_M + 2)];
+
+  void grad() {
+    if (prm->tpar == nullptr) { for (int r = 0; r < D; ++r) g[r] = -q[r]; return; }
+    if (dense) {
+      for (int r = 0; r < D; ++r) {
+        double a = 0.0;
+        for (int c = 0; c < D; ++c) a += -prm->tpar[(size_t)r * D + c] * q[c];
+        g[r] = a;
+      }
+    } else {
+      for (int r = 0; r < D; ++r) g[r] = -(prm->tpar[r] * q[r]);
+    }
+  }
+  bool dense;
+
+  void dots(const std::vector<double>& qo, const std::vector<double>& vo, double& d1, double& d2) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int e = 0; e < D; ++e) {
+      const double dq = q[e] - qo[e];
+      a1 += v[e] * dq;
+      a2 += vo[e] * dq;
+    }
+    d1 = a1; d2 = a2;
+  }
+
+  void tick(uint32_t t, const Cmd& c) {
+    const int NFAST = 2 + NLC;
+    for (auto& s : sums) s = 0.0;
+    if (c.op & OP_PICK) prop[(c.op & OP_IPPICK) ? 1 : 0] = qhist[t & 1];
+    if (c.op & OP_NEWITER) {
+      if (c.op & OP_INIT) {
+        for (int e = 0; e < D; ++e) q[e] = prm->q0[(size_t)cl * D + e];
+        prop[0] = q;
+      } else {
+        q = prop[(c.op & OP_IPNEW) ? 1 : 0];
+      }
+      double* row = prm->samples + ((size_t)cl * (prm->numIter + 1) + c.n) * prm->dg;
+      if (prm->generated == G_Q0_SUMSQ) {
+        row[0] = q[0];
+        double s = 0.0;
+        for (int e = 0; e < D; ++e) s += q[e] * q[e];
+        sums[Q_GEN] = s;
+      } else {
+        const int k = prm->generated == G_FIRSTK ? prm->gen_k : D;
+        for (int e = 0; e < k; ++e) row[e] = q[e];
+      }
+      if (!(c.op & (OP_INIT | OP_LAST))) {
+        double kp = 0.0;
+        for (int e = 0; e < D; ++e) { v[e] = zn[e]; kp += v[e] * v[e]; }
+        sums[Q_KEINIT] = kp;
+        qb = q; vb = v;
+      }
+    }
+    if (c.op & OP_SWAP) { q.swap(qb); v.swap(vb); }
+    const double hs = (c.op & OP_STEP) ? c.hs : 0.0, hs2 = 0.5 * hs;
+    for (int e = 0; e < D; ++e) { v[e] = v[e] + hs2 * g[e]; q[e] = q[e] + hs * v[e]; }
+    qhist[t & 1] = q;
+    grad();
+    double lp = 0.0, ke = 0.0;
+    for (int e = 0; e < D; ++e) { v[e] = v[e] + hs2 * g[e]; lp += q[e] * g[e]; ke += v[e] * v[e]; }
+    sums[Q_LP] = lp; sums[Q_KE] = ke;
+    if (c.op & OP_STEP) {
+      const int i = (int)((c.op >> OP_I_SHIFT) & 31u), n = (int)c.n;
+      const int nchk = nchecks(i, n);
+      for (int j = 0; j < nchk; ++j) {
+        if (!need_check(i, n, j)) continue;
+        double d1, d2;
+        if (j == 0) dots(qb, vb, d1, d2);
+        else if (j == 1) dots(qhist[(t - 1) & 1], VL, d1, d2);
+        else if (j < NFAST) dots(lq[j - 2], lv[j - 2], d1, d2);
+        else { const int sl = slot_of_leaf(n + 1 - (1 << j)); dots(sq[sl], sv[sl], d1, d2); }
+        sums[Q_DOT0 + 2 * j] = d1; sums[Q_DOT0 + 2 * j + 1] = d2;
+      }
+      if (i >= 1 && (n & 1) == 0) {
+        VL = v;
+        if (i >= 2 && (n & 3) == 0) {
+          for (int j = 2; j < NFAST; ++j)
+            if (j <= i && (n & ((1 << j) - 1)) == 0) { lq[j - 2] = q; lv[j - 2] = v; }
+          if (n == 0 ? (i >= NFAST) : (__builtin_ctz((unsigned)n) >= NFAST)) { const int sl = slot_of_leaf(n); sq[sl] = q; sv[sl] = v; }
+        }
+      }
+    }
+  }
+};
+
+struct HostIO {
+  const Params* prm;
+  int cl;
+  const double* sums;
+  double sum(int k) const { return sums[k]; }
+  void dots(int j, double& d1, double& d2) const { d1 = sums[Q_DOT0 + 2 * j]; d2 = sums[Q_DOT0 + 2 * j + 1]; }
+  void write_gen(size_t row, double v) const { prm->samples[((size_t)cl * (prm->numIter + 1) + row) * prm->dg + 1] = v; }
+  void write_diag(size_t row, const double* d) const {
+    double* o = prm->diag + ((size_t)cl * prm->numIter + row) * NDIAG;
+    for (int k = 0; k < NDIAG; ++k) o[k] = d[k];
+  }
+};
+
+}  // namespace
+
+// returns the number of ticks the slowest chain took (>= 0) or -1 when a chain exceeded its bound
+extern "C" long fastsim_run(Params* prm, int target, int nlc, double* idle_frac) {
+  const int D = prm->D;
+  long worst = 0;
+  double steps = 0, ticks = 0;
+  for (int cl = 0; cl < prm->C; ++cl) {
+    TSim T;
+    T.D = D; T.M = prm->M; T.NLC = nlc; T.prm = prm; T.cl = cl; T.dense = target == T_DENSEGAUSS;
+    for (auto* x : {&T.q, &T.v, &T.g, &T.qb, &T.vb, &T.VL, &T.zn, &T.qhist[0], &T.qhist[1], &T.prop[0], &T.prop[1]}) x->assign(D, 0.0);
+    T.lq.assign(nlc + 1, std::vector<double>(D, 0.0)); T.lv = T.lq;
+    T.sq.assign(prm->M + 2, std::vector<double>(D, 0.0)); T.sv = T.sq;
+    FastBook B;
+    B.init(prm->chain0 + (uint32_t)cl, true, prm->numIter);
+    Cmd cur, nxt;
+    cur.hs = 0.0; cur.n = 0; cur.op = OP_NEWITER | OP_INIT;
+    double psums[4 + 2 * (MAX_M + 2)] = {0};
+    const double cap = 64.0 + 1.3 * (double)prm->numIter * ((double)(1u << prm->M) + 4.0 * prm->M + 16.0);
+    uint32_t t = 0;
+    for (;; ++t) {
+      if ((double)t > cap) return -1;
+      // momentum normals: the B wave refills the buffer of a chain whose next iteration has none yet
+      if (B.zwant != B.zready && B.zwant >= 1) {
+        for (int e = 0; e < D; ++e) T.zn[e] = rng_normal(prm->seed, B.chain, (uint32_t)B.zwant, (uint32_t)e);
+        B.zready = B.zwant;
+      }
+      HostIO io{prm, cl, psums};
+      nxt = B.tick(*prm, io, t + 1);  // retires tick t-1, issues tick t+1
+      T.tick(t, cur);                 // tick t
+      memcpy(psums, T.sums, sizeof(psums));
+      if (cur.op & OP_STEP) steps += 1;
+      cur = nxt;
+      if (B.finished()) break;
+    }
+    ticks += t + 1;
+    if ((long)t + 1 > worst) worst = t + 1;
+  }
+  if (idle_frac) *idle_frac = 1.0 - steps / ticks;
+  return worst;
+}
+extern "C" int fastsim_params_size() { return (int)sizeof(Params); }

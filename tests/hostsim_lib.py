@@ -102,3 +102,47 @@ def walnuts(target, q0, integrator=0, tpar=None, H0=0.2, stepSizeRandScale=0.2, 
         return dict(samples=samples.transpose(0, 2, 1).copy(), diagnostics=diag, trace=trace, trace_n=tn,
                     orbitMin=omin.transpose(0, 2, 1).copy(), orbitMax=omax.transpose(0, 2, 1).copy())
     return dict(samples=samples.transpose(0, 2, 1).copy(), diagnostics=diag, trace=trace, trace_n=tn)
+
+
+# ---- role-split headline path: the bookkeeper of walnuts_amd/csrc/wn_fast.h on the CPU (tests/hostsim/fastsim.cpp)
+_FSRC = os.path.join(_HERE, "hostsim", "fastsim.cpp")
+_FSO = os.path.join(_HERE, "hostsim", "libfastsim.so")
+_flib = None
+
+
+def fast_lib():
+    global _flib
+    if _flib is None:
+        deps = [_FSRC] + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")]
+        if not os.path.exists(_FSO) or os.path.getmtime(_FSO) < max(os.path.getmtime(d) for d in deps):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared",
+                                   "-I" + _CSRC, "-o", _FSO, _FSRC])
+        _flib = C.CDLL(_FSO)
+        _flib.fastsim_run.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_double)]
+        _flib.fastsim_run.restype = C.c_long
+        assert _flib.fastsim_params_size() == C.sizeof(Params)
+    return _flib
+
+
+def fast_walnuts(target, q0, tpar=None, H0=0.2, stepSizeRandScale=0.2, delta0=0.05, numIter=10, M=10, generated=0, gen_k=0,
+                 seed=0, chain0=0, nlc=2):
+    """fixedLeapFrog on a std / diagonal / dense Gaussian through FastBook + the scalar T-wave stand-in."""
+    q0 = np.ascontiguousarray(np.atleast_2d(np.asarray(q0, float)))
+    Cn, D = q0.shape
+    prm = Params()
+    prm.D = D; prm.C = Cn; prm.mode = 0
+    prm.integrator = 0; prm.M = M; prm.numIter = numIter; prm.maxC = 10
+    prm.generated = generated; prm.gen_k = gen_k
+    dg = {0: D, 1: 2, 2: gen_k}[generated]
+    prm.dg = dg
+    prm.H = H0; prm.s = stepSizeRandScale; prm.delta = delta0; prm.R2Pprob0 = 2.0 / 3.0
+    prm.wtSumThresh = math.exp(-699.0)
+    prm.seed = seed; prm.chain0 = chain0
+    tp = np.ascontiguousarray(np.asarray(tpar, float)) if tpar is not None else None
+    samples = np.zeros((Cn, numIter + 1, dg)); diag = np.zeros((Cn, numIter, 24))
+    prm.q0 = _p(q0); prm.samples = _p(samples); prm.diag = _p(diag); prm.tpar = _p(tp)
+    idle = C.c_double(0.0)
+    ticks = fast_lib().fastsim_run(C.byref(prm), target, nlc, C.byref(idle))
+    if ticks < 0:
+        raise RuntimeError("fastsim: a chain exceeded its tick bound")
+    return dict(samples=samples.transpose(0, 2, 1).copy(), diagnostics=diag, ticks=ticks, idle_frac=idle.value)

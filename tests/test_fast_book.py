@@ -1,0 +1,93 @@
+"""CPU tests (no GPU) of the role-split headline path's bookkeeper (walnuts_amd/csrc/wn_fast.h): the
+issue / retire automaton with its two-tick lag, run by tests/hostsim/fastsim.cpp with a scalar stand-in for
+the T waves, must reproduce the oracle -- every diagnostics column, every draw -- on the reference goldens
+that use fixedLeapFrog on a Gaussian and on seeded edge cases (M reached, non-finite energies, zero weights)."""
+import numpy as np
+import pytest
+
+import hostsim_lib as hs
+import oracle_lib as ol
+import test_oracle_golden as tg
+
+INT_DIAG = (0, 1, 4, 5, 6, 7, 8, 9, 12, 13, 19, 20, 21, 22)
+
+
+def check(h, o, k=0, what=""):
+    d, rd = h["diagnostics"][k], o["diagnostics"]
+    for col in INT_DIAG:
+        np.testing.assert_array_equal(d[:, col], rd[:, col], err_msg=f"{what} diag col {col}")
+    tg.close(d, rd, rtol=1e-10, atol=1e-12)
+    tg.close(h["samples"][k], o["samples"], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["std3_fixed", "dense8_fixed", "std100_fixed", "std3_fixed_M3"])
+def test_bookkeeper_reproduces_reference_goldens(name):
+    c, ref = tg.load_case(name)
+    seed = int(tg.TR["seed"][0])
+    o = tg.run_oracle(c, ref, tape=False)
+    for nlc in (0, 1, 2, 3):
+        h = hs.fast_walnuts(c["target"], c["q0"], tpar=c["tpar"] if c["target"] != ol.T_STDGAUSS else None, H0=c["H0"], delta0=c["delta0"],
+                            numIter=c["numIter"], M=c["M"], generated=c["generated"], gen_k=c["gen_k"], seed=seed,
+                            chain0=c["chain"], nlc=nlc)
+        check(h, o, what=f"{name} nlc={nlc}")
+        # the reference's own draws (golden fixture), not only the oracle's
+        tg.close(h["samples"][0], ref["samples"], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("M", [1, 2, 4, 9])
+@pytest.mark.parametrize("gen", [0, 1, 2])
+def test_bookkeeper_depths_and_generated_kinds(M, gen):
+    rng = np.random.default_rng(M * 10 + gen)
+    D = 7
+    lam = np.logspace(0, 2, D)
+    q0 = rng.normal(size=(3, D)) * np.sqrt(lam)
+    kw = dict(H0=0.45, numIter=9, M=M, generated=gen, gen_k=3 if gen == 2 else 0, seed=77 + M)
+    h = hs.fast_walnuts(ol.T_DIAGGAUSS, q0, tpar=1.0 / lam, chain0=40, **kw)
+    for k in range(3):
+        o = ol.walnuts(ol.T_DIAGGAUSS, q0[k], integrator=ol.I_FIXED, tpar=1.0 / lam, chain=40 + k, **kw)
+        check(h, o, k, what=f"M={M} gen={gen} chain {k}")
+    assert 0.0 < h["idle_frac"] < 0.9  # M = 1: one leaf per iteration among the start-up ticks
+
+
+@pytest.mark.parametrize("scale,H0,expect", [(3e153, 0.05, {4}), (3e153, 0.5, {4, 5}), (1e154, 0.5, {999}), (1e200, 0.05, {999})])
+def test_bookkeeper_huge_energies_zero_and_infinite_weights(scale, H0, expect):
+    """Energies near the top of the double range: multinomial weights exp(-H + H0) are exactly 0 or inf, so
+    WnewSum stays 0 (the uniform of WALNUTS.py:426 is then NOT drawn, which shifts every later draw of the
+    iteration: the bookkeeper may not issue step sizes ahead) or becomes inf / NaN; beyond 1e154 the energy
+    itself overflows (stop code 999, Q3/Q4)."""
+    D = 5
+    q0 = np.random.default_rng(3).normal(size=(3, D)) * scale
+    kw = dict(H0=H0, numIter=8, M=8, generated=1, seed=11)
+    h = hs.fast_walnuts(ol.T_STDGAUSS, q0, chain0=3, **kw)
+    seen = set()
+    for k in range(3):
+        o = ol.walnuts(ol.T_STDGAUSS, q0[k], integrator=ol.I_FIXED, chain=3 + k, **kw)
+        with np.errstate(all="ignore"):
+            check(h, o, k, what=f"scale={scale} H0={H0} chain {k}")
+        seen |= set(o["diagnostics"][:, 19].astype(int).tolist())
+    assert expect <= seen, seen
+
+
+@pytest.mark.parametrize("amax", [30.0, 1e6])
+def test_bookkeeper_unstable_step_sizes(amax):
+    """Step sizes beyond the leapfrog stability limit in one coordinate (h*sqrt(a) > 2)."""
+    a = np.array([1.0, 1.0, 1.0, amax])
+    q0 = np.random.default_rng(3).normal(size=(4, 4)) / np.sqrt(a)
+    kw = dict(H0=0.5, numIter=14, M=10, generated=1, seed=11)
+    h = hs.fast_walnuts(ol.T_DIAGGAUSS, q0, tpar=a, chain0=3, **kw)
+    for k in range(4):
+        o = ol.walnuts(ol.T_DIAGGAUSS, q0[k], integrator=ol.I_FIXED, tpar=a, chain=3 + k, **kw)
+        check(h, o, k, what=f"amax={amax} chain {k}")
+
+
+def test_bookkeeper_config2_shape_many_chains():
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_dense_problem
+    A, q0 = make_dense_problem(100, 1e4, 3, 20251121)
+    kw = dict(H0=0.5, numIter=6, M=10, seed=20251121, generated=1)
+    h = hs.fast_walnuts(ol.T_DENSEGAUSS, q0, tpar=A.ravel(), **kw)
+    for k in range(3):
+        o = ol.walnuts(ol.T_DENSEGAUSS, q0[k], integrator=ol.I_FIXED, tpar=A.ravel(), chain=k, **kw)
+        check(h, o, k)
+    assert h["idle_frac"] < 0.06  # two idle ticks per doubling + one per iteration start
