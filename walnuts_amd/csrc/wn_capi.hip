@@ -400,6 +400,7 @@ struct wn_engine {
   KernelChoice kc{};
   bool have_kc = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int* kabort = nullptr;  // device flag: a kernel's bounded loop gave up (internal error), checked by wn_last_run_ms
   bool timed = false;
   std::string err;
 };
@@ -465,6 +466,9 @@ int wn_create(const wn_config* cfg, wn_engine** out) {
   r = hipEventCreate(&e->ev0);
   if (r == hipSuccess) r = hipEventCreate(&e->ev1);
   if (r != hipSuccess) { g_create_err = std::string("hipEventCreate: ") + hipGetErrorString(r); delete e; return WN_E_HIP; }
+  r = hipMalloc((void**)&e->kabort, 64);
+  if (r == hipSuccess) r = hipMemset(e->kabort, 0, 64);
+  if (r != hipSuccess) { g_create_err = std::string("hipMalloc: ") + hipGetErrorString(r); (void)hipGetLastError(); delete e; return r == hipErrorOutOfMemory ? WN_E_ALLOC : WN_E_HIP; }
   *out = e;
   return WN_OK;
 }
@@ -481,6 +485,7 @@ int wn_destroy(wn_engine* e) {
   if (e->sp_done) hipFree(e->sp_done);
   if (e->cl_red) hipFree(e->cl_red);
   if (e->cl_cnt) hipFree(e->cl_cnt);
+  if (e->kabort) hipFree(e->kabort);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   delete e;
@@ -569,6 +574,12 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
       HIPCHK(e, hipMemcpy2D(e->apad, (size_t)e->DP * sizeof(double), params_dev, (size_t)D * sizeof(double),
                             (size_t)D * sizeof(double), (size_t)D, hipMemcpyDeviceToDevice));
     }
+  }
+  if (kc.layout == 1 && e->cfg.integrator == WN_I_FIXED && e->cfg.warmup_iter == 0 && e->cfg.M <= 12 && !getenv("WN_COOP_LEGACY")) {
+    // plain sampling runs of this engine go to the role-split kernel (wn_k_fast.hip); traced / orbit-statistics
+    // runs and wn_integrator_step use the one-stream kernel of the same layout
+    const int NT = kc.p0 <= 16 ? 1 : 2;
+    snprintf(kc.name, sizeof(kc.name), "wn_fast_kernel<NT=%d,KS=%d,%s>", NT, kc.p0, kc.p1 == CK_DENSE ? "dense" : "diag");
   }
   e->kc = kc;
   e->have_kc = true;
@@ -683,7 +694,9 @@ static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
     HIPCHK(e, hipMemsetAsync(e->cl_cnt, 0, ((size_t)e->cfg.n_chains + 16) * sizeof(unsigned), st));
   }
   const Params& p_ = pc;
-  hipError_t r = e->kc.layout == 0 ? launch_lane(e->kc, adapt, warm, p_, st)
+  const bool coop_legacy = getenv("WN_COOP_LEGACY") != nullptr;  // diagnostic / A-B tests: one-stream kernel (read per launch)
+  hipError_t r = (!coop_legacy && fast_eligible(e->kc, adapt, warm, p_)) ? launch_fast(e->kc, p_, e->kabort, st)
+               : e->kc.layout == 0 ? launch_lane(e->kc, adapt, warm, p_, st)
                : e->kc.layout == 1 ? launch_coop(e->kc, adapt, warm, p_, st) : launch_wave(e->kc, adapt, warm, p_, st);
   if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
   if (timed) { HIPCHK(e, hipEventRecord(e->ev1, st)); e->timed = true; }
@@ -905,6 +918,13 @@ int wn_last_run_ms(wn_engine* e, float* ms) {
   if (!e->timed) { e->err = "no timed run yet"; return WN_E_ARG; }
   HIPCHK(e, hipEventSynchronize(e->ev1));
   HIPCHK(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
+  int ab = 0;
+  HIPCHK(e, hipMemcpy(&ab, e->kabort, sizeof(int), hipMemcpyDeviceToHost));
+  if (ab) {
+    (void)hipMemset(e->kabort, 0, sizeof(int));
+    e->err = "a kernel's tick loop exceeded its bound and gave up (internal error); the results of that run are incomplete";
+    return WN_E_HIP;
+  }
   return WN_OK;
 }
 

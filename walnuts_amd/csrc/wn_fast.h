@@ -48,7 +48,8 @@ enum {
   OP_PICK = 32u,     // copy the position of tick t-2 into proposal[ippick]
   OP_IPPICK = 64u,   // bit: ippick
   OP_IPNEW = 128u,   // bit: ipnew
-  OP_I_SHIFT = 8     // bits 8..12: doubling index i of an OP_STEP (n = leaf index inside the doubling)
+  OP_I_SHIFT = 8,    // bits 8..12: doubling index i of an OP_STEP (n = leaf index inside the doubling)
+  OP_DONE = 1u << 15 // every chain of the group has finished: all waves leave the tick loop
 };
 struct alignas(16) Cmd {
   double hs;
@@ -73,6 +74,21 @@ WN_HD bool need_check(int i, int n, int j) {
 }
 WN_HD int slot_of_leaf(int m) { return m == 0 ? 0 : __builtin_ctz((unsigned)m); }
 
+// U-turn verdicts of leaf n of doubling i from the summed dot products: bit j set when check j fired --
+// stopCondition (WALNUTS.py:95-97) with the older state on the side opposite to xi.  `src.dots(j, d1, d2)`.
+template <class Src>
+WN_HD uint32_t fire_of(int i, int n, int xi, Src& src) {
+  uint32_t firemask = 0;
+  const int nchk = nchecks(i, n);
+  for (int j = 0; j < nchk; ++j) {
+    if (!need_check(i, n, j)) continue;
+    double d1, d2;
+    src.dots(j, d1, d2);
+    if (((double)xi * d1 < 0.0) || ((double)xi * d2 < 0.0)) firemask |= (1u << j);
+  }
+  return firemask;
+}
+
 // ---- the bookkeeper: every per-chain scalar of one chain ---------------------------------------
 struct FastBook {
   enum { ST_NEEDITER = 0, ST_FIRST, ST_RUN, ST_DRAIN, ST_DEAD };
@@ -81,6 +97,9 @@ struct FastBook {
     int kind, n, row;
     bool discard, last, init;
     double h;
+    // member-wise copy: an aggregate copy (memcpy) keeps the whole bookkeeper in scratch memory on the device
+    WN_HD void set(const Slot& o) { kind = o.kind; n = o.n; row = o.row; discard = o.discard; last = o.last; init = o.init; h = o.h; }
+    WN_HD void clear() { kind = 0; n = 0; row = 0; discard = false; last = false; init = false; h = 0.0; }
   };
   // WALNUTS.py scalars (names as in wn_chain.h ChainScalars)
   double H0, Ha, Hb, lpP, lpPL, WoldSum, WnewSum, h2;
@@ -92,8 +111,8 @@ struct FastBook {
   int pick_ip, st;
   int zwant, zready;  // momentum normals: iteration wanted next / iteration the buffer holds
   Slot s0, s1;
-  uint32_t cblk[2];
-  double cu[2][2];
+  uint32_t cblkI, cblkR;  // cached Philox block of the uniform stream, issue side / retire side
+  double cuI0, cuI1, cuR0, cuR1;
   uint32_t chain;  // global chain id
 
   WN_HD void init(uint32_t chain_global, bool inrange, int numIter) {
@@ -106,31 +125,40 @@ struct FastBook {
     pend_pick = false; swap_next = false; pick_ip = 0;
     st = inrange ? ST_NEEDITER : ST_DEAD;
     zwant = (inrange && numIter >= 1) ? 1 : 0; zready = 0;
-    s0.kind = K_NONE; s0.n = s0.row = 0; s0.discard = s0.last = s0.init = false; s0.h = 0.0;
-    s1 = s0;
+    s0.clear();
+    s1.clear();
     if (inrange) { s1.kind = K_NEWITER; s1.init = true; }  // tick 0: every chain loads q0 (OP_INIT)
-    cblk[0] = cblk[1] = 0xFFFFFFFFu;
-    cu[0][0] = cu[0][1] = cu[1][0] = cu[1][1] = 0.0;
+    cblkI = cblkR = 0xFFFFFFFFu;
+    cuI0 = cuI1 = cuR0 = cuR1 = 0.0;
   }
 
-  // k-th uniform of (chain, iteration) -- wn_rng.h stream 0 -- through a two-block cache
-  WN_HD double U(const Params& prm, uint32_t k) {
-    const uint32_t blk = k >> 1, sl = blk & 1u;
-    if (cblk[sl] != blk) {
+  // k-th uniform of (chain, iteration) -- wn_rng.h stream 0.  Two one-block caches chosen at the call site: the
+  // issue side reads ahead (step sizes, direction bits) while the retire side follows (picks, accepts), one
+  // Philox block each per leaf pair.  (One cache indexed by block parity -- as an array or as selects between
+  // members -- kept the whole bookkeeper in scratch memory: SROA gives up on addresses chosen at run time.)
+  WN_HD double Ui(const Params& prm, uint32_t k) {
+    const uint32_t blk = k >> 1;
+    if (cblkI != blk) {
       Philox4 r = philox4x32_10(blk, (uint32_t)iter, chain, 0u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
-      cu[sl][0] = u53(r.w[0], r.w[1]);
-      cu[sl][1] = u53(r.w[2], r.w[3]);
-      cblk[sl] = blk;
+      cuI0 = u53(r.w[0], r.w[1]); cuI1 = u53(r.w[2], r.w[3]); cblkI = blk;
     }
-    return (k & 1u) ? cu[sl][1] : cu[sl][0];
+    return (k & 1u) ? cuI1 : cuI0;
+  }
+  WN_HD double Ur(const Params& prm, uint32_t k) {
+    const uint32_t blk = k >> 1;
+    if (cblkR != blk) {
+      Philox4 r = philox4x32_10(blk, (uint32_t)iter, chain, 0u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
+      cuR0 = u53(r.w[0], r.w[1]); cuR1 = u53(r.w[2], r.w[3]); cblkR = blk;
+    }
+    return (k & 1u) ? cuR1 : cuR0;
   }
   WN_HD int dir(const Params& prm, int j) {  // WALNUTS.py:216,283: B = floor(uniform(0,2,size=M)); xi = (-1)**B[j]
-    const double u0 = 0.0 + (2.0 - 0.0) * U(prm, (uint32_t)j);
+    const double u0 = 0.0 + (2.0 - 0.0) * Ui(prm, (uint32_t)j);
     return ((int)floor(u0) != 0) ? -1 : 1;
   }
   WN_HD double h_of(const Params& prm, uint32_t k) {  // numpy legacy uniform(low, high) = low + (high-low)*U
     const double low = prm.H * (1 - prm.s), high = prm.H * (1 + prm.s);
-    return low + (high - low) * U(prm, k);
+    return low + (high - low) * Ui(prm, k);
   }
 
   WN_HD void start_doubling_common() {  // WALNUTS.py:283-294
@@ -176,7 +204,7 @@ struct FastBook {
       end_iteration(prm, io);
       return;
     }
-    if (!(U(prm, ku++) < WnewSum / WoldSum)) revert_prop();  // :613-616
+    if (!(Ur(prm, ku++) < WnewSum / WoldSum)) revert_prop();  // :613-616
     const bool joined = (firemask & 1u) != 0;                // :622
     if (joined) {                                            // :625-634 (lwtSum = 0: never "both ends passive")
       stopCode = 4;
@@ -199,20 +227,10 @@ struct FastBook {
 
   // retire the leaf the T waves integrated in the tick whose sums `io` holds (wn_chain.h after_micro + step_done)
   template <class IO>
-  WN_HD void retire_step(const Params& prm, IO& io, const Slot& s) {
-    const int n = s.n;
-    const double h = s.h;
+  WN_HD void retire_step(const Params& prm, IO& io, const int n, const double h) {
     const double lpn = 0.5 * io.sum(Q_LP);          // lp = 1/2 q.g for the Gaussian targets
     const double Hn = -lpn + 0.5 * io.sum(Q_KE);    // adaptiveIntegrators.py:55
-    uint32_t firemask = 0;
-    const int nchk = nchecks(i, n);
-    for (int j = 0; j < nchk; ++j) {
-      if (!need_check(i, n, j)) continue;
-      double d1, d2;
-      io.dots(j, d1, d2);
-      // stopCondition (WALNUTS.py:95-97) with the older state on the side opposite to xi
-      if (((double)xi * d1 < 0.0) || ((double)xi * d2 < 0.0)) firemask |= (1u << j);
-    }
+    const uint32_t firemask = io.firemask(i, n, xi);  // bit j: U-turn check j of this leaf fired (fire_of)
     const bool first = (i == 0) || ((n & 1) == 0);
     const int idx = xi > 0 ? b + 1 + n : a - 1 - n;
     if (i == 0) ku += 1;                 // :298  the step size was drawn before the step
@@ -220,7 +238,13 @@ struct FastBook {
     nevalF += 1;
     if (isnan(Hn)) Hnan = true;
     Hmin = Hn < Hmin ? Hn : Hmin; Hmax = Hn > Hmax ? Hn : Hmax;
-    if (xi > 0) { maxFint = idx; timeLenF_ += h; } else { maxBint = idx; timeLenB_ += h; }
+    {  // select form: `if (xi > 0) timeLenF_ += h; else timeLenB_ += h;` became a store through a phi of the two
+       // members' addresses, which kept the whole bookkeeper in scratch memory
+      const bool fw = xi > 0;
+      const double tf = timeLenF_ + h, tb = timeLenB_ + h;
+      maxFint = fw ? idx : maxFint; maxBint = fw ? maxBint : idx;
+      timeLenF_ = fw ? tf : timeLenF_; timeLenB_ = fw ? timeLenB_ : tb;
+    }
     if (i == 0) orbitLen_ += h;  // :300
     n_rt = n + 1;
     if (!isfinite(Hn)) {         // :316-319, 414-417, 457-459 (Q3, Q4)
@@ -234,7 +258,7 @@ struct FastBook {
       pick_state(idx, lpn);
     } else {
       WnewSum += Wnew;
-      if (WnewSum > prm.wtSumThresh && U(prm, ku++) < Wnew / WnewSum) pick_state(idx, lpn);  // :426
+      if (WnewSum > prm.wtSumThresh && Ur(prm, ku++) < Wnew / WnewSum) pick_state(idx, lpn);  // :426
       orbitLen_ += h;
     }
     Ha = Hn;
@@ -248,14 +272,14 @@ struct FastBook {
   }
 
   template <class IO>
-  WN_HD void retire_newiter(const Params& prm, IO& io, const Slot& s) {
-    if (prm.generated == G_Q0_SUMSQ) io.write_gen((size_t)s.row, io.sum(Q_GEN));
-    if (s.init) {  // f0 = lpFun(q0)  (WALNUTS.py:177).  Iteration 1 was issued one tick ago, before this was
+  WN_HD void retire_newiter(const Params& prm, IO& io, const int row, const bool init_, const bool last_) {
+    if (prm.generated == G_Q0_SUMSQ) io.write_gen((size_t)row, io.sum(Q_GEN));
+    if (init_) {  // f0 = lpFun(q0)  (WALNUTS.py:177).  Iteration 1 was issued one tick ago, before this was
       lpP = 0.5 * io.sum(Q_LP);  // known: its copy of qPropLast's log density (start_doubling_common) is set here
       lpPL = lpP;
       return;
     }
-    if (s.last) return;
+    if (last_) return;
     // Hs[I0] = -f0 + 0.5*sum(v**2) (:256); multinomialLscale (:259)
     H0 = -lpP + 0.5 * io.sum(Q_KEINIT);
     Ha = Hb = H0;
@@ -266,11 +290,11 @@ struct FastBook {
   // One bookkeeper tick: retire tick t-1, issue tick t+1.  `tn` = t+1.
   template <class IO>
   WN_HD Cmd tick(const Params& prm, IO& io, uint32_t tn) {
-    if (s0.kind == K_NEWITER) retire_newiter(prm, io, s0);
-    else if (s0.kind == K_STEP && !s0.discard) retire_step(prm, io, s0);
-    s0 = s1;
+    if (s0.kind == K_NEWITER) retire_newiter(prm, io, s0.row, s0.init, s0.last);
+    else if (s0.kind == K_STEP && !s0.discard) retire_step(prm, io, s0.n, s0.h);
+    s0.set(s1);
     Slot ns;
-    ns.kind = K_NONE; ns.n = 0; ns.row = 0; ns.discard = ns.last = ns.init = false; ns.h = 0.0;
+    ns.clear();
     Cmd c;
     c.hs = 0.0; c.op = 0u; c.n = 0u;
     if (pend_pick) { c.op |= OP_PICK | (pick_ip ? OP_IPPICK : 0u); pend_pick = false; }
@@ -287,7 +311,7 @@ struct FastBook {
           WoldSum = 1.0; WnewSum = 0.0;
           stopCode = 0; nevalF = 0; Lold_ = L_ = 0; orbitLen_ = orbitLenSam_ = 0.0; NdS = NdC = 0;
           indexStat_ = indexStatOld_ = 0.0; timeLenF_ = timeLenB_ = 0.0;
-          cblk[0] = cblk[1] = 0xFFFFFFFFu;  // the uniform cache is keyed by block only
+          cblkI = cblkR = 0xFFFFFFFFu;  // the uniform caches are keyed by block only
           i = 0;
           xi = dir(prm, 0);
           ku = (uint32_t)prm.M;
@@ -334,7 +358,7 @@ struct FastBook {
     } else if (st == ST_DRAIN) {
       if (swap_next) { c.op |= OP_SWAP; swap_next = false; }
     }
-    s1 = ns;
+    s1.set(ns);
     return c;
   }
   WN_HD bool finished() const { return st == ST_DEAD && s0.kind == K_NONE && s1.kind == K_NONE && !pend_pick; }

@@ -1,0 +1,451 @@
+// wn_k_fast.hip -- role-split kernel of the headline path: fixedLeapFrog on a dense / diagonal Gaussian,
+// 16 chains per workgroup in the MFMA layout of wn_policy_coop.h, four T waves (vectors + MFMA) and one
+// B wave (the bookkeeper of wn_fast.h) per workgroup.  See wn_fast.h for the protocol.
+//
+// One tick of the workgroup:
+//
+//   T waves                                               B wave
+//   ------------------------------------------------     ---------------------------------------------
+//   read command C[t]; proposal store / iteration        read + sum the partials P[t-1] (lp, KE, U-turn
+//   start / end swap on command; first half of the       dots -> fire mask) of the leaf being retired
+//   leapfrog step; publish Q[t] to LDS
+//   ---------------------------- barrier A (LDS only) -----------------------------------------------
+//   G = -A Q (50 x v_mfma_f64_16x16x4_f64 per wave),     FastBook::tick: retire tick t-1 (energies, weights,
+//   second half step, per-wave partials P[t] of lp,      multinomial pick, doubling / iteration ends,
+//   KE and the U-turn dots due at this leaf, sub-tree    diagnostics row), issue command C[t+1]; momentum
+//   endpoint stores                                      normals of one chain's next iteration
+//   ---------------------------- barrier B (LDS only) -----------------------------------------------
+//
+// LDS (doubles): Q exchange 2 x [tp][e][lane] (double-buffered: buffer t&1 still holds the position of
+// tick t-2 when a pick of that leaf is commanded, buffer (t-1)&1 is the first state of the leaf pair),
+// passive orbit end (q, v), NLC cached sub-tree levels (q, v), partials [quantity][tp][chain], commands.
+// Memory: deeper sub-tree levels, the two proposal buffers (positions only: the gradient of a restart
+// state comes out of the idle tick's MFMA) and the momentum normals, in the engine's workspace.
+#include "wn_launch.h"  // hip_runtime first
+
+#include "wn_fast.h"
+#include "wn_policy_coop.h"  // d4_t, CK_DENSE / CK_DIAG
+
+namespace wn {
+using namespace fast;
+
+#define WN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <int NT, int KS, int TK, int NLC>
+struct FastGeom {
+  static constexpr int W = 4;                 // T waves
+  static constexpr int NE = NT * 4;           // doubles per lane and vector
+  static constexpr int VECD = W * NE * 64;    // one D-vector of the 16-chain group: [tp][e][lane]
+  static constexpr int DPAD = 16 * NT * W;
+  static constexpr int MP = 12;               // largest M (sizes the partials)
+  static constexpr int NQ = Q_DOT0 + 2 * (MP + 1);
+  static constexpr int NFAST = 2 + NLC;
+  // LDS map, in doubles
+  static constexpr int OFF_Q = 0;                          // 2 x VECD
+  static constexpr int OFF_COLD = OFF_Q + 2 * VECD;        // qb, vb
+  static constexpr int OFF_LC = OFF_COLD + 2 * VECD;       // NLC x (q, v)
+  static constexpr int OFF_PART = OFF_LC + NLC * 2 * VECD; // NQ x [tp][chain]
+  static constexpr int OFF_CMD = OFF_PART + NQ * 64;       // 2 x 16 commands of 2 doubles
+  static constexpr int LDS_DOUBLES = OFF_CMD + 2 * 16 * 2;
+  static_assert(LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget (160 KiB per CU)");
+  // workspace of one group, in doubles: (M+1) slots x (q, v), 2 proposals, momentum normals [chain][DPAD]
+  static constexpr size_t group_doubles(int M) { return (size_t)((M + 1) * 2 + 2) * VECD + (size_t)16 * DPAD; }
+};
+
+// x[l] + x[l^16] + x[l^32] + x[l^48] in every lane (CoopPolicy::rowsum4)
+__device__ __forceinline__ double fast_rowsum4(double x) {
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  u2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  u2_t b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double y = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  lo = __double2loint(y); hi = __double2hiint(y);
+  a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// T waves
+// ------------------------------------------------------------------------------------------------
+template <int NT, int KS, int TK, int NLC>
+__device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, int wave) {
+  using G = FastGeom<NT, KS, TK, NLC>;
+  constexpr int NE = G::NE, W = G::W, NFAST = G::NFAST;
+  const int lane = threadIdx.x & 63, cn = lane & 15, lg = lane >> 4;
+  const int tp = (wave + 3) & 3;  // tile pair of this wave: wave 0 (shares its SIMD with the B wave) gets the last, lightest one
+  const int cl = blockIdx.x * 16 + cn;
+  const bool inrange = cl < prm.C;
+  const int D = prm.D;
+  auto gidx = [&](int e) { return 16 * (tp * NT + (e >> 2)) + 4 * (e & 3) + lg; };
+  int ntl = (D + 15) / 16 - tp * NT;  // tiles of this wave that hold coordinates
+  ntl = ntl < 0 ? 0 : (ntl > NT ? NT : ntl);
+
+  double* ldsq = lds + G::OFF_Q;
+  double* const own = lds + (size_t)(tp * NE) * 64 + lane;  // + buffer / region offset + e*64
+  double* part = lds + G::OFF_PART;
+  const Cmd* cmdbuf = reinterpret_cast<const Cmd*>(lds + G::OFF_CMD);
+  double* wbase = prm.work + (size_t)blockIdx.x * G::group_doubles(prm.M);
+  auto gvec = [&](int vec) { return wbase + (size_t)vec * G::VECD + ((size_t)(cn * W + tp) * NE) * 4 + lg; };  // + e*4
+  const int vprop = (prm.M + 1) * 2;
+  const double* znext = wbase + (size_t)((prm.M + 1) * 2 + 2) * G::VECD + (size_t)cn * G::DPAD;
+
+  // -A fragments of this wave's row tiles, resident for the whole run
+  constexpr int NA = (TK == CK_DENSE) ? NT * KS : 1;
+  double afrag[NA];
+  double adiag[NE];
+  if (TK == CK_DENSE) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int row = 16 * (tp * NT + t) + (lane & 15);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int col = 4 * s + (lane >> 4);
+        afrag[t * KS + s] = (row < D && col < D) ? -prm.tpar[(size_t)row * D + col] : 0.0;
+      }
+    }
+  } else {
+    afrag[0] = 0.0;
+  }
+#pragma unroll
+  for (int e = 0; e < NE; ++e) adiag[e] = (TK == CK_DIAG && gidx(e) < D) ? prm.tpar[gidx(e)] : 0.0;
+
+  double q[NE], v[NE], g[NE], VL[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) { q[e] = v[e] = g[e] = VL[e] = 0.0; }
+
+  for (uint32_t t = 0;; ++t) {
+    const int bq_ = (int)(t & 1u) * G::VECD, bp_ = (int)((t + 1u) & 1u) * G::VECD;  // this tick's / the previous tick's Q buffer
+    Cmd c;
+    if (t == 0) { c.hs = 0.0; c.op = inrange ? (OP_NEWITER | OP_INIT) : 0u; c.n = 0u; }
+    else c = cmdbuf[(t & 1u) * 16 + cn];
+    const uint32_t op = c.op;
+    if (__any((op & OP_DONE) != 0)) break;
+    double keinit_part = 0.0, gen_part = 0.0;
+    // ---- phase 1: commands ----
+    if (__any((op & OP_PICK) != 0)) {  // the position of tick t-2 still sits in this tick's Q buffer
+      if (op & OP_PICK) {
+        double* dst = gvec(vprop + ((op & OP_IPPICK) ? 1 : 0));
+#pragma unroll
+        for (int e = 0; e < NE; ++e) dst[e * 4] = own[G::OFF_Q + bq_ + e * 64];
+      }
+    }
+    if (__any((op & OP_NEWITER) != 0)) {
+      if (op & OP_NEWITER) {
+        if (op & OP_INIT) {
+          double* dst = gvec(vprop);
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            q[e] = gidx(e) < D ? prm.q0[(size_t)cl * D + gidx(e)] : 0.0;
+            dst[e * 4] = q[e];
+          }
+        } else {
+          const double* src = gvec(vprop + ((op & OP_IPNEW) ? 1 : 0));
+#pragma unroll
+          for (int e = 0; e < NE; ++e) q[e] = src[e * 4];
+        }
+        // samples[:, row] = generated(q)  (WALNUTS.py:164,695)
+        double* row = prm.samples + ((size_t)cl * (prm.numIter + 1) + c.n) * prm.dg;
+        if (prm.generated == G_Q0_SUMSQ) {
+          if (tp == 0 && lg == 0) row[0] = q[0];
+          double s = 0.0;
+#pragma unroll
+          for (int e = 0; e < NE; ++e) s += q[e] * q[e];
+          gen_part = s;
+        } else {
+          const int k = prm.generated == G_FIRSTK ? prm.gen_k : D;
+#pragma unroll
+          for (int e = 0; e < NE; ++e) if (gidx(e) < k) row[gidx(e)] = q[e];
+        }
+        if (!(op & (OP_INIT | OP_LAST))) {  // v = normal(size=d); both ends start at (qc, v)  (:236-253)
+          double kp = 0.0;
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            const double z = znext[gidx(e)];
+            v[e] = z;
+            kp += z * z;
+          }
+          keinit_part = kp;
+#pragma unroll
+          for (int e = 0; e < NE; ++e) { own[G::OFF_COLD + e * 64] = q[e]; own[G::OFF_COLD + G::VECD + e * 64] = v[e]; }
+        }
+      }
+    }
+    if (__any((op & OP_SWAP) != 0)) {  // the other end of the orbit becomes the active one (:283-286)
+      if (op & OP_SWAP) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const double tq = own[G::OFF_COLD + e * 64], tv = own[G::OFF_COLD + G::VECD + e * 64];
+          own[G::OFF_COLD + e * 64] = q[e]; own[G::OFF_COLD + G::VECD + e * 64] = v[e];
+          q[e] = tq; v[e] = tv;
+        }
+      }
+    }
+    // ---- first half of the leapfrog step (adaptiveIntegrators.py:51-52 with hs = xi*h; v is kept in
+    // forward-time orientation: xi*(xi*v + h/2 g) = v + (xi h/2) g exactly) ----
+    const bool step = (op & OP_STEP) != 0;
+    const double hs = step ? c.hs : 0.0, hs2 = 0.5 * hs;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { v[e] = v[e] + hs2 * g[e]; q[e] = q[e] + hs * v[e]; }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) own[G::OFF_Q + bq_ + e * 64] = q[e];
+    WN_LDS_BARRIER();  // A
+    // ---- phase 2: gradient, second half step, partials ----
+    if (TK == CK_DENSE) {
+      d4_t acc[NT];
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) acc[tt] = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const double bq = ldsq[bq_ + s * 64 + lane];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+          if (tt < ntl) acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[tt * KS + s], bq, acc[tt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[tt * 4 + r] = acc[tt][r];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) g[e] = -(adiag[e] * q[e]);
+    }
+    double pl = 0.0, pk = 0.0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) pl += q[e] * g[e];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { v[e] = v[e] + hs2 * g[e]; pk += v[e] * v[e]; }
+    pl = fast_rowsum4(pl); pk = fast_rowsum4(pk);
+    if (lg == 0) { part[(Q_LP * 4 + tp) * 16 + cn] = pl; part[(Q_KE * 4 + tp) * 16 + cn] = pk; }
+    if (__any((op & OP_NEWITER) != 0)) {
+      keinit_part = fast_rowsum4(keinit_part); gen_part = fast_rowsum4(gen_part);
+      if (lg == 0) { part[(Q_KEINIT * 4 + tp) * 16 + cn] = keinit_part; part[(Q_GEN * 4 + tp) * 16 + cn] = gen_part; }
+    }
+    // ---- U-turn dots of the sub-tree checks due at this leaf + endpoint stores ----
+    if (__any(step)) {
+      const int i = (int)((op >> OP_I_SHIFT) & 31u), n = (int)c.n;
+      const int nchk = step ? nchecks(i, n) : 0;
+      auto put_dots = [&](int j, double d1, double d2) {
+        d1 = fast_rowsum4(d1); d2 = fast_rowsum4(d2);
+        if (lg == 0) { part[((Q_DOT0 + 2 * j) * 4 + tp) * 16 + cn] = d1; part[((Q_DOT0 + 2 * j + 1) * 4 + tp) * 16 + cn] = d2; }
+      };
+      // dq = q' - qo;  d1 = v'.dq, d2 = vo.dq   (stopCondition, WALNUTS.py:95-97; velocities forward-time)
+#define WN_FAST_DOTS(QO, VO)                          \
+  {                                                   \
+    _Pragma("unroll") for (int e = 0; e < NE; ++e) { \
+      const double dq = q[e] - (QO);                  \
+      d1 += v[e] * dq;                                \
+      d2 += (VO) * dq;                                \
+    }                                                 \
+  }
+      {  // check 0: the whole orbit against its passive end
+        const bool need = nchk > 0 && need_check(i, n, 0);
+        if (__any(need)) {
+          double d1 = 0.0, d2 = 0.0;
+          if (need) WN_FAST_DOTS(own[G::OFF_COLD + e * 64], own[G::OFF_COLD + G::VECD + e * 64])
+          put_dots(0, d1, d2);
+        }
+      }
+      {  // check 1: the leaf pair; its first state is the previous tick's Q buffer and VL
+        const bool need = nchk > 1;
+        if (__any(need)) {
+          double d1 = 0.0, d2 = 0.0;
+          if (need) WN_FAST_DOTS(own[G::OFF_Q + bp_ + e * 64], VL[e])
+          put_dots(1, d1, d2);
+        }
+      }
+#pragma unroll
+      for (int j = 2; j < NFAST; ++j) {  // LDS-cached sub-tree levels
+        const bool need = nchk > j;
+        if (__any(need)) {
+          double d1 = 0.0, d2 = 0.0;
+          if (need) WN_FAST_DOTS(own[G::OFF_LC + (j - 2) * 2 * G::VECD + e * 64], own[G::OFF_LC + ((j - 2) * 2 + 1) * G::VECD + e * 64])
+          put_dots(j, d1, d2);
+        }
+      }
+      for (int j = NFAST; __any(nchk > j); ++j) {  // deeper levels: left endpoint from the slot store in memory
+        const bool need = nchk > j;
+        double d1 = 0.0, d2 = 0.0;
+        if (need) {
+          const int sl = slot_of_leaf(n + 1 - (1 << j));
+          const double* pq = gvec(sl * 2);
+          const double* pv = gvec(sl * 2 + 1);
+          WN_FAST_DOTS(pq[e * 4], pv[e * 4])
+        }
+        put_dots(j, d1, d2);
+      }
+#undef WN_FAST_DOTS
+      // statePush (:431,518): only sub-tree left endpoints are ever read back
+      const bool even = step && i >= 1 && (n & 1) == 0;
+      if (even) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) VL[e] = v[e];
+      }
+      const bool ep = even && i >= 2 && (n & 3) == 0;
+      if (__any(ep)) {
+        if (ep) {
+#pragma unroll
+          for (int j = 2; j < NFAST; ++j)
+            if (j <= i && (n & ((1 << j) - 1)) == 0) {
+#pragma unroll
+              for (int e = 0; e < NE; ++e) {
+                own[G::OFF_LC + (j - 2) * 2 * G::VECD + e * 64] = q[e];
+                own[G::OFF_LC + ((j - 2) * 2 + 1) * G::VECD + e * 64] = v[e];
+              }
+            }
+          if (n == 0 ? (i >= NFAST) : (__builtin_ctz((unsigned)n) >= NFAST)) {
+            const int sl = slot_of_leaf(n);
+            double* pq = gvec(sl * 2);
+            double* pv = gvec(sl * 2 + 1);
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { pq[e * 4] = q[e]; pv[e * 4] = v[e]; }
+          }
+        }
+      }
+    }
+    WN_LDS_BARRIER();  // B
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// B wave
+// ------------------------------------------------------------------------------------------------
+struct FastDevIO {
+  const Params* prm;
+  int cl, lg;
+  double lp, ke, keinit, gen;
+  uint32_t fire;
+  __device__ __forceinline__ double sum(int k) const { return k == Q_LP ? lp : k == Q_KE ? ke : k == Q_KEINIT ? keinit : gen; }
+  __device__ __forceinline__ uint32_t firemask(int, int, int) const { return fire; }
+  __device__ __forceinline__ void write_gen(size_t row, double v) const {
+    if (lg == 0) prm->samples[((size_t)cl * (prm->numIter + 1) + row) * prm->dg + 1] = v;
+  }
+  // one diagnostics row = three 64-B lines; the four replicas of a chain write 16 B of each (CoopPolicy::diag_store)
+  __device__ __forceinline__ void write_diag(size_t row, const double* d) const {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    double* o = prm->diag + ((size_t)cl * prm->numIter + row) * NDIAG;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      d2_t v;
+      v[0] = lg == 0 ? d[8 * k] : lg == 1 ? d[8 * k + 2] : lg == 2 ? d[8 * k + 4] : d[8 * k + 6];
+      v[1] = lg == 0 ? d[8 * k + 1] : lg == 1 ? d[8 * k + 3] : lg == 2 ? d[8 * k + 5] : d[8 * k + 7];
+      *reinterpret_cast<d2_t*>(o + 8 * k + 2 * lg) = v;
+    }
+  }
+};
+
+template <int NT, int KS, int TK, int NLC>
+__device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int* abort_flag) {
+  using G = FastGeom<NT, KS, TK, NLC>;
+  const int lane = threadIdx.x & 63, cn = lane & 15, lg = lane >> 4;
+  const int cl = blockIdx.x * 16 + cn;
+  const bool inrange = cl < prm.C;
+  const double* part = lds + G::OFF_PART;
+  Cmd* cmdbuf = reinterpret_cast<Cmd*>(lds + G::OFF_CMD);
+  double* znext = prm.work + (size_t)blockIdx.x * G::group_doubles(prm.M) + (size_t)((prm.M + 1) * 2 + 2) * G::VECD;
+
+  FastBook bk;
+  bk.init(prm.chain0 + (uint32_t)cl, inrange, prm.numIter);
+  FastDevIO io;
+  io.prm = &prm; io.cl = cl; io.lg = lg;
+  io.lp = io.ke = io.keinit = io.gen = 0.0; io.fire = 0u;
+  // sum of the four waves' partials in tile order (the order of CoopPolicy::reduce)
+  auto sum4 = [&](int k) {
+    double s = 0.0;
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) s += part[(k * 4 + tp) * 16 + cn];
+    return s;
+  };
+  struct DotSrc {
+    const double* part; int cn;
+    __device__ __forceinline__ void dots(int j, double& d1, double& d2) const {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int tp = 0; tp < 4; ++tp) { a += part[((Q_DOT0 + 2 * j) * 4 + tp) * 16 + cn]; b += part[((Q_DOT0 + 2 * j + 1) * 4 + tp) * 16 + cn]; }
+      d1 = a; d2 = b;
+    }
+  } dsrc{part, cn};
+  // every chain needs at most numIter * (2^M - 1 + 2 idle ticks per doubling + start) ticks; twice that is an internal error
+  const double cap = 256.0 + 2.0 * (double)prm.numIter * ((double)(1u << prm.M) + 4.0 * (double)prm.M + 16.0);
+
+  for (uint32_t t = 0;; ++t) {
+    // ---- what tick t-1 left in the partials, before the T waves overwrite them (behind barrier A) ----
+    if (t > 0) {
+      io.lp = sum4(Q_LP); io.ke = sum4(Q_KE);
+      if (__any(bk.s0.kind == FastBook::K_NEWITER)) { io.keinit = sum4(Q_KEINIT); io.gen = sum4(Q_GEN); }
+      io.fire = 0u;
+      if (bk.s0.kind == FastBook::K_STEP && !bk.s0.discard) io.fire = fire_of(bk.i, bk.s0.n, bk.xi, dsrc);
+    }
+    WN_LDS_BARRIER();  // A
+    Cmd c = bk.tick(prm, io, t + 1u);
+    bool done = __all(bk.finished());
+    if ((double)t > cap) {  // cannot happen; never hang the GPU
+      if (lane == 0) atomicExch(abort_flag, 1);
+      done = true;
+    }
+    if (done) c.op |= OP_DONE;
+    if (lg == 0) cmdbuf[((t + 1u) & 1u) * 16 + cn] = c;
+    // ---- momentum normals v = normal(size=d) (WALNUTS.py:236, wn_rng.h stream 1) of ONE chain's next
+    // iteration per tick: lane L makes elements 2L, 2L+1 (one Philox block, one Box-Muller pair) ----
+    {
+      const unsigned long long want = __ballot(lg == 0 && bk.zwant != bk.zready && bk.zwant >= 1);
+      if (want) {
+        const int cs = __builtin_ctzll(want);  // lanes 0..15 are chains 0..15
+        const int it = __shfl(bk.zwant, cs);
+        const uint32_t ch = (uint32_t)__shfl((int)bk.chain, cs);
+        if (2 * lane < G::DPAD) {
+          Philox4 p = philox4x32_10((uint32_t)lane, (uint32_t)it, ch, 1u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
+          const uint64_t x0 = ((uint64_t)p.w[1] << 32) | p.w[0];
+          const double u1 = ((double)(x0 >> 12) + 0.5) * 0x1.0p-52;
+          const double u2 = u53(p.w[2], p.w[3]);
+          const double r = sqrt(-2.0 * log(u1));
+          const double th = 6.283185307179586476925286766559 * u2;
+          typedef double d2_t __attribute__((ext_vector_type(2)));
+          d2_t z;
+          z[0] = (2 * lane < prm.D) ? r * cos(th) : 0.0;
+          z[1] = (2 * lane + 1 < prm.D) ? r * sin(th) : 0.0;
+          *reinterpret_cast<d2_t*>(znext + (size_t)cs * G::DPAD + 2 * lane) = z;
+        }
+        if (cn == cs) bk.zready = it;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // visible to the T waves behind the barrier
+      }
+    }
+    WN_LDS_BARRIER();  // B
+    if (done) break;
+  }
+}
+
+template <int NT, int KS, int TK, int NLC>
+__global__ __launch_bounds__(320) void wn_fast_kernel(Params prm, int* abort_flag) {
+  __shared__ double lds[FastGeom<NT, KS, TK, NLC>::LDS_DOUBLES];
+  const int wave = threadIdx.x >> 6;
+  if (wave < 4) fast_t_wave<NT, KS, TK, NLC>(prm, lds, wave);
+  else fast_b_wave<NT, KS, TK, NLC>(prm, lds, abort_flag);
+}
+
+// can the role-split kernel run this launch?  fixedLeapFrog sampling without trace / warm-up / orbit statistics
+bool fast_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm) {
+  if (kc.layout != 1 || adapt != 0 || warm || prm.mode != MODE_SAMPLE) return false;
+  if (prm.trace_n || prm.omin || prm.M > 12) return false;
+  if (kc.p1 == CK_DENSE) return kc.p0 == 25 || kc.p0 == 32 || kc.p0 == 16;
+  return kc.p0 == 16 || kc.p0 == 32;
+}
+
+hipError_t launch_fast(const KernelChoice& kc, const Params& prm, int* abort_flag, hipStream_t st) {
+  dim3 grid((prm.C + 15) / 16), block(320);
+#define WN_FAST_GO(NT, KS, TK) \
+  { hipLaunchKernelGGL((wn_fast_kernel<NT, KS, TK, 2>), grid, block, 0, st, prm, abort_flag); return hipGetLastError(); }
+  if (kc.p1 == CK_DENSE) {
+    if (kc.p0 == 16) WN_FAST_GO(1, 16, CK_DENSE)
+    if (kc.p0 == 25) WN_FAST_GO(2, 25, CK_DENSE)
+    if (kc.p0 == 32) WN_FAST_GO(2, 32, CK_DENSE)
+  } else {
+    if (kc.p0 == 16) WN_FAST_GO(1, 16, CK_DIAG)
+    if (kc.p0 == 32) WN_FAST_GO(2, 32, CK_DIAG)
+  }
+#undef WN_FAST_GO
+  return hipErrorInvalidValue;
+}
+
+}  // namespace wn
