@@ -1,0 +1,141 @@
+"""GPU tests of the role-split headline kernel (wn_k_fast.hip: four T waves + one bookkeeper wave per 16-chain
+group) through the C ABI: against the oracle on seeded inputs, against the one-stream kernel of the same
+layout (WN_COOP_LEGACY=1, same arithmetic: identical integers, draws to 1e-12) at full BASELINE size, and the
+edge cases of tests/test_fast_book.py on the device."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+SEED = 20251121
+INT_DIAG = (0, 1, 4, 5, 6, 7, 8, 9, 12, 13, 19, 20, 21, 22)
+
+
+@pytest.fixture(scope="module")
+def wa():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import walnuts_amd
+    return walnuts_amd
+
+
+def close(a, b, rtol=1e-6, atol=1e-9, what=""):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    with np.errstate(all="ignore"):
+        ok = (np.isnan(a) & np.isnan(b)) | (np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))) | \
+             (np.abs(a - b) <= atol + rtol * np.abs(b))
+    assert ok.all(), f"{what}: {np.count_nonzero(~ok)} mismatches, first at {np.argwhere(~ok)[:4].tolist()}, " \
+                     f"got {a[~ok][:4]}, want {b[~ok][:4]}"
+
+
+def run(wa, target, tpar, q0, legacy=False, **kw):
+    C, D = q0.shape
+    if legacy:
+        os.environ["WN_COOP_LEGACY"] = "1"
+    try:
+        e = wa.Engine(D, C, integrator=ol.I_FIXED, **{k: v for k, v in kw.items() if k not in ("numIter", "seed")})
+        e.set_target(target, tpar)
+        name = e.kernel_name
+        s, d = e.run(q0, kw["seed"], kw["numIter"])
+        s = s.transpose(1, 2).cpu().numpy(); d = d.cpu().numpy()
+        ms = e.last_run_ms()
+        e.close()
+    finally:
+        os.environ.pop("WN_COOP_LEGACY", None)
+    return s, d, name, ms
+
+
+def dense_problem(D, kappa, C, seed=SEED):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_dense_problem
+    return make_dense_problem(D, kappa, C, seed)
+
+
+@pytest.mark.parametrize("D,C,M,gen", [(100, 48, 10, ol.G_Q0_SUMSQ), (100, 21, 6, ol.G_IDENTITY), (40, 16, 8, ol.G_FIRSTK),
+                                         (128, 17, 7, ol.G_Q0_SUMSQ), (20, 33, 12, ol.G_Q0_SUMSQ), (97, 5, 3, ol.G_IDENTITY)])
+def test_fast_dense_matches_oracle(wa, D, C, M, gen):
+    A, q0 = dense_problem(D, 1e3, C)
+    kw = dict(H0=0.5, M=M, generated=gen, gen_k=3 if gen == ol.G_FIRSTK else 0, chain_offset=11, numIter=5, seed=SEED + D)
+    s, d, name, _ = run(wa, ol.T_DENSEGAUSS, A, q0, **kw)
+    assert "wn_fast_kernel" in name and "dense" in name, name
+    for k in sorted({0, C - 1, C // 2, min(15, C - 1), min(16, C - 1)}):
+        o = ol.walnuts(ol.T_DENSEGAUSS, q0[k], integrator=ol.I_FIXED, tpar=A.ravel(), H0=0.5, numIter=5, M=M, seed=SEED + D,
+                       chain=11 + k, generated=gen, gen_k=kw["gen_k"])
+        for col in INT_DIAG:
+            np.testing.assert_array_equal(d[k][:, col], o["diagnostics"][:, col], err_msg=f"chain {k} diag col {col}")
+        close(d[k], o["diagnostics"], what=f"chain {k} diagnostics")
+        close(s[k], o["samples"], what=f"chain {k} draws")
+
+
+@pytest.mark.parametrize("D,tk", [(100, ol.T_DIAGGAUSS), (30, ol.T_STDGAUSS), (128, ol.T_DIAGGAUSS)])
+def test_fast_diag_matches_oracle(wa, D, tk):
+    lam = np.logspace(0, 3, D)
+    a = 1.0 / lam if tk == ol.T_DIAGGAUSS else None
+    q0 = np.random.default_rng(D).normal(size=(35, D)) * (np.sqrt(lam) if a is not None else 1.0)
+    H0 = 0.5 if a is not None else 1.4 * D ** -0.25
+    kw = dict(H0=H0, M=9, generated=ol.G_Q0_SUMSQ, chain_offset=0, numIter=6, seed=SEED)
+    s, d, name, _ = run(wa, tk, a, q0, **kw)
+    assert "wn_fast_kernel" in name and "diag" in name, name
+    for k in (0, 16, 34):
+        o = ol.walnuts(tk, q0[k], integrator=ol.I_FIXED, tpar=a, H0=H0, numIter=6, M=9, seed=SEED, chain=k, generated=ol.G_Q0_SUMSQ)
+        for col in INT_DIAG:
+            np.testing.assert_array_equal(d[k][:, col], o["diagnostics"][:, col], err_msg=f"chain {k} diag col {col}")
+        close(d[k], o["diagnostics"], what=f"chain {k} diagnostics")
+        close(s[k], o["samples"], what=f"chain {k} draws")
+
+
+def test_fast_equals_one_stream_kernel_at_baseline_size(wa):
+    """BASELINE configs[1] at the bench's size (4096 chains, D = 100, kappa = 1e4, M = 10), 12 iterations: the two
+    kernels do the same arithmetic in the same order, so every integer column is identical and draws agree to 1e-12;
+    16 random chains against the oracle."""
+    A, q0 = dense_problem(100, 1e4, 4096)
+    kw = dict(H0=0.5, M=10, generated=ol.G_Q0_SUMSQ, chain_offset=0, numIter=12, seed=SEED)
+    s, d, name, ms = run(wa, ol.T_DENSEGAUSS, A, q0, **kw)
+    s1, d1, name1, ms1 = run(wa, ol.T_DENSEGAUSS, A, q0, legacy=True, **kw)
+    assert "wn_fast_kernel" in name and "wn_coop_kernel" in name1, (name, name1)
+    for col in INT_DIAG:
+        np.testing.assert_array_equal(d[:, :, col], d1[:, :, col], err_msg=f"diag col {col}")
+    close(d, d1, rtol=1e-12, atol=1e-13, what="diagnostics vs one-stream kernel")
+    close(s, s1, rtol=1e-12, atol=1e-13, what="draws vs one-stream kernel")
+    steps = d[:, :, 6] + d[:, :, 7]
+    assert (d[:, :, 2] > 0).all() and steps.sum() > 4096 * 12 * 100
+    rng = np.random.default_rng(0)
+    for k in sorted(set(rng.integers(0, 4096, size=14).tolist() + [0, 4095])):
+        o = ol.walnuts(ol.T_DENSEGAUSS, q0[k], integrator=ol.I_FIXED, tpar=A.ravel(), H0=0.5, numIter=12, M=10, seed=SEED,
+                       chain=k, generated=ol.G_Q0_SUMSQ)
+        np.testing.assert_array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]], err_msg=f"chain {k}")
+        close(s[k], o["samples"], what=f"chain {k}")
+        close(d[k], o["diagnostics"], what=f"diagnostics chain {k}")
+    print(f"fast {ms:.1f} ms vs one-stream {ms1:.1f} ms")
+
+
+@pytest.mark.parametrize("scale,H0", [(3e153, 0.05), (3e153, 0.5), (1e154, 0.5), (1e200, 0.05)])
+def test_fast_huge_energies_on_device(wa, scale, H0):
+    """Zero / infinite multinomial weights and overflowing energies (tests/test_fast_book.py) on the device."""
+    D = 20
+    q0 = np.random.default_rng(3).normal(size=(6, D)) * scale
+    q0[4:] = np.random.default_rng(4).normal(size=(2, D))  # ordinary chains in the same group are not disturbed
+    kw = dict(H0=H0, M=8, generated=ol.G_Q0_SUMSQ, chain_offset=3, numIter=8, seed=11)
+    s, d, name, _ = run(wa, ol.T_STDGAUSS, None, q0, **kw)
+    assert "wn_fast_kernel" in name
+    for k in range(6):
+        o = ol.walnuts(ol.T_STDGAUSS, q0[k], integrator=ol.I_FIXED, H0=H0, numIter=8, M=8, seed=11, chain=3 + k, generated=ol.G_Q0_SUMSQ)
+        for col in INT_DIAG:
+            np.testing.assert_array_equal(d[k][:, col], o["diagnostics"][:, col], err_msg=f"chain {k} diag col {col}")
+        close(d[k], o["diagnostics"], what=f"chain {k} diagnostics")
+        close(s[k], o["samples"], what=f"chain {k} draws")
+
+
+def test_fast_zero_iterations_and_ragged_groups(wa):
+    A, q0 = dense_problem(100, 1e4, 19)
+    s, d, name, _ = run(wa, ol.T_DENSEGAUSS, A, q0, H0=0.5, M=5, generated=ol.G_IDENTITY, numIter=0, seed=1)
+    assert s.shape == (19, 100, 1) and d.shape == (19, 0, 24)
+    np.testing.assert_array_equal(s[:, :, 0], q0)
+    s, d, name, _ = run(wa, ol.T_DENSEGAUSS, A, q0, H0=0.5, M=5, generated=ol.G_IDENTITY, numIter=1, seed=1)
+    o = ol.walnuts(ol.T_DENSEGAUSS, q0[18], integrator=ol.I_FIXED, tpar=A.ravel(), H0=0.5, numIter=1, M=5, seed=1, chain=18)
+    close(s[18], o["samples"]); close(d[18], o["diagnostics"])
