@@ -1,6 +1,6 @@
 """GPU tests of the role-split headline kernel (wn_k_fast.hip: four T waves + one bookkeeper wave per 16-chain
 group) through the C ABI: against the oracle on seeded inputs, against the one-stream kernel of the same
-layout (WN_COOP_LEGACY=1, same arithmetic: identical integers, draws to 1e-12) at full BASELINE size, and the
+layout (WN_COOP_LEGACY=1: identical integers, draws to 1e-9) at full BASELINE size, and the
 edge cases of tests/test_fast_book.py on the device."""
 import os
 
@@ -72,7 +72,7 @@ def test_fast_dense_matches_oracle(wa, D, C, M, gen):
         close(s[k], o["samples"], what=f"chain {k} draws")
 
 
-@pytest.mark.parametrize("D,tk", [(100, ol.T_DIAGGAUSS), (30, ol.T_STDGAUSS), (128, ol.T_DIAGGAUSS)])
+@pytest.mark.parametrize("D,tk", [(100, ol.T_DIAGGAUSS), (30, ol.T_STDGAUSS), (112, ol.T_DIAGGAUSS), (65, ol.T_STDGAUSS)])
 def test_fast_diag_matches_oracle(wa, D, tk):
     lam = np.logspace(0, 3, D)
     a = 1.0 / lam if tk == ol.T_DIAGGAUSS else None
@@ -91,8 +91,8 @@ def test_fast_diag_matches_oracle(wa, D, tk):
 
 def test_fast_equals_one_stream_kernel_at_baseline_size(wa):
     """BASELINE configs[1] at the bench's size (4096 chains, D = 100, kappa = 1e4, M = 10), 12 iterations: the two
-    kernels do the same arithmetic in the same order, so every integer column is identical and draws agree to 1e-12;
-    16 random chains against the oracle."""
+    kernels differ only in how the D-term sums are associated (per 16-row tile here, per pair of tiles there), so
+    every integer column is identical and draws agree to 1e-9; 16 random chains against the oracle."""
     A, q0 = dense_problem(100, 1e4, 4096)
     kw = dict(H0=0.5, M=10, generated=ol.G_Q0_SUMSQ, chain_offset=0, numIter=12, seed=SEED)
     s, d, name, ms = run(wa, ol.T_DENSEGAUSS, A, q0, **kw)
@@ -100,8 +100,8 @@ def test_fast_equals_one_stream_kernel_at_baseline_size(wa):
     assert "wn_fast_kernel" in name and "wn_coop_kernel" in name1, (name, name1)
     for col in INT_DIAG:
         np.testing.assert_array_equal(d[:, :, col], d1[:, :, col], err_msg=f"diag col {col}")
-    close(d, d1, rtol=1e-12, atol=1e-13, what="diagnostics vs one-stream kernel")
-    close(s, s1, rtol=1e-12, atol=1e-13, what="draws vs one-stream kernel")
+    close(d, d1, rtol=1e-9, atol=1e-10, what="diagnostics vs one-stream kernel")
+    close(s, s1, rtol=1e-9, atol=1e-10, what="draws vs one-stream kernel")
     steps = d[:, :, 6] + d[:, :, 7]
     assert (d[:, :, 2] > 0).all() and steps.sum() > 4096 * 12 * 100
     rng = np.random.default_rng(0)

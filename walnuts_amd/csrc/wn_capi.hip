@@ -146,7 +146,10 @@ size_t kernel_work_doubles(const KernelChoice& kc, int C, int M) {
   if (kc.layout == 2) return wave_work_doubles(kc.p0, C, M, kc.G);
   if (kc.layout == 3) return split_work_doubles(kc.p0, C, M);
   const int NT = kc.p0 <= 16 ? 1 : kc.p0 <= 32 ? 2 : 4;
-  return coop_work_doubles(NT, kc.W, C, M);
+  // the role-split kernel of the same layout (wn_k_fast.hip) pads every vector to 8 tiles x 4 registers x 64 lanes
+  // whatever the dimension: (M+1) slots x (q, v) + 2 proposals + the momentum normals per 16-chain group
+  const size_t fast = (((size_t)C + 15) / 16) * (size_t)((M + 1) * 2 + 3) * 2048;
+  return std::max(coop_work_doubles(NT, kc.W, C, M), fast);
 }
 
 // lpFun(q) -> lp, grad for any target kind, scalar loops (test / plumbing entry points; the
@@ -575,12 +578,13 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
                             (size_t)D * sizeof(double), (size_t)D, hipMemcpyDeviceToDevice));
     }
   }
-  if (kc.layout == 1 && e->cfg.integrator == WN_I_FIXED && e->cfg.warmup_iter == 0 && e->cfg.M <= 12 && !(kc.p1 == CK_DENSE && kc.p0 == 32) &&
+  if (kc.layout == 1 && e->cfg.integrator == WN_I_FIXED && e->cfg.warmup_iter == 0 && e->cfg.M <= 12 && D <= 112 && !(kc.p1 == CK_DENSE && kc.p0 == 32) &&
       !getenv("WN_COOP_LEGACY")) {
     // plain sampling runs of this engine go to the role-split kernel (wn_k_fast.hip); traced / orbit-statistics
     // runs and wn_integrator_step use the one-stream kernel of the same layout
     const int NT = kc.p0 <= 16 ? 1 : 2;
-    snprintf(kc.name, sizeof(kc.name), "wn_fast_kernel<NT=%d,KS=%d,%s>", NT, kc.p0, kc.p1 == CK_DENSE ? "dense" : "diag");
+    snprintf(kc.name, sizeof(kc.name), "wn_fast_kernel<KS=%d,%s>", (kc.p1 != CK_DENSE && kc.p0 == 32) ? 28 : kc.p0, kc.p1 == CK_DENSE ? "dense" : "diag");
+    (void)NT;
   }
   e->kc = kc;
   e->have_kc = true;
@@ -745,19 +749,17 @@ int wn_run(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, do
     for (size_t w = 0; w < nw / 16; ++w) for (int k = 0; k < 16; ++k) tot[k] += (double)h[w * 16 + k];
     const char* names[16] = {"A_setup", "B_leapfrog+grad", "B_ke+reduce", "C_after_micro", "D_uturn", "E_rest", "ticks", "loop_head",
                              "E_to_exp", "E_pick+stores", "E_doubling_end", "", "", "", "", ""};
-    if (strstr(e->kc.name, "wn_fast_kernel")) {  // rows: 5 waves per 16-chain group (4 T waves, then the B wave)
-      double tt[8] = {0}, tb[8] = {0}; double nt = 0, nb = 0;
+    if (strstr(e->kc.name, "wn_fast_kernel")) {  // rows: 8 waves per 16-chain group (T waves 0..6, B wave 7)
       const size_t groups = (size_t)(p.C + 15) / 16;
-      for (size_t gI = 0; gI < groups; ++gI) for (int w = 0; w < 5; ++w) for (int k = 0; k < 8; ++k) {
-        if (w < 4) tt[k] += (double)h[(gI * 5 + w) * 16 + k]; else tb[k] += (double)h[(gI * 5 + w) * 16 + k];
+      for (int w = 0; w < 8; ++w) {
+        double a[8] = {0};
+        for (size_t gI = 0; gI < groups; ++gI) for (int k = 0; k < 8; ++k) a[k] += (double)h[(gI * 8 + w) * 16 + k];
+        if (a[6] <= 0) continue;
+        if (w < 7) fprintf(stderr, "[WN_STAMPS fast] T wave %d cycles/tick: cmd+halfstep=%.0f waitA=%.0f mfma+halfstep=%.0f lp/ke partials=%.0f checks(on-chip)+stores=%.0f "
+                                    "deeper checks=%.0f waitB=%.0f\n", w, a[0] / a[6], a[1] / a[6], a[2] / a[6], a[3] / a[6], a[4] / a[6], a[7] / a[6], a[5] / a[6]);
+        else fprintf(stderr, "[WN_STAMPS fast] B wave cycles/tick: read partials=%.0f waitA=%.0f bookkeeper=%.0f cmd+normals=%.0f waitB=%.0f (ticks %.0f)\n",
+                     a[0] / a[6], a[1] / a[6], a[2] / a[6], a[4] / a[6], a[5] / a[6], a[6] / groups);
       }
-      nt = tt[6]; nb = tb[6];
-      fprintf(stderr, "[WN_STAMPS fast] T wave cycles/tick: cmd+halfstep=%.0f waitA=%.0f mfma+halfstep=%.0f lp/ke partials=%.0f checks+stores=%.0f waitB=%.0f (ticks/wave %.0f)\n",
-              tt[0] / nt, tt[1] / nt, tt[2] / nt, tt[3] / nt, tt[4] / nt, tt[5] / nt, nt / (groups * 4));
-      fprintf(stderr, "[WN_STAMPS fast] B wave cycles/tick: read partials=%.0f waitA=%.0f bookkeeper=%.0f cmd+normals=%.0f waitB=%.0f\n",
-              tb[0] / nb, tb[1] / nb, tb[2] / nb, tb[4] / nb, tb[5] / nb);
-      for (int w = 0; w < 4; ++w) { double a[8] = {0}; for (size_t gI = 0; gI < groups; ++gI) for (int k = 0; k < 8; ++k) a[k] += (double)h[(gI * 5 + w) * 16 + k];
-        fprintf(stderr, "[WN_STAMPS fast]   T wave %d: cmd=%.0f waitA=%.0f mfma=%.0f part=%.0f checks(on-chip)+stores=%.0f deep checks=%.0f waitB=%.0f\n", w, a[0]/a[6], a[1]/a[6], a[2]/a[6], a[3]/a[6], a[4]/a[6], a[7]/a[6], a[5]/a[6]); }
       return rc;
     }
     fprintf(stderr, "[WN_STAMPS] per wave-tick cycles:");

@@ -1,6 +1,10 @@
 // wn_k_fast.hip -- role-split kernel of the headline path: fixedLeapFrog on a dense / diagonal Gaussian,
-// 16 chains per workgroup in the MFMA layout of wn_policy_coop.h, four T waves (vectors + MFMA) and one
-// B wave (the bookkeeper of wn_fast.h) per workgroup.  See wn_fast.h for the protocol.
+// 16 chains per workgroup in the MFMA layout of wn_policy_coop.h.  Eight waves per workgroup, two per SIMD:
+// seven T waves, each owning ONE 16-row tile of every D-vector (4 doubles per lane and vector, 25 resident
+// A fragments) and one B wave (the bookkeeper of wn_fast.h).  See wn_fast.h for the protocol.  Two waves per
+// SIMD hide each other's LDS / cross-lane latencies, and a T wave needs ~150 of its 256 registers, which
+// leaves room to keep every on-chip U-turn check of a tick in flight at once and to prefetch the left
+// endpoints of the deep sub-tree levels from memory under the MFMAs.
 //
 // One tick of the workgroup:
 //
@@ -10,13 +14,13 @@
 //   start / end swap on command; first half of the       dots -> fire mask) of the leaf being retired
 //   leapfrog step; publish Q[t] to LDS
 //   ---------------------------- barrier A (LDS only) -----------------------------------------------
-//   G = -A Q (50 x v_mfma_f64_16x16x4_f64 per wave),     FastBook::tick: retire tick t-1 (energies, weights,
+//   G = -A Q (25 x v_mfma_f64_16x16x4_f64 per wave),     FastBook::tick: retire tick t-1 (energies, weights,
 //   second half step, per-wave partials P[t] of lp,      multinomial pick, doubling / iteration ends,
 //   KE and the U-turn dots due at this leaf, sub-tree    diagnostics row), issue command C[t+1]; momentum
 //   endpoint stores                                      normals of one chain's next iteration
 //   ---------------------------- barrier B (LDS only) -----------------------------------------------
 //
-// LDS (doubles): Q exchange 2 x [tp][e][lane] (double-buffered: buffer t&1 still holds the position of
+// LDS (doubles): Q exchange 2 x [k-step][lane] (double-buffered: buffer t&1 still holds the position of
 // tick t-2 when a pick of that leaf is commanded, buffer (t-1)&1 is the first state of the leaf pair),
 // passive orbit end (q, v), NLC cached sub-tree levels (q, v), partials [quantity][tp][chain], commands.
 // Memory: deeper sub-tree levels, the two proposal buffers (positions only: the gradient of a restart
@@ -44,7 +48,7 @@ using namespace fast;
 #define WN_FSTAMP_DECL unsigned long long fst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fst_last_ = __builtin_readcyclecounter();
 #define WN_FSTAMP_OUT(prm)                                                                             \
   if ((prm).stamps && (threadIdx.x & 63) == 0) {                                                       \
-    unsigned long long* o_ = (prm).stamps + ((size_t)blockIdx.x * 5 + (threadIdx.x >> 6)) * 16;        \
+    unsigned long long* o_ = (prm).stamps + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16;        \
     for (int k = 0; k < 8; ++k) o_[k] = fst_[k];                                                       \
   }
 #else
@@ -53,24 +57,23 @@ using namespace fast;
 #define WN_FSTAMP_OUT(prm)
 #endif
 
-template <int NT, int KS, int TK, int NLC>
+template <int KS, int TK, int NLC>
 struct FastGeom {
-  static constexpr int W = 4;                 // T waves
-  static constexpr int NE = NT * 4;           // doubles per lane and vector
-  static constexpr int VECD = W * NE * 64;    // one D-vector of the 16-chain group in memory (padded)
-  static constexpr int REG = KS * 64;         // ... in LDS: [s][lane], s = tp*NE + e < KS (k-steps that hold coordinates)
-  static constexpr int DPAD = 16 * NT * W;
+  static constexpr int NW = 8;                // tile slots = waves (slot 7 is the B wave: no tile)
+  static constexpr int NE = 4;                // doubles per lane and vector: one 16-row tile
+  static constexpr int VECD = NW * NE * 64;   // one D-vector of the 16-chain group in memory (padded to 128 rows)
+  static constexpr int REG = KS * 64;         // ... in LDS: [s][lane], s = 4*tile + e < KS (k-steps that hold coordinates)
+  static constexpr int DPAD = 16 * NW;
   static constexpr int MP = 12;               // largest M (sizes the partials)
   static constexpr int NQ = Q_DOT0 + 2 * (MP + 1);
   static constexpr int NFAST = 2 + NLC;
-  static_assert(KS <= 4 * NT * W, "k-steps exceed the padded dimension");
+  static_assert(KS <= 28, "seven tiles of 16 rows");
   // LDS map, in doubles
   static constexpr int OFF_Q = 0;                          // 2 x REG
   static constexpr int OFF_COLD = OFF_Q + 2 * REG;         // qb, vb
   static constexpr int OFF_LC = OFF_COLD + 2 * REG;        // NLC x (q, v)
-  static constexpr int OFF_VL = OFF_LC + NLC * 2 * REG;    // velocity of the first state of the current leaf pair
-  static constexpr int OFF_PART = OFF_VL + REG;            // NQ x [chain][tp]
-  static constexpr int OFF_CMD = OFF_PART + NQ * 64;       // 2 x 16 commands of 2 doubles
+  static constexpr int OFF_PART = OFF_LC + NLC * 2 * REG;  // NQ x [chain][tile slot]
+  static constexpr int OFF_CMD = OFF_PART + NQ * 16 * NW;  // 2 x 16 commands of 2 doubles
   static constexpr int LDS_DOUBLES = OFF_CMD + 2 * 16 * 2;
   static_assert(LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget (160 KiB per CU)");
   // workspace of one group, in doubles: (M+1) slots x (q, v), 2 proposals, momentum normals [chain][DPAD]
@@ -93,42 +96,37 @@ __device__ __forceinline__ double fast_rowsum4(double x) {
 // ------------------------------------------------------------------------------------------------
 // T waves
 // ------------------------------------------------------------------------------------------------
-template <int NT, int KS, int TK, int NLC>
-__device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, int wave) {
-  using G = FastGeom<NT, KS, TK, NLC>;
-  constexpr int NE = G::NE, W = G::W, NFAST = G::NFAST;
+template <int KS, int TK, int NLC>
+__device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, const int tile) {
+  using G = FastGeom<KS, TK, NLC>;
+  constexpr int NE = G::NE, NFAST = G::NFAST;
   const int lane = threadIdx.x & 63, cn = lane & 15, lg = lane >> 4;
-  const int tp = (wave + 3) & 3;  // tile pair of this wave: wave 0 (shares its SIMD with the B wave) gets the last, lightest one
   const int cl = blockIdx.x * 16 + cn;
   const bool inrange = cl < prm.C;
   const int D = prm.D;
-  auto gidx = [&](int e) { return 16 * (tp * NT + (e >> 2)) + 4 * (e & 3) + lg; };
-  int ntl = (D + 15) / 16 - tp * NT;  // tiles of this wave that hold coordinates
-  ntl = ntl < 0 ? 0 : (ntl > NT ? NT : ntl);
-  int nev = KS - tp * NE;  // registers e < nev of this wave hold coordinates (k-steps s = tp*NE + e < KS); the rest stay 0
+  auto gidx = [&](int e) { return 16 * tile + 4 * e + lg; };
+  const bool has_tile = 16 * tile < D;  // this wave's tile holds coordinates (wave-uniform)
+  int nev = KS - 4 * tile;              // registers e < nev hold coordinates (k-steps s = 4*tile + e < KS); the rest stay 0
   nev = nev < 0 ? 0 : (nev > NE ? NE : nev);
 
-  double* const own = lds + (size_t)(tp * NE) * 64 + lane;  // + buffer / region offset + e*64
+  double* const own = lds + (size_t)(4 * tile) * 64 + lane;  // + region offset + e*64
   double* part = lds + G::OFF_PART;
   const Cmd* cmdbuf = reinterpret_cast<const Cmd*>(lds + G::OFF_CMD);
   double* wbase = prm.work + (size_t)blockIdx.x * G::group_doubles(prm.M);
-  auto gvec = [&](int vec) { return wbase + (size_t)vec * G::VECD + ((size_t)(cn * W + tp) * NE) * 4 + lg; };  // + e*4
+  auto gvec = [&](int vec) { return wbase + (size_t)vec * G::VECD + ((size_t)(cn * G::NW + tile) * NE) * 4 + lg; };  // + e*4
   const int vprop = (prm.M + 1) * 2;
   const double* znext = wbase + (size_t)((prm.M + 1) * 2 + 2) * G::VECD + (size_t)cn * G::DPAD;
 
-  // -A fragments of this wave's row tiles, resident for the whole run
-  constexpr int NA = (TK == CK_DENSE) ? NT * KS : 1;
+  // -A fragments of this wave's row tile, resident for the whole run
+  constexpr int NA = (TK == CK_DENSE) ? KS : 1;
   double afrag[NA];
   double adiag[NE];
   if (TK == CK_DENSE) {
+    const int row = 16 * tile + (lane & 15);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int row = 16 * (tp * NT + t) + (lane & 15);
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int col = 4 * s + (lane >> 4);
-        afrag[t * KS + s] = (row < D && col < D) ? -prm.tpar[(size_t)row * D + col] : 0.0;
-      }
+    for (int s = 0; s < KS; ++s) {
+      const int col = 4 * s + (lane >> 4);
+      afrag[s] = (row < D && col < D) ? -prm.tpar[(size_t)row * D + col] : 0.0;
     }
   } else {
     afrag[0] = 0.0;
@@ -136,9 +134,15 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, int 
 #pragma unroll
   for (int e = 0; e < NE; ++e) adiag[e] = (TK == CK_DIAG && gidx(e) < D) ? prm.tpar[gidx(e)] : 0.0;
 
-  double q[NE], v[NE], g[NE];
+  double q[NE], v[NE], g[NE], VL[NE];
 #pragma unroll
-  for (int e = 0; e < NE; ++e) { q[e] = v[e] = g[e] = 0.0; }
+  for (int e = 0; e < NE; ++e) { q[e] = v[e] = g[e] = VL[e] = 0.0; }
+
+  // partials for the bookkeeper: [quantity][chain][tile slot]
+  auto put = [&](int k, double x) {
+    x = fast_rowsum4(x);
+    if (lg == 0) part[(k * 16 + cn) * G::NW + tile] = x;
+  };
 
   WN_FSTAMP_DECL
   for (uint32_t t = 0;; ++t) {
@@ -148,8 +152,31 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, int 
     else c = cmdbuf[(t & 1u) * 16 + cn];
     const uint32_t op = c.op;
     if (__any((op & OP_DONE) != 0)) break;
+    const bool step = (op & OP_STEP) != 0;
+    const int i = (int)((op >> OP_I_SHIFT) & 31u), n = (int)c.n;
+    const int nchk = step ? nchecks(i, n) : 0;
     double keinit_part = 0.0, gen_part = 0.0;
     // ---- phase 1: commands ----
+    // left endpoints of the first two deep sub-tree levels this leaf closes: requested from memory now, used
+    // after the MFMAs (the slots were stored by these same lanes)
+    double pq0[NE], pv0[NE], pq1[NE], pv1[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { pq0[e] = pv0[e] = pq1[e] = pv1[e] = 0.0; }
+    const bool deep0 = nchk > NFAST, deep1 = nchk > NFAST + 1;
+    if (__any(deep0)) {
+      if (deep0) {
+        const int sl = slot_of_leaf(n + 1 - (1 << NFAST));
+        const double* sq = gvec(sl * 2);
+        const double* sv = gvec(sl * 2 + 1);
+        WN_EV(e) { pq0[e] = sq[e * 4]; pv0[e] = sv[e * 4]; }
+      }
+      if (deep1) {
+        const int sl = slot_of_leaf(n + 1 - (2 << NFAST));
+        const double* sq = gvec(sl * 2);
+        const double* sv = gvec(sl * 2 + 1);
+        WN_EV(e) { pq1[e] = sq[e * 4]; pv1[e] = sv[e * 4]; }
+      }
+    }
     if (__any((op & OP_PICK) != 0)) {  // the position of tick t-2 still sits in this tick's Q buffer
       if (op & OP_PICK) {
         double* dst = gvec(vprop + ((op & OP_IPPICK) ? 1 : 0));
@@ -171,7 +198,7 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, int 
         // samples[:, row] = generated(q)  (WALNUTS.py:164,695)
         double* row = prm.samples + ((size_t)cl * (prm.numIter + 1) + c.n) * prm.dg;
         if (prm.generated == G_Q0_SUMSQ) {
-          if (tp == 0 && lg == 0) row[0] = q[0];
+          if (tile == 0 && lg == 0) row[0] = q[0];
           double s = 0.0;
 #pragma unroll
           for (int e = 0; e < NE; ++e) s += q[e] * q[e];
@@ -204,7 +231,6 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, int 
     }
     // ---- first half of the leapfrog step (adaptiveIntegrators.py:51-52 with hs = xi*h; v is kept in
     // forward-time orientation: xi*(xi*v + h/2 g) = v + (xi h/2) g exactly) ----
-    const bool step = (op & OP_STEP) != 0;
     const double hs = step ? c.hs : 0.0, hs2 = 0.5 * hs;
 #pragma unroll
     for (int e = 0; e < NE; ++e) { v[e] = v[e] + hs2 * g[e]; q[e] = q[e] + hs * v[e]; }
@@ -214,30 +240,16 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, int 
     WN_FSTAMP(1);
     // ---- phase 2: gradient, second half step, partials ----
     if (TK == CK_DENSE) {
-      // one straight-line MFMA chain per case of "how many of this wave's tiles hold coordinates" (a branch per
-      // MFMA would cut the chain into basic blocks and stop the B-fragment loads from running ahead)
-      d4_t acc[NT];
-#pragma unroll
-      for (int tt = 0; tt < NT; ++tt) acc[tt] = (d4_t){0.0, 0.0, 0.0, 0.0};
-      if (ntl == NT) {
+      d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+      if (has_tile) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
           const double bq = lds[bq_ + s * 64 + lane];
-#pragma unroll
-          for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[tt * KS + s], bq, acc[tt], 0, 0, 0);
-        }
-      } else if (ntl > 0) {  // NT == 2: only the first tile
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const double bq = lds[bq_ + s * 64 + lane];
-          acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[s], bq, acc[0], 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[s], bq, acc, 0, 0, 0);
         }
       }
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) g[tt * 4 + r] = acc[tt][r];
-      }
+      for (int r = 0; r < 4; ++r) g[r] = acc[r];
     } else {
 #pragma unroll
       for (int e = 0; e < NE; ++e) g[e] = -(adiag[e] * q[e]);
@@ -248,15 +260,10 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, int 
 #pragma unroll
     for (int e = 0; e < NE; ++e) { v[e] = v[e] + hs2 * g[e]; pk += v[e] * v[e]; }
     WN_FSTAMP(2);
-    // partials for the bookkeeper: [quantity][chain][tile pair], one 32-byte row per chain
-    auto put = [&](int k, double x) {
-      x = fast_rowsum4(x);
-      if (lg == 0) part[(k * 16 + cn) * 4 + tp] = x;
-    };
     put(Q_LP, pl); put(Q_KE, pk);
     if (__any((op & OP_NEWITER) != 0)) { put(Q_KEINIT, keinit_part); put(Q_GEN, gen_part); }
     WN_FSTAMP(3);
-    // ---- U-turn dots of the sub-tree checks due at this leaf + endpoint stores ----
+    // ---- U-turn dots of the sub-tree checks due at this leaf ----
     // dq = q' - qo;  d1 = v'.dq, d2 = vo.dq   (stopCondition, WALNUTS.py:95-97; velocities forward-time)
 #define WN_FAST_DOTS(D1, D2, QO, VO)                  \
   {                                                   \
@@ -266,51 +273,47 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, int 
       D2 += (VO) * dq;                                \
     }                                                 \
   }
-    const int i = (int)((op >> OP_I_SHIFT) & 31u), n = (int)c.n;
-    const int nchk = step ? nchecks(i, n) : 0;
     if (__any(nchk > 0)) {
       // Every on-chip check of the group's chains in ONE straight-line block, needed by this lane's chain or not
-      // (the bookkeeper reads only what its leaf needs): leaf pair, cached sub-tree levels, and -- when some
-      // chain is at the last leaf of its doubling -- the passive orbit end.  Registers e >= nev are zero on both
-      // sides of every product.
-      // one level after the other (their loads all in flight at once do not fit the 256 registers of a wave), but no
-      // branches in between: the loads of a level run under the row sums of the one before
-      const bool any0 = __any(nchk > 0 && need_check(i, n, 0));
-      if (any0) {
-        double a1 = 0.0, a2 = 0.0;
-        WN_FAST_DOTS(a1, a2, (e < nev ? own[G::OFF_COLD + e * 64] : 0.0), (e < nev ? own[G::OFF_COLD + G::REG + e * 64] : 0.0))
-        put(Q_DOT0, a1); put(Q_DOT0 + 1, a2);
-      }
-      {
-        double a1 = 0.0, a2 = 0.0;
-        WN_FAST_DOTS(a1, a2, (e < nev ? own[bp_ + e * 64] : 0.0), (e < nev ? own[G::OFF_VL + e * 64] : 0.0))
-        put(Q_DOT0 + 2, a1); put(Q_DOT0 + 3, a2);
-      }
+      // (the bookkeeper reads only what its leaf needs): passive orbit end, leaf pair, cached sub-tree levels, and
+      // the two prefetched deep levels.  Registers e >= nev are zero on both sides of every product.
+      double d1[NFAST + 2], d2[NFAST + 2];
 #pragma unroll
-      for (int j = 2; j < NFAST; ++j) {
-        double a1 = 0.0, a2 = 0.0;
-        WN_FAST_DOTS(a1, a2, (e < nev ? own[G::OFF_LC + (j - 2) * 2 * G::REG + e * 64] : 0.0),
+      for (int j = 0; j < NFAST + 2; ++j) { d1[j] = 0.0; d2[j] = 0.0; }
+      WN_FAST_DOTS(d1[0], d2[0], (e < nev ? own[G::OFF_COLD + e * 64] : 0.0), (e < nev ? own[G::OFF_COLD + G::REG + e * 64] : 0.0))
+      WN_FAST_DOTS(d1[1], d2[1], (e < nev ? own[bp_ + e * 64] : 0.0), VL[e])
+#pragma unroll
+      for (int j = 2; j < NFAST; ++j)
+        WN_FAST_DOTS(d1[j], d2[j], (e < nev ? own[G::OFF_LC + (j - 2) * 2 * G::REG + e * 64] : 0.0),
                      (e < nev ? own[G::OFF_LC + ((j - 2) * 2 + 1) * G::REG + e * 64] : 0.0))
-        put(Q_DOT0 + 2 * j, a1); put(Q_DOT0 + 2 * j + 1, a2);
-      }
+      const bool anyd0 = __any(deep0), anyd1 = __any(deep1);
+      if (anyd0) WN_FAST_DOTS(d1[NFAST], d2[NFAST], pq0[e], pv0[e])
+      if (anyd1) WN_FAST_DOTS(d1[NFAST + 1], d2[NFAST + 1], pq1[e], pv1[e])
+#pragma unroll
+      for (int j = 0; j < NFAST; ++j) { put(Q_DOT0 + 2 * j, d1[j]); put(Q_DOT0 + 2 * j + 1, d2[j]); }
+      if (anyd0) { put(Q_DOT0 + 2 * NFAST, d1[NFAST]); put(Q_DOT0 + 2 * NFAST + 1, d2[NFAST]); }
+      if (anyd1) { put(Q_DOT0 + 2 * NFAST + 2, d1[NFAST + 1]); put(Q_DOT0 + 2 * NFAST + 3, d2[NFAST + 1]); }
       WN_FSTAMP(4);
-      for (int j = NFAST; __any(nchk > j); ++j) {  // deeper levels: left endpoint from the slot store in memory
+      for (int j = NFAST + 2; __any(nchk > j); ++j) {  // still deeper levels (one leaf in 2**(NFAST+2)): fetched here
         const bool need = nchk > j;
         double e1 = 0.0, e2 = 0.0;
         if (need) {
           const int sl = slot_of_leaf(n + 1 - (1 << j));
-          const double* pq = gvec(sl * 2);
-          const double* pv = gvec(sl * 2 + 1);
-          WN_FAST_DOTS(e1, e2, (e < nev ? pq[e * 4] : 0.0), (e < nev ? pv[e * 4] : 0.0))
+          const double* sq = gvec(sl * 2);
+          const double* sv = gvec(sl * 2 + 1);
+          WN_FAST_DOTS(e1, e2, (e < nev ? sq[e * 4] : 0.0), (e < nev ? sv[e * 4] : 0.0))
         }
         put(Q_DOT0 + 2 * j, e1); put(Q_DOT0 + 2 * j + 1, e2);
       }
       WN_FSTAMP(7);
     }
 #undef WN_FAST_DOTS
-    // statePush (:431,518): only sub-tree left endpoints are ever read back
+    // ---- statePush (:431,518): only sub-tree left endpoints are ever read back ----
     const bool even = step && i >= 1 && (n & 1) == 0;
-    if (even) { WN_EV(e) own[G::OFF_VL + e * 64] = v[e]; }
+    if (even) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) VL[e] = v[e];
+    }
     const bool ep = even && i >= 2 && (n & 3) == 0;
     if (__any(ep)) {
       if (ep) {
@@ -324,9 +327,9 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, int 
           }
         if (n == 0 ? (i >= NFAST) : (__builtin_ctz((unsigned)n) >= NFAST)) {
           const int sl = slot_of_leaf(n);
-          double* pq = gvec(sl * 2);
-          double* pv = gvec(sl * 2 + 1);
-          WN_EV(e) { pq[e * 4] = q[e]; pv[e * 4] = v[e]; }
+          double* sq = gvec(sl * 2);
+          double* sv = gvec(sl * 2 + 1);
+          WN_EV(e) { sq[e * 4] = q[e]; sv[e * 4] = v[e]; }
         }
       }
     }
@@ -367,13 +370,13 @@ struct FastDevIO {
   }
 };
 
-template <int NT, int KS, int TK, int NLC>
+template <int KS, int TK, int NLC>
 __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int* abort_flag) {
-  using G = FastGeom<NT, KS, TK, NLC>;
+  using G = FastGeom<KS, TK, NLC>;
   const int lane = threadIdx.x & 63, cn = lane & 15, lg = lane >> 4;
   const int cl = blockIdx.x * 16 + cn;
   const bool inrange = cl < prm.C;
-  const double* part = lds + G::OFF_PART;
+  double* part = lds + G::OFF_PART;
   Cmd* cmdbuf = reinterpret_cast<Cmd*>(lds + G::OFF_CMD);
   double* znext = prm.work + (size_t)blockIdx.x * G::group_doubles(prm.M) + (size_t)((prm.M + 1) * 2 + 2) * G::VECD;
 
@@ -382,25 +385,15 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
   FastDevIO io;
   io.prm = &prm; io.cl = cl; io.lg = lg;
   io.lp = io.ke = io.keinit = io.gen = 0.0; io.fire = 0u;
-  // sum of the four waves' partials in tile order (the order of CoopPolicy::reduce): one 32-byte row per chain
-  typedef double d4r_t __attribute__((ext_vector_type(4)));
-  auto sum4 = [&](int k) {
-    const d4r_t x = *reinterpret_cast<const d4r_t*>(part + (k * 16 + cn) * 4);
-    double s = 0.0;
-    s += x[0]; s += x[1]; s += x[2]; s += x[3];
-    return s;
+  // tile slot 7 belongs to this wave and holds no coordinates: its partials are zero for the whole run
+  for (int k = lg; k < G::NQ; k += 4) part[(k * 16 + cn) * G::NW + 7] = 0.0;
+  // sum of the tile partials of one quantity: lane group lg adds slots 2lg and 2lg+1, then the four lane groups
+  // are added in the fixed tree of fast_rowsum4, so all four replicas of a chain hold the same bits
+  typedef double d2r_t __attribute__((ext_vector_type(2)));
+  auto sumq = [&](int k) {
+    const d2r_t x = *reinterpret_cast<const d2r_t*>(part + (k * 16 + cn) * G::NW + 2 * lg);
+    return fast_rowsum4(x[0] + x[1]);
   };
-  struct DotSrc {
-    const double* part; int cn;
-    __device__ __forceinline__ void dots(int j, double& d1, double& d2) const {
-      const d4r_t x = *reinterpret_cast<const d4r_t*>(part + ((Q_DOT0 + 2 * j) * 16 + cn) * 4);
-      const d4r_t y = *reinterpret_cast<const d4r_t*>(part + ((Q_DOT0 + 2 * j + 1) * 16 + cn) * 4);
-      double a = 0.0, b = 0.0;
-      a += x[0]; a += x[1]; a += x[2]; a += x[3];
-      b += y[0]; b += y[1]; b += y[2]; b += y[3];
-      d1 = a; d2 = b;
-    }
-  } dsrc{part, cn};
   // every chain needs at most numIter * (2^M - 1 + 2 idle ticks per doubling + start) ticks; twice that is an internal error
   const double cap = 256.0 + 2.0 * (double)prm.numIter * ((double)(1u << prm.M) + 4.0 * (double)prm.M + 16.0);
 
@@ -408,10 +401,18 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
   for (uint32_t t = 0;; ++t) {
     // ---- what tick t-1 left in the partials, before the T waves overwrite them (behind barrier A) ----
     if (t > 0) {
-      io.lp = sum4(Q_LP); io.ke = sum4(Q_KE);
-      if (__any(bk.s0.kind == FastBook::K_NEWITER)) { io.keinit = sum4(Q_KEINIT); io.gen = sum4(Q_GEN); }
-      io.fire = 0u;
-      if (bk.s0.kind == FastBook::K_STEP && !bk.s0.discard) io.fire = fire_of(bk.i, bk.s0.n, bk.xi, dsrc);
+      io.lp = sumq(Q_LP); io.ke = sumq(Q_KE);
+      if (__any(bk.s0.kind == FastBook::K_NEWITER)) { io.keinit = sumq(Q_KEINIT); io.gen = sumq(Q_GEN); }
+      // U-turn verdicts of the leaf being retired (wn_fast.h fire_of; the sums need all lanes, so every lane walks
+      // the levels any chain of the group needs)
+      const bool live_step = bk.s0.kind == FastBook::K_STEP && !bk.s0.discard;
+      const int nchk = live_step ? nchecks(bk.i, bk.s0.n) : 0;
+      uint32_t fire = 0u;
+      for (int j = 0; __any(nchk > j); ++j) {
+        const double d1 = sumq(Q_DOT0 + 2 * j), d2 = sumq(Q_DOT0 + 2 * j + 1);
+        if (nchk > j && need_check(bk.i, bk.s0.n, j) && (((double)bk.xi * d1 < 0.0) || ((double)bk.xi * d2 < 0.0))) fire |= (1u << j);
+      }
+      io.fire = fire;
     }
     WN_FSTAMP(0);
     WN_LDS_BARRIER();  // A
@@ -433,7 +434,7 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
         const int cs = __builtin_ctzll(want);  // lanes 0..15 are chains 0..15
         const int it = __shfl(bk.zwant, cs);
         const uint32_t ch = (uint32_t)__shfl((int)bk.chain, cs);
-        if (2 * lane < G::DPAD) {
+        {
           Philox4 p = philox4x32_10((uint32_t)lane, (uint32_t)it, ch, 1u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
           const uint64_t x0 = ((uint64_t)p.w[1] << 32) | p.w[0];
           const double u1 = ((double)(x0 >> 12) + 0.5) * 0x1.0p-52;
@@ -461,32 +462,35 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
   WN_FSTAMP_OUT(prm)
 }
 
-template <int NT, int KS, int TK, int NLC>
-__global__ __launch_bounds__(320) void wn_fast_kernel(Params prm, int* abort_flag) {
-  __shared__ double lds[FastGeom<NT, KS, TK, NLC>::LDS_DOUBLES];
+template <int KS, int TK, int NLC>
+__global__ __launch_bounds__(512) void wn_fast_kernel(Params prm, int* abort_flag) {
+  __shared__ double lds[FastGeom<KS, TK, NLC>::LDS_DOUBLES];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform for the compiler too: no exec masking around MFMAs
-  if (wave < 4) fast_t_wave<NT, KS, TK, NLC>(prm, lds, wave);
-  else fast_b_wave<NT, KS, TK, NLC>(prm, lds, abort_flag);
+  // tile of T wave w.  Waves w and w+4 share a SIMD (a workgroup's waves are dealt to the SIMDs cyclically: speed only),
+  // so the B wave (7) sits beside wave 3, which gets the last tile -- for D = 100 the one with only 4 rows
+  if (wave < 7) fast_t_wave<KS, TK, NLC>(prm, lds, wave < 3 ? wave : (wave == 3 ? 6 : wave - 1));
+  else fast_b_wave<KS, TK, NLC>(prm, lds, abort_flag);
 }
 
 // can the role-split kernel run this launch?  fixedLeapFrog sampling without trace / warm-up / orbit statistics
 bool fast_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm) {
   if (kc.layout != 1 || adapt != 0 || warm || prm.mode != MODE_SAMPLE) return false;
   if (prm.trace_n || prm.omin || prm.M > 12) return false;
-  if (kc.p1 == CK_DENSE) return kc.p0 == 25 || kc.p0 == 16;  // KS = 32 (100 < D <= 128): 64 resident A fragments do not fit beside the rest
+  if (prm.D > 112) return false;  // seven 16-row tiles
+  if (kc.p1 == CK_DENSE) return kc.p0 == 25 || kc.p0 == 16;
   return kc.p0 == 16 || kc.p0 == 32;
 }
 
 hipError_t launch_fast(const KernelChoice& kc, const Params& prm, int* abort_flag, hipStream_t st) {
-  dim3 grid((prm.C + 15) / 16), block(320);
-#define WN_FAST_GO(NT, KS, TK) \
-  { hipLaunchKernelGGL((wn_fast_kernel<NT, KS, TK, (KS <= 25 ? 3 : 2)>), grid, block, 0, st, prm, abort_flag); return hipGetLastError(); }
+  dim3 grid((prm.C + 15) / 16), block(512);
+#define WN_FAST_GO(KS, TK) \
+  { hipLaunchKernelGGL((wn_fast_kernel<KS, TK, (KS <= 25 ? 3 : 2)>), grid, block, 0, st, prm, abort_flag); return hipGetLastError(); }
   if (kc.p1 == CK_DENSE) {
-    if (kc.p0 == 16) WN_FAST_GO(1, 16, CK_DENSE)
-    if (kc.p0 == 25) WN_FAST_GO(2, 25, CK_DENSE)
+    if (kc.p0 == 16) WN_FAST_GO(16, CK_DENSE)
+    if (kc.p0 == 25) WN_FAST_GO(25, CK_DENSE)
   } else {
-    if (kc.p0 == 16) WN_FAST_GO(1, 16, CK_DIAG)
-    if (kc.p0 == 32) WN_FAST_GO(2, 32, CK_DIAG)
+    if (kc.p0 == 16) WN_FAST_GO(16, CK_DIAG)
+    if (kc.p0 == 32) WN_FAST_GO(28, CK_DIAG)  // D <= 112
   }
 #undef WN_FAST_GO
   return hipErrorInvalidValue;
