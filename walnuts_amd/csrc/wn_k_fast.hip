@@ -74,7 +74,8 @@ struct FastGeom {
   static constexpr int OFF_LC = OFF_COLD + 2 * REG;        // NLC x (q, v)
   static constexpr int OFF_PART = OFF_LC + NLC * 2 * REG;  // NQ x [chain][tile slot]
   static constexpr int OFF_CMD = OFF_PART + NQ * 16 * NW;  // 2 x 16 commands of 2 doubles
-  static constexpr int LDS_DOUBLES = OFF_CMD + 2 * 16 * 2;
+  static constexpr int OFF_DUMP = OFF_CMD + 2 * 16 * 2;    // 64 doubles nobody reads (see put() of the T waves)
+  static constexpr int LDS_DOUBLES = OFF_DUMP + 64;
   static_assert(LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget (160 KiB per CU)");
   // workspace of one group, in doubles: (M+1) slots x (q, v), 2 proposals, momentum normals [chain][DPAD]
   static constexpr size_t group_doubles(int M) { return (size_t)((M + 1) * 2 + 2) * VECD + (size_t)16 * DPAD; }
@@ -93,21 +94,38 @@ __device__ __forceinline__ double fast_rowsum4(double x) {
   return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
 
+// the two halves of fast_rowsum4, for work that is spread over MFMA gaps
+__device__ __forceinline__ double fast_rowsum4_a(double x) {
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  const u2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const u2_t b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double fast_rowsum4_b(double y) {
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  const unsigned lo = __double2loint(y), hi = __double2hiint(y);
+  const u2_t a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const u2_t b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // T waves
 // ------------------------------------------------------------------------------------------------
-template <int KS, int TK, int NLC>
+// NEV: registers e < NEV of this wave hold coordinates (k-steps s = 4*tile + e < KS), the rest stay 0.  A template
+// parameter, not a run-time bound: every `e < nev` below is then resolved at compile time, and the phase-2 block of
+// the tick loop stays free of control flow (see there).
+template <int KS, int TK, int NLC, int NEV>
 __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, const int tile) {
   using G = FastGeom<KS, TK, NLC>;
+  constexpr int nev = NEV;
   constexpr int NE = G::NE, NFAST = G::NFAST;
   const int lane = threadIdx.x & 63, cn = lane & 15, lg = lane >> 4;
   const int cl = blockIdx.x * 16 + cn;
   const bool inrange = cl < prm.C;
   const int D = prm.D;
   auto gidx = [&](int e) { return 16 * tile + 4 * e + lg; };
-  const bool has_tile = 16 * tile < D;  // this wave's tile holds coordinates (wave-uniform)
-  int nev = KS - 4 * tile;              // registers e < nev hold coordinates (k-steps s = 4*tile + e < KS); the rest stay 0
-  nev = nev < 0 ? 0 : (nev > NE ? NE : nev);
 
   double* const own = lds + (size_t)(4 * tile) * 64 + lane;  // + region offset + e*64
   double* part = lds + G::OFF_PART;
@@ -139,9 +157,33 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, cons
   for (int e = 0; e < NE; ++e) { q[e] = v[e] = g[e] = VL[e] = 0.0; }
 
   // partials for the bookkeeper: [quantity][chain][tile slot]
+  // (every lane stores: lanes of lane groups 1..3 into a dump row.  A store under `if (lg == 0)` is control flow, and
+  // control flow between the MFMAs would cut the block in which the check work is to issue in their gaps)
+  double* const dump = lds + G::OFF_DUMP + lane;
+  double* const prow = part + cn * G::NW + tile;
   auto put = [&](int k, double x) {
     x = fast_rowsum4(x);
-    if (lg == 0) part[(k * 16 + cn) * G::NW + tile] = x;
+    double* dst = lg == 0 ? prow + k * 16 * G::NW : dump;
+    *dst = x;
+  };
+
+  // Row sums of FOUR quantities at once, as a butterfly: lane groups 0/1 exchange so that even rows end with a and b
+  // summed over the pair and odd rows with c and d, then the halves exchange: lane group 0 ends with the sum of a,
+  // 1 with c, 2 with b, 3 with d -- 6 permlane swaps and 3 additions instead of 16 and 8 -- and each lane group
+  // stores its quantity (same association as fast_rowsum4: (x0 + x1) + (x2 + x3)).
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  auto put4 = [&](int ka, int kb, int kc, int kd, double a, double b, double c, double d) {
+    auto pair16 = [](double P, double Q) {  // even rows: P_even + P_odd, odd rows: Q_even + Q_odd
+      const u2_t l = __builtin_amdgcn_permlane16_swap(__double2loint(P), __double2loint(Q), false, false);
+      const u2_t h = __builtin_amdgcn_permlane16_swap(__double2hiint(P), __double2hiint(Q), false, false);
+      return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+    };
+    const double r1 = pair16(a, c), r2 = pair16(b, d);
+    const u2_t l = __builtin_amdgcn_permlane32_swap(__double2loint(r1), __double2loint(r2), false, false);
+    const u2_t h = __builtin_amdgcn_permlane32_swap(__double2hiint(r1), __double2hiint(r2), false, false);
+    const double z = __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+    const int k = lg == 0 ? ka : lg == 1 ? kc : lg == 2 ? kb : kd;
+    prow[k * 16 * G::NW] = z;
   };
 
   WN_FSTAMP_DECL
@@ -239,14 +281,15 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, cons
     WN_LDS_BARRIER();  // A
     WN_FSTAMP(1);
     // ---- phase 2: gradient, second half step, partials ----
+    // (On this chip the FP64 matrix and vector instructions share their arithmetic units: vector work placed in the
+    // gaps of the MFMA chain -- tried, in source order and with sched_group_barrier -- lengthened the chain by about
+    // what it saved behind it.  What counts is the NUMBER of vector instructions per tick.)
     if (TK == CK_DENSE) {
-      d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
-      if (has_tile) {
+      d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};  // (a wave whose tile is beyond D multiplies zeros: no branch here)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const double bq = lds[bq_ + s * 64 + lane];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[s], bq, acc, 0, 0, 0);
-        }
+      for (int s = 0; s < KS; ++s) {
+        const double bq = lds[bq_ + s * 64 + lane];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[s], bq, acc, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) g[r] = acc[r];
@@ -260,54 +303,64 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, cons
 #pragma unroll
     for (int e = 0; e < NE; ++e) { v[e] = v[e] + hs2 * g[e]; pk += v[e] * v[e]; }
     WN_FSTAMP(2);
-    put(Q_LP, pl); put(Q_KE, pk);
+    // ---- U-turn dots of the sub-tree checks due at this leaf: dq = q' - qo, d1 = v'.dq, d2 = vo.dq (stopCondition,
+    // WALNUTS.py:95-97; velocities forward-time).  All on-chip levels of the group's chains, needed by this lane's
+    // chain or not (the bookkeeper reads only what its leaf needs): passive orbit end, leaf pair, cached sub-tree
+    // levels, the two prefetched deep levels.  Registers e >= nev are zero on both sides of every product. ----
+    constexpr int NCK = NFAST + 2;
+    const bool anychk = __any(nchk > 0);
+    if (anychk) {
+      double d1[NCK], d2[NCK];
+#pragma unroll
+      for (int j = 0; j < NCK; ++j) {
+        double qo[NE], vo[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          if (j == 0) { qo[e] = e < nev ? own[G::OFF_COLD + e * 64] : 0.0; vo[e] = e < nev ? own[G::OFF_COLD + G::REG + e * 64] : 0.0; }
+          else if (j == 1) { qo[e] = e < nev ? own[bp_ + e * 64] : 0.0; vo[e] = VL[e]; }
+          else if (j < NFAST) {
+            qo[e] = e < nev ? own[G::OFF_LC + (j - 2) * 2 * G::REG + e * 64] : 0.0;
+            vo[e] = e < nev ? own[G::OFF_LC + ((j - 2) * 2 + 1) * G::REG + e * 64] : 0.0;
+          } else if (j == NFAST) { qo[e] = pq0[e]; vo[e] = pv0[e]; }
+          else { qo[e] = pq1[e]; vo[e] = pv1[e]; }
+        }
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const double dqe = q[e] - qo[e];
+          a1 += v[e] * dqe;
+          a2 += vo[e] * dqe;
+        }
+        d1[j] = a1; d2[j] = a2;
+      }
+      // four quantities per butterfly (put4): (lp, KE, level 0), then two levels each
+      put4(Q_LP, Q_KE, Q_DOT0, Q_DOT0 + 1, pl, pk, d1[0], d2[0]);
+#pragma unroll
+      for (int j = 1; j + 1 < NCK; j += 2)
+        put4(Q_DOT0 + 2 * j, Q_DOT0 + 2 * j + 1, Q_DOT0 + 2 * j + 2, Q_DOT0 + 2 * j + 3, d1[j], d2[j], d1[j + 1], d2[j + 1]);
+      if ((NCK & 1) == 0) { put(Q_DOT0 + 2 * (NCK - 1), d1[NCK - 1]); put(Q_DOT0 + 2 * (NCK - 1) + 1, d2[NCK - 1]); }
+    } else {
+      put(Q_LP, pl); put(Q_KE, pk);
+    }
     if (__any((op & OP_NEWITER) != 0)) { put(Q_KEINIT, keinit_part); put(Q_GEN, gen_part); }
     WN_FSTAMP(3);
-    // ---- U-turn dots of the sub-tree checks due at this leaf ----
-    // dq = q' - qo;  d1 = v'.dq, d2 = vo.dq   (stopCondition, WALNUTS.py:95-97; velocities forward-time)
-#define WN_FAST_DOTS(D1, D2, QO, VO)                  \
-  {                                                   \
-    _Pragma("unroll") for (int e = 0; e < NE; ++e) { \
-      const double dq = q[e] - (QO);                  \
-      D1 += v[e] * dq;                                \
-      D2 += (VO) * dq;                                \
-    }                                                 \
-  }
-    if (__any(nchk > 0)) {
-      // Every on-chip check of the group's chains in ONE straight-line block, needed by this lane's chain or not
-      // (the bookkeeper reads only what its leaf needs): passive orbit end, leaf pair, cached sub-tree levels, and
-      // the two prefetched deep levels.  Registers e >= nev are zero on both sides of every product.
-      double d1[NFAST + 2], d2[NFAST + 2];
+    for (int j = NCK; __any(nchk > j); ++j) {  // still deeper levels (one leaf in 2**NCK): fetched here
+      const bool need = nchk > j;
+      double e1 = 0.0, e2 = 0.0;
+      if (need) {
+        const int sl = slot_of_leaf(n + 1 - (1 << j));
+        const double* sq = gvec(sl * 2);
+        const double* sv = gvec(sl * 2 + 1);
 #pragma unroll
-      for (int j = 0; j < NFAST + 2; ++j) { d1[j] = 0.0; d2[j] = 0.0; }
-      WN_FAST_DOTS(d1[0], d2[0], (e < nev ? own[G::OFF_COLD + e * 64] : 0.0), (e < nev ? own[G::OFF_COLD + G::REG + e * 64] : 0.0))
-      WN_FAST_DOTS(d1[1], d2[1], (e < nev ? own[bp_ + e * 64] : 0.0), VL[e])
-#pragma unroll
-      for (int j = 2; j < NFAST; ++j)
-        WN_FAST_DOTS(d1[j], d2[j], (e < nev ? own[G::OFF_LC + (j - 2) * 2 * G::REG + e * 64] : 0.0),
-                     (e < nev ? own[G::OFF_LC + ((j - 2) * 2 + 1) * G::REG + e * 64] : 0.0))
-      const bool anyd0 = __any(deep0), anyd1 = __any(deep1);
-      if (anyd0) WN_FAST_DOTS(d1[NFAST], d2[NFAST], pq0[e], pv0[e])
-      if (anyd1) WN_FAST_DOTS(d1[NFAST + 1], d2[NFAST + 1], pq1[e], pv1[e])
-#pragma unroll
-      for (int j = 0; j < NFAST; ++j) { put(Q_DOT0 + 2 * j, d1[j]); put(Q_DOT0 + 2 * j + 1, d2[j]); }
-      if (anyd0) { put(Q_DOT0 + 2 * NFAST, d1[NFAST]); put(Q_DOT0 + 2 * NFAST + 1, d2[NFAST]); }
-      if (anyd1) { put(Q_DOT0 + 2 * NFAST + 2, d1[NFAST + 1]); put(Q_DOT0 + 2 * NFAST + 3, d2[NFAST + 1]); }
-      WN_FSTAMP(4);
-      for (int j = NFAST + 2; __any(nchk > j); ++j) {  // still deeper levels (one leaf in 2**(NFAST+2)): fetched here
-        const bool need = nchk > j;
-        double e1 = 0.0, e2 = 0.0;
-        if (need) {
-          const int sl = slot_of_leaf(n + 1 - (1 << j));
-          const double* sq = gvec(sl * 2);
-          const double* sv = gvec(sl * 2 + 1);
-          WN_FAST_DOTS(e1, e2, (e < nev ? sq[e * 4] : 0.0), (e < nev ? sv[e * 4] : 0.0))
+        for (int e = 0; e < NE; ++e) {
+          const double dqe = q[e] - (e < nev ? sq[e * 4] : 0.0);
+          e1 += v[e] * dqe;
+          e2 += (e < nev ? sv[e * 4] : 0.0) * dqe;
         }
-        put(Q_DOT0 + 2 * j, e1); put(Q_DOT0 + 2 * j + 1, e2);
       }
-      WN_FSTAMP(7);
+      put(Q_DOT0 + 2 * j, e1); put(Q_DOT0 + 2 * j + 1, e2);
     }
-#undef WN_FAST_DOTS
+    WN_FSTAMP(7);
     // ---- statePush (:431,518): only sub-tree left endpoints are ever read back ----
     const bool even = step && i >= 1 && (n & 1) == 0;
     if (even) {
@@ -385,14 +438,34 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
   FastDevIO io;
   io.prm = &prm; io.cl = cl; io.lg = lg;
   io.lp = io.ke = io.keinit = io.gen = 0.0; io.fire = 0u;
-  // tile slot 7 belongs to this wave and holds no coordinates: its partials are zero for the whole run
-  for (int k = lg; k < G::NQ; k += 4) part[(k * 16 + cn) * G::NW + 7] = 0.0;
-  // sum of the tile partials of one quantity: lane group lg adds slots 2lg and 2lg+1, then the four lane groups
-  // are added in the fixed tree of fast_rowsum4, so all four replicas of a chain hold the same bits
-  typedef double d2r_t __attribute__((ext_vector_type(2)));
-  auto sumq = [&](int k) {
-    const d2r_t x = *reinterpret_cast<const d2r_t*>(part + (k * 16 + cn) * G::NW + 2 * lg);
-    return fast_rowsum4(x[0] + x[1]);
+  // tile slots without coordinates (slot 7 = this wave, and the tiles beyond the dimension, whose waves only keep the
+  // barriers company) are never written by a T wave: their partials are zero for the whole run.  The T waves write
+  // their first partials behind barrier A of tick 0.
+  for (int k = lane; k < G::NQ * 16 * G::NW; k += 64) part[k] = 0.0;
+  // Sum of the eight tile partials of one quantity, in tile order.  The four lane groups of a chain work on
+  // DIFFERENT quantities (lg 0..3: lp, KE, initial KE, generated sum; U-turn level j in lane group j & 3) and swap
+  // the results afterwards: one quantity per replica instead of every quantity in every replica.
+  typedef double d4r_t __attribute__((ext_vector_type(4)));
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  auto sum8 = [&](int k) {
+    const d4r_t x = *reinterpret_cast<const d4r_t*>(part + (k * 16 + cn) * G::NW);
+    const d4r_t y = *reinterpret_cast<const d4r_t*>(part + (k * 16 + cn) * G::NW + 4);
+    double s = 0.0;
+    s += x[0]; s += x[1]; s += x[2]; s += x[3];
+    s += y[0]; s += y[1]; s += y[2]; s += y[3];
+    return s;
+  };
+  auto swap16d = [&](double x) {  // the value of lane l ^ 16
+    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    const u2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const u2_t b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return (lg & 1) ? __hiloint2double(b[0], a[0]) : __hiloint2double(b[1], a[1]);
+  };
+  auto swap32d = [&](double x) {  // the value of lane l ^ 32
+    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    const u2_t a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const u2_t b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return (lg & 2) ? __hiloint2double(b[0], a[0]) : __hiloint2double(b[1], a[1]);
   };
   // every chain needs at most numIter * (2^M - 1 + 2 idle ticks per doubling + start) ticks; twice that is an internal error
   const double cap = 256.0 + 2.0 * (double)prm.numIter * ((double)(1u << prm.M) + 4.0 * (double)prm.M + 16.0);
@@ -401,16 +474,29 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
   for (uint32_t t = 0;; ++t) {
     // ---- what tick t-1 left in the partials, before the T waves overwrite them (behind barrier A) ----
     if (t > 0) {
-      io.lp = sumq(Q_LP); io.ke = sumq(Q_KE);
-      if (__any(bk.s0.kind == FastBook::K_NEWITER)) { io.keinit = sumq(Q_KEINIT); io.gen = sumq(Q_GEN); }
-      // U-turn verdicts of the leaf being retired (wn_fast.h fire_of; the sums need all lanes, so every lane walks
-      // the levels any chain of the group needs)
+      {
+        const double c0 = sum8(lg);  // Q_LP, Q_KE, Q_KEINIT, Q_GEN = 0..3
+        const double c1 = swap16d(c0), c2 = swap32d(c0), c3 = swap32d(c1);  // from lane groups lg^1, lg^2, lg^3
+        io.lp = lg == 0 ? c0 : lg == 1 ? c1 : lg == 2 ? c2 : c3;
+        io.ke = lg == 1 ? c0 : lg == 0 ? c1 : lg == 3 ? c2 : c3;
+        io.keinit = lg == 2 ? c0 : lg == 3 ? c1 : lg == 0 ? c2 : c3;
+        io.gen = lg == 3 ? c0 : lg == 2 ? c1 : lg == 1 ? c2 : c3;
+      }
+      // U-turn verdicts of the leaf being retired (wn_fast.h fire_of): level j0 + lg in lane group lg, then OR
       const bool live_step = bk.s0.kind == FastBook::K_STEP && !bk.s0.discard;
       const int nchk = live_step ? nchecks(bk.i, bk.s0.n) : 0;
       uint32_t fire = 0u;
-      for (int j = 0; __any(nchk > j); ++j) {
-        const double d1 = sumq(Q_DOT0 + 2 * j), d2 = sumq(Q_DOT0 + 2 * j + 1);
+      for (int j0 = 0; __any(nchk > j0); j0 += 4) {
+        const int j = j0 + lg;
+        const int jr = j <= G::MP ? j : G::MP;  // rows beyond the deepest level are not read
+        const double d1 = sum8(Q_DOT0 + 2 * jr), d2 = sum8(Q_DOT0 + 2 * jr + 1);
         if (nchk > j && need_check(bk.i, bk.s0.n, j) && (((double)bk.xi * d1 < 0.0) || ((double)bk.xi * d2 < 0.0))) fire |= (1u << j);
+      }
+      {
+        const u2_t a = __builtin_amdgcn_permlane16_swap(fire, fire, false, false);
+        fire = a[0] | a[1];
+        const u2_t b = __builtin_amdgcn_permlane32_swap(fire, fire, false, false);
+        fire = b[0] | b[1];
       }
       io.fire = fire;
     }
@@ -462,14 +548,35 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
   WN_FSTAMP_OUT(prm)
 }
 
+// a T wave whose tile lies beyond the dimension: it only keeps the barriers company
+template <int KS, int TK, int NLC>
+__device__ __forceinline__ void fast_idle_wave(double* lds) {
+  using G = FastGeom<KS, TK, NLC>;
+  const Cmd* cmdbuf = reinterpret_cast<const Cmd*>(lds + G::OFF_CMD);
+  const int cn = threadIdx.x & 15;
+  for (uint32_t t = 0;; ++t) {
+    if (t > 0 && __any((cmdbuf[(t & 1u) * 16 + cn].op & OP_DONE) != 0)) break;
+    WN_LDS_BARRIER();  // A
+    WN_LDS_BARRIER();  // B
+  }
+}
+
 template <int KS, int TK, int NLC>
 __global__ __launch_bounds__(512) void wn_fast_kernel(Params prm, int* abort_flag) {
   __shared__ double lds[FastGeom<KS, TK, NLC>::LDS_DOUBLES];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform for the compiler too: no exec masking around MFMAs
   // tile of T wave w.  Waves w and w+4 share a SIMD (a workgroup's waves are dealt to the SIMDs cyclically: speed only),
   // so the B wave (7) sits beside wave 3, which gets the last tile -- for D = 100 the one with only 4 rows
-  if (wave < 7) fast_t_wave<KS, TK, NLC>(prm, lds, wave < 3 ? wave : (wave == 3 ? 6 : wave - 1));
-  else fast_b_wave<KS, TK, NLC>(prm, lds, abort_flag);
+  if (wave < 7) {
+    const int tile = wave < 3 ? wave : (wave == 3 ? 6 : wave - 1);
+    constexpr int NEV_LAST = (KS % 4) ? (KS % 4) : 4;  // registers of the tile that holds the last k-steps
+    const int nev = KS - 4 * tile;
+    if (nev >= 4) fast_t_wave<KS, TK, NLC, 4>(prm, lds, tile);
+    else if (nev > 0) fast_t_wave<KS, TK, NLC, NEV_LAST>(prm, lds, tile);
+    else fast_idle_wave<KS, TK, NLC>(lds);
+  } else {
+    fast_b_wave<KS, TK, NLC>(prm, lds, abort_flag);
+  }
 }
 
 // can the role-split kernel run this launch?  fixedLeapFrog sampling without trace / warm-up / orbit statistics
