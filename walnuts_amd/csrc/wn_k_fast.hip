@@ -72,7 +72,7 @@ struct FastGeom {
   static constexpr int OFF_Q = 0;                          // 2 x REG
   static constexpr int OFF_COLD = OFF_Q + 2 * REG;         // qb, vb
   static constexpr int OFF_LC = OFF_COLD + 2 * REG;        // NLC x (q, v)
-  static constexpr int OFF_PART = OFF_LC + NLC * 2 * REG;  // NQ x [chain][tile slot]
+  static constexpr int OFF_PART = OFF_LC + NLC * 2 * REG;  // NQ x [tile pair][chain][2]: 16-byte stride between a wave's chains, two tiles per 16-byte read of the bookkeeper
   static constexpr int OFF_CMD = OFF_PART + NQ * 16 * NW;  // 2 x 16 commands of 2 doubles
   static constexpr int OFF_DUMP = OFF_CMD + 2 * 16 * 2;    // 64 doubles nobody reads (see put() of the T waves)
   static constexpr int LDS_DOUBLES = OFF_DUMP + 64;
@@ -160,7 +160,7 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, cons
   // (every lane stores: lanes of lane groups 1..3 into a dump row.  A store under `if (lg == 0)` is control flow, and
   // control flow between the MFMAs would cut the block in which the check work is to issue in their gaps)
   double* const dump = lds + G::OFF_DUMP + lane;
-  double* const prow = part + cn * G::NW + tile;
+  double* const prow = part + ((tile >> 1) * 16 + cn) * 2 + (tile & 1);  // + k * 16 * NW
   auto put = [&](int k, double x) {
     x = fast_rowsum4(x);
     double* dst = lg == 0 ? prow + k * 16 * G::NW : dump;
@@ -445,15 +445,12 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
   // Sum of the eight tile partials of one quantity, in tile order.  The four lane groups of a chain work on
   // DIFFERENT quantities (lg 0..3: lp, KE, initial KE, generated sum; U-turn level j in lane group j & 3) and swap
   // the results afterwards: one quantity per replica instead of every quantity in every replica.
-  typedef double d4r_t __attribute__((ext_vector_type(4)));
   typedef unsigned u2_t __attribute__((ext_vector_type(2)));
   auto sum8 = [&](int k) {
-    const d4r_t x = *reinterpret_cast<const d4r_t*>(part + (k * 16 + cn) * G::NW);
-    const d4r_t y = *reinterpret_cast<const d4r_t*>(part + (k * 16 + cn) * G::NW + 4);
-    double s = 0.0;
-    s += x[0]; s += x[1]; s += x[2]; s += x[3];
-    s += y[0]; s += y[1]; s += y[2]; s += y[3];
-    return s;
+    typedef double d2r_t __attribute__((ext_vector_type(2)));
+    const d2r_t* r = reinterpret_cast<const d2r_t*>(part + k * 16 * G::NW + cn * 2);  // + tile pair * 16
+    const d2r_t a = r[0], b = r[16], c = r[32], d = r[48];
+    return ((a[0] + a[1]) + (b[0] + b[1])) + ((c[0] + c[1]) + (d[0] + d[1]));
   };
   auto swap16d = [&](double x) {  // the value of lane l ^ 16
     const unsigned lo = __double2loint(x), hi = __double2hiint(x);
