@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 3
+#define WN_ABI_VERSION 4
 #define WN_NDIAG 24      /* diagnostics columns, WALNUTSpy/WALNUTS.py:670-693 */
 #define WN_TRACE_NSCAL 12 /* trace row = 12 scalars + q[D] + v[D] */
 
@@ -48,7 +48,7 @@ enum {
   WN_T_FUNNEL1 = 6,    /* targetDistr.py:88-93 (D = 2) */
   WN_T_MODFUNNEL = 7,  /* targetDistr.py:41-51 (D = 2) */
   /* (lpdf, grad) pairs of test/targets.py, used with walnuts() (walnuts/walnuts.py:362);
-   * wn_ext_orbit / wn_lpfun only */
+   * wn_wstep_* / wn_lpfun only */
   WN_T_TT_CORRNORMAL = 8, /* test/targets.py:9-15 (D = 2; note its grad[0] = -q0 + rho*q1) */
   WN_T_TT_FUNNEL = 9,     /* test/targets.py:23-29 (any D >= 2; no log-scale term) */
   /* lpFun evaluated by the CALLER (targetDistr.py:18 `lpFun(q) -> [lp, grad]` as a batched callable
@@ -177,21 +177,51 @@ int wn_lpfun(wn_engine *e, const double *q_dev, double *lp_dev, double *grad_dev
 int wn_lpfun_kind(int32_t device, int32_t target_kind, const double *tpar_dev, int32_t dim, int32_t B,
                   const double *q_dev, double *lp_dev, double *grad_dev, void *stream);
 
-/* extend_orbit(...) of the pseudocode-faithful variant (walnuts/walnuts.py:211-276) for B
- * independent chains: from (theta, rho) take n_macro macro steps; per macro step find the stable
- * micro-step count (stable_steps, :144-182), pick ell = {ell//2, ell, 2*ell}[lottery] (the host
- * draws `lottery` with the caller's Generator, :194), integrate (leapfrog, :74-95), find the
- * reverse stable count and accumulate the log weight (:264-271).
- *   theta_dev, rho_dev [B][D]; inv_mass_dev [D]; lottery_dev [B][n_macro] in {0,1,2};
- *   weight0_dev [B] log weight of the starting state;
- *   orbit_dev [B][n_macro][2][D] new states (theta, rho) in integration order;
- *   logw_dev [B][n_macro]; ell_dev [B][n_macro][3] = ell_stable, ell, ell_stable_next (may be NULL).
- * Stand-alone (no engine): tpar_dev as in wn_set_target, may be NULL for parameter-free targets. */
-int wn_ext_orbit(int32_t device, int32_t target_kind, const double *tpar_dev, int32_t dim, int32_t B,
-                 const double *theta_dev, const double *rho_dev, const double *inv_mass_dev,
-                 double macro_step, double max_error, int32_t n_macro, const int32_t *lottery_dev,
-                 const double *weight0_dev, double *orbit_dev, double *logw_dev, int32_t *ell_dev,
-                 void *stream);
+/* ---- walnuts_step(...) of the pseudocode-faithful variant (walnuts/walnuts.py:279-359), batched -------------
+ * B independent chains of dimension D advance by one transition.  The caller's numpy Generators are consumed on
+ * the host in the reference's order, which depends on the data (no uniform after a sub-U-turn :343, the categorical
+ * draw only after an accept :347-350): one NUTS doubling is one exchange.
+ *
+ *   wn_wstep_create(device, kind, tpar, n_tpar, D, B, max_nuts_depth, inv_mass, macro_step, max_error, &h);
+ *   per transition:
+ *     rho[b] = inv_mass**-0.5 * rng_b.normal(size=D)                       (:322-325)
+ *     wn_wstep_begin(h, theta, rho)                                        orbit = [(theta, rho)], weights = [-H]  (:326)
+ *     for depth in range(max_nuts_depth), while a chain is active:         (:328)
+ *       backward[b] = rng_b.binomial(1, .5); lottery[b][m] = rng_b.choice(3) for the 2**depth macro steps (:330,:194)
+ *       wn_wstep_extend(h, depth, backward, lottery, active, sub_uturn, lse_ext, lse_old)
+ *           device: extend_orbit (:211-276), sub_uturn of the extension (:343), both logsumexp of :345
+ *       active[b] &= !sub_uturn[b];  accept[b] = log(rng_b.uniform(0,1)) < lse_ext[b] - lse_old[b]   (:346-347)
+ *       u_choice[b] = rng_b.random() if accept[b]                          (Generator.choice(orbit_ext, p=softmax) :350)
+ *       wn_wstep_commit(h, accept, u_choice, uturn)
+ *           device: categorical pick by inversion, orbit merge (:351), uturn(orbit[0], orbit[-1]) (:352)
+ *       active[b] &= !uturn[b]
+ *     wn_wstep_result(h, theta_next)                                       theta_selected (:359)
+ *
+ * kind = a WN_T_* built-in (dim <= 64, or any dim for WN_T_STDGAUSS / WN_T_DIAGGAUSS), or WN_T_EXTERNAL: the target
+ * is the caller's (logp, grad) pair (:379-380).  Then every call above leaves chains waiting for an evaluation:
+ *     wn_wstep_ext_bind(h, x_req, lp, grad)                                caller-owned [B][D], [B], [B][D]
+ *     after begin / extend:  do { wn_wstep_ext_pending(h, &n); if (!n) break;
+ *                                 lp[b], grad[b] = logp(x_req[b]), grad(x_req[b]) for the chains of this round;
+ *                                 wn_wstep_ext_feed(h, sub_uturn, lse_ext, lse_old); } while (1);
+ * (every active chain that has not finished its extension waits in every round).
+ * All arrays are device memory; int arrays are int32.  Not thread-safe per handle. */
+typedef struct wn_wstep wn_wstep;
+int wn_wstep_create(int32_t device, int32_t target_kind, const double *tpar_dev, size_t n_tpar, int32_t dim,
+                    int32_t B, int32_t max_depth, const double *inv_mass_dev, double macro_step,
+                    double max_error, wn_wstep **out);
+int wn_wstep_begin(wn_wstep *h, const double *theta_dev, const double *rho_dev, void *stream);
+int wn_wstep_extend(wn_wstep *h, int32_t depth, const int32_t *backward_dev, const int32_t *lottery_dev,
+                    const int32_t *active_dev, int32_t *sub_uturn_dev, double *lse_ext_dev,
+                    double *lse_old_dev, void *stream);
+int wn_wstep_commit(wn_wstep *h, const int32_t *accept_dev, const double *u_choice_dev, int32_t *uturn_dev,
+                    void *stream);
+int wn_wstep_result(wn_wstep *h, double *theta_sel_dev, void *stream);
+int wn_wstep_ext_bind(wn_wstep *h, double *x_req_dev, const double *lp_dev, const double *grad_dev);
+int wn_wstep_ext_pending(wn_wstep *h, int32_t *n_pending, void *stream);
+int wn_wstep_ext_feed(wn_wstep *h, int32_t *sub_uturn_dev, double *lse_ext_dev, double *lse_old_dev,
+                      void *stream);
+const char *wn_wstep_last_error(wn_wstep *h); /* h may be NULL: last creation error */
+int wn_wstep_destroy(wn_wstep *h);
 
 /* Export the engine's random stream (wn_rng.h) so the oracle / the Python reference can be
  * driven by the same randomness: u_dev [C][n_u] uniforms, z_dev [C][D] normals of iteration

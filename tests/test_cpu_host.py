@@ -125,6 +125,14 @@ def test_walnuts_argument_errors_match_reference():
         with pytest.raises(ValueError):
             wa.walnuts_step(rng, theta, *sn, im, ms, depth, err)
     with pytest.raises(TypeError):
-        wa.walnuts_step(rng, np.zeros(2), lambda q: 0.0, lambda q: -q, np.ones(2), 1.0, 5, 0.1)
+        wa.walnuts_step(rng, np.zeros(2), 3.0, lambda q: -q, np.ones(2), 1.0, 5, 0.1)  # not callable
     with pytest.raises(ValueError):
         wa.walnuts_step(rng, np.zeros(2), tt.standard_normal_lpdf, tt.funnel_grad, np.ones(2), 1.0, 5, 0.1)
+    with pytest.raises(ValueError):
+        wa.walnuts_batch([rng], np.zeros((2, 3)), *sn, np.ones(3), 1.0, 5, 0.1, 0, 1)  # one Generator per chain
+    import torch
+    if not torch.cuda.is_available():  # plain (logp, grad) callables are accepted as in the reference: no GPU -> loud failure
+        with pytest.raises(wa.WalnutsError):
+            wa.walnuts_step(rng, np.zeros(2), lambda q: 0.0, lambda q: -q, np.ones(2), 1.0, 5, 0.1)
+        with pytest.raises(ImportError):
+            wa.walnuts_stan(rng, np.zeros(2), "model.stan", "data.json", np.ones(2), 1.0, 5, 0.1, 0, 1)  # no bridgestan here

@@ -448,3 +448,42 @@ def test_bench_two_ranks_sharing_one_gpu():
                                 capture_output=True, text=True, timeout=600, env=env, cwd=root))
         assert o["n_gpus"] == 2 and o["value"] > 0 and o["roofline"]["frac"] > 0, o
         assert len(o["per_rank_kernel_ms"]) == 2
+
+
+def test_walnuts_batch_config1_four_chains_in_one_call(wa):
+    """BASELINE configs[0] in ONE call: the four chains (seeds 123..126) advance together on the device; each reproduces
+    the reference's draws and leaves its Generator at the reference's stream position."""
+    from walnuts_amd import targets as tt
+    rngs = [np.random.default_rng(s) for s in (123, 124, 125, 126)]
+    d = wa.walnuts_batch(rngs, np.zeros((4, 10)), tt.standard_normal_lpdf, tt.standard_normal_grad, np.ones(10), 2.0, 10, 0.1, 0, 1000)
+    assert d.shape == (4, 1000, 10)
+    for k, s in enumerate((123, 124, 125, 126)):
+        close(d[k], WD[f"std10_seed{s}"], rtol=1e-9, atol=1e-11, what=f"seed {s}")
+        assert rngs[k].uniform() == WD[f"std10_seed{s}_next_uniform"][0]
+
+
+def test_walnuts_plain_python_callables_as_in_test_py(wa):
+    """The reference's (logp, grad) contract (walnuts.py:379-380, test/test.py:11-18): plain Python functions on numpy
+    vectors.  Same Generator consumption and draws as the device descriptor of the same target, and as the reference."""
+    def lpdf(x):
+        return -0.5 * np.dot(x, x)
+
+    def grad(x):
+        return -x
+
+    rng = np.random.default_rng(123)
+    d = wa.walnuts(rng, np.zeros(10), lpdf, grad, np.ones(10), 2.0, 10, 0.1, 0, 25)
+    close(d, WD["std10_seed123"][:25], rtol=1e-9, atol=1e-11, what="plain callables")
+    # a target with no device form at all, any dimension
+    A = np.diag(np.linspace(1.0, 4.0, 70))
+    rng1, rng2 = np.random.default_rng(5), np.random.default_rng(5)
+    d1 = wa.walnuts(rng1, np.ones(70), lambda x: -0.5 * x @ A @ x, lambda x: -A @ x, np.ones(70), 0.9, 6, 0.3, 2, 6)
+    from walnuts_amd import targetDistr as td
+    d2 = wa.walnuts(rng2, np.ones(70), *(2 * [td.diagGauss(np.diag(A))]), np.ones(70), 0.9, 6, 0.3, 2, 6)
+    close(d1, d2, rtol=1e-9, atol=1e-11, what="callable vs device target, D = 70")
+    assert rng1.uniform() == rng2.uniform()
+
+
+def test_walnuts_stan_shape(wa):
+    with pytest.raises(ImportError, match="bridgestan"):
+        wa.walnuts_stan(np.random.default_rng(0), np.zeros(3), "m.stan", "d.json", np.ones(3), 1.0, 5, 0.1, 0, 10)

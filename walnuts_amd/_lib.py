@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _VARIANT = os.environ.get("WN_LIB", "")
 LIB_PATH = os.path.join(_HERE, f"libwalnuts_amd_{_VARIANT}.so" if _VARIANT else "libwalnuts_amd.so")
 
-WN_ABI_VERSION = 3
+WN_ABI_VERSION = 4
 NDIAG = 24
 TRACE_NSCAL = 12
 
@@ -38,7 +38,8 @@ class WnConfig(C.Structure):
 
 # every symbol include/walnuts_amd.h declares
 SYMBOLS = ["wn_abi_version", "wn_create", "wn_set_target", "wn_run", "wn_run_orbit_stats", "wn_split_ld", "wn_split_begin", "wn_split_tick", "wn_split_done", "wn_integrator_step",
-           "wn_lpfun", "wn_lpfun_kind", "wn_ext_orbit", "wn_rng_tape", "wn_last_run_ms", "wn_kernel_name", "wn_last_error",
+           "wn_lpfun", "wn_lpfun_kind", "wn_wstep_create", "wn_wstep_begin", "wn_wstep_extend", "wn_wstep_commit", "wn_wstep_result",
+           "wn_wstep_ext_bind", "wn_wstep_ext_pending", "wn_wstep_ext_feed", "wn_wstep_last_error", "wn_wstep_destroy", "wn_rng_tape", "wn_last_run_ms", "wn_kernel_name", "wn_last_error",
            "wn_destroy"]
 
 _lib = None
@@ -79,9 +80,21 @@ def lib():
     L.wn_lpfun.argtypes = [vp, vp, vp, vp, vp]
     L.wn_lpfun_kind.restype = C.c_int
     L.wn_lpfun_kind.argtypes = [C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
-    L.wn_ext_orbit.restype = C.c_int
-    L.wn_ext_orbit.argtypes = [C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, vp, C.c_double,
-                               C.c_double, C.c_int32, vp, vp, vp, vp, vp, vp]
+    L.wn_wstep_create.restype = C.c_int
+    L.wn_wstep_create.argtypes = [C.c_int32, C.c_int32, vp, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, vp, C.c_double,
+                                  C.c_double, C.POINTER(vp)]
+    for name, nargs in (("wn_wstep_begin", 4), ("wn_wstep_commit", 5), ("wn_wstep_result", 3), ("wn_wstep_ext_bind", 4),
+                        ("wn_wstep_ext_feed", 5)):
+        getattr(L, name).restype = C.c_int
+        getattr(L, name).argtypes = [vp] * nargs
+    L.wn_wstep_extend.restype = C.c_int
+    L.wn_wstep_extend.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
+    L.wn_wstep_ext_pending.restype = C.c_int
+    L.wn_wstep_ext_pending.argtypes = [vp, C.POINTER(C.c_int32), vp]
+    L.wn_wstep_last_error.restype = C.c_char_p
+    L.wn_wstep_last_error.argtypes = [vp]
+    L.wn_wstep_destroy.restype = C.c_int
+    L.wn_wstep_destroy.argtypes = [vp]
     L.wn_rng_tape.restype = C.c_int
     L.wn_rng_tape.argtypes = [vp, C.c_uint64, C.c_int32, C.c_int32, vp, vp, vp]
     L.wn_last_run_ms.restype = C.c_int

@@ -12,6 +12,7 @@
 #include "wn_launch.h"
 #include "wn_policy_coop.h"  // CK_*
 #include "wn_policy_wave.h"  // EXT_*
+#include "wn_target_eval.h"
 
 using namespace wn;
 
@@ -152,79 +153,6 @@ size_t kernel_work_doubles(const KernelChoice& kc, int C, int M) {
   return std::max(coop_work_doubles(NT, kc.W, C, M), fast);
 }
 
-// lpFun(q) -> lp, grad for any target kind, scalar loops (test / plumbing entry points; the
-// samplers evaluate their targets inside the fused kernels)
-enum { T_TT_CORRNORMAL = 8, T_TT_FUNNEL = 9 };
-__device__ double wn_target_eval(int kind, int D, const double* tpar, const double* x, double* g) {
-  const double logC = 0.91893853320467274178, log3 = 1.09861228866810969140;
-  double r = 0.0;
-  switch (kind) {
-    case T_STDGAUSS:
-      for (int i = 0; i < D; ++i) { g[i] = -x[i]; r += x[i] * x[i]; }
-      r = -0.5 * r;
-      break;
-    case T_DIAGGAUSS:
-      for (int i = 0; i < D; ++i) { g[i] = -(tpar[i] * x[i]); r += x[i] * g[i]; }
-      r = 0.5 * r;
-      break;
-    case T_DENSEGAUSS:
-      for (int i = 0; i < D; ++i) {
-        double a = 0.0;
-        for (int j = 0; j < D; ++j) a += tpar[(size_t)i * D + j] * x[j];
-        g[i] = -a;
-        r += x[i] * g[i];
-      }
-      r = 0.5 * r;
-      break;
-    case T_FUNNEL10: {
-      double emq = exp(-x[0]), ss = 0.0;
-      for (int i = 1; i < 11; ++i) ss += x[i] * x[i];
-      g[0] = -5.0 - x[0] / 9.0 + 0.5 * emq * ss;
-      for (int i = 1; i < 11; ++i) g[i] = -x[i] * emq;
-      r = (-(x[0] * x[0]) / 18.0 - logC - log3) + (-0.5 * emq * ss - 10.0 * logC - 5.0 * x[0]);
-      r = (0.5 * x[0] > 709.782712893384) ? -INFINITY : r;
-    } break;
-    case T_CORRGAUSS: {
-      const double rho = 0.5, tmp = 1.0 - rho * rho;
-      double rr = x[1] - rho * x[0];
-      g[0] = -(x[0] - rho * x[1]) / tmp; g[1] = -(x[1] - rho * x[0]) / tmp;
-      r = -0.5 * (x[0] * x[0]) - (0.5 / tmp) * (rr * rr);
-    } break;
-    case T_SMILE: {
-      double q0s = x[0] * x[0], rr = x[1] - q0s;
-      g[0] = -x[0] + 2.0 * x[0] * x[1] - 2.0 * (q0s * x[0]); g[1] = q0s - x[1];
-      r = -0.5 * q0s - 0.5 * (rr * rr);
-    } break;
-    case T_FUNNEL1: {
-      double emq = exp(-x[0]);
-      g[0] = -0.5 - x[0] / 9.0 + 0.5 * (x[1] * x[1]) * emq; g[1] = -x[1] * emq;
-      r = (-(x[0] * x[0]) / 18.0 - logC - log3) + (-0.5 * (x[1] * x[1]) * emq - logC - 0.5 * x[0]);
-      r = (0.5 * x[0] > 709.782712893384) ? -INFINITY : r;
-    } break;
-    case T_MODFUNNEL: {
-      double t1 = exp(-3.0 * x[0]), t2 = 1.0 + t1, t3 = 1.0 / t2, t4 = x[1] * x[1];
-      g[0] = 1.5 * t1 * (t4 - t3) - x[0]; g[1] = -x[1] * t2;
-      r = -0.5 * (t2 * t4 + log(t3) + x[0] * x[0]);
-    } break;
-    case T_TT_CORRNORMAL: {  // test/targets.py:9-15
-      const double rho = 0.5;
-      double rr = x[1] - rho * x[0];
-      g[0] = -x[0] + rho * x[1];
-      g[1] = (-x[1] + rho * x[0]) / (1.0 - rho * rho);
-      r = -0.5 * (x[0] * x[0]) - 0.5 / (1.0 - rho * rho) * (rr * rr);
-    } break;
-    case T_TT_FUNNEL: {  // test/targets.py:23-29
-      double ss = 0.0;
-      for (int i = 1; i < D; ++i) ss += x[i] * x[i];
-      const double e = exp(0.5 * x[0]);
-      g[0] = -(x[0] / 9.0 - 0.25 * ss / e);
-      for (int i = 1; i < D; ++i) g[i] = -1.0 / e * x[i];
-      r = -0.5 * (x[0] * x[0]) / 9.0 - 0.5 * ss / e;
-    } break;
-  }
-  return r;
-}
-
 // sw_innov.stan:7-51, scalar form (wn_lpfun only; the sampler evaluates WTgtStockWatson in the wave kernel)
 __device__ double wn_stockwatson_eval(const double* tpar, const double* x, double* g) {
   double r = 0.0;
@@ -278,88 +206,6 @@ __global__ void wn_lpfun_kernel(int kind, int D, int B, const double* tpar, cons
   if (c >= B) return;
   lp[c] = kind == T_STOCKWATSON ? wn_stockwatson_eval(tpar, q + (size_t)c * D, grad + (size_t)c * D)
                                 : wn_target_eval(kind, D, tpar, q + (size_t)c * D, grad + (size_t)c * D);
-}
-
-// ---- walnuts/walnuts.py variant: extend_orbit for B chains, one thread per chain -----------------
-#define WN_EXT_DMAX 64
-struct ExtCtx {
-  int kind, D;
-  const double* tpar;
-  const double* im;  // inv_mass
-  double macro_step, max_error;
-};
-// H(theta, rho) = -logp(theta) + 0.5*dot(inv_mass, rho**2)   (walnuts.py:97-141)
-__device__ double ext_H(const ExtCtx& c, const double* th, const double* rh, double* gtmp) {
-  double lp = wn_target_eval(c.kind, c.D, c.tpar, th, gtmp);
-  double ke = 0.0;
-  for (int i = 0; i < c.D; ++i) ke += c.im[i] * (rh[i] * rh[i]);
-  return -lp + 0.5 * ke;
-}
-// stable_steps (walnuts.py:144-182): smallest ell = 2**n, n <= 10, with H_max - H_min <= max_error
-__device__ int ext_stable_steps(const ExtCtx& c, const double* th0, const double* rh0, double sgn,
-                                double* th, double* rh, double* g) {
-  int ell = 1;
-  for (int n = 0; n < 11; ++n) {
-    ell = 1 << n;
-    const double step = c.macro_step / (double)ell, half = 0.5 * step;
-    for (int i = 0; i < c.D; ++i) { th[i] = th0[i]; rh[i] = sgn * rh0[i]; }
-    double Hc = ext_H(c, th, rh, g), Hmin = Hc, Hmax = Hc;  // ext_H leaves grad(theta) in g
-    for (int i = 0; i < c.D; ++i) rh[i] = rh[i] + half * g[i];
-    for (int k = 0; k < ell - 1; ++k) {
-      for (int i = 0; i < c.D; ++i) th[i] = th[i] + (step * c.im[i]) * rh[i];
-      wn_target_eval(c.kind, c.D, c.tpar, th, g);
-      for (int i = 0; i < c.D; ++i) rh[i] = rh[i] + half * g[i];
-      Hc = ext_H(c, th, rh, g);
-      Hmin = (Hc < Hmin) ? Hc : Hmin; Hmax = (Hc > Hmax) ? Hc : Hmax;  // Python min()/max() order
-      for (int i = 0; i < c.D; ++i) rh[i] = rh[i] + half * g[i];
-    }
-    for (int i = 0; i < c.D; ++i) th[i] = th[i] + (step * c.im[i]) * rh[i];
-    wn_target_eval(c.kind, c.D, c.tpar, th, g);
-    for (int i = 0; i < c.D; ++i) rh[i] = rh[i] + half * g[i];
-    Hc = ext_H(c, th, rh, g);
-    Hmin = (Hc < Hmin) ? Hc : Hmin; Hmax = (Hc > Hmax) ? Hc : Hmax;
-    if (Hmax - Hmin <= c.max_error) return ell;
-  }
-  return ell;
-}
-__device__ double ext_micro_logp(int ell, int es) {  // walnuts.py:197-208
-  return (ell == es || ell == es / 2 || ell == es * 2) ? -1.0986122886681098 : -INFINITY;
-}
-__global__ void wn_ext_orbit_kernel(ExtCtx c, int B, const double* theta0, const double* rho0, int n_macro,
-                                    const int* lottery, const double* weight0, double* orbit, double* logw,
-                                    int* ell_out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  double th[WN_EXT_DMAX], rh[WN_EXT_DMAX], g[WN_EXT_DMAX], t2[WN_EXT_DMAX], r2[WN_EXT_DMAX];
-  const int D = c.D;
-  for (int i = 0; i < D; ++i) { th[i] = theta0[(size_t)b * D + i]; rh[i] = rho0[(size_t)b * D + i]; }
-  double weight = weight0[b];
-  for (int m = 0; m < n_macro; ++m) {
-    const double p0 = -ext_H(c, th, rh, g);                             // :252
-    const int es = ext_stable_steps(c, th, rh, 1.0, t2, r2, g);         // :253
-    const int idx = lottery[(size_t)b * n_macro + m];
-    const int ell = idx == 0 ? es / 2 : idx == 1 ? es : es * 2;         // :194
-    {  // leapfrog(grad, theta, rho, macro_step/ell, inv_mass, ell)  :74-95 (ell == 0 -> inf, Q9)
-      const double step = c.macro_step / (double)ell, half = 0.5 * step;
-      wn_target_eval(c.kind, D, c.tpar, th, g);
-      for (int i = 0; i < D; ++i) rh[i] = rh[i] + half * g[i];
-      for (int k = 0; k < ell - 1; ++k) {
-        for (int i = 0; i < D; ++i) th[i] = th[i] + (step * c.im[i]) * rh[i];
-        wn_target_eval(c.kind, D, c.tpar, th, g);
-        for (int i = 0; i < D; ++i) rh[i] = rh[i] + step * g[i];
-      }
-      for (int i = 0; i < D; ++i) th[i] = th[i] + (step * c.im[i]) * rh[i];
-      wn_target_eval(c.kind, D, c.tpar, th, g);
-      for (int i = 0; i < D; ++i) rh[i] = rh[i] + half * g[i];
-    }
-    const int en = ext_stable_steps(c, th, rh, -1.0, t2, r2, g);        // :261
-    const double p1 = -ext_H(c, th, rh, g);                             // :264
-    weight = p1 - p0 + ext_micro_logp(ell, en) - ext_micro_logp(ell, es) + weight;  // :265-271
-    double* o = orbit + ((size_t)b * n_macro + m) * 2 * D;
-    for (int i = 0; i < D; ++i) { o[i] = th[i]; o[D + i] = rh[i]; }
-    logw[(size_t)b * n_macro + m] = weight;
-    if (ell_out) { int* eo = ell_out + ((size_t)b * n_macro + m) * 3; eo[0] = es; eo[1] = ell; eo[2] = en; }
-  }
 }
 
 __global__ void wn_tape_kernel(uint64_t seed, uint32_t chain0, int C, int iter, int nu, int D,
@@ -897,26 +743,6 @@ int wn_lpfun_kind(int32_t device, int32_t target_kind, const double* tpar_dev, i
                      tpar_dev, q_dev, lp_dev, grad_dev);
   r = hipGetLastError();
   if (r != hipSuccess) { g_create_err = std::string("wn_lpfun_kind launch: ") + hipGetErrorString(r); return WN_E_HIP; }
-  return WN_OK;
-}
-
-int wn_ext_orbit(int32_t device, int32_t target_kind, const double* tpar_dev, int32_t dim, int32_t B,
-                 const double* theta_dev, const double* rho_dev, const double* inv_mass_dev, double macro_step,
-                 double max_error, int32_t n_macro, const int32_t* lottery_dev, const double* weight0_dev,
-                 double* orbit_dev, double* logw_dev, int32_t* ell_dev, void* stream) {
-  if (dim < 1 || dim > WN_EXT_DMAX || B < 1 || n_macro < 1 || !theta_dev || !rho_dev || !inv_mass_dev ||
-      !lottery_dev || !weight0_dev || !orbit_dev || !logw_dev) { g_create_err = "wn_ext_orbit: bad argument"; return WN_E_ARG; }
-  {
-    int rc = check_target_dim(target_kind, tpar_dev, dim);
-    if (rc) return rc;
-  }
-  hipError_t r = hipSetDevice(device);
-  if (r != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(r); return WN_E_HIP; }
-  ExtCtx c{target_kind, dim, tpar_dev, inv_mass_dev, macro_step, max_error};
-  hipLaunchKernelGGL(wn_ext_orbit_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, c, B, theta_dev,
-                     rho_dev, n_macro, lottery_dev, weight0_dev, orbit_dev, logw_dev, ell_dev);
-  r = hipGetLastError();
-  if (r != hipSuccess) { g_create_err = std::string("wn_ext_orbit launch: ") + hipGetErrorString(r); return WN_E_HIP; }
   return WN_OK;
 }
 

@@ -26,7 +26,7 @@
 //       certain to happen (WnewSum is non-decreasing inside a doubling, WALNUTS.py:424-426); otherwise the
 //       chain idles until it is known.
 //
-// FastBook is plain scalar code, host + device: tests/hostsim/fastsim.cpp runs it against the oracle on
+// FastBook is plain scalar code, host + device: a CPU test harness under tests/ runs it against the oracle on
 // the CPU with a scalar stand-in for the T waves (test tool only).
 #pragma once
 #include <math.h>

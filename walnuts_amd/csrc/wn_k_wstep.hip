@@ -1,0 +1,508 @@
+// wn_k_wstep.hip -- batched device form of the pseudocode-faithful variant walnuts/walnuts.py:
+// walnuts_step (:279-359) for B independent chains of any dimension.
+//
+// What runs where.  The caller's numpy Generators must be consumed in the reference's order, and that order depends
+// on the data (no uniform after a sub-U-turn :343, the categorical draw only after an accept :347-350), so one NUTS
+// doubling is one exchange with the host:
+//
+//   host:   normal(size=D) per chain (:325)                                     -> wn_wstep_begin
+//   per doubling:
+//     host:   binomial(1, .5) (:330) and one choice(3) per macro step (:194)    -> wn_wstep_extend
+//     device: extend_orbit (:211-276: stable_steps :144-182 both ways, leapfrog :74-95, weights :264-271),
+//             sub_uturn of the extension (:62-70), logsumexp of its weights and of the old ones (:345)
+//     host:   uniform (:346) for chains without a sub-U-turn, accept test      -> wn_wstep_commit
+//     device: softmax / cumulative sum / search of the categorical pick (:348-350: numpy Generator.choice's
+//             inversion with the host's uniform), orbit merge (:351), U-turn of the whole orbit (:352)
+//
+// One thread per chain; every D-vector lives in the handle's workspace, laid out [vector][element][chain] so that
+// the threads of a wave touch consecutive addresses.  extend_orbit is written as a MACHINE that stops whenever it
+// needs (logp, grad) at a new position: with a built-in target the kernel evaluates it in place and carries on
+// (fused); with WN_T_EXTERNAL the kernel returns, the caller evaluates its Python (logp, grad) pair for the
+// requested positions of all chains, and the next launch carries on (wn_wstep_ext_*) -- the reference's
+// (logp, grad) callable contract (:379-380) at the reference's granularity.
+#include <math.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/walnuts_amd.h"
+#include "wn_launch.h"
+#include "wn_target_eval.h"
+
+using namespace wn;
+
+namespace {
+
+enum { V_TH0 = 0, V_RH0, V_G0, V_TH, V_RH, V_G, V_SEL, V_THL, V_RHL, V_GL, V_THR, V_RHR, V_GR, V_NVEC };
+enum { ST_IDLE = 0, ST_INIT, ST_SF, ST_LF, ST_SB, ST_DONE };
+
+struct WScal {  // per-chain scalars of the machine and of the orbit
+  double lp0, lp, Hmin, Hmax, step, half, weight, p0;
+  double lpL, lpR, wL, wR;
+  int stage, n, k, ell, lf_ell, es, m, nmacro, backward, active, nw, sub_uturn;
+};
+
+struct WCtx {
+  int kind, D, B, nmax;
+  const double* tpar;
+  const double* im;
+  double macro_step, max_error;
+  double* vec;   // [V_NVEC][D][B]
+  double* eorb;  // [nmax][2][D][B] states of the extension in integration order
+  double* ew;    // [nmax][B]       their log weights
+  double* logw;  // [2*nmax][B]     log weights of the orbit so far (any order)
+  WScal* sc;     // [B]
+  const int* lottery;  // [B][nmax]
+  double* xreq;  // external target: [B][D] positions to evaluate, chain-major
+  const double* xlp;  // external: [B] log densities, [B][D] gradients
+  const double* xg;
+  int* npend;    // external: number of chains still waiting for an evaluation
+};
+
+struct Vecs {
+  const WCtx& c;
+  int b;
+  __device__ double& operator()(int v, int j) const { return c.vec[((size_t)v * c.D + j) * c.B + b]; }
+};
+
+__device__ double ke_of(const WCtx& c, const Vecs& V, int vr) {  // 0.5*dot(inv_mass, rho**2)  (:124)
+  double s = 0.0;
+  for (int i = 0; i < c.D; ++i) s += c.im[i] * (V(vr, i) * V(vr, i));
+  return 0.5 * s;
+}
+__device__ double mlogp(int ell, int es) {  // micro_steps_logp :197-208
+  return (ell == es || ell == es / 2 || ell == es * 2) ? -1.0986122886681098 : -INFINITY;
+}
+
+// start one pass of stable_steps (:163-170) from (TH0, sgn*RH0) with (lp0, G0) known; TH = next evaluation point
+__device__ void stable_setup(const WCtx& c, const Vecs& V, WScal& s, double sgn) {
+  s.ell = 1 << s.n;
+  s.step = c.macro_step / (double)s.ell;
+  s.half = 0.5 * s.step;
+  for (int i = 0; i < c.D; ++i) { V(V_TH, i) = V(V_TH0, i); V(V_RH, i) = sgn * V(V_RH0, i); }
+  const double Hc = -s.lp0 + ke_of(c, V, V_RH);
+  s.Hmin = s.Hmax = Hc;
+  for (int i = 0; i < c.D; ++i) V(V_RH, i) = V(V_RH, i) + s.half * V(V_G0, i);
+  s.k = 0;
+  for (int i = 0; i < c.D; ++i) V(V_TH, i) = V(V_TH, i) + (s.step * c.im[i]) * V(V_RH, i);
+}
+__device__ void leap_setup(const WCtx& c, const Vecs& V, WScal& s) {  // leapfrog :88-91 (ell == 0 -> infinite step, Q9)
+  s.step = c.macro_step / (double)s.lf_ell;
+  s.half = 0.5 * s.step;
+  for (int i = 0; i < c.D; ++i) { V(V_TH, i) = V(V_TH0, i); V(V_RH, i) = V(V_RH0, i) + s.half * V(V_G0, i); }
+  s.k = 0;
+  for (int i = 0; i < c.D; ++i) V(V_TH, i) = V(V_TH, i) + (s.step * c.im[i]) * V(V_RH, i);
+}
+__device__ void macro_setup(const WCtx& c, const Vecs& V, WScal& s) {  // :252-253
+  s.p0 = s.lp0 - ke_of(c, V, V_RH0);
+  s.stage = ST_SF; s.n = 0;
+  stable_setup(c, V, s, 1.0);
+}
+
+// (lp, G) = (logp, grad) at TH have arrived: advance to the next evaluation point (true) or to the end (false)
+__device__ bool advance(const WCtx& c, const Vecs& V, WScal& s) {
+  const int D = c.D;
+  if (s.stage == ST_INIT) {  // logp / grad of the initial state (:326): orbit = [(theta, rho)], weights = [-H]
+    for (int i = 0; i < D; ++i) {
+      const double g = V(V_G, i), th = V(V_TH, i), rh = V(V_RH, i);
+      V(V_GL, i) = g; V(V_GR, i) = g;
+      V(V_THL, i) = th; V(V_THR, i) = th; V(V_RHL, i) = rh; V(V_RHR, i) = rh; V(V_SEL, i) = th;
+    }
+    s.lpL = s.lpR = s.lp;
+    const double w = s.lp - ke_of(c, V, V_RH);
+    s.wL = s.wR = w;
+    c.logw[V.b] = w; s.nw = 1;
+    s.stage = ST_DONE;
+    return false;
+  }
+  if (s.stage == ST_SF || s.stage == ST_SB) {
+    if (s.k < s.ell - 1) {  // :172-176
+      for (int i = 0; i < D; ++i) V(V_RH, i) = V(V_RH, i) + s.half * V(V_G, i);
+      const double Hc = -s.lp + ke_of(c, V, V_RH);
+      s.Hmin = (Hc < s.Hmin) ? Hc : s.Hmin; s.Hmax = (Hc > s.Hmax) ? Hc : s.Hmax;  // Python min() / max() order
+      for (int i = 0; i < D; ++i) V(V_RH, i) = V(V_RH, i) + s.half * V(V_G, i);
+      s.k++;
+      for (int i = 0; i < D; ++i) V(V_TH, i) = V(V_TH, i) + (s.step * c.im[i]) * V(V_RH, i);
+      return true;
+    }
+    for (int i = 0; i < D; ++i) V(V_RH, i) = V(V_RH, i) + s.half * V(V_G, i);  // :178-181
+    const double Hc = -s.lp + ke_of(c, V, V_RH);
+    s.Hmin = (Hc < s.Hmin) ? Hc : s.Hmin; s.Hmax = (Hc > s.Hmax) ? Hc : s.Hmax;
+    if (!(s.Hmax - s.Hmin <= c.max_error) && s.n < 10) {
+      s.n++;
+      stable_setup(c, V, s, s.stage == ST_SF ? 1.0 : -1.0);
+      return true;
+    }
+    if (s.stage == ST_SF) {  // :256-258
+      s.es = s.ell;
+      const int idx = c.lottery[(size_t)V.b * c.nmax + s.m];
+      s.lf_ell = idx == 0 ? s.es / 2 : idx == 1 ? s.es : s.es * 2;
+      s.stage = ST_LF;
+      leap_setup(c, V, s);
+      return true;
+    }
+    // ST_SB done: the macro step is complete (:264-273); (TH0, RH0, lp0, G0) hold its end state
+    const int en = s.ell;
+    const double p1 = s.lp0 - ke_of(c, V, V_RH0);
+    s.weight = p1 - s.p0 + mlogp(s.lf_ell, en) - mlogp(s.lf_ell, s.es) + s.weight;
+    double* eo = c.eorb + (size_t)s.m * 2 * D * c.B;
+    for (int i = 0; i < D; ++i) { eo[(size_t)i * c.B + V.b] = V(V_TH0, i); eo[((size_t)D + i) * c.B + V.b] = V(V_RH0, i); }
+    c.ew[(size_t)s.m * c.B + V.b] = s.weight;
+    s.m++;
+    if (s.m == s.nmacro) { s.stage = ST_DONE; return false; }
+    macro_setup(c, V, s);
+    return true;
+  }
+  // ST_LF
+  if (s.k < s.lf_ell - 1) {  // :92-93
+    for (int i = 0; i < D; ++i) V(V_RH, i) = V(V_RH, i) + s.step * V(V_G, i);
+    s.k++;
+    for (int i = 0; i < D; ++i) V(V_TH, i) = V(V_TH, i) + (s.step * c.im[i]) * V(V_RH, i);
+    return true;
+  }
+  // :94-95 end of the macro step's integration; then stable_steps from (theta, -rho) (:261)
+  for (int i = 0; i < D; ++i) {
+    V(V_RH0, i) = V(V_RH, i) + s.half * V(V_G, i);
+    V(V_TH0, i) = V(V_TH, i);
+    V(V_G0, i) = V(V_G, i);
+  }
+  s.lp0 = s.lp;
+  s.stage = ST_SB; s.n = 0;
+  stable_setup(c, V, s, -1.0);
+  return true;
+}
+
+// first evaluation point of an extension (:242-248): from the orbit's first state with the momentum negated, or
+// from its last state
+__device__ void extend_setup(const WCtx& c, const Vecs& V, WScal& s, int backward, int nmacro) {
+  s.backward = backward; s.nmacro = nmacro; s.m = 0; s.sub_uturn = 0;
+  for (int i = 0; i < c.D; ++i) {
+    V(V_TH0, i) = backward ? V(V_THL, i) : V(V_THR, i);
+    V(V_RH0, i) = backward ? -V(V_RHL, i) : V(V_RHR, i);
+    V(V_G0, i) = backward ? V(V_GL, i) : V(V_GR, i);
+  }
+  s.lp0 = backward ? s.lpL : s.lpR;
+  s.weight = backward ? s.wL : s.wR;
+  macro_setup(c, V, s);
+}
+
+// uturn(state x, state y) (:16-33) between states of the extension given in LIST order (time order: the
+// integration order reversed when going backward, :274-275)
+__device__ bool ext_uturn(const WCtx& c, int b, int backward, int n, int x, int y) {
+  const int ix = backward ? n - 1 - x : x, iy = backward ? n - 1 - y : y;
+  const double* sx = c.eorb + (size_t)ix * 2 * c.D * c.B;
+  const double* sy = c.eorb + (size_t)iy * 2 * c.D * c.B;
+  double d1 = 0.0, d2 = 0.0;
+  for (int i = 0; i < c.D; ++i) {
+    const double diff = c.im[i] * (sy[(size_t)i * c.B + b] - sx[(size_t)i * c.B + b]);
+    d1 += sx[((size_t)c.D + i) * c.B + b] * diff;
+    d2 += sy[((size_t)c.D + i) * c.B + b] * diff;
+  }
+  return d1 < 0 || d2 < 0;
+}
+// scipy.special.logsumexp of n values with stride B
+__device__ double lse_of(const double* a, int n, int B) {
+  double mx = -INFINITY;
+  bool nan = false;
+  for (int i = 0; i < n; ++i) { const double x = a[(size_t)i * B]; if (isnan(x)) nan = true; mx = x > mx ? x : mx; }
+  if (nan) mx = NAN;
+  if (!isfinite(mx)) mx = 0.0;
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += exp(a[(size_t)i * B] - mx);
+  return log(s) + mx;
+}
+// the extension is complete: sub_uturn (:62-70) and the two logsumexp of :345
+__device__ void extend_finish(const WCtx& c, int b, WScal& s, int* sub_out, double* lse_ext, double* lse_old) {
+  const int n = s.nmacro;
+  bool su = false;
+  for (int span = n; span >= 2 && !su; span >>= 1)
+    for (int i = 0; i < n / span && !su; ++i) su = ext_uturn(c, b, s.backward, n, span * i, span * (i + 1) - 1);
+  s.sub_uturn = su ? 1 : 0;
+  sub_out[b] = s.sub_uturn;
+  lse_ext[b] = lse_of(c.ew + b, n, c.B);
+  lse_old[b] = lse_of(c.logw + b, s.nw, c.B);
+}
+
+__global__ void wstep_fused_kernel(WCtx c, int mode /*0 begin, 1 extend*/, const double* theta, const double* rho,
+                                   const int* backward, const int* active, int nmacro, int* sub_out, double* lse_ext,
+                                   double* lse_old) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= c.B) return;
+  WScal& s = c.sc[b];
+  Vecs V{c, b};
+  if (mode == 0) {
+    for (int i = 0; i < c.D; ++i) { V(V_TH, i) = theta[(size_t)b * c.D + i]; V(V_RH, i) = rho[(size_t)b * c.D + i]; }
+    s.stage = ST_INIT; s.active = 1; s.nmacro = 0; s.m = 0;
+  } else {
+    s.active = active[b];
+    if (!s.active) return;
+    extend_setup(c, V, s, backward[b], nmacro);
+  }
+  // evaluate the built-in target at TH until the machine is done (positions are strided in the workspace: gather,
+  // evaluate with the scalar target code of wn_capi.hip, scatter -- D <= 64 in registers, beyond that per element)
+  for (;;) {
+    double x[64], g[64];
+    if (c.D <= 64) {
+      for (int i = 0; i < c.D; ++i) x[i] = V(V_TH, i);
+      s.lp = wn_target_eval(c.kind, c.D, c.tpar, x, g);
+      for (int i = 0; i < c.D; ++i) V(V_G, i) = g[i];
+    } else {  // separable built-ins only (checked on the host): element-wise through the same code, one element at a time
+      double lp = 0.0;
+      for (int i = 0; i < c.D; ++i) {
+        const double xi = V(V_TH, i);
+        double gi;
+        lp += wn_target_eval(c.kind, 1, c.tpar ? c.tpar + i : nullptr, &xi, &gi);
+        V(V_G, i) = gi;
+      }
+      s.lp = lp;
+    }
+    if (!advance(c, V, s)) break;
+  }
+  if (mode == 1) extend_finish(c, b, s, sub_out, lse_ext, lse_old);
+}
+
+// external target, one machine step per launch: consume (lp, grad) of the requested point, advance, request the next
+__global__ void wstep_ext_kernel(WCtx c, int mode /*0 begin, 1 extend setup, 2 feed*/, const double* theta, const double* rho,
+                                 const int* backward, const int* active, int nmacro, int* sub_out, double* lse_ext,
+                                 double* lse_old) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= c.B) return;
+  WScal& s = c.sc[b];
+  Vecs V{c, b};
+  bool need = false;
+  if (mode == 0) {
+    for (int i = 0; i < c.D; ++i) { V(V_TH, i) = theta[(size_t)b * c.D + i]; V(V_RH, i) = rho[(size_t)b * c.D + i]; }
+    s.stage = ST_INIT; s.active = 1; s.nmacro = 0; s.m = 0;
+    need = true;
+  } else if (mode == 1) {
+    s.active = active[b];
+    if (!s.active) return;
+    extend_setup(c, V, s, backward[b], nmacro);
+    need = true;
+  } else {
+    if (!s.active || s.stage == ST_DONE || s.stage == ST_IDLE) return;
+    s.lp = c.xlp[b];
+    for (int i = 0; i < c.D; ++i) V(V_G, i) = c.xg[(size_t)b * c.D + i];
+    need = advance(c, V, s);
+    if (!need && s.nmacro > 0 && s.m == s.nmacro) extend_finish(c, b, s, sub_out, lse_ext, lse_old);
+  }
+  if (need) {
+    for (int i = 0; i < c.D; ++i) c.xreq[(size_t)b * c.D + i] = V(V_TH, i);
+    atomicAdd(c.npend, 1);
+  }
+}
+
+// accept / categorical pick (:347-350), orbit merge (:351), U-turn of the whole orbit (:352)
+__global__ void wstep_commit_kernel(WCtx c, const int* accept, const double* u_choice, int* uturn_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= c.B) return;
+  WScal& s = c.sc[b];
+  if (!s.active || s.sub_uturn) { uturn_out[b] = 0; return; }  // a sub-U-turn breaks out before the merge (:343)
+  Vecs V{c, b};
+  const int n = s.nmacro, D = c.D;
+  if (accept[b]) {
+    // p = softmax(log_weights_ext) in LIST order; Generator.choice: cdf = p.cumsum(); cdf /= cdf[-1];
+    // idx = cdf.searchsorted(u, side='right')
+    double mx = -INFINITY;
+    for (int i = 0; i < n; ++i) { const double x = c.ew[(size_t)i * c.B + b]; mx = x > mx ? x : mx; }
+    double tot = 0.0;
+    for (int i = 0; i < n; ++i) tot += exp(c.ew[(size_t)i * c.B + b] - mx);
+    double cs = 0.0;
+    for (int p = 0; p < n; ++p) { const int i = s.backward ? n - 1 - p : p; cs += exp(c.ew[(size_t)i * c.B + b] - mx) / tot; }
+    const double last = cs;
+    cs = 0.0;
+    int idx = n - 1;
+    for (int p = 0; p < n; ++p) {
+      const int i = s.backward ? n - 1 - p : p;
+      cs += exp(c.ew[(size_t)i * c.B + b] - mx) / tot;
+      if (u_choice[b] < cs / last) { idx = p; break; }
+    }
+    const int ii = s.backward ? n - 1 - idx : idx;
+    const double* st = c.eorb + (size_t)ii * 2 * D * c.B;
+    for (int i = 0; i < D; ++i) V(V_SEL, i) = st[(size_t)i * c.B + b];
+  }
+  // orbit = orbit_ext + orbit / orbit + orbit_ext: the new end is the LAST computed state
+  const double* st = c.eorb + (size_t)(n - 1) * 2 * D * c.B;
+  for (int i = 0; i < D; ++i) {
+    const double th = st[(size_t)i * c.B + b], rh = st[((size_t)D + i) * c.B + b], g = V(V_G0, i);
+    if (s.backward) { V(V_THL, i) = th; V(V_RHL, i) = rh; V(V_GL, i) = g; }
+    else { V(V_THR, i) = th; V(V_RHR, i) = rh; V(V_GR, i) = g; }
+  }
+  if (s.backward) { s.lpL = s.lp0; s.wL = c.ew[(size_t)(n - 1) * c.B + b]; }
+  else { s.lpR = s.lp0; s.wR = c.ew[(size_t)(n - 1) * c.B + b]; }
+  for (int i = 0; i < n; ++i) c.logw[(size_t)(s.nw + i) * c.B + b] = c.ew[(size_t)i * c.B + b];
+  s.nw += n;
+  double d1 = 0.0, d2 = 0.0;  // uturn(orbit[0], orbit[-1], inv_mass)
+  for (int i = 0; i < D; ++i) {
+    const double diff = c.im[i] * (V(V_THR, i) - V(V_THL, i));
+    d1 += V(V_RHL, i) * diff;
+    d2 += V(V_RHR, i) * diff;
+  }
+  uturn_out[b] = (d1 < 0 || d2 < 0) ? 1 : 0;
+}
+
+__global__ void wstep_result_kernel(WCtx c, double* theta_sel) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= c.B) return;
+  Vecs V{c, b};
+  for (int i = 0; i < c.D; ++i) theta_sel[(size_t)b * c.D + i] = V(V_SEL, i);
+}
+
+}  // namespace
+
+struct wn_wstep {
+  WCtx c{};
+  int device = 0, max_depth = 0;
+  bool external = false;
+  double *tpar = nullptr, *im = nullptr;
+  int* lot = nullptr;
+  std::string err;
+};
+static std::string g_wstep_err;
+
+#define WCHK(call)                                                                \
+  do {                                                                            \
+    hipError_t _r = (call);                                                       \
+    if (_r != hipSuccess) {                                                       \
+      h->err = std::string(#call) + ": " + hipGetErrorString(_r);                 \
+      return _r == hipErrorOutOfMemory ? WN_E_ALLOC : WN_E_HIP;                   \
+    }                                                                             \
+  } while (0)
+
+extern "C" {
+
+const char* wn_wstep_last_error(wn_wstep* h) { return h ? h->err.c_str() : g_wstep_err.c_str(); }
+
+int wn_wstep_destroy(wn_wstep* h) {
+  if (!h) return WN_OK;
+  hipSetDevice(h->device);
+  for (void* p : {(void*)h->tpar, (void*)h->im, (void*)h->lot, (void*)h->c.vec, (void*)h->c.eorb, (void*)h->c.ew, (void*)h->c.logw,
+                  (void*)h->c.sc, (void*)h->c.npend})
+    if (p) hipFree(p);
+  delete h;
+  return WN_OK;
+}
+
+int wn_wstep_create(int32_t device, int32_t target_kind, const double* tpar_dev, size_t n_tpar, int32_t dim, int32_t B,
+                    int32_t max_depth, const double* inv_mass_dev, double macro_step, double max_error, wn_wstep** out) {
+  if (!out) { g_wstep_err = "null argument"; return WN_E_ARG; }
+  *out = nullptr;
+  if (dim < 1 || B < 1 || max_depth < 1 || max_depth > 20 || !inv_mass_dev || !(macro_step > 0) || !(max_error > 0)) {
+    g_wstep_err = "wn_wstep_create: bad argument"; return WN_E_ARG;
+  }
+  const bool ext = target_kind == WN_T_EXTERNAL;
+  if (!ext) {
+    if (target_kind < 0 || target_kind > WN_T_TT_FUNNEL) { g_wstep_err = "unknown target"; return WN_E_ARG; }
+    if ((target_kind == WN_T_DIAGGAUSS || target_kind == WN_T_DENSEGAUSS) && !tpar_dev) { g_wstep_err = "target needs parameters"; return WN_E_ARG; }
+    if ((target_kind == WN_T_FUNNEL10 && dim != 11) ||
+        ((target_kind == WN_T_CORRGAUSS || target_kind == WN_T_SMILE || target_kind == WN_T_FUNNEL1 || target_kind == WN_T_MODFUNNEL ||
+          target_kind == WN_T_TT_CORRNORMAL) && dim != 2) || (target_kind == WN_T_TT_FUNNEL && dim < 2)) {
+      g_wstep_err = "dimension does not fit the target"; return WN_E_ARG;
+    }
+    if (dim > 64 && target_kind != WN_T_STDGAUSS && target_kind != WN_T_DIAGGAUSS) {
+      g_wstep_err = "built-in targets beyond dim 64: stdGauss / diagGauss only (others: pass (logp, grad) callables)"; return WN_E_UNSUPPORTED;
+    }
+  }
+  wn_wstep* h = new wn_wstep();
+  h->device = device; h->max_depth = max_depth; h->external = ext;
+  if (hipSetDevice(device) != hipSuccess) { g_wstep_err = "hipSetDevice failed"; delete h; return WN_E_HIP; }
+  WCtx& c = h->c;
+  c.kind = target_kind; c.D = dim; c.B = B; c.nmax = 1 << (max_depth - 1);
+  c.macro_step = macro_step; c.max_error = max_error;
+  auto fail = [&](int rc) { g_wstep_err = h->err; wn_wstep_destroy(h); return rc; };
+#define WALLOC(ptr, bytes)                                                                 \
+  do {                                                                                     \
+    hipError_t _r = hipMalloc((void**)&(ptr), (bytes));                                    \
+    if (_r != hipSuccess) { (ptr) = nullptr; (void)hipGetLastError(); h->err = std::string("hipMalloc: ") + hipGetErrorString(_r); \
+                            return fail(_r == hipErrorOutOfMemory ? WN_E_ALLOC : WN_E_HIP); }   \
+  } while (0)
+  if (tpar_dev && n_tpar) {
+    WALLOC(h->tpar, n_tpar * sizeof(double));
+    hipMemcpy(h->tpar, tpar_dev, n_tpar * sizeof(double), hipMemcpyDeviceToDevice);
+  }
+  WALLOC(h->im, (size_t)dim * sizeof(double));
+  hipMemcpy(h->im, inv_mass_dev, (size_t)dim * sizeof(double), hipMemcpyDeviceToDevice);
+  WALLOC(h->lot, (size_t)B * c.nmax * sizeof(int));
+  WALLOC(c.vec, (size_t)V_NVEC * dim * B * sizeof(double));
+  WALLOC(c.eorb, (size_t)c.nmax * 2 * dim * B * sizeof(double));
+  WALLOC(c.ew, (size_t)c.nmax * B * sizeof(double));
+  WALLOC(c.logw, (size_t)2 * c.nmax * B * sizeof(double));
+  WALLOC(c.sc, (size_t)B * sizeof(WScal));
+  WALLOC(c.npend, 64);
+#undef WALLOC
+  hipMemset(c.sc, 0, (size_t)B * sizeof(WScal));
+  hipMemset(c.vec, 0, (size_t)V_NVEC * dim * B * sizeof(double));
+  c.tpar = h->tpar; c.im = h->im; c.lottery = h->lot;
+  *out = h;
+  return WN_OK;
+}
+
+static int wstep_launch(wn_wstep* h, int mode, const double* theta, const double* rho, const int* backward, const int* active,
+                        int nmacro, int* sub_out, double* lse_ext, double* lse_old, hipStream_t st) {
+  dim3 grid((h->c.B + 63) / 64), block(64);
+  if (h->external) {
+    WCHK(hipMemsetAsync(h->c.npend, 0, sizeof(int), st));
+    hipLaunchKernelGGL(wstep_ext_kernel, grid, block, 0, st, h->c, mode, theta, rho, backward, active, nmacro, sub_out, lse_ext, lse_old);
+  } else {
+    hipLaunchKernelGGL(wstep_fused_kernel, grid, block, 0, st, h->c, mode, theta, rho, backward, active, nmacro, sub_out, lse_ext, lse_old);
+  }
+  WCHK(hipGetLastError());
+  return WN_OK;
+}
+
+int wn_wstep_begin(wn_wstep* h, const double* theta_dev, const double* rho_dev, void* stream) {
+  if (!h || !theta_dev || !rho_dev) { if (h) h->err = "null buffer"; return WN_E_ARG; }
+  WCHK(hipSetDevice(h->device));
+  return wstep_launch(h, 0, theta_dev, rho_dev, nullptr, nullptr, 0, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int wn_wstep_extend(wn_wstep* h, int32_t depth, const int32_t* backward_dev, const int32_t* lottery_dev, const int32_t* active_dev,
+                    int32_t* sub_uturn_dev, double* lse_ext_dev, double* lse_old_dev, void* stream) {
+  if (!h || !backward_dev || !lottery_dev || !active_dev || !sub_uturn_dev || !lse_ext_dev || !lse_old_dev) { if (h) h->err = "null buffer"; return WN_E_ARG; }
+  if (depth < 0 || depth >= h->max_depth) { h->err = "depth out of range"; return WN_E_ARG; }
+  WCHK(hipSetDevice(h->device));
+  const int n = 1 << depth;
+  // lottery [B][n] -> the handle's [B][nmax]
+  WCHK(hipMemcpy2DAsync(h->lot, (size_t)h->c.nmax * sizeof(int), lottery_dev, (size_t)n * sizeof(int), (size_t)n * sizeof(int), (size_t)h->c.B,
+                        hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return wstep_launch(h, 1, nullptr, nullptr, backward_dev, active_dev, n, sub_uturn_dev, lse_ext_dev, lse_old_dev, (hipStream_t)stream);
+}
+
+int wn_wstep_ext_pending(wn_wstep* h, int32_t* n_pending, void* stream) {
+  if (!h || !h->external || !n_pending) { if (h) h->err = "wn_wstep_ext_pending needs a WN_T_EXTERNAL handle"; return WN_E_ARG; }
+  int np = 0;
+  WCHK(hipMemcpyAsync(&np, h->c.npend, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  WCHK(hipStreamSynchronize((hipStream_t)stream));
+  *n_pending = np;
+  return WN_OK;
+}
+
+int wn_wstep_ext_bind(wn_wstep* h, double* x_req_dev, const double* lp_dev, const double* grad_dev) {
+  if (!h || !h->external || !x_req_dev || !lp_dev || !grad_dev) { if (h) h->err = "wn_wstep_ext_bind: bad argument"; return WN_E_ARG; }
+  h->c.xreq = x_req_dev; h->c.xlp = lp_dev; h->c.xg = grad_dev;
+  return WN_OK;
+}
+
+int wn_wstep_ext_feed(wn_wstep* h, int32_t* sub_uturn_dev, double* lse_ext_dev, double* lse_old_dev, void* stream) {
+  if (!h || !h->external || !h->c.xreq) { if (h) h->err = "wn_wstep_ext_feed: bind the exchange buffers first"; return WN_E_ARG; }
+  WCHK(hipSetDevice(h->device));
+  return wstep_launch(h, 2, nullptr, nullptr, nullptr, nullptr, 0, sub_uturn_dev, lse_ext_dev, lse_old_dev, (hipStream_t)stream);
+}
+
+int wn_wstep_commit(wn_wstep* h, const int32_t* accept_dev, const double* u_choice_dev, int32_t* uturn_dev, void* stream) {
+  if (!h || !accept_dev || !u_choice_dev || !uturn_dev) { if (h) h->err = "null buffer"; return WN_E_ARG; }
+  WCHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(wstep_commit_kernel, dim3((h->c.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->c, accept_dev, u_choice_dev, uturn_dev);
+  WCHK(hipGetLastError());
+  return WN_OK;
+}
+
+int wn_wstep_result(wn_wstep* h, double* theta_sel_dev, void* stream) {
+  if (!h || !theta_sel_dev) { if (h) h->err = "null buffer"; return WN_E_ARG; }
+  WCHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(wstep_result_kernel, dim3((h->c.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->c, theta_sel_dev);
+  WCHK(hipGetLastError());
+  return WN_OK;
+}
+
+}  // extern "C"

@@ -1,14 +1,18 @@
-"""walnuts() / walnuts_step() with the reference's signature (walnuts/walnuts.py:279-408).
+"""walnuts() / walnuts_step() / walnuts_stan() with the reference's signatures (walnuts/walnuts.py:279-408,
+walnuts/walnuts_stan.py:4-15), plus the batched forms walnuts_batch() / walnuts_step_batch().
 
-The caller's numpy Generator is consumed on the host in exactly the reference's order --
-normal(size=D) :325, binomial(1,0.5) :330, one choice([ell//2, ell, 2*ell]) per macro step :194,
-uniform(0,1) :346, choice(orbit_ext, p=softmax) :350 -- so a seeded run reproduces the reference's
-draws.  Everything that touches the target (energy, the stable_steps search, the leapfrog
-integration: extend_orbit :211-276) runs on the GPU through wn_ext_orbit; the host keeps only the
-orbit bookkeeping (U-turn tests and the categorical selection on the returned orbit).
+Everything a transition computes -- stable_steps searches, leapfrog integration, weights, sub-U-turn and U-turn
+tests, logsumexp accept bound, categorical pick -- runs on the GPU for all chains at once (csrc/wn_k_wstep.hip
+behind the wn_wstep_* entry points).  The host only consumes each caller-owned numpy Generator, in exactly the
+reference's order: normal(size=D) :325, then per doubling binomial(1, .5) :330, one choice(3) per macro step
+:194, uniform(0, 1) :346 unless the extension had a sub-U-turn :343, and the one random() of
+Generator.choice(orbit_ext, p=...) :350 after an accept -- so a seeded run reproduces the reference's draws
+and leaves the Generator at the reference's stream position.
 
-`logp` / `grad` are device descriptors from walnuts_amd.targets (mirrors of test/targets.py) or
-walnuts_amd.targetDistr; both arguments must describe the same target.
+`logp` / `grad` are either device descriptors (walnuts_amd.targets mirrors test/targets.py;
+walnuts_amd.targetDistr) or plain Python callables logp(theta) -> float, grad(theta) -> (D,) as in the
+reference (:379-380): the device then stops wherever the algorithm needs them, the pair is called once per
+waiting chain on the host, and the device carries on (the reference's contract at the reference's granularity).
 """
 import ctypes as C
 import warnings
@@ -19,134 +23,19 @@ from . import _lib as L
 from .targetDistr import DeviceTarget
 
 
-def disable_runtime_warnings():  # walnuts.py:7-13
-    warnings.filterwarnings("ignore", category=RuntimeWarning)
+def _quiet():
+    warnings.filterwarnings("ignore", category=RuntimeWarning)  # as the reference does at the top of walnuts() (:391)
 
 
-def uturn(theta_rho1, theta_rho2, inv_mass):  # walnuts.py:16-33
-    theta1, rho1 = theta_rho1
-    theta2, rho2 = theta_rho2
-    diff = inv_mass * (theta2 - theta1)
-    return np.dot(rho1, diff) < 0 or np.dot(rho2, diff) < 0
-
-
-def sub_uturn(orbit, start_ignore, end_ignore, inv_mass):  # walnuts.py:62-70 (ignores start/end, Q9)
-    length = np.shape(orbit)[0]
-    span = length
-    while span >= 2:
-        for i in range(length // span):
-            if uturn(orbit[span * i], orbit[span * (i + 1) - 1], inv_mass):
-                return True
-        span = span // 2
-    return False
-
-
-def _target_of(logp, grad):
-    t = logp if isinstance(logp, DeviceTarget) else getattr(logp, "target", None)
-    g = grad if isinstance(grad, DeviceTarget) else getattr(grad, "target", None)
-    if t is None or g is None:
-        raise TypeError("logp and grad must be device target descriptors (walnuts_amd.targets / "
-                        "walnuts_amd.targetDistr): a Python callable cannot run on the GPU")
-    if t is not g:
-        raise ValueError("logp and grad describe different targets")
-    return t
-
-
-class _Device:
-    """device buffers + the wn_ext_orbit call for one chain"""
-
-    def __init__(self, target, D, inv_mass):
-        import torch
-        if not torch.cuda.is_available():
-            from .engine import WalnutsError
-            raise WalnutsError("walnuts_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU fallback")
-        self.torch, self.lib, self.D, self.target = torch, L.lib(), D, target
-        self.dev = torch.device("cuda", torch.cuda.current_device())
-        self.im = torch.as_tensor(np.ascontiguousarray(inv_mass, dtype=np.float64), device=self.dev)
-        self.tpar = None
-        if target.params is not None:
-            self.tpar = torch.as_tensor(np.ascontiguousarray(np.asarray(target.params, dtype=np.float64)),
-                                        device=self.dev).reshape(-1)
-
-
-    def extend(self, theta, rho, n_macro, lottery, weight0, macro_step, max_error):
-        t = self.torch
-        P = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
-        th = t.as_tensor(np.ascontiguousarray(theta, dtype=np.float64), device=self.dev).reshape(1, -1)
-        rh = t.as_tensor(np.ascontiguousarray(rho, dtype=np.float64), device=self.dev).reshape(1, -1)
-        lot = t.as_tensor(np.ascontiguousarray(lottery, dtype=np.int32), device=self.dev).reshape(1, -1)
-        w0 = t.as_tensor(np.array([weight0], dtype=np.float64), device=self.dev)
-        orbit = t.empty((1, n_macro, 2, self.D), dtype=t.float64, device=self.dev)
-        logw = t.empty((1, n_macro), dtype=t.float64, device=self.dev)
-        rc = self.lib.wn_ext_orbit(self.dev.index, self.target.kind, P(self.tpar), self.D, 1, P(th), P(rh),
-                                   P(self.im), float(macro_step), float(max_error), int(n_macro), P(lot),
-                                   P(w0), P(orbit), P(logw), None,
-                                   C.c_void_p(t.cuda.current_stream(self.dev).cuda_stream))
-        if rc:
-            raise RuntimeError(self.lib.wn_last_error(None).decode())
-        o = orbit.cpu().numpy()[0]
-        return [(o[m, 0], o[m, 1]) for m in range(n_macro)], logw.cpu().numpy()[0].tolist()
-
-    def minus_H(self, theta, rho, inv_mass):
-        """-H(theta, rho) = logp(theta) - 0.5*dot(inv_mass, rho**2) (walnuts.py:127-141); logp on the GPU."""
-        t = self.torch
-        th = t.as_tensor(np.ascontiguousarray(theta, dtype=np.float64), device=self.dev).reshape(1, -1)
-        lp = t.empty(1, dtype=t.float64, device=self.dev)
-        g = t.empty_like(th)
-        rc = self.lib.wn_lpfun_kind(self.dev.index, self.target.kind,
-                                    C.c_void_p(self.tpar.data_ptr()) if self.tpar is not None else None,
-                                    self.D, 1, C.c_void_p(th.data_ptr()), C.c_void_p(lp.data_ptr()),
-                                    C.c_void_p(g.data_ptr()),
-                                    C.c_void_p(t.cuda.current_stream(self.dev).cuda_stream))
-        if rc:
-            raise RuntimeError(self.lib.wn_last_error(None).decode())
-        return float(lp.cpu()[0]) - 0.5 * np.dot(inv_mass, rho ** 2)
-
-
-def _walnuts_step(dev, rng, theta, inv_mass, macro_step, max_nuts_depth, max_error):
-    from scipy.special import logsumexp, softmax
-    L_mass = inv_mass ** -0.5
-    D = theta.size
-    rho = L_mass * rng.normal(size=D)                       # :325
-    orbit, log_weights = [(theta, rho)], [dev.minus_H(theta, rho, inv_mass)]  # :326
-    theta_selected = theta
-    for depth in range(max_nuts_depth):                     # :328
-        num_macro_steps = 2 ** depth
-        going_backward = bool(rng.binomial(1, 0.5))         # :330
-        # one choice([ell//2, ell, 2*ell]) per macro step (:194,:256): the index does not depend on ell
-        lottery = [int(rng.choice(3)) for _ in range(num_macro_steps)]
-        if going_backward:                                  # extend_orbit :242-248
-            th0, rh0 = orbit[0]
-            rh0 = -rh0
-            w0 = log_weights[0]
-        else:
-            th0, rh0 = orbit[-1]
-            w0 = log_weights[-1]
-        orbit_ext, log_weights_ext = dev.extend(th0, rh0, num_macro_steps, lottery, w0, macro_step, max_error)
-        if going_backward:                                  # :274-275
-            orbit_ext, log_weights_ext = orbit_ext[::-1], log_weights_ext[::-1]
-        if sub_uturn(orbit_ext, 0, num_macro_steps, inv_mass):  # :343
-            break
-        log_accept_prob_ub = logsumexp(log_weights_ext) - logsumexp(log_weights)  # :345
-        log_uniform = np.log(rng.uniform(0, 1))             # :346
-        if log_uniform < log_accept_prob_ub:                # :347-350
-            p = softmax(log_weights_ext)
-            theta_selected, _ = orbit_ext[int(rng.choice(len(orbit_ext), p=p))]
-        orbit = orbit_ext + orbit if going_backward else orbit + orbit_ext  # :351
-        if uturn(orbit[0], orbit[-1], inv_mass):            # :352
-            break
-        log_weights = log_weights_ext + log_weights if going_backward else log_weights + log_weights_ext
-    return theta_selected
-
-
-def _validate(theta, inv_mass, macro_step, max_nuts_depth, max_error):  # walnuts.py:307-320
+def _check_args(theta, inv_mass, macro_step, max_nuts_depth, max_error):
+    """The reference's argument errors (walnuts.py:307-320), same messages; theta may be (D,) or (C, D)."""
     theta = np.array(theta, dtype=np.float64)
     inv_mass = np.array(inv_mass, dtype=np.float64)
-    if theta.ndim != 1:
+    if theta.ndim not in (1, 2) or 0 in theta.shape:
         raise ValueError("theta not a vector")
     if inv_mass.ndim != 1:
         raise ValueError("inv_mass not a vector")
-    if theta.size != inv_mass.size:
+    if theta.shape[-1] != inv_mass.size:
         raise ValueError("size mismatch between theta and inv_mass")
     if not macro_step > 0:
         raise ValueError("non-positive macro_step")
@@ -157,31 +46,212 @@ def _validate(theta, inv_mass, macro_step, max_nuts_depth, max_error):  # walnut
     return theta, inv_mass
 
 
+def _resolve(logp, grad):
+    """-> (device descriptor, None) or (None, (logp, grad) host callables)."""
+    t = logp if isinstance(logp, DeviceTarget) else getattr(logp, "target", None)
+    g = grad if isinstance(grad, DeviceTarget) else getattr(grad, "target", None)
+    if t is not None or g is not None:
+        if t is not g:
+            raise ValueError("logp and grad describe different targets")
+        return t, None
+    if not (callable(logp) and callable(grad)):
+        raise TypeError("logp and grad must be callables (theta -> float, theta -> (D,)) or walnuts_amd target descriptors")
+    return None, (logp, grad)
+
+
+class _Stepper:
+    """The wn_wstep handle of B chains and its exchange buffers."""
+
+    def __init__(self, target, fns, B, D, inv_mass, macro_step, max_nuts_depth, max_error):
+        import torch
+        if not torch.cuda.is_available():
+            from .engine import WalnutsError
+            raise WalnutsError("walnuts_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU fallback")
+        self.t, self.lib, self.B, self.D, self.fns, self.depth = torch, L.lib(), B, D, fns, int(max_nuts_depth)
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        dv = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=self.dev)
+        self.dv = dv
+        im = dv(inv_mass)
+        tpar = dv(np.asarray(target.params, dtype=np.float64)).reshape(-1) if (target is not None and target.params is not None) else None
+        kind = L.T_EXTERNAL if target is None else target.kind
+        h = C.c_void_p()
+        rc = self.lib.wn_wstep_create(self.dev.index, kind, self.p(tpar), tpar.numel() if tpar is not None else 0, D, B, self.depth,
+                                      self.p(im), float(macro_step), float(max_error), C.byref(h))
+        if rc:
+            msg = self.lib.wn_wstep_last_error(None).decode()
+            raise NotImplementedError(msg) if rc == L.E_UNSUPPORTED else (MemoryError(msg) if rc == L.E_ALLOC else ValueError(msg))
+        self.h = h
+        z = lambda *s, dt=torch.float64: torch.zeros(s, dtype=dt, device=self.dev)
+        self.sub, self.uturn = z(B, dt=torch.int32), z(B, dt=torch.int32)
+        self.lse_ext, self.lse_old = z(B), z(B)
+        if fns is not None:
+            self.xreq, self.xlp, self.xg = z(B, D), z(B), z(B, D)
+            self._ck(self.lib.wn_wstep_ext_bind(self.h, self.p(self.xreq), self.p(self.xlp), self.p(self.xg)))
+
+    @staticmethod
+    def p(x):
+        return C.c_void_p(x.data_ptr()) if x is not None else None
+
+    def _st(self):
+        return C.c_void_p(self.t.cuda.current_stream(self.dev).cuda_stream)
+
+    def _ck(self, rc):
+        if rc:
+            raise RuntimeError(self.lib.wn_wstep_last_error(self.h).decode())
+
+    def _serve(self, waiting):
+        """Host (logp, grad) pair: evaluate the requested positions of the waiting chains until none waits."""
+        if self.fns is None:
+            return
+        logp, grad = self.fns
+        n = C.c_int32(0)
+        while True:
+            self._ck(self.lib.wn_wstep_ext_pending(self.h, C.byref(n), self._st()))
+            if n.value == 0:
+                return
+            x = self.xreq.cpu().numpy()
+            lp = np.zeros(self.B); g = np.zeros((self.B, self.D))
+            for b in waiting:
+                lp[b] = logp(x[b])
+                g[b] = grad(x[b])
+            self.xlp.copy_(self.dv(lp)); self.xg.copy_(self.dv(g))
+            self._ck(self.lib.wn_wstep_ext_feed(self.h, self.p(self.sub), self.p(self.lse_ext), self.p(self.lse_old), self._st()))
+
+    def step(self, rngs, theta, inv_mass):
+        """One transition of every chain (walnuts.py:322-359); theta (B, D) -> next states (B, D)."""
+        t, B, D = self.t, self.B, self.D
+        L_mass = inv_mass ** -0.5
+        rho = np.stack([L_mass * rngs[b].normal(size=D) for b in range(B)])          # :325
+        th_d, rho_d = self.dv(theta), self.dv(rho)
+        self._ck(self.lib.wn_wstep_begin(self.h, self.p(th_d), self.p(rho_d), self._st()))
+        self._serve(range(B))
+        active = np.ones(B, dtype=np.int32)
+        for depth in range(self.depth):                                               # :328
+            n = 1 << depth
+            act = [b for b in range(B) if active[b]]
+            if not act:
+                break
+            backward = np.zeros(B, dtype=np.int32); lottery = np.zeros((B, n), dtype=np.int32)
+            for b in act:
+                backward[b] = int(bool(rngs[b].binomial(1, 0.5)))                     # :330
+                lottery[b] = [int(rngs[b].choice(3)) for _ in range(n)]              # :194, one per macro step (:256)
+            bw_d, lo_d, ac_d = self.dv(backward, t.int32), self.dv(lottery, t.int32), self.dv(active, t.int32)
+            self._ck(self.lib.wn_wstep_extend(self.h, depth, self.p(bw_d), self.p(lo_d), self.p(ac_d), self.p(self.sub),
+                                              self.p(self.lse_ext), self.p(self.lse_old), self._st()))
+            self._serve(act)
+            sub = self.sub.cpu().numpy(); le = self.lse_ext.cpu().numpy(); lo = self.lse_old.cpu().numpy()
+            accept = np.zeros(B, dtype=np.int32); u_choice = np.zeros(B)
+            for b in act:
+                if sub[b]:                                                             # :343
+                    active[b] = 0
+                    continue
+                log_uniform = np.log(rngs[b].uniform(0, 1))                           # :346
+                if log_uniform < le[b] - lo[b]:                                       # :345-347
+                    accept[b] = 1
+                    u_choice[b] = rngs[b].random()                                    # Generator.choice(orbit_ext, p=p) :350
+            ac_d2, uc_d = self.dv(accept, t.int32), self.dv(u_choice)
+            self._ck(self.lib.wn_wstep_commit(self.h, self.p(ac_d2), self.p(uc_d), self.p(self.uturn), self._st()))
+            ut = self.uturn.cpu().numpy()
+            for b in act:
+                if active[b] and ut[b]:                                               # :352
+                    active[b] = 0
+        out = t.empty((B, D), dtype=t.float64, device=self.dev)
+        self._ck(self.lib.wn_wstep_result(self.h, self.p(out), self._st()))
+        return out.cpu().numpy()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.t.cuda.synchronize(self.dev)
+            self.lib.wn_wstep_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _stepper(theta, logp, grad, inv_mass, macro_step, max_nuts_depth, max_error):
+    target, fns = _resolve(logp, grad)
+    B, D = theta.shape
+    if target is not None:
+        target.check_dim(D)
+    return _Stepper(target, fns, B, D, inv_mass, macro_step, max_nuts_depth, max_error)
+
+
+def walnuts_step_batch(rngs, theta, logp, grad, inv_mass, macro_step, max_nuts_depth, max_error):
+    """Next states (C, D) of C independent WALNUTS chains from theta (C, D); rngs = one numpy Generator per chain."""
+    theta, inv_mass = _check_args(theta, inv_mass, macro_step, max_nuts_depth, max_error)
+    theta = np.atleast_2d(theta)
+    if len(rngs) != theta.shape[0]:
+        raise ValueError("one Generator per chain")
+    s = _stepper(theta, logp, grad, inv_mass, macro_step, max_nuts_depth, max_error)
+    try:
+        return s.step(rngs, theta, inv_mass)
+    finally:
+        s.close()
+
+
 def walnuts_step(rng, theta, logp, grad, inv_mass, macro_step, max_nuts_depth, max_error):
     """Next state of the WALNUTS chain from `theta` (walnuts.py:279-359)."""
-    theta, inv_mass = _validate(theta, inv_mass, macro_step, max_nuts_depth, max_error)
-    target = _target_of(logp, grad)
-    target.check_dim(theta.size)
-    dev = _Device(target, theta.size, inv_mass)
-    return _walnuts_step(dev, rng, theta, inv_mass, macro_step, max_nuts_depth, max_error)
+    theta, inv_mass = _check_args(theta, inv_mass, macro_step, max_nuts_depth, max_error)
+    if theta.ndim != 1:
+        raise ValueError("theta not a vector")
+    return walnuts_step_batch([rng], theta[None, :], logp, grad, inv_mass, macro_step, max_nuts_depth, max_error)[0]
 
 
-def walnuts(rng, theta_init, logp, grad, inv_mass, macro_step, max_nuts_depth, max_error, iter_warmup,
-            iter_sample):
-    """Markov chain of `iter_sample` draws, shape (iter_sample, D) (walnuts.py:362-408).  Warm-up
-    draws are discarded; this variant has no adaptation (walnuts.py:406)."""
-    disable_runtime_warnings()
-    theta = np.array(theta_init, dtype=np.float64)
-    D = theta.size
-    draws = np.empty((iter_sample, D))
-    dev = None
-    for i in range(iter_warmup + iter_sample):
-        theta, inv_mass_a = _validate(theta, inv_mass, macro_step, max_nuts_depth, max_error)
-        if dev is None:
-            target = _target_of(logp, grad)
-            target.check_dim(D)
-            dev = _Device(target, D, inv_mass_a)
-        theta = _walnuts_step(dev, rng, theta, inv_mass_a, macro_step, max_nuts_depth, max_error)
-        if i >= iter_warmup:
-            draws[i - iter_warmup] = theta
+def walnuts_batch(rngs, theta_init, logp, grad, inv_mass, macro_step, max_nuts_depth, max_error, iter_warmup, iter_sample):
+    """C chains at once: theta_init (C, D), one Generator per chain -> draws (C, iter_sample, D).  Chain c consumes
+    rngs[c] exactly as walnuts(rngs[c], theta_init[c], ...) would."""
+    _quiet()
+    theta, inv_mass = _check_args(theta_init, inv_mass, macro_step, max_nuts_depth, max_error)
+    theta = np.atleast_2d(theta)
+    Cn, D = theta.shape
+    if len(rngs) != Cn:
+        raise ValueError("one Generator per chain")
+    draws = np.empty((Cn, iter_sample, D))
+    s = _stepper(theta, logp, grad, inv_mass, macro_step, max_nuts_depth, max_error)
+    try:
+        for i in range(iter_warmup + iter_sample):
+            theta = s.step(rngs, theta, inv_mass)
+            if i >= iter_warmup:
+                draws[:, i - iter_warmup] = theta
+    finally:
+        s.close()
     return draws
+
+
+def walnuts(rng, theta_init, logp, grad, inv_mass, macro_step, max_nuts_depth, max_error, iter_warmup, iter_sample):
+    """Markov chain of `iter_sample` draws, shape (iter_sample, D) (walnuts.py:362-408).  Warm-up draws are
+    discarded; this variant has no adaptation (walnuts.py:406)."""
+    theta = np.array(theta_init, dtype=np.float64)
+    if theta.ndim != 1:
+        raise ValueError("theta not a vector")
+    return walnuts_batch([rng], theta[None, :], logp, grad, inv_mass, macro_step, max_nuts_depth, max_error,
+                         iter_warmup, iter_sample)[0]
+
+
+def walnuts_stan(rng, theta_init, stan_file, data_file, inv_mass, macro_step, max_nuts_depth, max_error, iter_warmup,
+                 iter_sample):
+    """walnuts() on a Stan model through bridgestan (walnuts/walnuts_stan.py:4-43): logp = StanModel.log_density,
+    grad = the gradient half of StanModel.log_density_gradient, both passed to walnuts() as host callables.
+    (The reference's own file stops with NameErrors before sampling -- SURVEY.md Q10; this is its documented intent.)
+    bridgestan is not part of this package: without it the call fails with the ImportError below.  For the one
+    Stan model of the reference's examples, StockWatson, `walnuts_amd.targetDistr.stockWatson(y)` is a fused device
+    target that needs no Stan toolchain."""
+    try:
+        import bridgestan as bs
+    except ImportError as ex:
+        raise ImportError("walnuts_stan needs the bridgestan package (and a Stan toolchain) to compile "
+                          f"{stan_file!r}; it is not installed here.  Pass logp / grad callables or a walnuts_amd device "
+                          "target to walnuts() instead.") from ex
+    model = bs.StanModel(stan_file, data_file)
+
+    def logp(theta):
+        return model.log_density(theta)
+
+    def grad(theta):
+        return model.log_density_gradient(theta)[1]
+
+    return walnuts(rng, theta_init, logp, grad, inv_mass, macro_step, max_nuts_depth, max_error, iter_warmup, iter_sample)
