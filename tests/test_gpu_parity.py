@@ -142,7 +142,7 @@ def test_integrator_kat_through_c_abi(wa, i):
     q1, v1, g1, io, do = e.integrator_step(KA[p + "q"], KA[p + "v"], KA[p + "g"], [Ham0], [h], [xi], [u])
     np.testing.assert_array_equal(io.cpu().numpy()[0], KA[p + "io"])
     close(do.cpu().numpy()[0][:2], KA[p + "do"][:2], what="lp,lwt")
-    close(do.cpu().numpy()[0][3], KA[p + "do"][2], rtol=1e-5, what="igrConst")
+    close(do.cpu().numpy()[0][3], KA[p + "do"][2], rtol=1e-6, what="igrConst")
     close(q1.cpu().numpy()[0], KA[p + "q1"], what="q"); close(v1.cpu().numpy()[0], KA[p + "v1"], what="v")
     close(g1.cpu().numpy()[0], KA[p + "g1"], what="grad")
     e.close()
