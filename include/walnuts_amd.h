@@ -74,7 +74,11 @@ enum {
 enum {
   WN_G_IDENTITY = 0, /* lambda q: q */
   WN_G_Q0_SUMSQ = 1, /* [q[0], sum(q*q)]  WALNUTSpy_examples/gaussian/mainGaussESS.py:29-30 */
-  WN_G_FIRSTK = 2    /* q[0:k]            WALNUTSpy_examples/funnel/mainFunnel.py:17-18 */
+  WN_G_FIRSTK = 2,   /* q[0:k]            WALNUTSpy_examples/funnel/mainFunnel.py:17-18 */
+  /* StockWatson: param_constrain(q, include_tp=True) (mainSW.py:28-29) for sw_innov.stan -- the 3T unconstrained
+   * parameters followed by the transformed parameters in declaration order: sigma, gpri, z[T-1], x[T], tau[T]
+   * (sw_innov.stan:17-35); dg = 6T + 1.  Needs the WN_T_STOCKWATSON target. */
+  WN_G_SW_CONSTRAIN = 3
 };
 
 /* keyword arguments of WALNUTS(...) (WALNUTS.py:111-129) + integratorAuxPar
@@ -153,7 +157,7 @@ int wn_split_done(wn_engine *e, int32_t *n_done, void *stream);
 
 /* wn_run with recordOrbitStats=True (WALNUTS.py:128,182-184,724-725): additionally fills
  * orbit_min_dev / orbit_max_dev [C][n_iter][dg] with the per-iteration minimum / maximum of
- * generated(q) over the states of the orbit.  generated must be WN_G_IDENTITY or WN_G_FIRSTK. */
+ * generated(q) over the states of the orbit (every WN_G_* kind that lives on the device). */
 int wn_run_orbit_stats(wn_engine *e, const double *q0_dev, uint64_t seed, int32_t n_iter,
                        double *samples_dev, double *diag_dev, double *orbit_min_dev,
                        double *orbit_max_dev, void *stream);

@@ -249,6 +249,12 @@ def main():
     add("smile_F", ol.T_SMILE, td.smileDistr, np.array([0.4, -0.1]), "F", H0=0.6, delta0=0.005, numIter=25, M=7)
     add("dense8_F_warm", ol.T_DENSEGAUSS, make_dense(A8w), S8w @ rng.normal(size=8), "F",
         tpar=A8w.ravel(), H0=0.8, delta0=0.02, numIter=30, M=6, warm=dict(warmupIter=20))
+    # recordOrbitStats with generated = [q[0], sum(q*q)] (WALNUTS.py:182-184,331-333 with mainGaussESS.py:29-30), SURVEY.md 8f
+    # rank 3 (appended: earlier cases keep their draws)
+    add("std6_fixed_orbit_ess", ol.T_STDGAUSS, td.stdGauss, rng.normal(size=6), "fixed",
+        H0=0.7, numIter=25, M=7, generated=ol.G_Q0_SUMSQ, genfn=gen_q0_sumsq, recordOrbitStats=True)
+    add("dense8_R2P_orbit_ess", ol.T_DENSEGAUSS, make_dense(A8w), S8w @ rng.normal(size=8), "R2P",
+        tpar=A8w.ravel(), H0=0.6, delta0=0.1, numIter=20, M=7, generated=ol.G_Q0_SUMSQ, genfn=gen_q0_sumsq, recordOrbitStats=True)
 
     for chain, c in enumerate(cases):
         fn, kind = INTEGRATORS[c["integ"]]

@@ -244,3 +244,20 @@ def test_stockwatson_python_api(wa):
     np.testing.assert_allclose(s2[3 * T, 3], np.exp(-0.5 * q[0]))
     x = q[T] + np.concatenate([[0.0], np.cumsum(np.exp(-0.5 * q[0]) * q[T + 1:2 * T])])
     np.testing.assert_allclose(s2[3 * T + 2 + (T - 1):3 * T + 2 + (T - 1) + T, 3], x, rtol=1e-12, atol=1e-12)
+
+
+def test_stockwatson_device_generated_matches_host_form(wa):
+    """generated = param_constrain(q, include_tp=True) (mainSW.py:28-29, sw_innov.stan:17-35) on the device
+    (WN_G_SW_CONSTRAIN) against the host form of the same transform applied to the stored identity draws: 1e-12."""
+    from walnuts_amd import adaptiveIntegrators as ai, targetDistr as td
+    T = SW_T
+    q0 = 0.05 * np.random.default_rng(2).normal(size=(3, 3 * T))
+    kw = dict(integrator=ai.adaptLeapFrogD, H0=0.1, delta0=0.3, numIter=4, warmupIter=0, M=5, igrAux=ai.integratorAuxPar(minC=3), seed=3)
+    sd, dd = wa.WALNUTS(td.stockWatson(_SW["y"]), q0, generated=wa.sw_constrain, **kw)
+    sh, dh = wa.WALNUTS(td.stockWatson(_SW["y"]), q0, generated=td.stockWatsonConstrain(_SW["y"]), **kw)
+    assert sd.shape == sh.shape == (3, 6 * T + 1, 5)
+    np.testing.assert_array_equal(dd, dh)
+    np.testing.assert_array_equal(sd[:, :3 * T], sh[:, :3 * T])
+    np.testing.assert_allclose(sd, sh, rtol=1e-12, atol=1e-13)
+    with pytest.raises(ValueError):
+        wa.WALNUTS(td.stdGauss, np.zeros(9), generated=wa.sw_constrain, numIter=1, warmupIter=0)

@@ -30,6 +30,9 @@ class Generated:
 
 identity = Generated(L.G_IDENTITY)
 q0_sumsq = Generated(L.G_Q0_SUMSQ)  # mainGaussESS.py:29-30  [q[0], sum(q*q)]
+# mainSW.py:28-29 generatedInnov(q) = param_constrain(q, include_tp=True) for sw_innov.stan, on the device (needs the
+# targetDistr.stockWatson target): q followed by sigma, gpri, z[T-1], x[T], tau[T]
+sw_constrain = Generated(L.G_SW_CONSTRAIN)
 
 
 def firstk(k):
@@ -92,8 +95,8 @@ def WALNUTS(lpFun, q0, generated=identity, integrator=ai.fixedLeapFrog, H0=0.2,
         out = eng.run_external(q0a, seed, numIter, lpFun.fn)
     elif recordOrbitStats:
         eng.set_target(lpFun.kind, lpFun.params)
-        if host_gen is not None or generated.kind == L.G_Q0_SUMSQ:
-            raise NotImplementedError("recordOrbitStats needs generated = identity or firstk(k) on the device")
+        if host_gen is not None:
+            raise NotImplementedError("recordOrbitStats needs a device form of generated (identity, firstk(k), q0_sumsq)")
         samples, diag, omin, omax = eng.run_orbit_stats(q0a, seed, numIter)
         out = (samples, diag, omin.transpose(1, 2), omax.transpose(1, 2))  # (dg, numIter) per chain (WALNUTS.py:183-184)
     else:

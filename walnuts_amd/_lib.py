@@ -19,7 +19,7 @@ T_STDGAUSS, T_FUNNEL10, T_DENSEGAUSS, T_DIAGGAUSS, T_CORRGAUSS, T_SMILE, T_FUNNE
 T_EXTERNAL = 10
 T_STOCKWATSON = 11
 I_FIXED, I_ADAPT_D, I_ADAPT_R2P, I_ADAPT_YOSHIDA, I_ADAPT_FLOWD = range(5)
-G_IDENTITY, G_Q0_SUMSQ, G_FIRSTK = range(3)
+G_IDENTITY, G_Q0_SUMSQ, G_FIRSTK, G_SW_CONSTRAIN = range(4)
 E_ARG, E_UNSUPPORTED, E_HIP, E_NOTARGET, E_ALLOC = -1, -2, -3, -4, -5
 
 

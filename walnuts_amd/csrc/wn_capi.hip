@@ -220,6 +220,27 @@ __global__ void wn_tape_kernel(uint64_t seed, uint32_t chain0, int C, int iter, 
       z[(size_t)c * D + j] = rng_normal(seed, chain0 + c, (uint32_t)iter, (uint32_t)j);
 }
 
+// generated = param_constrain(q, include_tp=True) for sw_innov.stan (mainSW.py:28-29; sw_innov.stan:17-35): each row of
+// `samples` holds the 3T unconstrained parameters (tSigma, z1, zinn[T-2], x1, xinn[T-1], tau1, tauinn[T-1]) at its head;
+// append sigma, gpri, z[T-1], x[T], tau[T].  One thread per draw, the recursions in the model's own order.
+__global__ void wn_sw_constrain_kernel(double* samples, size_t nrows, int T) {
+  const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const int dg = 6 * T + 1;
+  double* row = samples + r * dg;
+  const double tS = row[0], sigma = exp(-0.5 * tS), gpri = exp(tS);
+  const double *zinn = row + 2, *xinn = row + T + 1, *tin = row + 2 * T + 1;
+  double* o = row + 3 * T;
+  o[0] = sigma; o[1] = gpri;
+  double *z = o + 2, *x = z + (T - 1), *tau = x + T;
+  z[0] = row[1];
+  for (int t = 1; t < T - 1; ++t) z[t] = z[t - 1] + sigma * zinn[t - 1];
+  x[0] = row[T];
+  for (int t = 1; t < T; ++t) x[t] = x[t - 1] + sigma * xinn[t - 1];
+  tau[0] = row[2 * T];
+  for (int t = 1; t < T; ++t) tau[t] = tau[t - 1] + exp(0.5 * z[t - 1]) * tin[t - 1];
+}
+
 __global__ void wn_fill_kernel(double* p, size_t n, double v) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -306,7 +327,8 @@ int wn_create(const wn_config* cfg, wn_engine** out) {
     if (cfg->adapt_delta && cfg->adapt_delta_target < 0.0) { g_create_err = "bad adaptDeltaTarget"; return WN_E_ARG; }
     if (cfg->adapt_delta && !(cfg->adapt_delta_quantile >= 0.0 && cfg->adapt_delta_quantile <= 1.0)) { g_create_err = "adaptDeltaQuantile must be in [0,1]"; return WN_E_ARG; }
   }
-  if (cfg->generated < WN_G_IDENTITY || cfg->generated > WN_G_FIRSTK) { g_create_err = "unknown generated kind"; return WN_E_ARG; }
+  if (cfg->generated < WN_G_IDENTITY || cfg->generated > WN_G_SW_CONSTRAIN) { g_create_err = "unknown generated kind"; return WN_E_ARG; }
+  if (cfg->generated == WN_G_SW_CONSTRAIN && (cfg->dim % 3 || cfg->dim < 9)) { g_create_err = "WN_G_SW_CONSTRAIN needs dim = 3T"; return WN_E_ARG; }
   if (cfg->generated == WN_G_FIRSTK && (cfg->gen_k < 1 || cfg->gen_k > cfg->dim)) { g_create_err = "gen_k out of range"; return WN_E_ARG; }
   wn_engine* e = new wn_engine();
   e->cfg = *cfg;
@@ -360,6 +382,7 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
     default: e->err = "unknown target kind"; return WN_E_ARG;
   }
   if (need && (n_params != need || !params_dev)) { e->err = "wrong parameter count for target"; return WN_E_ARG; }
+  if (e->cfg.generated == WN_G_SW_CONSTRAIN && kind != WN_T_STOCKWATSON) { e->err = "generated = WN_G_SW_CONSTRAIN needs the StockWatson target"; return WN_E_ARG; }
   KernelChoice kc;
   if (choose_kernel(kind, D, e->cfg.waves_per_group, e->cfg.integrator, e->cfg.n_chains, &kc)) {
     e->err = "no device kernel for this (target, dim) yet";
@@ -445,6 +468,10 @@ static void fill_params(const wn_engine* e, Params* p) {
   p->integrator = c.integrator; p->M = c.M; p->minC = c.min_c; p->maxC = c.max_c;
   p->generated = c.generated; p->gen_k = c.gen_k;
   p->dg = c.generated == WN_G_IDENTITY ? c.dim : c.generated == WN_G_Q0_SUMSQ ? 2 : c.gen_k;
+  if (c.generated == WN_G_SW_CONSTRAIN) {  // the sampler stores identity draws at the head of each (6T+1)-wide row; wn_sw_constrain_kernel fills the rest
+    p->generated = G_IDENTITY;
+    p->dg = 2 * c.dim + 1;
+  }
   p->H = c.H0; p->s = c.step_size_rand_scale; p->delta = c.delta0; p->R2Pprob0 = c.r2p_prob0;
   p->logP = log(c.r2p_prob0); p->log1mP = log(1.0 - c.r2p_prob0);
   p->wtSumThresh = exp(WN_LOGZERO + 1.0);  // constants.py:14
@@ -550,6 +577,11 @@ static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
                : e->kc.layout == 0 ? launch_lane(e->kc, adapt, warm, p_, st)
                : e->kc.layout == 1 ? launch_coop(e->kc, adapt, warm, p_, st) : launch_wave(e->kc, adapt, warm, p_, st);
   if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
+  if (e->cfg.generated == WN_G_SW_CONSTRAIN && p.mode == MODE_SAMPLE) {
+    const size_t nrows = (size_t)p.C * (p.numIter + 1);
+    hipLaunchKernelGGL(wn_sw_constrain_kernel, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, st, p.samples, nrows, p.D / 3);
+    HIPCHK(e, hipGetLastError());
+  }
   if (timed) { HIPCHK(e, hipEventRecord(e->ev1, st)); e->timed = true; }
   if (e->kc.G > 1) {  // a cluster run reports a spin that gave up instead of returning unreduced sums
     int ab = 0;
@@ -622,7 +654,6 @@ int wn_run_orbit_stats(wn_engine* e, const double* q0_dev, uint64_t seed, int32_
   if (!e) return WN_E_ARG;
   if (!e->have_kc) { e->err = "wn_set_target has not been called"; return WN_E_NOTARGET; }
   if (!q0_dev || !samples_dev || !diag_dev || !orbit_min_dev || !orbit_max_dev || n_iter < 0) { e->err = "null buffer or negative n_iter"; return WN_E_ARG; }
-  if (e->cfg.generated == WN_G_Q0_SUMSQ) { e->err = "recordOrbitStats supports generated = identity / first-k"; return WN_E_UNSUPPORTED; }
   HIPCHK(e, hipSetDevice(e->cfg.device));
   Params p;
   fill_params(e, &p);

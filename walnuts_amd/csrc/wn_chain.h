@@ -138,6 +138,8 @@ enum { WARM_QL = 0, WARM_VL, WARM_QO, WARM_VO, WARM_GO, WARM_N };
   X(double, sp_hh2) /* split mode: half-step factor of the micro step in flight */               \
   /* adaptLeapFrogFlowD: lp / kinetic energy of the leapfrog half of the micro step, running max flow error */ \
   X(double, flp) X(double, fke) X(double, ferr_max)                                              \
+  /* recordOrbitStats with generated = [q0, sum q^2]: sum q^2 of the state after the last micro step / of the accepted forward result */ \
+  X(double, osq_cur) X(double, osq_out)                                                          \
   X(int, iter) X(uint32_t, Bbits)                                                                \
   X(int, i) X(int, xi) X(int, a) X(int, b) X(int, n) X(int, nleaf)                               \
   X(uint32_t, ku) X(uint32_t, ub0) /* ub0: first Philox block of the cached uniform window */    \
@@ -376,6 +378,7 @@ struct Engine : ChainScalars {
     if (WARM) igrOut = hh * pow(madnan ? NAN : madv, -1.0 / 3.0);  // :101 / :399 / :424
     lpOut = lp;
     HOut = Hi;
+    osq_out = osq_cur;
   }
   template <bool B_ = ADAPT>
   WN_HD typename std::enable_if<!B_>::type save_out(double, double) {}
@@ -627,20 +630,36 @@ struct Engine : ChainScalars {
   // ------------------------------------------------------------------------------------------
   // orbitMin/orbitMax[:,iterN-1] = np.minimum/np.maximum(..., generated(q))  (WALNUTS.py:274-276,
   // 331-333, 364-366, 434-436, ...): every lane updates the elements it owns, in memory
+  WN_HD bool orbit_sumsq() const { return prm.omin && prm.generated == G_Q0_SUMSQ; }
+  // generated = [q[0], sum(q*q)] (mainGaussESS.py:29-30): the second component is a sum over all lanes that serve
+  // the chain, so it rides in its own reduction right after the gradient (uniform: prm only)
+  WN_HD void orbit_sumsq_reduce(const Vec& q) {
+    if (!orbit_sumsq()) return;
+    double s[1] = {0.0};
+    WN_VFOR(e) s[0] += q.x[e] * q.x[e];
+    p.template reduce<1>(s);
+    osq_cur = s[0];
+  }
   WN_HD void orbit_stats(const Vec& q, bool init) {
     if (!prm.omin) return;
-    const int k = prm.generated == G_FIRSTK ? prm.gen_k : prm.D;
     const size_t row = ((size_t)p.chain_local() * prm.numIter + (iter - 1)) * prm.dg;
-    WN_VFOR(e) if (p.valid(e) && p.owner(e) && p.gidx(e) < k) {
-      double* mn = prm.omin + row + p.gidx(e);
-      double* mx = prm.omax + row + p.gidx(e);
-      const double x = q.x[e];
-      if (init) { *mn = x; *mx = x; }
-      else {
-        const double a = *mn, b = *mx;
-        *mn = (isnan(x) || isnan(a)) ? NAN : (x < a ? x : a);
-        *mx = (isnan(x) || isnan(b)) ? NAN : (x > b ? x : b);
-      }
+    if (prm.generated == G_Q0_SUMSQ) {
+      WN_VFOR(e) if (p.valid(e) && p.owner(e) && p.gidx(e) == 0) orbit_minmax(row, q.x[e], init);
+      // the sum of squares of the iteration's first state arrives with its draw (finish_generated)
+      if (!init && p.writer()) orbit_minmax(row + 1, ADAPT ? osq_out : osq_cur, false);
+      return;
+    }
+    const int k = prm.generated == G_FIRSTK ? prm.gen_k : prm.D;
+    WN_VFOR(e) if (p.valid(e) && p.owner(e) && p.gidx(e) < k) orbit_minmax(row + p.gidx(e), q.x[e], init);
+  }
+  WN_HD void orbit_minmax(size_t at, double x, bool init) {
+    double* mn = prm.omin + at;
+    double* mx = prm.omax + at;
+    if (init) { *mn = x; *mx = x; }
+    else {
+      const double a = *mn, b = *mx;
+      *mn = (isnan(x) || isnan(a)) ? NAN : (x < a ? x : a);
+      *mx = (isnan(x) || isnan(b)) ? NAN : (x > b ? x : b);
     }
   }
 
@@ -909,8 +928,14 @@ struct Engine : ChainScalars {
   }
   WN_HD void finish_generated(double total) {
     if (needGen) {
-      if (p.writer())
+      if (p.writer()) {
         prm.samples[((size_t)p.chain_local() * (prm.numIter + 1) + gen_iter) * prm.dg + 1] = total;
+        // orbitMin / orbitMax[:, iterN-1] start at generated(qc) (WALNUTS.py:274-276): iteration gen_iter + 1 starts here
+        if (orbit_sumsq() && gen_iter < prm.numIter) {
+          const size_t at = ((size_t)p.chain_local() * prm.numIter + gen_iter) * prm.dg + 1;
+          prm.omin[at] = total; prm.omax[at] = total;
+        }
+      }
       needGen = false;
       gen_part = 0.0;
     }
@@ -948,6 +973,7 @@ struct Engine : ChainScalars {
     lpn = Hn = lpOut = HOut = 0.0; H0 = Ha = Hb = 0.0;
     sp_stage = 0; sp_hh2 = 0.0; sp_act = false; sp_mid = false;
     flp = fke = 0.0; ferr_max = -INFINITY; ferr_nan = false;
+    osq_cur = osq_out = 0.0;
     zero_flow();
   }
 
@@ -1064,6 +1090,7 @@ struct Engine : ChainScalars {
         WN_VFOR(e) G.x[e] = gin.x[e];
         p.ext_lp(Q, G, part[0]);
       }
+      orbit_sumsq_reduce(Q);
       double ke = 0.0;
       WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; ke += V.x[e] * V.x[e]; }
       part[1] = ke; part[2] = keinit_part; part[3] = gen_part;
@@ -1280,6 +1307,7 @@ struct Engine : ChainScalars {
         } else {
           p.grad(Q, G, part[0]);
         }
+        orbit_sumsq_reduce(Q);
         WN_STAMP(1);
         double ke = 0.0;
         WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; ke += V.x[e] * V.x[e]; }

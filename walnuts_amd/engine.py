@@ -45,7 +45,7 @@ class Engine:
         cfg.adapt_delta_quantile = float(adaptDeltaQuantile)
         self.cfg = cfg
         self.dim, self.n_chains = int(dim), int(n_chains)
-        self.dg = {L.G_IDENTITY: self.dim, L.G_Q0_SUMSQ: 2, L.G_FIRSTK: int(gen_k)}[int(generated)]
+        self.dg = {L.G_IDENTITY: self.dim, L.G_Q0_SUMSQ: 2, L.G_FIRSTK: int(gen_k), L.G_SW_CONSTRAIN: 2 * self.dim + 1}[int(generated)]
         h = C.c_void_p()
         rc = self.lib.wn_create(C.byref(cfg), C.byref(h))
         if rc:

@@ -133,7 +133,8 @@ def stockWatsonConstrain(y):
     sw_innov.stan: the 3T unconstrained parameters followed by the transformed parameters in
     declaration order (sigma, gpri, z[T-1], x[T], tau[T]; sw_innov.stan:17-35).  Pass it as
     `generated=`: identity draws are stored on the device and the transform is applied to each stored
-    draw on the host, once per iteration, as in the reference."""
+    draw on the host, once per iteration, as in the reference.  The device form of the same transform is
+    `walnuts_amd.sw_constrain` (include/walnuts_amd.h WN_G_SW_CONSTRAIN); this host form is what it is tested against."""
     T = int(np.asarray(y).shape[0])
 
     def gen(q):
