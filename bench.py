@@ -24,8 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SEED = 20251121            # SURVEY.md 8d master seed
-FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix (v_mfma_f64_16x16x4_f64: 256 CU x 4 SIMD x 32 flop/clk
-                              # x 2.4 GHz); checked on the box by tools/mfma_f64_rate.hip (profiles/)
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix = FP64 vector (v_mfma_f64_16x16x4_f64: 256 CU x 4 SIMD x 32 flop/clk
+                              # x 2.4 GHz); measured on the box by tools/mfma_f64_rate.hip (profiles/r02_mfma_f64_rate.txt)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -63,6 +63,19 @@ def _cpu_worker(args):
     return float(d[:, 6].sum() + d[:, 7].sum()), dt
 
 
+def python_reference_cpu(key):
+    """The UNMODIFIED Python reference timed in the build container (tools/ref_cpu_baseline.py; it never travels to the
+    GPU box): BASELINE.md section 3's "measured elsewhere" figure, quoted with where it was measured."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r02_python_reference_cpu.json")))
+        r = j[key]
+        return {"unit": r["unit"], "per_core": r["one_core"]["per_core"], "all_cores": r["all_cores"]["value"],
+                "cores": r["all_cores"]["cores"], "measured": j["where"], "code": j["code"],
+                "note": "not measured in this run: the Python reference does not travel to the GPU box"}
+    except Exception:
+        return None
+
+
 def cpu_baseline(A, q0, iters, M, H0, budget_s=12.0):
     """Time the CPU oracle (the validated C restatement of the reference's path) on the host
     cores, one chain per process, on a bounded sample of the same workload."""
@@ -73,7 +86,7 @@ def cpu_baseline(A, q0, iters, M, H0, budget_s=12.0):
     # calibrate on one chain, one iteration
     s1, t1 = _cpu_worker((A, q0[0], 0, 1, M, H0))
     rate1 = s1 / max(t1, 1e-6)
-    per_iter = 540.0 / rate1 if rate1 > 0 else 1.0
+    per_iter = 540.0 / rate1 if rate1 > 0 else 1.0  # ~540 leapfrog steps per iteration of this workload; only sizes the sample
     n_it = int(max(1, min(iters, budget_s / max(per_iter, 1e-6))))
     nchain = min(cores, q0.shape[0])
     with mp.get_context("fork").Pool(nchain) as pool:
@@ -82,9 +95,12 @@ def cpu_baseline(A, q0, iters, M, H0, budget_s=12.0):
         res = pool.map(_cpu_worker, [(A, q0[c], c, n_it, M, H0) for c in range(nchain)], chunksize=1)
         wall = time.perf_counter() - t0
     steps = sum(r[0] for r in res)
+    C_all = q0.shape[0]
     return {"value": steps / wall, "unit": "leapfrog steps/s", "cores": nchain, "kind": "port",
-            "sample": f"{nchain} chains x {n_it} iterations of the same workload, one chain per process "
-                      f"(oracle/libwalnuts_oracle.so, C restatement pinned to the Python reference)"}
+            "sample": f"the first {nchain} of the {C_all} chains ({100.0 * nchain / C_all:.2f} %) x {n_it} of the {iters} iterations "
+                      f"({steps:.3g} leapfrog steps, {wall:.1f} s), one chain per process (oracle/libwalnuts_oracle.so, the C "
+                      f"restatement pinned to the Python reference)",
+            "python_reference": python_reference_cpu("cfg2_dense100_fixedLeapFrog")}
 
 
 def _self_launch(args):
@@ -226,10 +242,12 @@ def main():
         traffic = args.traffic_bytes
         if traffic is None:  # PMC traffic of this exact workload, measured in a separate rocprofv3 pass
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-                w = tj["workload"]
-                if (w["dim"], w["chains"], w["iters"]) == (D, C, args.iters) and w["kernel"] == eng.kernel_name:
-                    traffic = tj["bytes_per_launch"]
+                for name in ("r02_traffic.json", "r01_traffic.json"):
+                    tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    w = tj["workload"]
+                    if (w["dim"], w["chains"], w["iters"]) == (D, C, args.iters) and w["kernel"] == eng.kernel_name:
+                        traffic = tj["bytes_per_launch"]
+                        break
             except Exception:
                 traffic = None
             if traffic is None and D == 1000 and "split" in eng.kernel_name:
@@ -453,6 +471,12 @@ def _run_evals_workload(args, make_engine, q0_of, metric, workload, bytes_per_ev
                           "tick_us": float(np.mean(kms)) * 1e3 / float(np.mean(mx)),
                           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": ach / HBM_PEAK_GBS,
+                                       # `achieved` is SURVEY 8d's NOMINAL streaming figure (48*D bytes per evaluation); the fused
+                                       # kernel keeps its state on chip, so beside it: the measured HBM rate (PMC bytes) and the
+                                       # FP64-vector fraction at 14*D flop per evaluation
+                                       "measured_hbm_GBps": (None if traffic_key is None or _side_traffic(traffic_key, "bytes_per_gradient_evaluation") is None
+                                                             else _side_traffic(traffic_key, "bytes_per_gradient_evaluation") * tot / args.steps / (np.mean(kms) * 1e-3) / 1e9),
+                                       "fp64_vector_frac": tot / args.steps * 14.0 * (bytes_per_eval / 48.0) / (np.mean(kms) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                                        # measured HBM bytes of one launch of rank 0 (PMC bytes per evaluation x evaluations)
                                        "traffic": (None if traffic_key is None or _side_traffic(traffic_key, "bytes_per_gradient_evaluation") is None
                                                    else _side_traffic(traffic_key, "bytes_per_gradient_evaluation") * tot / args.steps),
