@@ -353,8 +353,11 @@ def side_configs(wa, L, torch, dev):
     e.run(torch.as_tensor(q0, device=dev), SEED + 1, 2)  # untimed first launch (code load)
     s, d = e.run(torch.as_tensor(q0, device=dev), SEED, 30)
     ev = float((d[:, :, 6] + d[:, :, 7]).sum().item())
+    res["note"] = ("one SHORT launch each, outside the timed region (iteration counts below, not SURVEY 8d's): a smoke reading only; "
+                   "the contract lines of these configurations are `bench.py --workload funnel | dense1000 | stockwatson` "
+                   "(profiles/r02_bench_*.json)")
     res["cfg3_funnel10_R2P_4096_chains"] = {"value": ev / (e.last_run_ms() * 1e-3), "unit": "gradient evaluations/s",
-                                            "kernel": e.kernel_name}
+                                            "kernel": e.kernel_name, "iterations": 30}
     e.close()
     A, q1 = make_dense_problem(1000, 100.0, 1024, SEED)
     e = wa.Engine(1000, 1024, integrator=L.I_FIXED, H0=0.5, M=10, generated=L.G_Q0_SUMSQ, device=dev.index)
@@ -362,7 +365,7 @@ def side_configs(wa, L, torch, dev):
     e.run(torch.as_tensor(q1, device=dev), SEED + 1, 2)
     s, d = e.run(torch.as_tensor(q1, device=dev), SEED, 30)
     st = float((d[:, :, 6] + d[:, :, 7]).sum().item()); ms = e.last_run_ms()
-    res["cfg4_dense1000_1024_chains"] = {"value": st / (ms * 1e-3), "unit": "leapfrog steps/s", "kernel": e.kernel_name,
+    res["cfg4_dense1000_1024_chains"] = {"value": st / (ms * 1e-3), "unit": "leapfrog steps/s", "kernel": e.kernel_name, "iterations": 30,
                                          "fp64_mfma_frac": st * (2.0e6 + 12.0e3) / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
     e.close()
     sw = np.load(os.path.join(ROOT, "tests", "golden", "stockwatson_data.npz"))
@@ -373,7 +376,7 @@ def side_configs(wa, L, torch, dev):
     s, d = e.run(torch.zeros((256, 3 * T), dtype=torch.float64, device=dev), SEED, 10)
     ev = float((d[:, :, 6] + d[:, :, 7]).sum().item())
     res["cfg5_stockwatson_adaptD_256_chains"] = {"value": ev / (e.last_run_ms() * 1e-3), "unit": "gradient evaluations/s",
-                                                 "kernel": e.kernel_name}
+                                                 "kernel": e.kernel_name, "iterations": 10}
     e.close()
     return res
 
