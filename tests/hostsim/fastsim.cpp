@@ -117,6 +117,7 @@ struct HostIO {
   double sum(int k) const { return sums[k]; }
   void dots(int j, double& d1, double& d2) const { d1 = sums[Q_DOT0 + 2 * j]; d2 = sums[Q_DOT0 + 2 * j + 1]; }
   uint32_t firemask(int i, int n, int xi) const { return fire_of(i, n, xi, *this); }
+  bool uniforms(int, int, uint32_t, double&, double&) const { return false; }  // no uniform service on the host
   void write_gen(size_t row, double v) const { prm->samples[((size_t)cl * (prm->numIter + 1) + row) * prm->dg + 1] = v; }
   void write_diag(size_t row, const double* d) const {
     double* o = prm->diag + ((size_t)cl * prm->numIter + row) * NDIAG;

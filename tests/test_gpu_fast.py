@@ -57,7 +57,7 @@ def dense_problem(D, kappa, C, seed=SEED):
 
 
 @pytest.mark.parametrize("D,C,M,gen", [(100, 48, 10, ol.G_Q0_SUMSQ), (100, 21, 6, ol.G_IDENTITY), (40, 16, 8, ol.G_FIRSTK),
-                                         (64, 17, 7, ol.G_Q0_SUMSQ), (20, 33, 12, ol.G_Q0_SUMSQ), (97, 5, 3, ol.G_IDENTITY)])
+                                         (64, 17, 7, ol.G_Q0_SUMSQ), (20, 33, 11, ol.G_Q0_SUMSQ), (97, 5, 3, ol.G_IDENTITY)])
 def test_fast_dense_matches_oracle(wa, D, C, M, gen):
     A, q0 = dense_problem(D, 1e3, C)
     kw = dict(H0=0.5, M=M, generated=gen, gen_k=3 if gen == ol.G_FIRSTK else 0, chain_offset=11, numIter=5, seed=SEED + D)

@@ -451,7 +451,7 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
                             (size_t)D * sizeof(double), (size_t)D, hipMemcpyDeviceToDevice));
     }
   }
-  if (kc.layout == 1 && e->cfg.integrator == WN_I_FIXED && e->cfg.warmup_iter == 0 && e->cfg.M <= 12 && D <= 112 && !(kc.p1 == CK_DENSE && kc.p0 == 32) &&
+  if (kc.layout == 1 && e->cfg.integrator == WN_I_FIXED && e->cfg.warmup_iter == 0 && e->cfg.M <= 11 && D <= 112 && !(kc.p1 == CK_DENSE && kc.p0 == 32) &&
       !getenv("WN_COOP_LEGACY")) {
     // plain sampling runs of this engine go to the role-split kernel (wn_k_fast.hip); traced / orbit-statistics
     // runs and wn_integrator_step use the one-stream kernel of the same layout

@@ -136,29 +136,43 @@ struct FastBook {
   // issue side reads ahead (step sizes, direction bits) while the retire side follows (picks, accepts), one
   // Philox block each per leaf pair.  (One cache indexed by block parity -- as an array or as selects between
   // members -- kept the whole bookkeeper in scratch memory: SROA gives up on addresses chosen at run time.)
-  WN_HD double Ui(const Params& prm, uint32_t k) {
+  // A miss first asks `io.uniforms(side, iter, block, ...)`: on the device another wave computes the blocks this
+  // chain will need next (wn_k_fast.hip), so the bookkeeper rarely runs Philox itself.
+  template <class IO>
+  WN_HD double Ui(const Params& prm, IO& io, uint32_t k) {
     const uint32_t blk = k >> 1;
     if (cblkI != blk) {
-      Philox4 r = philox4x32_10(blk, (uint32_t)iter, chain, 0u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
-      cuI0 = u53(r.w[0], r.w[1]); cuI1 = u53(r.w[2], r.w[3]); cblkI = blk;
+      double ua, ub;
+      if (!io.uniforms(0, iter, blk, ua, ub)) {
+        Philox4 r = philox4x32_10(blk, (uint32_t)iter, chain, 0u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
+        ua = u53(r.w[0], r.w[1]); ub = u53(r.w[2], r.w[3]);
+      }
+      cuI0 = ua; cuI1 = ub; cblkI = blk;
     }
     return (k & 1u) ? cuI1 : cuI0;
   }
-  WN_HD double Ur(const Params& prm, uint32_t k) {
+  template <class IO>
+  WN_HD double Ur(const Params& prm, IO& io, uint32_t k) {
     const uint32_t blk = k >> 1;
     if (cblkR != blk) {
-      Philox4 r = philox4x32_10(blk, (uint32_t)iter, chain, 0u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
-      cuR0 = u53(r.w[0], r.w[1]); cuR1 = u53(r.w[2], r.w[3]); cblkR = blk;
+      double ua, ub;
+      if (!io.uniforms(1, iter, blk, ua, ub)) {
+        Philox4 r = philox4x32_10(blk, (uint32_t)iter, chain, 0u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
+        ua = u53(r.w[0], r.w[1]); ub = u53(r.w[2], r.w[3]);
+      }
+      cuR0 = ua; cuR1 = ub; cblkR = blk;
     }
     return (k & 1u) ? cuR1 : cuR0;
   }
-  WN_HD int dir(const Params& prm, int j) {  // WALNUTS.py:216,283: B = floor(uniform(0,2,size=M)); xi = (-1)**B[j]
-    const double u0 = 0.0 + (2.0 - 0.0) * Ui(prm, (uint32_t)j);
+  template <class IO>
+  WN_HD int dir(const Params& prm, IO& io, int j) {  // WALNUTS.py:216,283: B = floor(uniform(0,2,size=M)); xi = (-1)**B[j]
+    const double u0 = 0.0 + (2.0 - 0.0) * Ui(prm, io, (uint32_t)j);
     return ((int)floor(u0) != 0) ? -1 : 1;
   }
-  WN_HD double h_of(const Params& prm, uint32_t k) {  // numpy legacy uniform(low, high) = low + (high-low)*U
+  template <class IO>
+  WN_HD double h_of(const Params& prm, IO& io, uint32_t k) {  // numpy legacy uniform(low, high) = low + (high-low)*U
     const double low = prm.H * (1 - prm.s), high = prm.H * (1 + prm.s);
-    return low + (high - low) * Ui(prm, k);
+    return low + (high - low) * Ui(prm, io, k);
   }
 
   WN_HD void start_doubling_common() {  // WALNUTS.py:283-294
@@ -204,7 +218,7 @@ struct FastBook {
       end_iteration(prm, io);
       return;
     }
-    if (!(Ur(prm, ku++) < WnewSum / WoldSum)) revert_prop();  // :613-616
+    if (!(Ur(prm, io, ku++) < WnewSum / WoldSum)) revert_prop();  // :613-616
     const bool joined = (firemask & 1u) != 0;                // :622
     if (joined) {                                            // :625-634 (lwtSum = 0: never "both ends passive")
       stopCode = 4;
@@ -219,7 +233,7 @@ struct FastBook {
     if (xi > 0) b += nleaf; else a -= nleaf;
     i++;
     if (i == prm.M) { end_iteration(prm, io); return; }
-    const int nxi = dir(prm, i);  // :283
+    const int nxi = dir(prm, io, i);  // :283
     if (nxi != xi) { const double th = Ha; Ha = Hb; Hb = th; xi = nxi; }  // the T waves swapped on OP_SWAP
     start_doubling_common();
     st = ST_RUN;
@@ -258,7 +272,7 @@ struct FastBook {
       pick_state(idx, lpn);
     } else {
       WnewSum += Wnew;
-      if (WnewSum > prm.wtSumThresh && Ur(prm, ku++) < Wnew / WnewSum) pick_state(idx, lpn);  // :426
+      if (WnewSum > prm.wtSumThresh && Ur(prm, io, ku++) < Wnew / WnewSum) pick_state(idx, lpn);  // :426
       orbitLen_ += h;
     }
     Ha = Hn;
@@ -313,19 +327,19 @@ struct FastBook {
           indexStat_ = indexStatOld_ = 0.0; timeLenF_ = timeLenB_ = 0.0;
           cblkI = cblkR = 0xFFFFFFFFu;  // the uniform caches are keyed by block only
           i = 0;
-          xi = dir(prm, 0);
+          xi = dir(prm, io, 0);
           ku = (uint32_t)prm.M;
           start_doubling_common();
           st = ST_FIRST;
         }
       }
     } else if (st == ST_FIRST) {  // the single leaf of doubling 0 (:296-369)
-      const double h = h_of(prm, ku);
+      const double h = h_of(prm, io, ku);
       c.op |= OP_STEP;  // i = 0, n = 0
       c.hs = (double)xi * h;
       ns.kind = K_STEP; ns.n = 0; ns.h = h;
       n_is = 1;
-      swap_next = (1 < prm.M) && dir(prm, 1) != xi;
+      swap_next = (1 < prm.M) && dir(prm, io, 1) != xi;
       st = ST_DRAIN;
     } else if (st == ST_RUN) {
       bool go = true;
@@ -339,7 +353,7 @@ struct FastBook {
             if (WnewSum > prm.wtSumThresh) kh = ku + (uint32_t)inflight;  // their multinomial draws are certain
             else go = false;                                             // not known yet: wait for them
           }
-          if (go) { h = h_of(prm, kh); h2 = h_of(prm, kh + 1u); }        // :395
+          if (go) { h = h_of(prm, io, kh); h2 = h_of(prm, io, kh + 1u); }        // :395
         }
       } else {
         h = h2;
@@ -351,7 +365,7 @@ struct FastBook {
         ns.kind = K_STEP; ns.n = n_is; ns.h = h;
         n_is++;
         if (n_is == nleaf) {
-          swap_next = (i + 1 < prm.M) && dir(prm, i + 1) != xi;
+          swap_next = (i + 1 < prm.M) && dir(prm, io, i + 1) != xi;
           st = ST_DRAIN;
         }
       }

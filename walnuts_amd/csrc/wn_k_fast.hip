@@ -64,7 +64,7 @@ struct FastGeom {
   static constexpr int VECD = NW * NE * 64;   // one D-vector of the 16-chain group in memory (padded to 128 rows)
   static constexpr int REG = KS * 64;         // ... in LDS: [s][lane], s = 4*tile + e < KS (k-steps that hold coordinates)
   static constexpr int DPAD = 16 * NW;
-  static constexpr int MP = 12;               // largest M (sizes the partials)
+  static constexpr int MP = 11;               // largest M (sizes the partials)
   static constexpr int NQ = Q_DOT0 + 2 * (MP + 1);
   static constexpr int NFAST = 2 + NLC;
   static_assert(KS <= 28, "seven tiles of 16 rows");
@@ -75,7 +75,10 @@ struct FastGeom {
   static constexpr int OFF_PART = OFF_LC + NLC * 2 * REG;  // NQ x [tile pair][chain][2]: 16-byte stride between a wave's chains, two tiles per 16-byte read of the bookkeeper
   static constexpr int OFF_CMD = OFF_PART + NQ * 16 * NW;  // 2 x 16 commands of 2 doubles
   static constexpr int OFF_DUMP = OFF_CMD + 2 * 16 * 2;    // 64 doubles nobody reads (see put() of the T waves)
-  static constexpr int LDS_DOUBLES = OFF_DUMP + 64;
+  static constexpr int OFF_RED = OFF_DUMP + 64;            // service wave -> bookkeeper: [chain][lp, KE, initial KE, generated sum, fire words 0..3 (2 doubles)]
+  static constexpr int OFF_RQ = OFF_RED + 16 * 6;          // bookkeeper -> service wave, 2 x [chain][iteration | block I, block R]
+  static constexpr int OFF_SVC = OFF_RQ + 2 * 16 * 2;      // service wave -> bookkeeper, 2 x [chain][4] x {iteration | block, u0, u1}
+  static constexpr int LDS_DOUBLES = OFF_SVC + 2 * 16 * 4 * 3;
   static_assert(LDS_DOUBLES * 8 <= 160 * 1024, "LDS budget (160 KiB per CU)");
   // workspace of one group, in doubles: (M+1) slots x (q, v), 2 proposals, momentum normals [chain][DPAD]
   static constexpr size_t group_doubles(int M) { return (size_t)((M + 1) * 2 + 2) * VECD + (size_t)16 * DPAD; }
@@ -92,6 +95,54 @@ __device__ __forceinline__ double fast_rowsum4(double x) {
   a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
   b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
   return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Service duties of T wave 3 (the wave that shares its SIMD with the bookkeeper and, for D = 100, owns the 4-row tile):
+// what the bookkeeper needs from a tick but any wave can compute.
+//   sums:     before barrier A of tick t, the sums over the tile slots of tick t-1's partials (lp, KE, initial KE,
+//             generated sum: one per lane group) and the U-turn verdicts of that tick's leaf (level j in lane group
+//             j & 3) -- wn_fast.h fire_of.
+//   uniforms: behind the MFMAs of tick t, the Philox blocks the bookkeeper asked for at tick t-1 (the next two of its
+//             issue-side and of its retire-side stream: one block per lane), which it will look up at tick t+1.
+// ------------------------------------------------------------------------------------------------
+template <class G>
+__device__ __forceinline__ void fast_service_sums(double* lds, uint32_t pop, uint32_t pn, double phs) {
+  const int lane = threadIdx.x & 63, cn = lane & 15, lg = lane >> 4;
+  const double* part = lds + G::OFF_PART;
+  auto sum8 = [&](int k) {  // sum of the eight tile partials of one quantity, in tile order
+    typedef double d2r_t __attribute__((ext_vector_type(2)));
+    const d2r_t* r = reinterpret_cast<const d2r_t*>(part + k * 16 * G::NW + cn * 2);  // + tile pair * 16
+    const d2r_t a = r[0], b = r[16], c = r[32], d = r[48];
+    return ((a[0] + a[1]) + (b[0] + b[1])) + ((c[0] + c[1]) + (d[0] + d[1]));
+  };
+  double* red = lds + G::OFF_RED + cn * 6;
+  red[lg] = sum8(lg);  // Q_LP, Q_KE, Q_KEINIT, Q_GEN = 0..3
+  const bool step = (pop & OP_STEP) != 0;
+  const int i = (int)((pop >> OP_I_SHIFT) & 31u), n = (int)pn;
+  const int nchk = step ? nchecks(i, n) : 0;
+  const double xi = phs < 0.0 ? -1.0 : 1.0;  // hs = xi * h
+  uint32_t fire = 0u;
+  for (int j0 = 0; __any(nchk > j0); j0 += 4) {
+    const int j = j0 + lg;
+    const int jr = j <= G::MP ? j : G::MP;  // rows beyond the deepest level are not read
+    const double d1 = sum8(Q_DOT0 + 2 * jr), d2 = sum8(Q_DOT0 + 2 * jr + 1);
+    if (nchk > j && need_check(i, n, j) && ((xi * d1 < 0.0) || (xi * d2 < 0.0))) fire |= (1u << j);
+  }
+  reinterpret_cast<uint32_t*>(red + 4)[lg] = fire;
+}
+template <class G>
+__device__ __forceinline__ void fast_service_uniforms(const Params& prm, double* lds, uint32_t t) {
+  const int lane = threadIdx.x & 63, cn = lane & 15, lg = lane >> 4;
+  const uint32_t* rq = reinterpret_cast<const uint32_t*>(lds + G::OFF_RQ + (t & 1u) * 32 + cn * 2);  // written at tick t-1
+  const uint32_t iter = rq[0], blk = ((lg & 1) ? rq[2] : rq[1]) + (uint32_t)(lg >> 1);
+  const uint32_t chain = prm.chain0 + blockIdx.x * 16 + cn;
+  Philox4 r = philox4x32_10(blk, iter, chain, 0u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
+  double* e = lds + G::OFF_SVC + (t & 1u) * 192 + (cn * 4 + lg) * 3;
+  reinterpret_cast<uint32_t*>(e)[0] = iter;
+  reinterpret_cast<uint32_t*>(e)[1] = blk;
+  e[1] = u53(r.w[0], r.w[1]);
+  e[2] = u53(r.w[2], r.w[3]);
 }
 
 // the two halves of fast_rowsum4, for work that is spread over MFMA gaps
@@ -116,7 +167,7 @@ __device__ __forceinline__ double fast_rowsum4_b(double y) {
 // NEV: registers e < NEV of this wave hold coordinates (k-steps s = 4*tile + e < KS), the rest stay 0.  A template
 // parameter, not a run-time bound: every `e < nev` below is then resolved at compile time, and the phase-2 block of
 // the tick loop stays free of control flow (see there).
-template <int KS, int TK, int NLC, int NEV>
+template <int KS, int TK, int NLC, int NEV, bool SVC>
 __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, const int tile) {
   using G = FastGeom<KS, TK, NLC>;
   constexpr int nev = NEV;
@@ -186,6 +237,8 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, cons
     prow[k * 16 * G::NW] = z;
   };
 
+  uint32_t pop = 0u, pn = 0u;  // last tick's command (service wave)
+  double phs = 0.0;
   WN_FSTAMP_DECL
   for (uint32_t t = 0;; ++t) {
     const int bq_ = G::OFF_Q + (int)(t & 1u) * G::REG, bp_ = G::OFF_Q + (int)((t + 1u) & 1u) * G::REG;  // this tick's / the previous tick's Q buffer
@@ -194,6 +247,7 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, cons
     else c = cmdbuf[(t & 1u) * 16 + cn];
     const uint32_t op = c.op;
     if (__any((op & OP_DONE) != 0)) break;
+    if (SVC && t > 0) fast_service_sums<G>(lds, pop, pn, phs);
     const bool step = (op & OP_STEP) != 0;
     const int i = (int)((op >> OP_I_SHIFT) & 31u), n = (int)c.n;
     const int nchk = step ? nchecks(i, n) : 0;
@@ -260,6 +314,10 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, cons
           keinit_part = kp;
           WN_EV(e) { own[G::OFF_COLD + e * 64] = q[e]; own[G::OFF_COLD + G::REG + e * 64] = v[e]; }
         }
+        // q and v were loaded from memory in here: wait for them HERE.  Left to the compiler, the wait lands on the
+        // common path in front of the half step as s_waitcnt vmcnt(0), which also waits for this tick's prefetches
+        // and for every store still in flight -- on every tick.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
       }
     }
     if (__any((op & OP_SWAP) != 0)) {  // the other end of the orbit becomes the active one (:283-286)
@@ -386,6 +444,7 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, cons
         }
       }
     }
+    if (SVC) { if (t > 0) fast_service_uniforms<G>(prm, lds, t); pop = op; pn = c.n; phs = step ? c.hs : 0.0; }
     WN_FSTAMP(4);
     WN_LDS_BARRIER();  // B
     WN_FSTAMP(5);
@@ -406,6 +465,16 @@ struct FastDevIO {
   uint32_t fire;
   __device__ __forceinline__ double sum(int k) const { return k == Q_LP ? lp : k == Q_KE ? ke : k == Q_KEINIT ? keinit : gen; }
   __device__ __forceinline__ uint32_t firemask(int, int, int) const { return fire; }
+  // the service wave's Philox blocks: entries side, side + 2 = the two next blocks of that stream when they were asked for
+  uint32_t s_it[4], s_blk[4];
+  double s_u0[4], s_u1[4];
+  __device__ __forceinline__ bool uniforms(int side, int iter, uint32_t blk, double& ua, double& ub) const {
+    const bool h0 = side ? (s_it[1] == (uint32_t)iter && s_blk[1] == blk) : (s_it[0] == (uint32_t)iter && s_blk[0] == blk);
+    const bool h1 = side ? (s_it[3] == (uint32_t)iter && s_blk[3] == blk) : (s_it[2] == (uint32_t)iter && s_blk[2] == blk);
+    ua = side ? (h0 ? s_u0[1] : s_u0[3]) : (h0 ? s_u0[0] : s_u0[2]);
+    ub = side ? (h0 ? s_u1[1] : s_u1[3]) : (h0 ? s_u1[0] : s_u1[2]);
+    return h0 || h1;
+  }
   __device__ __forceinline__ void write_gen(size_t row, double v) const {
     if (lg == 0) prm->samples[((size_t)cl * (prm->numIter + 1) + row) * prm->dg + 1] = v;
   }
@@ -438,78 +507,18 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
   FastDevIO io;
   io.prm = &prm; io.cl = cl; io.lg = lg;
   io.lp = io.ke = io.keinit = io.gen = 0.0; io.fire = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { io.s_it[k] = 0u; io.s_blk[k] = 0xFFFFFFFFu; io.s_u0[k] = io.s_u1[k] = 0.0; }
   // tile slots without coordinates (slot 7 = this wave, and the tiles beyond the dimension, whose waves only keep the
   // barriers company) are never written by a T wave: their partials are zero for the whole run.  The T waves write
   // their first partials behind barrier A of tick 0.
   for (int k = lane; k < G::NQ * 16 * G::NW; k += 64) part[k] = 0.0;
-  // Sum of the eight tile partials of one quantity, in tile order.  The four lane groups of a chain work on
-  // DIFFERENT quantities (lg 0..3: lp, KE, initial KE, generated sum; U-turn level j in lane group j & 3) and swap
-  // the results afterwards: one quantity per replica instead of every quantity in every replica.
-  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-  auto sum8 = [&](int k) {
-    typedef double d2r_t __attribute__((ext_vector_type(2)));
-    const d2r_t* r = reinterpret_cast<const d2r_t*>(part + k * 16 * G::NW + cn * 2);  // + tile pair * 16
-    const d2r_t a = r[0], b = r[16], c = r[32], d = r[48];
-    return ((a[0] + a[1]) + (b[0] + b[1])) + ((c[0] + c[1]) + (d[0] + d[1]));
-  };
-  auto swap16d = [&](double x) {  // the value of lane l ^ 16
-    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
-    const u2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const u2_t b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    return (lg & 1) ? __hiloint2double(b[0], a[0]) : __hiloint2double(b[1], a[1]);
-  };
-  auto swap32d = [&](double x) {  // the value of lane l ^ 32
-    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
-    const u2_t a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const u2_t b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    return (lg & 2) ? __hiloint2double(b[0], a[0]) : __hiloint2double(b[1], a[1]);
-  };
   // every chain needs at most numIter * (2^M - 1 + 2 idle ticks per doubling + start) ticks; twice that is an internal error
   const double cap = 256.0 + 2.0 * (double)prm.numIter * ((double)(1u << prm.M) + 4.0 * (double)prm.M + 16.0);
 
   WN_FSTAMP_DECL
   for (uint32_t t = 0;; ++t) {
-    // ---- what tick t-1 left in the partials, before the T waves overwrite them (behind barrier A) ----
-    if (t > 0) {
-      {
-        const double c0 = sum8(lg);  // Q_LP, Q_KE, Q_KEINIT, Q_GEN = 0..3
-        const double c1 = swap16d(c0), c2 = swap32d(c0), c3 = swap32d(c1);  // from lane groups lg^1, lg^2, lg^3
-        io.lp = lg == 0 ? c0 : lg == 1 ? c1 : lg == 2 ? c2 : c3;
-        io.ke = lg == 1 ? c0 : lg == 0 ? c1 : lg == 3 ? c2 : c3;
-        io.keinit = lg == 2 ? c0 : lg == 3 ? c1 : lg == 0 ? c2 : c3;
-        io.gen = lg == 3 ? c0 : lg == 2 ? c1 : lg == 1 ? c2 : c3;
-      }
-      // U-turn verdicts of the leaf being retired (wn_fast.h fire_of): level j0 + lg in lane group lg, then OR
-      const bool live_step = bk.s0.kind == FastBook::K_STEP && !bk.s0.discard;
-      const int nchk = live_step ? nchecks(bk.i, bk.s0.n) : 0;
-      uint32_t fire = 0u;
-      for (int j0 = 0; __any(nchk > j0); j0 += 4) {
-        const int j = j0 + lg;
-        const int jr = j <= G::MP ? j : G::MP;  // rows beyond the deepest level are not read
-        const double d1 = sum8(Q_DOT0 + 2 * jr), d2 = sum8(Q_DOT0 + 2 * jr + 1);
-        if (nchk > j && need_check(bk.i, bk.s0.n, j) && (((double)bk.xi * d1 < 0.0) || ((double)bk.xi * d2 < 0.0))) fire |= (1u << j);
-      }
-      {
-        const u2_t a = __builtin_amdgcn_permlane16_swap(fire, fire, false, false);
-        fire = a[0] | a[1];
-        const u2_t b = __builtin_amdgcn_permlane32_swap(fire, fire, false, false);
-        fire = b[0] | b[1];
-      }
-      io.fire = fire;
-    }
-    WN_FSTAMP(0);
-    WN_LDS_BARRIER();  // A
-    WN_FSTAMP(1);
-    Cmd c = bk.tick(prm, io, t + 1u);
-    WN_FSTAMP(2);
-    bool done = __all(bk.finished());
-    if ((double)t > cap) {  // cannot happen; never hang the GPU
-      if (lane == 0) atomicExch(abort_flag, 1);
-      done = true;
-    }
-    if (done) c.op |= OP_DONE;
-    if (lg == 0) cmdbuf[((t + 1u) & 1u) * 16 + cn] = c;
-    // ---- momentum normals v = normal(size=d) (WALNUTS.py:236, wn_rng.h stream 1) of ONE chain's next
+    // ---- (before barrier A: the service wave is summing tick t-1's partials meanwhile) momentum normals v = normal(size=d) (WALNUTS.py:236, wn_rng.h stream 1) of ONE chain's next
     // iteration per tick: lane L makes elements 2L, 2L+1 (one Philox block, one Box-Muller pair) ----
     {
       const unsigned long long want = __ballot(lg == 0 && bk.zwant != bk.zready && bk.zwant >= 1);
@@ -534,6 +543,35 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // visible to the T waves behind the barrier
       }
     }
+    WN_FSTAMP(0);
+    WN_LDS_BARRIER();  // A
+    WN_FSTAMP(1);
+    if (t > 0) {  // the service wave's sums / verdicts of tick t-1 and its uniforms of tick t-1
+      const double* red = lds + G::OFF_RED + cn * 6;
+      io.lp = red[0]; io.ke = red[1]; io.keinit = red[2]; io.gen = red[3];
+      const uint32_t* fw = reinterpret_cast<const uint32_t*>(red + 4);
+      io.fire = (fw[0] | fw[1]) | (fw[2] | fw[3]);
+      const double* sv = lds + G::OFF_SVC + ((t - 1u) & 1u) * 192 + cn * 12;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        io.s_it[k] = reinterpret_cast<const uint32_t*>(sv + 3 * k)[0]; io.s_blk[k] = reinterpret_cast<const uint32_t*>(sv + 3 * k)[1];
+        io.s_u0[k] = sv[3 * k + 1]; io.s_u1[k] = sv[3 * k + 2];
+      }
+    }
+    Cmd c = bk.tick(prm, io, t + 1u);
+    WN_FSTAMP(2);
+    bool done = __all(bk.finished());
+    if ((double)t > cap) {  // cannot happen; never hang the GPU
+      if (lane == 0) atomicExch(abort_flag, 1);
+      done = true;
+    }
+    if (done) c.op |= OP_DONE;
+    if (lg == 0) cmdbuf[((t + 1u) & 1u) * 16 + cn] = c;
+    // what the service wave is to compute next tick: the next two Philox blocks of both uniform streams
+    if (lg == 0) {
+      uint32_t* rq = reinterpret_cast<uint32_t*>(lds + G::OFF_RQ + ((t + 1u) & 1u) * 32 + cn * 2);
+      rq[0] = (uint32_t)bk.iter; rq[1] = bk.cblkI + 1u; rq[2] = bk.cblkR + 1u;
+    }
     WN_FSTAMP(4);
     WN_LDS_BARRIER();  // B
     WN_FSTAMP(5);
@@ -545,15 +583,23 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
   WN_FSTAMP_OUT(prm)
 }
 
-// a T wave whose tile lies beyond the dimension: it only keeps the barriers company
-template <int KS, int TK, int NLC>
-__device__ __forceinline__ void fast_idle_wave(double* lds) {
+// a T wave whose tile lies beyond the dimension: it only keeps the barriers company (wave 3: and does the service duties)
+template <int KS, int TK, int NLC, bool SVC>
+__device__ __forceinline__ void fast_idle_wave(const Params& prm, double* lds) {
   using G = FastGeom<KS, TK, NLC>;
   const Cmd* cmdbuf = reinterpret_cast<const Cmd*>(lds + G::OFF_CMD);
   const int cn = threadIdx.x & 15;
+  const bool inrange = (int)(blockIdx.x * 16 + cn) < prm.C;
+  uint32_t pop = 0u, pn = 0u;
+  double phs = 0.0;
   for (uint32_t t = 0;; ++t) {
-    if (t > 0 && __any((cmdbuf[(t & 1u) * 16 + cn].op & OP_DONE) != 0)) break;
+    Cmd c;
+    if (t == 0) { c.hs = 0.0; c.op = inrange ? (OP_NEWITER | OP_INIT) : 0u; c.n = 0u; }
+    else c = cmdbuf[(t & 1u) * 16 + cn];
+    if (__any((c.op & OP_DONE) != 0)) break;
+    if (SVC && t > 0) fast_service_sums<G>(lds, pop, pn, phs);
     WN_LDS_BARRIER();  // A
+    if (SVC) { if (t > 0) fast_service_uniforms<G>(prm, lds, t); pop = c.op; pn = c.n; phs = (c.op & OP_STEP) ? c.hs : 0.0; }
     WN_LDS_BARRIER();  // B
   }
 }
@@ -568,9 +614,13 @@ __global__ __launch_bounds__(512) void wn_fast_kernel(Params prm, int* abort_fla
     const int tile = wave < 3 ? wave : (wave == 3 ? 6 : wave - 1);
     constexpr int NEV_LAST = (KS % 4) ? (KS % 4) : 4;  // registers of the tile that holds the last k-steps
     const int nev = KS - 4 * tile;
-    if (nev >= 4) fast_t_wave<KS, TK, NLC, 4>(prm, lds, tile);
-    else if (nev > 0) fast_t_wave<KS, TK, NLC, NEV_LAST>(prm, lds, tile);
-    else fast_idle_wave<KS, TK, NLC>(lds);
+    if (wave == 3) {  // tile 6, and the service duties (fast_service_*)
+      constexpr int NEV3 = KS - 24 >= 4 ? 4 : (KS - 24 > 0 ? KS - 24 : 0);
+      if (NEV3 > 0) fast_t_wave<KS, TK, NLC, (NEV3 > 0 ? NEV3 : 1), true>(prm, lds, tile);
+      else fast_idle_wave<KS, TK, NLC, true>(prm, lds);
+    } else if (nev >= 4) fast_t_wave<KS, TK, NLC, 4, false>(prm, lds, tile);
+    else if (nev > 0) fast_t_wave<KS, TK, NLC, NEV_LAST, false>(prm, lds, tile);
+    else fast_idle_wave<KS, TK, NLC, false>(prm, lds);
   } else {
     fast_b_wave<KS, TK, NLC>(prm, lds, abort_flag);
   }
@@ -579,7 +629,7 @@ __global__ __launch_bounds__(512) void wn_fast_kernel(Params prm, int* abort_fla
 // can the role-split kernel run this launch?  fixedLeapFrog sampling without trace / warm-up / orbit statistics
 bool fast_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm) {
   if (kc.layout != 1 || adapt != 0 || warm || prm.mode != MODE_SAMPLE) return false;
-  if (prm.trace_n || prm.omin || prm.M > 12) return false;
+  if (prm.trace_n || prm.omin || prm.M > 11) return false;
   if (prm.D > 112) return false;  // seven 16-row tiles
   if (kc.p1 == CK_DENSE) return kc.p0 == 25 || kc.p0 == 16;
   return kc.p0 == 16 || kc.p0 == 32;
