@@ -114,6 +114,7 @@ struct FastBook {
   uint32_t cblkI, cblkR;  // cached Philox block of the uniform stream, issue side / retire side
   double cuI0, cuI1, cuR0, cuR1;
   uint32_t chain;  // global chain id
+  double pre_lpn, pre_Hn, pre_Wsum, pre_ratio;  // retire_pre -> retire_step
 
   WN_HD void init(uint32_t chain_global, bool inrange, int numIter) {
     chain = chain_global;
@@ -125,6 +126,7 @@ struct FastBook {
     pend_pick = false; swap_next = false; pick_ip = 0;
     st = inrange ? ST_NEEDITER : ST_DEAD;
     zwant = (inrange && numIter >= 1) ? 1 : 0; zready = 0;
+    pre_lpn = pre_Hn = pre_Wsum = pre_ratio = 0.0;
     s0.clear();
     s1.clear();
     if (inrange) { s1.kind = K_NEWITER; s1.init = true; }  // tick 0: every chain loads q0 (OP_INIT)
@@ -240,10 +242,22 @@ struct FastBook {
   }
 
   // retire the leaf the T waves integrated in the tick whose sums `io` holds (wn_chain.h after_micro + step_done)
+  // The arithmetic of retiring a leaf that needs nothing but the leaf's lp / KE sums and the state the previous tick left:
+  // energy, multinomial weight and the acceptance ratio of the new state.  Split off so that the device's bookkeeper
+  // can do it while the T waves are still in front of their barrier (wn_k_fast.hip); retire_step() takes it from here.
+  template <class IO>
+  WN_HD void retire_pre(const Params& prm, IO& io) {
+    if (!(s0.kind == K_STEP && !s0.discard)) return;
+    pre_lpn = 0.5 * io.sum(Q_LP);              // lp = 1/2 q.g for the Gaussian targets
+    pre_Hn = -pre_lpn + 0.5 * io.sum(Q_KE);    // adaptiveIntegrators.py:55
+    const double Wnew = exp(-pre_Hn + H0 + 0.0);   // lwtSum = 0
+    pre_Wsum = i == 0 ? Wnew : WnewSum + Wnew;     // :322 / :424
+    pre_ratio = Wnew / pre_Wsum;                   // :426
+  }
+
   template <class IO>
   WN_HD void retire_step(const Params& prm, IO& io, const int n, const double h) {
-    const double lpn = 0.5 * io.sum(Q_LP);          // lp = 1/2 q.g for the Gaussian targets
-    const double Hn = -lpn + 0.5 * io.sum(Q_KE);    // adaptiveIntegrators.py:55
+    const double lpn = pre_lpn, Hn = pre_Hn;
     const uint32_t firemask = io.firemask(i, n, xi);  // bit j: U-turn check j of this leaf fired (fire_of)
     const bool first = (i == 0) || ((n & 1) == 0);
     const int idx = xi > 0 ? b + 1 + n : a - 1 - n;
@@ -266,13 +280,11 @@ struct FastBook {
       end_iteration(prm, io);
       return;
     }
-    const double Wnew = exp(-Hn + H0 + 0.0);  // lwtSum = 0
+    WnewSum = pre_Wsum;
     if (i == 0) {  // :322-328, 368-369: unconditional, no uniform
-      WnewSum = Wnew;
       pick_state(idx, lpn);
     } else {
-      WnewSum += Wnew;
-      if (WnewSum > prm.wtSumThresh && Ur(prm, io, ku++) < Wnew / WnewSum) pick_state(idx, lpn);  // :426
+      if (WnewSum > prm.wtSumThresh && Ur(prm, io, ku++) < pre_ratio) pick_state(idx, lpn);  // :426
       orbitLen_ += h;
     }
     Ha = Hn;
@@ -304,6 +316,11 @@ struct FastBook {
   // One bookkeeper tick: retire tick t-1, issue tick t+1.  `tn` = t+1.
   template <class IO>
   WN_HD Cmd tick(const Params& prm, IO& io, uint32_t tn) {
+    retire_pre(prm, io);
+    return tick_post(prm, io, tn);
+  }
+  template <class IO>
+  WN_HD Cmd tick_post(const Params& prm, IO& io, uint32_t tn) {
     if (s0.kind == K_NEWITER) retire_newiter(prm, io, s0.row, s0.init, s0.last);
     else if (s0.kind == K_STEP && !s0.discard) retire_step(prm, io, s0.n, s0.h);
     s0.set(s1);

@@ -117,7 +117,7 @@ __device__ __forceinline__ void fast_service_sums(double* lds, uint32_t pop, uin
     return ((a[0] + a[1]) + (b[0] + b[1])) + ((c[0] + c[1]) + (d[0] + d[1]));
   };
   double* red = lds + G::OFF_RED + cn * 6;
-  red[lg] = sum8(lg);  // Q_LP, Q_KE, Q_KEINIT, Q_GEN = 0..3
+  if (__any((pop & OP_NEWITER) != 0)) red[lg] = sum8(lg);  // lg 2, 3 are read: Q_KEINIT, Q_GEN (the bookkeeper sums Q_LP, Q_KE itself)
   const bool step = (pop & OP_STEP) != 0;
   const int i = (int)((pop >> OP_I_SHIFT) & 31u), n = (int)pn;
   const int nchk = step ? nchecks(i, n) : 0;
@@ -239,6 +239,9 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, cons
 
   uint32_t pop = 0u, pn = 0u;  // last tick's command (service wave)
   double phs = 0.0;
+  double pq0[NE], pv0[NE], pq1[NE], pv1[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) { pq0[e] = pv0[e] = pq1[e] = pv1[e] = 0.0; }
   WN_FSTAMP_DECL
   for (uint32_t t = 0;; ++t) {
     const int bq_ = G::OFF_Q + (int)(t & 1u) * G::REG, bp_ = G::OFF_Q + (int)((t + 1u) & 1u) * G::REG;  // this tick's / the previous tick's Q buffer
@@ -255,9 +258,9 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, cons
     // ---- phase 1: commands ----
     // left endpoints of the first two deep sub-tree levels this leaf closes: requested from memory now, used
     // after the MFMAs (the slots were stored by these same lanes)
-    double pq0[NE], pv0[NE], pq1[NE], pv1[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) { pq0[e] = pv0[e] = pq1[e] = pv1[e] = 0.0; }
+    // (the registers live across ticks and are not cleared: clearing them here costs an s_waitcnt vmcnt(0) at the
+    // top of EVERY tick -- a possibly pending load into them -- which also waits for the previous tick's endpoint
+    // stores.  A lane that loads nothing computes dots from stale values, which its bookkeeper never looks at.)
     const bool deep0 = nchk > NFAST, deep1 = nchk > NFAST + 1;
     if (__any(deep0)) {
       if (deep0) {
@@ -518,7 +521,7 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
 
   WN_FSTAMP_DECL
   for (uint32_t t = 0;; ++t) {
-    // ---- (before barrier A: the service wave is summing tick t-1's partials meanwhile) momentum normals v = normal(size=d) (WALNUTS.py:236, wn_rng.h stream 1) of ONE chain's next
+    // ---- (before barrier A) momentum normals v = normal(size=d) (WALNUTS.py:236, wn_rng.h stream 1) of ONE chain's next
     // iteration per tick: lane L makes elements 2L, 2L+1 (one Philox block, one Box-Muller pair) ----
     {
       const unsigned long long want = __ballot(lg == 0 && bk.zwant != bk.zready && bk.zwant >= 1);
@@ -543,12 +546,25 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // visible to the T waves behind the barrier
       }
     }
+    // ---- still before barrier A (the T waves are busy with their commands and the first half step): the lp and KE
+    // sums over the tile slots of tick t-1's partials (in tile order, as fast_service_sums), and the arithmetic of
+    // retiring that leaf that needs nothing else (energy, exp, acceptance ratio: FastBook::retire_pre) ----
+    if (t > 0) {
+      typedef double d2r_t __attribute__((ext_vector_type(2)));
+      const d2r_t* r = reinterpret_cast<const d2r_t*>(part + cn * 2);  // + quantity * 16 * NW + tile pair * 16
+      const d2r_t a = r[0], b = r[16], c_ = r[32], d = r[48];
+      const d2r_t* r2 = r + (Q_KE * 16 * G::NW) / 2;
+      const d2r_t a2 = r2[0], b2 = r2[16], c2 = r2[32], d2 = r2[48];
+      io.lp = ((a[0] + a[1]) + (b[0] + b[1])) + ((c_[0] + c_[1]) + (d[0] + d[1]));
+      io.ke = ((a2[0] + a2[1]) + (b2[0] + b2[1])) + ((c2[0] + c2[1]) + (d2[0] + d2[1]));
+      bk.retire_pre(prm, io);
+    }
     WN_FSTAMP(0);
     WN_LDS_BARRIER();  // A
     WN_FSTAMP(1);
     if (t > 0) {  // the service wave's sums / verdicts of tick t-1 and its uniforms of tick t-1
       const double* red = lds + G::OFF_RED + cn * 6;
-      io.lp = red[0]; io.ke = red[1]; io.keinit = red[2]; io.gen = red[3];
+      io.keinit = red[2]; io.gen = red[3];
       const uint32_t* fw = reinterpret_cast<const uint32_t*>(red + 4);
       io.fire = (fw[0] | fw[1]) | (fw[2] | fw[3]);
       const double* sv = lds + G::OFF_SVC + ((t - 1u) & 1u) * 192 + cn * 12;
@@ -558,7 +574,7 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
         io.s_u0[k] = sv[3 * k + 1]; io.s_u1[k] = sv[3 * k + 2];
       }
     }
-    Cmd c = bk.tick(prm, io, t + 1u);
+    Cmd c = bk.tick_post(prm, io, t + 1u);
     WN_FSTAMP(2);
     bool done = __all(bk.finished());
     if ((double)t > cap) {  // cannot happen; never hang the GPU
