@@ -662,6 +662,13 @@ int wn_run(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, do
     fprintf(stderr, "[WN_STAMPS] per wave-tick cycles:");
     for (int k = 0; k < 11; ++k) if (k != 6) fprintf(stderr, " %s=%.0f", names[k], tot[k] / tot[6]);
     fprintf(stderr, " ticks/wave=%.0f\n", tot[6] / (nw / 16));
+    {  // the wave that ran longest
+      size_t wmax = 0; double cmax = -1;
+      for (size_t w = 0; w < nw / 16; ++w) { double c = 0; for (int k = 0; k < 16; ++k) if (k != 6) c += (double)h[w * 16 + k]; if (c > cmax) { cmax = c; wmax = w; } }
+      fprintf(stderr, "[WN_STAMPS] longest wave %zu (cycles %.3g):", wmax, cmax);
+      for (int k = 0; k < 16; ++k) fprintf(stderr, " %s=%.0f", k == 6 ? "ticks" : names[k], k == 6 ? (double)h[wmax * 16 + 6] : (double)h[wmax * 16 + k] / (double)h[wmax * 16 + 6]);
+      fprintf(stderr, "\n");
+    }
     return rc;
   }
 #endif

@@ -201,7 +201,10 @@ struct Engine : ChainScalars {
   // The k-th uniform of (chain, iteration) is a pure function of k (wn_rng.h); a window of four
   // Philox blocks is slid forward ONCE per tick, at one code site, so the draws themselves are
   // register selects.  A tick consumes at most 5 uniforms (h pair, R2P, pick, accept) < 7.
+  // (P::LANE_RNG: the layout keeps a window of uniforms of its own -- one chain per wave, 64 Philox blocks at a
+  // time, one per lane -- and next_u() asks it.)
   WN_HD void rng_refill() {
+    if constexpr (P::LANE_RNG) return;
     const uint32_t nb = ku >> 1;
 #pragma unroll 1
     while (p.any(live && ub0 != nb)) {
@@ -216,6 +219,7 @@ struct Engine : ChainScalars {
     }
   }
   WN_HD double next_u() {
+    if constexpr (P::LANE_RNG) return p.uniform(prm, iter, ku++);
     const uint32_t k = ku - 2u * ub0;
     ku++;
     const double a01 = (k & 1u) ? uc[1] : uc[0], a23 = (k & 1u) ? uc[3] : uc[2];
@@ -235,6 +239,11 @@ struct Engine : ChainScalars {
   // ------------------------------------------------------------------------------------------
   WN_HD void start_iteration() {
     Bbits = 0;
+    if constexpr (P::LANE_RNG) {  // :216  B = floor(uniform(0,2,size=M))
+#pragma unroll 1
+      for (uint32_t k = 0; k < (uint32_t)prm.M; ++k)
+        if ((int)floor(0.0 + (2.0 - 0.0) * p.uniform(prm, iter, k)) != 0) Bbits |= (1u << k);
+    } else
 #pragma unroll 1
     for (uint32_t blk = 0; 2u * blk < (uint32_t)prm.M; ++blk) {  // :216  B = floor(uniform(0,2,size=M))
       Philox4 r = philox4x32_10(blk, (uint32_t)iter, p.chain_global(), 0u, (uint32_t)prm.seed,

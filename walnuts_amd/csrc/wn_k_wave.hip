@@ -10,7 +10,8 @@ template <int NE, class Tgt, bool ADAPT, bool WARM, bool FLOW = false, int W = 1
 __global__ __launch_bounds__(64 * W) void wn_wave_kernel(Params prm) {
   using P = WavePolicy<NE, Tgt, W, CL>;
   __shared__ double lds[P::LDS_DOUBLES > 0 ? P::LDS_DOUBLES : 1];
-  P p(prm, blockIdx.x, lds);
+  extern __shared__ double wn_wave_dyn_lds[];  // P::VLDS: the chain's vectors (P::dyn_lds_bytes)
+  P p(prm, blockIdx.x, lds, wn_wave_dyn_lds);
   Engine<P, ADAPT, WARM, FLOW> eng(p, prm);
   eng.run();
 }
@@ -18,17 +19,18 @@ __global__ __launch_bounds__(64 * W) void wn_wave_kernel(Params prm) {
 template <int NE, class Tgt, int W = 1, bool CL = false>
 static hipError_t go(int adapt, bool warm, const Params& prm, hipStream_t st) {
   dim3 grid(CL ? prm.C * prm.cl_g : prm.C), block(64 * W);
+  const size_t dyn = WavePolicy<NE, Tgt, W, CL>::dyn_lds_bytes(prm.M);
   if (adapt == 2) {  // adaptLeapFrogFlowD
-    if (warm) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, true, true, W, CL>), grid, block, 0, st, prm);
-    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false, true, W, CL>), grid, block, 0, st, prm);
+    if (warm) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, true, true, W, CL>), grid, block, dyn, st, prm);
+    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false, true, W, CL>), grid, block, dyn, st, prm);
     return hipGetLastError();
   }
   if (warm) {
-    if (adapt) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, true, false, W, CL>), grid, block, 0, st, prm);
-    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, false, true, false, W, CL>), grid, block, 0, st, prm);
+    if (adapt) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, true, false, W, CL>), grid, block, dyn, st, prm);
+    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, false, true, false, W, CL>), grid, block, dyn, st, prm);
   } else {
-    if (adapt) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false, false, W, CL>), grid, block, 0, st, prm);
-    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, false, false, false, W, CL>), grid, block, 0, st, prm);
+    if (adapt) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false, false, W, CL>), grid, block, dyn, st, prm);
+    else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, false, false, false, W, CL>), grid, block, dyn, st, prm);
   }
   return hipGetLastError();
 }

@@ -42,6 +42,7 @@ struct CoopPolicy {
 #endif
   static constexpr int NLC = NT <= 2 ? WN_COOP_NLC : 0;
   static constexpr int ALIGN_LOG2 = WN_ALIGN_LOG2;  // iteration-start alignment (wn_chain.h run())
+  static constexpr bool LANE_RNG = false;           // uniforms come from the engine's own window (wn_chain.h rng_refill)
   static constexpr int NRED = 4 + 2 * (2 + NLC);
   static constexpr int LDS_Q = KS_MAX * 64;
   static constexpr int LDS_RED = 2 * NRED * W * 16;

@@ -14,6 +14,7 @@ template <int DMAX, class Tgt>
 struct LanePolicy {
   static constexpr int NE = DMAX;
   static constexpr int ALIGN_LOG2 = WN_ALIGN_LOG2;  // iteration-start alignment (wn_chain.h run())
+  static constexpr bool LANE_RNG = false;           // uniforms come from the engine's own window (wn_chain.h rng_refill)
   static constexpr int NLC = 0;  // no fast cache: every sub-tree left endpoint lives in the slot store
   struct Vec {
     double x[DMAX];

@@ -94,6 +94,7 @@ struct WTgtDiag {
   static constexpr int EXT = EXT_NONE;
   double a[NE];
   static constexpr int LDS_DOUBLES = 0;
+  static constexpr int VEC_LDS = 0;
   __device__ __forceinline__ void init(const Params& prm, int l0, double*) {
 #pragma unroll
     for (int e = 0; e < NE; ++e) a[e] = (e * ES + l0) < prm.D ? prm.tpar[e * ES + l0] : 0.0;
@@ -112,6 +113,7 @@ template <int NE, int EXT_>
 struct WTgtExt {
   static constexpr int EXT = EXT_;
   static constexpr int LDS_DOUBLES = 0;
+  static constexpr int VEC_LDS = 0;
   __device__ __forceinline__ void init(const Params&, int, double*) {}
   __device__ __forceinline__ double grad(const double*, double*, int) const { return 0.0; }
   __device__ __forceinline__ static double lp_finish(double r) { return EXT_ == EXT_HALF_QG ? 0.5 * r : r; }
@@ -132,6 +134,7 @@ struct WTgtStockWatson {
   static constexpr int EXT = EXT_NONE;
   static constexpr int TPL = 4;              // time points per lane
   static constexpr int LDS_DOUBLES = 64 * NE;
+  static constexpr int VEC_LDS = 0;
   int T;
   double y[TPL];
   double* lds;
@@ -294,6 +297,7 @@ struct WTgtStockWatson {
 struct WTgtFunnel10 {
   static constexpr int EXT = EXT_NONE;
   static constexpr int LDS_DOUBLES = 0;
+  static constexpr int VEC_LDS = 16;  // D <= 16: the chain's vectors live in LDS, 16 doubles apart (WavePolicy::VLDS)
   __device__ __forceinline__ void init(const Params&, int, double*) {}
   __device__ __forceinline__ static double lp_finish(double r) { return r; }
   __device__ __forceinline__ double grad(const double* q, double* g, int lane) const {
@@ -319,6 +323,7 @@ template <class LaneTgt>
 struct WTgtPair {
   static constexpr int EXT = EXT_NONE;
   static constexpr int LDS_DOUBLES = 0;
+  static constexpr int VEC_LDS = 16;  // D <= 16: the chain's vectors live in LDS, 16 doubles apart (WavePolicy::VLDS)
   __device__ __forceinline__ void init(const Params&, int, double*) {}
   __device__ __forceinline__ static double lp_finish(double r) { return r; }
   __device__ __forceinline__ double grad(const double* q, double* g, int lane) const {
@@ -342,9 +347,17 @@ struct WavePolicy {
   static constexpr int DP = ES * NE_;
   static constexpr int NLC = 0;         // every sub-tree left endpoint lives in the slot store
   static constexpr int ALIGN_LOG2 = 0;  // chains do not share a wave: nothing to align
+  static constexpr bool LANE_RNG = true; // uniform(): 64 Philox blocks at a time, one per lane
   static constexpr int NRED = 8;        // widest reduction (wn_chain.h NPB)
   static_assert(!CL_ || W_ > 1, "the cluster exchange hands results to the waves through the reduction LDS");
   static constexpr int LDS_DOUBLES = Tgt::LDS_DOUBLES + (W_ > 1 ? 2 * NRED * W_ : 0) + (CL_ ? NRED + 1 : 0);
+  // Targets of at most 16 dimensions (one register per vector, lanes 0..15): every vector of the chain -- sub-tree
+  // slots, orbit ends, proposals, the adaptive integrator's saved states -- lives in (dynamic) LDS, VS doubles apart,
+  // instead of the workspace in memory: a tick then waits for no global load (they were a third of its time).
+  static constexpr int VS = Tgt::VEC_LDS;
+  static constexpr bool VLDS = VS > 0 && NE_ == 1 && W_ == 1 && !CL_;
+  typedef __attribute__((address_space(3))) double lds_double;
+  static size_t dyn_lds_bytes(int M) { return VLDS ? nvec(M) * VS * sizeof(double) : 0; }
   struct Vec {
     double x[NE_];
   };
@@ -366,6 +379,10 @@ struct WavePolicy {
   int nslot;
   int redpar;
   double* ldsr;      // cross-wave reduction buffers [2][NRED][W]
+  // uniform(): lane l holds the two uniforms of Philox block rb_base + l of iteration rb_iter (wn_rng.h stream 0)
+  uint32_t rb_iter, rb_base;
+  double ru0, ru1;
+  lds_double* lv;    // VLDS: this chain's vectors in LDS, [vector][VS]
   double* vbase;     // this chain's vectors: [2*nslot + COLD_N + 4 + WARM_N + NPARK][DP]
   ChainScalars* sc;  // this chain's parked scalars
   double *xq, *xg;   // split mode: position out / gradient in, [C][DP]
@@ -377,7 +394,7 @@ struct WavePolicy {
   // workspace doubles for C chains: vectors, then parked scalars
   static size_t work_doubles(int C, int M, int G = 1) { return (size_t)C * (nvec(M) * DP * G + scalar_doubles()); }
 
-  __device__ WavePolicy(const Params& prm, int block, double* lds = nullptr)
+  __device__ WavePolicy(const Params& prm, int block, double* lds = nullptr, double* dyn_lds = nullptr)
       : D(prm.D), lane(threadIdx.x & 63), wave(W_ > 1 ? (int)(threadIdx.x >> 6) : 0), nslot(prm.M + 1), redpar(0) {
     t_start = 0; t_real = 0;
 #if defined(WN_STAMPS)
@@ -401,6 +418,12 @@ struct WavePolicy {
     xg = prm.xg ? prm.xg + (size_t)c * DP + l0 : nullptr;
     xlp = prm.xlp ? prm.xlp + c : nullptr;
     tgt.init(prm, goff + l0, lds);
+    rb_iter = 0xFFFFFFFFu; rb_base = 0u; ru0 = ru1 = 0.0;
+    lv = nullptr;
+    if constexpr (VLDS) {
+      lv = (lds_double*)dyn_lds;
+      for (int k = lane; k < (int)nvec(prm.M) * VS; k += 64) lv[k] = 0.0;
+    }
   }
 
   __device__ __forceinline__ bool valid(int e) const { return goff + e * ES + l0 < D; }
@@ -526,17 +549,39 @@ struct WavePolicy {
     if (CL_) cl_exchange<N, true>(v);
   }
 
+  // k-th uniform of (chain, iteration): the chain's scalars are replicated over the wave, so instead of every lane
+  // running the same Philox block, lane l runs block base + l and the draw is a v_readlane.  One refill per 128
+  // uniforms (the generic window of wn_chain.h costs one block, ~120 instructions, per two).
+  __device__ __forceinline__ double uniform(const Params& prm, int iter, uint32_t k) {
+    const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(k >> 1));
+    const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane(iter);
+    if (it != rb_iter || blk - rb_base >= 64u) {
+      rb_iter = it; rb_base = blk;
+      Philox4 r = philox4x32_10(blk + (uint32_t)lane, it, cg, 0u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
+      ru0 = u53(r.w[0], r.w[1]);
+      ru1 = u53(r.w[2], r.w[3]);
+    }
+    return wn_readlane((k & 1u) ? ru1 : ru0, (int)(blk - rb_base));
+  }
   __device__ __forceinline__ void grad(const Vec& q, Vec& g, double& lp_part) const { lp_part = tgt.grad(q.x, g.x, lane); }
   __device__ __forceinline__ double lp_finish(double r) const { return Tgt::lp_finish(r); }
 
   // ---- memory-resident vectors ------------------------------------------------------------------
   __device__ __forceinline__ double* vp(int v) const { return vbase + (size_t)v * vstride; }
   __device__ __forceinline__ void vput(int v, const Vec& x) const {
+    if constexpr (VLDS) {
+      if (l0 < VS) lv[v * VS + l0] = x.x[0];
+      return;
+    }
     double* d = vp(v);
 #pragma unroll
     for (int e = 0; e < NE; ++e) d[e * ES] = x.x[e];
   }
   __device__ __forceinline__ void vget(int v, Vec& x) const {
+    if constexpr (VLDS) {
+      x.x[0] = l0 < VS ? lv[v * VS + l0] : 0.0;
+      return;
+    }
     const double* s = vp(v);
 #pragma unroll
     for (int e = 0; e < NE; ++e) x.x[e] = s[e * ES];
