@@ -371,9 +371,7 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, cons
     constexpr int NCK = NFAST + 2;
     const bool anychk = __any(nchk > 0);
     if (anychk) {
-      double d1[NCK], d2[NCK];
-#pragma unroll
-      for (int j = 0; j < NCK; ++j) {
+      auto level = [&](int j, double& d1, double& d2) {  // j is a compile-time constant at every call
         double qo[NE], vo[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
@@ -392,14 +390,24 @@ __device__ __forceinline__ void fast_t_wave(const Params& prm, double* lds, cons
           a1 += v[e] * dqe;
           a2 += vo[e] * dqe;
         }
-        d1[j] = a1; d2[j] = a2;
-      }
-      // four quantities per butterfly (put4): (lp, KE, level 0), then two levels each
-      put4(Q_LP, Q_KE, Q_DOT0, Q_DOT0 + 1, pl, pk, d1[0], d2[0]);
+        d1 = a1; d2 = a2;
+      };
+      // four quantities per butterfly (put4): (lp, KE, level 0), then two levels each -- a pair only when some chain of
+      // the group checks that deep at this leaf (the deeper a level, the rarer: the bookkeeper never reads the stale rows)
+      double a1, a2, b1, b2;
+      level(0, a1, a2);
+      put4(Q_LP, Q_KE, Q_DOT0, Q_DOT0 + 1, pl, pk, a1, a2);
 #pragma unroll
-      for (int j = 1; j + 1 < NCK; j += 2)
-        put4(Q_DOT0 + 2 * j, Q_DOT0 + 2 * j + 1, Q_DOT0 + 2 * j + 2, Q_DOT0 + 2 * j + 3, d1[j], d2[j], d1[j + 1], d2[j + 1]);
-      if ((NCK & 1) == 0) { put(Q_DOT0 + 2 * (NCK - 1), d1[NCK - 1]); put(Q_DOT0 + 2 * (NCK - 1) + 1, d2[NCK - 1]); }
+      for (int j = 1; j + 1 < NCK; j += 2) {
+        if (j == 1 || __any(nchk > j)) {
+          level(j, a1, a2); level(j + 1, b1, b2);
+          put4(Q_DOT0 + 2 * j, Q_DOT0 + 2 * j + 1, Q_DOT0 + 2 * j + 2, Q_DOT0 + 2 * j + 3, a1, a2, b1, b2);
+        }
+      }
+      if ((NCK & 1) == 0 && __any(nchk > NCK - 1)) {
+        level(NCK - 1, a1, a2);
+        put(Q_DOT0 + 2 * (NCK - 1), a1); put(Q_DOT0 + 2 * (NCK - 1) + 1, a2);
+      }
     } else {
       put(Q_LP, pl); put(Q_KE, pk);
     }
