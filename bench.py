@@ -424,7 +424,13 @@ def _scaling_fields(dist, world, cdev, value, kernel_ms_avg, units_rank):
 
 def _side_traffic(key, field):
     try:
-        return float(json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_side.json")))[key][field])
+        for name in ("r02_traffic_side.json", "r01_traffic_side.json"):
+            f = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(f):
+                rec = json.load(open(f))
+                if key in rec and field in rec[key]:
+                    return float(rec[key][field])
+        return None
     except Exception:
         return None
 
