@@ -174,9 +174,17 @@ struct alignas(16) ChainScalars {
 // FLOW: adaptLeapFrogFlowD (adaptiveIntegrators.py:246-356) -- the search of adaptLeapFrogD with
 // c = 0..maxC, two gradient evaluations per micro step (new position, then the midpoint of
 // adaptiveIntegrators.py:272) and the flow-error criterion max(Errs) < delta (:294).  Implies ADAPT.
-template <class P, bool ADAPT, bool WARM = false, bool FLOW = false>
+// SPEC >= 0: a plain sampling run with integrator SPEC, known at compile time -- no trace, no orbit statistics, not the
+// one-macro-step mode of wn_integrator_step.  The run-time switches on those cost the funnel kernel a sixth of its
+// instructions and a third of its scalar-register spills (1.33e8 -> 1.57e8 evaluations/s on SURVEY 8d cfg 3).
+template <class P, bool ADAPT, bool WARM = false, bool FLOW = false, int SPEC = -1>
 struct Engine : ChainScalars {
   static_assert(!FLOW || ADAPT, "FLOW implies ADAPT");
+  WN_HD int integ() const { return SPEC >= 0 ? SPEC : prm.integrator; }
+  WN_HD int mode() const { return SPEC >= 0 ? (int)MODE_SAMPLE : prm.mode; }
+  WN_HD int* trace_n() const { return SPEC >= 0 ? nullptr : prm.trace_n; }
+  WN_HD double* omin() const { return SPEC >= 0 ? nullptr : prm.omin; }
+  WN_HD double* omax() const { return SPEC >= 0 ? nullptr : prm.omax; }
   using Vec = typename P::Vec;
   // U-turn checks 0 (full orbit), 1 (leaf pair) and 2..1+NLC (fast-cached sub-tree levels) have
   // their left state on chip; deeper levels are fetched from the slot store in memory.
@@ -322,7 +330,7 @@ struct Engine : ChainScalars {
   // ------------------------------------------------------------------------------------------
   WN_HD void setup_macro() {
     needMacro = false;
-    if (prm.mode == MODE_SAMPLE) {
+    if (mode() == MODE_SAMPLE) {
       if (i == 0) h = draw_h();                // :298
       else if ((n & 1) == 0) { h = draw_h(); h2 = draw_h(); }  // :395 size=2, before the first step
       else h = h2;
@@ -427,10 +435,10 @@ struct Engine : ChainScalars {
     if (ADAPT && ph == PH_BWD) restore_out();
     lpn = ADAPT ? lpOut : lpn;
     Hn = ADAPT ? HOut : Hn;
-    if (prm.integrator == I_ADAPT_D || prm.integrator == I_ADAPT_YOSHIDA || prm.integrator == I_ADAPT_FLOWD) {  // :135-137 / :238-240 / :354-356
+    if (integ() == I_ADAPT_D || integ() == I_ADAPT_YOSHIDA || integ() == I_ADAPT_FLOWD) {  // :135-137 / :238-240 / :354-356
       cret = If;
       lwt = (If != Ib) ? WN_LOGZERO : 0.0;
-    } else if (prm.integrator == I_ADAPT_R2P) {  // :466-475
+    } else if (integ() == I_ADAPT_R2P) {  // :466-475
       double lwtb = WN_LOGZERO;
       if (cSim == Ib) lwtb = prm.logP;
       else if (cSim == Ib + 1) lwtb = prm.log1mP;
@@ -444,7 +452,7 @@ struct Engine : ChainScalars {
   // energy bookkeeping of ONE micro step (adaptiveIntegrators.py:79-84): cheap, so several micro
   // steps of a long pass can run back to back before the heavier per-pass / per-step logic
   WN_HD void micro_account(double lp, double ke) {
-    if (prm.integrator == I_ADAPT_YOSHIDA && sub < 2) {  // adaptiveIntegrators.py:157-167: not yet a full step
+    if (integ() == I_ADAPT_YOSHIDA && sub < 2) {  // adaptiveIntegrators.py:157-167: not yet a full step
       sub++;
       if (ph == PH_BWD) nEvB++; else nEvF++;
       inPass = true;
@@ -546,8 +554,8 @@ struct Engine : ChainScalars {
       else if (c < prm.maxC) { c++; needPass = true; }
       else { If = prm.maxC; done = true; }  // Q5: last computed state is used silently
       if (done) {
-        if (prm.integrator == I_ADAPT_R2P) {
-          double u = (prm.mode == MODE_KAT) ? prm.ku_r2p[p.chain_local()] : next_u();  // :392
+        if (integ() == I_ADAPT_R2P) {
+          double u = (mode() == MODE_KAT) ? prm.ku_r2p[p.chain_local()] : next_u();  // :392
           if (u < prm.R2Pprob0) {  // :393-399, 430-433
             cSim = If; save_out(lp, Hi);
             maxTry = If - 1; Ib = If; lwtf = prm.logP;
@@ -581,7 +589,7 @@ struct Engine : ChainScalars {
     return __builtin_ctz((unsigned)(n + 1));
   }
   WN_HD int nchecks() const {  // number of check indices to evaluate (0 = none)
-    if (!(live && fin) || prm.mode != MODE_SAMPLE) return 0;
+    if (!(live && fin) || mode() != MODE_SAMPLE) return 0;
     int m = 0;
     if (n == nleaf - 1) m = 1;
     if (i >= 1 && (n & 1)) m = ctz_leaf() + 1;
@@ -603,7 +611,7 @@ struct Engine : ChainScalars {
   // dots of the on-chip checks: 0 = passive orbit end, 1 = first state of the leaf pair,
   // 2..NFAST-1 = fast-cached sub-tree left endpoints.  out[2*j], out[2*j+1].
   WN_HD void fast_dots(double* out) {
-    const bool on = live && fin && prm.mode == MODE_SAMPLE;
+    const bool on = live && fin && mode() == MODE_SAMPLE;
 #pragma unroll
     for (int j = 0; j < NFAST; ++j) {
       double d1 = 0.0, d2 = 0.0;
@@ -639,7 +647,7 @@ struct Engine : ChainScalars {
   // ------------------------------------------------------------------------------------------
   // orbitMin/orbitMax[:,iterN-1] = np.minimum/np.maximum(..., generated(q))  (WALNUTS.py:274-276,
   // 331-333, 364-366, 434-436, ...): every lane updates the elements it owns, in memory
-  WN_HD bool orbit_sumsq() const { return prm.omin && prm.generated == G_Q0_SUMSQ; }
+  WN_HD bool orbit_sumsq() const { return omin() && prm.generated == G_Q0_SUMSQ; }
   // generated = [q[0], sum(q*q)] (mainGaussESS.py:29-30): the second component is a sum over all lanes that serve
   // the chain, so it rides in its own reduction right after the gradient (uniform: prm only)
   WN_HD void orbit_sumsq_reduce(const Vec& q) {
@@ -650,7 +658,7 @@ struct Engine : ChainScalars {
     osq_cur = s[0];
   }
   WN_HD void orbit_stats(const Vec& q, bool init) {
-    if (!prm.omin) return;
+    if (!omin()) return;
     const size_t row = ((size_t)p.chain_local() * prm.numIter + (iter - 1)) * prm.dg;
     if (prm.generated == G_Q0_SUMSQ) {
       WN_VFOR(e) if (p.valid(e) && p.owner(e) && p.gidx(e) == 0) orbit_minmax(row, q.x[e], init);
@@ -662,8 +670,8 @@ struct Engine : ChainScalars {
     WN_VFOR(e) if (p.valid(e) && p.owner(e) && p.gidx(e) < k) orbit_minmax(row + p.gidx(e), q.x[e], init);
   }
   WN_HD void orbit_minmax(size_t at, double x, bool init) {
-    double* mn = prm.omin + at;
-    double* mx = prm.omax + at;
+    double* mn = omin() + at;
+    double* mx = omax() + at;
     if (init) { *mn = x; *mx = x; }
     else {
       const double a = *mn, b = *mx;
@@ -687,7 +695,7 @@ struct Engine : ChainScalars {
   }
 
   WN_HD void trace_row() {
-    if (!prm.trace_n) return;
+    if (!trace_n()) return;
     int cl = p.chain_local();
     int row = ntrace++;
     if (prm.trace && row < prm.trace_cap) {
@@ -942,7 +950,7 @@ struct Engine : ChainScalars {
         // orbitMin / orbitMax[:, iterN-1] start at generated(qc) (WALNUTS.py:274-276): iteration gen_iter + 1 starts here
         if (orbit_sumsq() && gen_iter < prm.numIter) {
           const size_t at = ((size_t)p.chain_local() * prm.numIter + gen_iter) * prm.dg + 1;
-          prm.omin[at] = total; prm.omax[at] = total;
+          omin()[at] = total; omax()[at] = total;
         }
       }
       needGen = false;
@@ -1188,7 +1196,7 @@ struct Engine : ChainScalars {
     }
     if (!p.any(live || needGen)) {
       sp_stage = 2;
-      if (prm.trace_n && p.chain_local() < prm.C && p.writer()) prm.trace_n[p.chain_local()] = ntrace;
+      if (trace_n() && p.chain_local() < prm.C && p.writer()) trace_n()[p.chain_local()] = ntrace;
       p.park_scalars(static_cast<const ChainScalars&>(*this));
       return false;
     }
@@ -1204,7 +1212,7 @@ struct Engine : ChainScalars {
       Vec& Q2 = QW(); Vec& V2 = VW(); Vec& G2 = GW();
       const bool act = live && !needIter;
       double hh2 = act ? 0.5 * hh : 0.0, hq = act ? hh : 0.0;
-      if (ADAPT && prm.integrator == I_ADAPT_YOSHIDA && act) {
+      if (ADAPT && integ() == I_ADAPT_YOSHIDA && act) {
         const double w = sub == 1 ? -1.702414383919315 : 1.351207191959658;
         hh2 = 0.5 * w * hh; hq = w * hh;
       }
@@ -1243,10 +1251,10 @@ struct Engine : ChainScalars {
     // q_c = q0; f0, grad0 = lpFun(q0)  (WALNUTS.py:177,249)
     const int cl = inrange ? p.chain_local() : 0;
     {
-      const double* src = prm.mode == MODE_KAT ? prm.kq : prm.q0;
+      const double* src = mode() == MODE_KAT ? prm.kq : prm.q0;
       WN_VFOR(e) qa.x[e] = (p.valid(e) && inrange) ? src[(size_t)cl * prm.D + p.gidx(e)] : 0.0;
     }
-    if (prm.mode == MODE_SAMPLE) {
+    if (mode() == MODE_SAMPLE) {
       double part[1];
       p.grad(qa, ga, part[0]);
       p.template reduce<1>(part);
@@ -1282,7 +1290,7 @@ struct Engine : ChainScalars {
     while (p.any(live || needGen)) {
       WN_STAMP(7);
       // ---- A ----
-      if (live && needIter && (prm.mode != MODE_SAMPLE || (T & ALIGN_MASK) == (1u & ALIGN_MASK))) start_iteration();
+      if (live && needIter && (mode() != MODE_SAMPLE || (T & ALIGN_MASK) == (1u & ALIGN_MASK))) start_iteration();
       T++;
       rng_refill();
       if (live && needDoubling) start_doubling();
@@ -1298,7 +1306,7 @@ struct Engine : ChainScalars {
       do {
         const bool act = live && !needIter && (kin == 0 || inPass);
         double hh2 = act ? 0.5 * hh : 0.0, hq = act ? hh : 0.0;
-        if (ADAPT && prm.integrator == I_ADAPT_YOSHIDA && act) {
+        if (ADAPT && integ() == I_ADAPT_YOSHIDA && act) {
           // 4th-order composition (adaptiveIntegrators.py:143-144): sub-steps firstLast, middle, firstLast
           const double w = sub == 1 ? -1.702414383919315 : 1.351207191959658;
           hh2 = 0.5 * w * hh; hq = w * hh;
@@ -1404,7 +1412,7 @@ struct Engine : ChainScalars {
       WN_STAMP(4);
       // ---- E ----
       if (live && fin) {
-        if (prm.mode == MODE_SAMPLE) step_done();
+        if (mode() == MODE_SAMPLE) step_done();
         else kat_done();
         if (endIter) end_iteration();
       }
@@ -1417,7 +1425,7 @@ struct Engine : ChainScalars {
       for (int k = 0; k < 16; ++k) o[k] = st_[k];
     }
 #endif
-    if (prm.trace_n && inrange && p.writer()) prm.trace_n[p.chain_local()] = ntrace;
+    if (trace_n() && inrange && p.writer()) trace_n()[p.chain_local()] = ntrace;
   }
 
   WN_HD void kat_done() {  // wn_integrator_step: return integratorReturn fields

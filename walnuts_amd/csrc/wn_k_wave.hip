@@ -6,13 +6,13 @@
 
 namespace wn {
 
-template <int NE, class Tgt, bool ADAPT, bool WARM, bool FLOW = false, int W = 1, bool CL = false>
+template <int NE, class Tgt, bool ADAPT, bool WARM, bool FLOW = false, int W = 1, bool CL = false, int SPEC = -1>
 __global__ __launch_bounds__(64 * W) void wn_wave_kernel(Params prm) {
   using P = WavePolicy<NE, Tgt, W, CL>;
   __shared__ double lds[P::LDS_DOUBLES > 0 ? P::LDS_DOUBLES : 1];
   extern __shared__ double wn_wave_dyn_lds[];  // P::VLDS: the chain's vectors (P::dyn_lds_bytes)
   P p(prm, blockIdx.x, lds, wn_wave_dyn_lds);
-  Engine<P, ADAPT, WARM, FLOW> eng(p, prm);
+  Engine<P, ADAPT, WARM, FLOW, SPEC> eng(p, prm);
   eng.run();
 }
 
@@ -20,6 +20,18 @@ template <int NE, class Tgt, int W = 1, bool CL = false>
 static hipError_t go(int adapt, bool warm, const Params& prm, hipStream_t st) {
   dim3 grid(CL ? prm.C * prm.cl_g : prm.C), block(64 * W);
   const size_t dyn = WavePolicy<NE, Tgt, W, CL>::dyn_lds_bytes(prm.M);
+  // the small targets (one register per vector) are tick-latency bound: plain sampling runs of the two integrators the
+  // reference's experiments use on them get an engine with the run-time switches compiled out (Engine SPEC)
+  if constexpr (WavePolicy<NE, Tgt, W, CL>::VLDS) if (adapt == 1 && !warm && prm.mode == MODE_SAMPLE && !prm.trace_n && !prm.omin) {
+    if (prm.integrator == I_ADAPT_R2P) {
+      hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false, false, W, CL, I_ADAPT_R2P>), grid, block, dyn, st, prm);
+      return hipGetLastError();
+    }
+    if (prm.integrator == I_ADAPT_D) {
+      hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false, false, W, CL, I_ADAPT_D>), grid, block, dyn, st, prm);
+      return hipGetLastError();
+    }
+  }
   if (adapt == 2) {  // adaptLeapFrogFlowD
     if (warm) hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, true, true, W, CL>), grid, block, dyn, st, prm);
     else hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false, true, W, CL>), grid, block, dyn, st, prm);
