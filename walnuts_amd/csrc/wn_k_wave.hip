@@ -16,13 +16,16 @@ __global__ __launch_bounds__(64 * W) void wn_wave_kernel(Params prm) {
   eng.run();
 }
 
+template <class T, class = void> struct wave_spec_engine { static constexpr bool value = false; };
+template <class T> struct wave_spec_engine<T, typename std::enable_if<T::SPEC_ENGINE>::type> { static constexpr bool value = true; };
+
 template <int NE, class Tgt, int W = 1, bool CL = false>
 static hipError_t go(int adapt, bool warm, const Params& prm, hipStream_t st) {
   dim3 grid(CL ? prm.C * prm.cl_g : prm.C), block(64 * W);
   const size_t dyn = WavePolicy<NE, Tgt, W, CL>::dyn_lds_bytes(prm.M);
-  // the small targets (one register per vector) are tick-latency bound: plain sampling runs of the two integrators the
+  // the small targets (one register per vector) and StockWatson are tick-latency bound: plain sampling runs of the two integrators the
   // reference's experiments use on them get an engine with the run-time switches compiled out (Engine SPEC)
-  if constexpr (WavePolicy<NE, Tgt, W, CL>::VLDS) if (adapt == 1 && !warm && prm.mode == MODE_SAMPLE && !prm.trace_n && !prm.omin) {
+  if constexpr (WavePolicy<NE, Tgt, W, CL>::VLDS || wave_spec_engine<Tgt>::value) if (adapt == 1 && !warm && prm.mode == MODE_SAMPLE && !prm.trace_n && !prm.omin) {
     if (prm.integrator == I_ADAPT_R2P) {
       hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false, false, W, CL, I_ADAPT_R2P>), grid, block, dyn, st, prm);
       return hipGetLastError();

@@ -135,6 +135,7 @@ struct WTgtStockWatson {
   static constexpr int TPL = 4;              // time points per lane
   static constexpr int LDS_DOUBLES = 64 * NE;
   static constexpr int VEC_LDS = 0;
+  static constexpr bool SPEC_ENGINE = true;  // tick-latency bound: plain sampling runs get the specialised engine (wn_k_wave.hip go())
   int T;
   double y[TPL];
   double* lds;
