@@ -1428,6 +1428,111 @@ struct Engine : ChainScalars {
     if (trace_n() && inrange && p.writer()) trace_n()[p.chain_local()] = ntrace;
   }
 
+  // ------------------------------------------------------------------------------------------
+  // run() for ONE chain per wavefront, adaptive integrators, plain sampling (SPEC >= 0): the same member functions in
+  // the same order, but driven by nested loops -- iteration / doubling / leaf / pass / micro step, as the reference is
+  // written -- instead of one flag-driven tick loop.  The tick form exists so that chains SHARING a wave or a workgroup
+  // stay in lockstep on the gradient; a chain that has its wave to itself only pays for it: every needX flag is
+  // loop-carried state that the compiler keeps as a lane mask and merges with and/andn2/or at every assignment.  Here
+  // the program counter is the state.  Same arithmetic, same reductions, same draw order: bit-identical to run().
+  // ------------------------------------------------------------------------------------------
+  WN_HD void run_nested() {
+    static_assert(ADAPT && !FLOW && !WARM && SPEC >= 0, "run_nested: adaptive integrators, plain sampling");
+    const bool inrange = p.chain_local() < prm.C;
+    init_scalars(inrange);
+    const int cl = inrange ? p.chain_local() : 0;
+    WN_VFOR(e) qa.x[e] = (p.valid(e) && inrange) ? prm.q0[(size_t)cl * prm.D + p.gidx(e)] : 0.0;
+    double part[NPB > 2 * NFAST ? NPB : 2 * NFAST];
+    {  // q_c = q0; f0, grad0 = lpFun(q0)  (WALNUTS.py:177,249)
+      p.grad(qa, ga, part[0]);
+      p.template reduce<1>(part);
+      lpP = p.lp_finish(part[0]);
+      p.prop_put(ip, qa, ga);
+      if (live) {
+        emit_generated(0);  // samples[:,0] = generated(q0)  (:164)
+        if (prm.numIter < 1) live = false; else needIter = true;
+      }
+    }
+    Vec& Q = QW(); Vec& V = VW(); Vec& G = GW();
+    while (p.any(live)) {                // ---- iterations (WALNUTS.py:189) ----
+      start_iteration();
+      for (;;) {                         // ---- doublings (:281) ----
+        if (p.any(needDoubling)) start_doubling();
+        for (;;) {                       // ---- leaves of the doubling: one macro step each ----
+          setup_macro();
+          for (;;) {                     // ---- micro passes of the integrator's searches (adaptiveIntegrators.py:69-132 / 363-464) ----
+            setup_pass();
+            do {                         // ---- one leapfrog micro step (:72-84) ----
+              double hh2 = 0.5 * hh, hq = hh;
+              if (integ() == I_ADAPT_YOSHIDA) {
+                const double w = sub == 1 ? -1.702414383919315 : 1.351207191959658;
+                hh2 = 0.5 * w * hh; hq = w * hh;
+              }
+              WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; Q.x[e] = Q.x[e] + hq * V.x[e]; }
+              p.grad(Q, G, part[0]);
+              double ke = 0.0;
+              WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; ke += V.x[e] * V.x[e]; }
+              part[1] = ke; part[2] = keinit_part; part[3] = gen_part;
+              // the initial kinetic energy / deferred generated() sum ride along only when one is pending
+              if (p.any(needKE || needGen)) p.template reduce<NPB>(part);
+              else p.template reduce<2>(part);
+              finish_generated(part[3]);
+              if (needKE) {  // Hs[I0] = -f0 + 0.5*sum(v**2)  (:256); multinomialLscale (:259)
+                H0 = -lp0 + 0.5 * part[2];
+                Ha = Hb = H0; Ham0 = H0;
+                HamPass0 = H0; allfin = isfinite(H0);
+                Hnan = isnan(H0); Hmin = Hmax = H0;
+                needKE = false; keinit_part = 0.0;
+              }
+              micro_account(p.lp_finish(part[0]), part[1]);
+            } while (p.any(inPass));
+            pass_end();
+            if (!p.any(needPass)) break;
+          }
+          // ---- U-turn checks of the finalised step ----
+          const int nchk = nchecks();
+          firemask = 0;
+          if (p.any(nchk > 0)) {
+            fast_dots(part);
+            p.template reduce<2 * NFAST>(part);
+            fast_fire(part, nchk);
+          }
+          for (int j0 = NFAST; p.any(nchk > j0); j0 += 4) {  // deep sub-tree levels, four checks per reduction
+            double dots[8];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int j = j0 + jj;
+              double d1 = 0.0, d2 = 0.0;
+              if ((nchk > j) && need_check(j)) {
+                Vec qo_, vo_;
+                p.slot_load(slot_of_leaf(n + 1 - (1 << j)), qo_, vo_);
+                uturn_dots(qo_, vo_, d1, d2);
+              }
+              dots[2 * jj] = d1; dots[2 * jj + 1] = d2;
+            }
+            p.template reduce<8>(dots);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int j = j0 + jj;
+              if (nchk > j && need_check(j) &&
+                  (((double)xi * dots[2 * jj] < 0.0) || ((double)xi * dots[2 * jj + 1] < 0.0)))
+                firemask |= (1u << j);
+            }
+          }
+          step_done();                   // NUTS bookkeeping (:296-648); ends the doubling / the iteration when due
+          if (!p.any(needMacro)) break;
+        }
+        if (p.any(endIter)) break;
+      }
+      end_iteration();
+    }
+    if (p.any(needGen)) {  // the deferred generated() sum of the last draw
+      part[0] = 0.0; part[1] = 0.0; part[2] = keinit_part; part[3] = gen_part;
+      p.template reduce<NPB>(part);
+      finish_generated(part[3]);
+    }
+  }
+
   WN_HD void kat_done() {  // wn_integrator_step: return integratorReturn fields
     const int cl = p.chain_local();
     WN_VFOR(e) if (p.valid(e) && p.owner(e)) {

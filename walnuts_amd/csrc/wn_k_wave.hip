@@ -13,7 +13,8 @@ __global__ __launch_bounds__(64 * W) void wn_wave_kernel(Params prm) {
   extern __shared__ double wn_wave_dyn_lds[];  // P::VLDS: the chain's vectors (P::dyn_lds_bytes)
   P p(prm, blockIdx.x, lds, wn_wave_dyn_lds);
   Engine<P, ADAPT, WARM, FLOW, SPEC> eng(p, prm);
-  eng.run();
+  if constexpr (SPEC >= 0 && W == 1 && !CL) eng.run_nested();  // one chain per wave: nested loops instead of the tick loop
+  else eng.run();
 }
 
 template <class T, class = void> struct wave_spec_engine { static constexpr bool value = false; };
