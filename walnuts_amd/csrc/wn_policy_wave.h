@@ -50,6 +50,35 @@ __device__ __forceinline__ double wn_wavesum(double x) {
   return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
 
+// ---- sums of quantities that live in lanes 0..15 only (the <= 16-D targets: WavePolicy::VLDS) ----
+// sum over the row of 16 lanes, in the order of wn_wavesum's first four steps; every lane of a row gets its row's sum
+__device__ __forceinline__ double wn_rowsum16(double x) {
+  x += wn_dpp<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += wn_dpp<0x4E>(x);   // quad_perm [2,3,0,1]
+  x += wn_dpp<0x141>(x);  // row_half_mirror
+  x += wn_dpp<0x140>(x);  // row_mirror
+  return x;
+}
+// [a rows 0,1 | b rows 0,1]
+__device__ __forceinline__ double wn_pack32(double a, double b) {
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  const u2_t l = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+  const u2_t h = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+  return __hiloint2double(h[0], l[0]);
+}
+// [a row 0 | b row 0 | a row 2 | b row 2]
+__device__ __forceinline__ double wn_pack16(double a, double b) {
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  const u2_t l = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+  const u2_t h = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+  return __hiloint2double(h[0], l[0]);
+}
+// the wave sum of a quantity whose rows 1..3 are zero, with wn_wavesum's bits ((s + 0) + (0 + 0)): one row reduction
+__device__ __forceinline__ double wn_rowsum0(double x) {
+  x = wn_rowsum16(x);
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 0), __builtin_amdgcn_readlane(__double2loint(x), 0)) + 0.0;
+}
+
 
 template <int CTRL>
 __device__ __forceinline__ double wn_dpp0(double x) {  // out-of-row sources read as zero
@@ -307,7 +336,7 @@ struct WTgtFunnel10 {
     const double q0 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(q[0])),
                                        __builtin_amdgcn_readfirstlane(__double2loint(q[0])));  // lane 0 holds q_0
     const double emq = exp(-q0);
-    const double ss = wn_wavesum((lane >= 1 && lane < 11) ? q[0] * q[0] : 0.0);
+    const double ss = wn_rowsum0((lane >= 1 && lane < 11) ? q[0] * q[0] : 0.0);
     g[0] = lane == 0 ? (-5.0 - q0 / 9.0 + 0.5 * emq * ss) : (lane < 11 ? -q[0] * emq : 0.0);
     const double lp = (-(q0 * q0) / 18.0 - logC - log3) + (-0.5 * emq * ss - 10.0 * logC - 5.0 * q0);
     // s = np.exp(0.5*q0) overflowing makes the reference's lp -inf (targetDistr.py:75, WALNUTS.py:316)
@@ -495,6 +524,26 @@ struct WavePolicy {
   template <int N>
   __device__ __forceinline__ void reduce(double* v) {
     static_assert(N <= NRED, "reduce width");
+    if constexpr (VLDS) {
+      // Only row 0 (lanes 0..15) holds data.  Four quantities are packed into the four rows of one register (three
+      // permlane swaps), reduced together by ONE row reduction, and read back with v_readlane: 26 instructions for
+      // four sums instead of 72, and the same bits as wn_wavesum gives for a quantity whose rows 1..3 are zero.
+#pragma unroll
+      for (int k0 = 0; k0 < N; k0 += 4) {
+        const int m = N - k0 < 4 ? N - k0 : 4;
+        double r;
+        if (m == 1) r = v[k0];
+        else if (m == 2) r = wn_pack32(v[k0], v[k0 + 1]);
+        else r = wn_pack16(wn_pack32(v[k0], v[k0 + 2]), wn_pack32(v[k0 + 1], v[k0 + (m == 4 ? 3 : 2)]));
+        r = wn_rowsum16(r);
+#pragma unroll
+        for (int k = 0; k < m; ++k) {
+          const int src = m == 2 ? 32 * k : 16 * k;
+          v[k0 + k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(r), src), __builtin_amdgcn_readlane(__double2loint(r), src)) + 0.0;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] = wn_wavesum(v[k]);
     if (W_ > 1) {
