@@ -354,7 +354,7 @@ struct Engine : ChainScalars {
     needPass = false;
     sub = 0;
     nstep = 1 << c;
-    hh = h / (double)nstep;  // adaptiveIntegrators.py:70-71
+    hh = ldexp(h, -c);  // h / 2**c, adaptiveIntegrators.py:70-71 (exact scaling either way: same bits, one instruction instead of a division)
     im = 0;
     if (ph == PH_BWD) {  // :112-118 from (qOut, -vOut, gOut), Hams[0] = H0b
       p.template warm_get<WARM_QO>(qw); p.template warm_get<WARM_VO>(vw); p.template warm_get<WARM_GO>(gw);
@@ -1453,15 +1453,23 @@ struct Engine : ChainScalars {
         if (prm.numIter < 1) live = false; else needIter = true;
       }
     }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) st_[k] = 0;
+    st_last_ = 0;
+#if defined(WN_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    st_last_ = __builtin_readcyclecounter();
+#endif
     Vec& Q = QW(); Vec& V = VW(); Vec& G = GW();
     while (p.any(live)) {                // ---- iterations (WALNUTS.py:189) ----
       start_iteration();
       for (;;) {                         // ---- doublings (:281) ----
         if (p.any(needDoubling)) start_doubling();
         for (;;) {                       // ---- leaves of the doubling: one macro step each ----
+          WN_STAMP(7);
           setup_macro();
           for (;;) {                     // ---- micro passes of the integrator's searches (adaptiveIntegrators.py:69-132 / 363-464) ----
             setup_pass();
+            WN_STAMP(0);
             do {                         // ---- one leapfrog micro step (:72-84) ----
               double hh2 = 0.5 * hh, hq = hh;
               if (integ() == I_ADAPT_YOSHIDA) {
@@ -1486,7 +1494,9 @@ struct Engine : ChainScalars {
               }
               micro_account(p.lp_finish(part[0]), part[1]);
             } while (p.any(inPass));
+            WN_STAMP(1);
             pass_end();
+            WN_STAMP(3);
             if (!p.any(needPass)) break;
           }
           // ---- U-turn checks of the finalised step ----
@@ -1519,13 +1529,22 @@ struct Engine : ChainScalars {
                 firemask |= (1u << j);
             }
           }
+          WN_STAMP(4);
           step_done();                   // NUTS bookkeeping (:296-648); ends the doubling / the iteration when due
+          WN_STAMP(5);
+          st_[6] += 1;
           if (!p.any(needMacro)) break;
         }
         if (p.any(endIter)) break;
       }
       end_iteration();
     }
+#if defined(WN_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+    if (prm.stamps && (threadIdx.x & 63) == 0) {
+      unsigned long long* o = prm.stamps + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
+      for (int k = 0; k < 16; ++k) o[k] = st_[k];
+    }
+#endif
     if (p.any(needGen)) {  // the deferred generated() sum of the last draw
       part[0] = 0.0; part[1] = 0.0; part[2] = keinit_part; part[3] = gen_part;
       p.template reduce<NPB>(part);
