@@ -212,7 +212,7 @@ struct Engine : ChainScalars {
   // (P::LANE_RNG: the layout keeps a window of uniforms of its own -- one chain per wave, 64 Philox blocks at a
   // time, one per lane -- and next_u() asks it.)
   WN_HD void rng_refill() {
-    if constexpr (P::LANE_RNG) return;
+    if constexpr (P::LANE_RNG) { p.rng_ensure(prm, iter, ku); return; }
     const uint32_t nb = ku >> 1;
 #pragma unroll 1
     while (p.any(live && ub0 != nb)) {
@@ -248,6 +248,7 @@ struct Engine : ChainScalars {
   WN_HD void start_iteration() {
     Bbits = 0;
     if constexpr (P::LANE_RNG) {  // :216  B = floor(uniform(0,2,size=M))
+      p.rng_ensure(prm, iter, 0u);  // blocks 0..63 of the new iteration: the M <= 24 direction bits and the first steps
 #pragma unroll 1
       for (uint32_t k = 0; k < (uint32_t)prm.M; ++k)
         if ((int)floor(0.0 + (2.0 - 0.0) * p.uniform(prm, iter, k)) != 0) Bbits |= (1u << k);
@@ -1070,6 +1071,7 @@ struct Engine : ChainScalars {
     p.ext_load_g(gin);
     p.unpark_scalars(static_cast<ChainScalars&>(*this));
     if (sp_stage == 2) return false;
+    rng_refill();  // (P::LANE_RNG: the layout's window of uniforms does not survive the launch boundary)
     keinit_part = p.unpark_partial(keinit_part);
     gen_part = p.unpark_partial(gen_part);
     unpark_late();
@@ -1466,6 +1468,7 @@ struct Engine : ChainScalars {
         if (p.any(needDoubling)) start_doubling();
         for (;;) {                       // ---- leaves of the doubling: one macro step each ----
           WN_STAMP(7);
+          rng_refill();
           setup_macro();
           for (;;) {                     // ---- micro passes of the integrator's searches (adaptiveIntegrators.py:69-132 / 363-464) ----
             setup_pass();

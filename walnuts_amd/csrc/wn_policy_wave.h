@@ -600,18 +600,23 @@ struct WavePolicy {
   }
 
   // k-th uniform of (chain, iteration): the chain's scalars are replicated over the wave, so instead of every lane
-  // running the same Philox block, lane l runs block base + l and the draw is a v_readlane.  One refill per 128
-  // uniforms (the generic window of wn_chain.h costs one block, ~120 instructions, per two).
-  __device__ __forceinline__ double uniform(const Params& prm, int iter, uint32_t k) {
+  // running the same Philox block, lane l runs block base + l and the draw is a v_readlane (the generic window of
+  // wn_chain.h costs one block, ~120 instructions, per two uniforms).  The window is moved at ONE code site per macro
+  // step (rng_ensure, from Engine::rng_refill / start_iteration) -- a step draws at most five uniforms, the window is
+  // kept four blocks ahead -- so the draws themselves carry no refill branch and no second copy of Philox.
+  __device__ __forceinline__ void rng_ensure(const Params& prm, int iter, uint32_t k) {
     const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(k >> 1));
     const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane(iter);
-    if (it != rb_iter || blk - rb_base >= 64u) {
+    if (it != rb_iter || blk - rb_base > 60u) {  // blocks blk .. blk + 3 must be inside [rb_base, rb_base + 64)
       rb_iter = it; rb_base = blk;
       Philox4 r = philox4x32_10(blk + (uint32_t)lane, it, cg, 0u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
       ru0 = u53(r.w[0], r.w[1]);
       ru1 = u53(r.w[2], r.w[3]);
     }
-    return wn_readlane((k & 1u) ? ru1 : ru0, (int)(blk - rb_base));
+  }
+  __device__ __forceinline__ double uniform(const Params&, int, uint32_t k) const {
+    const int l = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)(k >> 1)) - rb_base);
+    return wn_readlane((k & 1u) ? ru1 : ru0, l);
   }
   __device__ __forceinline__ void grad(const Vec& q, Vec& g, double& lp_part) const { lp_part = tgt.grad(q.x, g.x, lane); }
   __device__ __forceinline__ double lp_finish(double r) const { return Tgt::lp_finish(r); }
