@@ -1470,7 +1470,11 @@ struct Engine : ChainScalars {
           WN_STAMP(7);
           rng_refill();
           setup_macro();
-          for (;;) {                     // ---- micro passes of the integrator's searches (adaptiveIntegrators.py:69-132 / 363-464) ----
+          // ---- the integrator's searches, written as the reference writes them (adaptiveIntegrators.py:67-137 /
+          // 363-475) instead of through pass_end()'s phase machine: forward search over c, adaptLeapFrogR2P's draw
+          // and re-integration at c = If+1, backward search from the accepted result ----
+          auto run_pass = [&](const int cc) -> bool {  // one micro pass of 2**cc leapfrog steps from the state `ph` names
+            c = cc;
             setup_pass();
             WN_STAMP(0);
             do {                         // ---- one leapfrog micro step (:72-84) ----
@@ -1498,9 +1502,44 @@ struct Engine : ChainScalars {
               micro_account(p.lp_finish(part[0]), part[1]);
             } while (p.any(inPass));
             WN_STAMP(1);
-            pass_end();
+            // pass complete: all(isfinite(Hams)) and abs(Hams[0]-Hams[-1]) < delta   (:87-94)
+            return allfin && (fabs(HamPass0 - HCur) < dc);
+          };
+          {
+            int cc = cmin();             // forward search (:69-94 / 366-389); ph = PH_FWD from setup_macro()
+            bool ok;
+            for (;;) {
+              ok = run_pass(cc);
+              if (p.any(ok) || cc >= prm.maxC) break;
+              ++cc;
+            }
+            If = ok ? cc : prm.maxC;     // Q5: the last computed state is used silently
+            if (integ() == I_ADAPT_R2P) {
+              const double u = next_u();  // :392
+              if (p.any(u < prm.R2Pprob0)) {  // :393-399, 430-433
+                cSim = If; save_out(lpCur, HCur);
+                maxTry = If - 1; Ib = If; lwtf = prm.logP;
+              } else {                   // :400-424, 434-437: re-integrate at c = If+1
+                ph = PH_FWD2;
+                run_pass(If + 1);
+                cSim = If + 1; save_out(lpCur, HCur);
+                maxTry = prm.maxC; Ib = prm.maxC; lwtf = prm.log1mP;
+              }
+            } else {                     // adaptLeapFrogD :96-111
+              cSim = If; save_out(lpCur, HCur);
+              maxTry = If - 1; Ib = If; lwtf = 0.0;
+            }
+            if (p.any(maxTry >= cmin())) {  // backward search from (qOut, -vOut, gOut)  (:107-132 / 440-464)
+              ph = PH_BWD;
+              for (cc = cmin();; ++cc) {
+                ok = run_pass(cc);
+                if (p.any(ok)) { Ib = cc; break; }
+                if (p.any(cc >= maxTry)) break;
+              }
+            }
+            needPass = false;
+            finalize_macro();            // restores the accepted forward result after backward passes; lwt (:135-137 / 466-475)
             WN_STAMP(3);
-            if (!p.any(needPass)) break;
           }
           // ---- U-turn checks of the finalised step ----
           const int nchk = nchecks();
