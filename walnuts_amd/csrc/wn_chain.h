@@ -735,15 +735,24 @@ struct Engine : ChainScalars {
     }
     if (isnan(Hn)) Hnan = true;
     Hmin = Hn < Hmin ? Hn : Hmin; Hmax = Hn > Hmax ? Hn : Hmax;
-    if (xi > 0) { maxFint = idx; timeLenF_ += h; } else { maxBint = idx; timeLenB_ += h; }
+    {  // select form (a branch on xi is an exec-mask save / restore around two one-line bodies)
+      const bool fw = xi > 0;
+      const double tf = timeLenF_ + h, tb = timeLenB_ + h;
+      maxFint = fw ? idx : maxFint; maxBint = fw ? maxBint : idx;
+      timeLenF_ = fw ? tf : timeLenF_; timeLenB_ = fw ? timeLenB_ : tb;
+    }
     if (i == 0) orbitLen_ += h;  // :300 (before the integrator call)
     if (!isfinite(Hn)) {         // :316-319, 414-417, 457-459 (Q3, Q4)
       if (first) stopCode = 999;
       endIter = true;
       return;
     }
-    if (i == 0) { if (xi > 0) lwtSumf = lwt; else lwtSumb = lwt; }             // :321 / 354
-    else if (first || xi > 0) { if (xi > 0) lwtSumf += lwt; else lwtSumb += lwt; }  // :420,507,550; Q2
+    {  // i == 0: lwtSum = lwt (:321 / 354); else: lwtSum += lwt, on the backward side only at the first leaf of a pair (:420,507,550; Q2)
+      const bool fw = xi > 0, upd = (i == 0) || first || fw;
+      const double nf = (i == 0) ? lwt : lwtSumf + lwt, nb = (i == 0) ? lwt : lwtSumb + lwt;
+      lwtSumf = (upd && fw) ? nf : lwtSumf;
+      lwtSumb = (upd && !fw) ? nb : lwtSumb;
+    }
     const double lwtSum = xi > 0 ? lwtSumf : lwtSumb;
     const double Wnew = exp(-Hn + H0 + lwtSum);
     WN_STAMP(8);
