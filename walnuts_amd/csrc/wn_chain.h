@@ -1526,19 +1526,21 @@ struct Engine : ChainScalars {
             if (integ() == I_ADAPT_R2P) {
               const double u = next_u();  // :392
               if (p.any(u < prm.R2Pprob0)) {  // :393-399, 430-433
-                cSim = If; save_out(lpCur, HCur);
+                cSim = If; lpOut = lpCur; HOut = HCur; osq_out = osq_cur;
                 maxTry = If - 1; Ib = If; lwtf = prm.logP;
               } else {                   // :400-424, 434-437: re-integrate at c = If+1
                 ph = PH_FWD2;
                 run_pass(If + 1);
-                cSim = If + 1; save_out(lpCur, HCur);
+                cSim = If + 1; lpOut = lpCur; HOut = HCur; osq_out = osq_cur;
                 maxTry = prm.maxC; Ib = prm.maxC; lwtf = prm.log1mP;
               }
             } else {                     // adaptLeapFrogD :96-111
-              cSim = If; save_out(lpCur, HCur);
+              cSim = If; lpOut = lpCur; HOut = HCur; osq_out = osq_cur;
               maxTry = If - 1; Ib = If; lwtf = 0.0;
             }
             if (p.any(maxTry >= cmin())) {  // backward search from (qOut, -vOut, gOut)  (:107-132 / 440-464)
+              // (the accepted forward result is the work state itself: it is saved only when backward passes are about to overwrite it)
+              p.template warm_put<WARM_QO>(qw); p.template warm_put<WARM_VO>(vw); p.template warm_put<WARM_GO>(gw);
               ph = PH_BWD;
               for (cc = cmin();; ++cc) {
                 ok = run_pass(cc);
