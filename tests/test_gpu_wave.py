@@ -261,3 +261,40 @@ def test_stockwatson_device_generated_matches_host_form(wa):
     np.testing.assert_allclose(sd, sh, rtol=1e-12, atol=1e-13)
     with pytest.raises(ValueError):
         wa.WALNUTS(td.stdGauss, np.zeros(9), generated=wa.sw_constrain, numIter=1, warmupIter=0)
+
+
+@pytest.mark.parametrize("tk,D,ig,minC", [(ol.T_FUNNEL10, 11, ol.I_ADAPT_R2P, 0), (ol.T_FUNNEL10, 11, ol.I_ADAPT_D, 0),
+                                           (ol.T_FUNNEL10, 11, ol.I_ADAPT_R2P, 2), (ol.T_CORRGAUSS, 2, ol.I_ADAPT_R2P, 0),
+                                           (ol.T_STOCKWATSON, 0, ol.I_ADAPT_D, 3)])
+def test_nested_driver_is_bit_identical_to_the_tick_loop(wa, tk, D, ig, minC):
+    """Plain sampling runs of the one-chain-per-wave kernels go through Engine::run_nested() (nested loops, the
+    integrator's searches written out, specialised engine); a traced run of the same chains goes through the generic
+    tick loop Engine::run().  Same member functions, same reductions, same draw order: every draw and every
+    diagnostics column must agree bit for bit (integer columns and floats alike)."""
+    import torch
+    rng = np.random.default_rng(5)
+    tpar = None
+    C = 37
+    if tk == ol.T_STOCKWATSON:
+        sw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stockwatson_data.npz"))
+        T = int(sw["T"][0]); D = 3 * T
+        tpar = np.concatenate([[float(T)], sw["y"]])
+        q0 = np.zeros((6, D)); C = 6
+        kw = dict(H0=0.1, delta0=0.3, M=8, numIter=3)
+    elif tk == ol.T_FUNNEL10:
+        q0 = np.zeros((C, 11)); q0[:, 0] = 2.0 * rng.normal(size=C); q0[:, 1:] = np.exp(0.5 * q0[:, :1]) * rng.normal(size=(C, 10))
+        kw = dict(H0=0.3, delta0=0.3, M=9, numIter=12)
+    else:
+        q0 = rng.normal(size=(C, D))
+        kw = dict(H0=0.4, delta0=0.1, M=7, numIter=10)
+    outs = []
+    for traced in (False, True):
+        e = wa.Engine(D, C, integrator=ig, H0=kw["H0"], delta0=kw["delta0"], M=kw["M"], minC=minC, chain_offset=123)
+        e.set_target(tk, tpar)
+        assert "wave" in e.kernel_name, e.kernel_name
+        r = e.run(q0, SEED, kw["numIter"], trace_cap=4 if traced else 0)
+        outs.append((r[0].cpu().numpy(), r[1].cpu().numpy()))
+        e.close()
+    np.testing.assert_array_equal(outs[0][1], outs[1][1], err_msg="diagnostics")
+    np.testing.assert_array_equal(outs[0][0], outs[1][0], err_msg="draws")
+    assert outs[0][1][:, :, 6].sum() > 0
