@@ -789,8 +789,7 @@ struct Engine : ChainScalars {
       sub = (firemask & m) != 0;
     }
     n++;
-    if (sub) doubling_end(true);
-    else if (n == nleaf) doubling_end(false);
+    if (sub || n == nleaf) doubling_end(sub);  // (one call site: the function is inlined)
     else needMacro = true;
     WN_STAMP(10);
   }
