@@ -332,9 +332,10 @@ struct Engine : ChainScalars {
   WN_HD void setup_macro() {
     needMacro = false;
     if (mode() == MODE_SAMPLE) {
-      if (i == 0) h = draw_h();                // :298
-      else if ((n & 1) == 0) { h = draw_h(); h2 = draw_h(); }  // :395 size=2, before the first step
-      else h = h2;
+      if (i == 0 || (n & 1) == 0) {            // :298: one draw; :395: size=2, before the first step of a leaf pair
+        h = draw_h();
+        if (i != 0) h2 = draw_h();
+      } else h = h2;
     }
     Ham0 = Ha;  // Hs[] of the neighbouring stored index = energy at the active end (:302,400,443,487,530)
     nEvF = nEvB = 0;
@@ -757,13 +758,14 @@ struct Engine : ChainScalars {
     const double Wnew = exp(-Hn + H0 + lwtSum);
     WN_STAMP(8);
     orbit_stats(QN(), false);
+    bool pick;
     if (i == 0) {  // :322-328, 368-369: unconditional, no uniform
       WnewSum = Wnew;
-      pick_state(idx);
+      pick = true;
     } else {
       WnewSum += Wnew;
       // :426  the uniform is not drawn when the first clause is false
-      if (WnewSum > prm.wtSumThresh && next_u() < Wnew / WnewSum) pick_state(idx);
+      pick = WnewSum > prm.wtSumThresh && next_u() < Wnew / WnewSum;
       orbitLen_ += h;  // :432 / 471 / 519 / 561
       if ((n & 1) == 0) {  // statePush (:431,518) -- only sub-tree left endpoints are ever read back
         p.template warm_put<WARM_QL>(QN()); p.template warm_put<WARM_VL>(VN());
@@ -779,6 +781,7 @@ struct Engine : ChainScalars {
         }
       }
     }
+    if (pick) pick_state(idx);  // (one call site: the function is inlined)
     WN_STAMP(9);
     // the new state becomes the active end (qp/qm = intOut.q ...)
     if (ADAPT) { WN_VFOR(e) { qa.x[e] = QN().x[e]; va.x[e] = VN().x[e]; ga.x[e] = GN().x[e]; } }
