@@ -581,6 +581,10 @@ struct WavePolicy {
   template <int N>
   __device__ __forceinline__ void reduce_max(double* v) {
     static_assert(N <= NRED, "reduce width");
+    if constexpr (VLDS) {  // lanes >= VS hold copies of row-0 elements (vget): they count as the zeros they used to be
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = l0 < VS ? v[k] : 0.0;
+    }
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] = wavemax(v[k]);
     if (W_ > 1) {
@@ -637,7 +641,9 @@ struct WavePolicy {
   }
   __device__ __forceinline__ void vget(int v, Vec& x) const {
     if constexpr (VLDS) {
-      x.x[0] = l0 < VS ? lv[v * VS + l0] : 0.0;
+      // (every lane loads: lanes >= VS get a copy of a row-0 element -- a masked load is an exec save / restore around
+      //  it.  Nothing reads those lanes: stores, global I/O and the reductions of this layout take row 0 only.)
+      x.x[0] = lv[v * VS + (l0 & (VS - 1))];
       return;
     }
     const double* s = vp(v);
