@@ -209,7 +209,7 @@ struct Engine : ChainScalars {
   // The k-th uniform of (chain, iteration) is a pure function of k (wn_rng.h); a window of four
   // Philox blocks is slid forward ONCE per tick, at one code site, so the draws themselves are
   // register selects.  A tick consumes at most 5 uniforms (h pair, R2P, pick, accept) < 7.
-  // (P::LANE_RNG: the layout keeps a window of uniforms of its own -- one chain per wave, 64 Philox blocks at a
+  // (P::LANE_RNG: the layout keeps a window of uniforms of its own -- one chain per wave, 64 uniforms (32 Philox blocks) at a
   // time, one per lane -- and next_u() asks it.)
   WN_HD void rng_refill() {
     if constexpr (P::LANE_RNG) { p.rng_ensure(prm, iter, ku); return; }
@@ -248,7 +248,7 @@ struct Engine : ChainScalars {
   WN_HD void start_iteration() {
     Bbits = 0;
     if constexpr (P::LANE_RNG) {  // :216  B = floor(uniform(0,2,size=M))
-      p.rng_ensure(prm, iter, 0u);  // blocks 0..63 of the new iteration: the M <= 24 direction bits and the first steps
+      p.rng_ensure(prm, iter, 0u);  // uniforms 0..63 of the new iteration: the M <= 24 direction bits and the first steps
 #pragma unroll 1
       for (uint32_t k = 0; k < (uint32_t)prm.M; ++k)
         if ((int)floor(0.0 + (2.0 - 0.0) * p.uniform(prm, iter, k)) != 0) Bbits |= (1u << k);

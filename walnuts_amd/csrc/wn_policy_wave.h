@@ -380,7 +380,7 @@ struct WavePolicy {
   static constexpr int DP = ES * NE_;
   static constexpr int NLC = 0;         // every sub-tree left endpoint lives in the slot store
   static constexpr int ALIGN_LOG2 = 0;  // chains do not share a wave: nothing to align
-  static constexpr bool LANE_RNG = true; // uniform(): 64 Philox blocks at a time, one per lane
+  static constexpr bool LANE_RNG = true; // uniform(): 64 uniforms (32 Philox blocks) at a time, one per lane
   static constexpr int NRED = 8;        // widest reduction (wn_chain.h NPB)
   static_assert(!CL_ || W_ > 1, "the cluster exchange hands results to the waves through the reduction LDS");
   static constexpr int LDS_DOUBLES = Tgt::LDS_DOUBLES + (W_ > 1 ? 2 * NRED * W_ : 0) + (CL_ ? NRED + 1 : 0);
@@ -412,9 +412,9 @@ struct WavePolicy {
   int nslot;
   int redpar;
   double* ldsr;      // cross-wave reduction buffers [2][NRED][W]
-  // uniform(): lane l holds the two uniforms of Philox block rb_base + l of iteration rb_iter (wn_rng.h stream 0)
+  // uniform(): lane l holds uniform 2 * rb_base + l of iteration rb_iter (wn_rng.h stream 0)
   uint32_t rb_iter, rb_base;
-  double ru0, ru1;
+  double ru0;
   lds_double* lv;    // VLDS: this chain's vectors in LDS, [vector][VS]
   double* vbase;     // this chain's vectors: [2*nslot + COLD_N + 4 + WARM_N + NPARK][DP]
   ChainScalars* sc;  // this chain's parked scalars
@@ -451,7 +451,7 @@ struct WavePolicy {
     xg = prm.xg ? prm.xg + (size_t)c * DP + l0 : nullptr;
     xlp = prm.xlp ? prm.xlp + c : nullptr;
     tgt.init(prm, goff + l0, lds);
-    rb_iter = 0xFFFFFFFFu; rb_base = 0u; ru0 = ru1 = 0.0;
+    rb_iter = 0xFFFFFFFFu; rb_base = 0u; ru0 = 0.0;
     lv = nullptr;
     if constexpr (VLDS) {
       lv = (lds_double*)dyn_lds;
@@ -614,16 +614,17 @@ struct WavePolicy {
   __device__ __forceinline__ void rng_ensure(const Params& prm, int iter, uint32_t k) {
     const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(k >> 1));
     const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane(iter);
-    if (it != rb_iter || blk - rb_base > 60u) {  // blocks blk .. blk + 3 must be inside [rb_base, rb_base + 64)
+    if (it != rb_iter || blk - rb_base > 28u) {  // blocks blk .. blk + 3 must be inside [rb_base, rb_base + 32)
       rb_iter = it; rb_base = blk;
-      Philox4 r = philox4x32_10(blk + (uint32_t)lane, it, cg, 0u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
-      ru0 = u53(r.w[0], r.w[1]);
-      ru1 = u53(r.w[2], r.w[3]);
+      // lane l holds uniform 2 * rb_base + l: word pair l & 1 of block rb_base + (l >> 1) (the select is paid here, once
+      // per 56 uniforms, not at every draw)
+      Philox4 r = philox4x32_10(blk + (uint32_t)(lane >> 1), it, cg, 0u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
+      ru0 = (lane & 1) ? u53(r.w[2], r.w[3]) : u53(r.w[0], r.w[1]);
     }
   }
   __device__ __forceinline__ double uniform(const Params&, int, uint32_t k) const {
-    const int l = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)(k >> 1)) - rb_base);
-    return wn_readlane((k & 1u) ? ru1 : ru0, l);
+    const int l = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)k) - 2u * rb_base);
+    return wn_readlane(ru0, l);
   }
   __device__ __forceinline__ void grad(const Vec& q, Vec& g, double& lp_part) const { lp_part = tgt.grad(q.x, g.x, lane); }
   __device__ __forceinline__ double lp_finish(double r) const { return Tgt::lp_finish(r); }
