@@ -1559,7 +1559,9 @@ struct Engine : ChainScalars {
           firemask = 0;
           if (p.any(nchk > 0)) {
             fast_dots(part);
-            p.template reduce<2 * NFAST>(part);
+            // (widths by need: the full-orbit check 0 is due at the last leaf of a doubling only)
+            if (NFAST == 2 && !p.any(need_check(0))) p.template reduce<2>(part + 2);
+            else p.template reduce<2 * NFAST>(part);
             fast_fire(part, nchk);
           }
           for (int j0 = NFAST; p.any(nchk > j0); j0 += 4) {  // deep sub-tree levels, four checks per reduction
@@ -1575,7 +1577,8 @@ struct Engine : ChainScalars {
               }
               dots[2 * jj] = d1; dots[2 * jj + 1] = d2;
             }
-            p.template reduce<8>(dots);
+            if (p.any(nchk > j0 + 2)) p.template reduce<8>(dots);
+            else p.template reduce<4>(dots);  // one or two levels of this group are due
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
               const int j = j0 + jj;
