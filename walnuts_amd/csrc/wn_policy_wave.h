@@ -651,14 +651,22 @@ struct WavePolicy {
 #pragma unroll
     for (int e = 0; e < NE; ++e) x.x[e] = s[e * ES];
   }
-  __device__ __forceinline__ void slot_store(int slot, const Vec& q, const Vec& v) const { vput(2 * slot, q); vput(2 * slot + 1, v); }
+  // two vectors under ONE lane mask (VLDS: a masked store is an exec save / restore around it)
+  __device__ __forceinline__ void vput2(int v1, const Vec& x1, int v2, const Vec& x2) const {
+    if constexpr (VLDS) {
+      if (l0 < VS) { lv[v1 * VS + l0] = x1.x[0]; lv[v2 * VS + l0] = x2.x[0]; }
+      return;
+    }
+    vput(v1, x1); vput(v2, x2);
+  }
+  __device__ __forceinline__ void slot_store(int slot, const Vec& q, const Vec& v) const { vput2(2 * slot, q, 2 * slot + 1, v); }
   __device__ __forceinline__ void slot_load(int slot, Vec& q, Vec& v) const { vget(2 * slot, q); vget(2 * slot + 1, v); }
   __device__ __forceinline__ void lslot_store(int, const Vec&, const Vec&) const {}
   __device__ __forceinline__ void lslot_load(int, Vec&, Vec&) const {}
   template <int K> __device__ __forceinline__ void cold_put(const Vec& x) const { vput(2 * nslot + K, x); }
   template <int K> __device__ __forceinline__ void cold_get(Vec& x) const { vget(2 * nslot + K, x); }
   __device__ __forceinline__ void prop_put(int which, const Vec& q, const Vec& g) const {
-    vput(2 * nslot + COLD_N + 2 * which, q); vput(2 * nslot + COLD_N + 2 * which + 1, g);
+    vput2(2 * nslot + COLD_N + 2 * which, q, 2 * nslot + COLD_N + 2 * which + 1, g);
   }
   __device__ __forceinline__ void prop_get(int which, Vec& q, Vec& g) const {
     vget(2 * nslot + COLD_N + 2 * which, q); vget(2 * nslot + COLD_N + 2 * which + 1, g);
