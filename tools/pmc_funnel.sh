@@ -12,6 +12,6 @@ for f in glob.glob(os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/pmc_funnel
     for r in csv.DictReader(open(f)):
         if 'wn_wave' in r['Kernel_Name']:
             k=r['Counter_Name']; acc[k]=acc.get(k,0)+float(r['Counter_Value'])
-T=4096*21394.0
-for k in sorted(acc): print(f"{k:28s} {acc[k]:.4g}  per tick {acc[k]/T:.1f}")
+E=1.204e8  # gradient evaluations of one launch of the bench workload (4096 chains x 300 iterations)
+for k in sorted(acc): print(f"{k:28s} {acc[k]:.4g}  per evaluation {acc[k]/E:.1f}")
 PY
