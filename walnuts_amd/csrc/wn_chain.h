@@ -1475,6 +1475,17 @@ struct Engine : ChainScalars {
     Vec& Q = QW(); Vec& V = VW(); Vec& G = GW();
     while (p.any(live)) {                // ---- iterations (WALNUTS.py:189) ----
       start_iteration();
+      {  // Hs[I0] = -f0 + 0.5*sum(v**2)  (:256), multinomialLscale (:259), and the deferred generated() sum of the
+         // previous draw: one reduction per iteration here (the tick loop lets them ride on the first micro step's)
+        part[2] = keinit_part; part[3] = gen_part;
+        p.template reduce<2>(part + 2);
+        finish_generated(part[3]);
+        H0 = -lp0 + 0.5 * part[2];
+        Ha = Hb = H0; Ham0 = H0;
+        HamPass0 = H0; allfin = isfinite(H0);
+        Hnan = isnan(H0); Hmin = Hmax = H0;
+        needKE = false; keinit_part = 0.0;
+      }
       for (;;) {                         // ---- doublings (:281) ----
         if (p.any(needDoubling)) start_doubling();
         for (;;) {                       // ---- leaves of the doubling: one macro step each ----
@@ -1498,18 +1509,8 @@ struct Engine : ChainScalars {
               p.grad(Q, G, part[0]);
               double ke = 0.0;
               WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; ke += V.x[e] * V.x[e]; }
-              part[1] = ke; part[2] = keinit_part; part[3] = gen_part;
-              // the initial kinetic energy / deferred generated() sum ride along only when one is pending
-              if (p.any(needKE || needGen)) p.template reduce<NPB>(part);
-              else p.template reduce<2>(part);
-              finish_generated(part[3]);
-              if (needKE) {  // Hs[I0] = -f0 + 0.5*sum(v**2)  (:256); multinomialLscale (:259)
-                H0 = -lp0 + 0.5 * part[2];
-                Ha = Hb = H0; Ham0 = H0;
-                HamPass0 = H0; allfin = isfinite(H0);
-                Hnan = isnan(H0); Hmin = Hmax = H0;
-                needKE = false; keinit_part = 0.0;
-              }
+              part[1] = ke;
+              p.template reduce<2>(part);
               micro_account(p.lp_finish(part[0]), part[1]);
             } while (p.any(inPass));
             WN_STAMP(1);
