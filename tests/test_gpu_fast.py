@@ -137,3 +137,20 @@ def test_fast_one_iteration_and_ragged_groups(wa):
     o = ol.walnuts(ol.T_DENSEGAUSS, q0[18], integrator=ol.I_FIXED, tpar=A.ravel(), H0=0.5, numIter=1, M=5, seed=1, chain=18)
     np.testing.assert_array_equal(s[:, :, 0], q0)
     close(s[18], o["samples"]); close(d[18], o["diagnostics"])
+
+
+def test_fast_result_does_not_depend_on_the_previous_launch(wa):
+    """LDS keeps what the previous kernel on the CU left there.  The bookkeeper reads the service wave's uniform entries
+    of tick 0 (never written) at tick 1; a well-formed entry {iteration 1, block b, u0, u1} left by an EARLIER launch of
+    this kernel (any numIter = 1 run) was taken for the chain's own uniforms when (iteration, block) matched.  The
+    control areas are zeroed at kernel start now: the same problem gives the same bits whatever ran before it."""
+    A, q0 = dense_problem(100, 1e4, 4096)
+    kw = dict(H0=0.5, M=10, generated=ol.G_Q0_SUMSQ, chain_offset=0, numIter=3, seed=SEED)
+    s0, d0, name, _ = run(wa, ol.T_DENSEGAUSS, A, q0, **kw)
+    assert "wn_fast_kernel" in name
+    for rep in range(4):
+        # launches that leave iteration-1 entries of OTHER streams in every CU's LDS
+        run(wa, ol.T_DENSEGAUSS, A, q0, H0=0.5, M=10, generated=ol.G_Q0_SUMSQ, chain_offset=7 + rep, numIter=1, seed=SEED + 1 + rep)
+        s1, d1, _, _ = run(wa, ol.T_DENSEGAUSS, A, q0, **kw)
+        np.testing.assert_array_equal(d1, d0, err_msg=f"diagnostics, repetition {rep}")
+        np.testing.assert_array_equal(s1, s0, err_msg=f"draws, repetition {rep}")

@@ -524,6 +524,11 @@ __device__ __forceinline__ void fast_b_wave(const Params& prm, double* lds, int*
   // barriers company) are never written by a T wave: their partials are zero for the whole run.  The T waves write
   // their first partials behind barrier A of tick 0.
   for (int k = lane; k < G::NQ * 16 * G::NW; k += 64) part[k] = 0.0;
+  // commands, sums, requests and the service wave's uniform entries: LDS keeps what the PREVIOUS kernel on this CU left
+  // there, and an entry {iteration, block, u0, u1} of an earlier launch of this very kernel is well-formed -- the
+  // bookkeeper reads the entries of tick 0 (never written) at tick 1 and would take another run's uniforms for its own
+  // whenever (iteration, block) happened to match (seen once in ~15 full test-suite runs, after a numIter = 1 launch)
+  for (int k = G::OFF_CMD + lane; k < G::LDS_DOUBLES; k += 64) lds[k] = 0.0;
   // every chain needs at most numIter * (2^M - 1 + 2 idle ticks per doubling + start) ticks; twice that is an internal error
   const double cap = 256.0 + 2.0 * (double)prm.numIter * ((double)(1u << prm.M) + 4.0 * (double)prm.M + 16.0);
 
