@@ -25,6 +25,7 @@ struct TSim {  // what the four T waves hold for ONE chain
   std::vector<double> prop[2];
   std::vector<std::vector<double>> lq, lv, sq, sv;  // LDS-cached levels, memory slots
   double sums[4 + 2 * (MAX_M + 2)];
+  int ntr = 0;  // trace rows written (the T wave's own count: wn_k_fast4.hip)
 
   void grad() {
     if (prm->tpar == nullptr) { for (int r = 0; r < D; ++r) g[r] = -q[r]; return; }
@@ -54,6 +55,7 @@ struct TSim {  // what the four T waves hold for ONE chain
     const int NFAST = 2 + NLC;
     for (auto& s : sums) s = 0.0;
     if (c.op & OP_PICK) prop[(c.op & OP_IPPICK) ? 1 : 0] = qhist[t & 1];
+    if (c.op & OP_UNDO) ntr -= 1;  // the leaf in flight when the iteration ended is not an integrator call of the reference
     if (c.op & OP_NEWITER) {
       if (c.op & OP_INIT) {
         for (int e = 0; e < D; ++e) q[e] = prm->q0[(size_t)cl * D + e];
@@ -87,6 +89,11 @@ struct TSim {  // what the four T waves hold for ONE chain
     for (int e = 0; e < D; ++e) { v[e] = v[e] + hs2 * g[e]; lp += q[e] * g[e]; ke += v[e] * v[e]; }
     sums[Q_LP] = lp; sums[Q_KE] = ke;
     if (c.op & OP_STEP) {
+      if (prm->trace && ntr >= 0 && ntr < prm->trace_cap) {
+        double* tr = prm->trace + ((size_t)cl * prm->trace_cap + ntr) * (TRACE_NSCAL + 2 * D) + TRACE_NSCAL;
+        for (int e = 0; e < D; ++e) { tr[e] = q[e]; tr[D + e] = v[e]; }
+      }
+      ntr += 1;
       const int i = (int)((c.op >> OP_I_SHIFT) & 31u), n = (int)c.n;
       const int nchk = nchecks(i, n);
       for (int j = 0; j < nchk; ++j) {
@@ -114,6 +121,14 @@ struct HostIO {
   const Params* prm;
   int cl;
   const double* sums;
+  int* ntrace;
+  void trace_step(int iter, int i, int xi, double h, double ham0, double lpn) {
+    const int row = (*ntrace)++;
+    if (prm->trace && row < prm->trace_cap) {
+      double* r = prm->trace + ((size_t)cl * prm->trace_cap + row) * (TRACE_NSCAL + 2 * prm->D);
+      r[0] = iter; r[1] = i; r[2] = xi; r[3] = h; r[4] = ham0; r[5] = lpn; r[6] = 0; r[7] = 0; r[8] = 0; r[9] = 0.0; r[10] = 1; r[11] = 0;
+    }
+  }
   double sum(int k) const { return sums[k]; }
   void dots(int j, double& d1, double& d2) const { d1 = sums[Q_DOT0 + 2 * j]; d2 = sums[Q_DOT0 + 2 * j + 1]; }
   uint32_t firemask(int i, int n, int xi) const { return fire_of(i, n, xi, *this); }
@@ -145,6 +160,7 @@ extern "C" long fastsim_run(Params* prm, int target, int nlc, double* idle_frac)
     double psums[4 + 2 * (MAX_M + 2)] = {0};
     const double cap = 64.0 + 1.3 * (double)prm->numIter * ((double)(1u << prm->M) + 4.0 * prm->M + 16.0);
     uint32_t t = 0;
+    int ntrace = 0;
     for (;; ++t) {
       if ((double)t > cap) return -1;
       // momentum normals: the B wave refills the buffer of a chain whose next iteration has none yet
@@ -152,7 +168,7 @@ extern "C" long fastsim_run(Params* prm, int target, int nlc, double* idle_frac)
         for (int e = 0; e < D; ++e) T.zn[e] = rng_normal(prm->seed, B.chain, (uint32_t)B.zwant, (uint32_t)e);
         B.zready = B.zwant;
       }
-      HostIO io{prm, cl, psums};
+      HostIO io{prm, cl, psums, &ntrace};
       nxt = B.tick(*prm, io, t + 1);  // retires tick t-1, issues tick t+1
       T.tick(t, cur);                 // tick t
       memcpy(psums, T.sums, sizeof(psums));
@@ -160,6 +176,7 @@ extern "C" long fastsim_run(Params* prm, int target, int nlc, double* idle_frac)
       cur = nxt;
       if (B.finished()) break;
     }
+    if (prm->trace_n) prm->trace_n[cl] = ntrace;
     ticks += t + 1;
     if ((long)t + 1 > worst) worst = t + 1;
   }

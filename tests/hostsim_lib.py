@@ -125,7 +125,7 @@ def fast_lib():
 
 
 def fast_walnuts(target, q0, tpar=None, H0=0.2, stepSizeRandScale=0.2, delta0=0.05, numIter=10, M=10, generated=0, gen_k=0,
-                 seed=0, chain0=0, nlc=2):
+                 seed=0, chain0=0, nlc=2, trace_cap=0):
     """fixedLeapFrog on a std / diagonal / dense Gaussian through FastBook + the scalar T-wave stand-in."""
     q0 = np.ascontiguousarray(np.atleast_2d(np.asarray(q0, float)))
     Cn, D = q0.shape
@@ -141,8 +141,14 @@ def fast_walnuts(target, q0, tpar=None, H0=0.2, stepSizeRandScale=0.2, delta0=0.
     tp = np.ascontiguousarray(np.asarray(tpar, float)) if tpar is not None else None
     samples = np.zeros((Cn, numIter + 1, dg)); diag = np.zeros((Cn, numIter, 24))
     prm.q0 = _p(q0); prm.samples = _p(samples); prm.diag = _p(diag); prm.tpar = _p(tp)
+    trace = tn = None
+    if trace_cap:
+        trace = np.zeros((Cn, trace_cap, 12 + 2 * D)); tn = np.zeros(Cn, dtype=np.int32)
+        prm.trace = _p(trace); prm.trace_cap = trace_cap
+        prm.trace_n = _p(tn, ip)
     idle = C.c_double(0.0)
     ticks = fast_lib().fastsim_run(C.byref(prm), target, nlc, C.byref(idle))
     if ticks < 0:
         raise RuntimeError("fastsim: a chain exceeded its tick bound")
-    return dict(samples=samples.transpose(0, 2, 1).copy(), diagnostics=diag, ticks=ticks, idle_frac=idle.value)
+    return dict(samples=samples.transpose(0, 2, 1).copy(), diagnostics=diag, ticks=ticks, idle_frac=idle.value,
+                trace=trace, trace_n=tn)

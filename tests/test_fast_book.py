@@ -91,3 +91,24 @@ def test_bookkeeper_config2_shape_many_chains():
         o = ol.walnuts(ol.T_DENSEGAUSS, q0[k], integrator=ol.I_FIXED, tpar=A.ravel(), chain=k, **kw)
         check(h, o, k)
     assert h["idle_frac"] < 0.06  # two idle ticks per doubling + one per iteration start
+
+
+@pytest.mark.parametrize("M,scale", [(6, 1.0), (3, 1.0), (8, 3e153)])
+def test_bookkeeper_trace_rows_match_the_oracle(M, scale):
+    """Traced runs of the pair kernel (wn_k_fast4.hip): the T wave writes (q', v') of every leaf it integrates at its own
+    row count and takes the row back on OP_UNDO (the leaf in flight when a sub-U-turn / non-finite energy ended the
+    iteration); the bookkeeper writes the row's scalars when it retires the leaf.  Row for row the oracle's trace
+    (one row per integrator call of the reference, adaptiveIntegrators.py:49-59)."""
+    rng = np.random.default_rng(5 + M)
+    D = 6
+    lam = np.logspace(0, 2, D)
+    q0 = rng.normal(size=(3, D)) * np.sqrt(lam) * scale
+    kw = dict(H0=0.45, numIter=7, M=M, generated=0, seed=123 + M)
+    h = hs.fast_walnuts(ol.T_DIAGGAUSS, q0, tpar=1.0 / lam, chain0=9, trace_cap=2000, **kw)
+    for k in range(3):
+        o = ol.walnuts(ol.T_DIAGGAUSS, q0[k], integrator=ol.I_FIXED, tpar=1.0 / lam, chain=9 + k, trace_cap=2000, **kw)
+        n = o["ncalls"]
+        assert h["trace_n"][k] == n
+        cols = [0, 1, 2, 6, 7, 8, 10, 11]
+        np.testing.assert_array_equal(h["trace"][k, :n][:, cols], o["trace"][:n][:, cols])
+        tg.close(h["trace"][k, :n], o["trace"][:n], rtol=1e-10, atol=1e-12)

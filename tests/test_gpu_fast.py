@@ -62,7 +62,7 @@ def test_fast_dense_matches_oracle(wa, D, C, M, gen):
     A, q0 = dense_problem(D, 1e3, C)
     kw = dict(H0=0.5, M=M, generated=gen, gen_k=3 if gen == ol.G_FIRSTK else 0, chain_offset=11, numIter=5, seed=SEED + D)
     s, d, name, _ = run(wa, ol.T_DENSEGAUSS, A, q0, **kw)
-    assert "wn_fast_kernel" in name and "dense" in name, name
+    assert "wn_fast4_kernel" in name and "dense" in name, name
     for k in sorted({0, C - 1, C // 2, min(15, C - 1), min(16, C - 1)}):
         o = ol.walnuts(ol.T_DENSEGAUSS, q0[k], integrator=ol.I_FIXED, tpar=A.ravel(), H0=0.5, numIter=5, M=M, seed=SEED + D,
                        chain=11 + k, generated=gen, gen_k=kw["gen_k"])
@@ -97,7 +97,7 @@ def test_fast_equals_one_stream_kernel_at_baseline_size(wa):
     kw = dict(H0=0.5, M=10, generated=ol.G_Q0_SUMSQ, chain_offset=0, numIter=12, seed=SEED)
     s, d, name, ms = run(wa, ol.T_DENSEGAUSS, A, q0, **kw)
     s1, d1, name1, ms1 = run(wa, ol.T_DENSEGAUSS, A, q0, legacy=True, **kw)
-    assert "wn_fast_kernel" in name and "wn_coop_kernel" in name1, (name, name1)
+    assert "wn_fast4_kernel" in name and "wn_coop_kernel" in name1, (name, name1)
     for col in INT_DIAG:
         np.testing.assert_array_equal(d[:, :, col], d1[:, :, col], err_msg=f"diag col {col}")
     close(d, d1, rtol=1e-9, atol=1e-10, what="diagnostics vs one-stream kernel")
@@ -147,7 +147,7 @@ def test_fast_result_does_not_depend_on_the_previous_launch(wa):
     A, q0 = dense_problem(100, 1e4, 4096)
     kw = dict(H0=0.5, M=10, generated=ol.G_Q0_SUMSQ, chain_offset=0, numIter=3, seed=SEED)
     s0, d0, name, _ = run(wa, ol.T_DENSEGAUSS, A, q0, **kw)
-    assert "wn_fast_kernel" in name
+    assert "wn_fast4_kernel" in name
     for rep in range(4):
         # launches that leave iteration-1 entries of OTHER streams in every CU's LDS
         run(wa, ol.T_DENSEGAUSS, A, q0, H0=0.5, M=10, generated=ol.G_Q0_SUMSQ, chain_offset=7 + rep, numIter=1, seed=SEED + 1 + rep)

@@ -315,7 +315,7 @@ def test_kernel_names_are_per_engine_and_failed_set_target_leaves_no_target(wa):
     fails after the previous target was released leaves the engine without a target instead of the old kernel."""
     first = wa.Engine(100, 16).set_target(ol.T_DENSEGAUSS, np.eye(100).ravel())
     name0 = first.kernel_name
-    assert "wn_fast_kernel" in name0 and "dense" in name0
+    assert "wn_fast4_kernel" in name0 and "dense" in name0
     others = [wa.Engine(11, 4, integrator=ol.I_ADAPT_R2P).set_target(ol.T_FUNNEL10) for _ in range(12)]
     assert first.lib.wn_kernel_name(first.h).decode() == name0
     assert all("funnel10" in o.kernel_name for o in others)

@@ -205,7 +205,7 @@ def test_lane_layout_on_request_and_by_chain_count(wa, tk, D):
             close(s[k], o["samples"], what=f"lane D={D} ig={ig} chain {k}")
     big = wa.Engine(D, 8192, integrator=ol.I_FIXED, H0=0.7, M=4).set_target(tk, tpar)
     small = wa.Engine(D, 4096, integrator=ol.I_FIXED, H0=0.7, M=4).set_target(tk, tpar)
-    assert "lane" in big.kernel_name and ("coop" in small.kernel_name or "wn_fast_kernel" in small.kernel_name)
+    assert "lane" in big.kernel_name and ("coop" in small.kernel_name or "wn_fast" in small.kernel_name)
     big.close(); small.close()
 
 

@@ -150,7 +150,7 @@ size_t kernel_work_doubles(const KernelChoice& kc, int C, int M) {
   // the role-split kernel of the same layout (wn_k_fast.hip) pads every vector to 8 tiles x 4 registers x 64 lanes
   // whatever the dimension: (M+1) slots x (q, v) + 2 proposals + the momentum normals per 16-chain group
   const size_t fast = (((size_t)C + 15) / 16) * (size_t)((M + 1) * 2 + 3) * 2048;
-  return std::max(coop_work_doubles(NT, kc.W, C, M), fast);
+  return std::max(std::max(coop_work_doubles(NT, kc.W, C, M), fast), fast4_work_doubles(C, M));
 }
 
 // sw_innov.stan:7-51, scalar form (wn_lpfun only; the sampler evaluates WTgtStockWatson in the wave kernel)
@@ -458,6 +458,9 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
     const int NT = kc.p0 <= 16 ? 1 : 2;
     snprintf(kc.name, sizeof(kc.name), "wn_fast_kernel<KS=%d,%s>", (kc.p1 != CK_DENSE && kc.p0 == 32) ? 28 : kc.p0, kc.p1 == CK_DENSE ? "dense" : "diag");
     (void)NT;
+    if (kc.p1 == CK_DENSE && D <= 100 && !getenv("WN_FAST_LEGACY"))  // dense, D <= 100: wave pairs of four chains (wn_k_fast4.hip), traced runs too
+      snprintf(kc.name, sizeof(kc.name), "wn_fast4_kernel<NS=%d%s,dense,pairs=%d>", D <= 32 ? 2 : D <= 64 ? 4 : D <= 96 ? 6 : 7, D > 96 ? ",tail" : "",
+               fast4_pairs(e->cfg.n_chains));
   }
   e->kc = kc;
   e->have_kc = true;
@@ -592,7 +595,9 @@ static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
   }
   const Params& p_ = pc;
   const bool coop_legacy = getenv("WN_COOP_LEGACY") != nullptr;  // diagnostic / A-B tests: one-stream kernel (read per launch)
-  hipError_t r = (!coop_legacy && fast_eligible(e->kc, adapt, warm, p_)) ? launch_fast(e->kc, p_, e->kabort, st)
+  const bool fast_legacy = getenv("WN_FAST_LEGACY") != nullptr;  // diagnostic / A-B tests: the seven-T-wave kernel for dense targets too
+  hipError_t r = (!coop_legacy && !fast_legacy && fast4_eligible(e->kc, adapt, warm, p_)) ? launch_fast4(e->kc, p_, e->kabort, st)
+               : (!coop_legacy && fast_eligible(e->kc, adapt, warm, p_)) ? launch_fast(e->kc, p_, e->kabort, st)
                : e->kc.layout == 0 ? launch_lane(e->kc, adapt, warm, p_, st)
                : e->kc.layout == 1 ? launch_coop(e->kc, adapt, warm, p_, st) : launch_wave(e->kc, adapt, warm, p_, st);
   if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
@@ -646,6 +651,20 @@ int wn_run(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, do
     for (size_t w = 0; w < nw / 16; ++w) for (int k = 0; k < 16; ++k) tot[k] += (double)h[w * 16 + k];
     const char* names[16] = {"A_setup", "B_leapfrog+grad", "B_ke+reduce", "C_after_micro", "D_uturn", "E_rest", "ticks", "loop_head",
                              "E_to_exp", "E_pick+stores", "E_doubling_end", "", "", "", "", ""};
+    if (strstr(e->kc.name, "wn_fast4_kernel")) {  // rows: up to 8 waves per workgroup (T waves 0..pairs-1, then the B waves)
+      const int pairs = fast4_pairs(p.C);
+      const size_t groups = ((size_t)(p.C + 3) / 4 + pairs - 1) / pairs;
+      for (int w = 0; w < 2 * pairs; ++w) {
+        double a[8] = {0};
+        for (size_t gI = 0; gI < groups; ++gI) for (int k = 0; k < 8; ++k) a[k] += (double)h[(gI * 8 + w) * 16 + k];
+        if (a[6] <= 0) continue;
+        if (w < pairs) fprintf(stderr, "[WN_STAMPS fast4] T wave %d cycles/tick: commands+halfstep=%.0f mfma=%.0f halfstep+checks+sums=%.0f stores=%.0f wait=%.0f (ticks %.0f)\n",
+                               w, a[0] / a[6], a[1] / a[6], a[2] / a[6], a[3] / a[6], a[4] / a[6], a[6] / groups);
+        else fprintf(stderr, "[WN_STAMPS fast4] B wave %d cycles/tick: normals+window=%.0f sums+verdicts=%.0f bookkeeper=%.0f command=%.0f wait=%.0f\n",
+                     w - pairs, a[0] / a[6], a[1] / a[6], a[2] / a[6], a[3] / a[6], a[4] / a[6]);
+      }
+      return rc;
+    }
     if (strstr(e->kc.name, "wn_fast_kernel")) {  // rows: 8 waves per 16-chain group (T waves 0..6, B wave 7)
       const size_t groups = (size_t)(p.C + 15) / 16;
       for (int w = 0; w < 8; ++w) {

@@ -49,6 +49,8 @@ enum {
   OP_IPPICK = 64u,   // bit: ippick
   OP_IPNEW = 128u,   // bit: ipnew
   OP_I_SHIFT = 8,    // bits 8..12: doubling index i of an OP_STEP (n = leaf index inside the doubling)
+  OP_UNDO = 1u << 14, // traced runs: the leaf that was in flight when the iteration ended is not an integrator call of the
+                     // reference -- the T wave takes its trace row back
   OP_DONE = 1u << 15 // every chain of the group has finished: all waves leave the tick loop
 };
 struct alignas(16) Cmd {
@@ -107,7 +109,7 @@ struct FastBook {
   int iter, i, xi, a, b, nleaf, n_rt, n_is;
   uint32_t ku;
   int nevalF, L_, Lold_, NdS, NdC, maxFint, maxBint, stopCode, ip, ipl;
-  bool Hnan, pend_pick, swap_next;
+  bool Hnan, pend_pick, swap_next, undo;
   int pick_ip, st;
   int zwant, zready;  // momentum normals: iteration wanted next / iteration the buffer holds
   Slot s0, s1;
@@ -123,7 +125,7 @@ struct FastBook {
     Hmin = INFINITY; Hmax = -INFINITY; Hnan = false;
     iter = 1; i = 0; xi = 1; a = b = 0; nleaf = 1; n_rt = n_is = 0; ku = 0;
     nevalF = L_ = Lold_ = NdS = NdC = maxFint = maxBint = stopCode = 0; ip = ipl = 0;
-    pend_pick = false; swap_next = false; pick_ip = 0;
+    pend_pick = false; swap_next = false; undo = false; pick_ip = 0;
     st = inrange ? ST_NEEDITER : ST_DEAD;
     zwant = (inrange && numIter >= 1) ? 1 : 0; zready = 0;
     pre_lpn = pre_Hn = pre_Wsum = pre_ratio = 0.0;
@@ -206,7 +208,7 @@ struct FastBook {
     d[23] = indexStat_;
     io.write_diag((size_t)(iter - 1), d);
     iter++;
-    if (s1.kind == K_STEP) s1.discard = true;  // the leaf in flight belongs to the orbit that just ended
+    if (s1.kind == K_STEP) { s1.discard = true; undo = true; }  // the leaf in flight belongs to the orbit that just ended
     swap_next = false;
     st = ST_NEEDITER;
   }
@@ -261,6 +263,7 @@ struct FastBook {
     const uint32_t firemask = io.firemask(i, n, xi);  // bit j: U-turn check j of this leaf fired (fire_of)
     const bool first = (i == 0) || ((n & 1) == 0);
     const int idx = xi > 0 ? b + 1 + n : a - 1 - n;
+    io.trace_step(iter, i, xi, h, Ha, lpn);  // one row per integrator call (traced runs; Ham0 = the neighbouring state's Hamiltonian)
     if (i == 0) ku += 1;                 // :298  the step size was drawn before the step
     else if ((n & 1) == 0) ku += 2;      // :395  size=2, before the first step of the pair
     nevalF += 1;
@@ -329,6 +332,7 @@ struct FastBook {
     Cmd c;
     c.hs = 0.0; c.op = 0u; c.n = 0u;
     if (pend_pick) { c.op |= OP_PICK | (pick_ip ? OP_IPPICK : 0u); pend_pick = false; }
+    if (undo) { c.op |= OP_UNDO; undo = false; }
     const bool odd = (tn & 1u) != 0;
     if (st == ST_NEEDITER) {
       if (odd && (iter > prm.numIter || zready == iter)) {

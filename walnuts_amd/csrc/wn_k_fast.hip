@@ -476,6 +476,7 @@ struct FastDevIO {
   uint32_t fire;
   __device__ __forceinline__ double sum(int k) const { return k == Q_LP ? lp : k == Q_KE ? ke : k == Q_KEINIT ? keinit : gen; }
   __device__ __forceinline__ uint32_t firemask(int, int, int) const { return fire; }
+  __device__ __forceinline__ void trace_step(int, int, int, double, double, double) const {}  // traced runs go to wn_k_fast4.hip / the one-stream kernel
   // the service wave's Philox blocks: entries side, side + 2 = the two next blocks of that stream when they were asked for
   uint32_t s_it[4], s_blk[4];
   double s_u0[4], s_u1[4];

@@ -1,0 +1,730 @@
+// wn_k_fast4.hip -- the headline path, fixedLeapFrog on a dense Gaussian with D <= 100 (BASELINE configs[1]), as
+// wave PAIRS: one T wave owns ALL coordinates of a group of FOUR chains, one B wave (the bookkeeper of wn_fast.h)
+// owns those chains' scalars.  A workgroup holds 1, 2 or 4 pairs (16 chains per CU at 4096 chains, 4 at 1024).
+//
+// Why four chains per wave.  wn_k_fast.hip spreads a 16-chain group over seven T waves (one 16-row tile each): every
+// tick they exchange the positions through LDS, sum their partial dot products through LDS and a service wave, and
+// meet at two barriers -- ~4.5 k of a tick's 7.7 k cycles.  v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks,
+// 16 cycles: the same flop per cycle as 16x16x4, tools/mfma_f64_4x4_probe.hip) makes a 4-chain group small enough
+// for ONE wave: 7 doubles per lane and vector.  Nothing crosses waves any more: no position exchange, every dot
+// product is complete inside the wave, one barrier per tick (the T / B hand-off), and the -A fragments stream from
+// one LDS image shared by the workgroup's T waves.
+//
+// Lane l = 16 r + 4 b + x.  Measured operand layout of the instruction (probe): A[block b][i][k] sits in lane
+// 16 k + 4 b + i, B[b][k][j] in lane 16 k + 4 b + j, D[b][i][j] in lane 16 i + 4 b + j.  Register s of a vector holds
+// coordinate 16 s + 4 b + r of chain x -- the D layout of the 16-row set s when block b computes rows 16 s + 4 b ..
+// + 3.  So the ROWS of a set are split over the blocks and every block needs the same four coordinates of Q as its B
+// operand: k-step kappa (coordinates 4 kappa .. 4 kappa + 3) is block kappa & 3 of register kappa >> 2, broadcast to
+// the other blocks with two DPP moves per half -- work that depends on Q only and issues in the shadow of the
+// MFMAs.  G comes out complete and where Q lives: nothing is reduced across lanes on the dependent path.  (The first
+// form of this kernel split K over the blocks instead: no broadcasts, but a 15-instruction reduce-scatter with three
+// FP64 additions behind every 24 MFMAs -- measured 3.5 k cycles for the 157 MFMAs of a tick, whose pipe time is 2.5 k;
+// FP64 vector instructions wait for the FP64 matrix pipe.)  For D = 100 rows 96..99 would be a seventh set with 12 of 16
+// rows padding: they are done K-split (six MFMAs on the registers as they are, one block sum, one MFMA for columns
+// 96..99): 157 MFMAs per tick instead of 175.
+//
+// One tick of a pair (the protocol, commands and two-tick lag are wn_fast.h's):
+//   T wave                                                      B wave
+//   read command C[t]; pick / iteration start / end swap;       read the sums P[t-1]; FastBook::tick: retire tick t-1,
+//   first half step; G = -A Q; second half step; sums P[t]      issue C[t+1]; momentum normals; uniform window
+//   of lp, KE and the U-turn dots due at this leaf; endpoint
+//   stores
+//   ----------------------------------- barrier (LDS only) ---------------------------------------------------------
+#include "wn_launch.h"  // hip_runtime first
+
+#include "wn_fast.h"
+
+namespace wn {
+using namespace fast;
+
+template <int NS_, bool TAIL_>
+struct Fast4Geom {
+  static constexpr int NS = NS_;                 // registers per lane and vector: coordinate 16 s + 4 b + r
+  static constexpr bool TAIL = TAIL_;            // the last k-step holds <= 4 coordinates (block 0 only): tail MFMA
+  static constexpr int KF = TAIL ? NS - 1 : NS;  // full k-steps of the main loop
+  static constexpr int VEC = NS * 64;            // one vector of a 4-chain group, [s][lane]
+  static constexpr int DPAD = 128;               // momentum normals per chain
+  static constexpr int MP = 11;                  // largest M
+  static constexpr int NB = 8;                   // batches of four sums: (lp, KE, level 0), levels (1,2) .. (11,-), (keinit, gen)
+  static constexpr int NFAST = 3;                // check levels 0 (passive end), 1 (registers), 2 (LDS) are on chip
+  // -A fragments (64 doubles each).  Main: k-step kappa (coordinates 4 kappa .. 4 kappa + 3) x 16-row set S, usage order
+  // kappa-major; with TAIL the last four rows (row group 4 (NS-1)) are done K-split: NS-1 fragments + one for the tail columns
+  static constexpr int NSR = TAIL ? NS - 1 : NS;                  // 16-row sets computed with replicated operands
+  static constexpr int NK = TAIL ? 4 * (NS - 1) + 1 : 4 * NS;     // k-steps of four coordinates
+  static constexpr int NMAIN = NK * NSR;
+  static constexpr int NFR = NMAIN + (TAIL ? NS : 0);
+  static_assert(NSR % 2 == 0, "two fragments per 16-byte LDS read");
+  // LDS, in doubles: the fragment image, then one region per pair
+  static constexpr int OFF_A = 0;
+  static constexpr int P_COLD = 0;                      // passive orbit end: qb, vb
+  static constexpr int P_LC = P_COLD + 2 * VEC;         // level-2 left endpoint: q, v
+  static constexpr int P_SUMS = P_LC + 2 * VEC;         // 2 x [batch][block b][chain x]
+  static constexpr int P_CMD = P_SUMS + 2 * NB * 16;    // 2 x 4 commands of 2 doubles
+  static constexpr int P_USTAT = P_CMD + 16;            // uniform blocks 0..7 of the running iteration: [chain][8] x {tag, u0, u1}
+  static constexpr int P_URING = P_USTAT + 4 * 8 * 3;   // sliding window of 16 blocks: [chain][blk & 15] x {tag, u0, u1}
+  static constexpr int P_DSTAGE = P_URING + 4 * 16 * 3; // diagnostics rows on their way out: [chain][24]
+  static constexpr int P_FLAGS = P_DSTAGE + 4 * NDIAG;  // 2 x {done}, pad
+  static constexpr int PAIR_DOUBLES = P_FLAGS + 8;
+  static constexpr int OFF_PAIR = NFR * 64;
+  __host__ __device__ static constexpr size_t lds_bytes(int pairs) { return ((size_t)OFF_PAIR + (size_t)pairs * PAIR_DOUBLES) * sizeof(double); }
+  // workspace of one 4-chain group, in doubles: (M+1) slots x (q, v), 2 proposals, momentum normals [chain][DPAD]
+  __host__ __device__ static constexpr size_t group_doubles(int M) { return (size_t)((M + 1) * 2 + 2) * VEC + (size_t)4 * DPAD; }
+};
+
+#define WN4_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// diagnostic builds (tools/build_variant.sh stamps -DWN_STAMPS): cycles per segment of the tick, summed per wave
+#if defined(WN_STAMPS)
+#define WN4_STAMP(k)                                                                         \
+  do {                                                                                       \
+    unsigned long long _t;                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); \
+    fst_[k] += _t - fst_last_;                                                               \
+    fst_last_ = _t;                                                                          \
+  } while (0)
+#define WN4_STAMP_DECL unsigned long long fst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fst_last_ = __builtin_readcyclecounter();
+#define WN4_STAMP_OUT(prm)                                                                             \
+  if ((prm).stamps && (threadIdx.x & 63) == 0) {                                                       \
+    unsigned long long* o_ = (prm).stamps + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16;        \
+    for (int k = 0; k < 8; ++k) o_[k] = fst_[k];                                                       \
+  }
+#else
+#define WN4_STAMP(k) do {} while (0)
+#define WN4_STAMP_DECL
+#define WN4_STAMP_OUT(prm)
+#endif
+
+__device__ __forceinline__ double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+
+// DPP move of a double: lanes whose bank (= block b = (lane >> 2) & 3) is in BANKS take src moved by CTL inside their row of
+// 16 lanes, the others keep old
+template <int CTL, int BANKS>
+__device__ __forceinline__ double dpp_sel(double old, double src) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTL, 0xF, BANKS, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTL, 0xF, BANKS, false);
+  return __hiloint2double(hi, lo);
+}
+enum { DPP_SHL4 = 0x104, DPP_SHL8 = 0x108, DPP_SHR4 = 0x114, DPP_SHR8 = 0x118, DPP_ROR8 = 0x128 };  // row_shl:n lane l <- l+n; row_shr:n lane l <- l-n
+
+// block b' ends with x_{b'} summed over the four blocks: (x[0] + x[2]) + (x[1] + x[3])
+__device__ __forceinline__ double blocks_reduce_scatter(double x0, double x1, double x2, double x3) {
+  // distance 8: blocks 0,1 keep x0 / x1, blocks 2,3 keep x2 / x3
+  const double u = dpp_sel<DPP_ROR8, 0xC>(x0, x2) + dpp_sel<DPP_ROR8, 0x3>(x2, x0);  // [x0(0+2), x0(1+3), x2(0+2), x2(1+3)]
+  const double w = dpp_sel<DPP_ROR8, 0xC>(x1, x3) + dpp_sel<DPP_ROR8, 0x3>(x3, x1);  // the same of x1 / x3
+  // distance 4: even blocks keep u, odd blocks keep w
+  return dpp_sel<DPP_SHR4, 0xA>(u, w) + dpp_sel<DPP_SHL4, 0x5>(w, u);  // [x0, x1, x2, x3] summed
+}
+__device__ __forceinline__ double blocks_sum(double x) {  // every block ends with the sum over the four blocks
+  x = x + dpp_sel<DPP_ROR8, 0xF>(x, x);
+  return dpp_sel<DPP_SHR4, 0xA>(x, x) + dpp_sel<DPP_SHL4, 0x5>(x, x);
+}
+__device__ __forceinline__ double block0_bcast(double x) {  // block 0 of every row to the row's other blocks
+  x = dpp_sel<DPP_SHR4, 0x2>(x, x);
+  return dpp_sel<DPP_SHR8, 0xC>(x, x);
+}
+// x[l] + x[l^16] + x[l^32] + x[l^48] in every lane (the sum over r)
+__device__ __forceinline__ double rows_sum(double x) {
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  u2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  u2_t b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double y = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  lo = __double2loint(y); hi = __double2hiint(y);
+  a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// T wave
+// ------------------------------------------------------------------------------------------------
+template <class G, bool TRACE>
+__device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* lds, double* pr, const int grp) {
+  constexpr int NS = G::NS, NFAST = G::NFAST;
+  const int lane = threadIdx.x & 63, x = lane & 3, b = (lane >> 2) & 3, r = lane >> 4;
+  const int cl = grp * 4 + x;
+  const bool inrange = cl < prm.C;
+  const int D = prm.D;
+  auto coord = [&](int s) { return 16 * s + 4 * b + r; };
+  double* const wbase = prm.work + (size_t)grp * G::group_doubles(prm.M);
+  auto gvec = [&](int vec) { return wbase + (size_t)vec * G::VEC + lane; };  // + s * 64
+  const int vprop = (prm.M + 1) * 2;
+  const double* const znext = wbase + (size_t)((prm.M + 1) * 2 + 2) * G::VEC + (size_t)x * G::DPAD;
+  double* const cold = pr + G::P_COLD + lane;  // qb: + s * 64, vb: + VEC + s * 64
+  double* const lc = pr + G::P_LC + lane;
+  double* const sums = pr + G::P_SUMS;
+  const Cmd* const cmdbuf = reinterpret_cast<const Cmd*>(pr + G::P_CMD);
+
+  double q[NS], v[NS], g[NS], VL[NS], qm1[NS];
+  double pq0[NS], pv0[NS], pq1[NS], pv1[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { q[s] = v[s] = g[s] = VL[s] = qm1[s] = 0.0; pq0[s] = pv0[s] = pq1[s] = pv1[s] = 0.0; }
+  int ntr = 0;  // trace rows written (TRACE)
+
+  // one batch of four per-chain sums: lanes r = 0 hold [block b'][chain x] = 16 consecutive doubles
+  auto put4 = [&](double* dst, double a0, double a1, double a2, double a3) {
+    const double z = rows_sum(blocks_reduce_scatter(a0, a1, a2, a3));
+    if (lane < 16) dst[lane] = z;
+  };
+
+  WN4_STAMP_DECL
+  for (uint32_t t = 0;; ++t) {
+    Cmd c;
+    if (t == 0) { c.hs = 0.0; c.op = inrange ? (OP_NEWITER | OP_INIT) : 0u; c.n = 0u; }
+    else c = cmdbuf[(t & 1u) * 4 + x];
+    const uint32_t op = c.op;
+    if (__any((op & OP_DONE) != 0)) break;
+    double* const sp = sums + (t & 1u) * (G::NB * 16);
+    const bool step = (op & OP_STEP) != 0;
+    const int i = (int)((op >> OP_I_SHIFT) & 31u), n = (int)c.n;
+    const int nchk = step ? nchecks(i, n) : 0;
+    double keinit_part = 0.0, gen_part = 0.0;
+    // ---- commands ----
+    // left endpoints of the first two off-chip sub-tree levels this leaf closes: requested now, used behind the MFMAs.
+    // (The registers live across ticks and are not cleared: see wn_k_fast.hip.)
+    const bool deep0 = nchk > NFAST, deep1 = nchk > NFAST + 1;
+    // ONE vote for everything that does not happen on an ordinary leaf (every vote is a vector compare + a scalar branch
+    // that waits for it)
+    const bool anyrare = __any((op & (OP_PICK | OP_NEWITER | OP_SWAP | OP_UNDO)) != 0 || deep0);
+    if (anyrare && __any(deep0)) {
+      if (deep0) {
+        const int sl = slot_of_leaf(n + 1 - (1 << NFAST));
+        const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { pq0[s] = sq[s * 64]; pv0[s] = sv[s * 64]; }
+      }
+      if (deep1) {
+        const int sl = slot_of_leaf(n + 1 - (2 << NFAST));
+        const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { pq1[s] = sq[s * 64]; pv1[s] = sv[s * 64]; }
+      }
+    }
+    if (anyrare && __any((op & OP_PICK) != 0)) {  // qm1 still holds the position of tick t-2
+      if (op & OP_PICK) {
+        double* dst = gvec(vprop + ((op & OP_IPPICK) ? 1 : 0));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) dst[s * 64] = qm1[s];
+      }
+    }
+    if (TRACE && anyrare) { if (op & OP_UNDO) ntr -= 1; }  // the leaf in flight when the iteration ended
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qm1[s] = q[s];  // the position of tick t-1: level-1 left endpoint, next tick's pick source
+    if (anyrare && __any((op & OP_NEWITER) != 0)) {
+      if (op & OP_NEWITER) {
+        if (op & OP_INIT) {
+          double* dst = gvec(vprop);
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            q[s] = coord(s) < D ? prm.q0[(size_t)cl * D + coord(s)] : 0.0;
+            dst[s * 64] = q[s];
+          }
+        } else {
+          const double* src = gvec(vprop + ((op & OP_IPNEW) ? 1 : 0));
+#pragma unroll
+          for (int s = 0; s < NS; ++s) q[s] = src[s * 64];
+        }
+        // samples[:, row] = generated(q)  (WALNUTS.py:164,695)
+        double* row = prm.samples + ((size_t)cl * (prm.numIter + 1) + c.n) * prm.dg;
+        if (prm.generated == G_Q0_SUMSQ) {
+          if (lane < 4) row[0] = q[0];  // coordinate 0: register 0 of lane (r = 0, b = 0, x)
+          double s2 = 0.0;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) s2 += q[s] * q[s];
+          gen_part = s2;
+        } else {
+          const int k = prm.generated == G_FIRSTK ? prm.gen_k : D;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) if (coord(s) < k) row[coord(s)] = q[s];
+        }
+        if (!(op & (OP_INIT | OP_LAST))) {  // v = normal(size=d); both ends start at (qc, v)  (:236-253)
+          double kp = 0.0;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            const double z = znext[coord(s)];
+            v[s] = z;
+            kp += z * z;
+          }
+          keinit_part = kp;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) { cold[s * 64] = q[s]; cold[G::VEC + s * 64] = v[s]; }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): waited for HERE, not on the common path (wn_k_fast.hip)
+      }
+    }
+    if (anyrare && __any((op & OP_SWAP) != 0)) {  // the other end of the orbit becomes the active one (:283-286)
+      if (op & OP_SWAP) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const double tq = cold[s * 64], tv = cold[G::VEC + s * 64];
+          cold[s * 64] = q[s]; cold[G::VEC + s * 64] = v[s];
+          q[s] = tq; v[s] = tv;
+        }
+      }
+    }
+    // ---- first half of the leapfrog step (adaptiveIntegrators.py:51-52 with hs = xi*h; v stays forward-time) ----
+    const double hs = step ? c.hs : 0.0, hs2 = 0.5 * hs;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { v[s] = v[s] + hs2 * g[s]; q[s] = q[s] + hs * v[s]; }
+    WN4_STAMP(0);
+    // ---- G = -A Q ----
+    {
+      constexpr int NSR = G::NSR, NK = G::NK, NP = NSR / 2;
+      typedef double d2_t __attribute__((ext_vector_type(2)));
+      const double* const img = lds + G::OFF_A + 2 * lane;
+      // fragments of k-step kappa: NSR / 2 reads of 16 bytes (the image interleaves two fragments per lane: ds_read_b128 moves
+      // 256 B per clock; the ds_read2st64_b64 the compiler makes of two 8-byte reads moves half that, and four T waves reading
+      // 80 KB each per tick then keep the LDS busy for 2.5 k cycles).  Four k-steps are in flight / in use.
+      d2_t fa[4][NP];
+      auto load_k = [&](int kap, d2_t* f) {
+#if defined(WN4_NOLDS)  // timing diagnostic only (wrong fragments)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { f[j][0] = hs * (double)(kap + j); f[j][1] = hs2 + (double)j; }
+#else
+#pragma unroll
+        for (int j = 0; j < NP; ++j) f[j] = *reinterpret_cast<const d2_t*>(img + (kap * NP + j) * 128);
+#endif
+      };
+#pragma unroll
+      for (int k0 = 0; k0 < 3; ++k0) if (k0 < NK) load_k(k0, fa[k0]);
+      // the K-split row group of the last four rows (TAIL): its fragments, then one MFMA under each of the first k-steps
+      d2_t fx[(NS - 1) / 2 > 0 ? (NS - 1) / 2 : 1];
+      double ftail = 0.0, accx = 0.0, gx = 0.0;
+      if (G::TAIL) {
+#pragma unroll
+        for (int j = 0; j < (NS - 1) / 2; ++j) fx[j] = *reinterpret_cast<const d2_t*>(img + G::NMAIN * 64 + j * 128);
+        ftail = lds[G::OFF_A + (G::NMAIN + NS - 1) * 64 + lane];
+      }
+      double acc[NSR];
+#pragma unroll
+      for (int S = 0; S < NSR; ++S) acc[S] = 0.0;
+      auto bcast = [&](double x_, int bp) {  // block bp of every row of 16 lanes to the row's other blocks
+        if (bp == 0) { x_ = dpp_sel<DPP_SHR4, 0x2>(x_, x_); return dpp_sel<DPP_SHR8, 0xC>(x_, x_); }
+        if (bp == 1) { x_ = dpp_sel<DPP_SHL4, 0x1>(x_, x_); return dpp_sel<DPP_SHR8, 0xC>(x_, x_); }
+        if (bp == 2) { x_ = dpp_sel<DPP_SHR4, 0x8>(x_, x_); return dpp_sel<DPP_SHL8, 0x3>(x_, x_); }
+        x_ = dpp_sel<DPP_SHL4, 0x4>(x_, x_); return dpp_sel<DPP_SHL8, 0x3>(x_, x_);
+      };
+#pragma unroll
+      for (int kap = 0; kap < NK; ++kap) {
+        if (kap + 3 < NK) load_k(kap + 3, fa[(kap + 3) & 3]);
+        const double qk = bcast(q[kap >> 2], kap & 3);  // (TAIL: the last k-step is block 0 of the last register)
+        const d2_t* f = fa[kap & 3];
+#pragma unroll
+        for (int S = 0; S < NSR; ++S) acc[S] = mfma4(f[S >> 1][S & 1], qk, acc[S]);
+#if defined(WN4_SGB)
+        // issue order: an MFMA holds the SIMD's vector issue for part of its 16 cycles only; one LDS read or two vector
+        // instructions behind each MFMA cost nothing, a cluster of six between two MFMAs does
+#pragma unroll
+        for (int S = 0; S < NSR; ++S) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (S < NP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x002, WN4_SGB, 0);
+        }
+        if (G::TAIL && kap < NS - 1) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#endif
+        if (G::TAIL) {
+          if (kap < NS - 1) accx = mfma4(fx[kap >> 1][kap & 1], q[kap], accx);
+          if (kap == NS + 1) gx = blocks_sum(accx);          // (two k-steps behind its last MFMA)
+          if (kap == NK - 1) gx = mfma4(ftail, qk, gx);      // columns 16 (NS-1) .. + 3
+        }
+      }
+#pragma unroll
+      for (int S = 0; S < NSR; ++S) g[S] = acc[S];
+      if (G::TAIL) g[NS - 1] = b == 0 ? gx : 0.0;  // blocks 1..3 of the last register are padding
+    }
+    WN4_STAMP(1);
+    // ---- second half step; lp = 1/2 q.g, KE = 1/2 v.v ----
+    double pl = 0.0, pk = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) pl += q[s] * g[s];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { v[s] = v[s] + hs2 * g[s]; pk += v[s] * v[s]; }
+    if (TRACE) {  // one row per integrator call: the state (q', v') goes here, the scalars come from the bookkeeper
+      if (step && prm.trace && ntr < prm.trace_cap && ntr >= 0) {
+        double* tr = prm.trace + ((size_t)cl * prm.trace_cap + ntr) * (TRACE_NSCAL + 2 * D) + TRACE_NSCAL;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if (coord(s) < D) { tr[coord(s)] = q[s]; tr[D + coord(s)] = v[s]; }
+      }
+      if (step) ntr += 1;
+    }
+    // ---- U-turn dots of the sub-tree checks due at this leaf (stopCondition, WALNUTS.py:95-97) ----
+    auto dots = [&](const double* qo, const double* vo, double& d1, double& d2) {
+      double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const double dq = q[s] - qo[s];
+        a1 += v[s] * dq;
+        a2 += vo[s] * dq;
+      }
+      d1 = a1; d2 = a2;
+    };
+    {
+      double a1 = 0.0, a2 = 0.0;
+      if (__any(step && n == (1 << i) - 1)) {  // level 0: the whole orbit against its passive end
+        double qo[NS], vo[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { qo[s] = cold[s * 64]; vo[s] = cold[G::VEC + s * 64]; }
+        dots(qo, vo, a1, a2);
+      }
+      put4(sp, pl, pk, a1, a2);
+    }
+    if (__any(nchk > 1)) {  // levels 1 (the leaf pair: registers) and 2 (LDS)
+      double a1, a2, b1 = 0.0, b2 = 0.0;
+      dots(qm1, VL, a1, a2);
+      if (__any(nchk > 2)) {
+        double qo[NS], vo[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { qo[s] = lc[s * 64]; vo[s] = lc[G::VEC + s * 64]; }
+        dots(qo, vo, b1, b2);
+      }
+      put4(sp + 16, a1, a2, b1, b2);
+    }
+    if (__any(nchk > 3)) {  // levels 3, 4: prefetched
+      double a1, a2, b1, b2;
+      dots(pq0, pv0, a1, a2);
+      dots(pq1, pv1, b1, b2);
+      put4(sp + 32, a1, a2, b1, b2);
+    }
+    for (int j = 5; __any(nchk > j); j += 2) {  // still deeper levels (one leaf in 32): fetched here
+      double e[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (nchk > j + h) {
+          const int sl = slot_of_leaf(n + 1 - (1 << (j + h)));
+          const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
+          double qo[NS], vo[NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) { qo[s] = sq[s * 64]; vo[s] = sv[s * 64]; }
+          dots(qo, vo, e[2 * h], e[2 * h + 1]);
+        }
+      }
+      put4(sp + 16 * ((j + 1) >> 1), e[0], e[1], e[2], e[3]);
+    }
+    if (anyrare && __any((op & OP_NEWITER) != 0)) put4(sp + 16 * (G::NB - 1), keinit_part, gen_part, 0.0, 0.0);
+    WN4_STAMP(2);
+    // ---- statePush (:431,518): only sub-tree left endpoints are ever read back ----
+    const bool even = step && i >= 1 && (n & 1) == 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) VL[s] = even ? v[s] : VL[s];  // (selects: no branch on the common path)
+    const bool ep = even && i >= 2 && (n & 3) == 0;
+    if (__any(ep)) {
+      if (ep) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { lc[s * 64] = q[s]; lc[G::VEC + s * 64] = v[s]; }
+        if (n == 0 ? (i >= NFAST) : (__builtin_ctz((unsigned)n) >= NFAST)) {
+          const int sl = slot_of_leaf(n);
+          double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
+#pragma unroll
+          for (int s = 0; s < NS; ++s) { sq[s * 64] = q[s]; sv[s * 64] = v[s]; }
+        }
+      }
+    }
+    WN4_STAMP(3);
+    WN4_BARRIER();
+    WN4_STAMP(4);
+#if defined(WN_STAMPS)
+    fst_[6] += 1;
+#endif
+  }
+  WN4_STAMP_OUT(prm)
+}
+
+// ------------------------------------------------------------------------------------------------
+// B wave: lane l serves chain x = l & 3 as replica l >> 2 (sixteen replicas run the identical scalar code on identical
+// inputs and stay bit-identical); replica j turns check level j's dots into its verdict bit
+// ------------------------------------------------------------------------------------------------
+template <class G, bool TRACE>
+struct Fast4IO {
+  const Params* prm;
+  double* pr;
+  int cl, x, rep;
+  double lp, ke, keinit, gen;
+  uint32_t fire;
+  int ntrace;
+  // three entries of the uniform window read with the tick's other LDS words: the blocks the chain is about to use
+  // (scalar members: arrays in this struct sent it -- and the kernel's parameter block with it -- to scratch memory)
+  uint32_t p_it0, p_it1, p_it2, p_blk0, p_blk1, p_blk2;
+  double p_u00, p_u01, p_u02, p_u10, p_u11, p_u12;
+  __device__ __forceinline__ double sum(int k) const { return k == Q_LP ? lp : k == Q_KE ? ke : k == Q_KEINIT ? keinit : gen; }
+  __device__ __forceinline__ uint32_t firemask(int, int, int) const { return fire; }
+  __device__ __forceinline__ bool uniforms(int, int iter, uint32_t blk, double& ua, double& ub) const {
+    const bool h0 = p_it0 == (uint32_t)iter && p_blk0 == blk, h1 = p_it1 == (uint32_t)iter && p_blk1 == blk,
+               h2 = p_it2 == (uint32_t)iter && p_blk2 == blk;
+    // (single exit, select form: an early return here kept the whole bookkeeper in scratch memory)
+    bool hit = h0 || h1 || h2;
+    // (the members are read into registers behind an opaque barrier: left alone, the compiler turns a select between two loaded
+    // members into a load from a selected ADDRESS, and a struct whose members' addresses are selected at run time stays in memory)
+    double a0 = p_u00, a1 = p_u01, a2 = p_u02, b0 = p_u10, b1 = p_u11, b2 = p_u12;
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2));
+    double va = h0 ? a0 : h1 ? a1 : a2, vb = h0 ? b0 : h1 ? b1 : b2;
+    if (!hit) {
+      const double* e = pr + (blk < 8u ? G::P_USTAT + (x * 8 + (int)blk) * 3 : G::P_URING + (x * 16 + (int)(blk & 15u)) * 3);
+      const uint32_t* tag = reinterpret_cast<const uint32_t*>(e);
+      va = e[1]; vb = e[2];
+      hit = tag[0] == (uint32_t)iter && tag[1] == blk;
+    }
+    ua = va; ub = vb;
+    return hit;
+  }
+  __device__ __forceinline__ void write_gen(size_t row, double v) const {
+    if (rep == 0) prm->samples[((size_t)cl * (prm->numIter + 1) + row) * prm->dg + 1] = v;
+  }
+  // one diagnostics row = 192 B: staged in LDS by replica 0, stored as twelve 16-byte pieces by replicas 0..11
+  __device__ __forceinline__ void write_diag(size_t row, const double* d) const {
+    double* st = pr + G::P_DSTAGE + x * NDIAG;
+    if (rep == 0) {
+#pragma unroll
+      for (int k = 0; k < NDIAG; ++k) st[k] = d[k];
+    }
+    if (rep < 12) {
+      typedef double d2_t __attribute__((ext_vector_type(2)));
+      const d2_t v = *reinterpret_cast<const d2_t*>(st + 2 * rep);
+      *reinterpret_cast<d2_t*>(prm->diag + ((size_t)cl * prm->numIter + row) * NDIAG + 2 * rep) = v;
+    }
+  }
+  __device__ __forceinline__ void trace_step(int iter, int i, int xi, double h, double ham0, double lpn) {
+    if (!TRACE) return;
+    const int row = ntrace++;
+    if (prm->trace && row < prm->trace_cap && rep == 0) {
+      double* r = prm->trace + ((size_t)cl * prm->trace_cap + row) * (TRACE_NSCAL + 2 * prm->D);
+      r[0] = iter; r[1] = i; r[2] = xi; r[3] = h; r[4] = ham0; r[5] = lpn; r[6] = 0; r[7] = 0;
+      r[8] = 0; r[9] = 0.0; r[10] = 1; r[11] = 0;  // fixedLeapFrog: If = Ib = c = 0, lwt = 0, one gradient (adaptiveIntegrators.py:57-59)
+    }
+  }
+};
+
+template <class G, bool TRACE>
+__device__ __forceinline__ void fast4_b_wave(const Params& prm, double* lds, double* pr, const int grp, const int pairs, int* abort_flag) {
+  const int lane = threadIdx.x & 63, x = lane & 3, rep = lane >> 2;
+  const int cl = grp * 4 + x;
+  const bool inrange = cl < prm.C;
+  Cmd* const cmdbuf = reinterpret_cast<Cmd*>(pr + G::P_CMD);
+  double* const znext = prm.work + (size_t)grp * G::group_doubles(prm.M) + (size_t)((prm.M + 1) * 2 + 2) * G::VEC;
+  FastBook bk;
+  bk.init(prm.chain0 + (uint32_t)cl, inrange, prm.numIter);
+  Fast4IO<G, TRACE> io;
+  io.prm = &prm; io.pr = pr; io.cl = cl; io.x = x; io.rep = rep;
+  io.lp = io.ke = io.keinit = io.gen = 0.0; io.fire = 0u; io.ntrace = 0;
+  int witer = 0;          // iteration and first block of the uniform window
+  uint32_t wbase = 0u;
+  // every chain needs at most numIter * (2^M - 1 + 2 idle ticks per doubling + start) ticks; twice that is an internal error
+  const double cap = 256.0 + 2.0 * (double)prm.numIter * ((double)(1u << prm.M) + 4.0 * (double)prm.M + 16.0);
+
+  WN4_STAMP_DECL
+  for (uint32_t t = 0;; ++t) {
+#if defined(WN4_NOB)  // diagnostic (with WN4_TONLY): the bookkeeper waves only write the fixed command
+    {
+      Cmd c;
+      c.hs = 1.0e-4; c.op = OP_STEP | (10u << OP_I_SHIFT); c.n = t & 1023u;
+      const bool done = t >= (uint32_t)(WN4_TONLY);
+      if (done) c.op |= OP_DONE;
+      if (rep == 0) cmdbuf[((t + 1u) & 1u) * 4 + x] = c;
+      WN4_BARRIER();
+      if (done) break;
+      continue;
+    }
+#endif
+    // ---- momentum normals v = normal(size=d) (WALNUTS.py:236, wn_rng.h stream 1) of ONE chain's next iteration per tick:
+    // lane L makes elements 2L, 2L+1 (one Philox block, one Box-Muller pair) ----
+    {
+      const unsigned long long want = __ballot(rep == 0 && bk.zwant != bk.zready && bk.zwant >= 1);
+      if (want) {
+        const int cs = __builtin_ctzll(want);  // lanes 0..3 are chains 0..3
+        const int it = __shfl(bk.zwant, cs);
+        const uint32_t ch = (uint32_t)__shfl((int)bk.chain, cs);
+        {
+          Philox4 p = philox4x32_10((uint32_t)lane, (uint32_t)it, ch, 1u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
+          const uint64_t x0 = ((uint64_t)p.w[1] << 32) | p.w[0];
+          const double u1 = ((double)(x0 >> 12) + 0.5) * 0x1.0p-52;
+          const double u2 = u53(p.w[2], p.w[3]);
+          const double rr = sqrt(-2.0 * log(u1));
+          const double th = 6.283185307179586476925286766559 * u2;
+          typedef double d2_t __attribute__((ext_vector_type(2)));
+          d2_t z;
+          z[0] = (2 * lane < prm.D) ? rr * cos(th) : 0.0;
+          z[1] = (2 * lane + 1 < prm.D) ? rr * sin(th) : 0.0;
+          *reinterpret_cast<d2_t*>(znext + (size_t)cs * G::DPAD + 2 * lane) = z;
+        }
+        if (x == cs) bk.zready = it;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // visible to the T wave behind the barrier
+      }
+    }
+    // ---- the window of uniforms (wn_rng.h stream 0): when a chain starts an iteration or nears the end of its sliding
+    // window, ONE Philox pass makes sixteen blocks for each of the four chains (lane = chain x, block base + replica).
+    // Blocks 0..7 of the iteration stay (the direction bits of WALNUTS.py:216 are read until the last doubling).
+    {
+      const bool fresh = bk.iter != witer;
+      const bool need = inrange && bk.iter <= prm.numIter && (fresh || (bk.ku >> 1) + 4u > wbase + 15u);
+      if (__any(need)) {
+        const uint32_t nb = fresh ? 0u : (bk.ku >> 1);
+        const uint32_t blk = nb + (uint32_t)rep;
+        const Philox4 p = philox4x32_10(blk, (uint32_t)bk.iter, bk.chain, 0u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
+        const double u0 = u53(p.w[0], p.w[1]), u1 = u53(p.w[2], p.w[3]);
+        double* e = pr + G::P_URING + (x * 16 + (int)(blk & 15u)) * 3;
+        reinterpret_cast<uint32_t*>(e)[0] = (uint32_t)bk.iter; reinterpret_cast<uint32_t*>(e)[1] = blk;
+        e[1] = u0; e[2] = u1;
+        if (blk < 8u) {
+          double* es = pr + G::P_USTAT + (x * 8 + (int)blk) * 3;
+          reinterpret_cast<uint32_t*>(es)[0] = (uint32_t)bk.iter; reinterpret_cast<uint32_t*>(es)[1] = blk;
+          es[1] = u0; es[2] = u1;
+        }
+        witer = bk.iter; wbase = nb;
+      }
+    }
+    WN4_STAMP(0);
+    // ---- every LDS word of this tick, requested together: the sums of tick t-1 (at t = 0: the zeroed other half), the dots
+    // of check level j = replica index, the other pairs' finished flags, three entries of the uniform window ----
+    const double* sp = pr + G::P_SUMS + ((t + 1u) & 1u) * (G::NB * 16);
+    const int jl = rep <= G::MP ? rep : G::MP;
+    const double* dp = sp + (jl == 0 ? 8 : 16 * ((jl + 1) >> 1) + ((jl & 1) ? 0 : 8)) + x;
+    const double s_lp = sp[x], s_ke = sp[4 + x], s_ki = sp[16 * (G::NB - 1) + x], s_gen = sp[16 * (G::NB - 1) + 4 + x];
+    const double d1 = dp[0], d2 = dp[4];
+    const double* fbase = lds + G::OFF_PAIR + G::P_FLAGS + ((t + 1u) & 1u);
+    const double fl0 = fbase[0], fl1 = fbase[(size_t)(1 < pairs ? 1 : 0) * G::PAIR_DOUBLES],
+                 fl2 = fbase[(size_t)(2 < pairs ? 2 : 0) * G::PAIR_DOUBLES], fl3 = fbase[(size_t)(3 < pairs ? 3 : 0) * G::PAIR_DOUBLES];
+    {
+      const uint32_t b0 = bk.ku >> 1;
+      const double* e0 = pr + G::P_URING + (x * 16 + (int)(b0 & 15u)) * 3;
+      const double* e1 = pr + G::P_URING + (x * 16 + (int)((b0 + 1u) & 15u)) * 3;
+      const double* e2 = pr + G::P_URING + (x * 16 + (int)((b0 + 2u) & 15u)) * 3;
+      io.p_it0 = reinterpret_cast<const uint32_t*>(e0)[0]; io.p_blk0 = reinterpret_cast<const uint32_t*>(e0)[1]; io.p_u00 = e0[1]; io.p_u10 = e0[2];
+      io.p_it1 = reinterpret_cast<const uint32_t*>(e1)[0]; io.p_blk1 = reinterpret_cast<const uint32_t*>(e1)[1]; io.p_u01 = e1[1]; io.p_u11 = e1[2];
+      io.p_it2 = reinterpret_cast<const uint32_t*>(e2)[0]; io.p_blk2 = reinterpret_cast<const uint32_t*>(e2)[1]; io.p_u02 = e2[1]; io.p_u12 = e2[2];
+    }
+    io.lp = s_lp; io.ke = s_ke; io.keinit = s_ki; io.gen = s_gen;
+    {  // verdict of check level j = replica index (wn_fast.h fire_of), then OR over the replicas of the chain
+      uint32_t f = 0u;
+      if (bk.s0.kind == FastBook::K_STEP && !bk.s0.discard && rep <= G::MP && need_check(bk.i, bk.s0.n, rep)) {
+        const double xi = (double)bk.xi;
+        if ((xi * d1 < 0.0) || (xi * d2 < 0.0)) f = 1u << rep;
+      }
+      f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x124, 0xF, 0xF, false);  // row_ror:4
+      f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x128, 0xF, 0xF, false);  // row_ror:8
+      typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+      u2_t w = __builtin_amdgcn_permlane16_swap(f, f, false, false);
+      f = w[0] | w[1];
+      w = __builtin_amdgcn_permlane32_swap(f, f, false, false);
+      io.fire = w[0] | w[1];
+    }
+    WN4_STAMP(1);
+#if defined(WN4_TONLY)  // diagnostic: the T waves alone, on a fixed stream of ordinary leaves
+    Cmd c;
+    c.hs = 1.0e-4; c.op = OP_STEP | (10u << OP_I_SHIFT); c.n = t & 1023u;
+    const bool done = t >= (uint32_t)(WN4_TONLY);
+    bool mine = true;
+#else
+    Cmd c = bk.tick(prm, io, t + 1u);
+    WN4_STAMP(2);
+    // ---- every pair of the workgroup has finished: all waves leave (the flags were written one tick ago) ----
+    const bool done = t > 0 && fl0 != 0.0 && fl1 != 0.0 && fl2 != 0.0 && fl3 != 0.0;
+    bool mine = __all(bk.finished());
+    if ((double)t > cap) {  // cannot happen; never hang the GPU
+      if (lane == 0) atomicExch(abort_flag, 1);
+      mine = true;
+    }
+#endif
+    if (lane == 0) pr[G::P_FLAGS + (t & 1u)] = mine ? 1.0 : 0.0;
+    if (done) c.op |= OP_DONE;
+    if (rep == 0) cmdbuf[((t + 1u) & 1u) * 4 + x] = c;
+    WN4_STAMP(3);
+    WN4_BARRIER();
+    WN4_STAMP(4);
+#if defined(WN_STAMPS)
+    fst_[6] += 1;
+#endif
+    if (done) break;
+  }
+  WN4_STAMP_OUT(prm)
+  if (TRACE && prm.trace_n && inrange && rep == 0) prm.trace_n[cl] = io.ntrace;
+}
+
+template <int NS, bool TAIL, bool TRACE>
+__global__ __launch_bounds__(512) void wn_fast4_kernel(Params prm, int* abort_flag, int pairs) {
+  using G = Fast4Geom<NS, TAIL>;
+  extern __shared__ double lds[];
+  // the -A fragment image (see the header): fragment f, lane (r, b, x)
+  const int D = prm.D;
+  for (int idx = threadIdx.x; idx < G::NFR * 64; idx += blockDim.x) {
+    const int f = idx >> 6, l = idx & 63, x = l & 3, b = (l >> 2) & 3, r = l >> 4;  // A operand: lane 16 k + 4 b + i
+    int row, col, dst;
+    if (f < G::NMAIN) {  // k-step kappa x row set S: block b holds rows 16 S + 4 b + i against columns 4 kappa + k
+      const int kap = f / G::NSR, S = f - kap * G::NSR;
+      row = 16 * S + 4 * b + x; col = 4 * kap + r;
+      dst = (f >> 1) * 128 + 2 * l + (f & 1);
+    } else {             // TAIL: rows 16 (NS-1) + i, K split over the blocks (columns 16 s + 4 b + k); last: the tail columns
+      const int sx = f - G::NMAIN;
+      row = 16 * (NS - 1) + x;
+      if (sx < NS - 1) { col = 16 * sx + 4 * b + r; dst = G::NMAIN * 64 + (sx >> 1) * 128 + 2 * l + (sx & 1); }
+      else { col = 16 * (NS - 1) + r; dst = (G::NMAIN + NS - 1) * 64 + l; }
+    }
+    lds[G::OFF_A + dst] = (row < D && col < D) ? -prm.tpar[(size_t)row * D + col] : 0.0;
+  }
+  // LDS keeps what the previous kernel on this CU left there: every control area starts from zero
+  for (int idx = threadIdx.x; idx < pairs * G::PAIR_DOUBLES; idx += blockDim.x) lds[G::OFF_PAIR + idx] = 0.0;
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int pair = wave < pairs ? wave : wave - pairs;  // waves w and w + 4 share a SIMD (speed only)
+  double* pr = lds + G::OFF_PAIR + (size_t)pair * G::PAIR_DOUBLES;
+  const int grp = blockIdx.x * pairs + pair;
+#if defined(WN4_BFIRST)  // the bookkeepers are the older waves of their SIMDs
+  const bool is_t = wave >= pairs;
+#else
+  const bool is_t = wave < pairs;
+#endif
+  if (is_t) {
+#if defined(WN4_TPRIO)
+    __builtin_amdgcn_s_setprio(WN4_TPRIO);
+#endif
+    fast4_t_wave<G, TRACE>(prm, lds, pr, grp);
+  } else {
+#if defined(WN4_BPRIO)
+    __builtin_amdgcn_s_setprio(WN4_BPRIO);
+#endif
+    fast4_b_wave<G, TRACE>(prm, lds, pr, grp, pairs, abort_flag);
+  }
+}
+
+// can the pair kernel run this launch?  fixedLeapFrog sampling on a dense Gaussian, D <= 100, no warm-up / orbit statistics
+bool fast4_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm) {
+  if (kc.layout != 1 || adapt != 0 || warm || prm.mode != MODE_SAMPLE) return false;
+  if (prm.omin || prm.M > 11 || prm.D > 100 || kc.p1 != 0 /* CK_DENSE */) return false;
+  return true;
+}
+
+int fast4_pairs(int C) {  // pairs per workgroup: fill the chip's 256 CUs before stacking pairs on a CU
+  const int groups = (C + 3) / 4;
+  return groups >= 4 * 256 ? 4 : groups >= 2 * 256 ? 2 : 1;
+}
+
+template <int NS, bool TAIL>
+static hipError_t fast4_go(const Params& prm, int* abort_flag, hipStream_t st) {
+  using G = Fast4Geom<NS, TAIL>;
+  const int pairs = fast4_pairs(prm.C), groups = (prm.C + 3) / 4;
+  dim3 grid((groups + pairs - 1) / pairs), block(128 * pairs);
+  const size_t shm = G::lds_bytes(pairs);
+  hipError_t r;
+  if (prm.trace_n) {
+    r = hipFuncSetAttribute((const void*)wn_fast4_kernel<NS, TAIL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (r != hipSuccess) return r;
+    hipLaunchKernelGGL((wn_fast4_kernel<NS, TAIL, true>), grid, block, shm, st, prm, abort_flag, pairs);
+  } else {
+    r = hipFuncSetAttribute((const void*)wn_fast4_kernel<NS, TAIL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (r != hipSuccess) return r;
+    hipLaunchKernelGGL((wn_fast4_kernel<NS, TAIL, false>), grid, block, shm, st, prm, abort_flag, pairs);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_fast4(const KernelChoice&, const Params& prm, int* abort_flag, hipStream_t st) {
+  const int D = prm.D;
+  if (D <= 32) return fast4_go<2, false>(prm, abort_flag, st);
+  if (D <= 64) return fast4_go<4, false>(prm, abort_flag, st);
+  if (D <= 96) return fast4_go<6, false>(prm, abort_flag, st);
+  if (D <= 100) return fast4_go<7, true>(prm, abort_flag, st);
+  return hipErrorInvalidValue;
+}
+
+// doubles of workspace per chain group, for wn_capi.hip's allocation (every geometry fits the role-split kernel's share)
+size_t fast4_work_doubles(int C, int M) { return (size_t)((C + 3) / 4) * Fast4Geom<7, true>::group_doubles(M); }
+
+}  // namespace wn

@@ -30,6 +30,11 @@ hipError_t launch_dense_grad(const double* A, const double* xq, double* xg, int 
 // role-split form of the fixedLeapFrog coop path (wn_k_fast.hip)
 bool fast_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm);
 hipError_t launch_fast(const KernelChoice& kc, const Params& prm, int* abort_flag, hipStream_t st);
+// wave-pair form of the same path for dense targets with D <= 100 (wn_k_fast4.hip): plain and traced sampling runs
+bool fast4_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm);
+hipError_t launch_fast4(const KernelChoice& kc, const Params& prm, int* abort_flag, hipStream_t st);
+int fast4_pairs(int C);
+size_t fast4_work_doubles(int C, int M);
 size_t wave_work_doubles(int NE, int C, int M, int G);
 size_t split_work_doubles(int NE, int C, int M);
 
