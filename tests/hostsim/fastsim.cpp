@@ -132,7 +132,12 @@ struct HostIO {
   double sum(int k) const { return sums[k]; }
   void dots(int j, double& d1, double& d2) const { d1 = sums[Q_DOT0 + 2 * j]; d2 = sums[Q_DOT0 + 2 * j + 1]; }
   uint32_t firemask(int i, int n, int xi) const { return fire_of(i, n, xi, *this); }
-  bool uniforms(int, int, uint32_t, double&, double&) const { return false; }  // no uniform service on the host
+  // the uniform window of the device (wn_k_fast4.hip) always has the block: here it is computed on the spot
+  bool uniforms(int, int iter, uint32_t blk, double& ua, double& ub) const {
+    Philox4 r = philox4x32_10(blk, (uint32_t)iter, prm->chain0 + (uint32_t)cl, 0u, (uint32_t)prm->seed, (uint32_t)(prm->seed >> 32));
+    ua = u53(r.w[0], r.w[1]); ub = u53(r.w[2], r.w[3]);
+    return true;
+  }
   void write_gen(size_t row, double v) const { prm->samples[((size_t)cl * (prm->numIter + 1) + row) * prm->dg + 1] = v; }
   void write_diag(size_t row, const double* d) const {
     double* o = prm->diag + ((size_t)cl * prm->numIter + row) * NDIAG;
@@ -143,7 +148,13 @@ struct HostIO {
 }  // namespace
 
 // returns the number of ticks the slowest chain took (>= 0) or -1 when a chain exceeded its bound
-extern "C" long fastsim_run(Params* prm, int target, int nlc, double* idle_frac) {
+// fastmode: 0 = FastBook::tick() only; 1 = the ordinary-leaf fast path whenever fast_prepare() allows it; 2 = as 1, and on
+// every tick BOTH paths run on copies and every member of the bookkeeper and the command must come out identical
+static long g_fast_ticks = 0, g_all_ticks = 0;
+extern "C" void fastsim_fast_stats(long* fast, long* all) { *fast = g_fast_ticks; *all = g_all_ticks; }
+extern "C" long fastsim_run2(Params* prm, int target, int nlc, double* idle_frac, int fastmode);
+extern "C" long fastsim_run(Params* prm, int target, int nlc, double* idle_frac) { return fastsim_run2(prm, target, nlc, idle_frac, 2); }
+extern "C" long fastsim_run2(Params* prm, int target, int nlc, double* idle_frac, int fastmode) {
   const int D = prm->D;
   long worst = 0;
   double steps = 0, ticks = 0;
@@ -169,7 +180,21 @@ extern "C" long fastsim_run(Params* prm, int target, int nlc, double* idle_frac)
         B.zready = B.zwant;
       }
       HostIO io{prm, cl, psums, &ntrace};
-      nxt = B.tick(*prm, io, t + 1);  // retires tick t-1, issues tick t+1
+      FastBook::Fast ff;
+      const bool fast = fastmode && B.fast_prepare(*prm, io, t + 1, ff);
+      g_all_ticks++;
+      if (fast) g_fast_ticks++;
+      if (fast && fastmode == 2) {
+        int nt2 = ntrace, nt3 = ntrace;
+        HostIO io2{prm, cl, psums, &nt2}, io3{prm, cl, psums, &nt3};
+        FastBook B2 = B, B3 = B;
+        const Cmd c2 = B2.tick(*prm, io2, t + 1), c3 = B3.fast_commit(*prm, io3, ff);
+        // (the one-block uniform caches may hold different -- equally valid -- blocks: the values are functions of the index)
+        B2.cblkI = B3.cblkI; B2.cuI0 = B3.cuI0; B2.cuI1 = B3.cuI1; B2.cblkR = B3.cblkR; B2.cuR0 = B3.cuR0; B2.cuR1 = B3.cuR1;
+        if (memcmp(&B2, &B3, sizeof(FastBook)) != 0 || c2.op != c3.op || c2.n != c3.n || memcmp(&c2.hs, &c3.hs, sizeof(double)) != 0 || nt2 != nt3) return -2;
+      }
+      if (fast) nxt = B.fast_commit(*prm, io, ff);
+      else nxt = B.tick(*prm, io, t + 1);  // retires tick t-1, issues tick t+1
       T.tick(t, cur);                 // tick t
       memcpy(psums, T.sums, sizeof(psums));
       if (cur.op & OP_STEP) steps += 1;

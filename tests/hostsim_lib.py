@@ -148,6 +148,8 @@ def fast_walnuts(target, q0, tpar=None, H0=0.2, stepSizeRandScale=0.2, delta0=0.
         prm.trace_n = _p(tn, ip)
     idle = C.c_double(0.0)
     ticks = fast_lib().fastsim_run(C.byref(prm), target, nlc, C.byref(idle))
+    if ticks == -2:
+        raise RuntimeError("fastsim: the ordinary-leaf fast path and FastBook::tick() disagree")
     if ticks < 0:
         raise RuntimeError("fastsim: a chain exceeded its tick bound")
     return dict(samples=samples.transpose(0, 2, 1).copy(), diagnostics=diag, ticks=ticks, idle_frac=idle.value,

@@ -32,10 +32,12 @@ def close(a, b, rtol=1e-6, atol=1e-9, what=""):
                      f"got {a[~ok][:4]}, want {b[~ok][:4]}"
 
 
-def run(wa, target, tpar, q0, legacy=False, **kw):
+def run(wa, target, tpar, q0, legacy=False, pair=False, **kw):
     C, D = q0.shape
     if legacy:
         os.environ["WN_COOP_LEGACY"] = "1"
+    if pair:  # the wave-pair kernel (wn_k_fast4.hip) at any chain count
+        os.environ["WN_FAST4"] = "1"
     try:
         e = wa.Engine(D, C, integrator=ol.I_FIXED, **{k: v for k, v in kw.items() if k not in ("numIter", "seed")})
         e.set_target(target, tpar)
@@ -46,6 +48,7 @@ def run(wa, target, tpar, q0, legacy=False, **kw):
         e.close()
     finally:
         os.environ.pop("WN_COOP_LEGACY", None)
+        os.environ.pop("WN_FAST4", None)
     return s, d, name, ms
 
 
@@ -97,7 +100,15 @@ def test_fast_equals_one_stream_kernel_at_baseline_size(wa):
     kw = dict(H0=0.5, M=10, generated=ol.G_Q0_SUMSQ, chain_offset=0, numIter=12, seed=SEED)
     s, d, name, ms = run(wa, ol.T_DENSEGAUSS, A, q0, **kw)
     s1, d1, name1, ms1 = run(wa, ol.T_DENSEGAUSS, A, q0, legacy=True, **kw)
-    assert "wn_fast4_kernel" in name and "wn_coop_kernel" in name1, (name, name1)
+    assert "wn_fast_kernel" in name and "wn_coop_kernel" in name1, (name, name1)
+    # the wave-pair kernel at the same size: identical integers too (it sums the D terms of a dot product in its own order)
+    s4, d4, name4, ms4 = run(wa, ol.T_DENSEGAUSS, A, q0, pair=True, **kw)
+    assert "wn_fast4_kernel" in name4, name4
+    for col in INT_DIAG:
+        np.testing.assert_array_equal(d4[:, :, col], d1[:, :, col], err_msg=f"pair kernel diag col {col}")
+    close(d4, d1, rtol=1e-9, atol=1e-10, what="pair kernel diagnostics vs one-stream kernel")
+    close(s4, s1, rtol=1e-9, atol=1e-10, what="pair kernel draws vs one-stream kernel")
+    print(f"pair kernel {ms4:.1f} ms")
     for col in INT_DIAG:
         np.testing.assert_array_equal(d[:, :, col], d1[:, :, col], err_msg=f"diag col {col}")
     close(d, d1, rtol=1e-9, atol=1e-10, what="diagnostics vs one-stream kernel")
@@ -147,10 +158,72 @@ def test_fast_result_does_not_depend_on_the_previous_launch(wa):
     A, q0 = dense_problem(100, 1e4, 4096)
     kw = dict(H0=0.5, M=10, generated=ol.G_Q0_SUMSQ, chain_offset=0, numIter=3, seed=SEED)
     s0, d0, name, _ = run(wa, ol.T_DENSEGAUSS, A, q0, **kw)
-    assert "wn_fast4_kernel" in name
+    assert "wn_fast_kernel" in name
     for rep in range(4):
         # launches that leave iteration-1 entries of OTHER streams in every CU's LDS
         run(wa, ol.T_DENSEGAUSS, A, q0, H0=0.5, M=10, generated=ol.G_Q0_SUMSQ, chain_offset=7 + rep, numIter=1, seed=SEED + 1 + rep)
         s1, d1, _, _ = run(wa, ol.T_DENSEGAUSS, A, q0, **kw)
         np.testing.assert_array_equal(d1, d0, err_msg=f"diagnostics, repetition {rep}")
         np.testing.assert_array_equal(s1, s0, err_msg=f"draws, repetition {rep}")
+
+
+def _traced(wa, A, q0, pair, keep=None, **kw):
+    """(samples, diagnostics, trace, trace_n) of a traced fixedLeapFrog run through the C ABI"""
+    import torch
+    C, D = q0.shape
+    if pair:
+        os.environ["WN_FAST4"] = "1"
+    try:
+        e = wa.Engine(D, C, integrator=ol.I_FIXED, **{k: v for k, v in kw.items() if k not in ("numIter", "seed", "trace_cap")})
+        e.set_target(ol.T_DENSEGAUSS, A)
+        name = e.kernel_name
+        out = e.run(q0, kw["seed"], kw["numIter"], trace_cap=kw["trace_cap"])
+        e.close()
+    finally:
+        os.environ.pop("WN_FAST4", None)
+    s, d, tr, tn = out
+    if keep is not None:  # (a 4096-chain trace is gigabytes: only the checked chains leave the device)
+        tr = tr[keep]
+    return s.transpose(1, 2).cpu().numpy(), d.cpu().numpy(), tr.cpu().numpy(), tn.cpu().numpy(), name
+
+
+@pytest.mark.parametrize("D,C,M", [(100, 24, 7), (64, 9, 6), (97, 5, 8), (20, 13, 5)])
+def test_pair_kernel_per_step_states_match_oracle(wa, D, C, M):
+    """north_star: per-step (q, p) parity.  A traced run of the wave-pair kernel writes one row per integrator call
+    (adaptiveIntegrators.py:49-59): the T wave the state (q', v'), the bookkeeper the scalars; every row of every checked
+    chain against the oracle's trace to rtol 1e-6, row counts and integer columns exact."""
+    A, q0 = dense_problem(D, 1e3, C)
+    kw = dict(H0=0.5, M=M, generated=ol.G_IDENTITY, chain_offset=5, numIter=4, seed=SEED + D, trace_cap=4 * (1 << M))
+    s, d, tr, tn, name = _traced(wa, A, q0, False, **kw)
+    assert "wn_fast4_kernel" in name, name
+    for k in sorted({0, C - 1, C // 2, min(3, C - 1), min(4, C - 1)}):
+        o = ol.walnuts(ol.T_DENSEGAUSS, q0[k], integrator=ol.I_FIXED, tpar=A.ravel(), H0=0.5, numIter=4, M=M, seed=SEED + D,
+                       chain=5 + k, trace_cap=kw["trace_cap"])
+        n = o["ncalls"]
+        assert tn[k] == n, (k, tn[k], n)
+        cols = [0, 1, 2, 6, 7, 8, 10, 11]
+        np.testing.assert_array_equal(tr[k, :n][:, cols], o["trace"][:n][:, cols], err_msg=f"chain {k} integer columns")
+        close(tr[k, :n], o["trace"][:n], what=f"chain {k} trace rows")
+        close(s[k], o["samples"], what=f"chain {k} draws")
+        np.testing.assert_array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]])
+
+
+def test_pair_kernel_per_step_states_at_4096_chains(wa):
+    """The same at BASELINE size: 4096 chains, D = 100, kappa = 1e4, M = 10, two iterations traced; 8 chains against
+    the oracle step by step, and the traced run's draws equal the plain run's bit for bit (tracing changes nothing)."""
+    A, q0 = dense_problem(100, 1e4, 4096)
+    kw = dict(H0=0.5, M=10, generated=ol.G_Q0_SUMSQ, chain_offset=0, numIter=2, seed=SEED)
+    rng = np.random.default_rng(4)
+    keep = sorted(set(rng.integers(0, 4096, size=6).tolist() + [0, 4095]))
+    s, d, tr, tn, name = _traced(wa, A, q0, True, keep=keep, trace_cap=1400, **kw)
+    assert "wn_fast4_kernel" in name, name
+    sp, dp, namep, _ = run(wa, ol.T_DENSEGAUSS, A, q0, pair=True, **kw)
+    np.testing.assert_array_equal(s, sp); np.testing.assert_array_equal(d, dp)
+    assert (tn == (d[:, :, 6] + d[:, :, 7]).sum(1)).all()
+    for j, k in enumerate(keep):
+        o = ol.walnuts(ol.T_DENSEGAUSS, q0[k], integrator=ol.I_FIXED, tpar=A.ravel(), H0=0.5, numIter=2, M=10, seed=SEED, chain=k,
+                       generated=ol.G_Q0_SUMSQ, trace_cap=2100)
+        n = o["ncalls"]
+        assert tn[k] == n
+        m = min(n, 1400)
+        close(tr[j, :m], o["trace"][:m], what=f"chain {k} trace rows")

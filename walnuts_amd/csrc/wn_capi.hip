@@ -458,7 +458,9 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
     const int NT = kc.p0 <= 16 ? 1 : 2;
     snprintf(kc.name, sizeof(kc.name), "wn_fast_kernel<KS=%d,%s>", (kc.p1 != CK_DENSE && kc.p0 == 32) ? 28 : kc.p0, kc.p1 == CK_DENSE ? "dense" : "diag");
     (void)NT;
-    if (kc.p1 == CK_DENSE && D <= 100 && !getenv("WN_FAST_LEGACY"))  // dense, D <= 100: wave pairs of four chains (wn_k_fast4.hip), traced runs too
+    // dense, D <= 100, fewer than 4096 chains: wave pairs of four chains (wn_k_fast4.hip) -- 1024 chains are 256 pairs, one per CU,
+    // where the seven-wave kernel fills 64 CUs.  (Traced runs of every size go there too: see launch().)
+    if (kc.p1 == CK_DENSE && D <= 100 && (e->cfg.n_chains < 4096 || getenv("WN_FAST4")) && !getenv("WN_FAST_LEGACY"))
       snprintf(kc.name, sizeof(kc.name), "wn_fast4_kernel<NS=%d%s,dense,pairs=%d>", D <= 32 ? 2 : D <= 64 ? 4 : D <= 96 ? 6 : 7, D > 96 ? ",tail" : "",
                fast4_pairs(e->cfg.n_chains));
   }
@@ -596,7 +598,8 @@ static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
   const Params& p_ = pc;
   const bool coop_legacy = getenv("WN_COOP_LEGACY") != nullptr;  // diagnostic / A-B tests: one-stream kernel (read per launch)
   const bool fast_legacy = getenv("WN_FAST_LEGACY") != nullptr;  // diagnostic / A-B tests: the seven-T-wave kernel for dense targets too
-  hipError_t r = (!coop_legacy && !fast_legacy && fast4_eligible(e->kc, adapt, warm, p_)) ? launch_fast4(e->kc, p_, e->kabort, st)
+  const bool want4 = p_.trace_n != nullptr || p_.C < 4096 || getenv("WN_FAST4") != nullptr;  // (measured: 4096 chains 1.00e9 vs 1.12e9, 1024 chains 3.4e8 vs 2.8e8)
+  hipError_t r = (!coop_legacy && !fast_legacy && want4 && fast4_eligible(e->kc, adapt, warm, p_)) ? launch_fast4(e->kc, p_, e->kabort, st)
                : (!coop_legacy && fast_eligible(e->kc, adapt, warm, p_)) ? launch_fast(e->kc, p_, e->kabort, st)
                : e->kc.layout == 0 ? launch_lane(e->kc, adapt, warm, p_, st)
                : e->kc.layout == 1 ? launch_coop(e->kc, adapt, warm, p_, st) : launch_wave(e->kc, adapt, warm, p_, st);

@@ -34,6 +34,12 @@
 
 #include "wn_chain.h"
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WN_OPAQUE4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#else
+#define WN_OPAQUE4(a, b, c, d) do {} while (0)
+#endif
+
 namespace wn {
 namespace fast {
 
@@ -173,11 +179,12 @@ struct FastBook {
     const double u0 = 0.0 + (2.0 - 0.0) * Ui(prm, io, (uint32_t)j);
     return ((int)floor(u0) != 0) ? -1 : 1;
   }
-  template <class IO>
-  WN_HD double h_of(const Params& prm, IO& io, uint32_t k) {  // numpy legacy uniform(low, high) = low + (high-low)*U
+  WN_HD static double h_from(const Params& prm, double U) {  // numpy legacy uniform(low, high) = low + (high-low)*U
     const double low = prm.H * (1 - prm.s), high = prm.H * (1 + prm.s);
-    return low + (high - low) * Ui(prm, io, k);
+    return low + (high - low) * U;
   }
+  template <class IO>
+  WN_HD double h_of(const Params& prm, IO& io, uint32_t k) { return h_from(prm, Ui(prm, io, k)); }
 
   WN_HD void start_doubling_common() {  // WALNUTS.py:283-294
     n_rt = 0; n_is = 0;
@@ -394,6 +401,125 @@ struct FastBook {
       if (swap_next) { c.op |= OP_SWAP; swap_next = false; }
     }
     s1.set(ns);
+    return c;
+  }
+
+  // ---- the ordinary leaf: fast path of tick() ----------------------------------------------------------------
+  // Most ticks of a chain are the same event: in the middle of a doubling (i >= 1) the leaf of tick t-1 is retired -- a
+  // finite energy, no sub-tree U-turn, its multinomial draw taken -- and leaf n+2 is issued while leaf n+1 is in flight.
+  // tick() handles it through the same branches as every rare event; on the device every branch is an exec-mask save, a
+  // vote and a jump, and the bookkeeper's ~600 instructions per tick compete with the T wave's MFMAs for the SIMD (FP64
+  // MFMAs and vector instructions do not overlap on this chip: tools/mfma_valu_coissue.hip).  fast_prepare() decides
+  // WITHOUT touching the state whether this tick is that event and computes what it changes, straight-line;
+  // fast_commit() applies it.  State, command and draws are bit for bit those of tick() (tests/test_fast_book.py runs
+  // both on every tick and compares every member).  A wave takes the fast path when all its chains are ordinary.
+  struct Fast {
+    double lpn, Hn, Wsum, ratio, h, hnext2;
+    uint32_t ku_new;
+    int n, idx;
+    bool pick, even_issue;
+  };
+  // u = k-th uniform of this iteration if it is at hand without running Philox (either one-block cache, or the io's window)
+  template <class IO>
+  WN_HD bool peek(const IO& io, uint32_t k, double& u) const {
+    const uint32_t bl = k >> 1;
+    double w0, w1;
+    const bool hw = io.uniforms(2, iter, bl, w0, w1);
+    // (select form over register copies: a select between two loaded members becomes a load from a selected ADDRESS, and a
+    // struct whose members' addresses are selected at run time stays in scratch memory)
+    double r0 = cuR0, r1 = cuR1, i0 = cuI0, i1 = cuI1;
+    WN_OPAQUE4(r0, r1, i0, i1);
+    const bool cr = bl == cblkR, ci = bl == cblkI;
+    const double x0 = cr ? r0 : ci ? i0 : w0, x1 = cr ? r1 : ci ? i1 : w1;
+    u = (k & 1u) ? x1 : x0;
+    return cr || ci || hw;
+  }
+  // first uniform index an ordinary retirement of this tick reads (the io prefetches its block and the next two)
+  WN_HD uint32_t fast_first_uniform() const { return ku + (((s0.n & 1) == 0) ? 2u : 0u); }
+  template <class IO>
+  WN_HD bool fast_prepare(const Params& prm, const IO& io, uint32_t tn, Fast& f) const {
+    bool ok = s0.kind == K_STEP && !s0.discard && s1.kind == K_STEP && !s1.discard && st == ST_RUN && i >= 1 && !undo;
+    const int n = s0.n;
+    f.n = n;
+    // retire_pre
+    f.lpn = 0.5 * io.sum(Q_LP);
+    f.Hn = -f.lpn + 0.5 * io.sum(Q_KE);
+    const double Wnew = exp(-f.Hn + H0 + 0.0);
+    f.Wsum = WnewSum + Wnew;
+    f.ratio = Wnew / f.Wsum;
+    ok = ok && isfinite(f.Hn);
+    // no sub-tree U-turn at an odd leaf; the last leaf of the doubling is not ordinary (s1 is leaf n+1 < nleaf)
+    if (n & 1) {
+      const uint32_t m = ((2u << __builtin_ctz((unsigned)(n + 1))) - 1u) & ~1u;
+      ok = ok && (io.firemask(i, n, xi) & m) == 0;
+    }
+    ok = ok && s1.n == n + 1 && n_is == n + 2 && n_rt == n;
+    f.idx = xi > 0 ? b + 1 + n : a - 1 - n;
+    uint32_t k = ku + (((n & 1) == 0) ? 2u : 0u);     // :395 size=2, before the first step of the pair
+    // the leaf's multinomial draw (:426) must happen (then leaf n+1's will too: WnewSum does not decrease)
+    ok = ok && f.Wsum > prm.wtSumThresh;
+    double u;
+    ok = peek(io, k, u) && ok;
+    f.pick = u < f.ratio;
+    k += 1u;
+    // issue leaf n+2 (tick_post, ST_RUN): not the last leaf of the doubling (its issue draws the next direction)
+    ok = ok && n + 3 < nleaf;
+    f.even_issue = (n & 1) == 0;
+    ok = ok && (!f.even_issue || (tn & 1u) == 0);  // leaf pairs start on even ticks
+    double ua = 0.0, ub = 0.0;
+    if (f.even_issue) {  // h, h2 = uniforms k+1, k+2 (one leaf in flight: its draw comes first)
+      ok = peek(io, k + 1u, ua) && ok;
+      ok = peek(io, k + 2u, ub) && ok;
+      f.h = h_from(prm, ua);
+      f.hnext2 = h_from(prm, ub);
+    } else {
+      f.h = h2;
+      f.hnext2 = h2;
+    }
+    f.ku_new = k;
+    return ok;
+  }
+  template <class IO>
+  WN_HD Cmd fast_commit(const Params& prm, IO& io, const Fast& f) {
+    const int n = f.n;
+    const double h = s0.h;
+    io.trace_step(iter, i, xi, h, Ha, f.lpn);
+    pre_lpn = f.lpn; pre_Hn = f.Hn; pre_Wsum = f.Wsum; pre_ratio = f.ratio;
+    nevalF += 1;
+    Hmin = f.Hn < Hmin ? f.Hn : Hmin; Hmax = f.Hn > Hmax ? f.Hn : Hmax;
+    {
+      const bool fw = xi > 0;
+      const double tf = timeLenF_ + h, tb = timeLenB_ + h;
+      maxFint = fw ? f.idx : maxFint; maxBint = fw ? maxBint : f.idx;
+      timeLenF_ = fw ? tf : timeLenF_; timeLenB_ = fw ? timeLenB_ : tb;
+    }
+    n_rt = n + 1;
+    WnewSum = f.Wsum;
+    ku = f.ku_new;
+    // (the one-block uniform caches keep what they hold: still valid blocks of this iteration)
+    {  // pick_state(idx, lpn), select form
+      const bool p = f.pick;
+      const int nip = (ip == ipl) ? (ip ^ 1) : ip;
+      ip = p ? nip : ip;
+      pick_ip = p ? ip : pick_ip;
+      pend_pick = pend_pick || p;
+      lpP = p ? f.lpn : lpP;
+      L_ = p ? f.idx : L_;
+      const double is = xi > 0 ? timeLenF_ : -timeLenB_;
+      indexStat_ = p ? is : indexStat_;
+    }
+    orbitLen_ += h;
+    Ha = f.Hn;
+    // tick_post
+    s0.kind = K_STEP; s0.n = n + 1; s0.row = 0; s0.discard = false; s0.last = false; s0.init = false; s0.h = s1.h;
+    Cmd c;
+    c.op = OP_STEP | ((uint32_t)i << OP_I_SHIFT) | (pend_pick ? (OP_PICK | (pick_ip ? OP_IPPICK : 0u)) : 0u);
+    pend_pick = false;
+    c.n = (uint32_t)(n + 2);
+    c.hs = (double)xi * f.h;
+    h2 = f.hnext2;
+    s1.kind = K_STEP; s1.n = n + 2; s1.row = 0; s1.discard = false; s1.last = false; s1.init = false; s1.h = f.h;
+    n_is = n + 3;
     return c;
   }
   WN_HD bool finished() const { return st == ST_DEAD && s0.kind == K_NONE && s1.kind == K_NONE && !pend_pick; }

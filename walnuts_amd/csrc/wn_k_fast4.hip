@@ -583,7 +583,7 @@ __device__ __forceinline__ void fast4_b_wave(const Params& prm, double* lds, dou
     const double fl0 = fbase[0], fl1 = fbase[(size_t)(1 < pairs ? 1 : 0) * G::PAIR_DOUBLES],
                  fl2 = fbase[(size_t)(2 < pairs ? 2 : 0) * G::PAIR_DOUBLES], fl3 = fbase[(size_t)(3 < pairs ? 3 : 0) * G::PAIR_DOUBLES];
     {
-      const uint32_t b0 = bk.ku >> 1;
+      const uint32_t b0 = bk.fast_first_uniform() >> 1;  // the blocks an ordinary retirement + issue of this tick read
       const double* e0 = pr + G::P_URING + (x * 16 + (int)(b0 & 15u)) * 3;
       const double* e1 = pr + G::P_URING + (x * 16 + (int)((b0 + 1u) & 15u)) * 3;
       const double* e2 = pr + G::P_URING + (x * 16 + (int)((b0 + 2u) & 15u)) * 3;
@@ -613,7 +613,17 @@ __device__ __forceinline__ void fast4_b_wave(const Params& prm, double* lds, dou
     const bool done = t >= (uint32_t)(WN4_TONLY);
     bool mine = true;
 #else
-    Cmd c = bk.tick(prm, io, t + 1u);
+    // the ordinary leaf (wn_fast.h, fast_prepare / fast_commit): straight-line when every chain of the wave is there
+    Cmd c;
+#if defined(WN4_FASTPATH)  // (pays only once the pairs of a workgroup stop sharing a barrier: with four pairs in lockstep a tick is as
+                           // slow as its slowest bookkeeper, and all four are on the fast path on 27 % of the ticks: measured 8.6e8 vs 9.9e8)
+    FastBook::Fast ff;
+    const bool ordinary = bk.fast_prepare(prm, io, t + 1u, ff);
+    if (__all(ordinary)) c = bk.fast_commit(prm, io, ff);
+    else c = bk.tick(prm, io, t + 1u);
+#else
+    c = bk.tick(prm, io, t + 1u);
+#endif
     WN4_STAMP(2);
     // ---- every pair of the workgroup has finished: all waves leave (the flags were written one tick ago) ----
     const bool done = t > 0 && fl0 != 0.0 && fl1 != 0.0 && fl2 != 0.0 && fl3 != 0.0;
