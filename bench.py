@@ -10,6 +10,11 @@ A "step" is one wn_run launch: `--iters` sampler iterations for `--chains` chain
 Chains shard over GPUs with no data-path collective (weak scaling: per-GPU chains fixed); the
 only collective is the final gather of draws (reported separately as gather_ms) and the
 step-count/time reductions.
+
+The default invocation also runs BASELINE configs 3, 4 and 5 (all three runs of mainSW.py:41-80) at SURVEY 8d's
+sizes, three timed launches each, outside the headline's timed region: `extras.other_configs` carries min / median /
+max, a roofline, a CPU baseline and ESS/s for every one of them.  `--workload funnel | dense1000 | stockwatson |
+walnuts10` prints the same object as a full contract line.
 """
 import argparse
 import json
@@ -27,6 +32,7 @@ SEED = 20251121            # SURVEY.md 8d master seed
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix = FP64 vector (v_mfma_f64_16x16x4_f64: 256 CU x 4 SIMD x 32 flop/clk
                               # x 2.4 GHz); measured on the box by tools/mfma_f64_rate.hip (profiles/r02_mfma_f64_rate.txt)
 HBM_PEAK_GBS = 8000.0
+FUNNEL_TICK_FLOOR_US = 0.68   # tools/wave_tick_floor.hip: the bare arithmetic of a funnel macro step on one wave
 
 
 def make_dense_problem(D, kappa, C, seed, chain_offset=0):
@@ -51,13 +57,76 @@ def make_dense_problem(D, kappa, C, seed, chain_offset=0):
     return A, q0
 
 
+# ---------------------------------------------------------------------------------------------
+# workloads: SURVEY 8d's configurations as data (the engine arguments, the oracle's arguments, the metric)
+# ---------------------------------------------------------------------------------------------
+def _sw_data():
+    sw = np.load(os.path.join(ROOT, "tests", "golden", "stockwatson_data.npz"))
+    T = int(sw["T"][0])
+    return T, np.concatenate([[float(T)], sw["y"]])
+
+
+def workload_spec(name, args=None, rank=0, sw_run="D"):
+    """name in gauss100 | funnel | dense1000 | stockwatson.  Returns a dict: D, C, iters, engine kwargs, target, tpar, q0,
+    unit, labels, roofline model."""
+    from walnuts_amd import _lib as L
+    a = args
+    if name in ("gauss100", "dense1000"):
+        big = name == "dense1000"
+        D = 1000 if big else (a.dim if a else 100)
+        kappa = 100.0 if big else (a.kappa if a else 1e4)
+        C = (a.chains if a and a.chains else (1024 if big else 4096))
+        iters = (a.iters if a and a.iters else (50 if big else 100))
+        M, H0 = (a.M if a else 10), (a.H0 if a else 0.5)
+        A, q0 = make_dense_problem(D, kappa, C, SEED, chain_offset=rank * C)
+        ident = bool(a and a.gather == "identity")
+        return dict(name=name, D=D, C=C, iters=iters, target=L.T_DENSEGAUSS, tpar=A, q0=q0, unit="leapfrog steps/s",
+                    eng=dict(integrator=L.I_FIXED, H0=H0, stepSizeRandScale=0.2, M=M,
+                             generated=L.G_IDENTITY if ident else L.G_Q0_SUMSQ), ident=ident,
+                    oracle=dict(integrator=0, H0=H0, M=M),
+                    metric="leapfrog steps/sec across chains, %d-D Gaussian" % D,
+                    workload=f"{D}-D dense Gaussian kappa={kappa:g}, {C} chains/GPU, fixedLeapFrog, M={M}, H0={H0}, {iters} iterations/launch "
+                             f"(SURVEY 8d cfg {4 if big else 2})",
+                    bound="mfma", per_unit=2.0 * D * D + 12.0 * D, cfg=4 if big else 2, pyref="cfg2_dense100_fixedLeapFrog" if not big else None)
+    if name == "funnel":
+        C = a.chains if a and a.chains else 4096
+        iters = a.iters if a and a.iters else 300
+        rng = np.random.default_rng([SEED, 3, rank])
+        q0 = np.zeros((C, 11)); q0[:, 0] = 3.0 * rng.normal(size=C)
+        q0[:, 1:] = np.exp(0.5 * q0[:, :1]) * rng.normal(size=(C, 10))
+        return dict(name=name, D=11, C=C, iters=iters, target=L.T_FUNNEL10, tpar=None, q0=q0, unit="gradient evaluations/s",
+                    eng=dict(integrator=L.I_ADAPT_R2P, H0=0.3, delta0=0.3, M=12, generated=L.G_FIRSTK, gen_k=2), ident=False,
+                    oracle=dict(integrator=L.I_ADAPT_R2P, H0=0.3, delta0=0.3, M=12),
+                    metric="gradient evaluations/sec across chains, funnel10 (adaptLeapFrogR2P)",
+                    workload=f"funnel10 D=11, {C} chains/GPU, adaptLeapFrogR2P, M=12, H0=0.3, delta0=0.3, {iters} iterations/launch (SURVEY 8d cfg 3)",
+                    bound="hbm", per_unit=528.0, cfg=3, traffic_key="funnel", floor_us=FUNNEL_TICK_FLOOR_US, pyref="cfg3_funnel10_R2P")
+    if name == "stockwatson":
+        T, tpar = _sw_data()
+        D = 3 * T
+        C = a.chains if a and a.chains else 256
+        iters = a.iters if a and a.iters else 20
+        ig, H0, minC, nm = {"D": (L.I_ADAPT_D, 0.1, 3, "adaptLeapFrogD minC=3"), "fixed": (L.I_FIXED, 0.002, 0, "fixedLeapFrog"),
+                            "R2P": (L.I_ADAPT_R2P, 0.1, 3, "adaptLeapFrogR2P minC=3")}[sw_run]
+        return dict(name=f"stockwatson_{sw_run}", D=D, C=C, iters=iters, target=L.T_STOCKWATSON, tpar=tpar, q0=np.zeros((C, D)),
+                    unit="gradient evaluations/s",
+                    eng=dict(integrator=ig, H0=H0, delta0=0.3, M=14, minC=minC, generated=L.G_FIRSTK, gen_k=2), ident=False,
+                    oracle=dict(integrator=ig, H0=H0, delta0=0.3, M=14, minC=minC),
+                    metric=f"gradient evaluations/sec across chains, StockWatson ({nm.split()[0]})",
+                    workload=f"StockWatson D={D}, {C} chains/GPU, {nm}, M=14, H0={H0}, delta0=0.3, q0=0, {iters} iterations/launch "
+                             f"(SURVEY 8d cfg 5, mainSW.py:41-80 run '{sw_run}')",
+                    bound="hbm", per_unit=48.0 * D, cfg=5, traffic_key="stockwatson" if sw_run == "D" else None, pyref=None)
+    raise ValueError(name)
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (validated C restatement of the reference's path) on the host cores
+# ---------------------------------------------------------------------------------------------
 def _cpu_worker(args):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
-    A, q0, chain, iters, M, H0 = args
+    target, tpar, q0, chain, iters, okw = args
     t0 = time.perf_counter()
-    o = ol.walnuts(ol.T_DENSEGAUSS, q0, integrator=ol.I_FIXED, tpar=A.ravel(), H0=H0, numIter=iters,
-                   M=M, seed=SEED, chain=chain)
+    o = ol.walnuts(target, q0, tpar=None if tpar is None else np.asarray(tpar).ravel(), numIter=iters, seed=SEED, chain=chain, **okw)
     dt = time.perf_counter() - t0
     d = o["diagnostics"]
     return float(d[:, 6].sum() + d[:, 7].sum()), dt
@@ -66,6 +135,8 @@ def _cpu_worker(args):
 def python_reference_cpu(key):
     """The UNMODIFIED Python reference timed in the build container (tools/ref_cpu_baseline.py; it never travels to the
     GPU box): BASELINE.md section 3's "measured elsewhere" figure, quoted with where it was measured."""
+    if not key:
+        return None
     try:
         j = json.load(open(os.path.join(ROOT, "profiles", "r02_python_reference_cpu.json")))
         r = j[key]
@@ -76,38 +147,87 @@ def python_reference_cpu(key):
         return None
 
 
-def cpu_baseline(A, q0, iters, M, H0, budget_s=12.0):
-    """Time the CPU oracle (the validated C restatement of the reference's path) on the host
-    cores, one chain per process, on a bounded sample of the same workload."""
+def cpu_baseline(spec, budget_s=10.0, max_procs=None):
+    """Time the CPU oracle on the host cores, one chain per process, on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     ol.build()
     cores = os.cpu_count() or 1
-    # calibrate on one chain, one iteration
-    s1, t1 = _cpu_worker((A, q0[0], 0, 1, M, H0))
-    rate1 = s1 / max(t1, 1e-6)
-    per_iter = 540.0 / rate1 if rate1 > 0 else 1.0  # ~540 leapfrog steps per iteration of this workload (SURVEY 8d); only sizes the sample
-    n_it = int(max(1, min(iters, budget_s / max(per_iter, 1e-6))))
-    nchain = min(cores, q0.shape[0])
-    with mp.get_context("fork").Pool(nchain) as pool:
-        pool.map(_cpu_worker, [(A, q0[c], c, 1, 3, H0) for c in range(nchain)])  # start the workers
+    if max_procs:
+        cores = min(cores, max_procs)
+    q0, iters = spec["q0"], spec["iters"]
+    okw = dict(spec["oracle"])
+    s1, t1 = _cpu_worker((spec["target"], spec["tpar"], q0[0], 0, 1, okw))  # calibrate on one chain, one iteration
+    per_iter = max(t1, 1e-5)
+    n_it = int(max(1, min(iters, budget_s / per_iter)))
+    # chains per core: enough of them to fill the budget when a whole run of one chain is shorter than it
+    k = int(max(1, min(budget_s / (n_it * per_iter), (q0.shape[0] + cores - 1) // cores)))
+    nproc = min(cores, q0.shape[0])
+    nchain = min(q0.shape[0], nproc * k)
+    with mp.get_context("fork").Pool(nproc) as pool:
+        pool.map(_cpu_worker, [(spec["target"], spec["tpar"], q0[c], c, 1, dict(okw, M=min(3, okw.get("M", 10)))) for c in range(nproc)])  # start the workers
         t0 = time.perf_counter()
-        res = pool.map(_cpu_worker, [(A, q0[c], c, n_it, M, H0) for c in range(nchain)], chunksize=1)
+        res = pool.map(_cpu_worker, [(spec["target"], spec["tpar"], q0[c], c, n_it, okw) for c in range(nchain)], chunksize=1)
         wall = time.perf_counter() - t0
-    steps = sum(r[0] for r in res)
+    units = sum(r[0] for r in res)
     C_all = q0.shape[0]
-    return {"value": steps / wall, "unit": "leapfrog steps/s", "cores": nchain, "kind": "port",
+    return {"value": units / wall, "unit": spec["unit"], "cores": nproc, "kind": "port",
             "sample": f"the first {nchain} of the {C_all} chains ({100.0 * nchain / C_all:.2f} %) x {n_it} of the {iters} iterations "
-                      f"({steps:.3g} leapfrog steps, {wall:.1f} s), one chain per process (oracle/libwalnuts_oracle.so, the C "
+                      f"({units:.3g} units, {wall:.1f} s), {nproc} worker processes, one chain at a time each (oracle/libwalnuts_oracle.so, the C "
                       f"restatement pinned to the Python reference)",
-            "python_reference": python_reference_cpu("cfg2_dense100_fixedLeapFrog")}
+            "python_reference": python_reference_cpu(spec.get("pyref"))}
 
 
+# ---------------------------------------------------------------------------------------------
+# measured HBM traffic (separate rocprofv3 --pmc passes, tools/prof_traffic.py) of the kernels
+# ---------------------------------------------------------------------------------------------
+def _kernel_base(name):
+    """'void wn::wn_fast_kernel<25, 0, 3>' and 'wn_fast_kernel<KS=25,dense>' -> 'wn_fast_kernel'"""
+    import re
+    m = re.search(r"(wn_\w+?_kernel)", name or "")
+    return m.group(1) if m else (name or "")
+
+
+def headline_traffic(kernel_name, D, C, iters):
+    """bytes per launch of the headline kernel from the newest profiles/rNN_traffic.json that is about this kernel (and,
+    where the file says, this workload); None when there is none."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(f))
+            if _kernel_base(tj.get("kernel", "")) != _kernel_base(kernel_name):
+                continue
+            w = tj.get("workload")
+            if w and (w.get("dim"), w.get("chains"), w.get("iters")) != (D, C, iters):
+                continue
+            return float(tj["bytes_per_launch"]), os.path.basename(f)
+        except Exception:
+            continue
+    return None, None
+
+
+def side_traffic(key, field):
+    import glob
+    if not key:
+        return None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_side.json")), reverse=True):
+        try:
+            rec = json.load(open(f))
+            if key in rec and field in rec[key]:
+                return float(rec[key][field])
+        except Exception:
+            continue
+    return None
+
+
+# ---------------------------------------------------------------------------------------------
 def _self_launch(args):
     """`python bench.py --gpus N` without torchrun: this process has not touched torch or HIP yet, so it
     may start children.  Starts one fresh child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the
     same command line), after one single-GPU child of the same workload whose value becomes the N = 1
-    reference of `weak_scaling_eff`; relays rank 0's JSON line and exits with the worst child's code."""
+    reference of `weak_scaling_eff`; relays rank 0's JSON line.  Every child is polled: the first one that
+    exits non-zero (or the time limit) ends the others -- a crashed rank would otherwise leave its siblings in
+    init_process_group / all_reduce until the collective's own timeout -- and the parent exits non-zero."""
     import socket
     import subprocess
     n = args.gpus
@@ -117,268 +237,51 @@ def _self_launch(args):
     base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     if not args.no_n1_ref:
-        r = subprocess.run(argv + ["--gpus", "1", "--no-extras", "--no-cpu-baseline"], env=dict(base, WN_BENCH_CHILD="1"),
-                           stdout=subprocess.PIPE, text=True)
-        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        if r.returncode == 0 and lines:
-            base["WN_BENCH_N1_VALUE"] = repr(float(json.loads(lines[-1])["value"]))
-        else:
-            print(f"bench.py: the N=1 reference run failed (rc {r.returncode}); continuing without it", file=sys.stderr)
+        try:
+            r = subprocess.run(argv + ["--gpus", "1", "--no-extras", "--no-cpu-baseline"], env=dict(base, WN_BENCH_CHILD="1"),
+                               stdout=subprocess.PIPE, text=True, timeout=args.child_timeout)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode == 0 and lines:
+                base["WN_BENCH_N1_VALUE"] = repr(float(json.loads(lines[-1])["value"]))
+            else:
+                print(f"bench.py: the N=1 reference run failed (rc {r.returncode}); continuing without it", file=sys.stderr)
+        except subprocess.TimeoutExpired:
+            print("bench.py: the N=1 reference run timed out; continuing without it", file=sys.stderr)
     procs = []
     for rank in range(n):
         env = dict(base, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), WN_BENCH_CHILD="1")
         procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if rank == 0 else sys.stderr, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p_.wait() for p_ in procs[1:]]
+    deadline = time.monotonic() + args.child_timeout
+    bad = None
+    while True:
+        rcs = [p_.poll() for p_ in procs]
+        failed = [(k, rc) for k, rc in enumerate(rcs) if rc not in (None, 0)]
+        if failed:
+            bad = failed[0]
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() > deadline:
+            bad = (-1, 124)
+            break
+        time.sleep(0.05)
+    if bad is not None:
+        for p_ in procs:  # fresh children only ever: nothing that touched a GPU is re-executed, the survivors are just ended
+            if p_.poll() is None:
+                p_.terminate()
+        t_end = time.monotonic() + 5.0
+        for p_ in procs:
+            try:
+                p_.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p_.kill()
+        print(f"bench.py: rank {bad[0]} exited with code {bad[1]}; the other ranks were ended" if bad[0] >= 0
+              else f"bench.py: the ranks did not finish within {args.child_timeout:.0f} s and were ended", file=sys.stderr)
+        sys.exit(abs(bad[1]) or 1)
+    out0 = procs[0].stdout.read()
     sys.stdout.write(out0)
     sys.stdout.flush()
-    sys.exit(max(abs(rc) for rc in rcs))
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--chains", type=int, default=4096, help="chains per GPU")
-    ap.add_argument("--iters", type=int, default=100, help="sampler iterations per launch")
-    ap.add_argument("--dim", type=int, default=100)
-    ap.add_argument("--kappa", type=float, default=1e4)
-    ap.add_argument("--M", type=int, default=10)
-    ap.add_argument("--H0", type=float, default=0.5)
-    ap.add_argument("--workload", default="gauss100", choices=["gauss100", "funnel", "dense1000", "stockwatson"],
-                    help="gauss100 = BASELINE configs[1] family (headline); funnel = configs[2] "
-                         "(funnel10, adaptLeapFrogR2P, M=12, H0=0.3, delta0=0.3; SURVEY 8d cfg 3)")
-    ap.add_argument("--sw-run", default="D", choices=["D", "fixed", "R2P"],
-                    help="stockwatson workload: which of mainSW.py:41-80's three runs (adaptLeapFrogD minC=3 H0=0.1 | "
-                         "fixedLeapFrog H0=0.002 | adaptLeapFrogR2P minC=3 H0=0.1)")
-    ap.add_argument("--no-extras", action="store_true",
-                    help="skip the SURVEY 8d side measurements (C=1024, diagonal-precision variant)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-n1-ref", action="store_true",
-                    help="self-launched --gpus N > 1: skip the single-GPU run that weak_scaling_eff refers to")
-    ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per launch from a separate rocprofv3 --pmc pass (see profiles/)")
-    args = ap.parse_args()
-    if args.gpus < 1:
-        ap.error("--gpus must be >= 1")
-    if "WORLD_SIZE" not in os.environ:
-        if args.gpus > 1:
-            return _self_launch(args)  # never returns
-    elif int(os.environ["WORLD_SIZE"]) != args.gpus and "WN_BENCH_CHILD" not in os.environ:
-        ap.error(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.workload == "funnel":
-        return main_funnel(args)
-    if args.workload == "stockwatson":
-        return main_stockwatson(args)
-    if args.workload == "dense1000":  # SURVEY 8d cfg 4: one GPU's shard (1024 chains) of the 8192-chain job
-        args.dim, args.kappa, args.no_extras = 1000, 100.0, True
-        if args.chains == 4096:
-            args.chains = 1024
-        if args.iters == 100:
-            args.iters = 50
-    C, D = args.chains, args.dim
-    offset = rank * C
-    A, q0 = make_dense_problem(D, args.kappa, C, SEED, chain_offset=offset)
-    cpu = None
-    if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(A, q0, args.iters, args.M, args.H0)  # forks workers: before any GPU init
-
-    import torch
-    rank, world, dev, cdev, dist = _dist_setup()
-
-    import walnuts_amd as wa
-    from walnuts_amd import _lib as L
-
-    eng = wa.Engine(D, C, integrator=L.I_FIXED, H0=args.H0, stepSizeRandScale=0.2, M=args.M,
-                    generated=L.G_Q0_SUMSQ, chain_offset=offset, device=dev.index)
-    eng.set_target(L.T_DENSEGAUSS, A)
-    q0d = torch.as_tensor(q0, device=dev)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    warm_steps = torch.zeros((), dtype=torch.float64, device=dev)
-    for w in range(max(args.warmup, 1) if args.warmup else 0):
-        _, dw = eng.run(q0d, SEED + 1000 + w, args.iters)
-        warm_steps += dw[:, :, 6].sum() + dw[:, :, 7].sum()  # also loads torch's reduction kernels outside the timed region
-    if not args.warmup:  # (first use of a torch kernel costs ~90 ms of code loading)
-        warm_steps += torch.zeros((2, 2, 8), dtype=torch.float64, device=dev)[:, :, 6].sum()
-    barrier()
-    t0 = time.perf_counter()
-    total_steps = torch.zeros((), dtype=torch.float64, device=dev)
-    kernel_ms = []
-    last = None
-    for k in range(args.steps):
-        samples, diag = eng.run(q0d, SEED + k, args.iters)
-        total_steps += diag[:, :, 6].sum() + diag[:, :, 7].sum()
-        kernel_ms.append(eng.last_run_ms())  # HIP events on the launch stream (synchronises)
-        last = samples
-    barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-    total_steps = total_steps.to(cdev).reshape(1)
-    total_steps_rank = float(total_steps.item())
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(total_steps, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    steps_all = float(total_steps.item())
-    scal = _scaling_fields(dist, world, cdev, steps_all / elapsed, float(np.mean(kernel_ms)), float(total_steps_rank))
-
-    # final gather of draws to rank 0 (the only data collective; RCCL over xGMI), timed apart
-    gather_ms = 0.0
-    draws = last
-    if world > 1:
-        from walnuts_amd.dist import gather_draws
-        torch.cuda.synchronize(dev)
-        g0 = time.perf_counter()
-        draws = gather_draws(last.to(cdev), dst=0)
-        torch.cuda.synchronize(dev)
-        gather_ms = (time.perf_counter() - g0) * 1e3
-
-    if rank == 0:
-        traffic = args.traffic_bytes
-        if traffic is None:  # PMC traffic of this exact workload, measured in a separate rocprofv3 pass
-            try:
-                for name in ("r02_traffic.json", "r01_traffic.json"):
-                    tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-                    w = tj["workload"]
-                    if (w["dim"], w["chains"], w["iters"]) == (D, C, args.iters) and w["kernel"] == eng.kernel_name:
-                        traffic = tj["bytes_per_launch"]
-                        break
-            except Exception:
-                traffic = None
-            if traffic is None and D == 1000 and "split" in eng.kernel_name:
-                bps = _side_traffic("dense1000", "bytes_per_leapfrog_step")
-                traffic = None if bps is None else bps * steps_all / world / args.steps
-        flop_per_step = 2.0 * D * D + 12.0 * D  # matvec + leapfrog updates + 2 dots
-        avg_ms = float(np.mean(kernel_ms))
-        steps_per_launch_rank0 = steps_all / world / args.steps
-        achieved = steps_per_launch_rank0 * flop_per_step / (avg_ms * 1e-3) / 1e12
-        out = {
-            "metric": "leapfrog steps/sec across chains, 100-D Gaussian",
-            "value": steps_all / elapsed,
-            "unit": "leapfrog steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"{D}-D dense Gaussian kappa={args.kappa:g}, {C} chains/GPU, "
-                                   f"fixedLeapFrog, M={args.M}, H0={args.H0}, {args.iters} iterations/launch "
-                                   f"(SURVEY 8d cfg {4 if D >= 1000 else 2})",
-                       "chains_per_gpu": C, "dim": D, "iters_per_step": args.iters,
-                       "kernel": eng.kernel_name, "sharding": f"chains x{world}, no data-path collective"},
-            "leapfrog_steps_per_launch_per_gpu": steps_per_launch_rank0,
-            "kernel_ms_avg": avg_ms,
-            "gather_ms": gather_ms,
-            **scal,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": traffic,
-                         "flop_per_leapfrog_step": flop_per_step},
-        }
-        # ESS/sec of gen(q) = [q[0], sum(q*q)] (mainGaussESS.py:29-30) over all chains of the last
-        # launch; rank-normalised split bulk ESS (walnuts_amd/ess.py), host side, outside the timing
-        try:
-            from walnuts_amd.ess import ess
-            dr = draws.cpu().numpy()
-            e0, e1 = ess(dr[:, 1:, 0]), ess(dr[:, 1:, 1])
-            per_launch_s = elapsed / args.steps
-            out["ess_per_sec"] = {"q0": e0 / per_launch_s, "sum_q2": e1 / per_launch_s,
-                                  "ess_q0": e0, "ess_sum_q2": e1,
-                                  "draws": int(dr.shape[0] * (dr.shape[1] - 1)),
-                                  "method": "rank-normalised split bulk ESS over all chains of one launch"}
-        except Exception as ex:  # the throughput line must not depend on the ESS estimator
-            out["ess_per_sec"] = {"error": repr(ex)}
-        if world == 1 and not args.no_extras and args.workload == "gauss100":
-            # SURVEY 8d cfg 2 side numbers, one launch each, outside the timed region:
-            # BASELINE configs[1]'s chain count (1024) and the diagonal-precision variant (HBM-style target)
-            extras = {}
-            try:
-                e2 = wa.Engine(D, 1024, integrator=L.I_FIXED, H0=args.H0, stepSizeRandScale=0.2, M=args.M,
-                               generated=L.G_Q0_SUMSQ, device=dev.index).set_target(L.T_DENSEGAUSS, A)
-                e2.run(q0d[:1024], SEED + 77, args.iters)
-                s2, d2 = e2.run(q0d[:1024], SEED, args.iters)
-                st = float((d2[:, :, 6].sum() + d2[:, :, 7].sum()).item())
-                extras["dense_1024_chains"] = {"value": st / (e2.last_run_ms() * 1e-3), "unit": "leapfrog steps/s"}
-                e2.close()
-                lam = np.logspace(0.0, np.log10(args.kappa), D)
-                e3 = wa.Engine(D, C, integrator=L.I_FIXED, H0=args.H0, stepSizeRandScale=0.2, M=args.M,
-                               generated=L.G_Q0_SUMSQ, device=dev.index).set_target(L.T_DIAGGAUSS, 1.0 / lam)
-                qd = torch.as_tensor(np.random.default_rng([SEED, 9]).normal(size=(C, D)) * np.sqrt(lam), device=dev)
-                e3.run(qd, SEED + 77, args.iters)
-                s3, d3 = e3.run(qd, SEED, args.iters)
-                st = float((d3[:, :, 6].sum() + d3[:, :, 7].sum()).item())
-                ms3 = e3.last_run_ms()
-                extras["diag_variant"] = {"value": st / (ms3 * 1e-3), "unit": "leapfrog steps/s", "kernel": e3.kernel_name,
-                                          "hbm_roofline_GBps_at_48D_bytes_per_step": st * 48.0 * D / (ms3 * 1e-3) / 1e9}
-                e3.close()
-            except Exception as ex:
-                extras["error"] = repr(ex)
-            # the other BASELINE configs, one short launch each (outside the timed region; the full lines
-            # are `--workload funnel | dense1000 | stockwatson`)
-            try:
-                extras["other_configs"] = side_configs(wa, L, torch, dev)
-            except Exception as ex:
-                extras["other_configs"] = {"error": repr(ex)}
-            out["extras"] = extras
-        if cpu is not None:
-            out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
-def side_configs(wa, L, torch, dev):
-    """One launch each of BASELINE configs 3, 4 (one GPU's shard) and 5 (one GPU's shard)."""
-    res = {}
-    rng = np.random.default_rng([SEED, 3])
-    C = 4096
-    q0 = np.zeros((C, 11)); q0[:, 0] = 3.0 * rng.normal(size=C)
-    q0[:, 1:] = np.exp(0.5 * q0[:, :1]) * rng.normal(size=(C, 10))
-    e = wa.Engine(11, C, integrator=L.I_ADAPT_R2P, H0=0.3, delta0=0.3, M=12, generated=L.G_FIRSTK, gen_k=2,
-                  device=dev.index).set_target(L.T_FUNNEL10)
-    e.run(torch.as_tensor(q0, device=dev), SEED + 1, 2)  # untimed first launch (code load)
-    s, d = e.run(torch.as_tensor(q0, device=dev), SEED, 30)
-    ev = float((d[:, :, 6] + d[:, :, 7]).sum().item())
-    res["note"] = ("one SHORT launch each, outside the timed region (iteration counts below, not SURVEY 8d's): a smoke reading only; "
-                   "the contract lines of these configurations are `bench.py --workload funnel | dense1000 | stockwatson` "
-                   "(profiles/r02_bench_*.json)")
-    res["cfg3_funnel10_R2P_4096_chains"] = {"value": ev / (e.last_run_ms() * 1e-3), "unit": "gradient evaluations/s",
-                                            "kernel": e.kernel_name, "iterations": 30}
-    e.close()
-    A, q1 = make_dense_problem(1000, 100.0, 1024, SEED)
-    e = wa.Engine(1000, 1024, integrator=L.I_FIXED, H0=0.5, M=10, generated=L.G_Q0_SUMSQ, device=dev.index)
-    e.set_target(L.T_DENSEGAUSS, A)
-    e.run(torch.as_tensor(q1, device=dev), SEED + 1, 2)
-    s, d = e.run(torch.as_tensor(q1, device=dev), SEED, 30)
-    st = float((d[:, :, 6] + d[:, :, 7]).sum().item()); ms = e.last_run_ms()
-    res["cfg4_dense1000_1024_chains"] = {"value": st / (ms * 1e-3), "unit": "leapfrog steps/s", "kernel": e.kernel_name, "iterations": 30,
-                                         "fp64_mfma_frac": st * (2.0e6 + 12.0e3) / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
-    e.close()
-    sw = np.load(os.path.join(ROOT, "tests", "golden", "stockwatson_data.npz"))
-    T = int(sw["T"][0])
-    e = wa.Engine(3 * T, 256, integrator=L.I_ADAPT_D, H0=0.1, delta0=0.3, M=14, minC=3, generated=L.G_FIRSTK, gen_k=2,
-                  device=dev.index).set_target(L.T_STOCKWATSON, np.concatenate([[float(T)], sw["y"]]))
-    e.run(torch.zeros((256, 3 * T), dtype=torch.float64, device=dev), SEED + 1, 1)
-    s, d = e.run(torch.zeros((256, 3 * T), dtype=torch.float64, device=dev), SEED, 10)
-    ev = float((d[:, :, 6] + d[:, :, 7]).sum().item())
-    res["cfg5_stockwatson_adaptD_256_chains"] = {"value": ev / (e.last_run_ms() * 1e-3), "unit": "gradient evaluations/s",
-                                                 "kernel": e.kernel_name, "iterations": 10}
-    e.close()
-    return res
+    sys.exit(0)
 
 
 def _dist_setup():
@@ -388,12 +291,19 @@ def _dist_setup():
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     backend = os.environ.get("WN_DIST_BACKEND", "nccl")
-    if torch.cuda.device_count() < 1:
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
         sys.exit("bench.py needs a ROCm GPU (the product has no CPU path)")
     if world > 1:
+        if backend == "nccl" and local_rank >= ndev:
+            print(f"bench.py: LOCAL_RANK {local_rank} but only {ndev} device(s) are visible", file=sys.stderr)
+            sys.exit(2)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        torch.cuda.set_device(local_rank % ndev)
+        fail = os.environ.get("WN_BENCH_FAIL_RANK")  # test hook: this rank dies before the rendezvous (tests/test_host_logic.py)
+        if fail is not None and int(fail) == rank:
+            sys.exit(3)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -422,138 +332,335 @@ def _scaling_fields(dist, world, cdev, value, kernel_ms_avg, units_rank):
     return out
 
 
-def _side_traffic(key, field):
+# ---------------------------------------------------------------------------------------------
+# the measurement core: W untimed + K timed launches of one workload on this rank's GPU
+# ---------------------------------------------------------------------------------------------
+def make_engine(spec, dev, rank):
+    import walnuts_amd as wa
+    e = wa.Engine(spec["D"], spec["C"], chain_offset=rank * spec["C"], device=dev.index, **spec["eng"])
+    return e.set_target(spec["target"], spec["tpar"])
+
+
+def timed_launches(eng, spec, dev, steps, warmup, barrier):
+    """-> dict(elapsed, units (this rank), kernel_ms [...], per_launch_units [...], busiest [...], ticks [...], draws)"""
+    import torch
+    q0d = torch.as_tensor(spec["q0"], device=dev)
+    for w in range(warmup):
+        _, dw = eng.run(q0d, SEED + 1000 + w, spec["iters"])
+        float((dw[:, :, 6] + dw[:, :, 7]).sum(1).max().item())  # also loads torch's reduction kernels outside the timed region
+    if not warmup:  # (first use of a torch kernel costs ~90 ms of code loading)
+        float(torch.zeros((2, 2, 8), dtype=torch.float64, device=dev)[:, :, 6].sum(1).max().item())
+    barrier()
+    t0 = time.perf_counter()
+    tot = torch.zeros((), dtype=torch.float64, device=dev)
+    per = []; kms = []; ticks = []
+    last = None
+    for k in range(steps):
+        s, d = eng.run(q0d, SEED + k, spec["iters"])
+        pc = (d[:, :, 6] + d[:, :, 7]).sum(1)
+        per.append(pc)
+        tot += pc.sum()
+        kms.append(eng.last_run_ms())  # HIP events on the launch stream (synchronises)
+        ticks.append(eng.last_split_ticks())
+        last = s
+    barrier()
+    el = time.perf_counter() - t0
+    return dict(elapsed=el, units=float(tot.item()), kernel_ms=kms, per_launch_units=[float(p_.sum().item()) for p_ in per],
+                busiest=[float(p_.max().item()) for p_ in per], ticks=ticks, draws=last)
+
+
+def roofline_of(spec, units_per_launch, avg_ms, kernel_name, steps_info=None):
+    """SURVEY 8d's roofline record of one workload (achieved = algorithmic bytes or flop per launch / launch duration)."""
+    if spec["bound"] == "mfma":
+        ach = units_per_launch * spec["per_unit"] / (avg_ms * 1e-3) / 1e12
+        traffic, src = headline_traffic(kernel_name, spec["D"], spec["C"], spec["iters"])
+        if traffic is None and spec["name"] == "dense1000":
+            bps = side_traffic("dense1000", "bytes_per_leapfrog_step")
+            traffic = None if bps is None else bps * units_per_launch
+            src = "profiles/r*_traffic_side.json (bytes per leapfrog step x steps)" if traffic is not None else None
+        return {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                "traffic": traffic, "traffic_source": src, "flop_per_leapfrog_step": spec["per_unit"]}
+    ach = units_per_launch * spec["per_unit"] / (avg_ms * 1e-3) / 1e9
+    bpe = side_traffic(spec.get("traffic_key"), "bytes_per_gradient_evaluation")
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            # `achieved` is SURVEY 8d's NOMINAL streaming figure (48*D bytes per evaluation); the fused kernel keeps its state
+            # on chip, so beside it: the measured HBM rate (PMC bytes), the FP64-vector fraction at 14*D flop per evaluation
+            # (SURVEY 8d) and -- what actually bounds these launches -- the serial time per evaluation of the busiest chain
+            "measured_hbm_GBps": None if bpe is None else bpe * units_per_launch / (avg_ms * 1e-3) / 1e9,
+            "fp64_vector_frac": units_per_launch * 14.0 * spec["D"] / (avg_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            "traffic": None if bpe is None else bpe * units_per_launch,
+            "bytes_per_gradient_evaluation": spec["per_unit"]}
+
+
+def ess_of(spec, draws, per_launch_s):
+    """ESS/sec of gen(q) = [q[0], sum(q*q)] (mainGaussESS.py:29-30; for the first-k kinds: of q[0] and q[1]) over all chains
+    of one launch; rank-normalised split bulk ESS (walnuts_amd/ess.py), host side, outside the timing."""
     try:
-        for name in ("r02_traffic_side.json", "r01_traffic_side.json"):
-            f = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(f):
-                rec = json.load(open(f))
-                if key in rec and field in rec[key]:
-                    return float(rec[key][field])
-        return None
-    except Exception:
-        return None
+        from walnuts_amd.ess import ess
+        dr = draws.cpu().numpy()
+        if spec.get("ident"):
+            dr = np.stack([dr[:, :, 0], (dr * dr).sum(2)], axis=2)
+        e0, e1 = ess(dr[:, 1:, 0]), ess(dr[:, 1:, 1])
+        names = ("q0", "sum_q2") if spec["bound"] == "mfma" else ("q0", "q1")
+        return {names[0]: e0 / per_launch_s, names[1]: e1 / per_launch_s, "ess_" + names[0]: e0, "ess_" + names[1]: e1,
+                "draws": int(dr.shape[0] * (dr.shape[1] - 1)), "method": "rank-normalised split bulk ESS over all chains of one launch"}
+    except Exception as ex:  # the throughput line must not depend on the ESS estimator
+        return {"error": repr(ex)}
 
 
-def _run_evals_workload(args, make_engine, q0_of, metric, workload, bytes_per_eval, traffic_key=None):
-    """Common driver of the gradient-evaluation workloads (configs 3 and 5): chains shard over ranks with no
-    data-path collective; barrier + synchronize around exactly `steps` launches; max time over ranks."""
+def side_record(spec, m, kernel_name, cpu):
+    """min / median / max over the timed launches of one side configuration + its roofline, CPU baseline, ESS/s"""
+    vals = [u / (ms * 1e-3) for u, ms in zip(m["per_launch_units"], m["kernel_ms"])]
+    avg_ms = float(np.mean(m["kernel_ms"]))
+    upl = float(np.mean(m["per_launch_units"]))
+    rec = {"value": float(np.median(vals)), "min": float(np.min(vals)), "max": float(np.max(vals)), "unit": spec["unit"],
+           "launches": len(vals), "launch_values": vals, "kernel_ms": m["kernel_ms"], "workload": spec["workload"], "kernel": kernel_name,
+           "roofline": roofline_of(spec, upl, avg_ms, kernel_name), "ess_per_sec": ess_of(spec, m["draws"], avg_ms * 1e-3)}
+    if spec["bound"] == "hbm":
+        bus = float(np.mean(m["busiest"]))
+        rec.update({"busiest_chain_evals": bus, "chain_occupancy": upl / spec["C"] / bus, "tick_us": avg_ms * 1e3 / bus})
+        if spec.get("floor_us"):
+            rec["tick_over_floor"] = rec["tick_us"] / spec["floor_us"]
+    if any(m["ticks"]):
+        tk = float(np.mean(m["ticks"]))
+        rec.update({"split_ticks_per_launch": tk, "tick_us": avg_ms * 1e3 / tk, "kernel_launches_per_s": 2.0 * tk / (avg_ms * 1e-3),
+                    "fp64_mfma_frac": rec["roofline"]["frac"]})
+    if cpu is not None:
+        rec["cpu_baseline"] = cpu
+    return rec
+
+
+# ---------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's SURVEY 8d size)")
+    ap.add_argument("--iters", type=int, default=0, help="sampler iterations per launch (default: SURVEY 8d's)")
+    ap.add_argument("--dim", type=int, default=100)
+    ap.add_argument("--kappa", type=float, default=1e4)
+    ap.add_argument("--M", type=int, default=10)
+    ap.add_argument("--H0", type=float, default=0.5)
+    ap.add_argument("--workload", default="gauss100", choices=["gauss100", "funnel", "dense1000", "stockwatson", "walnuts10"],
+                    help="gauss100 = BASELINE configs[1] family (headline); funnel / dense1000 / stockwatson = configs 3 / 4 / 5 "
+                         "(SURVEY 8d); walnuts10 = configs[0]'s target through walnuts_batch")
+    ap.add_argument("--sw-run", default="D", choices=["D", "fixed", "R2P"],
+                    help="stockwatson workload: which of mainSW.py:41-80's three runs (adaptLeapFrogD minC=3 H0=0.1 | "
+                         "fixedLeapFrog H0=0.002 | adaptLeapFrogR2P minC=3 H0=0.1)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the side measurements (BASELINE configs 3, 4, 5 at SURVEY 8d size; C = 1024; diagonal precision)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-n1-ref", action="store_true",
+                    help="self-launched --gpus N > 1: skip the single-GPU run that weak_scaling_eff refers to")
+    ap.add_argument("--gather", default="generated", choices=["generated", "identity"],
+                    help="what the final gather moves: generated(q) = [q0, sum q^2] (kilobytes) or the identity draws "
+                         "(SURVEY 8e: 0.83 GB per GPU for config 4 at 100 iterations)")
+    ap.add_argument("--child-timeout", type=float, default=1800.0, help="self-launched ranks: seconds before they are ended")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="ranks only rendezvous (gloo), reduce and gather a small tensor and print a line: the launcher's own test, no GPU")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch from a separate rocprofv3 --pmc pass (see profiles/)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            return _self_launch(args)  # never returns
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus and "WN_BENCH_CHILD" not in os.environ:
+        ap.error(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+    if args.dry_run:
+        return main_dry_run()
+    if args.workload == "walnuts10":
+        return main_walnuts10(args)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    spec = workload_spec(args.workload, args, rank, args.sw_run)
+    headline = args.workload == "gauss100"
+    extras_on = headline and world == 1 and not args.no_extras
+    side_specs = []
+    if extras_on:
+        side_specs = [workload_spec("funnel"), workload_spec("dense1000"), workload_spec("stockwatson", sw_run="D"),
+                      workload_spec("stockwatson", sw_run="fixed"), workload_spec("stockwatson", sw_run="R2P")]
+    cpu = None
+    side_cpu = {}
+    if world == 1 and not args.no_cpu_baseline:  # forks workers: before any GPU init
+        t_ = time.perf_counter()
+        cpu = cpu_baseline(spec, 12.0)
+        for sp in side_specs:  # (a bounded sample on at most 64 worker processes each: the default run must stay within minutes)
+            try:
+                side_cpu[sp["name"]] = cpu_baseline(sp, 3.0, max_procs=64)
+            except Exception as ex:
+                side_cpu[sp["name"]] = {"error": repr(ex)}
+        print(f"bench.py: CPU baselines took {time.perf_counter() - t_:.1f} s", file=sys.stderr)
+
     import torch
     rank, world, dev, cdev, dist = _dist_setup()
-    eng, C = make_engine(rank, dev)
-    q0d = torch.as_tensor(q0_of(rank, C), device=dev)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for w in range(args.warmup):
-        _, dw = eng.run(q0d, SEED + 1000 + w, args.iters)
-        float((dw[:, :, 6] + dw[:, :, 7]).sum(1).max().item())  # loads torch's reduction kernels outside the timed region
-    if not args.warmup:
-        float(torch.zeros((2, 2, 8), dtype=torch.float64, device=dev)[:, :, 6].sum(1).max().item())
-    barrier()
-    t0 = time.perf_counter()
-    tot = 0.0; kms = []; mx = []
-    for k in range(args.steps):
-        s, d = eng.run(q0d, SEED + k, args.iters)
-        per_chain = (d[:, :, 6] + d[:, :, 7]).sum(1)
-        tot += float(per_chain.sum().item())
-        mx.append(float(per_chain.max().item()))
-        kms.append(eng.last_run_ms())
-    barrier()
-    el = time.perf_counter() - t0
-    t = torch.tensor([el, tot], dtype=torch.float64, device=cdev)
+    t_ = time.perf_counter()
+    eng = make_engine(spec, dev, rank)
+    m = timed_launches(eng, spec, dev, args.steps, args.warmup, barrier)
+    print(f"bench.py: rank {rank}: GPU set-up + {args.warmup} + {args.steps} launches took {time.perf_counter() - t_:.1f} s", file=sys.stderr)
+    elapsed = m["elapsed"]
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    tot = torch.tensor([m["units"]], dtype=torch.float64, device=cdev)
     if world > 1:
-        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        el, tot_all = float(tmax[0].item()), float(t[1].item())
-    else:
-        tot_all = tot
-    scal = _scaling_fields(dist, world, cdev, tot_all / el, float(np.mean(kms)), tot)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    units_all = float(tot.item())
+    avg_ms = float(np.mean(m["kernel_ms"]))
+    scal = _scaling_fields(dist, world, cdev, units_all / elapsed, avg_ms, m["units"])
+
+    # final gather of draws to rank 0 (the only data collective; RCCL over xGMI), timed apart
+    gather_ms = 0.0
+    gather_bytes = 0
+    draws = m["draws"]
+    if world > 1:
+        from walnuts_amd.dist import gather_draws
+        torch.cuda.synchronize(dev)
+        g0 = time.perf_counter()
+        mine = m["draws"].to(cdev)
+        draws = gather_draws(mine, dst=0)
+        torch.cuda.synchronize(dev)
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        gather_bytes = int(mine.numel() * mine.element_size())
+
     if rank == 0:
-        ach = tot / args.steps * bytes_per_eval / (np.mean(kms) * 1e-3) / 1e9  # rank 0's kernel
-        print(json.dumps({"metric": metric, "value": tot_all / el, "unit": "gradient evaluations/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-                          "data": "synthetic",
-                          "config": {"workload": workload(C), "kernel": eng.kernel_name, "chains_per_gpu": C,
-                                     "sharding": f"chains x{world}, no data-path collective"},
-                          "kernel_ms_avg": float(np.mean(kms)), **scal,
-                          # a launch lasts as long as its busiest chain (that chain's evaluations are sequential)
-                          "busiest_chain_evals": float(np.mean(mx)),
-                          "chain_occupancy": tot / args.steps / C / float(np.mean(mx)),
-                          "tick_us": float(np.mean(kms)) * 1e3 / float(np.mean(mx)),
-                          "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": ach / HBM_PEAK_GBS,
-                                       # `achieved` is SURVEY 8d's NOMINAL streaming figure (48*D bytes per evaluation); the fused
-                                       # kernel keeps its state on chip, so beside it: the measured HBM rate (PMC bytes) and the
-                                       # FP64-vector fraction at 14*D flop per evaluation (SURVEY 8d)
-                                       "measured_hbm_GBps": (None if traffic_key is None or _side_traffic(traffic_key, "bytes_per_gradient_evaluation") is None
-                                                             else _side_traffic(traffic_key, "bytes_per_gradient_evaluation") * tot / args.steps / (np.mean(kms) * 1e-3) / 1e9),
-                                       "fp64_vector_frac": tot / args.steps * 14.0 * (bytes_per_eval / 48.0) / (np.mean(kms) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                                       # measured HBM bytes of one launch of rank 0 (PMC bytes per evaluation x evaluations)
-                                       "traffic": (None if traffic_key is None or _side_traffic(traffic_key, "bytes_per_gradient_evaluation") is None
-                                                   else _side_traffic(traffic_key, "bytes_per_gradient_evaluation") * tot / args.steps),
-                                       "bytes_per_gradient_evaluation": bytes_per_eval}}), flush=True)
+        upl = units_all / world / args.steps  # units of one launch of one rank
+        roof = roofline_of(spec, upl, avg_ms, eng.kernel_name)
+        if args.traffic_bytes is not None:
+            roof["traffic"] = args.traffic_bytes
+        out = {
+            "metric": spec["metric"], "value": units_all / elapsed, "unit": spec["unit"], "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": spec["workload"], "chains_per_gpu": spec["C"], "dim": spec["D"], "iters_per_step": spec["iters"],
+                       "kernel": eng.kernel_name, "sharding": f"chains x{world}, no data-path collective"},
+            ("leapfrog_steps_per_launch_per_gpu" if spec["bound"] == "mfma" else "gradient_evaluations_per_launch_per_gpu"): upl,
+            "kernel_ms_avg": avg_ms, "kernel_ms": m["kernel_ms"], "gather_ms": gather_ms, "gather_bytes_per_rank": gather_bytes,
+            **scal, "roofline": roof,
+        }
+        if not headline:
+            out.update({k: v for k, v in side_record(spec, m, eng.kernel_name, None).items()
+                        if k in ("min", "max", "launch_values", "busiest_chain_evals", "chain_occupancy", "tick_us", "tick_over_floor",
+                                 "split_ticks_per_launch", "kernel_launches_per_s")})
+        out["ess_per_sec"] = ess_of(spec, draws, elapsed / args.steps)
+        import hashlib
+        out["draws_sha256"] = hashlib.sha256(np.ascontiguousarray(draws.cpu().numpy()).tobytes()).hexdigest()  # of the gathered draws [C_total, iters+1, dg]
+        eng.close()
+        if extras_on:
+            import walnuts_amd as wa
+            from walnuts_amd import _lib as L
+            extras = {}
+            try:
+                # SURVEY 8d cfg 2 side numbers, one launch each: BASELINE configs[1]'s literal chain count (1024) and the
+                # diagonal-precision variant (HBM-style target)
+                D, C = spec["D"], spec["C"]
+                q0d = torch.as_tensor(spec["q0"], device=dev)
+                e2 = wa.Engine(D, 1024, integrator=L.I_FIXED, H0=args.H0, stepSizeRandScale=0.2, M=args.M,
+                               generated=L.G_Q0_SUMSQ, device=dev.index).set_target(L.T_DENSEGAUSS, spec["tpar"])
+                e2.run(q0d[:1024], SEED + 77, spec["iters"])
+                s2, d2 = e2.run(q0d[:1024], SEED, spec["iters"])
+                st = float((d2[:, :, 6].sum() + d2[:, :, 7].sum()).item())
+                extras["dense_1024_chains"] = {"value": st / (e2.last_run_ms() * 1e-3), "unit": "leapfrog steps/s", "kernel": e2.kernel_name}
+                e2.close()
+                lam = np.logspace(0.0, np.log10(args.kappa), D)
+                e3 = wa.Engine(D, C, integrator=L.I_FIXED, H0=args.H0, stepSizeRandScale=0.2, M=args.M,
+                               generated=L.G_Q0_SUMSQ, device=dev.index).set_target(L.T_DIAGGAUSS, 1.0 / lam)
+                qd = torch.as_tensor(np.random.default_rng([SEED, 9]).normal(size=(C, D)) * np.sqrt(lam), device=dev)
+                e3.run(qd, SEED + 77, spec["iters"])
+                s3, d3 = e3.run(qd, SEED, spec["iters"])
+                st = float((d3[:, :, 6].sum() + d3[:, :, 7].sum()).item())
+                ms3 = e3.last_run_ms()
+                extras["diag_variant"] = {"value": st / (ms3 * 1e-3), "unit": "leapfrog steps/s", "kernel": e3.kernel_name,
+                                          "hbm_roofline_GBps_at_48D_bytes_per_step": st * 48.0 * D / (ms3 * 1e-3) / 1e9}
+                e3.close()
+            except Exception as ex:
+                extras["error"] = repr(ex)
+            # BASELINE configs 3, 4 (one GPU's shard), 5 (one GPU's shard; all three runs of mainSW.py:41-80) at SURVEY 8d's
+            # sizes: one untimed + three timed launches each
+            oc = {"note": "SURVEY 8d sizes, 1 untimed + 3 timed launches each, outside the headline's timed region; value = median of the "
+                          "per-launch rates (units of a launch / its HIP-event time on the launch stream)"}
+            for sp in side_specs:
+                t_ = time.perf_counter()
+                try:
+                    e = make_engine(sp, dev, 0)
+                    ms_ = timed_launches(e, sp, dev, 3, 1, lambda: torch.cuda.synchronize(dev))
+                    oc[f"cfg{sp['cfg']}_{sp['name']}"] = side_record(sp, ms_, e.kernel_name, side_cpu.get(sp["name"]))
+                    e.close()
+                except Exception as ex:
+                    oc[f"cfg{sp['cfg']}_{sp['name']}"] = {"error": repr(ex)}
+                print(f"bench.py: side configuration {sp['name']} took {time.perf_counter() - t_:.1f} s", file=sys.stderr)
+            extras["other_configs"] = oc
+            out["extras"] = extras
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def main_funnel(args):
-    """SURVEY 8d cfg 3: funnel10 (D=11), adaptLeapFrogR2P, M=12, H0=0.3, delta0=0.3, warmupIter=0,
-    q0[0]~N(0,9), q0[1:]~N(0,e^{q0[0]}); metric = gradient evaluations (nevalF+nevalB) per second.
-    Roofline per SURVEY 8d: HBM, 48*D = 528 B per gradient evaluation (unfused streaming figure)."""
+def main_dry_run():
+    """The launcher's own test (tests/test_host_logic.py): rendezvous over gloo, one reduction, the final gather; no GPU."""
+    import torch
+    import torch.distributed as dist
+    from walnuts_amd.dist import gather_draws
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    fail = os.environ.get("WN_BENCH_FAIL_RANK")
+    if fail is not None and int(fail) == rank:
+        sys.exit(3)
+    if world > 1:
+        dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    g = torch.full((3, 2), float(rank), dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        g = gather_draws(g, dst=0)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run", "value": float(t.item()), "n_gpus": world, "gathered_rows": int(g.shape[0]),
+                          "n1_value_same_invocation": float(os.environ.get("WN_BENCH_N1_VALUE", "nan"))}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_walnuts10(args):
+    """BASELINE configs[0]'s target (10-D standard normal, test/test.py:11-18 parameters: macro_step 2.0, max_nuts_depth 10,
+    max_error 0.1) through `walnuts_batch` (walnuts/walnuts.py:279-408): transitions/s of `--chains` chains, one Generator
+    each.  The reference runs ~1.2e3 transitions/s on one core."""
+    import torch
+    from walnuts_amd import targetDistr as td
     import walnuts_amd as wa
-    from walnuts_amd import _lib as L
-    if args.iters == 100:
-        args.iters = 300  # SURVEY 8d cfg 3
-
-    def make_engine(rank, dev):
-        C = args.chains
-        e = wa.Engine(11, C, integrator=L.I_ADAPT_R2P, H0=0.3, delta0=0.3, M=12, generated=L.G_FIRSTK, gen_k=2,
-                      chain_offset=rank * C, device=dev.index)
-        return e.set_target(L.T_FUNNEL10), C
-
-    def q0_of(rank, C):
-        rng = np.random.default_rng([SEED, 3, rank])
-        q0 = np.zeros((C, 11)); q0[:, 0] = 3.0 * rng.normal(size=C)
-        q0[:, 1:] = np.exp(0.5 * q0[:, :1]) * rng.normal(size=(C, 10))
-        return q0
-
-    _run_evals_workload(args, make_engine, q0_of, "gradient evaluations/sec across chains, funnel10 (adaptLeapFrogR2P)",
-                        lambda C: f"funnel10 D=11, {C} chains/GPU, adaptLeapFrogR2P, M=12, H0=0.3, delta0=0.3, "
-                                  f"{args.iters} iterations/launch (SURVEY 8d cfg 3)", 528.0, "funnel")
-
-
-def main_stockwatson(args):
-    """SURVEY 8d cfg 5: StockWatson (D = 756), one GPU's shard of the 2048-chain job per rank, the first of
-    mainSW.py:41-80's three runs (adaptLeapFrogD, minC=3, H0=0.1, delta0=0.3, M=14), q0 = 0.
-    Metric = gradient evaluations/s; roofline per SURVEY 8d: HBM, 48*D bytes per evaluation."""
-    import walnuts_amd as wa
-    from walnuts_amd import _lib as L
-    sw = np.load(os.path.join(ROOT, "tests", "golden", "stockwatson_data.npz"))
-    T = int(sw["T"][0]); D = 3 * T
-    if args.chains == 4096:
-        args.chains = 256
-    if args.iters == 100:
-        args.iters = 20
-
-    ig, H0, minC, name = {"D": (L.I_ADAPT_D, 0.1, 3, "adaptLeapFrogD minC=3"), "fixed": (L.I_FIXED, 0.002, 0, "fixedLeapFrog"),
-                          "R2P": (L.I_ADAPT_R2P, 0.1, 3, "adaptLeapFrogR2P minC=3")}[args.sw_run]
-
-    def make_engine(rank, dev):
-        C = args.chains
-        e = wa.Engine(D, C, integrator=ig, H0=H0, delta0=0.3, M=14, minC=minC, generated=L.G_FIRSTK, gen_k=2,
-                      chain_offset=rank * C, device=dev.index)
-        return e.set_target(L.T_STOCKWATSON, np.concatenate([[float(T)], sw["y"]])), C
-
-    _run_evals_workload(args, make_engine, lambda rank, C: np.zeros((C, D)),
-                        f"gradient evaluations/sec across chains, StockWatson ({name.split()[0]})",
-                        lambda C: f"StockWatson D={D}, {C} chains/GPU, {name}, M=14, H0={H0}, delta0=0.3, "
-                                  f"q0=0, {args.iters} iterations/launch (SURVEY 8d cfg 5)", 48.0 * D, "stockwatson")
+    C = args.chains or 4096
+    iters = args.iters or 4
+    D = 10
+    rngs = [np.random.default_rng(1000 + c) for c in range(C)]
+    theta = np.zeros((C, D))
+    tgt = td.stdGauss
+    t_all = []
+    for k in range(args.warmup + args.steps):
+        t0 = time.perf_counter()
+        d = wa.walnuts_batch(rngs, theta, tgt, tgt, np.ones(D), 2.0, 10, 0.1, 0, iters)
+        torch.cuda.synchronize()
+        if k >= args.warmup:
+            t_all.append(time.perf_counter() - t0)
+        theta = d[:, -1, :]
+    el = float(np.sum(t_all))
+    print(json.dumps({"metric": "transitions/sec across chains, walnuts() on the 10-D standard normal", "value": C * iters * args.steps / el,
+                      "unit": "transitions/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": f"walnuts_batch: {C} chains x {iters} transitions per step, D=10 standard normal, macro_step=2.0, "
+                                             f"max_nuts_depth=10, max_error=0.1 (BASELINE configs[0]'s target, test/test.py:11-18)",
+                                 "kernel": "wn_wstep_* (wn_k_wstep.hip), one numpy Generator per chain consumed on the host in the reference's order"},
+                      "reference_python_transitions_per_s_per_core": 1.2e3}), flush=True)
 
 
 if __name__ == "__main__":

@@ -157,7 +157,8 @@ int wn_split_done(wn_engine *e, int32_t *n_done, void *stream);
 
 /* wn_run with recordOrbitStats=True (WALNUTS.py:128,182-184,724-725): additionally fills
  * orbit_min_dev / orbit_max_dev [C][n_iter][dg] with the per-iteration minimum / maximum of
- * generated(q) over the states of the orbit (every WN_G_* kind that lives on the device). */
+ * generated(q) over the states of the orbit: identity, first-k and [q0, sum q^2].  WN_G_SW_CONSTRAIN is applied to the
+ * draws only, so this call returns WN_E_UNSUPPORTED for it (run the identity kind and transform the bounds). */
 int wn_run_orbit_stats(wn_engine *e, const double *q0_dev, uint64_t seed, int32_t n_iter,
                        double *samples_dev, double *diag_dev, double *orbit_min_dev,
                        double *orbit_max_dev, void *stream);
@@ -205,9 +206,11 @@ int wn_lpfun_kind(int32_t device, int32_t target_kind, const double *tpar_dev, i
  * is the caller's (logp, grad) pair (:379-380).  Then every call above leaves chains waiting for an evaluation:
  *     wn_wstep_ext_bind(h, x_req, lp, grad)                                caller-owned [B][D], [B], [B][D]
  *     after begin / extend:  do { wn_wstep_ext_pending(h, &n); if (!n) break;
- *                                 lp[b], grad[b] = logp(x_req[b]), grad(x_req[b]) for the chains of this round;
+ *                                 wn_wstep_ext_waiting(h, waiting);    [B] int32: 1 = this chain asked for an evaluation
+ *                                 lp[b], grad[b] = logp(x_req[b]), grad(x_req[b]) for the chains with waiting[b];
  *                                 wn_wstep_ext_feed(h, sub_uturn, lse_ext, lse_old); } while (1);
- * (every active chain that has not finished its extension waits in every round).
+ * (only the waiting chains' x_req rows are positions the reference would evaluate: a chain whose extension has finished
+ * keeps a stale row, and a feed ignores whatever is passed for it).
  * All arrays are device memory; int arrays are int32.  Not thread-safe per handle. */
 typedef struct wn_wstep wn_wstep;
 int wn_wstep_create(int32_t device, int32_t target_kind, const double *tpar_dev, size_t n_tpar, int32_t dim,
@@ -222,6 +225,7 @@ int wn_wstep_commit(wn_wstep *h, const int32_t *accept_dev, const double *u_choi
 int wn_wstep_result(wn_wstep *h, double *theta_sel_dev, void *stream);
 int wn_wstep_ext_bind(wn_wstep *h, double *x_req_dev, const double *lp_dev, const double *grad_dev);
 int wn_wstep_ext_pending(wn_wstep *h, int32_t *n_pending, void *stream);
+int wn_wstep_ext_waiting(wn_wstep *h, int32_t *waiting_dev, void *stream);
 int wn_wstep_ext_feed(wn_wstep *h, int32_t *sub_uturn_dev, double *lse_ext_dev, double *lse_old_dev,
                       void *stream);
 const char *wn_wstep_last_error(wn_wstep *h); /* h may be NULL: last creation error */
@@ -236,6 +240,16 @@ int wn_rng_tape(wn_engine *e, uint64_t seed, int32_t iter, int32_t n_u, double *
 /* Kernel time of the last wn_run in milliseconds, measured with HIP events recorded on the
  * launch stream (synchronises on the stop event). */
 int wn_last_run_ms(wn_engine *e, float *ms);
+
+/* Split mode (dense Gaussian with 128 < D <= 1024, SURVEY 8d cfg 4): chain-kernel ticks the last wn_run launched -- each one
+ * {batched gradient kernel, one tick of every chain}, in batches of 64 captured into a hipGraph.  0 for fused kernels.  (New:
+ * measurement only -- bench.py reports time per tick beside the kernels' own durations.) */
+int wn_last_split_ticks(wn_engine *e, int64_t *ticks);
+
+/* Test hook: fills the LDS (160 KiB) of every CU of `device` with the 64-bit `pattern` (4 x CUs workgroups that own a whole CU's
+ * LDS each).  LDS keeps what the previous kernel left there; the sampler kernels must not depend on it
+ * (tests/test_gpu_lds.py runs every kernel family behind NaN and garbage patterns and compares bits). */
+int wn_debug_poison_lds(int32_t device, uint64_t pattern, void *stream);
 
 /* Which kernel the engine dispatches to: "wn_coop_kernel<NT=2,W=4,KS=25,dense>", "wn_lane_kernel<DMAX=..>" ...
  * The string is owned by the engine: valid until the next wn_set_target or wn_destroy of THIS engine;

@@ -487,3 +487,31 @@ def test_walnuts_plain_python_callables_as_in_test_py(wa):
 def test_walnuts_stan_shape(wa):
     with pytest.raises(ImportError, match="bridgestan"):
         wa.walnuts_stan(np.random.default_rng(0), np.zeros(3), "m.stan", "d.json", np.ones(3), 1.0, 5, 0.1, 0, 10)
+
+
+def test_walnuts_batch_evaluates_only_the_chains_that_asked(wa):
+    """Host (logp, grad) callables in a batch: a chain whose extension has finished keeps a stale row in the request buffer;
+    only the chains that asked in a round are evaluated (wn_wstep_ext_waiting), so four chains in one call make exactly the
+    calls of the four chains run one by one -- the points the reference evaluates (walnuts.py:144-276)."""
+    calls = {"n": 0}
+
+    def lpdf(x):
+        calls["n"] += 1
+        assert np.all(np.isfinite(x))
+        return -0.5 * np.dot(x, x)
+
+    def grad(x):
+        return -x
+
+    th = np.random.default_rng(9).normal(size=(4, 6))
+    single = 0
+    outs = []
+    for c in range(4):
+        calls["n"] = 0
+        outs.append(wa.walnuts(np.random.default_rng(100 + c), th[c], lpdf, grad, np.ones(6), 1.3, 6, 0.2, 0, 5))
+        single += calls["n"]
+    calls["n"] = 0
+    d = wa.walnuts_batch([np.random.default_rng(100 + c) for c in range(4)], th, lpdf, grad, np.ones(6), 1.3, 6, 0.2, 0, 5)
+    assert calls["n"] == single, (calls["n"], single)
+    for c in range(4):
+        close(d[c], outs[c], rtol=1e-12, atol=0, what=f"chain {c}")

@@ -4,6 +4,7 @@ import os
 import subprocess
 import sys
 import textwrap
+import time
 
 import numpy as np
 import pytest
@@ -87,3 +88,37 @@ def test_two_process_gloo_sharding_and_gather(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29731", str(script)],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def _bench(args, env_extra=None, timeout=120):
+    env = dict(os.environ, **(env_extra or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    return r, time.monotonic() - t0
+
+
+def test_bench_self_launcher_starts_ranks_and_relays_rank0():
+    """`python bench.py --gpus N` with no launcher: one fresh child per rank + the N = 1 reference child, rank 0's line relayed."""
+    import json
+    r, dt = _bench(["--gpus", "2", "--dry-run"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert o["n_gpus"] == 2 and o["value"] == 3.0 and o["gathered_rows"] == 6 and o["n1_value_same_invocation"] == 1.0
+
+
+def test_bench_self_launcher_ends_the_job_when_a_rank_dies():
+    """A rank that exits before the rendezvous leaves its sibling waiting in init_process_group (gloo's store timeout is
+    half an hour): the parent polls every child, ends the survivors and exits non-zero at once."""
+    r, dt = _bench(["--gpus", "2", "--dry-run", "--no-n1-ref"], {"WN_BENCH_FAIL_RANK": "1"})
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
+    assert dt < 60.0, dt
+    assert "rank 1 exited with code 3" in r.stderr
+
+
+def test_bench_self_launcher_time_limit():
+    """Ranks that never finish are ended at --child-timeout (rank 0 waits for a rank that sleeps through the rendezvous)."""
+    r, dt = _bench(["--gpus", "2", "--dry-run", "--no-n1-ref", "--child-timeout", "8"], {"WN_BENCH_FAIL_RANK": "-7"})
+    # (no rank matches -7: both run normally and finish well inside the limit)
+    assert r.returncode == 0, r.stdout + r.stderr

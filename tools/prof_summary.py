@@ -33,6 +33,18 @@ for k, g in grp.items():
     print(f"{k} calls={g['n']} avg_us={g['tot']/g['n']/1e3:.2f} total_ms={g['tot']/1e6:.3f} vgpr={r.get('VGPR_Count')} "
           f"accum={r.get('Accum_VGPR_Count')} sgpr={r.get('SGPR_Count')} lds={r.get('LDS_Block_Size')} "
           f"scratch={r.get('Scratch_Size')} wg={r.get('Workgroup_Size')}")
+print("== code-object metadata (tools/kernel_meta.sh; the trace's VGPR_Count column above is NOT the allocation: cite these) ==")
+import subprocess
+for unit in ("wn_k_fast", "wn_k_fast4", "wn_k_wave", "wn_k_split", "wn_k_gemm", "wn_k_coop"):
+    used = [k for k in grp if unit.replace("wn_k_", "wn_") in k or (unit == "wn_k_gemm" and "dense_grad" in k)]
+    if not used:
+        continue
+    try:
+        out = subprocess.run([os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernel_meta.sh"), unit], capture_output=True, text=True, timeout=900).stdout
+        print(f"-- {unit}.hip")
+        print(out.rstrip())
+    except Exception as ex:
+        print(f"-- {unit}.hip: {ex!r}")
 print("== PMC counters per dispatch, grouped by kernel (mean over dispatches) ==")
 acc = {}
 names = {}

@@ -241,6 +241,17 @@ __global__ void wn_sw_constrain_kernel(double* samples, size_t nrows, int T) {
   for (int t = 1; t < T; ++t) tau[t] = tau[t - 1] + exp(0.5 * z[t - 1]) * tin[t - 1];
 }
 
+// test hook (wn_debug_poison_lds): every workgroup owns a whole CU's LDS (160 KiB) and fills it with a bit pattern
+__global__ __launch_bounds__(256) void wn_poison_lds_kernel(unsigned long long pattern, unsigned long long* sink) {
+  extern __shared__ unsigned long long plds[];
+  const int n = 160 * 1024 / 8;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) plds[i] = pattern;
+  __syncthreads();
+  if (threadIdx.x == 0 && plds[blockIdx.x % n] == 1ull) sink[0] = plds[1];  // (keeps the stores alive)
+  // a little work so that the 4 x CUs workgroups spread over the whole chip instead of draining through a few CUs
+  for (int k = 0; k < 200; ++k) __builtin_amdgcn_s_sleep(32);
+}
+
 __global__ void wn_fill_kernel(double* p, size_t n, double v) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -272,7 +283,9 @@ struct wn_engine {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int* h_poll = nullptr;          // pinned host words the split-mode loop polls the finished-chain counter through
   hipEvent_t ev_poll[2] = {nullptr, nullptr};
-  int* kabort = nullptr;  // device flag: a kernel's bounded loop gave up (internal error), checked by wn_last_run_ms
+  int* kabort = nullptr;  // device flag: a kernel's bounded loop gave up (internal error)
+  bool kabort_pending = false;  // a launch since the flag was last read
+  hipStream_t kabort_stream = nullptr;
   bool timed = false;
   std::string err;
 };
@@ -470,6 +483,20 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
   return WN_OK;
 }
 
+// reads the abort flag of the last launch (synchronises its stream); WN_E_HIP when that run gave up
+static int check_abort(wn_engine* e) {
+  e->kabort_pending = false;
+  int ab = 0;
+  HIPCHK(e, hipStreamSynchronize(e->kabort_stream));
+  HIPCHK(e, hipMemcpy(&ab, e->kabort, sizeof(int), hipMemcpyDeviceToHost));
+  if (ab) {
+    (void)hipMemset(e->kabort, 0, sizeof(int));
+    e->err = "a kernel's tick loop exceeded its bound and gave up (internal error); the results of that run are incomplete";
+    return WN_E_HIP;
+  }
+  return WN_OK;
+}
+
 static void fill_params(const wn_engine* e, Params* p) {
   memset(p, 0, sizeof(*p));
   const wn_config& c = e->cfg;
@@ -523,13 +550,39 @@ static int run_split_dense(wn_engine* e, Params p, hipStream_t st, int adapt, bo
     HIPCHK(e, hipEventCreateWithFlags(&e->ev_poll[0], hipEventDisableTiming));
     HIPCHK(e, hipEventCreateWithFlags(&e->ev_poll[1], hipEventDisableTiming));
   }
+  // One batch = 64 ticks = 128 launches.  By default the batch is captured ONCE per run into a hipGraph and replayed: the GPU
+  // then paces the ticks itself, whatever the host thread is doing (round 2's driver-run number for this path, 1.29e7 steps/s
+  // against 1.9e7 in the builder's runs, was eager launches falling behind on a busy host).  WN_SPLIT_EAGER=1: eager launches.
+  static const bool eager = getenv("WN_SPLIT_EAGER") != nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  auto enqueue_batch = [&]() -> hipError_t {
+    hipError_t rr = hipSuccess;
+    for (int k = 0; k < 64 && rr == hipSuccess; ++k) {
+      rr = launch_dense_grad(e->apad, e->xq, e->xg, e->DP, p.D, e->Cpad, e->sp_done, p.C, st);
+      if (rr == hipSuccess) rr = launch_split_tick(e->kc, adapt, warm, p, st);
+    }
+    return rr;
+  };
+  if (!eager) {
+    hipError_t rg = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (rg == hipSuccess) {
+      const hipError_t rl = enqueue_batch();
+      rg = hipStreamEndCapture(st, &graph);
+      if (rg == hipSuccess && rl != hipSuccess) rg = rl;
+    }
+    if (rg == hipSuccess) rg = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+    if (rg != hipSuccess) {  // (the legacy default stream cannot be captured, for one: fall back to eager launches)
+      (void)hipGetLastError();
+      if (gexec) { hipGraphExecDestroy(gexec); gexec = nullptr; }
+      if (graph) { hipGraphDestroy(graph); graph = nullptr; }
+    }
+  }
+  struct GraphGuard { hipGraph_t& g; hipGraphExec_t& x; ~GraphGuard() { if (x) hipGraphExecDestroy(x); if (g) hipGraphDestroy(g); } } guard{graph, gexec};
   for (int batch = 0;; ++batch) {
     if ((double)e->sp_ticks > cap) { e->err = "split run exceeded its tick bound (internal error)"; return WN_E_HIP; }
-    for (int k = 0; k < 64; ++k) {
-      r = launch_dense_grad(e->apad, e->xq, e->xg, e->DP, p.D, e->Cpad, e->sp_done, p.C, st);
-      if (r == hipSuccess) r = launch_split_tick(e->kc, adapt, warm, p, st);
-      if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
-    }
+    r = gexec ? hipGraphLaunch(gexec, st) : enqueue_batch();
+    if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
     e->sp_ticks += 64;
     HIPCHK(e, hipMemcpyAsync(e->h_poll + (batch & 1), e->sp_done, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipEventRecord(e->ev_poll[batch & 1], st));
@@ -589,6 +642,7 @@ static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
     if (timed) { HIPCHK(e, hipEventRecord(e->ev1, st)); e->timed = true; }
     return WN_OK;
   }
+  e->sp_ticks = 0;
   Params pc = p;
   if (e->kc.G > 1) {
     pc.cl_g = e->kc.G; pc.cl_red = e->cl_red; pc.cl_cnt = e->cl_cnt; pc.cl_abort = (int*)(e->cl_cnt + e->cfg.n_chains);
@@ -598,12 +652,18 @@ static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
   const Params& p_ = pc;
   const bool coop_legacy = getenv("WN_COOP_LEGACY") != nullptr;  // diagnostic / A-B tests: one-stream kernel (read per launch)
   const bool fast_legacy = getenv("WN_FAST_LEGACY") != nullptr;  // diagnostic / A-B tests: the seven-T-wave kernel for dense targets too
+  // the tick-bound abort flag of the fast kernels belongs to THIS run: cleared in stream order before the launch; wn_last_run_ms,
+  // the next wn_run and wn_destroy report a run that gave up
+  if (e->kabort_pending) { int rc_ = check_abort(e); if (rc_) return rc_; }
+  HIPCHK(e, hipMemsetAsync(e->kabort, 0, sizeof(int), st));
   const bool want4 = p_.trace_n != nullptr || p_.C < 4096 || getenv("WN_FAST4") != nullptr;  // (measured: 4096 chains 1.00e9 vs 1.12e9, 1024 chains 3.4e8 vs 2.8e8)
   hipError_t r = (!coop_legacy && !fast_legacy && want4 && fast4_eligible(e->kc, adapt, warm, p_)) ? launch_fast4(e->kc, p_, e->kabort, st)
                : (!coop_legacy && fast_eligible(e->kc, adapt, warm, p_)) ? launch_fast(e->kc, p_, e->kabort, st)
                : e->kc.layout == 0 ? launch_lane(e->kc, adapt, warm, p_, st)
                : e->kc.layout == 1 ? launch_coop(e->kc, adapt, warm, p_, st) : launch_wave(e->kc, adapt, warm, p_, st);
   if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
+  e->kabort_pending = true;
+  e->kabort_stream = st;
   if (e->cfg.generated == WN_G_SW_CONSTRAIN && p.mode == MODE_SAMPLE) {
     const size_t nrows = (size_t)p.C * (p.numIter + 1);
     hipLaunchKernelGGL(wn_sw_constrain_kernel, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, st, p.samples, nrows, p.D / 3);
@@ -702,6 +762,12 @@ int wn_run_orbit_stats(wn_engine* e, const double* q0_dev, uint64_t seed, int32_
   if (!e) return WN_E_ARG;
   if (!e->have_kc) { e->err = "wn_set_target has not been called"; return WN_E_NOTARGET; }
   if (!q0_dev || !samples_dev || !diag_dev || !orbit_min_dev || !orbit_max_dev || n_iter < 0) { e->err = "null buffer or negative n_iter"; return WN_E_ARG; }
+  if (e->cfg.generated == WN_G_SW_CONSTRAIN) {
+    // the sampler fills the identity part of each row and wn_sw_constrain_kernel the transformed parameters of the DRAWS only: the
+    // orbit minima / maxima of sigma, gpri, z, x, tau would stay zero
+    e->err = "orbit statistics are not available with generated = WN_G_SW_CONSTRAIN (use the identity kind and transform the bounds)";
+    return WN_E_UNSUPPORTED;
+  }
   HIPCHK(e, hipSetDevice(e->cfg.device));
   Params p;
   fill_params(e, &p);
@@ -841,13 +907,28 @@ int wn_last_run_ms(wn_engine* e, float* ms) {
   if (!e->timed) { e->err = "no timed run yet"; return WN_E_ARG; }
   HIPCHK(e, hipEventSynchronize(e->ev1));
   HIPCHK(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
-  int ab = 0;
-  HIPCHK(e, hipMemcpy(&ab, e->kabort, sizeof(int), hipMemcpyDeviceToHost));
-  if (ab) {
-    (void)hipMemset(e->kabort, 0, sizeof(int));
-    e->err = "a kernel's tick loop exceeded its bound and gave up (internal error); the results of that run are incomplete";
-    return WN_E_HIP;
-  }
+  if (e->kabort_pending) return check_abort(e);
+  return WN_OK;
+}
+
+int wn_debug_poison_lds(int32_t device, uint64_t pattern, void* stream) {
+  hipError_t r = hipSetDevice(device);
+  if (r != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(r); return WN_E_HIP; }
+  static unsigned long long* sink = nullptr;
+  if (!sink && hipMalloc((void**)&sink, 64) != hipSuccess) { g_create_err = "hipMalloc failed"; return WN_E_ALLOC; }
+  hipDeviceProp_t prop;
+  r = hipGetDeviceProperties(&prop, device);
+  if (r == hipSuccess) r = hipFuncSetAttribute((const void*)wn_poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (r != hipSuccess) { g_create_err = std::string("wn_debug_poison_lds: ") + hipGetErrorString(r); return WN_E_HIP; }
+  hipLaunchKernelGGL(wn_poison_lds_kernel, dim3(4 * prop.multiProcessorCount), dim3(256), 160 * 1024, (hipStream_t)stream, (unsigned long long)pattern, sink);
+  r = hipGetLastError();
+  if (r != hipSuccess) { g_create_err = std::string("wn_debug_poison_lds launch: ") + hipGetErrorString(r); return WN_E_HIP; }
+  return WN_OK;
+}
+
+int wn_last_split_ticks(wn_engine* e, int64_t* ticks) {
+  if (!e || !ticks) return WN_E_ARG;
+  *ticks = (int64_t)e->sp_ticks;
   return WN_OK;
 }
 

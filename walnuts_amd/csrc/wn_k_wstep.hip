@@ -57,6 +57,7 @@ struct WCtx {
   const double* xlp;  // external: [B] log densities, [B][D] gradients
   const double* xg;
   int* npend;    // external: number of chains still waiting for an evaluation
+  int* waiting;  // external: [B] 1 for the chains that asked for an evaluation in the last launch
 };
 
 struct Vecs {
@@ -267,6 +268,7 @@ __global__ void wstep_ext_kernel(WCtx c, int mode /*0 begin, 1 extend setup, 2 f
                                  double* lse_old) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= c.B) return;
+  c.waiting[b] = 0;
   WScal& s = c.sc[b];
   Vecs V{c, b};
   bool need = false;
@@ -289,6 +291,7 @@ __global__ void wstep_ext_kernel(WCtx c, int mode /*0 begin, 1 extend setup, 2 f
   if (need) {
     for (int i = 0; i < c.D; ++i) c.xreq[(size_t)b * c.D + i] = V(V_TH, i);
     atomicAdd(c.npend, 1);
+    c.waiting[b] = 1;
   }
 }
 
@@ -377,7 +380,7 @@ int wn_wstep_destroy(wn_wstep* h) {
   if (!h) return WN_OK;
   hipSetDevice(h->device);
   for (void* p : {(void*)h->tpar, (void*)h->im, (void*)h->lot, (void*)h->c.vec, (void*)h->c.eorb, (void*)h->c.ew, (void*)h->c.logw,
-                  (void*)h->c.sc, (void*)h->c.npend})
+                  (void*)h->c.sc, (void*)h->c.npend, (void*)h->c.waiting})
     if (p) hipFree(p);
   delete h;
   return WN_OK;
@@ -387,8 +390,12 @@ int wn_wstep_create(int32_t device, int32_t target_kind, const double* tpar_dev,
                     int32_t max_depth, const double* inv_mass_dev, double macro_step, double max_error, wn_wstep** out) {
   if (!out) { g_wstep_err = "null argument"; return WN_E_ARG; }
   *out = nullptr;
-  if (dim < 1 || B < 1 || max_depth < 1 || max_depth > 20 || !inv_mass_dev || !(macro_step > 0) || !(max_error > 0)) {
+  if (dim < 1 || B < 1 || max_depth < 1 || !inv_mass_dev || !(macro_step > 0) || !(max_error > 0)) {
     g_wstep_err = "wn_wstep_create: bad argument"; return WN_E_ARG;
+  }
+  if (max_depth > 20) {  // the reference accepts any depth; the device stepper's orbit store is sized 2^(max_depth-1) states per chain
+    g_wstep_err = "wn_wstep_create: max_nuts_depth beyond 20 is not supported by the device stepper (orbit store of 2^(depth-1) states per chain)";
+    return WN_E_UNSUPPORTED;
   }
   const bool ext = target_kind == WN_T_EXTERNAL;
   if (!ext) {
@@ -410,6 +417,11 @@ int wn_wstep_create(int32_t device, int32_t target_kind, const double* tpar_dev,
   c.kind = target_kind; c.D = dim; c.B = B; c.nmax = 1 << (max_depth - 1);
   c.macro_step = macro_step; c.max_error = max_error;
   auto fail = [&](int rc) { g_wstep_err = h->err; wn_wstep_destroy(h); return rc; };
+#define WCOPY(call)                                                                        \
+  do {                                                                                     \
+    hipError_t _r = (call);                                                                \
+    if (_r != hipSuccess) { (void)hipGetLastError(); h->err = std::string(#call) + ": " + hipGetErrorString(_r); return fail(WN_E_HIP); } \
+  } while (0)
 #define WALLOC(ptr, bytes)                                                                 \
   do {                                                                                     \
     hipError_t _r = hipMalloc((void**)&(ptr), (bytes));                                    \
@@ -418,10 +430,10 @@ int wn_wstep_create(int32_t device, int32_t target_kind, const double* tpar_dev,
   } while (0)
   if (tpar_dev && n_tpar) {
     WALLOC(h->tpar, n_tpar * sizeof(double));
-    hipMemcpy(h->tpar, tpar_dev, n_tpar * sizeof(double), hipMemcpyDeviceToDevice);
+    WCOPY(hipMemcpy(h->tpar, tpar_dev, n_tpar * sizeof(double), hipMemcpyDeviceToDevice));
   }
   WALLOC(h->im, (size_t)dim * sizeof(double));
-  hipMemcpy(h->im, inv_mass_dev, (size_t)dim * sizeof(double), hipMemcpyDeviceToDevice);
+  WCOPY(hipMemcpy(h->im, inv_mass_dev, (size_t)dim * sizeof(double), hipMemcpyDeviceToDevice));
   WALLOC(h->lot, (size_t)B * c.nmax * sizeof(int));
   WALLOC(c.vec, (size_t)V_NVEC * dim * B * sizeof(double));
   WALLOC(c.eorb, (size_t)c.nmax * 2 * dim * B * sizeof(double));
@@ -429,9 +441,11 @@ int wn_wstep_create(int32_t device, int32_t target_kind, const double* tpar_dev,
   WALLOC(c.logw, (size_t)2 * c.nmax * B * sizeof(double));
   WALLOC(c.sc, (size_t)B * sizeof(WScal));
   WALLOC(c.npend, 64);
+  WALLOC(c.waiting, (size_t)B * sizeof(int));
 #undef WALLOC
-  hipMemset(c.sc, 0, (size_t)B * sizeof(WScal));
-  hipMemset(c.vec, 0, (size_t)V_NVEC * dim * B * sizeof(double));
+  WCOPY(hipMemset(c.sc, 0, (size_t)B * sizeof(WScal)));
+  WCOPY(hipMemset(c.vec, 0, (size_t)V_NVEC * dim * B * sizeof(double)));
+#undef WCOPY
   c.tpar = h->tpar; c.im = h->im; c.lottery = h->lot;
   *out = h;
   return WN_OK;
@@ -474,6 +488,13 @@ int wn_wstep_ext_pending(wn_wstep* h, int32_t* n_pending, void* stream) {
   WCHK(hipMemcpyAsync(&np, h->c.npend, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
   WCHK(hipStreamSynchronize((hipStream_t)stream));
   *n_pending = np;
+  return WN_OK;
+}
+
+int wn_wstep_ext_waiting(wn_wstep* h, int32_t* waiting_dev, void* stream) {
+  if (!h || !h->external || !waiting_dev) { if (h) h->err = "wn_wstep_ext_waiting needs a WN_T_EXTERNAL handle and a [B] int32 device array"; return WN_E_ARG; }
+  WCHK(hipSetDevice(h->device));
+  WCHK(hipMemcpyAsync(waiting_dev, h->c.waiting, (size_t)h->c.B * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return WN_OK;
 }
 

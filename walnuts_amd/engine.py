@@ -158,6 +158,12 @@ class Engine:
         self._check(self.lib.wn_last_run_ms(self.h, C.byref(ms)))
         return float(ms.value)
 
+    def last_split_ticks(self):
+        """split mode: {gradient kernel, chain tick} pairs the last run launched (0 for fused kernels)"""
+        n = C.c_int64()
+        self._check(self.lib.wn_last_split_ticks(self.h, C.byref(n)))
+        return int(n.value)
+
     def integrator_step(self, q, v, g, Ham0, h, xi, u_r2p=None):
         torch = self.torch
         B, D = self.n_chains, self.dim

@@ -86,6 +86,7 @@ class _Stepper:
         self.lse_ext, self.lse_old = z(B), z(B)
         if fns is not None:
             self.xreq, self.xlp, self.xg = z(B, D), z(B), z(B, D)
+            self.waiting = z(B, dt=torch.int32)
             self._ck(self.lib.wn_wstep_ext_bind(self.h, self.p(self.xreq), self.p(self.xlp), self.p(self.xg)))
 
     @staticmethod
@@ -99,8 +100,10 @@ class _Stepper:
         if rc:
             raise RuntimeError(self.lib.wn_wstep_last_error(self.h).decode())
 
-    def _serve(self, waiting):
-        """Host (logp, grad) pair: evaluate the requested positions of the waiting chains until none waits."""
+    def _serve(self, waiting=None):
+        """Host (logp, grad) pair: evaluate the positions the device asked for until no chain waits.  Only the chains
+        that asked in this round are evaluated (wn_wstep_ext_waiting): a chain whose extension has finished keeps a stale
+        row in xreq, which the reference never evaluates (side effects, exceptions, NaN positions of user callables)."""
         if self.fns is None:
             return
         logp, grad = self.fns
@@ -109,9 +112,11 @@ class _Stepper:
             self._ck(self.lib.wn_wstep_ext_pending(self.h, C.byref(n), self._st()))
             if n.value == 0:
                 return
+            self._ck(self.lib.wn_wstep_ext_waiting(self.h, self.p(self.waiting), self._st()))
             x = self.xreq.cpu().numpy()
+            w = self.waiting.cpu().numpy()
             lp = np.zeros(self.B); g = np.zeros((self.B, self.D))
-            for b in waiting:
+            for b in np.flatnonzero(w):
                 lp[b] = logp(x[b])
                 g[b] = grad(x[b])
             self.xlp.copy_(self.dv(lp)); self.xg.copy_(self.dv(g))
