@@ -440,6 +440,14 @@ def test_bench_two_ranks_sharing_one_gpu():
     o1 = line(subprocess.run([sys.executable, bench, "--steps", "1", "--warmup", "0", "--chains", "512", "--iters", "5",
                               "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600, env=env, cwd=root))
     assert o1["n_gpus"] == 1 and o1["leapfrog_steps_per_launch_per_gpu"] == 2 * out["leapfrog_steps_per_launch_per_gpu"]
+    # --gather identity: the final gather moves the identity draws (SURVEY 8e's message, 8 * C/G * (iters+1) * D bytes per GPU);
+    # what rank 0 holds afterwards is bit for bit the draws of the same 512 chains run by one rank
+    g2 = line(subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--chains", "256", "--iters", "5",
+                              "--gather", "identity", "--no-n1-ref"], capture_output=True, text=True, timeout=600, env=env, cwd=root))
+    g1 = line(subprocess.run([sys.executable, bench, "--steps", "1", "--warmup", "0", "--chains", "512", "--iters", "5", "--gather", "identity",
+                              "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600, env=env, cwd=root))
+    assert g2["gather_bytes_per_rank"] == 256 * 6 * 100 * 8 and g2["gather_ms"] > 0
+    assert g2["draws_sha256"] == g1["draws_sha256"]
     # the other workloads shard the same way (configs 3, 4, 5)
     for extra in (["--workload", "funnel", "--chains", "64", "--iters", "3"],
                   ["--workload", "dense1000", "--chains", "64", "--iters", "2", "--no-cpu-baseline"],
