@@ -181,6 +181,7 @@ extern "C" long fastsim_run2(Params* prm, int target, int nlc, double* idle_frac
       }
       HostIO io{prm, cl, psums, &ntrace};
       FastBook::Fast ff;
+      B.retire_pre(*prm, io);  // tick() = retire_pre() + tick_post()
       const bool fast = fastmode && B.fast_prepare(*prm, io, t + 1, ff);
       g_all_ticks++;
       if (fast) g_fast_ticks++;
@@ -188,13 +189,13 @@ extern "C" long fastsim_run2(Params* prm, int target, int nlc, double* idle_frac
         int nt2 = ntrace, nt3 = ntrace;
         HostIO io2{prm, cl, psums, &nt2}, io3{prm, cl, psums, &nt3};
         FastBook B2 = B, B3 = B;
-        const Cmd c2 = B2.tick(*prm, io2, t + 1), c3 = B3.fast_commit(*prm, io3, ff);
+        const Cmd c2 = B2.tick_post(*prm, io2, t + 1), c3 = B3.fast_commit(*prm, io3, ff);
         // (the one-block uniform caches may hold different -- equally valid -- blocks: the values are functions of the index)
         B2.cblkI = B3.cblkI; B2.cuI0 = B3.cuI0; B2.cuI1 = B3.cuI1; B2.cblkR = B3.cblkR; B2.cuR0 = B3.cuR0; B2.cuR1 = B3.cuR1;
         if (memcmp(&B2, &B3, sizeof(FastBook)) != 0 || c2.op != c3.op || c2.n != c3.n || memcmp(&c2.hs, &c3.hs, sizeof(double)) != 0 || nt2 != nt3) return -2;
       }
       if (fast) nxt = B.fast_commit(*prm, io, ff);
-      else nxt = B.tick(*prm, io, t + 1);  // retires tick t-1, issues tick t+1
+      else nxt = B.tick_post(*prm, io, t + 1);  // retires tick t-1, issues tick t+1
       T.tick(t, cur);                 // tick t
       memcpy(psums, T.sums, sizeof(psums));
       if (cur.op & OP_STEP) steps += 1;

@@ -32,12 +32,12 @@ def close(a, b, rtol=1e-6, atol=1e-9, what=""):
                      f"got {a[~ok][:4]}, want {b[~ok][:4]}"
 
 
-def run(wa, target, tpar, q0, legacy=False, pair=False, **kw):
+def run(wa, target, tpar, q0, legacy=False, seven=False, **kw):
     C, D = q0.shape
     if legacy:
         os.environ["WN_COOP_LEGACY"] = "1"
-    if pair:  # the wave-pair kernel (wn_k_fast4.hip) at any chain count
-        os.environ["WN_FAST4"] = "1"
+    if seven:  # the seven-T-wave kernel (wn_k_fast.hip) for a dense target (diagnostic: the wave-pair kernel is the default)
+        os.environ["WN_FAST_LEGACY"] = "1"
     try:
         e = wa.Engine(D, C, integrator=ol.I_FIXED, **{k: v for k, v in kw.items() if k not in ("numIter", "seed")})
         e.set_target(target, tpar)
@@ -48,7 +48,7 @@ def run(wa, target, tpar, q0, legacy=False, pair=False, **kw):
         e.close()
     finally:
         os.environ.pop("WN_COOP_LEGACY", None)
-        os.environ.pop("WN_FAST4", None)
+        os.environ.pop("WN_FAST_LEGACY", None)
     return s, d, name, ms
 
 
@@ -100,15 +100,15 @@ def test_fast_equals_one_stream_kernel_at_baseline_size(wa):
     kw = dict(H0=0.5, M=10, generated=ol.G_Q0_SUMSQ, chain_offset=0, numIter=12, seed=SEED)
     s, d, name, ms = run(wa, ol.T_DENSEGAUSS, A, q0, **kw)
     s1, d1, name1, ms1 = run(wa, ol.T_DENSEGAUSS, A, q0, legacy=True, **kw)
-    assert "wn_fast_kernel" in name and "wn_coop_kernel" in name1, (name, name1)
-    # the wave-pair kernel at the same size: identical integers too (it sums the D terms of a dot product in its own order)
-    s4, d4, name4, ms4 = run(wa, ol.T_DENSEGAUSS, A, q0, pair=True, **kw)
-    assert "wn_fast4_kernel" in name4, name4
+    assert "wn_fast4_kernel" in name and "wn_coop_kernel" in name1, (name, name1)
+    # the seven-T-wave kernel at the same size: identical integers too (each kernel sums the D terms of a dot product in its own order)
+    s4, d4, name4, ms4 = run(wa, ol.T_DENSEGAUSS, A, q0, seven=True, **kw)
+    assert "wn_fast_kernel" in name4, name4
     for col in INT_DIAG:
-        np.testing.assert_array_equal(d4[:, :, col], d1[:, :, col], err_msg=f"pair kernel diag col {col}")
-    close(d4, d1, rtol=1e-9, atol=1e-10, what="pair kernel diagnostics vs one-stream kernel")
-    close(s4, s1, rtol=1e-9, atol=1e-10, what="pair kernel draws vs one-stream kernel")
-    print(f"pair kernel {ms4:.1f} ms")
+        np.testing.assert_array_equal(d4[:, :, col], d1[:, :, col], err_msg=f"seven-wave kernel diag col {col}")
+    close(d4, d1, rtol=1e-9, atol=1e-10, what="seven-wave kernel diagnostics vs one-stream kernel")
+    close(s4, s1, rtol=1e-9, atol=1e-10, what="seven-wave kernel draws vs one-stream kernel")
+    print(f"seven-wave kernel {ms4:.1f} ms")
     for col in INT_DIAG:
         np.testing.assert_array_equal(d[:, :, col], d1[:, :, col], err_msg=f"diag col {col}")
     close(d, d1, rtol=1e-9, atol=1e-10, what="diagnostics vs one-stream kernel")
@@ -157,12 +157,12 @@ def test_fast_result_does_not_depend_on_the_previous_launch(wa):
     control areas are zeroed at kernel start now: the same problem gives the same bits whatever ran before it."""
     A, q0 = dense_problem(100, 1e4, 4096)
     kw = dict(H0=0.5, M=10, generated=ol.G_Q0_SUMSQ, chain_offset=0, numIter=3, seed=SEED)
-    s0, d0, name, _ = run(wa, ol.T_DENSEGAUSS, A, q0, **kw)
+    s0, d0, name, _ = run(wa, ol.T_DENSEGAUSS, A, q0, seven=True, **kw)
     assert "wn_fast_kernel" in name
     for rep in range(4):
         # launches that leave iteration-1 entries of OTHER streams in every CU's LDS
-        run(wa, ol.T_DENSEGAUSS, A, q0, H0=0.5, M=10, generated=ol.G_Q0_SUMSQ, chain_offset=7 + rep, numIter=1, seed=SEED + 1 + rep)
-        s1, d1, _, _ = run(wa, ol.T_DENSEGAUSS, A, q0, **kw)
+        run(wa, ol.T_DENSEGAUSS, A, q0, seven=True, H0=0.5, M=10, generated=ol.G_Q0_SUMSQ, chain_offset=7 + rep, numIter=1, seed=SEED + 1 + rep)
+        s1, d1, _, _ = run(wa, ol.T_DENSEGAUSS, A, q0, seven=True, **kw)
         np.testing.assert_array_equal(d1, d0, err_msg=f"diagnostics, repetition {rep}")
         np.testing.assert_array_equal(s1, s0, err_msg=f"draws, repetition {rep}")
 
@@ -171,8 +171,6 @@ def _traced(wa, A, q0, pair, keep=None, **kw):
     """(samples, diagnostics, trace, trace_n) of a traced fixedLeapFrog run through the C ABI"""
     import torch
     C, D = q0.shape
-    if pair:
-        os.environ["WN_FAST4"] = "1"
     try:
         e = wa.Engine(D, C, integrator=ol.I_FIXED, **{k: v for k, v in kw.items() if k not in ("numIter", "seed", "trace_cap")})
         e.set_target(ol.T_DENSEGAUSS, A)
@@ -180,7 +178,7 @@ def _traced(wa, A, q0, pair, keep=None, **kw):
         out = e.run(q0, kw["seed"], kw["numIter"], trace_cap=kw["trace_cap"])
         e.close()
     finally:
-        os.environ.pop("WN_FAST4", None)
+        pass
     s, d, tr, tn = out
     if keep is not None:  # (a 4096-chain trace is gigabytes: only the checked chains leave the device)
         tr = tr[keep]
@@ -217,7 +215,7 @@ def test_pair_kernel_per_step_states_at_4096_chains(wa):
     keep = sorted(set(rng.integers(0, 4096, size=6).tolist() + [0, 4095]))
     s, d, tr, tn, name = _traced(wa, A, q0, True, keep=keep, trace_cap=1400, **kw)
     assert "wn_fast4_kernel" in name, name
-    sp, dp, namep, _ = run(wa, ol.T_DENSEGAUSS, A, q0, pair=True, **kw)
+    sp, dp, namep, _ = run(wa, ol.T_DENSEGAUSS, A, q0, **kw)
     np.testing.assert_array_equal(s, sp); np.testing.assert_array_equal(d, dp)
     assert (tn == (d[:, :, 6] + d[:, :, 7]).sum(1)).all()
     for j, k in enumerate(keep):

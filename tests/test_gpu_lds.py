@@ -62,8 +62,8 @@ def _dense(D, C):
 def test_headline_kernels_do_not_read_stale_lds(wa):
     A, q0 = _dense(100, 4096)
     mk = lambda: wa.Engine(100, 4096, integrator=ol.I_FIXED, H0=0.5, M=10, generated=ol.G_Q0_SUMSQ).set_target(ol.T_DENSEGAUSS, A)
-    assert "wn_fast_kernel" in _three_runs(wa, mk, q0, 3)
-    assert "wn_fast4_kernel" in _three_runs(wa, mk, q0, 3, env={"WN_FAST4": "1"})
+    assert "wn_fast4_kernel" in _three_runs(wa, mk, q0, 3)
+    assert "wn_fast_kernel" in _three_runs(wa, mk, q0, 3, env={"WN_FAST_LEGACY": "1"})
     assert "wn_coop_kernel" in _three_runs(wa, mk, q0, 2, env={"WN_COOP_LEGACY": "1"})
     A, q1 = _dense(100, 1024)
     mk1 = lambda: wa.Engine(100, 1024, integrator=ol.I_FIXED, H0=0.5, M=8, generated=ol.G_IDENTITY).set_target(ol.T_DENSEGAUSS, A)

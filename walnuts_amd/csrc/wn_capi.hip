@@ -471,9 +471,9 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
     const int NT = kc.p0 <= 16 ? 1 : 2;
     snprintf(kc.name, sizeof(kc.name), "wn_fast_kernel<KS=%d,%s>", (kc.p1 != CK_DENSE && kc.p0 == 32) ? 28 : kc.p0, kc.p1 == CK_DENSE ? "dense" : "diag");
     (void)NT;
-    // dense, D <= 100, fewer than 4096 chains: wave pairs of four chains (wn_k_fast4.hip) -- 1024 chains are 256 pairs, one per CU,
-    // where the seven-wave kernel fills 64 CUs.  (Traced runs of every size go there too: see launch().)
-    if (kc.p1 == CK_DENSE && D <= 100 && (e->cfg.n_chains < 4096 || getenv("WN_FAST4")) && !getenv("WN_FAST_LEGACY"))
+    // dense, D <= 100: wave pairs of four chains (wn_k_fast4.hip), traced runs too.  (4096 chains: 1.24e9 steps/s against the
+    // seven-wave kernel's 1.12e9; 1024 chains are 256 pairs, one per CU, where that kernel fills 64 CUs: 3.9e8 against 2.8e8.)
+    if (kc.p1 == CK_DENSE && D <= 100 && !getenv("WN_FAST_LEGACY"))
       snprintf(kc.name, sizeof(kc.name), "wn_fast4_kernel<NS=%d%s,dense,pairs=%d>", D <= 32 ? 2 : D <= 64 ? 4 : D <= 96 ? 6 : 7, D > 96 ? ",tail" : "",
                fast4_pairs(e->cfg.n_chains));
   }
@@ -656,8 +656,7 @@ static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
   // the next wn_run and wn_destroy report a run that gave up
   if (e->kabort_pending) { int rc_ = check_abort(e); if (rc_) return rc_; }
   HIPCHK(e, hipMemsetAsync(e->kabort, 0, sizeof(int), st));
-  const bool want4 = p_.trace_n != nullptr || p_.C < 4096 || getenv("WN_FAST4") != nullptr;  // (measured: 4096 chains 1.00e9 vs 1.12e9, 1024 chains 3.4e8 vs 2.8e8)
-  hipError_t r = (!coop_legacy && !fast_legacy && want4 && fast4_eligible(e->kc, adapt, warm, p_)) ? launch_fast4(e->kc, p_, e->kabort, st)
+  hipError_t r = (!coop_legacy && !fast_legacy && fast4_eligible(e->kc, adapt, warm, p_)) ? launch_fast4(e->kc, p_, e->kabort, st)
                : (!coop_legacy && fast_eligible(e->kc, adapt, warm, p_)) ? launch_fast(e->kc, p_, e->kabort, st)
                : e->kc.layout == 0 ? launch_lane(e->kc, adapt, warm, p_, st)
                : e->kc.layout == 1 ? launch_coop(e->kc, adapt, warm, p_, st) : launch_wave(e->kc, adapt, warm, p_, st);
@@ -723,8 +722,8 @@ int wn_run(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, do
         if (a[6] <= 0) continue;
         if (w < pairs) fprintf(stderr, "[WN_STAMPS fast4] T wave %d cycles/tick: commands+halfstep=%.0f mfma=%.0f halfstep+checks+sums=%.0f stores=%.0f wait=%.0f (ticks %.0f)\n",
                                w, a[0] / a[6], a[1] / a[6], a[2] / a[6], a[3] / a[6], a[4] / a[6], a[6] / groups);
-        else fprintf(stderr, "[WN_STAMPS fast4] B wave %d cycles/tick: normals+window=%.0f sums+verdicts=%.0f bookkeeper=%.0f command=%.0f wait=%.0f\n",
-                     w - pairs, a[0] / a[6], a[1] / a[6], a[2] / a[6], a[3] / a[6], a[4] / a[6]);
+        else fprintf(stderr, "[WN_STAMPS fast4] B wave %d cycles/tick: normals+window=%.0f wait for T=%.0f sums+verdicts=%.0f bookkeeper=%.0f command=%.0f (fast-path ticks %.1f %%)\n",
+                     w - pairs, a[0] / a[6], a[5] / a[6], a[1] / a[6], a[2] / a[6], a[3] / a[6], 100.0 * a[7] / a[6]);
       }
       return rc;
     }

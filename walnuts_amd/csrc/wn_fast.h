@@ -410,11 +410,11 @@ struct FastBook {
   // tick() handles it through the same branches as every rare event; on the device every branch is an exec-mask save, a
   // vote and a jump, and the bookkeeper's ~600 instructions per tick compete with the T wave's MFMAs for the SIMD (FP64
   // MFMAs and vector instructions do not overlap on this chip: tools/mfma_valu_coissue.hip).  fast_prepare() decides
-  // WITHOUT touching the state whether this tick is that event and computes what it changes, straight-line;
+  // (after retire_pre(), WITHOUT touching the state) whether this tick is that event and computes what it changes, straight-line;
   // fast_commit() applies it.  State, command and draws are bit for bit those of tick() (tests/test_fast_book.py runs
   // both on every tick and compares every member).  A wave takes the fast path when all its chains are ordinary.
-  struct Fast {
-    double lpn, Hn, Wsum, ratio, h, hnext2;
+  struct Fast {  // (the leaf's energy, weight sum and acceptance ratio are retire_pre()'s: pre_lpn, pre_Hn, pre_Wsum, pre_ratio)
+    double h, hnext2;
     uint32_t ku_new;
     int n, idx;
     bool pick, even_issue;
@@ -441,13 +441,7 @@ struct FastBook {
     bool ok = s0.kind == K_STEP && !s0.discard && s1.kind == K_STEP && !s1.discard && st == ST_RUN && i >= 1 && !undo;
     const int n = s0.n;
     f.n = n;
-    // retire_pre
-    f.lpn = 0.5 * io.sum(Q_LP);
-    f.Hn = -f.lpn + 0.5 * io.sum(Q_KE);
-    const double Wnew = exp(-f.Hn + H0 + 0.0);
-    f.Wsum = WnewSum + Wnew;
-    f.ratio = Wnew / f.Wsum;
-    ok = ok && isfinite(f.Hn);
+    ok = ok && isfinite(pre_Hn);  // retire_pre() has run
     // no sub-tree U-turn at an odd leaf; the last leaf of the doubling is not ordinary (s1 is leaf n+1 < nleaf)
     if (n & 1) {
       const uint32_t m = ((2u << __builtin_ctz((unsigned)(n + 1))) - 1u) & ~1u;
@@ -457,10 +451,10 @@ struct FastBook {
     f.idx = xi > 0 ? b + 1 + n : a - 1 - n;
     uint32_t k = ku + (((n & 1) == 0) ? 2u : 0u);     // :395 size=2, before the first step of the pair
     // the leaf's multinomial draw (:426) must happen (then leaf n+1's will too: WnewSum does not decrease)
-    ok = ok && f.Wsum > prm.wtSumThresh;
+    ok = ok && pre_Wsum > prm.wtSumThresh;
     double u;
     ok = peek(io, k, u) && ok;
-    f.pick = u < f.ratio;
+    f.pick = u < pre_ratio;
     k += 1u;
     // issue leaf n+2 (tick_post, ST_RUN): not the last leaf of the doubling (its issue draws the next direction)
     ok = ok && n + 3 < nleaf;
@@ -483,10 +477,9 @@ struct FastBook {
   WN_HD Cmd fast_commit(const Params& prm, IO& io, const Fast& f) {
     const int n = f.n;
     const double h = s0.h;
-    io.trace_step(iter, i, xi, h, Ha, f.lpn);
-    pre_lpn = f.lpn; pre_Hn = f.Hn; pre_Wsum = f.Wsum; pre_ratio = f.ratio;
+    io.trace_step(iter, i, xi, h, Ha, pre_lpn);
     nevalF += 1;
-    Hmin = f.Hn < Hmin ? f.Hn : Hmin; Hmax = f.Hn > Hmax ? f.Hn : Hmax;
+    Hmin = pre_Hn < Hmin ? pre_Hn : Hmin; Hmax = pre_Hn > Hmax ? pre_Hn : Hmax;
     {
       const bool fw = xi > 0;
       const double tf = timeLenF_ + h, tb = timeLenB_ + h;
@@ -494,7 +487,7 @@ struct FastBook {
       timeLenF_ = fw ? tf : timeLenF_; timeLenB_ = fw ? timeLenB_ : tb;
     }
     n_rt = n + 1;
-    WnewSum = f.Wsum;
+    WnewSum = pre_Wsum;
     ku = f.ku_new;
     // (the one-block uniform caches keep what they hold: still valid blocks of this iteration)
     {  // pick_state(idx, lpn), select form
@@ -503,13 +496,13 @@ struct FastBook {
       ip = p ? nip : ip;
       pick_ip = p ? ip : pick_ip;
       pend_pick = pend_pick || p;
-      lpP = p ? f.lpn : lpP;
+      lpP = p ? pre_lpn : lpP;
       L_ = p ? f.idx : L_;
       const double is = xi > 0 ? timeLenF_ : -timeLenB_;
       indexStat_ = p ? is : indexStat_;
     }
     orbitLen_ += h;
-    Ha = f.Hn;
+    Ha = pre_Hn;
     // tick_post
     s0.kind = K_STEP; s0.n = n + 1; s0.row = 0; s0.discard = false; s0.last = false; s0.init = false; s0.h = s1.h;
     Cmd c;

@@ -32,6 +32,8 @@
 //   ----------------------------------- barrier (LDS only) ---------------------------------------------------------
 #include "wn_launch.h"  // hip_runtime first
 
+#include <type_traits>
+
 #include "wn_fast.h"
 
 namespace wn {
@@ -56,19 +58,19 @@ struct Fast4Geom {
   static_assert(NSR % 2 == 0, "two fragments per 16-byte LDS read");
   // LDS, in doubles: the fragment image, then one region per pair
   static constexpr int OFF_A = 0;
-  static constexpr int P_COLD = 0;                      // passive orbit end: qb, vb
-  static constexpr int P_LC = P_COLD + 2 * VEC;         // level-2 left endpoint: q, v
-  static constexpr int P_SUMS = P_LC + 2 * VEC;         // 2 x [batch][block b][chain x]
+  static constexpr int P_LC = 0;                        // level-2 left endpoint: q, v
+  static constexpr int P_STAGE = P_LC + 2 * VEC;        // this tick's position, from where the MFMAs' B operands are read block-replicated
+  static constexpr int P_SUMS = P_STAGE + VEC;          // 2 x [batch][block b][chain x]
   static constexpr int P_CMD = P_SUMS + 2 * NB * 16;    // 2 x 4 commands of 2 doubles
   static constexpr int P_USTAT = P_CMD + 16;            // uniform blocks 0..7 of the running iteration: [chain][8] x {tag, u0, u1}
   static constexpr int P_URING = P_USTAT + 4 * 8 * 3;   // sliding window of 16 blocks: [chain][blk & 15] x {tag, u0, u1}
   static constexpr int P_DSTAGE = P_URING + 4 * 16 * 3; // diagnostics rows on their way out: [chain][24]
-  static constexpr int P_FLAGS = P_DSTAGE + 4 * NDIAG;  // 2 x {done}, pad
-  static constexpr int PAIR_DOUBLES = P_FLAGS + 8;
+  static constexpr int P_SEQ = P_DSTAGE + 4 * NDIAG;    // hand-off words of the pair: ticks the T wave has finished, commands the B wave has issued
+  static constexpr int PAIR_DOUBLES = P_SEQ + 8;
   static constexpr int OFF_PAIR = NFR * 64;
   __host__ __device__ static constexpr size_t lds_bytes(int pairs) { return ((size_t)OFF_PAIR + (size_t)pairs * PAIR_DOUBLES) * sizeof(double); }
-  // workspace of one 4-chain group, in doubles: (M+1) slots x (q, v), 2 proposals, momentum normals [chain][DPAD]
-  __host__ __device__ static constexpr size_t group_doubles(int M) { return (size_t)((M + 1) * 2 + 2) * VEC + (size_t)4 * DPAD; }
+  // workspace of one 4-chain group, in doubles: (M+1) slots x (q, v), 2 proposals, the passive orbit end (q, v), momentum normals [chain][DPAD]
+  __host__ __device__ static constexpr size_t group_doubles(int M) { return (size_t)((M + 1) * 2 + 4) * VEC + (size_t)4 * DPAD; }
 };
 
 #define WN4_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -138,8 +140,20 @@ __device__ __forceinline__ double rows_sum(double x) {
 // ------------------------------------------------------------------------------------------------
 // T wave
 // ------------------------------------------------------------------------------------------------
+// the pair's hand-off: a word counts up in LDS; the partner polls it (LDS operations of one wave execute in order: data first, then
+// the word).  Bounded: a protocol error must not hang the GPU.
+__device__ __forceinline__ bool seq_wait(const volatile uint32_t* p, uint32_t want) {
+  uint32_t spins = 0;
+  while ((int32_t)(*p - want) < 0) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 23)) return false;
+  }
+  asm volatile("" ::: "memory");
+  return true;
+}
+
 template <class G, bool TRACE>
-__device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* lds, double* pr, const int grp) {
+__device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* lds, double* pr, const int grp, int* abort_flag) {
   constexpr int NS = G::NS, NFAST = G::NFAST;
   const int lane = threadIdx.x & 63, x = lane & 3, b = (lane >> 2) & 3, r = lane >> 4;
   const int cl = grp * 4 + x;
@@ -148,17 +162,21 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
   auto coord = [&](int s) { return 16 * s + 4 * b + r; };
   double* const wbase = prm.work + (size_t)grp * G::group_doubles(prm.M);
   auto gvec = [&](int vec) { return wbase + (size_t)vec * G::VEC + lane; };  // + s * 64
-  const int vprop = (prm.M + 1) * 2;
-  const double* const znext = wbase + (size_t)((prm.M + 1) * 2 + 2) * G::VEC + (size_t)x * G::DPAD;
-  double* const cold = pr + G::P_COLD + lane;  // qb: + s * 64, vb: + VEC + s * 64
+  const int vprop = (prm.M + 1) * 2, vcold = vprop + 2;
+  const double* const znext = wbase + (size_t)((prm.M + 1) * 2 + 4) * G::VEC + (size_t)x * G::DPAD;
   double* const lc = pr + G::P_LC + lane;
+  double* const stage = pr + G::P_STAGE;
   double* const sums = pr + G::P_SUMS;
   const Cmd* const cmdbuf = reinterpret_cast<const Cmd*>(pr + G::P_CMD);
+  volatile uint32_t* const seq = reinterpret_cast<volatile uint32_t*>(pr + G::P_SEQ);  // [0]: ticks finished by T, [2]: commands issued by B
 
-  double q[NS], v[NS], g[NS], VL[NS], qm1[NS];
+  // P(t) = the position after the drift of tick t lives in X[t & 1]: at the start of tick t, X[(t-1) & 1] is the current position and
+  // X[t & 1] still holds P(t-2), the source of a multinomial pick commanded now (wn_fast.h); the drift overwrites it with P(t), and
+  // P(t-1) stays for the level-1 check behind the gradient.  No copies.
+  double X0[NS], X1[NS], v[NS], g[NS], VL[NS];
   double pq0[NS], pv0[NS], pq1[NS], pv1[NS];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) { q[s] = v[s] = g[s] = VL[s] = qm1[s] = 0.0; pq0[s] = pv0[s] = pq1[s] = pv1[s] = 0.0; }
+  for (int s = 0; s < NS; ++s) { X0[s] = X1[s] = v[s] = g[s] = VL[s] = 0.0; pq0[s] = pv0[s] = pq1[s] = pv1[s] = 0.0; }
   int ntr = 0;  // trace rows written (TRACE)
 
   // one batch of four per-chain sums: lanes r = 0 hold [block b'][chain x] = 16 consecutive doubles
@@ -166,164 +184,161 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     const double z = rows_sum(blocks_reduce_scatter(a0, a1, a2, a3));
     if (lane < 16) dst[lane] = z;
   };
-
   WN4_STAMP_DECL
-  for (uint32_t t = 0;; ++t) {
+
+  // One tick.  PAR = t & 1 is a compile-time constant (the loop below is unrolled by two): the bookkeeper starts leaf pairs on even
+  // ticks, so a stepping chain's leaf index has the tick's parity -- sub-tree checks (odd leaves), their prefetches, iteration starts
+  // (odd ticks) and endpoint stores (even leaves) each live in one of the two bodies only.  Returns false when the run is over.
+  auto tick = [&](auto par_tag, double (&qc)[NS], double (&qn)[NS], const uint32_t t) -> bool {
+    constexpr int PAR = decltype(par_tag)::value;
+    constexpr int NSR = G::NSR, NK = G::NK, NP = NSR / 2;
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const double* const img = lds + G::OFF_A + 2 * lane;
+    // the first fragments do not depend on the command: requested before it is waited for
+    d2_t fa[4][NP];
+    auto load_k = [&](int kap, d2_t* f) {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) f[j] = *reinterpret_cast<const d2_t*>(img + (kap * NP + j) * 128);
+    };
+#pragma unroll
+    for (int k0 = 0; k0 < 3; ++k0) if (k0 < NK) load_k(k0, fa[k0]);
+    d2_t fx[(NS - 1) / 2 > 0 ? (NS - 1) / 2 : 1];
+    double ftail = 0.0;
+    if (G::TAIL) {
+#pragma unroll
+      for (int j = 0; j < (NS - 1) / 2; ++j) fx[j] = *reinterpret_cast<const d2_t*>(img + G::NMAIN * 64 + j * 128);
+      ftail = lds[G::OFF_A + (G::NMAIN + NS - 1) * 64 + lane];
+    }
     Cmd c;
     if (t == 0) { c.hs = 0.0; c.op = inrange ? (OP_NEWITER | OP_INIT) : 0u; c.n = 0u; }
-    else c = cmdbuf[(t & 1u) * 4 + x];
+    else {
+      if (!seq_wait(seq + 2, t)) { if (lane == 0) atomicExch(abort_flag, 1); return false; }
+      c = cmdbuf[(t & 1u) * 4 + x];
+    }
     const uint32_t op = c.op;
-    if (__any((op & OP_DONE) != 0)) break;
+    if (__any((op & OP_DONE) != 0)) return false;
     double* const sp = sums + (t & 1u) * (G::NB * 16);
     const bool step = (op & OP_STEP) != 0;
     const int i = (int)((op >> OP_I_SHIFT) & 31u), n = (int)c.n;
-    const int nchk = step ? nchecks(i, n) : 0;
+    const int nchk = (PAR == 1 && step) ? nchecks(i, n) : 0;   // checks of levels >= 1 close at odd leaves
+    const bool l0due = step && n == (1 << i) - 1;               // the whole orbit against its passive end: last leaf of a doubling
     double keinit_part = 0.0, gen_part = 0.0;
     // ---- commands ----
-    // left endpoints of the first two off-chip sub-tree levels this leaf closes: requested now, used behind the MFMAs.
-    // (The registers live across ticks and are not cleared: see wn_k_fast.hip.)
     const bool deep0 = nchk > NFAST, deep1 = nchk > NFAST + 1;
-    // ONE vote for everything that does not happen on an ordinary leaf (every vote is a vector compare + a scalar branch
-    // that waits for it)
+    // ONE vote for everything that does not happen on an ordinary leaf
     const bool anyrare = __any((op & (OP_PICK | OP_NEWITER | OP_SWAP | OP_UNDO)) != 0 || deep0);
-    if (anyrare && __any(deep0)) {
-      if (deep0) {
-        const int sl = slot_of_leaf(n + 1 - (1 << NFAST));
-        const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
+    if (anyrare) {
+      if (PAR == 1 && __any(deep0)) {
+        if (deep0) {
+          const int sl = slot_of_leaf(n + 1 - (1 << NFAST));
+          const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) { pq0[s] = sq[s * 64]; pv0[s] = sv[s * 64]; }
-      }
-      if (deep1) {
-        const int sl = slot_of_leaf(n + 1 - (2 << NFAST));
-        const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) { pq1[s] = sq[s * 64]; pv1[s] = sv[s * 64]; }
-      }
-    }
-    if (anyrare && __any((op & OP_PICK) != 0)) {  // qm1 still holds the position of tick t-2
-      if (op & OP_PICK) {
-        double* dst = gvec(vprop + ((op & OP_IPPICK) ? 1 : 0));
-#pragma unroll
-        for (int s = 0; s < NS; ++s) dst[s * 64] = qm1[s];
-      }
-    }
-    if (TRACE && anyrare) { if (op & OP_UNDO) ntr -= 1; }  // the leaf in flight when the iteration ended
-#pragma unroll
-    for (int s = 0; s < NS; ++s) qm1[s] = q[s];  // the position of tick t-1: level-1 left endpoint, next tick's pick source
-    if (anyrare && __any((op & OP_NEWITER) != 0)) {
-      if (op & OP_NEWITER) {
-        if (op & OP_INIT) {
-          double* dst = gvec(vprop);
-#pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            q[s] = coord(s) < D ? prm.q0[(size_t)cl * D + coord(s)] : 0.0;
-            dst[s * 64] = q[s];
-          }
-        } else {
-          const double* src = gvec(vprop + ((op & OP_IPNEW) ? 1 : 0));
-#pragma unroll
-          for (int s = 0; s < NS; ++s) q[s] = src[s * 64];
+          for (int s = 0; s < NS; ++s) { pq0[s] = sq[s * 64]; pv0[s] = sv[s * 64]; }
         }
-        // samples[:, row] = generated(q)  (WALNUTS.py:164,695)
-        double* row = prm.samples + ((size_t)cl * (prm.numIter + 1) + c.n) * prm.dg;
-        if (prm.generated == G_Q0_SUMSQ) {
-          if (lane < 4) row[0] = q[0];  // coordinate 0: register 0 of lane (r = 0, b = 0, x)
-          double s2 = 0.0;
+        if (deep1) {
+          const int sl = slot_of_leaf(n + 1 - (2 << NFAST));
+          const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
 #pragma unroll
-          for (int s = 0; s < NS; ++s) s2 += q[s] * q[s];
-          gen_part = s2;
-        } else {
-          const int k = prm.generated == G_FIRSTK ? prm.gen_k : D;
-#pragma unroll
-          for (int s = 0; s < NS; ++s) if (coord(s) < k) row[coord(s)] = q[s];
-        }
-        if (!(op & (OP_INIT | OP_LAST))) {  // v = normal(size=d); both ends start at (qc, v)  (:236-253)
-          double kp = 0.0;
-#pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            const double z = znext[coord(s)];
-            v[s] = z;
-            kp += z * z;
-          }
-          keinit_part = kp;
-#pragma unroll
-          for (int s = 0; s < NS; ++s) { cold[s * 64] = q[s]; cold[G::VEC + s * 64] = v[s]; }
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): waited for HERE, not on the common path (wn_k_fast.hip)
-      }
-    }
-    if (anyrare && __any((op & OP_SWAP) != 0)) {  // the other end of the orbit becomes the active one (:283-286)
-      if (op & OP_SWAP) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          const double tq = cold[s * 64], tv = cold[G::VEC + s * 64];
-          cold[s * 64] = q[s]; cold[G::VEC + s * 64] = v[s];
-          q[s] = tq; v[s] = tv;
+          for (int s = 0; s < NS; ++s) { pq1[s] = sq[s * 64]; pv1[s] = sv[s * 64]; }
         }
       }
+      if (__any((op & OP_PICK) != 0)) {  // qn still holds the position of tick t-2
+        if (op & OP_PICK) {
+          double* dst = gvec(vprop + ((op & OP_IPPICK) ? 1 : 0));
+#pragma unroll
+          for (int s = 0; s < NS; ++s) dst[s * 64] = qn[s];
+        }
+      }
+      if (TRACE) { if (op & OP_UNDO) ntr -= 1; }  // the leaf in flight when the iteration ended
     }
     // ---- first half of the leapfrog step (adaptiveIntegrators.py:51-52 with hs = xi*h; v stays forward-time) ----
     const double hs = step ? c.hs : 0.0, hs2 = 0.5 * hs;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) { v[s] = v[s] + hs2 * g[s]; q[s] = q[s] + hs * v[s]; }
+    for (int s = 0; s < NS; ++s) { v[s] = v[s] + hs2 * g[s]; qn[s] = qc[s] + hs * v[s]; }
+    // iteration starts and end swaps replace the position this tick produces (qn; such ticks do not step: hs = 0).  qc is left alone: it
+    // is the position of tick t-1, which a pick commanded at tick t+1 copies (the last leaf of a doubling can be picked while the end swap
+    // of the next doubling is already under way)
+    if (anyrare) {
+      if ((PAR == 1 || t == 0) && __any((op & OP_NEWITER) != 0)) {  // (iterations start on odd ticks; tick 0 loads q0)
+        if (op & OP_NEWITER) {
+          if (op & OP_INIT) {
+            double* dst = gvec(vprop);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+              qn[s] = coord(s) < D ? prm.q0[(size_t)cl * D + coord(s)] : 0.0;
+              dst[s * 64] = qn[s];
+            }
+          } else {
+            const double* src = gvec(vprop + ((op & OP_IPNEW) ? 1 : 0));
+#pragma unroll
+            for (int s = 0; s < NS; ++s) qn[s] = src[s * 64];
+          }
+          // samples[:, row] = generated(q)  (WALNUTS.py:164,695)
+          double* row = prm.samples + ((size_t)cl * (prm.numIter + 1) + c.n) * prm.dg;
+          if (prm.generated == G_Q0_SUMSQ) {
+            if (lane < 4) row[0] = qn[0];  // coordinate 0: register 0 of lane (r = 0, b = 0, x)
+            double s2 = 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) s2 += qn[s] * qn[s];
+            gen_part = s2;
+          } else {
+            const int k = prm.generated == G_FIRSTK ? prm.gen_k : D;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) if (coord(s) < k) row[coord(s)] = qn[s];
+          }
+          if (!(op & (OP_INIT | OP_LAST))) {  // v = normal(size=d); both ends start at (qc, v)  (:236-253)
+            double kp = 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+              const double z = znext[coord(s)];
+              v[s] = z;
+              kp += z * z;
+            }
+            keinit_part = kp;
+            double *dq_ = gvec(vcold), *dv_ = gvec(vcold + 1);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { dq_[s * 64] = qn[s]; dv_[s * 64] = v[s]; }
+          }
+          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): waited for HERE, not on the common path (wn_k_fast.hip)
+        }
+      }
+      if (__any((op & OP_SWAP) != 0)) {  // the other end of the orbit becomes the active one (:283-286); the passive end lives in memory
+        if (op & OP_SWAP) {
+          double *dq_ = gvec(vcold), *dv_ = gvec(vcold + 1);
+          double tq[NS], tv[NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) { tq[s] = dq_[s * 64]; tv[s] = dv_[s * 64]; }
+#pragma unroll
+          for (int s = 0; s < NS; ++s) { dq_[s * 64] = qc[s]; dv_[s * 64] = v[s]; qn[s] = tq[s]; v[s] = tv[s]; }  // (no step on this tick)
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+      }
+    }
+    // the position goes to LDS: k-step kappa's B operand (coordinates 4 kappa .. + 3 in EVERY block) is read back from there with the
+    // block index replaced -- one LDS read per k-step instead of six DPP moves (FP64 MFMAs and vector instructions share the SIMD)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) stage[s * 64 + lane] = qn[s];
     WN4_STAMP(0);
     // ---- G = -A Q ----
     {
-      constexpr int NSR = G::NSR, NK = G::NK, NP = NSR / 2;
-      typedef double d2_t __attribute__((ext_vector_type(2)));
-      const double* const img = lds + G::OFF_A + 2 * lane;
-      // fragments of k-step kappa: NSR / 2 reads of 16 bytes (the image interleaves two fragments per lane: ds_read_b128 moves
-      // 256 B per clock; the ds_read2st64_b64 the compiler makes of two 8-byte reads moves half that, and four T waves reading
-      // 80 KB each per tick then keep the LDS busy for 2.5 k cycles).  Four k-steps are in flight / in use.
-      d2_t fa[4][NP];
-      auto load_k = [&](int kap, d2_t* f) {
-#if defined(WN4_NOLDS)  // timing diagnostic only (wrong fragments)
-#pragma unroll
-        for (int j = 0; j < NP; ++j) { f[j][0] = hs * (double)(kap + j); f[j][1] = hs2 + (double)j; }
-#else
-#pragma unroll
-        for (int j = 0; j < NP; ++j) f[j] = *reinterpret_cast<const d2_t*>(img + (kap * NP + j) * 128);
-#endif
-      };
-#pragma unroll
-      for (int k0 = 0; k0 < 3; ++k0) if (k0 < NK) load_k(k0, fa[k0]);
-      // the K-split row group of the last four rows (TAIL): its fragments, then one MFMA under each of the first k-steps
-      d2_t fx[(NS - 1) / 2 > 0 ? (NS - 1) / 2 : 1];
-      double ftail = 0.0, accx = 0.0, gx = 0.0;
-      if (G::TAIL) {
-#pragma unroll
-        for (int j = 0; j < (NS - 1) / 2; ++j) fx[j] = *reinterpret_cast<const d2_t*>(img + G::NMAIN * 64 + j * 128);
-        ftail = lds[G::OFF_A + (G::NMAIN + NS - 1) * 64 + lane];
-      }
+      const double* const st0 = stage + 16 * r + x;  // + s * 64 + 4 * b'
+      double accx = 0.0, gx = 0.0;
       double acc[NSR];
 #pragma unroll
       for (int S = 0; S < NSR; ++S) acc[S] = 0.0;
-      auto bcast = [&](double x_, int bp) {  // block bp of every row of 16 lanes to the row's other blocks
-        if (bp == 0) { x_ = dpp_sel<DPP_SHR4, 0x2>(x_, x_); return dpp_sel<DPP_SHR8, 0xC>(x_, x_); }
-        if (bp == 1) { x_ = dpp_sel<DPP_SHL4, 0x1>(x_, x_); return dpp_sel<DPP_SHR8, 0xC>(x_, x_); }
-        if (bp == 2) { x_ = dpp_sel<DPP_SHR4, 0x8>(x_, x_); return dpp_sel<DPP_SHL8, 0x3>(x_, x_); }
-        x_ = dpp_sel<DPP_SHL4, 0x4>(x_, x_); return dpp_sel<DPP_SHL8, 0x3>(x_, x_);
-      };
+      double qks[3];  // the B operands of three k-steps in flight / in use
+#pragma unroll
+      for (int k0 = 0; k0 < 2; ++k0) if (k0 < NK) qks[k0] = st0[(k0 >> 2) * 64 + 4 * (k0 & 3)];
 #pragma unroll
       for (int kap = 0; kap < NK; ++kap) {
         if (kap + 3 < NK) load_k(kap + 3, fa[(kap + 3) & 3]);
-        const double qk = bcast(q[kap >> 2], kap & 3);  // (TAIL: the last k-step is block 0 of the last register)
+        if (kap + 2 < NK) qks[(kap + 2) % 3] = st0[((kap + 2) >> 2) * 64 + 4 * ((kap + 2) & 3)];
+        const double qk = qks[kap % 3];
         const d2_t* f = fa[kap & 3];
 #pragma unroll
         for (int S = 0; S < NSR; ++S) acc[S] = mfma4(f[S >> 1][S & 1], qk, acc[S]);
-#if defined(WN4_SGB)
-        // issue order: an MFMA holds the SIMD's vector issue for part of its 16 cycles only; one LDS read or two vector
-        // instructions behind each MFMA cost nothing, a cluster of six between two MFMAs does
-#pragma unroll
-        for (int S = 0; S < NSR; ++S) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (S < NP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          else __builtin_amdgcn_sched_group_barrier(0x002, WN4_SGB, 0);
-        }
-        if (G::TAIL && kap < NS - 1) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#endif
         if (G::TAIL) {
-          if (kap < NS - 1) accx = mfma4(fx[kap >> 1][kap & 1], q[kap], accx);
+          if (kap < NS - 1) accx = mfma4(fx[kap >> 1][kap & 1], qn[kap], accx);
           if (kap == NS + 1) gx = blocks_sum(accx);          // (two k-steps behind its last MFMA)
           if (kap == NK - 1) gx = mfma4(ftail, qk, gx);      // columns 16 (NS-1) .. + 3
         }
@@ -333,17 +348,30 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
       if (G::TAIL) g[NS - 1] = b == 0 ? gx : 0.0;  // blocks 1..3 of the last register are padding
     }
     WN4_STAMP(1);
+    // the passive orbit end lives in memory (once per doubling: the whole-orbit check at its last leaf, and the end swaps): requested
+    // here, in the registers the fragments have left, used after the half step
+    const bool anyl0 = __any(l0due);
+    double cq[NS], cv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { cq[s] = 0.0; cv[s] = 0.0; }
+    if (anyl0) {
+      if (l0due) {
+        const double *sq = gvec(vcold), *sv = gvec(vcold + 1);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { cq[s] = sq[s * 64]; cv[s] = sv[s * 64]; }
+      }
+    }
     // ---- second half step; lp = 1/2 q.g, KE = 1/2 v.v ----
     double pl = 0.0, pk = 0.0;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) pl += q[s] * g[s];
+    for (int s = 0; s < NS; ++s) pl += qn[s] * g[s];
 #pragma unroll
     for (int s = 0; s < NS; ++s) { v[s] = v[s] + hs2 * g[s]; pk += v[s] * v[s]; }
     if (TRACE) {  // one row per integrator call: the state (q', v') goes here, the scalars come from the bookkeeper
       if (step && prm.trace && ntr < prm.trace_cap && ntr >= 0) {
         double* tr = prm.trace + ((size_t)cl * prm.trace_cap + ntr) * (TRACE_NSCAL + 2 * D) + TRACE_NSCAL;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) if (coord(s) < D) { tr[coord(s)] = q[s]; tr[D + coord(s)] = v[s]; }
+        for (int s = 0; s < NS; ++s) if (coord(s) < D) { tr[coord(s)] = qn[s]; tr[D + coord(s)] = v[s]; }
       }
       if (step) ntr += 1;
     }
@@ -352,7 +380,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
       double a1 = 0.0, a2 = 0.0;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const double dq = q[s] - qo[s];
+        const double dq = qn[s] - qo[s];
         a1 += v[s] * dq;
         a2 += vo[s] * dq;
       }
@@ -360,71 +388,76 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     };
     {
       double a1 = 0.0, a2 = 0.0;
-      if (__any(step && n == (1 << i) - 1)) {  // level 0: the whole orbit against its passive end
-        double qo[NS], vo[NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) { qo[s] = cold[s * 64]; vo[s] = cold[G::VEC + s * 64]; }
-        dots(qo, vo, a1, a2);
-      }
+      if (anyl0) dots(cq, cv, a1, a2);  // level 0
       put4(sp, pl, pk, a1, a2);
     }
-    if (__any(nchk > 1)) {  // levels 1 (the leaf pair: registers) and 2 (LDS)
-      double a1, a2, b1 = 0.0, b2 = 0.0;
-      dots(qm1, VL, a1, a2);
-      if (__any(nchk > 2)) {
-        double qo[NS], vo[NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) { qo[s] = lc[s * 64]; vo[s] = lc[G::VEC + s * 64]; }
-        dots(qo, vo, b1, b2);
-      }
-      put4(sp + 16, a1, a2, b1, b2);
-    }
-    if (__any(nchk > 3)) {  // levels 3, 4: prefetched
-      double a1, a2, b1, b2;
-      dots(pq0, pv0, a1, a2);
-      dots(pq1, pv1, b1, b2);
-      put4(sp + 32, a1, a2, b1, b2);
-    }
-    for (int j = 5; __any(nchk > j); j += 2) {  // still deeper levels (one leaf in 32): fetched here
-      double e[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if (nchk > j + h) {
-          const int sl = slot_of_leaf(n + 1 - (1 << (j + h)));
-          const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
+    if (PAR == 1) {
+      if (__any(nchk > 1)) {  // levels 1 (the leaf pair: registers) and 2 (LDS)
+        double a1, a2, b1 = 0.0, b2 = 0.0;
+        dots(qc, VL, a1, a2);
+        if (__any(nchk > 2)) {
           double qo[NS], vo[NS];
 #pragma unroll
-          for (int s = 0; s < NS; ++s) { qo[s] = sq[s * 64]; vo[s] = sv[s * 64]; }
-          dots(qo, vo, e[2 * h], e[2 * h + 1]);
+          for (int s = 0; s < NS; ++s) { qo[s] = lc[s * 64]; vo[s] = lc[G::VEC + s * 64]; }
+          dots(qo, vo, b1, b2);
+        }
+        put4(sp + 16, a1, a2, b1, b2);
+      }
+      if (anyrare && __any(nchk > 3)) {  // levels 3, 4: prefetched
+        double a1, a2, b1, b2;
+        dots(pq0, pv0, a1, a2);
+        dots(pq1, pv1, b1, b2);
+        put4(sp + 32, a1, a2, b1, b2);
+      }
+      if (anyrare) {
+        for (int j = 5; __any(nchk > j); j += 2) {  // still deeper levels (one leaf in 32): fetched here
+          double e[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (nchk > j + h) {
+              const int sl = slot_of_leaf(n + 1 - (1 << (j + h)));
+              const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
+              double qo[NS], vo[NS];
+#pragma unroll
+              for (int s = 0; s < NS; ++s) { qo[s] = sq[s * 64]; vo[s] = sv[s * 64]; }
+              dots(qo, vo, e[2 * h], e[2 * h + 1]);
+            }
+          }
+          put4(sp + 16 * ((j + 1) >> 1), e[0], e[1], e[2], e[3]);
         }
       }
-      put4(sp + 16 * ((j + 1) >> 1), e[0], e[1], e[2], e[3]);
     }
-    if (anyrare && __any((op & OP_NEWITER) != 0)) put4(sp + 16 * (G::NB - 1), keinit_part, gen_part, 0.0, 0.0);
+    if ((PAR == 1 || t == 0) && anyrare && __any((op & OP_NEWITER) != 0)) put4(sp + 16 * (G::NB - 1), keinit_part, gen_part, 0.0, 0.0);
     WN4_STAMP(2);
-    // ---- statePush (:431,518): only sub-tree left endpoints are ever read back ----
-    const bool even = step && i >= 1 && (n & 1) == 0;
+    // ---- statePush (:431,518): only sub-tree left endpoints are ever read back; they are even leaves ----
+    if (PAR == 0) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) VL[s] = even ? v[s] : VL[s];  // (selects: no branch on the common path)
-    const bool ep = even && i >= 2 && (n & 3) == 0;
-    if (__any(ep)) {
-      if (ep) {
+      for (int s = 0; s < NS; ++s) VL[s] = v[s];  // (a chain that does not step now sets VL again before its next odd leaf reads it)
+      const bool ep = step && i >= 2 && (n & 3) == 0;
+      if (__any(ep)) {
+        if (ep) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) { lc[s * 64] = q[s]; lc[G::VEC + s * 64] = v[s]; }
-        if (n == 0 ? (i >= NFAST) : (__builtin_ctz((unsigned)n) >= NFAST)) {
-          const int sl = slot_of_leaf(n);
-          double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
+          for (int s = 0; s < NS; ++s) { lc[s * 64] = qn[s]; lc[G::VEC + s * 64] = v[s]; }
+          if (n == 0 ? (i >= NFAST) : (__builtin_ctz((unsigned)n) >= NFAST)) {
+            const int sl = slot_of_leaf(n);
+            double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
 #pragma unroll
-          for (int s = 0; s < NS; ++s) { sq[s * 64] = q[s]; sv[s * 64] = v[s]; }
+            for (int s = 0; s < NS; ++s) { sq[s * 64] = qn[s]; sv[s * 64] = v[s]; }
+          }
         }
       }
     }
     WN4_STAMP(3);
-    WN4_BARRIER();
+    if (lane == 0) seq[0] = t + 1u;  // the sums of tick t are in LDS (same wave, in order)
     WN4_STAMP(4);
 #if defined(WN_STAMPS)
     fst_[6] += 1;
 #endif
+    return true;
+  };
+  for (uint32_t t = 0;; t += 2) {
+    if (!tick(std::integral_constant<int, 0>{}, X1, X0, t)) break;
+    if (!tick(std::integral_constant<int, 1>{}, X0, X1, t + 1u)) break;
   }
   WN4_STAMP_OUT(prm)
 }
@@ -441,22 +474,23 @@ struct Fast4IO {
   double lp, ke, keinit, gen;
   uint32_t fire;
   int ntrace;
-  // three entries of the uniform window read with the tick's other LDS words: the blocks the chain is about to use
+  // three consecutive entries of the uniform window (blocks p_b0 .. p_b0 + 2 of iteration p_iter), read with the tick's other LDS
+  // words and checked ONCE: the blocks an ordinary retirement + issue of this tick use.  A lookup is then a select by index.
   // (scalar members: arrays in this struct sent it -- and the kernel's parameter block with it -- to scratch memory)
-  uint32_t p_it0, p_it1, p_it2, p_blk0, p_blk1, p_blk2;
+  uint32_t p_iter, p_b0;
+  bool p_valid;
   double p_u00, p_u01, p_u02, p_u10, p_u11, p_u12;
   __device__ __forceinline__ double sum(int k) const { return k == Q_LP ? lp : k == Q_KE ? ke : k == Q_KEINIT ? keinit : gen; }
   __device__ __forceinline__ uint32_t firemask(int, int, int) const { return fire; }
   __device__ __forceinline__ bool uniforms(int, int iter, uint32_t blk, double& ua, double& ub) const {
-    const bool h0 = p_it0 == (uint32_t)iter && p_blk0 == blk, h1 = p_it1 == (uint32_t)iter && p_blk1 == blk,
-               h2 = p_it2 == (uint32_t)iter && p_blk2 == blk;
+    const uint32_t j = blk - p_b0;
     // (single exit, select form: an early return here kept the whole bookkeeper in scratch memory)
-    bool hit = h0 || h1 || h2;
+    bool hit = p_valid && p_iter == (uint32_t)iter && j < 3u;
     // (the members are read into registers behind an opaque barrier: left alone, the compiler turns a select between two loaded
     // members into a load from a selected ADDRESS, and a struct whose members' addresses are selected at run time stays in memory)
     double a0 = p_u00, a1 = p_u01, a2 = p_u02, b0 = p_u10, b1 = p_u11, b2 = p_u12;
     asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2));
-    double va = h0 ? a0 : h1 ? a1 : a2, vb = h0 ? b0 : h1 ? b1 : b2;
+    double va = j == 0u ? a0 : j == 1u ? a1 : a2, vb = j == 0u ? b0 : j == 1u ? b1 : b2;
     if (!hit) {
       const double* e = pr + (blk < 8u ? G::P_USTAT + (x * 8 + (int)blk) * 3 : G::P_URING + (x * 16 + (int)(blk & 15u)) * 3);
       const uint32_t* tag = reinterpret_cast<const uint32_t*>(e);
@@ -494,17 +528,19 @@ struct Fast4IO {
 };
 
 template <class G, bool TRACE>
-__device__ __forceinline__ void fast4_b_wave(const Params& prm, double* lds, double* pr, const int grp, const int pairs, int* abort_flag) {
+__device__ __forceinline__ void fast4_b_wave(const Params& prm, double* pr, const int grp, int* abort_flag) {
   const int lane = threadIdx.x & 63, x = lane & 3, rep = lane >> 2;
   const int cl = grp * 4 + x;
   const bool inrange = cl < prm.C;
   Cmd* const cmdbuf = reinterpret_cast<Cmd*>(pr + G::P_CMD);
-  double* const znext = prm.work + (size_t)grp * G::group_doubles(prm.M) + (size_t)((prm.M + 1) * 2 + 2) * G::VEC;
+  double* const znext = prm.work + (size_t)grp * G::group_doubles(prm.M) + (size_t)((prm.M + 1) * 2 + 4) * G::VEC;
+  volatile uint32_t* const seq = reinterpret_cast<volatile uint32_t*>(pr + G::P_SEQ);  // [0]: ticks finished by T, [2]: commands issued by B
   FastBook bk;
   bk.init(prm.chain0 + (uint32_t)cl, inrange, prm.numIter);
   Fast4IO<G, TRACE> io;
   io.prm = &prm; io.pr = pr; io.cl = cl; io.x = x; io.rep = rep;
   io.lp = io.ke = io.keinit = io.gen = 0.0; io.fire = 0u; io.ntrace = 0;
+  io.p_iter = 0u; io.p_b0 = 0u; io.p_valid = false; io.p_u00 = io.p_u01 = io.p_u02 = io.p_u10 = io.p_u11 = io.p_u12 = 0.0;
   int witer = 0;          // iteration and first block of the uniform window
   uint32_t wbase = 0u;
   // every chain needs at most numIter * (2^M - 1 + 2 idle ticks per doubling + start) ticks; twice that is an internal error
@@ -518,8 +554,9 @@ __device__ __forceinline__ void fast4_b_wave(const Params& prm, double* lds, dou
       c.hs = 1.0e-4; c.op = OP_STEP | (10u << OP_I_SHIFT); c.n = t & 1023u;
       const bool done = t >= (uint32_t)(WN4_TONLY);
       if (done) c.op |= OP_DONE;
+      if (t > 0 && !seq_wait(seq, t)) break;
       if (rep == 0) cmdbuf[((t + 1u) & 1u) * 4 + x] = c;
-      WN4_BARRIER();
+      if (lane == 0) seq[2] = t + 1u;
       if (done) break;
       continue;
     }
@@ -572,73 +609,87 @@ __device__ __forceinline__ void fast4_b_wave(const Params& prm, double* lds, dou
       }
     }
     WN4_STAMP(0);
-    // ---- every LDS word of this tick, requested together: the sums of tick t-1 (at t = 0: the zeroed other half), the dots
-    // of check level j = replica index, the other pairs' finished flags, three entries of the uniform window ----
+    // ---- the T wave has finished tick t-1: its sums are in LDS ----
+    if (t > 0 && !seq_wait(seq, t)) { if (lane == 0) atomicExch(abort_flag, 1); break; }
+    WN4_STAMP(5);
+    // ---- the LDS words of this tick, requested together: the lp / KE sums of tick t-1 (at t = 0: the zeroed other half), three
+    // entries of the uniform window; the U-turn dots and the iteration-start sums only on the ticks that retire something that has them
     const double* sp = pr + G::P_SUMS + ((t + 1u) & 1u) * (G::NB * 16);
-    const int jl = rep <= G::MP ? rep : G::MP;
-    const double* dp = sp + (jl == 0 ? 8 : 16 * ((jl + 1) >> 1) + ((jl & 1) ? 0 : 8)) + x;
-    const double s_lp = sp[x], s_ke = sp[4 + x], s_ki = sp[16 * (G::NB - 1) + x], s_gen = sp[16 * (G::NB - 1) + 4 + x];
-    const double d1 = dp[0], d2 = dp[4];
-    const double* fbase = lds + G::OFF_PAIR + G::P_FLAGS + ((t + 1u) & 1u);
-    const double fl0 = fbase[0], fl1 = fbase[(size_t)(1 < pairs ? 1 : 0) * G::PAIR_DOUBLES],
-                 fl2 = fbase[(size_t)(2 < pairs ? 2 : 0) * G::PAIR_DOUBLES], fl3 = fbase[(size_t)(3 < pairs ? 3 : 0) * G::PAIR_DOUBLES];
+    const bool retiring = bk.s0.kind == FastBook::K_STEP && !bk.s0.discard;
+    const bool haschk = retiring && ((bk.s0.n & 1) != 0 || bk.s0.n == (1 << bk.i) - 1);  // odd leaves close sub-trees, the last leaf the orbit
+    const unsigned long long vote = __ballot(haschk) | (__ballot(bk.s0.kind == FastBook::K_NEWITER) ? 1ull << 63 : 0ull);  // (one branch for both)
+    const double s_lp = sp[x], s_ke = sp[4 + x];
     {
-      const uint32_t b0 = bk.fast_first_uniform() >> 1;  // the blocks an ordinary retirement + issue of this tick read
+      const uint32_t b0 = bk.fast_first_uniform() >> 1;
       const double* e0 = pr + G::P_URING + (x * 16 + (int)(b0 & 15u)) * 3;
       const double* e1 = pr + G::P_URING + (x * 16 + (int)((b0 + 1u) & 15u)) * 3;
       const double* e2 = pr + G::P_URING + (x * 16 + (int)((b0 + 2u) & 15u)) * 3;
-      io.p_it0 = reinterpret_cast<const uint32_t*>(e0)[0]; io.p_blk0 = reinterpret_cast<const uint32_t*>(e0)[1]; io.p_u00 = e0[1]; io.p_u10 = e0[2];
-      io.p_it1 = reinterpret_cast<const uint32_t*>(e1)[0]; io.p_blk1 = reinterpret_cast<const uint32_t*>(e1)[1]; io.p_u01 = e1[1]; io.p_u11 = e1[2];
-      io.p_it2 = reinterpret_cast<const uint32_t*>(e2)[0]; io.p_blk2 = reinterpret_cast<const uint32_t*>(e2)[1]; io.p_u02 = e2[1]; io.p_u12 = e2[2];
+      const uint32_t it0 = reinterpret_cast<const uint32_t*>(e0)[0], bl0 = reinterpret_cast<const uint32_t*>(e0)[1];
+      const uint32_t it1 = reinterpret_cast<const uint32_t*>(e1)[0], bl1 = reinterpret_cast<const uint32_t*>(e1)[1];
+      const uint32_t it2 = reinterpret_cast<const uint32_t*>(e2)[0], bl2 = reinterpret_cast<const uint32_t*>(e2)[1];
+      io.p_u00 = e0[1]; io.p_u10 = e0[2]; io.p_u01 = e1[1]; io.p_u11 = e1[2]; io.p_u02 = e2[1]; io.p_u12 = e2[2];
+      const uint32_t it = (uint32_t)bk.iter;
+      io.p_iter = it; io.p_b0 = b0;
+      io.p_valid = it0 == it && it1 == it && it2 == it && bl0 == b0 && bl1 == b0 + 1u && bl2 == b0 + 2u;
     }
-    io.lp = s_lp; io.ke = s_ke; io.keinit = s_ki; io.gen = s_gen;
-    {  // verdict of check level j = replica index (wn_fast.h fire_of), then OR over the replicas of the chain
-      uint32_t f = 0u;
-      if (bk.s0.kind == FastBook::K_STEP && !bk.s0.discard && rep <= G::MP && need_check(bk.i, bk.s0.n, rep)) {
-        const double xi = (double)bk.xi;
-        if ((xi * d1 < 0.0) || (xi * d2 < 0.0)) f = 1u << rep;
+    io.lp = s_lp; io.ke = s_ke;
+    io.fire = 0u;
+    if (vote) {
+      if (vote >> 63) { io.keinit = sp[16 * (G::NB - 1) + x]; io.gen = sp[16 * (G::NB - 1) + 4 + x]; }
+      if (vote << 1) {  // verdict of check level j = replica index (wn_fast.h fire_of), then OR over the replicas of the chain
+        const int jl = rep <= G::MP ? rep : G::MP;
+        const double* dp = sp + (jl == 0 ? 8 : 16 * ((jl + 1) >> 1) + ((jl & 1) ? 0 : 8)) + x;
+        const double d1 = dp[0], d2 = dp[4];
+        uint32_t f = 0u;
+        if (retiring && rep <= G::MP && need_check(bk.i, bk.s0.n, rep)) {
+          const double xi = (double)bk.xi;
+          if ((xi * d1 < 0.0) || (xi * d2 < 0.0)) f = 1u << rep;
+        }
+        f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x124, 0xF, 0xF, false);  // row_ror:4
+        f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x128, 0xF, 0xF, false);  // row_ror:8
+        typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+        u2_t w = __builtin_amdgcn_permlane16_swap(f, f, false, false);
+        f = w[0] | w[1];
+        w = __builtin_amdgcn_permlane32_swap(f, f, false, false);
+        io.fire = w[0] | w[1];
       }
-      f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x124, 0xF, 0xF, false);  // row_ror:4
-      f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x128, 0xF, 0xF, false);  // row_ror:8
-      typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-      u2_t w = __builtin_amdgcn_permlane16_swap(f, f, false, false);
-      f = w[0] | w[1];
-      w = __builtin_amdgcn_permlane32_swap(f, f, false, false);
-      io.fire = w[0] | w[1];
     }
     WN4_STAMP(1);
 #if defined(WN4_TONLY)  // diagnostic: the T waves alone, on a fixed stream of ordinary leaves
     Cmd c;
     c.hs = 1.0e-4; c.op = OP_STEP | (10u << OP_I_SHIFT); c.n = t & 1023u;
-    const bool done = t >= (uint32_t)(WN4_TONLY);
-    bool mine = true;
+    bool done = t >= (uint32_t)(WN4_TONLY);
 #else
     // the ordinary leaf (wn_fast.h, fast_prepare / fast_commit): straight-line when every chain of the wave is there
     Cmd c;
 #if defined(WN4_FASTPATH)  // (pays only once the pairs of a workgroup stop sharing a barrier: with four pairs in lockstep a tick is as
                            // slow as its slowest bookkeeper, and all four are on the fast path on 27 % of the ticks: measured 8.6e8 vs 9.9e8)
     FastBook::Fast ff;
+    bk.retire_pre(prm, io);  // (tick() = retire_pre() + tick_post(): the leaf's energy / weight arithmetic is common to both paths)
     const bool ordinary = bk.fast_prepare(prm, io, t + 1u, ff);
-    if (__all(ordinary)) c = bk.fast_commit(prm, io, ff);
-    else c = bk.tick(prm, io, t + 1u);
+    if (__builtin_expect(__all(ordinary), 1)) {
+      c = bk.fast_commit(prm, io, ff);
+#if defined(WN_STAMPS)
+      fst_[7] += 1;
+#endif
+    } else {
+      c = bk.tick_post(prm, io, t + 1u);
+    }
 #else
     c = bk.tick(prm, io, t + 1u);
 #endif
     WN4_STAMP(2);
-    // ---- every pair of the workgroup has finished: all waves leave (the flags were written one tick ago) ----
-    const bool done = t > 0 && fl0 != 0.0 && fl1 != 0.0 && fl2 != 0.0 && fl3 != 0.0;
-    bool mine = __all(bk.finished());
+    // ---- every chain of the pair has finished: both waves leave (the pairs of a workgroup do not wait for each other) ----
+    bool done = __all(bk.finished());
     if ((double)t > cap) {  // cannot happen; never hang the GPU
       if (lane == 0) atomicExch(abort_flag, 1);
-      mine = true;
+      done = true;
     }
 #endif
-    if (lane == 0) pr[G::P_FLAGS + (t & 1u)] = mine ? 1.0 : 0.0;
     if (done) c.op |= OP_DONE;
     if (rep == 0) cmdbuf[((t + 1u) & 1u) * 4 + x] = c;
+    if (lane == 0) seq[2] = t + 1u;  // command t+1 is in LDS (same wave, in order)
     WN4_STAMP(3);
-    WN4_BARRIER();
-    WN4_STAMP(4);
 #if defined(WN_STAMPS)
     fst_[6] += 1;
 #endif
@@ -676,21 +727,24 @@ __global__ __launch_bounds__(512) void wn_fast4_kernel(Params prm, int* abort_fl
   const int pair = wave < pairs ? wave : wave - pairs;  // waves w and w + 4 share a SIMD (speed only)
   double* pr = lds + G::OFF_PAIR + (size_t)pair * G::PAIR_DOUBLES;
   const int grp = blockIdx.x * pairs + pair;
-#if defined(WN4_BFIRST)  // the bookkeepers are the older waves of their SIMDs
-  const bool is_t = wave >= pairs;
-#else
+  // The bookkeepers are the OLDER waves of their SIMDs (waves 0 .. pairs-1): the SIMD issues the oldest ready wave first, and a
+  // bookkeeper behind a T wave got a vector instruction in only when the T wave stalled -- the two ran one after the other (8.2 k
+  // cycles per tick; measured 1.08e9 -> 1.24e9 steps/s with the order swapped, s_setprio for the bookkeeper gives the same).
+#if defined(WN4_TFIRST)
   const bool is_t = wave < pairs;
+#else
+  const bool is_t = wave >= pairs;
 #endif
   if (is_t) {
 #if defined(WN4_TPRIO)
     __builtin_amdgcn_s_setprio(WN4_TPRIO);
 #endif
-    fast4_t_wave<G, TRACE>(prm, lds, pr, grp);
+    fast4_t_wave<G, TRACE>(prm, lds, pr, grp, abort_flag);
   } else {
 #if defined(WN4_BPRIO)
     __builtin_amdgcn_s_setprio(WN4_BPRIO);
 #endif
-    fast4_b_wave<G, TRACE>(prm, lds, pr, grp, pairs, abort_flag);
+    fast4_b_wave<G, TRACE>(prm, pr, grp, abort_flag);
   }
 }
 
