@@ -634,32 +634,46 @@ def main_dry_run():
 
 def main_walnuts10(args):
     """BASELINE configs[0]'s target (10-D standard normal, test/test.py:11-18 parameters: macro_step 2.0, max_nuts_depth 10,
-    max_error 0.1) through `walnuts_batch` (walnuts/walnuts.py:279-408): transitions/s of `--chains` chains, one Generator
-    each.  The reference runs ~1.2e3 transitions/s on one core."""
+    max_error 0.1) as whole transitions on the device (`walnuts_device`: walnuts/walnuts.py:279-359 with the engine's random
+    stream): transitions/s of `--chains` chains.  Beside it, the host-Generator form (`walnuts_batch`, the reference's contract)
+    on a small batch.  The reference runs ~1.2e3 transitions/s on one core."""
     import torch
     from walnuts_amd import targetDistr as td
     import walnuts_amd as wa
     C = args.chains or 4096
-    iters = args.iters or 4
+    iters = args.iters or 20
     D = 10
-    rngs = [np.random.default_rng(1000 + c) for c in range(C)]
     theta = np.zeros((C, D))
-    tgt = td.stdGauss
     t_all = []
+    d = None
     for k in range(args.warmup + args.steps):
         t0 = time.perf_counter()
-        d = wa.walnuts_batch(rngs, theta, tgt, tgt, np.ones(D), 2.0, 10, 0.1, 0, iters)
+        d = wa.walnuts_device(SEED + k, theta, td.stdGauss, np.ones(D), 2.0, 10, 0.1, 0, iters, transitions_per_launch=iters)
         torch.cuda.synchronize()
         if k >= args.warmup:
             t_all.append(time.perf_counter() - t0)
-        theta = d[:, -1, :]
     el = float(np.sum(t_all))
+    # the host-Generator form on 64 chains, 2 transitions
+    rngs = [np.random.default_rng(1000 + c) for c in range(64)]
+    t0 = time.perf_counter()
+    wa.walnuts_batch(rngs, np.zeros((64, D)), td.stdGauss, td.stdGauss, np.ones(D), 2.0, 10, 0.1, 0, 2)
+    host_rate = 64 * 2 / (time.perf_counter() - t0)
+    from walnuts_amd.ess import ess
+    per = el / args.steps
     print(json.dumps({"metric": "transitions/sec across chains, walnuts() on the 10-D standard normal", "value": C * iters * args.steps / el,
-                      "unit": "transitions/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+                      "unit": "transitions/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per * 1e3,
                       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                      "config": {"workload": f"walnuts_batch: {C} chains x {iters} transitions per step, D=10 standard normal, macro_step=2.0, "
+                      "config": {"workload": f"walnuts_device: {C} chains x {iters} transitions per step, D=10 standard normal, macro_step=2.0, "
                                              f"max_nuts_depth=10, max_error=0.1 (BASELINE configs[0]'s target, test/test.py:11-18)",
-                                 "kernel": "wn_wstep_* (wn_k_wstep.hip), one numpy Generator per chain consumed on the host in the reference's order"},
+                                 "kernel": "wstep_auto_kernel (wn_k_wstep.hip): one thread per chain, whole transitions on the device, Philox stream of wn_rng.h"},
+                      "note": "a launch lasts as long as its slowest chain, and the cost of a transition of this sampler has a heavy tail (a macro step whose "
+                              "energy error stays above max_error runs stable_steps to 2^10 micro steps, walnuts.py:144-181; an orbit can reach 2^10 macro "
+                              "steps): 256 chains x 100 transitions measured 0.15 s to 5.1 s depending on which chains they were; one chain alone makes ~500 "
+                              "typical transitions/s",
+                      "draws_mean_abs_max": float(np.abs(d.mean(axis=(0, 1))).max()), "draws_var_mean": float(d.var(axis=(0, 1)).mean()),
+                      "ess_per_sec": {"q0": ess(d[:, :, 0]) / per, "method": "rank-normalised split bulk ESS over all chains of one step"},
+                      "host_generator_form": {"value": host_rate, "unit": "transitions/s", "what": "walnuts_batch, 64 chains x 2 transitions, one numpy Generator per chain "
+                                              "consumed on the host in the reference's order (the reference's contract)"},
                       "reference_python_transitions_per_s_per_core": 1.2e3}), flush=True)
 
 

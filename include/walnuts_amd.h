@@ -223,6 +223,12 @@ int wn_wstep_extend(wn_wstep *h, int32_t depth, const int32_t *backward_dev, con
 int wn_wstep_commit(wn_wstep *h, const int32_t *accept_dev, const double *u_choice_dev, int32_t *uturn_dev,
                     void *stream);
 int wn_wstep_result(wn_wstep *h, double *theta_sel_dev, void *stream);
+/* n_transitions whole transitions of every chain in ONE launch, with the engine's own random stream (wn_rng.h: Philox keyed by seed,
+ * global chain id = chain_offset + b, transition number iter0 + i) in place of the caller's numpy Generators: the same transition
+ * kernel (walnuts.py:322-359), no host round trip per doubling.  theta_dev [B][D] is read and overwritten with the last states;
+ * draws_dev [B][n_transitions][D] (or NULL) receives every state.  Built-in targets only. */
+int wn_wstep_run_device_rng(wn_wstep *h, uint64_t seed, int64_t chain_offset, int32_t iter0, int32_t n_transitions,
+                            double *theta_dev, double *draws_dev, void *stream);
 int wn_wstep_ext_bind(wn_wstep *h, double *x_req_dev, const double *lp_dev, const double *grad_dev);
 int wn_wstep_ext_pending(wn_wstep *h, int32_t *n_pending, void *stream);
 int wn_wstep_ext_waiting(wn_wstep *h, int32_t *waiting_dev, void *stream);

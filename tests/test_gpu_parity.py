@@ -523,3 +523,27 @@ def test_walnuts_batch_evaluates_only_the_chains_that_asked(wa):
     assert calls["n"] == single, (calls["n"], single)
     for c in range(4):
         close(d[c], outs[c], rtol=1e-12, atol=0, what=f"chain {c}")
+
+
+def test_walnuts_device_whole_transitions_on_the_device(wa):
+    """walnuts_device: walnuts_step's transition kernel (walnuts.py:279-359) with the engine's Philox stream in place of numpy
+    Generators.  Reproducible, independent of batching / sharding and of the launch granularity, and it samples the target:
+    512 chains x 60 transitions of the 10-D standard normal with test.py's parameters."""
+    from walnuts_amd import targetDistr as td
+    th0 = np.zeros((512, 10))
+    args = (td.stdGauss, np.ones(10), 2.0, 10, 0.1, 5, 60)
+    d = wa.walnuts_device(77, th0, *args)
+    assert d.shape == (512, 60, 10) and np.isfinite(d).all()
+    np.testing.assert_array_equal(d, wa.walnuts_device(77, th0, *args, transitions_per_launch=7))
+    lo = wa.walnuts_device(77, th0[:200], *args); hi = wa.walnuts_device(77, th0[200:], *args, chain_offset=200)
+    np.testing.assert_array_equal(d, np.concatenate([lo, hi]))
+    x = d[:, 10:, :]
+    assert np.abs(x.mean(axis=(0, 1))).max() < 0.03, x.mean(axis=(0, 1))
+    assert np.abs(x.var(axis=(0, 1)) - 1.0).max() < 0.05, x.var(axis=(0, 1))
+    # a different seed is a different stream
+    assert not np.array_equal(d, wa.walnuts_device(78, th0, *args))
+    # the same kernel as the host-Generator form: same one-transition law (first two moments of the first transition)
+    rngs = [np.random.default_rng(c) for c in range(512)]
+    h = wa.walnuts_batch(rngs, th0, td.stdGauss, td.stdGauss, np.ones(10), 2.0, 10, 0.1, 0, 1)[:, 0]
+    one = wa.walnuts_device(5, th0, td.stdGauss, np.ones(10), 2.0, 10, 0.1, 0, 1)[:, 0]
+    assert abs(h.var() - one.var()) < 0.15 * h.var(), (h.var(), one.var())

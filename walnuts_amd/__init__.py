@@ -6,9 +6,9 @@ targetDistr): the same call shapes, executed by hand-written gfx950 HIP kernels 
 """
 from . import _lib
 from . import adaptiveIntegrators, targetDistr, targets
-from .walnuts import walnuts, walnuts_step, walnuts_batch, walnuts_step_batch, walnuts_stan
+from .walnuts import walnuts, walnuts_step, walnuts_batch, walnuts_step_batch, walnuts_stan, walnuts_device
 from .WALNUTS import WALNUTS, Generated, identity, q0_sumsq, firstk, sw_constrain
 from .engine import Engine, WalnutsError
 
-__all__ = ["WALNUTS", "walnuts", "walnuts_step", "walnuts_batch", "walnuts_step_batch", "walnuts_stan", "targets", "Engine", "WalnutsError", "adaptiveIntegrators", "targetDistr", "Generated",
+__all__ = ["WALNUTS", "walnuts", "walnuts_step", "walnuts_batch", "walnuts_step_batch", "walnuts_stan", "walnuts_device", "targets", "Engine", "WalnutsError", "adaptiveIntegrators", "targetDistr", "Generated",
            "identity", "q0_sumsq", "firstk", "sw_constrain"]

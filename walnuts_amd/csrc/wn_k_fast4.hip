@@ -563,8 +563,13 @@ __device__ __forceinline__ void fast4_b_wave(const Params& prm, double* pr, cons
 #endif
     // ---- momentum normals v = normal(size=d) (WALNUTS.py:236, wn_rng.h stream 1) of ONE chain's next iteration per tick:
     // lane L makes elements 2L, 2L+1 (one Philox block, one Box-Muller pair) ----
-    {
-      const unsigned long long want = __ballot(rep == 0 && bk.zwant != bk.zready && bk.zwant >= 1);
+    // (ONE vote per tick for the three things that are rarely due: momentum normals, a window refill, the end of the run)
+    const bool zw = bk.zwant != bk.zready && bk.zwant >= 1;
+    const bool fresh = bk.iter != witer;
+    const bool need = inrange && bk.iter <= prm.numIter && (fresh || (bk.ku >> 1) + 4u > wbase + 15u);
+    const bool anyrare = __any(zw || need || bk.st == FastBook::ST_DEAD);
+    if (anyrare) {
+      const unsigned long long want = __ballot(rep == 0 && zw);
       if (want) {
         const int cs = __builtin_ctzll(want);  // lanes 0..3 are chains 0..3
         const int it = __shfl(bk.zwant, cs);
@@ -589,9 +594,7 @@ __device__ __forceinline__ void fast4_b_wave(const Params& prm, double* pr, cons
     // ---- the window of uniforms (wn_rng.h stream 0): when a chain starts an iteration or nears the end of its sliding
     // window, ONE Philox pass makes sixteen blocks for each of the four chains (lane = chain x, block base + replica).
     // Blocks 0..7 of the iteration stay (the direction bits of WALNUTS.py:216 are read until the last doubling).
-    {
-      const bool fresh = bk.iter != witer;
-      const bool need = inrange && bk.iter <= prm.numIter && (fresh || (bk.ku >> 1) + 4u > wbase + 15u);
+    if (anyrare) {
       if (__any(need)) {
         const uint32_t nb = fresh ? 0u : (bk.ku >> 1);
         const uint32_t blk = nb + (uint32_t)rep;
@@ -680,7 +683,7 @@ __device__ __forceinline__ void fast4_b_wave(const Params& prm, double* pr, cons
 #endif
     WN4_STAMP(2);
     // ---- every chain of the pair has finished: both waves leave (the pairs of a workgroup do not wait for each other) ----
-    bool done = __all(bk.finished());
+    bool done = anyrare && __all(bk.finished());  // (finished() needs ST_DEAD, which was part of this tick's one vote, or shows at the next)
     if ((double)t > cap) {  // cannot happen; never hang the GPU
       if (lane == 0) atomicExch(abort_flag, 1);
       done = true;

@@ -63,7 +63,8 @@ struct WCtx {
 struct Vecs {
   const WCtx& c;
   int b;
-  __device__ double& operator()(int v, int j) const { return c.vec[((size_t)v * c.D + j) * c.B + b]; }
+  double* lds;  // null: the chain's vectors live in the workspace, strided by B; else: [V_NVEC][D] in LDS (one chain per workgroup)
+  __device__ double& operator()(int v, int j) const { return lds ? lds[v * c.D + j] : c.vec[((size_t)v * c.D + j) * c.B + b]; }
 };
 
 __device__ double ke_of(const WCtx& c, const Vecs& V, int vr) {  // 0.5*dot(inv_mass, rho**2)  (:124)
@@ -224,30 +225,15 @@ __device__ void extend_finish(const WCtx& c, int b, WScal& s, int* sub_out, doub
   lse_old[b] = lse_of(c.logw + b, s.nw, c.B);
 }
 
-__global__ void wstep_fused_kernel(WCtx c, int mode /*0 begin, 1 extend*/, const double* theta, const double* rho,
-                                   const int* backward, const int* active, int nmacro, int* sub_out, double* lse_ext,
-                                   double* lse_old) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= c.B) return;
-  WScal& s = c.sc[b];
-  Vecs V{c, b};
-  if (mode == 0) {
-    for (int i = 0; i < c.D; ++i) { V(V_TH, i) = theta[(size_t)b * c.D + i]; V(V_RH, i) = rho[(size_t)b * c.D + i]; }
-    s.stage = ST_INIT; s.active = 1; s.nmacro = 0; s.m = 0;
-  } else {
-    s.active = active[b];
-    if (!s.active) return;
-    extend_setup(c, V, s, backward[b], nmacro);
-  }
-  // evaluate the built-in target at TH until the machine is done (positions are strided in the workspace: gather,
-  // evaluate with the scalar target code of wn_capi.hip, scatter -- D <= 64 in registers, beyond that per element)
+// evaluate the built-in target at TH until the machine is done (the loop of wstep_fused_kernel)
+__device__ void run_machine(const WCtx& c, const Vecs& V, WScal& s) {
   for (;;) {
     double x[64], g[64];
     if (c.D <= 64) {
       for (int i = 0; i < c.D; ++i) x[i] = V(V_TH, i);
       s.lp = wn_target_eval(c.kind, c.D, c.tpar, x, g);
       for (int i = 0; i < c.D; ++i) V(V_G, i) = g[i];
-    } else {  // separable built-ins only (checked on the host): element-wise through the same code, one element at a time
+    } else {
       double lp = 0.0;
       for (int i = 0; i < c.D; ++i) {
         const double xi = V(V_TH, i);
@@ -259,6 +245,32 @@ __global__ void wstep_fused_kernel(WCtx c, int mode /*0 begin, 1 extend*/, const
     }
     if (!advance(c, V, s)) break;
   }
+}
+
+// the same with the chain's vectors contiguous in LDS (wstep_auto_kernel): evaluated in place, no private arrays (a kernel with
+// per-thread arrays in scratch memory runs only a fraction of its waves at a time)
+__device__ void run_machine_lds(const WCtx& c, const Vecs& V, WScal& s) {
+  for (;;) {
+    s.lp = wn_target_eval(c.kind, c.D, c.tpar, &V(V_TH, 0), &V(V_G, 0));
+    if (!advance(c, V, s)) break;
+  }
+}
+__global__ void wstep_fused_kernel(WCtx c, int mode /*0 begin, 1 extend*/, const double* theta, const double* rho,
+                                   const int* backward, const int* active, int nmacro, int* sub_out, double* lse_ext,
+                                   double* lse_old) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= c.B) return;
+  WScal& s = c.sc[b];
+  Vecs V{c, b, nullptr};
+  if (mode == 0) {
+    for (int i = 0; i < c.D; ++i) { V(V_TH, i) = theta[(size_t)b * c.D + i]; V(V_RH, i) = rho[(size_t)b * c.D + i]; }
+    s.stage = ST_INIT; s.active = 1; s.nmacro = 0; s.m = 0;
+  } else {
+    s.active = active[b];
+    if (!s.active) return;
+    extend_setup(c, V, s, backward[b], nmacro);
+  }
+  run_machine(c, V, s);  // (positions are strided in the workspace: gather, evaluate with the scalar target code of wn_capi.hip, scatter)
   if (mode == 1) extend_finish(c, b, s, sub_out, lse_ext, lse_old);
 }
 
@@ -270,7 +282,7 @@ __global__ void wstep_ext_kernel(WCtx c, int mode /*0 begin, 1 extend setup, 2 f
   if (b >= c.B) return;
   c.waiting[b] = 0;
   WScal& s = c.sc[b];
-  Vecs V{c, b};
+  Vecs V{c, b, nullptr};
   bool need = false;
   if (mode == 0) {
     for (int i = 0; i < c.D; ++i) { V(V_TH, i) = theta[(size_t)b * c.D + i]; V(V_RH, i) = rho[(size_t)b * c.D + i]; }
@@ -296,14 +308,11 @@ __global__ void wstep_ext_kernel(WCtx c, int mode /*0 begin, 1 extend setup, 2 f
 }
 
 // accept / categorical pick (:347-350), orbit merge (:351), U-turn of the whole orbit (:352)
-__global__ void wstep_commit_kernel(WCtx c, const int* accept, const double* u_choice, int* uturn_out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= c.B) return;
-  WScal& s = c.sc[b];
-  if (!s.active || s.sub_uturn) { uturn_out[b] = 0; return; }  // a sub-U-turn breaks out before the merge (:343)
-  Vecs V{c, b};
+__device__ int commit_chain(const WCtx& c, const int b, WScal& s, const bool accept_b, const double u_choice_b, double* vlds = nullptr) {
+  if (!s.active || s.sub_uturn) return 0;  // a sub-U-turn breaks out before the merge (:343)
+  Vecs V{c, b, vlds};
   const int n = s.nmacro, D = c.D;
-  if (accept[b]) {
+  if (accept_b) {
     // p = softmax(log_weights_ext) in LIST order; Generator.choice: cdf = p.cumsum(); cdf /= cdf[-1];
     // idx = cdf.searchsorted(u, side='right')
     double mx = -INFINITY;
@@ -318,7 +327,7 @@ __global__ void wstep_commit_kernel(WCtx c, const int* accept, const double* u_c
     for (int p = 0; p < n; ++p) {
       const int i = s.backward ? n - 1 - p : p;
       cs += exp(c.ew[(size_t)i * c.B + b] - mx) / tot;
-      if (u_choice[b] < cs / last) { idx = p; break; }
+      if (u_choice_b < cs / last) { idx = p; break; }
     }
     const int ii = s.backward ? n - 1 - idx : idx;
     const double* st = c.eorb + (size_t)ii * 2 * D * c.B;
@@ -341,13 +350,84 @@ __global__ void wstep_commit_kernel(WCtx c, const int* accept, const double* u_c
     d1 += V(V_RHL, i) * diff;
     d2 += V(V_RHR, i) * diff;
   }
-  uturn_out[b] = (d1 < 0 || d2 < 0) ? 1 : 0;
+  return (d1 < 0 || d2 < 0) ? 1 : 0;
+}
+__global__ void wstep_commit_kernel(WCtx c, const int* accept, const double* u_choice, int* uturn_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= c.B) return;
+  uturn_out[b] = commit_chain(c, b, c.sc[b], accept[b] != 0, u_choice[b]);
+}
+
+
+// Whole transitions on the device with the ENGINE's random stream (wn_rng.h: Philox keyed by seed, global chain id and transition
+// number) in place of the caller's numpy Generators: walnuts_step (walnuts.py:322-359) n_trans times per chain and launch, no host
+// round trip.  Same transition kernel as the host-driven calls above, a different (documented) source of randomness: draw k of
+// transition `it` of a chain is rng_uniform(seed, chain, it, k) in the reference's order of use -- direction bit (:330), one lottery
+// index per macro step (:194), the acceptance uniform (:346) and, after an accept, the categorical uniform (:350); the momentum is
+// rng_normal(seed, chain, it, j) / sqrt(inv_mass[j]) (:325).
+__global__ void wstep_auto_kernel(WCtx c0, int* lottery, uint64_t seed, uint32_t chain0, int it0, int n_trans, int max_depth,
+                                  double* theta_io, double* draws) {
+  // ONE CHAIN PER WAVEFRONT (lane 0 works): the machine's stages, the search depths and the orbit lengths differ from chain to chain,
+  // and 64 chains in one wave each waited for every branch of every other (measured: 0.53 s per transition of a wave, 7.7e3
+  // transitions/s for 4096 chains); alone in its wave a chain pays only its own path
+  const int b = blockIdx.x;
+  __shared__ double vl[V_NVEC * 64];
+  __shared__ WScal sl;
+  if (b >= c0.B || threadIdx.x != 0) return;
+  // This chain's private view of the handle: batch size 1, every array offset to the chain's own contiguous part.  The
+  // thread-per-chain kernels stride every array by the batch size (coalescing across 64 chains); a lone chain walking arrays
+  // strided by 32 KB touches a new page with every element (measured: 64 chains 2.3 ms per transition, 256 chains 38 ms).
+  WCtx c = c0;
+  c.B = 1;
+  c.eorb = c0.eorb + (size_t)b * c0.nmax * 2 * c0.D;
+  c.ew = c0.ew + (size_t)b * c0.nmax;
+  c.logw = c0.logw + (size_t)b * 2 * c0.nmax;
+  c.vec = c0.vec + (size_t)b * V_NVEC * c0.D;
+  c.lottery = lottery + (size_t)b * c0.nmax;
+  int* const lot = lottery + (size_t)b * c0.nmax;
+  // the chain's vectors and scalars in LDS (D <= 64: checked on the host)
+  WScal& s = sl;
+  Vecs V{c, 0, vl};
+  const uint32_t chain = chain0 + (uint32_t)b;
+  int sub1 = 0;
+  double lse2[2] = {0.0, 0.0};
+  for (int tr = 0; tr < n_trans; ++tr) {
+    const uint32_t it = (uint32_t)(it0 + tr);
+    uint32_t k = 0;
+    for (int i = 0; i < c.D; ++i) {
+      V(V_TH, i) = theta_io[(size_t)b * c.D + i];
+      V(V_RH, i) = rng_normal(seed, chain, it, (uint32_t)i) / sqrt(c.im[i]);
+    }
+    s.stage = ST_INIT; s.active = 1; s.nmacro = 0; s.m = 0; s.sub_uturn = 0;
+    run_machine_lds(c, V, s);
+    for (int depth = 0; depth < max_depth; ++depth) {
+      const int n = 1 << depth;
+      const int backward = rng_uniform(seed, chain, it, k++) < 0.5 ? 1 : 0;
+      for (int m = 0; m < n; ++m) {
+        const int idx = (int)(3.0 * rng_uniform(seed, chain, it, k++));
+        lot[m] = idx > 2 ? 2 : idx;
+      }
+      extend_setup(c, V, s, backward, n);
+      run_machine_lds(c, V, s);
+      extend_finish(c, 0, s, &sub1, &lse2[0], &lse2[1]);
+      if (s.sub_uturn) break;
+      const double logu = log(rng_uniform(seed, chain, it, k++));
+      const bool acc = logu < lse2[0] - lse2[1];
+      const double uc = acc ? rng_uniform(seed, chain, it, k++) : 0.0;
+      if (commit_chain(c, 0, s, acc, uc, V.lds)) break;
+    }
+    for (int i = 0; i < c.D; ++i) {
+      const double th = V(V_SEL, i);
+      theta_io[(size_t)b * c.D + i] = th;
+      if (draws) draws[((size_t)b * n_trans + tr) * c.D + i] = th;
+    }
+  }
 }
 
 __global__ void wstep_result_kernel(WCtx c, double* theta_sel) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= c.B) return;
-  Vecs V{c, b};
+  Vecs V{c, b, nullptr};
   for (int i = 0; i < c.D; ++i) theta_sel[(size_t)b * c.D + i] = V(V_SEL, i);
 }
 
@@ -359,6 +439,8 @@ struct wn_wstep {
   bool external = false;
   double *tpar = nullptr, *im = nullptr;
   int* lot = nullptr;
+  int* asub = nullptr;     // device-RNG transitions: per-chain scratch of extend_finish
+  double* alse = nullptr;  // [2][B]
   std::string err;
 };
 static std::string g_wstep_err;
@@ -380,7 +462,7 @@ int wn_wstep_destroy(wn_wstep* h) {
   if (!h) return WN_OK;
   hipSetDevice(h->device);
   for (void* p : {(void*)h->tpar, (void*)h->im, (void*)h->lot, (void*)h->c.vec, (void*)h->c.eorb, (void*)h->c.ew, (void*)h->c.logw,
-                  (void*)h->c.sc, (void*)h->c.npend, (void*)h->c.waiting})
+                  (void*)h->c.sc, (void*)h->c.npend, (void*)h->c.waiting, (void*)h->asub, (void*)h->alse})
     if (p) hipFree(p);
   delete h;
   return WN_OK;
@@ -442,6 +524,8 @@ int wn_wstep_create(int32_t device, int32_t target_kind, const double* tpar_dev,
   WALLOC(c.sc, (size_t)B * sizeof(WScal));
   WALLOC(c.npend, 64);
   WALLOC(c.waiting, (size_t)B * sizeof(int));
+  WALLOC(h->asub, (size_t)B * sizeof(int));
+  WALLOC(h->alse, (size_t)2 * B * sizeof(double));
 #undef WALLOC
   WCOPY(hipMemset(c.sc, 0, (size_t)B * sizeof(WScal)));
   WCOPY(hipMemset(c.vec, 0, (size_t)V_NVEC * dim * B * sizeof(double)));
@@ -514,6 +598,19 @@ int wn_wstep_commit(wn_wstep* h, const int32_t* accept_dev, const double* u_choi
   if (!h || !accept_dev || !u_choice_dev || !uturn_dev) { if (h) h->err = "null buffer"; return WN_E_ARG; }
   WCHK(hipSetDevice(h->device));
   hipLaunchKernelGGL(wstep_commit_kernel, dim3((h->c.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->c, accept_dev, u_choice_dev, uturn_dev);
+  WCHK(hipGetLastError());
+  return WN_OK;
+}
+
+int wn_wstep_run_device_rng(wn_wstep* h, uint64_t seed, int64_t chain_offset, int32_t iter0, int32_t n_transitions, double* theta_dev,
+                            double* draws_dev, void* stream) {
+  if (!h || !theta_dev || n_transitions < 1 || iter0 < 0) { if (h) h->err = "wn_wstep_run_device_rng: bad argument"; return WN_E_ARG; }
+  if (h->external) { h->err = "wn_wstep_run_device_rng needs a built-in target (a host callable cannot run inside the kernel)"; return WN_E_UNSUPPORTED; }
+  if (h->c.D > 64) { h->err = "wn_wstep_run_device_rng: dim <= 64 (the chain's vectors live in LDS)"; return WN_E_UNSUPPORTED; }
+  if (chain_offset < 0 || (uint64_t)chain_offset + (uint64_t)h->c.B > (1ull << 32)) { h->err = "chain_offset + B must stay within [0, 2^32)"; return WN_E_ARG; }
+  WCHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(wstep_auto_kernel, dim3(h->c.B), dim3(64), 0, (hipStream_t)stream, h->c, h->lot, seed, (uint32_t)chain_offset,
+                     (int)iter0, (int)n_transitions, h->max_depth, theta_dev, draws_dev);
   WCHK(hipGetLastError());
   return WN_OK;
 }

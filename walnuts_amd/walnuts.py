@@ -227,6 +227,42 @@ def walnuts_batch(rngs, theta_init, logp, grad, inv_mass, macro_step, max_nuts_d
     return draws
 
 
+def walnuts_device(seed, theta_init, target, inv_mass, macro_step, max_nuts_depth, max_error, iter_warmup, iter_sample,
+                   chain_offset=0, transitions_per_launch=64):
+    """C chains with the DEVICE's random stream instead of numpy Generators: theta_init (C, D) -> draws (C, iter_sample, D).
+    The transition kernel is walnuts_step's (walnuts.py:279-359); the randomness is the engine's Philox stream keyed by
+    (seed, chain_offset + chain, transition number) -- wn_rng.h -- so a chain's draws do not depend on how chains are batched
+    or sharded, and whole transitions run on the GPU with no host round trip per doubling (`walnuts_batch` keeps the
+    reference's Generator contract and pays ~4 host exchanges per doubling for it).  `target` is a walnuts_amd device target
+    (e.g. walnuts_amd.targetDistr.stdGauss), not a host callable."""
+    _quiet()
+    theta, inv_mass = _check_args(theta_init, inv_mass, macro_step, max_nuts_depth, max_error)
+    theta = np.atleast_2d(theta)
+    Cn, D = theta.shape
+    tgt, fns = _resolve(target, target)
+    if tgt is None:
+        raise ValueError("walnuts_device needs a device target descriptor; host callables go through walnuts_batch")
+    s = _stepper(theta, target, target, inv_mass, macro_step, max_nuts_depth, max_error)
+    try:
+        t = s.t
+        th = s.dv(theta)
+        n_tot = int(iter_warmup) + int(iter_sample)
+        out = t.empty((Cn, int(iter_sample), D), dtype=t.float64, device=s.dev)
+        it = 1
+        done = 0
+        while done < n_tot:
+            n = min(int(transitions_per_launch), n_tot - done)
+            buf = t.empty((Cn, n, D), dtype=t.float64, device=s.dev)
+            s._ck(s.lib.wn_wstep_run_device_rng(s.h, int(seed), int(chain_offset), it, n, s.p(th), s.p(buf), s._st()))
+            lo = max(done, int(iter_warmup))
+            if done + n > lo:
+                out[:, lo - int(iter_warmup):done + n - int(iter_warmup)] = buf[:, lo - done:]
+            done += n; it += n
+        return out.cpu().numpy()
+    finally:
+        s.close()
+
+
 def walnuts(rng, theta_init, logp, grad, inv_mass, macro_step, max_nuts_depth, max_error, iter_warmup, iter_sample):
     """Markov chain of `iter_sample` draws, shape (iter_sample, D) (walnuts.py:362-408).  Warm-up draws are
     discarded; this variant has no adaptation (walnuts.py:406)."""
