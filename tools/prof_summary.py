@@ -40,9 +40,9 @@ for unit in ("wn_k_fast", "wn_k_fast4", "wn_k_wave", "wn_k_split", "wn_k_gemm", 
     if not used:
         continue
     try:
-        out = subprocess.run([os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernel_meta.sh"), unit], capture_output=True, text=True, timeout=900).stdout
+        meta = subprocess.run([os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernel_meta.sh"), unit], capture_output=True, text=True, timeout=900).stdout
         print(f"-- {unit}.hip")
-        print(out.rstrip())
+        print(meta.rstrip())
     except Exception as ex:
         print(f"-- {unit}.hip: {ex!r}")
 print("== PMC counters per dispatch, grouped by kernel (mean over dispatches) ==")

@@ -259,9 +259,17 @@ struct FastBook {
     if (!(s0.kind == K_STEP && !s0.discard)) return;
     pre_lpn = 0.5 * io.sum(Q_LP);              // lp = 1/2 q.g for the Gaussian targets
     pre_Hn = -pre_lpn + 0.5 * io.sum(Q_KE);    // adaptiveIntegrators.py:55
+#if defined(WN4_NOEXP)  // timing diagnostic only (wrong weights): what the FP64 exp costs the bookkeeper's tick
+    const double Wnew = 1.0 + 1e-9 * (-pre_Hn + H0 + 0.0);
+#else
     const double Wnew = exp(-pre_Hn + H0 + 0.0);   // lwtSum = 0
+#endif
     pre_Wsum = i == 0 ? Wnew : WnewSum + Wnew;     // :322 / :424
+#if defined(WN4_NODIV)  // timing diagnostic only
+    pre_ratio = Wnew * 0.5;
+#else
     pre_ratio = Wnew / pre_Wsum;                   // :426
+#endif
   }
 
   template <class IO>

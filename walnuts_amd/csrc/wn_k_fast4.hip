@@ -161,7 +161,10 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
   const int D = prm.D;
   auto coord = [&](int s) { return 16 * s + 4 * b + r; };
   double* const wbase = prm.work + (size_t)grp * G::group_doubles(prm.M);
-  auto gvec = [&](int vec) { return wbase + (size_t)vec * G::VEC + lane; };  // + s * 64
+  // vectors in memory are chain-major: [chain x][register s][16 r-b lanes] -- a store by ONE chain of the group (an endpoint push, a pick)
+  // then writes whole 128-byte lines (in [s][lane] order it scattered 8-byte pieces at a 32-byte stride over four times as many lines:
+  // 178 GB of L2 write-backs per launch measured, profiles/r03_traffic_first.json)
+  auto gvec = [&](int vec) { return wbase + (size_t)vec * G::VEC + x * (NS * 16) + 4 * r + b; };  // + s * 16
   const int vprop = (prm.M + 1) * 2, vcold = vprop + 2;
   const double* const znext = wbase + (size_t)((prm.M + 1) * 2 + 4) * G::VEC + (size_t)x * G::DPAD;
   double* const lc = pr + G::P_LC + lane;
@@ -233,20 +236,20 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
           const int sl = slot_of_leaf(n + 1 - (1 << NFAST));
           const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
 #pragma unroll
-          for (int s = 0; s < NS; ++s) { pq0[s] = sq[s * 64]; pv0[s] = sv[s * 64]; }
+          for (int s = 0; s < NS; ++s) { pq0[s] = sq[s * 16]; pv0[s] = sv[s * 16]; }
         }
         if (deep1) {
           const int sl = slot_of_leaf(n + 1 - (2 << NFAST));
           const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
 #pragma unroll
-          for (int s = 0; s < NS; ++s) { pq1[s] = sq[s * 64]; pv1[s] = sv[s * 64]; }
+          for (int s = 0; s < NS; ++s) { pq1[s] = sq[s * 16]; pv1[s] = sv[s * 16]; }
         }
       }
       if (__any((op & OP_PICK) != 0)) {  // qn still holds the position of tick t-2
         if (op & OP_PICK) {
           double* dst = gvec(vprop + ((op & OP_IPPICK) ? 1 : 0));
 #pragma unroll
-          for (int s = 0; s < NS; ++s) dst[s * 64] = qn[s];
+          for (int s = 0; s < NS; ++s) dst[s * 16] = qn[s];
         }
       }
       if (TRACE) { if (op & OP_UNDO) ntr -= 1; }  // the leaf in flight when the iteration ended
@@ -266,12 +269,12 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
               qn[s] = coord(s) < D ? prm.q0[(size_t)cl * D + coord(s)] : 0.0;
-              dst[s * 64] = qn[s];
+              dst[s * 16] = qn[s];
             }
           } else {
             const double* src = gvec(vprop + ((op & OP_IPNEW) ? 1 : 0));
 #pragma unroll
-            for (int s = 0; s < NS; ++s) qn[s] = src[s * 64];
+            for (int s = 0; s < NS; ++s) qn[s] = src[s * 16];
           }
           // samples[:, row] = generated(q)  (WALNUTS.py:164,695)
           double* row = prm.samples + ((size_t)cl * (prm.numIter + 1) + c.n) * prm.dg;
@@ -297,7 +300,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
             keinit_part = kp;
             double *dq_ = gvec(vcold), *dv_ = gvec(vcold + 1);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) { dq_[s * 64] = qn[s]; dv_[s * 64] = v[s]; }
+            for (int s = 0; s < NS; ++s) { dq_[s * 16] = qn[s]; dv_[s * 16] = v[s]; }
           }
           __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): waited for HERE, not on the common path (wn_k_fast.hip)
         }
@@ -307,9 +310,9 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
           double *dq_ = gvec(vcold), *dv_ = gvec(vcold + 1);
           double tq[NS], tv[NS];
 #pragma unroll
-          for (int s = 0; s < NS; ++s) { tq[s] = dq_[s * 64]; tv[s] = dv_[s * 64]; }
+          for (int s = 0; s < NS; ++s) { tq[s] = dq_[s * 16]; tv[s] = dv_[s * 16]; }
 #pragma unroll
-          for (int s = 0; s < NS; ++s) { dq_[s * 64] = qc[s]; dv_[s * 64] = v[s]; qn[s] = tq[s]; v[s] = tv[s]; }  // (no step on this tick)
+          for (int s = 0; s < NS; ++s) { dq_[s * 16] = qc[s]; dv_[s * 16] = v[s]; qn[s] = tq[s]; v[s] = tv[s]; }  // (no step on this tick)
           __builtin_amdgcn_s_waitcnt(0x0F70);
         }
       }
@@ -358,7 +361,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
       if (l0due) {
         const double *sq = gvec(vcold), *sv = gvec(vcold + 1);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) { cq[s] = sq[s * 64]; cv[s] = sv[s * 64]; }
+        for (int s = 0; s < NS; ++s) { cq[s] = sq[s * 16]; cv[s] = sv[s * 16]; }
       }
     }
     // ---- second half step; lp = 1/2 q.g, KE = 1/2 v.v ----
@@ -419,7 +422,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
               const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
               double qo[NS], vo[NS];
 #pragma unroll
-              for (int s = 0; s < NS; ++s) { qo[s] = sq[s * 64]; vo[s] = sv[s * 64]; }
+              for (int s = 0; s < NS; ++s) { qo[s] = sq[s * 16]; vo[s] = sv[s * 16]; }
               dots(qo, vo, e[2 * h], e[2 * h + 1]);
             }
           }
@@ -442,7 +445,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
             const int sl = slot_of_leaf(n);
             double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) { sq[s * 64] = qn[s]; sv[s * 64] = v[s]; }
+            for (int s = 0; s < NS; ++s) { sq[s * 16] = qn[s]; sv[s * 16] = v[s]; }
           }
         }
       }
