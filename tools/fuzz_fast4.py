@@ -1,0 +1,58 @@
+"""Randomised differential test of the wave-pair headline kernel (wn_k_fast4.hip) against the CPU oracle: random dimension (all four
+geometries), chain count (1, 2 and 4 pairs per workgroup, ragged last groups), depth, step size, conditioning, generated kind,
+traced or plain.  Every diagnostics column, every draw and -- traced -- every row of the per-step trace of the checked chains.
+python tools/fuzz_fast4.py [n] [seed]   (GPU)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle_lib as ol
+import walnuts_amd as wa
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+INT = (0, 1, 4, 5, 6, 7, 8, 9, 12, 13, 19, 20, 21, 22)
+bad = 0
+
+
+def close(a, b, tol=1e-6):
+    with np.errstate(all="ignore"):
+        scale = np.nanmax(np.abs(b), axis=0, keepdims=True) if b.size else 1.0
+        return bool(((np.isnan(a) & np.isnan(b)) | (np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))) |
+                     (np.abs(a - b) <= 1e-9 + tol * np.maximum(np.abs(b), scale))).all())
+
+
+for it in range(n):
+    D = int(rng.choice([2, 5, 16, 17, 31, 32, 33, 47, 64, 65, 80, 96, 97, 99, 100]))
+    C = int(rng.choice([1, 3, 4, 5, 17, 70, 300, 1100, 2500, 4300], p=[.1, .1, .1, .1, .15, .15, .1, .1, .05, .05]))
+    M = int(rng.integers(1, 9)) if rng.random() < 0.85 else int(rng.integers(9, 12))
+    if C > 1000: M = min(M, 8)
+    numIter = int(rng.integers(1, 6))
+    Q, _ = np.linalg.qr(rng.normal(size=(D, D))); lam = np.logspace(0, rng.uniform(0.0, 4.0), D)
+    A = (Q * (1.0 / lam)) @ Q.T; A = 0.5 * (A + A.T)
+    q0 = rng.normal(size=(C, D)) @ (Q * np.sqrt(lam)).T
+    if rng.random() < 0.1: q0[: max(1, C // 7)] *= 10.0 ** rng.uniform(100, 200)  # overflowing energies: stop code 999, zero / infinite weights
+    H0 = float(rng.uniform(0.2, 1.1))
+    gen, gk = (ol.G_IDENTITY, 0) if rng.random() < 0.4 else ((ol.G_Q0_SUMSQ, 0) if rng.random() < 0.5 else (ol.G_FIRSTK, int(rng.integers(1, min(3, D) + 1))))
+    traced = rng.random() < 0.35 and C <= 300
+    cap = numIter * (1 << M) + 8
+    off = int(rng.integers(0, 1 << 20))
+    e = wa.Engine(D, C, integrator=ol.I_FIXED, H0=H0, M=M, generated=gen, gen_k=gk, chain_offset=off)
+    e.set_target(ol.T_DENSEGAUSS, A)
+    name = e.kernel_name
+    assert "wn_fast4_kernel" in name, name
+    out = e.run(q0, 4242 + it, numIter, trace_cap=cap if traced else 0)
+    s = out[0].transpose(1, 2).cpu().numpy(); d = out[1].cpu().numpy()
+    tr, tn = (out[2].cpu().numpy(), out[3].cpu().numpy()) if traced else (None, None)
+    e.close()
+    for k in sorted({0, C - 1, C // 2, min(C - 1, 3), min(C - 1, 4), int(rng.integers(0, C))}):
+        o = ol.walnuts(ol.T_DENSEGAUSS, q0[k], integrator=ol.I_FIXED, tpar=A.ravel(), H0=H0, numIter=numIter, M=M, seed=4242 + it,
+                       chain=off + k, generated=gen, gen_k=gk, trace_cap=cap if traced else 0)
+        ok = all(np.array_equal(d[k][:, c], o["diagnostics"][:, c]) for c in INT) and close(d[k], o["diagnostics"]) and close(s[k], o["samples"])
+        if traced and ok:
+            m = o["ncalls"]
+            ok = tn[k] == m and close(tr[k, :m], o["trace"][:m])
+        if not ok:
+            bad += 1
+            print(f"MISMATCH it={it} D={D} C={C} M={M} iters={numIter} gen={gen} H0={H0:.4f} traced={traced} chain={k} kernel={name}", flush=True)
+print(f"fuzz_fast4: {n} configurations, {bad} mismatching chains")
