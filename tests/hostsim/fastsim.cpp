@@ -1,6 +1,6 @@
 // fastsim.cpp -- CPU run of the role-split headline path's bookkeeper (walnuts_amd/csrc/wn_fast.h,
-// FastBook) with a scalar stand-in for the T waves of wn_k_fast.hip: same command / partial-sum
-// protocol, same two-tick lag, one chain at a time, plain loops for the vectors.
+// FastBookT<LAG>) with a scalar stand-in for the T waves of wn_k_fast.hip (LAG = 2) / wn_k_fast4.hip (LAG = 3): same
+// command / partial-sum protocol, same lag, one chain at a time, plain loops for the vectors.
 //
 // TEST TOOL ONLY (see hostsim.cpp): checks the issue / retire automaton against the oracle in a
 // container without a GPU.  Never loaded by the walnuts_amd package.
@@ -21,7 +21,8 @@ struct TSim {  // what the four T waves hold for ONE chain
   const Params* prm;
   int cl;
   std::vector<double> q, v, g, qb, vb, VL, zn;
-  std::vector<double> qhist[2];
+  std::vector<double> qhist[3];  // position of tick t in qhist[t % LAG]
+  int LAG = 2;
   std::vector<double> prop[2];
   std::vector<std::vector<double>> lq, lv, sq, sv;  // LDS-cached levels, memory slots
   double sums[4 + 2 * (MAX_M + 2)];
@@ -54,8 +55,9 @@ struct TSim {  // what the four T waves hold for ONE chain
   void tick(uint32_t t, const Cmd& c) {
     const int NFAST = 2 + NLC;
     for (auto& s : sums) s = 0.0;
-    if (c.op & OP_PICK) prop[(c.op & OP_IPPICK) ? 1 : 0] = qhist[t & 1];
-    if (c.op & OP_UNDO) ntr -= 1;  // the leaf in flight when the iteration ended is not an integrator call of the reference
+    if (c.op & OP_PICK) prop[(c.op & OP_IPPICK) ? 1 : 0] = qhist[t % LAG];  // the position of tick t - LAG
+    if (c.op & OP_UNDO) ntr -= 1;  // the leaves in flight when the iteration ended are not integrator calls of the reference
+    if (c.op & OP_UNDO2) ntr -= 1;
     if (c.op & OP_NEWITER) {
       if (c.op & OP_INIT) {
         for (int e = 0; e < D; ++e) q[e] = prm->q0[(size_t)cl * D + e];
@@ -83,7 +85,7 @@ struct TSim {  // what the four T waves hold for ONE chain
     if (c.op & OP_SWAP) { q.swap(qb); v.swap(vb); }
     const double hs = (c.op & OP_STEP) ? c.hs : 0.0, hs2 = 0.5 * hs;
     for (int e = 0; e < D; ++e) { v[e] = v[e] + hs2 * g[e]; q[e] = q[e] + hs * v[e]; }
-    qhist[t & 1] = q;
+    qhist[t % LAG] = q;
     grad();
     double lp = 0.0, ke = 0.0;
     for (int e = 0; e < D; ++e) { v[e] = v[e] + hs2 * g[e]; lp += q[e] * g[e]; ke += v[e] * v[e]; }
@@ -100,7 +102,7 @@ struct TSim {  // what the four T waves hold for ONE chain
         if (!need_check(i, n, j)) continue;
         double d1, d2;
         if (j == 0) dots(qb, vb, d1, d2);
-        else if (j == 1) dots(qhist[(t - 1) & 1], VL, d1, d2);
+        else if (j == 1) dots(qhist[(t - 1) % LAG], VL, d1, d2);
         else if (j < NFAST) dots(lq[j - 2], lv[j - 2], d1, d2);
         else { const int sl = slot_of_leaf(n + 1 - (1 << j)); dots(sq[sl], sv[sl], d1, d2); }
         sums[Q_DOT0 + 2 * j] = d1; sums[Q_DOT0 + 2 * j + 1] = d2;
@@ -148,28 +150,27 @@ struct HostIO {
 }  // namespace
 
 // returns the number of ticks the slowest chain took (>= 0) or -1 when a chain exceeded its bound
-// fastmode: 0 = FastBook::tick() only; 1 = the ordinary-leaf fast path whenever fast_prepare() allows it; 2 = as 1, and on
-// every tick BOTH paths run on copies and every member of the bookkeeper and the command must come out identical
-static long g_fast_ticks = 0, g_all_ticks = 0;
-extern "C" void fastsim_fast_stats(long* fast, long* all) { *fast = g_fast_ticks; *all = g_all_ticks; }
-extern "C" long fastsim_run2(Params* prm, int target, int nlc, double* idle_frac, int fastmode);
-extern "C" long fastsim_run(Params* prm, int target, int nlc, double* idle_frac) { return fastsim_run2(prm, target, nlc, idle_frac, 2); }
-extern "C" long fastsim_run2(Params* prm, int target, int nlc, double* idle_frac, int fastmode) {
+template <int LAG>
+static long run_lag(Params* prm, int target, int nlc, double* idle_frac) {
   const int D = prm->D;
   long worst = 0;
   double steps = 0, ticks = 0;
+  constexpr int NSUM = 4 + 2 * (MAX_M + 2);
   for (int cl = 0; cl < prm->C; ++cl) {
     TSim T;
-    T.D = D; T.M = prm->M; T.NLC = nlc; T.prm = prm; T.cl = cl; T.dense = target == T_DENSEGAUSS;
-    for (auto* x : {&T.q, &T.v, &T.g, &T.qb, &T.vb, &T.VL, &T.zn, &T.qhist[0], &T.qhist[1], &T.prop[0], &T.prop[1]}) x->assign(D, 0.0);
+    T.D = D; T.M = prm->M; T.NLC = nlc; T.prm = prm; T.cl = cl; T.dense = target == T_DENSEGAUSS; T.LAG = LAG;
+    for (auto* x : {&T.q, &T.v, &T.g, &T.qb, &T.vb, &T.VL, &T.zn, &T.qhist[0], &T.qhist[1], &T.qhist[2], &T.prop[0], &T.prop[1]}) x->assign(D, 0.0);
     T.lq.assign(nlc + 1, std::vector<double>(D, 0.0)); T.lv = T.lq;
     T.sq.assign(prm->M + 2, std::vector<double>(D, 0.0)); T.sv = T.sq;
-    FastBook B;
+    FastBookT<LAG> B;
     B.init(prm->chain0 + (uint32_t)cl, true, prm->numIter);
+    // commands issued and not yet executed: the bookkeeper's tick t issues tick t+1; sums written and not yet retired: its tick t
+    // retires tick t+1-LAG
     Cmd cur, nxt;
     cur.hs = 0.0; cur.n = 0; cur.op = OP_NEWITER | OP_INIT;
-    double psums[4 + 2 * (MAX_M + 2)] = {0};
-    const double cap = 64.0 + 1.3 * (double)prm->numIter * ((double)(1u << prm->M) + 4.0 * prm->M + 16.0);
+    double hist[3][NSUM] = {{0}};  // sums of tick t in hist[t % 3]
+    double psums[NSUM] = {0};
+    const double cap = 64.0 + 1.3 * (double)prm->numIter * ((double)(1u << prm->M) + 6.0 * prm->M + 16.0);
     uint32_t t = 0;
     int ntrace = 0;
     for (;; ++t) {
@@ -179,25 +180,12 @@ extern "C" long fastsim_run2(Params* prm, int target, int nlc, double* idle_frac
         for (int e = 0; e < D; ++e) T.zn[e] = rng_normal(prm->seed, B.chain, (uint32_t)B.zwant, (uint32_t)e);
         B.zready = B.zwant;
       }
+      if (t + 1 >= (uint32_t)LAG) memcpy(psums, hist[(t + 1 - LAG) % 3], sizeof(psums));  // the sums of tick t+1-LAG
+      else memset(psums, 0, sizeof(psums));
       HostIO io{prm, cl, psums, &ntrace};
-      FastBook::Fast ff;
-      B.retire_pre(*prm, io);  // tick() = retire_pre() + tick_post()
-      const bool fast = fastmode && B.fast_prepare(*prm, io, t + 1, ff);
-      g_all_ticks++;
-      if (fast) g_fast_ticks++;
-      if (fast && fastmode == 2) {
-        int nt2 = ntrace, nt3 = ntrace;
-        HostIO io2{prm, cl, psums, &nt2}, io3{prm, cl, psums, &nt3};
-        FastBook B2 = B, B3 = B;
-        const Cmd c2 = B2.tick_post(*prm, io2, t + 1), c3 = B3.fast_commit(*prm, io3, ff);
-        // (the one-block uniform caches may hold different -- equally valid -- blocks: the values are functions of the index)
-        B2.cblkI = B3.cblkI; B2.cuI0 = B3.cuI0; B2.cuI1 = B3.cuI1; B2.cblkR = B3.cblkR; B2.cuR0 = B3.cuR0; B2.cuR1 = B3.cuR1;
-        if (memcmp(&B2, &B3, sizeof(FastBook)) != 0 || c2.op != c3.op || c2.n != c3.n || memcmp(&c2.hs, &c3.hs, sizeof(double)) != 0 || nt2 != nt3) return -2;
-      }
-      if (fast) nxt = B.fast_commit(*prm, io, ff);
-      else nxt = B.tick_post(*prm, io, t + 1);  // retires tick t-1, issues tick t+1
+      nxt = B.tick(*prm, io, t + 1);  // retires tick t+1-LAG, issues tick t+1
       T.tick(t, cur);                 // tick t
-      memcpy(psums, T.sums, sizeof(psums));
+      memcpy(hist[t % 3], T.sums, sizeof(psums));
       if (cur.op & OP_STEP) steps += 1;
       cur = nxt;
       if (B.finished()) break;
@@ -209,4 +197,62 @@ extern "C" long fastsim_run2(Params* prm, int target, int nlc, double* idle_frac
   if (idle_frac) *idle_frac = 1.0 - steps / ticks;
   return worst;
 }
+// the bookkeeper as two instruction streams (wn_fast.h RetireBook / IssueBook, wn_k_fast4.hip): per tick the retire side retires tick
+// t-2 from the command the T wave executed then and posts its message, the issue side applies it and issues tick t+1
+static long run_split(Params* prm, int target, int nlc, double* idle_frac) {
+  constexpr int LAG = 3;
+  const int D = prm->D;
+  long worst = 0;
+  double steps = 0, ticks = 0;
+  constexpr int NSUM = 4 + 2 * (MAX_M + 2);
+  for (int cl = 0; cl < prm->C; ++cl) {
+    TSim T;
+    T.D = D; T.M = prm->M; T.NLC = nlc; T.prm = prm; T.cl = cl; T.dense = target == T_DENSEGAUSS; T.LAG = LAG;
+    for (auto* x : {&T.q, &T.v, &T.g, &T.qb, &T.vb, &T.VL, &T.zn, &T.qhist[0], &T.qhist[1], &T.qhist[2], &T.prop[0], &T.prop[1]}) x->assign(D, 0.0);
+    T.lq.assign(nlc + 1, std::vector<double>(D, 0.0)); T.lv = T.lq;
+    T.sq.assign(prm->M + 2, std::vector<double>(D, 0.0)); T.sv = T.sq;
+    RetireBook R;
+    IssueBook I;
+    R.init(prm->chain0 + (uint32_t)cl, true, prm->numIter);
+    I.init(prm->chain0 + (uint32_t)cl, true, prm->numIter);
+    Cmd ring[4];  // the command of tick t in ring[t % 4]
+    for (auto& c : ring) { c.hs = 0.0; c.n = 0; c.op = 0; }
+    ring[0].op = OP_NEWITER | OP_INIT;
+    double hist[3][NSUM] = {{0}};  // sums of tick t in hist[t % 3]
+    double psums[NSUM] = {0};
+    const double cap = 64.0 + 1.3 * (double)prm->numIter * ((double)(1u << prm->M) + 6.0 * prm->M + 16.0);
+    uint32_t t = 0;
+    int ntrace = 0;
+    for (;; ++t) {
+      if ((double)t > cap) return -1;
+      if (I.zwant != I.zready && I.zwant >= 1) {  // momentum normals (the I wave)
+        for (int e = 0; e < D; ++e) T.zn[e] = rng_normal(prm->seed, I.chain, (uint32_t)I.zwant, (uint32_t)e);
+        I.zready = I.zwant;
+      }
+      Cmd old;
+      old.hs = 0.0; old.n = 0; old.op = 0;
+      if (t + 1 >= (uint32_t)LAG) { memcpy(psums, hist[(t + 1 - LAG) % 3], sizeof(psums)); old = ring[(t + 1 - LAG) % 4]; }
+      else memset(psums, 0, sizeof(psums));
+      HostIO io{prm, cl, psums, &ntrace};
+      const RMsg m = R.tick(*prm, io, old);           // retires tick t-2
+      const Cmd nxt = I.tick(*prm, io, t + 1, m);     // issues tick t+1
+      T.tick(t, ring[t % 4]);                         // tick t
+      memcpy(hist[t % 3], T.sums, sizeof(psums));
+      if (ring[t % 4].op & OP_STEP) steps += 1;
+      ring[(t + 1) % 4] = nxt;
+      if (I.finished()) break;
+    }
+    if (prm->trace_n) prm->trace_n[cl] = ntrace;
+    ticks += t + 1;
+    if ((long)t + 1 > worst) worst = t + 1;
+  }
+  if (idle_frac) *idle_frac = 1.0 - steps / ticks;
+  return worst;
+}
+// lag: 2, 3 = FastBookT<lag>; 4 = the two-stream form of lag 3
+extern "C" long fastsim_run2(Params* prm, int target, int nlc, double* idle_frac, int lag) {
+  if (lag == 4) return run_split(prm, target, nlc, idle_frac);
+  return lag == 3 ? run_lag<3>(prm, target, nlc, idle_frac) : run_lag<2>(prm, target, nlc, idle_frac);
+}
+extern "C" long fastsim_run(Params* prm, int target, int nlc, double* idle_frac) { return fastsim_run2(prm, target, nlc, idle_frac, 2); }
 extern "C" int fastsim_params_size() { return (int)sizeof(Params); }

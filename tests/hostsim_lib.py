@@ -118,15 +118,16 @@ def fast_lib():
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared",
                                    "-I" + _CSRC, "-o", _FSO, _FSRC])
         _flib = C.CDLL(_FSO)
-        _flib.fastsim_run.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_double)]
-        _flib.fastsim_run.restype = C.c_long
+        _flib.fastsim_run2.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
+        _flib.fastsim_run2.restype = C.c_long
         assert _flib.fastsim_params_size() == C.sizeof(Params)
     return _flib
 
 
 def fast_walnuts(target, q0, tpar=None, H0=0.2, stepSizeRandScale=0.2, delta0=0.05, numIter=10, M=10, generated=0, gen_k=0,
-                 seed=0, chain0=0, nlc=2, trace_cap=0):
-    """fixedLeapFrog on a std / diagonal / dense Gaussian through FastBook + the scalar T-wave stand-in."""
+                 seed=0, chain0=0, nlc=2, trace_cap=0, lag=2):
+    """fixedLeapFrog on a std / diagonal / dense Gaussian through FastBookT<lag> + the scalar T-wave stand-in
+    (lag 2: wn_k_fast.hip, lag 3: wn_k_fast4.hip)."""
     q0 = np.ascontiguousarray(np.atleast_2d(np.asarray(q0, float)))
     Cn, D = q0.shape
     prm = Params()
@@ -147,9 +148,7 @@ def fast_walnuts(target, q0, tpar=None, H0=0.2, stepSizeRandScale=0.2, delta0=0.
         prm.trace = _p(trace); prm.trace_cap = trace_cap
         prm.trace_n = _p(tn, ip)
     idle = C.c_double(0.0)
-    ticks = fast_lib().fastsim_run(C.byref(prm), target, nlc, C.byref(idle))
-    if ticks == -2:
-        raise RuntimeError("fastsim: the ordinary-leaf fast path and FastBook::tick() disagree")
+    ticks = fast_lib().fastsim_run2(C.byref(prm), target, nlc, C.byref(idle), lag)
     if ticks < 0:
         raise RuntimeError("fastsim: a chain exceeded its tick bound")
     return dict(samples=samples.transpose(0, 2, 1).copy(), diagnostics=diag, ticks=ticks, idle_frac=idle.value,

@@ -13,6 +13,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 INT = (0, 1, 4, 5, 6, 7, 8, 9, 12, 13, 19, 20, 21, 22)
 bad = 0
+other = 0
 
 
 def close(a, b, tol=1e-6):
@@ -23,7 +24,7 @@ def close(a, b, tol=1e-6):
 
 
 for it in range(n):
-    D = int(rng.choice([2, 5, 16, 17, 31, 32, 33, 47, 64, 65, 80, 96, 97, 99, 100]))
+    D = int(rng.choice([5, 16, 17, 31, 32, 33, 47, 64, 65, 80, 96, 97, 99, 100]))
     C = int(rng.choice([1, 3, 4, 5, 17, 70, 300, 1100, 2500, 4300], p=[.1, .1, .1, .1, .15, .15, .1, .1, .05, .05]))
     M = int(rng.integers(1, 9)) if rng.random() < 0.85 else int(rng.integers(9, 12))
     if C > 1000: M = min(M, 8)
@@ -40,7 +41,8 @@ for it in range(n):
     e = wa.Engine(D, C, integrator=ol.I_FIXED, H0=H0, M=M, generated=gen, gen_k=gk, chain_offset=off)
     e.set_target(ol.T_DENSEGAUSS, A)
     name = e.kernel_name
-    assert "wn_fast4_kernel" in name, name
+    if "wn_fast4_kernel" not in name:  # (small dimensions with many chains go to the lane layout)
+        other += 1; e.close(); continue
     out = e.run(q0, 4242 + it, numIter, trace_cap=cap if traced else 0)
     s = out[0].transpose(1, 2).cpu().numpy(); d = out[1].cpu().numpy()
     tr, tn = (out[2].cpu().numpy(), out[3].cpu().numpy()) if traced else (None, None)
@@ -55,4 +57,4 @@ for it in range(n):
         if not ok:
             bad += 1
             print(f"MISMATCH it={it} D={D} C={C} M={M} iters={numIter} gen={gen} H0={H0:.4f} traced={traced} chain={k} kernel={name}", flush=True)
-print(f"fuzz_fast4: {n} configurations, {bad} mismatching chains")
+print(f"fuzz_fast4: {n} configurations ({other} not on the pair kernel), {bad} mismatching chains")

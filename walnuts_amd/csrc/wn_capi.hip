@@ -716,14 +716,18 @@ int wn_run(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, do
     if (strstr(e->kc.name, "wn_fast4_kernel")) {  // rows: up to 8 waves per workgroup (T waves 0..pairs-1, then the B waves)
       const int pairs = fast4_pairs(p.C);
       const size_t groups = ((size_t)(p.C + 3) / 4 + pairs - 1) / pairs;
-      for (int w = 0; w < 2 * pairs; ++w) {
+      for (int w = 0; w < pairs + 2 * ((pairs + 1) / 2); ++w) {
         double a[8] = {0};
         for (size_t gI = 0; gI < groups; ++gI) for (int k = 0; k < 8; ++k) a[k] += (double)h[(gI * 8 + w) * 16 + k];
         if (a[6] <= 0) continue;
-        if (w < pairs) fprintf(stderr, "[WN_STAMPS fast4] T wave %d cycles/tick: commands+halfstep=%.0f mfma=%.0f halfstep+checks+sums=%.0f stores=%.0f wait=%.0f (ticks %.0f)\n",
-                               w, a[0] / a[6], a[1] / a[6], a[2] / a[6], a[3] / a[6], a[4] / a[6], a[6] / groups);
-        else fprintf(stderr, "[WN_STAMPS fast4] B wave %d cycles/tick: normals+window=%.0f wait for T=%.0f sums+verdicts=%.0f bookkeeper=%.0f command=%.0f (fast-path ticks %.1f %%)\n",
-                     w - pairs, a[0] / a[6], a[5] / a[6], a[1] / a[6], a[2] / a[6], a[3] / a[6], 100.0 * a[7] / a[6]);
+        // waves 0 .. 2 quads - 1: the bookkeeper (R, I alternating), then the T waves
+        const int quads = (pairs + 1) / 2;
+        if (w >= 2 * quads) fprintf(stderr, "[WN_STAMPS fast4] T wave %d cycles/tick: fragment requests=%.0f wait for the command=%.0f commands+halfstep=%.0f mfma=%.0f halfstep+checks+sums=%.0f stores=%.0f (ticks %.0f)\n",
+                               w, a[7] / a[6], a[5] / a[6], a[0] / a[6], a[1] / a[6], a[2] / a[6], (a[3] + a[4]) / a[6], a[6] / groups);
+        else if (w & 1) fprintf(stderr, "[WN_STAMPS fast4] I wave %d cycles/tick: normals+window=%.0f wait for R=%.0f message=%.0f issue=%.0f command=%.0f\n",
+                     w, a[0] / a[6], a[5] / a[6], a[1] / a[6], a[2] / a[6], a[3] / a[6]);
+        else fprintf(stderr, "[WN_STAMPS fast4] R wave %d cycles/tick: wait for T=%.0f sums+verdicts=%.0f retire=%.0f message=%.0f\n",
+                     w, a[5] / a[6], a[1] / a[6], a[2] / a[6], a[3] / a[6]);
       }
       return rc;
     }

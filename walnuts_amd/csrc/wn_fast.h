@@ -26,6 +26,12 @@
 //       certain to happen (WnewSum is non-decreasing inside a doubling, WALNUTS.py:424-426); otherwise the
 //       chain idles until it is known.
 //
+// The lag is a template parameter.  LAG = 2 is the protocol above (wn_k_fast.hip).  LAG = 3 (wn_k_fast4.hip) retires tick t-2
+// while tick t runs: the bookkeeper then has TWO vector ticks for one of its own, so neither wave waits for the other on an
+// ordinary leaf (with LAG = 2 every slow tick of either side stalled the other one).  Two leaves are in flight instead of one:
+// a pick copies the position of tick t-3 (the T wave keeps it), an iteration end discards up to two leaves, and the step sizes of
+// a leaf pair are issued ahead of up to two retirements (their draws counted as above).
+//
 // FastBook is plain scalar code, host + device: a CPU test harness under tests/ runs it against the oracle on
 // the CPU with a scalar stand-in for the T waves (test tool only).
 #pragma once
@@ -33,12 +39,6 @@
 #include <stdint.h>
 
 #include "wn_chain.h"
-
-#if defined(__HIP_DEVICE_COMPILE__)
-#define WN_OPAQUE4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-#else
-#define WN_OPAQUE4(a, b, c, d) do {} while (0)
-#endif
 
 namespace wn {
 namespace fast {
@@ -51,10 +51,11 @@ enum {
   OP_INIT = 4u,      // with OP_NEWITER at tick 0: q <- q0, proposal[0] <- q, no momentum (draw row 0)
   OP_LAST = 8u,      // with OP_NEWITER: only the emit (the run's last draw); the chain is finished
   OP_SWAP = 16u,     // before the step: exchange (q, v) with the passive orbit end (WALNUTS.py:283-286)
-  OP_PICK = 32u,     // copy the position of tick t-2 into proposal[ippick]
+  OP_PICK = 32u,     // copy the position of tick t-LAG into proposal[ippick]
   OP_IPPICK = 64u,   // bit: ippick
   OP_IPNEW = 128u,   // bit: ipnew
   OP_I_SHIFT = 8,    // bits 8..12: doubling index i of an OP_STEP (n = leaf index inside the doubling)
+  OP_UNDO2 = 1u << 13, // (LAG = 3) a second one
   OP_UNDO = 1u << 14, // traced runs: the leaf that was in flight when the iteration ended is not an integrator call of the
                      // reference -- the T wave takes its trace row back
   OP_DONE = 1u << 15 // every chain of the group has finished: all waves leave the tick loop
@@ -98,7 +99,9 @@ WN_HD uint32_t fire_of(int i, int n, int xi, Src& src) {
 }
 
 // ---- the bookkeeper: every per-chain scalar of one chain ---------------------------------------
-struct FastBook {
+template <int LAG>
+struct FastBookT {
+  static_assert(LAG == 2 || LAG == 3, "ticks between a leaf and its retirement");
   enum { ST_NEEDITER = 0, ST_FIRST, ST_RUN, ST_DRAIN, ST_DEAD };
   enum { K_NONE = 0, K_STEP, K_NEWITER };
   struct Slot {  // what the T waves were told to do in one tick
@@ -115,10 +118,11 @@ struct FastBook {
   int iter, i, xi, a, b, nleaf, n_rt, n_is;
   uint32_t ku;
   int nevalF, L_, Lold_, NdS, NdC, maxFint, maxBint, stopCode, ip, ipl;
-  bool Hnan, pend_pick, swap_next, undo;
+  bool Hnan, pend_pick, swap_next;
+  int undo;  // trace rows the T wave has to take back (leaves discarded at an iteration end)
   int pick_ip, st;
   int zwant, zready;  // momentum normals: iteration wanted next / iteration the buffer holds
-  Slot s0, s1;
+  Slot s0, s1, s2;  // ticks t-LAG+1 (retired next) .. t+1 (s2: LAG = 3 only)
   uint32_t cblkI, cblkR;  // cached Philox block of the uniform stream, issue side / retire side
   double cuI0, cuI1, cuR0, cuR1;
   uint32_t chain;  // global chain id
@@ -131,13 +135,17 @@ struct FastBook {
     Hmin = INFINITY; Hmax = -INFINITY; Hnan = false;
     iter = 1; i = 0; xi = 1; a = b = 0; nleaf = 1; n_rt = n_is = 0; ku = 0;
     nevalF = L_ = Lold_ = NdS = NdC = maxFint = maxBint = stopCode = 0; ip = ipl = 0;
-    pend_pick = false; swap_next = false; undo = false; pick_ip = 0;
+    pend_pick = false; swap_next = false; undo = 0; pick_ip = 0;
     st = inrange ? ST_NEEDITER : ST_DEAD;
     zwant = (inrange && numIter >= 1) ? 1 : 0; zready = 0;
     pre_lpn = pre_Hn = pre_Wsum = pre_ratio = 0.0;
     s0.clear();
     s1.clear();
-    if (inrange) { s1.kind = K_NEWITER; s1.init = true; }  // tick 0: every chain loads q0 (OP_INIT)
+    s2.clear();
+    if (inrange) {  // tick 0: every chain loads q0 (OP_INIT)
+      Slot& f = LAG == 3 ? s2 : s1;
+      f.kind = K_NEWITER; f.init = true;
+    }
     cblkI = cblkR = 0xFFFFFFFFu;
     cuI0 = cuI1 = cuR0 = cuR1 = 0.0;
   }
@@ -215,7 +223,9 @@ struct FastBook {
     d[23] = indexStat_;
     io.write_diag((size_t)(iter - 1), d);
     iter++;
-    if (s1.kind == K_STEP) { s1.discard = true; undo = true; }  // the leaf in flight belongs to the orbit that just ended
+    // the leaves in flight belong to the orbit that just ended
+    if (s1.kind == K_STEP) { s1.discard = true; undo += 1; }
+    if (LAG == 3) { if (s2.kind == K_STEP) { s2.discard = true; undo += 1; } }
     swap_next = false;
     st = ST_NEEDITER;
   }
@@ -331,7 +341,7 @@ struct FastBook {
     if (iter + 1 <= prm.numIter) zwant = iter + 1;  // the momentum buffer is free again
   }
 
-  // One bookkeeper tick: retire tick t-1, issue tick t+1.  `tn` = t+1.
+  // One bookkeeper tick: retire tick t+1-LAG, issue tick t+1.  `tn` = t+1.
   template <class IO>
   WN_HD Cmd tick(const Params& prm, IO& io, uint32_t tn) {
     retire_pre(prm, io);
@@ -342,12 +352,13 @@ struct FastBook {
     if (s0.kind == K_NEWITER) retire_newiter(prm, io, s0.row, s0.init, s0.last);
     else if (s0.kind == K_STEP && !s0.discard) retire_step(prm, io, s0.n, s0.h);
     s0.set(s1);
+    if (LAG == 3) s1.set(s2);
     Slot ns;
     ns.clear();
     Cmd c;
     c.hs = 0.0; c.op = 0u; c.n = 0u;
     if (pend_pick) { c.op |= OP_PICK | (pick_ip ? OP_IPPICK : 0u); pend_pick = false; }
-    if (undo) { c.op |= OP_UNDO; undo = false; }
+    if (undo > 0) { c.op |= OP_UNDO | (undo > 1 ? OP_UNDO2 : 0u); undo = 0; }
     const bool odd = (tn & 1u) != 0;
     if (st == ST_NEEDITER) {
       if (odd && (iter > prm.numIter || zready == iter)) {
@@ -383,11 +394,12 @@ struct FastBook {
       if ((n_is & 1) == 0) {
         if (odd) go = false;  // leaf pairs start on even ticks: all chains of a group check / store in step
         else {
-          const int inflight = n_is - n_rt;  // leaves issued and not yet retired (0 or 1)
+          // leaves issued and not yet retired (at most LAG - 1): retiring an even one advances the draw count by its pair's two
+          // step sizes (:395) -- drawn when the pair was issued -- and every one by its multinomial draw (:426)
           uint32_t kh = ku;
-          if (inflight > 0) {
-            if (WnewSum > prm.wtSumThresh) kh = ku + (uint32_t)inflight;  // their multinomial draws are certain
-            else go = false;                                             // not known yet: wait for them
+          if (n_is > n_rt) {
+            if (WnewSum > prm.wtSumThresh) kh = first_issue_uniform();  // their multinomial draws are certain
+            else go = false;                                            // not known yet: wait for them
           }
           if (go) { h = h_of(prm, io, kh); h2 = h_of(prm, io, kh + 1u); }        // :395
         }
@@ -408,122 +420,350 @@ struct FastBook {
     } else if (st == ST_DRAIN) {
       if (swap_next) { c.op |= OP_SWAP; swap_next = false; }
     }
-    s1.set(ns);
+    if (LAG == 3) s2.set(ns); else s1.set(ns);
     return c;
   }
+  // first uniform index an ordinary retirement of this tick reads, and the first one the issue of an ordinary leaf pair behind it
+  // reads (the io prefetches their blocks)
+  WN_HD uint32_t first_retire_uniform() const { return ku + (((s0.n & 1) == 0) ? 2u : 0u); }
+  WN_HD uint32_t first_issue_uniform() const {  // ku + sum over the leaves m in flight of (m even ? 3 : 1)
+    return ku + (uint32_t)(n_is - n_rt) + 2u * (uint32_t)(((n_is + 1) >> 1) - ((n_rt + 1) >> 1));
+  }
 
-  // ---- the ordinary leaf: fast path of tick() ----------------------------------------------------------------
-  // Most ticks of a chain are the same event: in the middle of a doubling (i >= 1) the leaf of tick t-1 is retired -- a
-  // finite energy, no sub-tree U-turn, its multinomial draw taken -- and leaf n+2 is issued while leaf n+1 is in flight.
-  // tick() handles it through the same branches as every rare event; on the device every branch is an exec-mask save, a
-  // vote and a jump, and the bookkeeper's ~600 instructions per tick compete with the T wave's MFMAs for the SIMD (FP64
-  // MFMAs and vector instructions do not overlap on this chip: tools/mfma_valu_coissue.hip).  fast_prepare() decides
-  // (after retire_pre(), WITHOUT touching the state) whether this tick is that event and computes what it changes, straight-line;
-  // fast_commit() applies it.  State, command and draws are bit for bit those of tick() (tests/test_fast_book.py runs
-  // both on every tick and compares every member).  A wave takes the fast path when all its chains are ordinary.
-  struct Fast {  // (the leaf's energy, weight sum and acceptance ratio are retire_pre()'s: pre_lpn, pre_Hn, pre_Wsum, pre_ratio)
-    double h, hnext2;
-    uint32_t ku_new;
-    int n, idx;
-    bool pick, even_issue;
-  };
-  // u = k-th uniform of this iteration if it is at hand without running Philox (either one-block cache, or the io's window)
+  WN_HD bool finished() const { return st == ST_DEAD && s0.kind == K_NONE && s1.kind == K_NONE && (LAG == 2 || s2.kind == K_NONE) && !pend_pick; }
+};
+using FastBook = FastBookT<2>;
+
+// ================================================================================================
+// The same bookkeeper (LAG = 3) as TWO instruction streams, wn_k_fast4.hip: a RETIRE wave and an ISSUE wave, each
+// serving the chains of two T waves.  Why: FP64 matrix and vector instructions share a SIMD's issue slots on this
+// chip (tools/mfma_valu_coissue.hip), so a tick's period is the T wave's instructions PLUS the bookkeeper's; one
+// bookkeeper stream per T wave (~600 instructions for four chains in sixteen redundant replicas) cost 2.9 k of a
+// 7.5 k-cycle tick.  Eight chains per stream halve the streams, and cutting the stream in two keeps the SIMDs even.
+//   RetireBook  (R wave)  everything FastBookT does when it retires a tick -- energies, weights, multinomial and
+//       acceptance draws, U-turn verdicts, doubling / iteration ends, diagnostics -- told WHAT the tick was by the
+//       command record the T wave executed (kind, leaf index n, |hs| = h), not by the issue side;
+//   IssueBook   (I wave)  everything it does when it issues one: the automaton NEEDITER / FIRST / RUN / DRAIN, step
+//       sizes and direction bits, momentum normals and the uniform window (wn_k_fast4.hip).
+// One message per chain and tick goes R -> I (RMsg): the draw count and retired-leaf count the issue side needs to
+// index its step-size draws, whether the multinomial draws of the leaves in flight are certain, doubling / iteration
+// end events, the proposal index, the pick of the retired leaf.  I(t) applies R(t)'s message and then does exactly
+// what FastBookT<3>::tick_post does behind its retirement: results are those of FastBookT<3>, tick for tick
+// (tests/test_fast_book.py runs both against the oracle).
+struct alignas(16) RMsg {
+  uint32_t ku, w, iter, zwant;
+};
+enum {
+  RM_NRT_MASK = 0xFFFFu,  // leaves of the running doubling retired so far
+  RM_CERTAIN = 1u << 16,  // WnewSum > wtSumThresh: the leaves in flight will take their multinomial draws
+  RM_CONT = 1u << 17,     // this tick's retirement ended a doubling; the orbit goes on with doubling i+1
+  RM_END = 1u << 18,      // ... ended the iteration (`iter` is the next one's index)
+  RM_IP = 1u << 19,       // proposal buffer that holds the state the next iteration starts from
+  RM_PICK = 1u << 20,     // the retired leaf was picked: the T wave copies its position into proposal[RM_PICKIP]
+  RM_PICKIP = 1u << 21,
+  RM_DEAD = 1u << 22      // the run's last draw has been retired
+};
+
+struct BookUniforms {  // the chain's uniform stream (wn_rng.h stream 0) behind a one-block cache
+  uint32_t chain;
+  int iter;
+  uint32_t cblk;
+  double cu0, cu1;
   template <class IO>
-  WN_HD bool peek(const IO& io, uint32_t k, double& u) const {
-    const uint32_t bl = k >> 1;
-    double w0, w1;
-    const bool hw = io.uniforms(2, iter, bl, w0, w1);
-    // (select form over register copies: a select between two loaded members becomes a load from a selected ADDRESS, and a
-    // struct whose members' addresses are selected at run time stays in scratch memory)
-    double r0 = cuR0, r1 = cuR1, i0 = cuI0, i1 = cuI1;
-    WN_OPAQUE4(r0, r1, i0, i1);
-    const bool cr = bl == cblkR, ci = bl == cblkI;
-    const double x0 = cr ? r0 : ci ? i0 : w0, x1 = cr ? r1 : ci ? i1 : w1;
-    u = (k & 1u) ? x1 : x0;
-    return cr || ci || hw;
-  }
-  // first uniform index an ordinary retirement of this tick reads (the io prefetches its block and the next two)
-  WN_HD uint32_t fast_first_uniform() const { return ku + (((s0.n & 1) == 0) ? 2u : 0u); }
-  template <class IO>
-  WN_HD bool fast_prepare(const Params& prm, const IO& io, uint32_t tn, Fast& f) const {
-    bool ok = s0.kind == K_STEP && !s0.discard && s1.kind == K_STEP && !s1.discard && st == ST_RUN && i >= 1 && !undo;
-    const int n = s0.n;
-    f.n = n;
-    ok = ok && isfinite(pre_Hn);  // retire_pre() has run
-    // no sub-tree U-turn at an odd leaf; the last leaf of the doubling is not ordinary (s1 is leaf n+1 < nleaf)
-    if (n & 1) {
-      const uint32_t m = ((2u << __builtin_ctz((unsigned)(n + 1))) - 1u) & ~1u;
-      ok = ok && (io.firemask(i, n, xi) & m) == 0;
+  WN_HD double U(const Params& prm, IO& io, int side, uint32_t k) {
+    const uint32_t blk = k >> 1;
+    if (cblk != blk) {
+      double ua, ub;
+      if (!io.uniforms(side, iter, blk, ua, ub)) {
+        Philox4 r = philox4x32_10(blk, (uint32_t)iter, chain, 0u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
+        ua = u53(r.w[0], r.w[1]); ub = u53(r.w[2], r.w[3]);
+      }
+      cu0 = ua; cu1 = ub; cblk = blk;
     }
-    ok = ok && s1.n == n + 1 && n_is == n + 2 && n_rt == n;
-    f.idx = xi > 0 ? b + 1 + n : a - 1 - n;
-    uint32_t k = ku + (((n & 1) == 0) ? 2u : 0u);     // :395 size=2, before the first step of the pair
-    // the leaf's multinomial draw (:426) must happen (then leaf n+1's will too: WnewSum does not decrease)
-    ok = ok && pre_Wsum > prm.wtSumThresh;
-    double u;
-    ok = peek(io, k, u) && ok;
-    f.pick = u < pre_ratio;
-    k += 1u;
-    // issue leaf n+2 (tick_post, ST_RUN): not the last leaf of the doubling (its issue draws the next direction)
-    ok = ok && n + 3 < nleaf;
-    f.even_issue = (n & 1) == 0;
-    ok = ok && (!f.even_issue || (tn & 1u) == 0);  // leaf pairs start on even ticks
-    double ua = 0.0, ub = 0.0;
-    if (f.even_issue) {  // h, h2 = uniforms k+1, k+2 (one leaf in flight: its draw comes first)
-      ok = peek(io, k + 1u, ua) && ok;
-      ok = peek(io, k + 2u, ub) && ok;
-      f.h = h_from(prm, ua);
-      f.hnext2 = h_from(prm, ub);
-    } else {
-      f.h = h2;
-      f.hnext2 = h2;
-    }
-    f.ku_new = k;
-    return ok;
+    return (k & 1u) ? cu1 : cu0;
   }
   template <class IO>
-  WN_HD Cmd fast_commit(const Params& prm, IO& io, const Fast& f) {
-    const int n = f.n;
-    const double h = s0.h;
-    io.trace_step(iter, i, xi, h, Ha, pre_lpn);
+  WN_HD int dir(const Params& prm, IO& io, int side, int j) {  // WALNUTS.py:216,283
+    const double u0 = 0.0 + (2.0 - 0.0) * U(prm, io, side, (uint32_t)j);
+    return ((int)floor(u0) != 0) ? -1 : 1;
+  }
+};
+
+struct RetireBook : BookUniforms {
+  double H0, Ha, Hb, lpP, lpPL, WoldSum, WnewSum;
+  double orbitLen_, orbitLenSam_, indexStat_, indexStatOld_, timeLenF_, timeLenB_, Hmin, Hmax;
+  int i, xi, a, b, nleaf, n_rt;
+  uint32_t ku;
+  int nevalF, L_, Lold_, NdS, NdC, maxFint, maxBint, stopCode, ip, ipl;
+  bool Hnan, pend_pick, discarding, dead;
+  int pick_ip, zwant;
+  uint32_t ev;
+  double pre_lpn, pre_Hn, pre_Wsum, pre_ratio;
+
+  WN_HD void init(uint32_t chain_global, bool inrange, int numIter) {
+    chain = chain_global; iter = 1; cblk = 0xFFFFFFFFu; cu0 = cu1 = 0.0;
+    H0 = Ha = Hb = lpP = lpPL = 0.0; WoldSum = 1.0; WnewSum = 0.0;
+    orbitLen_ = orbitLenSam_ = indexStat_ = indexStatOld_ = timeLenF_ = timeLenB_ = 0.0;
+    Hmin = INFINITY; Hmax = -INFINITY; Hnan = false;
+    i = 0; xi = 1; a = b = 0; nleaf = 1; n_rt = 0; ku = 0;
+    nevalF = L_ = Lold_ = NdS = NdC = maxFint = maxBint = stopCode = 0; ip = ipl = 0;
+    pend_pick = false; discarding = false; dead = !inrange; pick_ip = 0;
+    zwant = (inrange && numIter >= 1) ? 1 : 0;
+    ev = 0u;
+    pre_lpn = pre_Hn = pre_Wsum = pre_ratio = 0.0;
+  }
+  WN_HD void start_doubling_common() {  // WALNUTS.py:283-294
+    n_rt = 0;
+    nleaf = 1 << i;
+    ipl = ip; lpPL = lpP; Lold_ = L_; indexStatOld_ = indexStat_;
+    if (i > 0) WnewSum = 0.0;  // :390
+  }
+  WN_HD void pick_state(int idx, double lpn) {
+    if (ip == ipl) ip ^= 1;  // keep qPropLast intact
+    pend_pick = true; pick_ip = ip;
+    lpP = lpn; L_ = idx;
+    indexStat_ = xi > 0 ? timeLenF_ : -timeLenB_;
+  }
+  WN_HD void revert_prop() { ip = ipl; lpP = lpPL; L_ = Lold_; indexStat_ = indexStatOld_; }  // qProp = qPropLast (:599-601, 614-616)
+
+  template <class IO>
+  WN_HD void end_iteration(const Params& prm, IO& io) {  // WALNUTS.py:653-695 (the draw itself: next OP_NEWITER)
+    double d[NDIAG];
+    d[0] = L_; d[1] = NdS; d[2] = orbitLen_; d[3] = orbitLenSam_; d[4] = maxFint; d[5] = maxBint;
+    d[6] = nevalF; d[7] = 0.0;
+    d[8] = 0; d[9] = 0; d[10] = 0.0; d[11] = 0.0;  // fixedLeapFrog: If = Ib = c = 0, lwt = 0 (adaptiveIntegrators.py:57-59)
+    d[12] = 0.0; d[13] = 0.0; d[14] = 0.0;
+    d[15] = prm.H; d[16] = 1.0;
+    d[17] = Hnan ? NAN : (Hmax - Hmin);
+    d[18] = prm.delta; d[19] = (double)stopCode; d[20] = NdC; d[21] = 0; d[22] = 0;
+    d[23] = indexStat_;
+    io.write_diag((size_t)(iter - 1), d);
+    iter++;
+    discarding = true;  // the leaves in flight belong to the orbit that just ended: every step up to the next iteration start
+    ev = RM_END;
+  }
+  template <class IO>
+  WN_HD void doubling_end(const Params& prm, IO& io, bool sub, uint32_t firemask) {
+    indexStat_ = indexStat_ / (timeLenF_ + timeLenB_);  // :595 (Q6)
+    if (sub) {  // :597-605
+      revert_prop();
+      NdS = i; NdC = i + 1; stopCode = 5;
+      end_iteration(prm, io);
+      return;
+    }
+    if (!(U(prm, io, 1, ku++) < WnewSum / WoldSum)) revert_prop();  // :613-616
+    const bool joined = (firemask & 1u) != 0;                   // :622
+    if (joined) {                                               // :625-634 (lwtSum = 0: never "both ends passive")
+      stopCode = 4;
+      NdS = NdC = i + 1;
+      orbitLenSam_ = orbitLen_;
+      end_iteration(prm, io);
+      return;
+    }
+    WoldSum += WnewSum;  // :641-648
+    orbitLenSam_ = orbitLen_;
+    NdS = NdC = i + 1;
+    if (xi > 0) b += nleaf; else a -= nleaf;
+    i++;
+    if (i == prm.M) { end_iteration(prm, io); return; }
+    const int nxi = dir(prm, io, 1, i);  // :283
+    if (nxi != xi) { const double th = Ha; Ha = Hb; Hb = th; xi = nxi; }  // the T waves swapped on OP_SWAP
+    start_doubling_common();
+    ev = RM_CONT;
+  }
+  template <class IO>
+  WN_HD void retire_step(const Params& prm, IO& io, const int n, const double h) {
+    const double lpn = pre_lpn, Hn = pre_Hn;
+    const uint32_t firemask = io.firemask(i, n, xi);  // bit j: U-turn check j of this leaf fired (fire_of)
+    const bool first = (i == 0) || ((n & 1) == 0);
+    const int idx = xi > 0 ? b + 1 + n : a - 1 - n;
+    io.trace_step(iter, i, xi, h, Ha, lpn);
+    if (i == 0) ku += 1;                 // :298  the step size was drawn before the step
+    else if ((n & 1) == 0) ku += 2;      // :395  size=2, before the first step of the pair
     nevalF += 1;
-    Hmin = pre_Hn < Hmin ? pre_Hn : Hmin; Hmax = pre_Hn > Hmax ? pre_Hn : Hmax;
+    if (isnan(Hn)) Hnan = true;
+    Hmin = Hn < Hmin ? Hn : Hmin; Hmax = Hn > Hmax ? Hn : Hmax;
     {
       const bool fw = xi > 0;
       const double tf = timeLenF_ + h, tb = timeLenB_ + h;
-      maxFint = fw ? f.idx : maxFint; maxBint = fw ? maxBint : f.idx;
+      maxFint = fw ? idx : maxFint; maxBint = fw ? maxBint : idx;
       timeLenF_ = fw ? tf : timeLenF_; timeLenB_ = fw ? timeLenB_ : tb;
     }
+    if (i == 0) orbitLen_ += h;  // :300
     n_rt = n + 1;
-    WnewSum = pre_Wsum;
-    ku = f.ku_new;
-    // (the one-block uniform caches keep what they hold: still valid blocks of this iteration)
-    {  // pick_state(idx, lpn), select form
-      const bool p = f.pick;
-      const int nip = (ip == ipl) ? (ip ^ 1) : ip;
-      ip = p ? nip : ip;
-      pick_ip = p ? ip : pick_ip;
-      pend_pick = pend_pick || p;
-      lpP = p ? pre_lpn : lpP;
-      L_ = p ? f.idx : L_;
-      const double is = xi > 0 ? timeLenF_ : -timeLenB_;
-      indexStat_ = p ? is : indexStat_;
+    if (!isfinite(Hn)) {         // :316-319, 414-417, 457-459 (Q3, Q4)
+      if (first) stopCode = 999;
+      end_iteration(prm, io);
+      return;
     }
-    orbitLen_ += h;
-    Ha = pre_Hn;
-    // tick_post
-    s0.kind = K_STEP; s0.n = n + 1; s0.row = 0; s0.discard = false; s0.last = false; s0.init = false; s0.h = s1.h;
-    Cmd c;
-    c.op = OP_STEP | ((uint32_t)i << OP_I_SHIFT) | (pend_pick ? (OP_PICK | (pick_ip ? OP_IPPICK : 0u)) : 0u);
+    WnewSum = pre_Wsum;
+    if (i == 0) {  // :322-328, 368-369: unconditional, no uniform
+      pick_state(idx, lpn);
+    } else {
+      if (WnewSum > prm.wtSumThresh && U(prm, io, 1, ku++) < pre_ratio) pick_state(idx, lpn);  // :426
+      orbitLen_ += h;
+    }
+    Ha = Hn;
+    bool sub = false;
+    if (i >= 1 && (n & 1)) {
+      const uint32_t m = ((2u << __builtin_ctz((unsigned)(n + 1))) - 1u) & ~1u;  // checks 1..ctz(n+1)
+      sub = (firemask & m) != 0;
+    }
+    if (sub) doubling_end(prm, io, true, firemask);
+    else if (n + 1 == nleaf) doubling_end(prm, io, false, firemask);
+  }
+  template <class IO>
+  WN_HD void retire_newiter(const Params& prm, IO& io, const Cmd& c) {
+    const bool init_ = (c.op & OP_INIT) != 0, last_ = (c.op & OP_LAST) != 0;
+    discarding = false;
+    if (!init_ && !last_) {  // WALNUTS.py:196-276, scalar part (FastBookT does it when it issues the iteration start)
+      a = 0; b = 0; maxFint = 0; maxBint = 0;
+      WoldSum = 1.0; WnewSum = 0.0;
+      stopCode = 0; nevalF = 0; Lold_ = L_ = 0; orbitLen_ = orbitLenSam_ = 0.0; NdS = NdC = 0;
+      indexStat_ = indexStatOld_ = 0.0; timeLenF_ = timeLenB_ = 0.0;
+      cblk = 0xFFFFFFFFu;  // the uniform cache is keyed by block only
+      i = 0;
+      xi = dir(prm, io, 1, 0);
+      ku = (uint32_t)prm.M;
+      start_doubling_common();
+    }
+    if (prm.generated == G_Q0_SUMSQ) io.write_gen((size_t)c.n, io.sum(Q_GEN));
+    if (init_) {  // f0 = lpFun(q0)  (WALNUTS.py:177)
+      lpP = 0.5 * io.sum(Q_LP);
+      lpPL = lpP;
+      return;
+    }
+    if (last_) { dead = true; return; }
+    H0 = -lpP + 0.5 * io.sum(Q_KEINIT);  // Hs[I0] = -f0 + 0.5*sum(v**2) (:256)
+    Ha = Hb = H0;
+    Hnan = isnan(H0); Hmin = Hmax = H0;
+    if (iter + 1 <= prm.numIter) zwant = iter + 1;  // the momentum buffer is free again
+  }
+  // does the command `c` (the one the T wave executed in the tick whose sums `io` holds) retire a leaf?
+  WN_HD bool retires_step(const Cmd& c) const { return (c.op & OP_STEP) != 0 && (c.op & OP_NEWITER) == 0 && !discarding; }
+  template <class IO>
+  WN_HD RMsg tick(const Params& prm, IO& io, const Cmd& c) {
+    ev = 0u;
+    if (c.op & OP_NEWITER) retire_newiter(prm, io, c);
+    else if (retires_step(c)) {
+      pre_lpn = 0.5 * io.sum(Q_LP);              // lp = 1/2 q.g for the Gaussian targets
+      pre_Hn = -pre_lpn + 0.5 * io.sum(Q_KE);    // adaptiveIntegrators.py:55
+      const double Wnew = exp(-pre_Hn + H0 + 0.0);   // lwtSum = 0
+      pre_Wsum = i == 0 ? Wnew : WnewSum + Wnew;     // :322 / :424
+      pre_ratio = Wnew / pre_Wsum;                   // :426
+      retire_step(prm, io, (int)c.n, fabs(c.hs));    // hs = xi * h
+    }
+    RMsg m;
+    m.ku = ku; m.iter = (uint32_t)iter; m.zwant = (uint32_t)zwant;
+    m.w = ((uint32_t)n_rt & RM_NRT_MASK) | (WnewSum > prm.wtSumThresh ? RM_CERTAIN : 0u) | ev | (ip ? RM_IP : 0u) |
+          (pend_pick ? (RM_PICK | (pick_ip ? RM_PICKIP : 0u)) : 0u) | (dead ? RM_DEAD : 0u);
     pend_pick = false;
-    c.n = (uint32_t)(n + 2);
-    c.hs = (double)xi * f.h;
-    h2 = f.hnext2;
-    s1.kind = K_STEP; s1.n = n + 2; s1.row = 0; s1.discard = false; s1.last = false; s1.init = false; s1.h = f.h;
-    n_is = n + 3;
+    return m;
+  }
+};
+
+struct IssueBook : BookUniforms {
+  enum { ST_NEEDITER = 0, ST_FIRST, ST_RUN, ST_DRAIN, ST_DEAD };
+  int st, i, xi, nleaf, n_is, n_rt;
+  uint32_t ku;
+  bool certain, swap_next, c1step, c2step, rdead;
+  double h2;
+  int zwant, zready, ip;
+
+  WN_HD void init(uint32_t chain_global, bool inrange, int numIter) {
+    chain = chain_global; iter = 1; cblk = 0xFFFFFFFFu; cu0 = cu1 = 0.0;
+    st = inrange ? ST_NEEDITER : ST_DEAD;
+    i = 0; xi = 1; nleaf = 1; n_is = n_rt = 0; ku = 0u;
+    certain = false; swap_next = false; c1step = c2step = false; rdead = !inrange;
+    h2 = 0.0;
+    zwant = (inrange && numIter >= 1) ? 1 : 0; zready = 0; ip = 0;
+  }
+  WN_HD static double h_from(const Params& prm, double Uu) {  // numpy legacy uniform(low, high) = low + (high-low)*U
+    const double low = prm.H * (1 - prm.s), high = prm.H * (1 + prm.s);
+    return low + (high - low) * Uu;
+  }
+  template <class IO>
+  WN_HD double h_of(const Params& prm, IO& io, uint32_t k) { return h_from(prm, U(prm, io, 0, k)); }
+  WN_HD uint32_t first_issue_uniform() const {  // ku + sum over the leaves m in flight of (m even ? 3 : 1)
+    return ku + (uint32_t)(n_is - n_rt) + 2u * (uint32_t)(((n_is + 1) >> 1) - ((n_rt + 1) >> 1));
+  }
+  // One tick: apply the retire side's message of this tick, issue tick `tn`.
+  template <class IO>
+  WN_HD Cmd tick(const Params& prm, IO& io, uint32_t tn, const RMsg& m) {
+    Cmd c;
+    c.hs = 0.0; c.op = 0u; c.n = 0u;
+    ku = m.ku; n_rt = (int)(m.w & RM_NRT_MASK); certain = (m.w & RM_CERTAIN) != 0;
+    zwant = (int)m.zwant; rdead = (m.w & RM_DEAD) != 0;
+    if (m.w & RM_PICK) c.op |= OP_PICK | ((m.w & RM_PICKIP) ? OP_IPPICK : 0u);
+    if (m.w & RM_END) {  // the leaves in flight (the commands of ticks tn-1, tn-2) belong to the orbit that just ended
+      const int u = (c1step ? 1 : 0) + (c2step ? 1 : 0);
+      if (u > 0) c.op |= OP_UNDO | (u > 1 ? OP_UNDO2 : 0u);
+      c1step = c2step = false;
+      st = ST_NEEDITER; iter = (int)m.iter; ip = (m.w & RM_IP) ? 1 : 0;
+      swap_next = false;
+      cblk = 0xFFFFFFFFu;  // the uniform cache is keyed by block only
+    }
+    if (m.w & RM_CONT) {  // doubling i+1 (WALNUTS.py:283-294)
+      i++;
+      xi = dir(prm, io, 0, i);
+      n_is = 0; nleaf = 1 << i;
+      st = ST_RUN;
+    }
+    const bool odd = (tn & 1u) != 0;
+    if (st == ST_NEEDITER) {
+      if (odd && (iter > prm.numIter || zready == iter)) {
+        const bool last = iter > prm.numIter;
+        c.op |= OP_NEWITER | (ip ? OP_IPNEW : 0u) | (last ? OP_LAST : 0u);
+        c.n = (uint32_t)(iter - 1);
+        if (last) st = ST_DEAD;
+        else {
+          i = 0;
+          xi = dir(prm, io, 0, 0);
+          n_is = 0; nleaf = 1;
+          st = ST_FIRST;
+        }
+      }
+    } else if (st == ST_FIRST) {  // the single leaf of doubling 0 (:296-369)
+      const double h = h_of(prm, io, (uint32_t)prm.M);
+      c.op |= OP_STEP;  // i = 0, n = 0
+      c.hs = (double)xi * h;
+      n_is = 1;
+      swap_next = (1 < prm.M) && dir(prm, io, 0, 1) != xi;
+      st = ST_DRAIN;
+    } else if (st == ST_RUN) {
+      bool go = true;
+      double h = 0.0;
+      if ((n_is & 1) == 0) {
+        if (odd) go = false;  // leaf pairs start on even ticks: all chains of a group check / store in step
+        else {
+          uint32_t kh = ku;
+          if (n_is > n_rt) {
+            if (certain) kh = first_issue_uniform();  // the multinomial draws of the leaves in flight are certain
+            else go = false;                          // not known yet: wait for them
+          }
+          if (go) { h = h_of(prm, io, kh); h2 = h_of(prm, io, kh + 1u); }        // :395
+        }
+      } else {
+        h = h2;
+      }
+      if (go) {
+        c.op |= OP_STEP | ((uint32_t)i << OP_I_SHIFT);
+        c.n = (uint32_t)n_is;
+        c.hs = (double)xi * h;
+        n_is++;
+        if (n_is == nleaf) {
+          swap_next = (i + 1 < prm.M) && dir(prm, io, 0, i + 1) != xi;
+          st = ST_DRAIN;
+        }
+      }
+    } else if (st == ST_DRAIN) {
+      if (swap_next) { c.op |= OP_SWAP; swap_next = false; }
+    }
+    c2step = c1step;
+    c1step = (c.op & OP_STEP) != 0;
     return c;
   }
-  WN_HD bool finished() const { return st == ST_DEAD && s0.kind == K_NONE && s1.kind == K_NONE && !pend_pick; }
+  WN_HD bool finished() const { return st == ST_DEAD && rdead; }
 };
 
 }  // namespace fast

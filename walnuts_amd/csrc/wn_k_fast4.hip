@@ -23,13 +23,15 @@
 // rows padding: they are done K-split (six MFMAs on the registers as they are, one block sum, one MFMA for columns
 // 96..99): 157 MFMAs per tick instead of 175.
 //
-// One tick of a pair (the protocol, commands and two-tick lag are wn_fast.h's):
+// One tick of a pair (the protocol and commands are wn_fast.h's, with its THREE-tick lag: FastBookT<3>):
 //   T wave                                                      B wave
-//   read command C[t]; pick / iteration start / end swap;       read the sums P[t-1]; FastBook::tick: retire tick t-1,
+//   read command C[t]; pick / iteration start / end swap;       read the sums P[t-2]; FastBook::tick: retire tick t-2,
 //   first half step; G = -A Q; second half step; sums P[t]      issue C[t+1]; momentum normals; uniform window
 //   of lp, KE and the U-turn dots due at this leaf; endpoint
 //   stores
-//   ----------------------------------- barrier (LDS only) ---------------------------------------------------------
+// Hand-off through two counters in LDS (ticks finished by T, commands issued by B); sums and commands are triple-buffered.  The
+// bookkeeper has two vector ticks for one of its own: on an ordinary leaf neither wave waits (with the two-tick lag of
+// wn_k_fast.hip every slow tick of either wave stalled the other: T waited 21 % of its time, B 10 %).
 #include "wn_launch.h"  // hip_runtime first
 
 #include <type_traits>
@@ -60,14 +62,18 @@ struct Fast4Geom {
   static constexpr int OFF_A = 0;
   static constexpr int P_LC = 0;                        // level-2 left endpoint: q, v
   static constexpr int P_STAGE = P_LC + 2 * VEC;        // this tick's position, from where the MFMAs' B operands are read block-replicated
-  static constexpr int P_SUMS = P_STAGE + VEC;          // 2 x [batch][block b][chain x]
-  static constexpr int P_CMD = P_SUMS + 2 * NB * 16;    // 2 x 4 commands of 2 doubles
-  static constexpr int P_USTAT = P_CMD + 16;            // uniform blocks 0..7 of the running iteration: [chain][8] x {tag, u0, u1}
+  static constexpr int P_PK = P_STAGE + VEC;            // the position of tick t-2, kept one more tick: a pick commanded at tick t+1 copies it
+  static constexpr int P_SUMS = P_PK + VEC;             // 3 x [batch][block b][chain x]  (tick t in slot t % 3)
+  static constexpr int P_CMD = P_SUMS + 3 * NB * 16;    // 4 x 4 commands of 2 doubles    (tick t in slot t & 3)
+  static constexpr int P_MSG = P_CMD + 32;              // 3 x 4 messages R -> I of 2 doubles (bookkeeper tick t in slot t % 3)
+  static constexpr int P_USTAT = P_MSG + 24;            // uniform blocks 0..7 of the running iteration: [chain][8] x {tag, u0, u1}
   static constexpr int P_URING = P_USTAT + 4 * 8 * 3;   // sliding window of 16 blocks: [chain][blk & 15] x {tag, u0, u1}
-  static constexpr int P_DSTAGE = P_URING + 4 * 16 * 3; // diagnostics rows on their way out: [chain][24]
-  static constexpr int P_SEQ = P_DSTAGE + 4 * NDIAG;    // hand-off words of the pair: ticks the T wave has finished, commands the B wave has issued
+  // hand-off words (32 bit): [0] ticks the T wave has finished, [2] commands the I wave has issued, [4] ticks the R wave has
+  // finished, [6] the run is over (the last two in the FIRST pair of a quad only)
+  static constexpr int P_SEQ = P_URING + 4 * 16 * 3;
   static constexpr int PAIR_DOUBLES = P_SEQ + 8;
   static constexpr int OFF_PAIR = NFR * 64;
+  static_assert(((size_t)OFF_PAIR + 4 * (size_t)PAIR_DOUBLES) * sizeof(double) <= 160 * 1024, "four pairs and the fragment image in one CU's LDS");
   __host__ __device__ static constexpr size_t lds_bytes(int pairs) { return ((size_t)OFF_PAIR + (size_t)pairs * PAIR_DOUBLES) * sizeof(double); }
   // workspace of one 4-chain group, in doubles: (M+1) slots x (q, v), 2 proposals, the passive orbit end (q, v), momentum normals [chain][DPAD]
   __host__ __device__ static constexpr size_t group_doubles(int M) { return (size_t)((M + 1) * 2 + 4) * VEC + (size_t)4 * DPAD; }
@@ -142,7 +148,33 @@ __device__ __forceinline__ double rows_sum(double x) {
 // ------------------------------------------------------------------------------------------------
 // the pair's hand-off: a word counts up in LDS; the partner polls it (LDS operations of one wave execute in order: data first, then
 // the word).  Bounded: a protocol error must not hang the GPU.
-__device__ __forceinline__ bool seq_wait(const volatile uint32_t* p, uint32_t want) {
+// The hand-off words are read and written through LDS-address-space pointers: through a generic `volatile uint32_t*` the compiler
+// emits FLAT loads with system scope, and every poll then waits for vmcnt(0) -- i.e. for every global store the wave still has in
+// flight (the endpoint stores of the tick before: a full store latency at the top of the next tick).
+typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+typedef __attribute__((address_space(3))) volatile uint64_t lds_vu64;
+typedef __attribute__((address_space(3))) volatile double lds_vf64;
+__device__ __forceinline__ lds_vu32* lds_words(const double* p) { return (lds_vu32*)p; }
+// A command record in LDS = {hs, op | n << 32}; bits 16..31 of op carry the tick it is for (CMD_TAG), so the T wave polls the record
+// itself -- one LDS round trip per tick instead of a counter and then the record.  The writer stores hs first, the reader reads it second
+// (LDS operations of a wave execute in order).
+enum { CMD_TAG_SHIFT = 16 };
+__device__ __forceinline__ void cmd_publish(double* rec, const Cmd& c, uint32_t tick) {
+  *(lds_vf64*)rec = c.hs;
+  *(lds_vu64*)(rec + 1) = (uint64_t)(c.op | ((tick & 0xFFFFu) << CMD_TAG_SHIFT)) | ((uint64_t)c.n << 32);
+}
+__device__ __forceinline__ bool cmd_poll(const double* rec, uint32_t tick, Cmd& c) {  // false: not within the bound
+  uint32_t spins = 0;
+  for (;;) {
+    const uint64_t w = *(const lds_vu64*)(rec + 1);
+    const double hs = *(const lds_vf64*)rec;
+    const bool ready = (((uint32_t)w >> CMD_TAG_SHIFT) & 0xFFFFu) == (tick & 0xFFFFu);
+    if (__all(ready)) { c.hs = hs; c.op = (uint32_t)w & 0xFFFFu; c.n = (uint32_t)(w >> 32); return true; }
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 23)) return false;
+  }
+}
+__device__ __forceinline__ bool seq_wait(const lds_vu32* p, uint32_t want) {
   uint32_t spins = 0;
   while ((int32_t)(*p - want) < 0) {
     __builtin_amdgcn_s_sleep(1);
@@ -169,13 +201,14 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
   const double* const znext = wbase + (size_t)((prm.M + 1) * 2 + 4) * G::VEC + (size_t)x * G::DPAD;
   double* const lc = pr + G::P_LC + lane;
   double* const stage = pr + G::P_STAGE;
+  double* const pk = pr + G::P_PK + lane;
   double* const sums = pr + G::P_SUMS;
-  const Cmd* const cmdbuf = reinterpret_cast<const Cmd*>(pr + G::P_CMD);
-  volatile uint32_t* const seq = reinterpret_cast<volatile uint32_t*>(pr + G::P_SEQ);  // [0]: ticks finished by T, [2]: commands issued by B
+  lds_vu32* const seq = lds_words(pr + G::P_SEQ);  // [0]: ticks finished by T
 
   // P(t) = the position after the drift of tick t lives in X[t & 1]: at the start of tick t, X[(t-1) & 1] is the current position and
-  // X[t & 1] still holds P(t-2), the source of a multinomial pick commanded now (wn_fast.h); the drift overwrites it with P(t), and
-  // P(t-1) stays for the level-1 check behind the gradient.  No copies.
+  // X[t & 1] still holds P(t-2); the drift overwrites it with P(t), and P(t-1) stays for the level-1 check behind the gradient.  No
+  // register copies.  A multinomial pick commanded at tick t copies P(t-3) (wn_fast.h, LAG = 3): P(t-2) goes to LDS at the top of every
+  // tick (`pk`) and is read from there one tick later.
   double X0[NS], X1[NS], v[NS], g[NS], VL[NS];
   double pq0[NS], pv0[NS], pq1[NS], pv1[NS];
 #pragma unroll
@@ -192,7 +225,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
   // One tick.  PAR = t & 1 is a compile-time constant (the loop below is unrolled by two): the bookkeeper starts leaf pairs on even
   // ticks, so a stepping chain's leaf index has the tick's parity -- sub-tree checks (odd leaves), their prefetches, iteration starts
   // (odd ticks) and endpoint stores (even leaves) each live in one of the two bodies only.  Returns false when the run is over.
-  auto tick = [&](auto par_tag, double (&qc)[NS], double (&qn)[NS], const uint32_t t) -> bool {
+  auto tick = [&](auto par_tag, double (&qc)[NS], double (&qn)[NS], const uint32_t t, const int t3) -> bool {  // t3 = t % 3
     constexpr int PAR = decltype(par_tag)::value;
     constexpr int NSR = G::NSR, NK = G::NK, NP = NSR / 2;
     typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -215,12 +248,13 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     Cmd c;
     if (t == 0) { c.hs = 0.0; c.op = inrange ? (OP_NEWITER | OP_INIT) : 0u; c.n = 0u; }
     else {
-      if (!seq_wait(seq + 2, t)) { if (lane == 0) atomicExch(abort_flag, 1); return false; }
-      c = cmdbuf[(t & 1u) * 4 + x];
+      WN4_STAMP(7);
+      if (!cmd_poll(pr + G::P_CMD + ((t & 3u) * 4 + x) * 2, t, c)) { if (lane == 0) atomicExch(abort_flag, 1); return false; }
+      WN4_STAMP(5);
     }
     const uint32_t op = c.op;
     if (__any((op & OP_DONE) != 0)) return false;
-    double* const sp = sums + (t & 1u) * (G::NB * 16);
+    double* const sp = sums + t3 * (G::NB * 16);
     const bool step = (op & OP_STEP) != 0;
     const int i = (int)((op >> OP_I_SHIFT) & 31u), n = (int)c.n;
     const int nchk = (PAR == 1 && step) ? nchecks(i, n) : 0;   // checks of levels >= 1 close at odd leaves
@@ -245,21 +279,23 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
           for (int s = 0; s < NS; ++s) { pq1[s] = sq[s * 16]; pv1[s] = sv[s * 16]; }
         }
       }
-      if (__any((op & OP_PICK) != 0)) {  // qn still holds the position of tick t-2
+      if (__any((op & OP_PICK) != 0)) {  // `pk` holds the position of tick t-3
         if (op & OP_PICK) {
           double* dst = gvec(vprop + ((op & OP_IPPICK) ? 1 : 0));
 #pragma unroll
-          for (int s = 0; s < NS; ++s) dst[s * 16] = qn[s];
+          for (int s = 0; s < NS; ++s) dst[s * 16] = pk[s * 64];
         }
       }
-      if (TRACE) { if (op & OP_UNDO) ntr -= 1; }  // the leaf in flight when the iteration ended
+      if (TRACE) { ntr -= ((op & OP_UNDO) ? 1 : 0) + ((op & OP_UNDO2) ? 1 : 0); }  // the leaves in flight when the iteration ended
     }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) pk[s * 64] = qn[s];  // P(t-2): a pick commanded at the next tick copies it (same wave: after the read above)
     // ---- first half of the leapfrog step (adaptiveIntegrators.py:51-52 with hs = xi*h; v stays forward-time) ----
     const double hs = step ? c.hs : 0.0, hs2 = 0.5 * hs;
 #pragma unroll
     for (int s = 0; s < NS; ++s) { v[s] = v[s] + hs2 * g[s]; qn[s] = qc[s] + hs * v[s]; }
     // iteration starts and end swaps replace the position this tick produces (qn; such ticks do not step: hs = 0).  qc is left alone: it
-    // is the position of tick t-1, which a pick commanded at tick t+1 copies (the last leaf of a doubling can be picked while the end swap
+    // is the position of tick t-1, which a pick commanded at tick t+2 copies (the last leaf of a doubling can be picked while the end swap
     // of the next doubling is already under way)
     if (anyrare) {
       if ((PAR == 1 || t == 0) && __any((op & OP_NEWITER) != 0)) {  // (iterations start on odd ticks; tick 0 loads q0)
@@ -431,6 +467,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
       }
     }
     if ((PAR == 1 || t == 0) && anyrare && __any((op & OP_NEWITER) != 0)) put4(sp + 16 * (G::NB - 1), keinit_part, gen_part, 0.0, 0.0);
+    if (lane == 0) seq[0] = t + 1u;  // the sums of tick t are in LDS (same wave, in order)
     WN4_STAMP(2);
     // ---- statePush (:431,518): only sub-tree left endpoints are ever read back; they are even leaves ----
     if (PAR == 0) {
@@ -451,72 +488,54 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
       }
     }
     WN4_STAMP(3);
-    if (lane == 0) seq[0] = t + 1u;  // the sums of tick t are in LDS (same wave, in order)
     WN4_STAMP(4);
 #if defined(WN_STAMPS)
     fst_[6] += 1;
 #endif
     return true;
   };
+  int t3 = 0;
   for (uint32_t t = 0;; t += 2) {
-    if (!tick(std::integral_constant<int, 0>{}, X1, X0, t)) break;
-    if (!tick(std::integral_constant<int, 1>{}, X0, X1, t + 1u)) break;
+    if (!tick(std::integral_constant<int, 0>{}, X1, X0, t, t3)) break;
+    t3 = t3 == 2 ? 0 : t3 + 1;
+    if (!tick(std::integral_constant<int, 1>{}, X0, X1, t + 1u, t3)) break;
+    t3 = t3 == 2 ? 0 : t3 + 1;
   }
   WN4_STAMP_OUT(prm)
 }
 
 // ------------------------------------------------------------------------------------------------
-// B wave: lane l serves chain x = l & 3 as replica l >> 2 (sixteen replicas run the identical scalar code on identical
-// inputs and stay bit-identical); replica j turns check level j's dots into its verdict bit
+// The bookkeeper: an R wave (RetireBook) and an I wave (IssueBook) per QUAD = two pairs (wn_fast.h).  Lane l serves chain slot
+// l & 7 (pair (l >> 2) & 1 of the quad, chain x = l & 3) as replica l >> 3: eight replicas run the identical scalar code on
+// identical inputs and stay bit-identical; in the R wave replica j turns check levels j and j + 8 into their verdict bits.
 // ------------------------------------------------------------------------------------------------
 template <class G, bool TRACE>
 struct Fast4IO {
   const Params* prm;
-  double* pr;
+  double* pr;  // the LDS region of this lane's pair
   int cl, x, rep;
   double lp, ke, keinit, gen;
   uint32_t fire;
   int ntrace;
-  // three consecutive entries of the uniform window (blocks p_b0 .. p_b0 + 2 of iteration p_iter), read with the tick's other LDS
-  // words and checked ONCE: the blocks an ordinary retirement + issue of this tick use.  A lookup is then a select by index.
-  // (scalar members: arrays in this struct sent it -- and the kernel's parameter block with it -- to scratch memory)
-  uint32_t p_iter, p_b0;
-  bool p_valid;
-  double p_u00, p_u01, p_u02, p_u10, p_u11, p_u12;
   __device__ __forceinline__ double sum(int k) const { return k == Q_LP ? lp : k == Q_KE ? ke : k == Q_KEINIT ? keinit : gen; }
   __device__ __forceinline__ uint32_t firemask(int, int, int) const { return fire; }
+  // a block of the chain's uniform stream from the window the I wave keeps in LDS (a miss: the caller runs Philox itself)
   __device__ __forceinline__ bool uniforms(int, int iter, uint32_t blk, double& ua, double& ub) const {
-    const uint32_t j = blk - p_b0;
-    // (single exit, select form: an early return here kept the whole bookkeeper in scratch memory)
-    bool hit = p_valid && p_iter == (uint32_t)iter && j < 3u;
-    // (the members are read into registers behind an opaque barrier: left alone, the compiler turns a select between two loaded
-    // members into a load from a selected ADDRESS, and a struct whose members' addresses are selected at run time stays in memory)
-    double a0 = p_u00, a1 = p_u01, a2 = p_u02, b0 = p_u10, b1 = p_u11, b2 = p_u12;
-    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2));
-    double va = j == 0u ? a0 : j == 1u ? a1 : a2, vb = j == 0u ? b0 : j == 1u ? b1 : b2;
-    if (!hit) {
-      const double* e = pr + (blk < 8u ? G::P_USTAT + (x * 8 + (int)blk) * 3 : G::P_URING + (x * 16 + (int)(blk & 15u)) * 3);
-      const uint32_t* tag = reinterpret_cast<const uint32_t*>(e);
-      va = e[1]; vb = e[2];
-      hit = tag[0] == (uint32_t)iter && tag[1] == blk;
-    }
-    ua = va; ub = vb;
-    return hit;
+    const double* e = pr + (blk < 8u ? G::P_USTAT + (x * 8 + (int)blk) * 3 : G::P_URING + (x * 16 + (int)(blk & 15u)) * 3);
+    const lds_vu32* tag = lds_words(e);
+    const uint32_t t0 = tag[0], t1 = tag[1];  // (the writer stores the values first, then the tag)
+    asm volatile("" ::: "memory");
+    ua = e[1]; ub = e[2];
+    return t0 == (uint32_t)iter && t1 == blk;
   }
   __device__ __forceinline__ void write_gen(size_t row, double v) const {
     if (rep == 0) prm->samples[((size_t)cl * (prm->numIter + 1) + row) * prm->dg + 1] = v;
   }
-  // one diagnostics row = 192 B: staged in LDS by replica 0, stored as twelve 16-byte pieces by replicas 0..11
-  __device__ __forceinline__ void write_diag(size_t row, const double* d) const {
-    double* st = pr + G::P_DSTAGE + x * NDIAG;
+  __device__ __forceinline__ void write_diag(size_t row, const double* d) const {  // once per chain and iteration
     if (rep == 0) {
+      double* o = prm->diag + ((size_t)cl * prm->numIter + row) * NDIAG;
 #pragma unroll
-      for (int k = 0; k < NDIAG; ++k) st[k] = d[k];
-    }
-    if (rep < 12) {
-      typedef double d2_t __attribute__((ext_vector_type(2)));
-      const d2_t v = *reinterpret_cast<const d2_t*>(st + 2 * rep);
-      *reinterpret_cast<d2_t*>(prm->diag + ((size_t)cl * prm->numIter + row) * NDIAG + 2 * rep) = v;
+      for (int k = 0; k < NDIAG; ++k) o[k] = d[k];
     }
   }
   __device__ __forceinline__ void trace_step(int iter, int i, int xi, double h, double ham0, double lpn) {
@@ -530,37 +549,129 @@ struct Fast4IO {
   }
 };
 
+// wait until *p >= want (every lane its own word) or the quad's run-is-over word is set; false: neither within the bound
+__device__ __forceinline__ bool seq_wait2(const lds_vu32* p, uint32_t want, const lds_vu32* over) {
+  uint32_t spins = 0;
+  while (__any((int32_t)(*p - want) < 0) && *over == 0u) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 23)) return false;
+  }
+  asm volatile("" ::: "memory");
+  return true;
+}
+
 template <class G, bool TRACE>
-__device__ __forceinline__ void fast4_b_wave(const Params& prm, double* pr, const int grp, int* abort_flag) {
-  const int lane = threadIdx.x & 63, x = lane & 3, rep = lane >> 2;
-  const int cl = grp * 4 + x;
-  const bool inrange = cl < prm.C;
-  Cmd* const cmdbuf = reinterpret_cast<Cmd*>(pr + G::P_CMD);
-  double* const znext = prm.work + (size_t)grp * G::group_doubles(prm.M) + (size_t)((prm.M + 1) * 2 + 4) * G::VEC;
-  volatile uint32_t* const seq = reinterpret_cast<volatile uint32_t*>(pr + G::P_SEQ);  // [0]: ticks finished by T, [2]: commands issued by B
-  FastBook bk;
+__device__ __forceinline__ void fast4_r_wave(const Params& prm, double* quad, const int grp0, const int npairs, int* abort_flag) {
+  const int lane = threadIdx.x & 63, c8 = lane & 7, pq = c8 >> 2, x = c8 & 3, rep = lane >> 3;
+  const int cl = (grp0 + pq) * 4 + x;
+  const bool inrange = pq < npairs && cl < prm.C;
+  double* const pr = quad + (size_t)(pq < npairs ? pq : 0) * G::PAIR_DOUBLES;  // (lanes without a pair look at pair 0 and do nothing)
+  const Cmd* const cmdbuf = reinterpret_cast<const Cmd*>(pr + G::P_CMD);
+  RMsg* const msgbuf = reinterpret_cast<RMsg*>(pr + G::P_MSG);
+  const lds_vu32* const seqT = lds_words(pr + G::P_SEQ);
+  lds_vu32* const seqQ = lds_words(quad + G::P_SEQ);  // [4]: R ticks finished, [6]: over
+  RetireBook bk;
   bk.init(prm.chain0 + (uint32_t)cl, inrange, prm.numIter);
   Fast4IO<G, TRACE> io;
   io.prm = &prm; io.pr = pr; io.cl = cl; io.x = x; io.rep = rep;
   io.lp = io.ke = io.keinit = io.gen = 0.0; io.fire = 0u; io.ntrace = 0;
-  io.p_iter = 0u; io.p_b0 = 0u; io.p_valid = false; io.p_u00 = io.p_u01 = io.p_u02 = io.p_u10 = io.p_u11 = io.p_u12 = 0.0;
+  WN4_STAMP_DECL
+  int t3 = 1;  // (t - 2) % 3: the slot of the sums this tick retires
+  for (uint32_t t = 0;; ++t, t3 = t3 == 2 ? 0 : t3 + 1) {
+    // ---- the T waves of the quad have finished tick t-2: its sums are in LDS ----
+    if (t > 1 && !seq_wait2(seqT, t - 1u, seqQ + 6)) { if (lane == 0) atomicExch(abort_flag, 1); break; }
+    if (seqQ[6] != 0u) break;
+#if defined(WN4_URGENT)
+    // the T waves run at priority 1.  They need command t+1 at the end of their tick t: once one of them is IN tick t the quad's
+    // bookkeeper goes ahead of them (priority 2), before that it takes the issue slots they leave (priority 0)
+    if (__any((int32_t)(*seqT - t) >= 0)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#endif
+#if defined(WN4_TONLY)  // diagnostic: nothing is retired
+    if (lane == 0) seqQ[4] = t + 1u;
+    continue;
+#endif
+    WN4_STAMP(5);
+    Cmd c;
+    c.hs = 0.0; c.op = 0u; c.n = 0u;
+    if (t > 1 && inrange) { c = cmdbuf[((t - 2u) & 3u) * 4 + x]; c.op &= 0xFFFFu; }  // what the T wave did in that tick (without the record's tick tag)
+    const double* sp = pr + G::P_SUMS + t3 * (G::NB * 16);
+    const bool retiring = bk.retires_step(c);
+    const int cn = (int)c.n;
+    const bool haschk = retiring && ((cn & 1) != 0 || cn == (1 << bk.i) - 1);  // odd leaves close sub-trees, the last leaf the orbit
+    const unsigned long long vote = __ballot(haschk) | (__ballot((c.op & OP_NEWITER) != 0) ? 1ull << 63 : 0ull);  // (one branch for both)
+    io.lp = sp[x]; io.ke = sp[4 + x];
+    io.fire = 0u;
+    if (vote) {
+      if (vote >> 63) { io.keinit = sp[16 * (G::NB - 1) + x]; io.gen = sp[16 * (G::NB - 1) + 4 + x]; }
+      if (vote << 1) {  // verdict of check level j (wn_fast.h fire_of) by replica j & 7, then OR over the replicas of the chain
+        uint32_t f = 0u;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const int j = rep + 8 * pass;
+          const int jl = j <= G::MP ? j : G::MP;
+          const double* dp = sp + (jl == 0 ? 8 : 16 * ((jl + 1) >> 1) + ((jl & 1) ? 0 : 8)) + x;
+          const double d1 = dp[0], d2 = dp[4];
+          if (retiring && j <= G::MP && need_check(bk.i, cn, j)) {
+            const double xi = (double)bk.xi;
+            if ((xi * d1 < 0.0) || (xi * d2 < 0.0)) f |= 1u << j;
+          }
+        }
+        f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x128, 0xF, 0xF, false);  // row_ror:8: lanes l and l ^ 8
+        typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+        u2_t w = __builtin_amdgcn_permlane16_swap(f, f, false, false);
+        f = w[0] | w[1];
+        w = __builtin_amdgcn_permlane32_swap(f, f, false, false);
+        io.fire = w[0] | w[1];
+      }
+    }
+    WN4_STAMP(1);
+    const RMsg m = bk.tick(prm, io, c);
+    WN4_STAMP(2);
+    if (rep == 0 && pq < npairs) msgbuf[t3 == 0 ? 2 * 4 + x : (t3 - 1) * 4 + x] = m;  // slot t % 3 = (t3 + 2) % 3
+    if (lane == 0) seqQ[4] = t + 1u;  // message t is in LDS (same wave, in order)
+    WN4_STAMP(3);
+#if defined(WN_STAMPS)
+    fst_[6] += 1;
+#endif
+  }
+  WN4_STAMP_OUT(prm)
+  if (TRACE && prm.trace_n && inrange && rep == 0) prm.trace_n[cl] = io.ntrace;
+}
+
+template <class G, bool TRACE>
+__device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, const int grp0, const int npairs, int* abort_flag) {
+  const int lane = threadIdx.x & 63, c8 = lane & 7, pq = c8 >> 2, x = c8 & 3, rep = lane >> 3;
+  const int cl = (grp0 + pq) * 4 + x;
+  const bool inrange = pq < npairs && cl < prm.C;
+  double* const pr = quad + (size_t)(pq < npairs ? pq : 0) * G::PAIR_DOUBLES;
+  const RMsg* const msgbuf = reinterpret_cast<const RMsg*>(pr + G::P_MSG);
+  lds_vu32* const seqQ = lds_words(quad + G::P_SEQ);    // [4]: R ticks finished, [6]: over
+  IssueBook bk;
+  bk.init(prm.chain0 + (uint32_t)cl, inrange, prm.numIter);
+  Fast4IO<G, TRACE> io;
+  io.prm = &prm; io.pr = pr; io.cl = cl; io.x = x; io.rep = rep;
+  io.lp = io.ke = io.keinit = io.gen = 0.0; io.fire = 0u; io.ntrace = 0;
   int witer = 0;          // iteration and first block of the uniform window
   uint32_t wbase = 0u;
-  // every chain needs at most numIter * (2^M - 1 + 2 idle ticks per doubling + start) ticks; twice that is an internal error
-  const double cap = 256.0 + 2.0 * (double)prm.numIter * ((double)(1u << prm.M) + 4.0 * (double)prm.M + 16.0);
-
+  // every chain needs at most numIter * (2^M - 1 + idle ticks per doubling + start) ticks; twice that is an internal error
+  const double cap = 256.0 + 2.0 * (double)prm.numIter * ((double)(1u << prm.M) + 6.0 * (double)prm.M + 16.0);
   WN4_STAMP_DECL
-  for (uint32_t t = 0;; ++t) {
-#if defined(WN4_NOB)  // diagnostic (with WN4_TONLY): the bookkeeper waves only write the fixed command
+  int t3 = 0;  // t % 3
+  for (uint32_t t = 0;; ++t, t3 = t3 == 2 ? 0 : t3 + 1) {
+#if defined(WN4_TONLY)  // diagnostic: the T waves alone, on a fixed stream of ordinary leaves
     {
       Cmd c;
+#if defined(WN4_TONLY_MIS)  // ... with the four chains of a wave at different places of their orbits (as in a real run)
+      c.hs = 1.0e-4; c.op = OP_STEP | (10u << OP_I_SHIFT); c.n = (t + 26u * (uint32_t)x + 14u * (uint32_t)pq) & 1023u;
+#else
       c.hs = 1.0e-4; c.op = OP_STEP | (10u << OP_I_SHIFT); c.n = t & 1023u;
+#endif
       const bool done = t >= (uint32_t)(WN4_TONLY);
-      if (done) c.op |= OP_DONE;
-      if (t > 0 && !seq_wait(seq, t)) break;
-      if (rep == 0) cmdbuf[((t + 1u) & 1u) * 4 + x] = c;
-      if (lane == 0) seq[2] = t + 1u;
+      if (done) { c.op |= OP_DONE; if (lane == 0) seqQ[6] = 1u; }
+      if (rep == 0 && pq < npairs) cmd_publish(pr + G::P_CMD + (((t + 1u) & 3u) * 4 + x) * 2, c, t + 1u);
       if (done) break;
+      const lds_vu32* sT = lds_words(pr + G::P_SEQ);
+      if (t > 1 && !seq_wait2(sT, t - 1u, seqQ + 6)) break;
       continue;
     }
 #endif
@@ -569,14 +680,15 @@ __device__ __forceinline__ void fast4_b_wave(const Params& prm, double* pr, cons
     // (ONE vote per tick for the three things that are rarely due: momentum normals, a window refill, the end of the run)
     const bool zw = bk.zwant != bk.zready && bk.zwant >= 1;
     const bool fresh = bk.iter != witer;
-    const bool need = inrange && bk.iter <= prm.numIter && (fresh || (bk.ku >> 1) + 4u > wbase + 15u);
-    const bool anyrare = __any(zw || need || bk.st == FastBook::ST_DEAD);
+    const bool need = inrange && bk.iter <= prm.numIter && (fresh || (bk.ku >> 1) + 6u > wbase + 15u);
+    const bool anyrare = __any(zw || need || bk.st == IssueBook::ST_DEAD);
     if (anyrare) {
       const unsigned long long want = __ballot(rep == 0 && zw);
       if (want) {
-        const int cs = __builtin_ctzll(want);  // lanes 0..3 are chains 0..3
+        const int cs = __builtin_ctzll(want);  // lanes 0..7 are chain slots 0..7
         const int it = __shfl(bk.zwant, cs);
         const uint32_t ch = (uint32_t)__shfl((int)bk.chain, cs);
+        double* const znext = prm.work + (size_t)(grp0 + (cs >> 2)) * G::group_doubles(prm.M) + (size_t)((prm.M + 1) * 2 + 4) * G::VEC + (size_t)(cs & 3) * G::DPAD;
         {
           Philox4 p = philox4x32_10((uint32_t)lane, (uint32_t)it, ch, 1u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
           const uint64_t x0 = ((uint64_t)p.w[1] << 32) | p.w[0];
@@ -588,113 +700,58 @@ __device__ __forceinline__ void fast4_b_wave(const Params& prm, double* pr, cons
           d2_t z;
           z[0] = (2 * lane < prm.D) ? rr * cos(th) : 0.0;
           z[1] = (2 * lane + 1 < prm.D) ? rr * sin(th) : 0.0;
-          *reinterpret_cast<d2_t*>(znext + (size_t)cs * G::DPAD + 2 * lane) = z;
+          *reinterpret_cast<d2_t*>(znext + 2 * lane) = z;
         }
-        if (x == cs) bk.zready = it;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // visible to the T wave behind the barrier
+        if (c8 == cs) bk.zready = it;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // visible to the T wave before the command that reads it is
       }
-    }
-    // ---- the window of uniforms (wn_rng.h stream 0): when a chain starts an iteration or nears the end of its sliding
-    // window, ONE Philox pass makes sixteen blocks for each of the four chains (lane = chain x, block base + replica).
-    // Blocks 0..7 of the iteration stay (the direction bits of WALNUTS.py:216 are read until the last doubling).
-    if (anyrare) {
+      // ---- the window of uniforms (wn_rng.h stream 0): when a chain starts an iteration or nears the end of its sliding
+      // window, two Philox passes make sixteen blocks for each of the eight chains (lane = chain slot, block base + replica,
+      // + 8).  Blocks 0..7 of the iteration stay (the direction bits of WALNUTS.py:216 are read until the last doubling).
       if (__any(need)) {
         const uint32_t nb = fresh ? 0u : (bk.ku >> 1);
-        const uint32_t blk = nb + (uint32_t)rep;
-        const Philox4 p = philox4x32_10(blk, (uint32_t)bk.iter, bk.chain, 0u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
-        const double u0 = u53(p.w[0], p.w[1]), u1 = u53(p.w[2], p.w[3]);
-        double* e = pr + G::P_URING + (x * 16 + (int)(blk & 15u)) * 3;
-        reinterpret_cast<uint32_t*>(e)[0] = (uint32_t)bk.iter; reinterpret_cast<uint32_t*>(e)[1] = blk;
-        e[1] = u0; e[2] = u1;
-        if (blk < 8u) {
-          double* es = pr + G::P_USTAT + (x * 8 + (int)blk) * 3;
-          reinterpret_cast<uint32_t*>(es)[0] = (uint32_t)bk.iter; reinterpret_cast<uint32_t*>(es)[1] = blk;
-          es[1] = u0; es[2] = u1;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const uint32_t blk = nb + (uint32_t)(rep + 8 * pass);
+          const Philox4 p = philox4x32_10(blk, (uint32_t)bk.iter, bk.chain, 0u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
+          const double u0 = u53(p.w[0], p.w[1]), u1 = u53(p.w[2], p.w[3]);
+          if (need) {
+            double* e = pr + G::P_URING + (x * 16 + (int)(blk & 15u)) * 3;
+            e[1] = u0; e[2] = u1;
+            asm volatile("" ::: "memory");  // values first, then the tag (the R wave reads the tag first)
+            lds_words(e)[0] = (uint32_t)bk.iter; lds_words(e)[1] = blk;
+            if (blk < 8u) {
+              double* es = pr + G::P_USTAT + (x * 8 + (int)blk) * 3;
+              es[1] = u0; es[2] = u1;
+              asm volatile("" ::: "memory");
+              lds_words(es)[0] = (uint32_t)bk.iter; lds_words(es)[1] = blk;
+            }
+          }
         }
-        witer = bk.iter; wbase = nb;
+        if (need) { witer = bk.iter; wbase = nb; }
       }
     }
     WN4_STAMP(0);
-    // ---- the T wave has finished tick t-1: its sums are in LDS ----
-    if (t > 0 && !seq_wait(seq, t)) { if (lane == 0) atomicExch(abort_flag, 1); break; }
+    // ---- the R wave has finished its tick t: its messages are in LDS ----
+    if (!seq_wait2(seqQ + 4, t + 1u, seqQ + 6)) { if (lane == 0) atomicExch(abort_flag, 1); break; }
     WN4_STAMP(5);
-    // ---- the LDS words of this tick, requested together: the lp / KE sums of tick t-1 (at t = 0: the zeroed other half), three
-    // entries of the uniform window; the U-turn dots and the iteration-start sums only on the ticks that retire something that has them
-    const double* sp = pr + G::P_SUMS + ((t + 1u) & 1u) * (G::NB * 16);
-    const bool retiring = bk.s0.kind == FastBook::K_STEP && !bk.s0.discard;
-    const bool haschk = retiring && ((bk.s0.n & 1) != 0 || bk.s0.n == (1 << bk.i) - 1);  // odd leaves close sub-trees, the last leaf the orbit
-    const unsigned long long vote = __ballot(haschk) | (__ballot(bk.s0.kind == FastBook::K_NEWITER) ? 1ull << 63 : 0ull);  // (one branch for both)
-    const double s_lp = sp[x], s_ke = sp[4 + x];
-    {
-      const uint32_t b0 = bk.fast_first_uniform() >> 1;
-      const double* e0 = pr + G::P_URING + (x * 16 + (int)(b0 & 15u)) * 3;
-      const double* e1 = pr + G::P_URING + (x * 16 + (int)((b0 + 1u) & 15u)) * 3;
-      const double* e2 = pr + G::P_URING + (x * 16 + (int)((b0 + 2u) & 15u)) * 3;
-      const uint32_t it0 = reinterpret_cast<const uint32_t*>(e0)[0], bl0 = reinterpret_cast<const uint32_t*>(e0)[1];
-      const uint32_t it1 = reinterpret_cast<const uint32_t*>(e1)[0], bl1 = reinterpret_cast<const uint32_t*>(e1)[1];
-      const uint32_t it2 = reinterpret_cast<const uint32_t*>(e2)[0], bl2 = reinterpret_cast<const uint32_t*>(e2)[1];
-      io.p_u00 = e0[1]; io.p_u10 = e0[2]; io.p_u01 = e1[1]; io.p_u11 = e1[2]; io.p_u02 = e2[1]; io.p_u12 = e2[2];
-      const uint32_t it = (uint32_t)bk.iter;
-      io.p_iter = it; io.p_b0 = b0;
-      io.p_valid = it0 == it && it1 == it && it2 == it && bl0 == b0 && bl1 == b0 + 1u && bl2 == b0 + 2u;
-    }
-    io.lp = s_lp; io.ke = s_ke;
-    io.fire = 0u;
-    if (vote) {
-      if (vote >> 63) { io.keinit = sp[16 * (G::NB - 1) + x]; io.gen = sp[16 * (G::NB - 1) + 4 + x]; }
-      if (vote << 1) {  // verdict of check level j = replica index (wn_fast.h fire_of), then OR over the replicas of the chain
-        const int jl = rep <= G::MP ? rep : G::MP;
-        const double* dp = sp + (jl == 0 ? 8 : 16 * ((jl + 1) >> 1) + ((jl & 1) ? 0 : 8)) + x;
-        const double d1 = dp[0], d2 = dp[4];
-        uint32_t f = 0u;
-        if (retiring && rep <= G::MP && need_check(bk.i, bk.s0.n, rep)) {
-          const double xi = (double)bk.xi;
-          if ((xi * d1 < 0.0) || (xi * d2 < 0.0)) f = 1u << rep;
-        }
-        f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x124, 0xF, 0xF, false);  // row_ror:4
-        f |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, 0x128, 0xF, 0xF, false);  // row_ror:8
-        typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-        u2_t w = __builtin_amdgcn_permlane16_swap(f, f, false, false);
-        f = w[0] | w[1];
-        w = __builtin_amdgcn_permlane32_swap(f, f, false, false);
-        io.fire = w[0] | w[1];
-      }
-    }
+#if defined(WN4_URGENT)
+    if (__any((int32_t)(*lds_words(pr + G::P_SEQ) - t) >= 0)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#endif
+    RMsg m;
+    m.ku = 0u; m.w = RM_DEAD; m.iter = 1u; m.zwant = 0u;  // (lanes without a pair: nothing to do, finished)
+    if (pq < npairs) m = msgbuf[t3 * 4 + x];
     WN4_STAMP(1);
-#if defined(WN4_TONLY)  // diagnostic: the T waves alone, on a fixed stream of ordinary leaves
-    Cmd c;
-    c.hs = 1.0e-4; c.op = OP_STEP | (10u << OP_I_SHIFT); c.n = t & 1023u;
-    bool done = t >= (uint32_t)(WN4_TONLY);
-#else
-    // the ordinary leaf (wn_fast.h, fast_prepare / fast_commit): straight-line when every chain of the wave is there
-    Cmd c;
-#if defined(WN4_FASTPATH)  // (pays only once the pairs of a workgroup stop sharing a barrier: with four pairs in lockstep a tick is as
-                           // slow as its slowest bookkeeper, and all four are on the fast path on 27 % of the ticks: measured 8.6e8 vs 9.9e8)
-    FastBook::Fast ff;
-    bk.retire_pre(prm, io);  // (tick() = retire_pre() + tick_post(): the leaf's energy / weight arithmetic is common to both paths)
-    const bool ordinary = bk.fast_prepare(prm, io, t + 1u, ff);
-    if (__builtin_expect(__all(ordinary), 1)) {
-      c = bk.fast_commit(prm, io, ff);
-#if defined(WN_STAMPS)
-      fst_[7] += 1;
-#endif
-    } else {
-      c = bk.tick_post(prm, io, t + 1u);
-    }
-#else
-    c = bk.tick(prm, io, t + 1u);
-#endif
+    Cmd c = bk.tick(prm, io, t + 1u, m);
     WN4_STAMP(2);
-    // ---- every chain of the pair has finished: both waves leave (the pairs of a workgroup do not wait for each other) ----
+    // ---- every chain of the quad has finished: all its waves leave (the quads of a workgroup do not wait for each other) ----
     bool done = anyrare && __all(bk.finished());  // (finished() needs ST_DEAD, which was part of this tick's one vote, or shows at the next)
     if ((double)t > cap) {  // cannot happen; never hang the GPU
       if (lane == 0) atomicExch(abort_flag, 1);
       done = true;
     }
-#endif
-    if (done) c.op |= OP_DONE;
-    if (rep == 0) cmdbuf[((t + 1u) & 1u) * 4 + x] = c;
-    if (lane == 0) seq[2] = t + 1u;  // command t+1 is in LDS (same wave, in order)
+    if (done) { c.op |= OP_DONE; if (lane == 0) seqQ[6] = 1u; }
+    if (rep == 0 && pq < npairs) cmd_publish(pr + G::P_CMD + (((t + 1u) & 3u) * 4 + x) * 2, c, t + 1u);
     WN4_STAMP(3);
 #if defined(WN_STAMPS)
     fst_[6] += 1;
@@ -702,7 +759,6 @@ __device__ __forceinline__ void fast4_b_wave(const Params& prm, double* pr, cons
     if (done) break;
   }
   WN4_STAMP_OUT(prm)
-  if (TRACE && prm.trace_n && inrange && rep == 0) prm.trace_n[cl] = io.ntrace;
 }
 
 template <int NS, bool TAIL, bool TRACE>
@@ -729,28 +785,44 @@ __global__ __launch_bounds__(512) void wn_fast4_kernel(Params prm, int* abort_fl
   // LDS keeps what the previous kernel on this CU left there: every control area starts from zero
   for (int idx = threadIdx.x; idx < pairs * G::PAIR_DOUBLES; idx += blockDim.x) lds[G::OFF_PAIR + idx] = 0.0;
   __syncthreads();
+  // tick 0 is not commanded by anybody: every chain loads q0 (the R wave reads the record when it retires the tick)
+  for (int idx = threadIdx.x; idx < pairs * 4; idx += blockDim.x) {
+    Cmd* c0 = reinterpret_cast<Cmd*>(lds + G::OFF_PAIR + (size_t)(idx >> 2) * G::PAIR_DOUBLES + G::P_CMD) + (idx & 3);
+    const bool in = (blockIdx.x * pairs + (idx >> 2)) * 4 + (idx & 3) < prm.C;
+    c0->hs = 0.0; c0->op = in ? (OP_NEWITER | OP_INIT) : 0u; c0->n = 0u;
+  }
+  __syncthreads();
+  // Waves: quads = ceil(pairs / 2) bookkeeper pairs (R, I) first, then the T waves.  With four pairs: R0 I0 R1 I1 T0 T1 T2 T3, and waves
+  // w, w + 4 share a SIMD (speed only): every SIMD runs one T wave and one half of a bookkeeper, which serves the quad's two T waves.
+  // The bookkeeper waves are the OLDER waves of their SIMDs: the SIMD issues the oldest ready wave first, and a bookkeeper behind a
+  // T wave got a vector instruction in only when the T wave stalled.
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int pair = wave < pairs ? wave : wave - pairs;  // waves w and w + 4 share a SIMD (speed only)
-  double* pr = lds + G::OFF_PAIR + (size_t)pair * G::PAIR_DOUBLES;
-  const int grp = blockIdx.x * pairs + pair;
-  // The bookkeepers are the OLDER waves of their SIMDs (waves 0 .. pairs-1): the SIMD issues the oldest ready wave first, and a
-  // bookkeeper behind a T wave got a vector instruction in only when the T wave stalled -- the two ran one after the other (8.2 k
-  // cycles per tick; measured 1.08e9 -> 1.24e9 steps/s with the order swapped, s_setprio for the bookkeeper gives the same).
-#if defined(WN4_TFIRST)
+  const int quads = (pairs + 1) >> 1;
+#if defined(WN4_TFIRST)  // diagnostic: the T waves are the older ones
   const bool is_t = wave < pairs;
+  const int tw = wave, bw = wave - pairs;
 #else
-  const bool is_t = wave >= pairs;
+  const bool is_t = wave >= 2 * quads;
+  const int tw = wave - 2 * quads, bw = wave;
 #endif
   if (is_t) {
-#if defined(WN4_TPRIO)
-    __builtin_amdgcn_s_setprio(WN4_TPRIO);
+    // the T waves go first: the bookkeeper waves have half a tick of slack and take the issue slots a T wave leaves (measured: T waves
+    // at priority 1 1.32e9 steps/s, equal priorities with the bookkeepers as the older waves 1.27e9)
+#if !defined(WN4_TPRIO)
+#define WN4_TPRIO 1
 #endif
-    fast4_t_wave<G, TRACE>(prm, lds, pr, grp, abort_flag);
+    __builtin_amdgcn_s_setprio(WN4_TPRIO);
+    double* pr = lds + G::OFF_PAIR + (size_t)tw * G::PAIR_DOUBLES;
+    fast4_t_wave<G, TRACE>(prm, lds, pr, (int)blockIdx.x * pairs + tw, abort_flag);
   } else {
 #if defined(WN4_BPRIO)
     __builtin_amdgcn_s_setprio(WN4_BPRIO);
 #endif
-    fast4_b_wave<G, TRACE>(prm, pr, grp, abort_flag);
+    const int quad = bw >> 1;
+    double* qd = lds + G::OFF_PAIR + (size_t)(2 * quad) * G::PAIR_DOUBLES;
+    const int np = pairs - 2 * quad >= 2 ? 2 : 1;
+    if (bw & 1) fast4_i_wave<G, TRACE>(prm, qd, (int)blockIdx.x * pairs + 2 * quad, np, abort_flag);
+    else fast4_r_wave<G, TRACE>(prm, qd, (int)blockIdx.x * pairs + 2 * quad, np, abort_flag);
   }
 }
 
@@ -770,7 +842,7 @@ template <int NS, bool TAIL>
 static hipError_t fast4_go(const Params& prm, int* abort_flag, hipStream_t st) {
   using G = Fast4Geom<NS, TAIL>;
   const int pairs = fast4_pairs(prm.C), groups = (prm.C + 3) / 4;
-  dim3 grid((groups + pairs - 1) / pairs), block(128 * pairs);
+  dim3 grid((groups + pairs - 1) / pairs), block(64 * (pairs + 2 * ((pairs + 1) / 2)));
   const size_t shm = G::lds_bytes(pairs);
   hipError_t r;
   if (prm.trace_n) {
