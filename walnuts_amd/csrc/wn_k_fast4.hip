@@ -1,37 +1,40 @@
-// wn_k_fast4.hip -- the headline path, fixedLeapFrog on a dense Gaussian with D <= 100 (BASELINE configs[1]), as
-// wave PAIRS: one T wave owns ALL coordinates of a group of FOUR chains, one B wave (the bookkeeper of wn_fast.h)
-// owns those chains' scalars.  A workgroup holds 1, 2 or 4 pairs (16 chains per CU at 4096 chains, 4 at 1024).
+// wn_k_fast4.hip -- the headline path, fixedLeapFrog on a dense Gaussian with D <= 100 (BASELINE configs[1]): one T wave owns
+// ALL coordinates of a group of FOUR chains (a "pair": the name is from the first form, one bookkeeper wave per T wave); the
+// chains' scalars (wn_fast.h) are kept by a RETIRE wave and an ISSUE wave per QUAD = two T waves.  A workgroup holds 1, 2 or 4
+// T waves (16 chains per CU at 4096 chains, 4 at 1024): [R I] T, [R I] T T, or [R I R I] T T T T -- every SIMD then runs one T wave
+// and one half of a bookkeeper.
 //
 // Why four chains per wave.  wn_k_fast.hip spreads a 16-chain group over seven T waves (one 16-row tile each): every
 // tick they exchange the positions through LDS, sum their partial dot products through LDS and a service wave, and
 // meet at two barriers -- ~4.5 k of a tick's 7.7 k cycles.  v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks,
 // 16 cycles: the same flop per cycle as 16x16x4, tools/mfma_f64_4x4_probe.hip) makes a 4-chain group small enough
 // for ONE wave: 7 doubles per lane and vector.  Nothing crosses waves any more: no position exchange, every dot
-// product is complete inside the wave, one barrier per tick (the T / B hand-off), and the -A fragments stream from
-// one LDS image shared by the workgroup's T waves.
+// product is complete inside the wave, no barrier in the tick, and the -A fragments stream from one LDS image shared by
+// the workgroup's T waves.
 //
 // Lane l = 16 r + 4 b + x.  Measured operand layout of the instruction (probe): A[block b][i][k] sits in lane
 // 16 k + 4 b + i, B[b][k][j] in lane 16 k + 4 b + j, D[b][i][j] in lane 16 i + 4 b + j.  Register s of a vector holds
 // coordinate 16 s + 4 b + r of chain x -- the D layout of the 16-row set s when block b computes rows 16 s + 4 b ..
 // + 3.  So the ROWS of a set are split over the blocks and every block needs the same four coordinates of Q as its B
-// operand: k-step kappa (coordinates 4 kappa .. 4 kappa + 3) is block kappa & 3 of register kappa >> 2, broadcast to
-// the other blocks with two DPP moves per half -- work that depends on Q only and issues in the shadow of the
-// MFMAs.  G comes out complete and where Q lives: nothing is reduced across lanes on the dependent path.  (The first
-// form of this kernel split K over the blocks instead: no broadcasts, but a 15-instruction reduce-scatter with three
-// FP64 additions behind every 24 MFMAs -- measured 3.5 k cycles for the 157 MFMAs of a tick, whose pipe time is 2.5 k;
-// FP64 vector instructions wait for the FP64 matrix pipe.)  For D = 100 rows 96..99 would be a seventh set with 12 of 16
-// rows padding: they are done K-split (six MFMAs on the registers as they are, one block sum, one MFMA for columns
-// 96..99): 157 MFMAs per tick instead of 175.
+// operand: k-step kappa (coordinates 4 kappa .. 4 kappa + 3) is block kappa & 3 of register kappa >> 2, read back
+// block-replicated from a copy of the position in LDS.  G comes out complete and where Q lives: nothing is reduced across
+// lanes on the dependent path.  (The first form of this kernel split K over the blocks instead: no replication, but a
+// 15-instruction reduce-scatter with three FP64 additions behind every 24 MFMAs -- measured 3.5 k cycles for the 157 MFMAs of
+// a tick, whose pipe time is 2.5 k; FP64 vector instructions wait for the FP64 matrix pipe.)  For D = 100 rows 96..99 would be
+// a seventh set with 12 of 16 rows padding: they are done K-split (six MFMAs on the registers as they are, one block sum, one
+// MFMA for columns 96..99): 157 MFMAs per tick instead of 175.
 //
-// One tick of a pair (the protocol and commands are wn_fast.h's, with its THREE-tick lag: FastBookT<3>):
-//   T wave                                                      B wave
-//   read command C[t]; pick / iteration start / end swap;       read the sums P[t-2]; FastBook::tick: retire tick t-2,
-//   first half step; G = -A Q; second half step; sums P[t]      issue C[t+1]; momentum normals; uniform window
-//   of lp, KE and the U-turn dots due at this leaf; endpoint
-//   stores
-// Hand-off through two counters in LDS (ticks finished by T, commands issued by B); sums and commands are triple-buffered.  The
-// bookkeeper has two vector ticks for one of its own: on an ordinary leaf neither wave waits (with the two-tick lag of
-// wn_k_fast.hip every slow tick of either wave stalled the other: T waited 21 % of its time, B 10 %).
+// One tick (the protocol and commands are wn_fast.h's, THREE-tick lag: RetireBook / IssueBook = FastBookT<3> in two streams):
+//   T wave (tick t)                          R wave (tick t)                          I wave (tick t)
+//   poll command record C[t]; pick /         wait for T's tick t-2; read C[t-2]       momentum normals, uniform window;
+//   iteration start / end swap; first        and the sums P[t-2]; U-turn verdicts;    wait for R's tick t; read its messages;
+//   half step; G = -A Q; second half step;   RetireBook::tick; message to I           IssueBook::tick; publish C[t+1]; touch the
+//   sums P[t] of lp, KE and the U-turn                                                lines T will fetch in tick t+1
+//   dots due at this leaf; endpoint stores
+// Hand-off through counters in LDS and the tick tag inside the command record; sums / messages triple-, commands
+// quadruple-buffered.  The bookkeeper has two vector ticks for one of its own, and the T waves run at a higher priority: on an
+// ordinary leaf the T wave does not wait (with the two-tick lag of wn_k_fast.hip every slow tick of either side stalled the
+// other: T waited 21 % of its time, the bookkeeper 10 %).
 #include "wn_launch.h"  // hip_runtime first
 
 #include <type_traits>
@@ -78,8 +81,6 @@ struct Fast4Geom {
   // workspace of one 4-chain group, in doubles: (M+1) slots x (q, v), 2 proposals, the passive orbit end (q, v), momentum normals [chain][DPAD]
   __host__ __device__ static constexpr size_t group_doubles(int M) { return (size_t)((M + 1) * 2 + 4) * VEC + (size_t)4 * DPAD; }
 };
-
-#define WN4_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // diagnostic builds (tools/build_variant.sh stamps -DWN_STAMPS): cycles per segment of the tick, summed per wave
 #if defined(WN_STAMPS)
@@ -362,9 +363,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     {
       const double* const st0 = stage + 16 * r + x;  // + s * 64 + 4 * b'
       double accx = 0.0, gx = 0.0;
-      double acc[NSR];
-#pragma unroll
-      for (int S = 0; S < NSR; ++S) acc[S] = 0.0;
+      double acc[NSR];  // (set by the first k-step, whose accumulator operand is the literal 0: no register zeroing)
       double qks[3];  // the B operands of three k-steps in flight / in use
 #pragma unroll
       for (int k0 = 0; k0 < 2; ++k0) if (k0 < NK) qks[k0] = st0[(k0 >> 2) * 64 + 4 * (k0 & 3)];
@@ -375,9 +374,9 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
         const double qk = qks[kap % 3];
         const d2_t* f = fa[kap & 3];
 #pragma unroll
-        for (int S = 0; S < NSR; ++S) acc[S] = mfma4(f[S >> 1][S & 1], qk, acc[S]);
+        for (int S = 0; S < NSR; ++S) acc[S] = kap == 0 ? mfma4(f[S >> 1][S & 1], qk, 0.0) : mfma4(f[S >> 1][S & 1], qk, acc[S]);
         if (G::TAIL) {
-          if (kap < NS - 1) accx = mfma4(fx[kap >> 1][kap & 1], qn[kap], accx);
+          if (kap < NS - 1) accx = kap == 0 ? mfma4(fx[0][0], qn[0], 0.0) : mfma4(fx[kap >> 1][kap & 1], qn[kap], accx);
           if (kap == NS + 1) gx = blocks_sum(accx);          // (two k-steps behind its last MFMA)
           if (kap == NK - 1) gx = mfma4(ftail, qk, gx);      // columns 16 (NS-1) .. + 3
         }
@@ -392,7 +391,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     const bool anyl0 = __any(l0due);
     double cq[NS], cv[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) { cq[s] = 0.0; cv[s] = 0.0; }
+    for (int s = 0; s < NS; ++s) asm volatile("" : "=v"(cq[s]), "=v"(cv[s]));  // (whatever the registers hold: the level-0 sums of a chain that is not at its last leaf are never read)
     if (anyl0) {
       if (l0due) {
         const double *sq = gvec(vcold), *sv = gvec(vcold + 1);
@@ -581,11 +580,6 @@ __device__ __forceinline__ void fast4_r_wave(const Params& prm, double* quad, co
     // ---- the T waves of the quad have finished tick t-2: its sums are in LDS ----
     if (t > 1 && !seq_wait2(seqT, t - 1u, seqQ + 6)) { if (lane == 0) atomicExch(abort_flag, 1); break; }
     if (seqQ[6] != 0u) break;
-#if defined(WN4_URGENT)
-    // the T waves run at priority 1.  They need command t+1 at the end of their tick t: once one of them is IN tick t the quad's
-    // bookkeeper goes ahead of them (priority 2), before that it takes the issue slots they leave (priority 0)
-    if (__any((int32_t)(*seqT - t) >= 0)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
-#endif
 #if defined(WN4_TONLY)  // diagnostic: nothing is retired
     if (lane == 0) seqQ[4] = t + 1u;
     continue;
@@ -735,9 +729,6 @@ __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, co
     // ---- the R wave has finished its tick t: its messages are in LDS ----
     if (!seq_wait2(seqQ + 4, t + 1u, seqQ + 6)) { if (lane == 0) atomicExch(abort_flag, 1); break; }
     WN4_STAMP(5);
-#if defined(WN4_URGENT)
-    if (__any((int32_t)(*lds_words(pr + G::P_SEQ) - t) >= 0)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
-#endif
     RMsg m;
     m.ku = 0u; m.w = RM_DEAD; m.iter = 1u; m.zwant = 0u;  // (lanes without a pair: nothing to do, finished)
     if (pq < npairs) m = msgbuf[t3 * 4 + x];
@@ -752,6 +743,42 @@ __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, co
     }
     if (done) { c.op |= OP_DONE; if (lane == 0) seqQ[6] = 1u; }
     if (rep == 0 && pq < npairs) cmd_publish(pr + G::P_CMD + (((t + 1u) & 3u) * 4 + x) * 2, c, t + 1u);
+#if !defined(WN4_NOTOUCH)
+    // ---- the vectors the T wave will fetch from memory in tick t+1 with nothing to do meanwhile -- the passive orbit end (last leaf of a
+    // doubling, end swap) and the sub-tree endpoints of levels >= 5 (fetched when due) -- are pulled into the CU's vector cache now: one
+    // 4-byte load per 128-byte line (replica s touches register s of the chain's vector); the values are not used.
+    {
+      constexpr int NS = G::NS;
+      const bool step = (c.op & OP_STEP) != 0;
+      const int ci = (int)((c.op >> OP_I_SHIFT) & 31u), cn = (int)c.n;
+      const bool cold = inrange && ((step && cn == (1 << ci) - 1) || (c.op & OP_SWAP) != 0);
+      const int nchk = (inrange && step && (cn & 1)) ? nchecks(ci, cn) : 0;
+      if (__any(cold || nchk > 5)) {
+        const uint32_t* const wb = reinterpret_cast<const uint32_t*>(prm.work + (size_t)(grp0 + (pq < npairs ? pq : 0)) * G::group_doubles(prm.M) +
+                                                                     x * (NS * 16) + (rep < NS ? rep : 0) * 16);
+        const size_t vstride = (size_t)G::VEC * 2;  // (in 4-byte words)
+        const int vcold = (prm.M + 1) * 2 + 2;
+        uint32_t tch[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tch[k] = 0u;
+        if (cold && rep < NS) { tch[0] = wb[vcold * vstride]; tch[1] = wb[(vcold + 1) * vstride]; }
+#pragma unroll
+        for (int j = 5; j <= G::MP; ++j) {
+          if (__any(nchk > j)) {
+            if (nchk > j && rep < NS) {
+              const int sl = slot_of_leaf(cn + 1 - (1 << j));
+              tch[2 * (j - 4)] = wb[(size_t)(sl * 2) * vstride];
+              tch[2 * (j - 4) + 1] = wb[(size_t)(sl * 2 + 1) * vstride];
+            }
+          }
+        }
+        uint32_t a = 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a ^= tch[k];
+        asm volatile("" ::"v"(a));
+      }
+    }
+#endif
     WN4_STAMP(3);
 #if defined(WN_STAMPS)
     fst_[6] += 1;
@@ -794,8 +821,6 @@ __global__ __launch_bounds__(512) void wn_fast4_kernel(Params prm, int* abort_fl
   __syncthreads();
   // Waves: quads = ceil(pairs / 2) bookkeeper pairs (R, I) first, then the T waves.  With four pairs: R0 I0 R1 I1 T0 T1 T2 T3, and waves
   // w, w + 4 share a SIMD (speed only): every SIMD runs one T wave and one half of a bookkeeper, which serves the quad's two T waves.
-  // The bookkeeper waves are the OLDER waves of their SIMDs: the SIMD issues the oldest ready wave first, and a bookkeeper behind a
-  // T wave got a vector instruction in only when the T wave stalled.
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int quads = (pairs + 1) >> 1;
 #if defined(WN4_TFIRST)  // diagnostic: the T waves are the older ones
@@ -807,7 +832,8 @@ __global__ __launch_bounds__(512) void wn_fast4_kernel(Params prm, int* abort_fl
 #endif
   if (is_t) {
     // the T waves go first: the bookkeeper waves have half a tick of slack and take the issue slots a T wave leaves (measured: T waves
-    // at priority 1 1.32e9 steps/s, equal priorities with the bookkeepers as the older waves 1.27e9)
+    // at priority 1 1.32e9 steps/s, equal priorities with the bookkeepers as the older waves 1.27e9; raising the R or I wave to the
+    // T waves' priority, or only while a T wave is about to need their command, was slower)
 #if !defined(WN4_TPRIO)
 #define WN4_TPRIO 1
 #endif
@@ -815,8 +841,11 @@ __global__ __launch_bounds__(512) void wn_fast4_kernel(Params prm, int* abort_fl
     double* pr = lds + G::OFF_PAIR + (size_t)tw * G::PAIR_DOUBLES;
     fast4_t_wave<G, TRACE>(prm, lds, pr, (int)blockIdx.x * pairs + tw, abort_flag);
   } else {
-#if defined(WN4_BPRIO)
-    __builtin_amdgcn_s_setprio(WN4_BPRIO);
+#if defined(WN4_RPRIO)
+    if (!(bw & 1)) __builtin_amdgcn_s_setprio(WN4_RPRIO);
+#endif
+#if defined(WN4_IPRIO)
+    if (bw & 1) __builtin_amdgcn_s_setprio(WN4_IPRIO);
 #endif
     const int quad = bw >> 1;
     double* qd = lds + G::OFF_PAIR + (size_t)(2 * quad) * G::PAIR_DOUBLES;
