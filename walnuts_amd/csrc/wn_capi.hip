@@ -700,7 +700,7 @@ int wn_run(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, do
 #ifdef WN_STAMPS
   {  // diagnostic build: per-phase cycle stamps, dumped to $WN_STAMPS_OUT after the run
     static unsigned long long* sbuf = nullptr;
-    const size_t nw = (size_t)(p.C + 15) * 16;  // one 16-entry row per wave in every layout
+    const size_t nw = (size_t)(p.C + 15) * 16 * 4;  // one 16-entry row per wave in every layout (the pair kernel: eight rows per workgroup of >= 4 chains)
     static size_t scap = 0;
     if (nw > scap) { if (sbuf) hipFree(sbuf); hipMalloc((void**)&sbuf, nw * sizeof(unsigned long long)); scap = nw; }
     hipMemset(sbuf, 0, nw * sizeof(unsigned long long));

@@ -164,17 +164,11 @@ __device__ __forceinline__ void cmd_publish(double* rec, const Cmd& c, uint32_t 
   *(lds_vf64*)rec = c.hs;
   *(lds_vu64*)(rec + 1) = (uint64_t)(c.op | ((tick & 0xFFFFu) << CMD_TAG_SHIFT)) | ((uint64_t)c.n << 32);
 }
-__device__ __forceinline__ bool cmd_poll(const double* rec, uint32_t tick, Cmd& c) {  // false: not within the bound
-  uint32_t spins = 0;
-  for (;;) {
-    const uint64_t w = *(const lds_vu64*)(rec + 1);
-    const double hs = *(const lds_vf64*)rec;
-    const bool ready = (((uint32_t)w >> CMD_TAG_SHIFT) & 0xFFFFu) == (tick & 0xFFFFu);
-    if (__all(ready)) { c.hs = hs; c.op = (uint32_t)w & 0xFFFFu; c.n = (uint32_t)(w >> 32); return true; }
-    __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1u << 23)) return false;
-  }
+__device__ __forceinline__ void cmd_read(const double* rec, uint64_t& w, double& hs) {
+  w = *(const lds_vu64*)(rec + 1);
+  hs = *(const lds_vf64*)rec;
 }
+__device__ __forceinline__ bool cmd_is_for(uint64_t w, uint32_t tick) { return (((uint32_t)w >> CMD_TAG_SHIFT) & 0xFFFFu) == (tick & 0xFFFFu); }
 __device__ __forceinline__ bool seq_wait(const lds_vu32* p, uint32_t want) {
   uint32_t spins = 0;
   while ((int32_t)(*p - want) < 0) {
@@ -231,7 +225,12 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     constexpr int NSR = G::NSR, NK = G::NK, NP = NSR / 2;
     typedef double d2_t __attribute__((ext_vector_type(2)));
     const double* const img = lds + G::OFF_A + 2 * lane;
-    // the first fragments do not depend on the command: requested before it is waited for
+    // the command record is asked for first, the fragments of the first k-steps (which do not depend on it) right behind: LDS returns in
+    // order, so an ordinary tick has its command after one round trip and the fragments arrive while it is decoded
+    const double* const rec = pr + G::P_CMD + ((t & 3u) * 4 + x) * 2;
+    uint64_t cw = 0;
+    double chs = 0.0;
+    if (t != 0) cmd_read(rec, cw, chs);
     d2_t fa[4][NP];
     auto load_k = [&](int kap, d2_t* f) {
 #pragma unroll
@@ -250,11 +249,16 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     if (t == 0) { c.hs = 0.0; c.op = inrange ? (OP_NEWITER | OP_INIT) : 0u; c.n = 0u; }
     else {
       WN4_STAMP(7);
-      if (!cmd_poll(pr + G::P_CMD + ((t & 3u) * 4 + x) * 2, t, c)) { if (lane == 0) atomicExch(abort_flag, 1); return false; }
+      uint32_t spins = 0;
+      while (!__all(cmd_is_for(cw, t))) {  // (bounded: a protocol error must not hang the GPU)
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 23)) { if (lane == 0) atomicExch(abort_flag, 1); return false; }
+        cmd_read(rec, cw, chs);
+      }
+      c.hs = chs; c.op = (uint32_t)cw & 0xFFFFu; c.n = (uint32_t)(cw >> 32);
       WN4_STAMP(5);
     }
     const uint32_t op = c.op;
-    if (__any((op & OP_DONE) != 0)) return false;
     double* const sp = sums + t3 * (G::NB * 16);
     const bool step = (op & OP_STEP) != 0;
     const int i = (int)((op >> OP_I_SHIFT) & 31u), n = (int)c.n;
@@ -264,8 +268,9 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     // ---- commands ----
     const bool deep0 = nchk > NFAST, deep1 = nchk > NFAST + 1;
     // ONE vote for everything that does not happen on an ordinary leaf
-    const bool anyrare = __any((op & (OP_PICK | OP_NEWITER | OP_SWAP | OP_UNDO)) != 0 || deep0);
+    const bool anyrare = __any((op & (OP_PICK | OP_NEWITER | OP_SWAP | OP_UNDO | OP_DONE)) != 0 || deep0);
     if (anyrare) {
+      if (__any((op & OP_DONE) != 0)) return false;
       if (PAR == 1 && __any(deep0)) {
         if (deep0) {
           const int sl = slot_of_leaf(n + 1 - (1 << NFAST));
@@ -523,8 +528,7 @@ struct Fast4IO {
     const double* e = pr + (blk < 8u ? G::P_USTAT + (x * 8 + (int)blk) * 3 : G::P_URING + (x * 16 + (int)(blk & 15u)) * 3);
     const lds_vu32* tag = lds_words(e);
     const uint32_t t0 = tag[0], t1 = tag[1];  // (the writer stores the values first, then the tag)
-    asm volatile("" ::: "memory");
-    ua = e[1]; ub = e[2];
+    ua = *(const lds_vf64*)(e + 1); ub = *(const lds_vf64*)(e + 2);
     return t0 == (uint32_t)iter && t1 == blk;
   }
   __device__ __forceinline__ void write_gen(size_t row, double v) const {
@@ -552,7 +556,7 @@ struct Fast4IO {
 __device__ __forceinline__ bool seq_wait2(const lds_vu32* p, uint32_t want, const lds_vu32* over) {
   uint32_t spins = 0;
   while (__any((int32_t)(*p - want) < 0) && *over == 0u) {
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(1);  // (coarser polling, up to s_sleep 16, changes nothing: gpurun_out/r03/ab30.txt)
     if (++spins > (1u << 23)) return false;
   }
   asm volatile("" ::: "memory");
