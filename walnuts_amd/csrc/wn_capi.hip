@@ -283,6 +283,8 @@ struct wn_engine {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int* h_poll = nullptr;          // pinned host words the split-mode loop polls the finished-chain counter through
   hipEvent_t ev_poll[2] = {nullptr, nullptr};
+  hipStream_t sp_main = nullptr;  // split mode: stands in for the (uncapturable) legacy default stream
+  hipEvent_t sp_fork0 = nullptr;
   int* kabort = nullptr;  // device flag: a kernel's bounded loop gave up (internal error)
   bool kabort_pending = false;  // a launch since the flag was last read
   hipStream_t kabort_stream = nullptr;
@@ -374,6 +376,8 @@ int wn_destroy(wn_engine* e) {
   if (e->kabort) hipFree(e->kabort);
   if (e->h_poll) hipHostFree(e->h_poll);
   for (hipEvent_t ev : e->ev_poll) if (ev) hipEventDestroy(ev);
+  if (e->sp_main) hipStreamDestroy(e->sp_main);
+  if (e->sp_fork0) hipEventDestroy(e->sp_fork0);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   delete e;
@@ -525,6 +529,18 @@ static void fill_params(const wn_engine* e, Params* p) {
 // of ticks; a launch whose chains have all finished is a few microseconds of early exits.
 static int run_split_dense(wn_engine* e, Params p, hipStream_t st, int adapt, bool warm) {
   if (p.mode != MODE_SAMPLE) { e->err = "wn_integrator_step is not available in split mode"; return WN_E_UNSUPPORTED; }
+  if (st == nullptr) {
+    // The legacy default stream cannot be captured into a hipGraph -- and every caller that does not say otherwise is on it (until
+    // round 3 the "graph" path of this function therefore always fell back to eager launches).  The run goes to a stream of the
+    // engine's own, ordered behind the work already queued on the default stream; it is complete when this function returns.
+    if (!e->sp_main) {
+      HIPCHK(e, hipStreamCreateWithFlags(&e->sp_main, hipStreamNonBlocking));
+      HIPCHK(e, hipEventCreateWithFlags(&e->sp_fork0, hipEventDisableTiming));
+    }
+    HIPCHK(e, hipEventRecord(e->sp_fork0, nullptr));
+    HIPCHK(e, hipStreamWaitEvent(e->sp_main, e->sp_fork0, 0));
+    st = e->sp_main;
+  }
   p.xq = e->xq; p.xg = e->xg; p.xlp = nullptr; p.sp_done = e->sp_done;
   HIPCHK(e, hipMemsetAsync(e->sp_done, 0, 64, st));
   hipError_t r = launch_split_begin(e->kc, adapt, warm, p, st);
@@ -572,7 +588,8 @@ static int run_split_dense(wn_engine* e, Params p, hipStream_t st, int adapt, bo
       if (rg == hipSuccess && rl != hipSuccess) rg = rl;
     }
     if (rg == hipSuccess) rg = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
-    if (rg != hipSuccess) {  // (the legacy default stream cannot be captured, for one: fall back to eager launches)
+    if (getenv("WN_SPLIT_DEBUG")) fprintf(stderr, "[wn split] hipGraph of 64 ticks: %s\n", rg == hipSuccess ? "captured" : hipGetErrorString(rg));
+    if (rg != hipSuccess) {  // (fall back to eager launches)
       (void)hipGetLastError();
       if (gexec) { hipGraphExecDestroy(gexec); gexec = nullptr; }
       if (graph) { hipGraphDestroy(graph); graph = nullptr; }
