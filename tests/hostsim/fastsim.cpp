@@ -124,6 +124,8 @@ struct HostIO {
   int cl;
   const double* sums;
   int* ntrace;
+  double* h0 = nullptr;  // (two-stream form) the iteration's initial Hamiltonian, retire side -> issue side
+  void write_h0(double v) const { if (h0) *h0 = v; }
   void trace_step(int iter, int i, int xi, double h, double ham0, double lpn) {
     const int row = (*ntrace)++;
     if (prm->trace && row < prm->trace_cap) {
@@ -223,6 +225,7 @@ static long run_split(Params* prm, int target, int nlc, double* idle_frac) {
     const double cap = 64.0 + 1.3 * (double)prm->numIter * ((double)(1u << prm->M) + 6.0 * prm->M + 16.0);
     uint32_t t = 0;
     int ntrace = 0;
+    double h0_shared = 0.0;
     for (;; ++t) {
       if ((double)t > cap) return -1;
       if (I.zwant != I.zready && I.zwant >= 1) {  // momentum normals (the I wave)
@@ -233,9 +236,11 @@ static long run_split(Params* prm, int target, int nlc, double* idle_frac) {
       old.hs = 0.0; old.n = 0; old.op = 0;
       if (t + 1 >= (uint32_t)LAG) { memcpy(psums, hist[(t + 1 - LAG) % 3], sizeof(psums)); old = ring[(t + 1 - LAG) % 4]; }
       else memset(psums, 0, sizeof(psums));
-      HostIO io{prm, cl, psums, &ntrace};
+      HostIO io{prm, cl, psums, &ntrace, &h0_shared};
       const RMsg m = R.tick(*prm, io, old);           // retires tick t-2
-      const Cmd nxt = I.tick(*prm, io, t + 1, m);     // issues tick t+1
+      bool early = false;  // the first leaf of a doubling (tick t-1), certified by the issue side from the T wave's sums
+      if (I.wants_early(t + 1, m)) early = IssueBook::early_certain(*prm, hist[(t - 1) % 3][Q_LP], hist[(t - 1) % 3][Q_KE], h0_shared);
+      const Cmd nxt = I.tick(*prm, io, t + 1, m, early);  // issues tick t+1
       T.tick(t, ring[t % 4]);                         // tick t
       memcpy(hist[t % 3], T.sums, sizeof(psums));
       if (ring[t % 4].op & OP_STEP) steps += 1;

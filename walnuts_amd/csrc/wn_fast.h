@@ -637,6 +637,7 @@ struct RetireBook : BookUniforms {
     H0 = -lpP + 0.5 * io.sum(Q_KEINIT);  // Hs[I0] = -f0 + 0.5*sum(v**2) (:256)
     Ha = Hb = H0;
     Hnan = isnan(H0); Hmin = Hmax = H0;
+    io.write_h0(H0);  // (the issue side certifies the first leaf of a doubling itself: IssueBook::early_certain)
     if (iter + 1 <= prm.numIter) zwant = iter + 1;  // the momentum buffer is free again
   }
   // does the command `c` (the one the T wave executed in the tick whose sums `io` holds) retire a leaf?
@@ -687,12 +688,26 @@ struct IssueBook : BookUniforms {
   WN_HD uint32_t first_issue_uniform() const {  // ku + sum over the leaves m in flight of (m even ? 3 : 1)
     return ku + (uint32_t)(n_is - n_rt) + 2u * (uint32_t)(((n_is + 1) >> 1) - ((n_rt + 1) >> 1));
   }
+  // The second leaf pair of a doubling is due while its first pair is still in flight, and whether those two leaves take their
+  // multinomial draws (WALNUTS.py:426: only if WnewSum > wtSumThresh) decides where in the stream the pair's step sizes are.  The
+  // retire side knows one tick too late (two idle ticks per doubling).  The issue side can know in time: the sub-tree's weight sum
+  // starts from zero (:390), so the first leaf's own weight decides, and its sums are in LDS when the T wave has finished that tick.
+  // wants_early(): this tick's issue is that case; early_certain(): the retire side's arithmetic (RetireBook::tick), bit for bit.
+  WN_HD bool wants_early(uint32_t tn, const RMsg& m) const {
+    return st == ST_RUN && n_is == 2 && (tn & 1u) == 0 && (m.w & (RM_END | RM_CONT | RM_CERTAIN | RM_NRT_MASK)) == 0;
+  }
+  WN_HD static bool early_certain(const Params& prm, double lp_sum, double ke_sum, double H0) {
+    const double lpn = 0.5 * lp_sum;
+    const double Hn = -lpn + 0.5 * ke_sum;
+    const double Wnew = exp(-Hn + H0 + 0.0);
+    return (0.0 + Wnew) > prm.wtSumThresh;
+  }
   // One tick: apply the retire side's message of this tick, issue tick `tn`.
   template <class IO>
-  WN_HD Cmd tick(const Params& prm, IO& io, uint32_t tn, const RMsg& m) {
+  WN_HD Cmd tick(const Params& prm, IO& io, uint32_t tn, const RMsg& m, bool early = false) {
     Cmd c;
     c.hs = 0.0; c.op = 0u; c.n = 0u;
-    ku = m.ku; n_rt = (int)(m.w & RM_NRT_MASK); certain = (m.w & RM_CERTAIN) != 0;
+    ku = m.ku; n_rt = (int)(m.w & RM_NRT_MASK); certain = (m.w & RM_CERTAIN) != 0 || early;
     zwant = (int)m.zwant; rdead = (m.w & RM_DEAD) != 0;
     if (m.w & RM_PICK) c.op |= OP_PICK | ((m.w & RM_PICKIP) ? OP_IPPICK : 0u);
     if (m.w & RM_END) {  // the leaves in flight (the commands of ticks tn-1, tn-2) belong to the orbit that just ended

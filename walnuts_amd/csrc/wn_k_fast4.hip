@@ -74,7 +74,8 @@ struct Fast4Geom {
   // hand-off words (32 bit): [0] ticks the T wave has finished, [2] commands the I wave has issued, [4] ticks the R wave has
   // finished, [6] the run is over (the last two in the FIRST pair of a quad only)
   static constexpr int P_SEQ = P_URING + 4 * 16 * 3;
-  static constexpr int PAIR_DOUBLES = P_SEQ + 8;
+  static constexpr int P_H0 = P_SEQ + 8;               // the running iteration's initial Hamiltonian per chain (R wave -> I wave)
+  static constexpr int PAIR_DOUBLES = P_H0 + 4;
   static constexpr int OFF_PAIR = NFR * 64;
   static_assert(((size_t)OFF_PAIR + 4 * (size_t)PAIR_DOUBLES) * sizeof(double) <= 160 * 1024, "four pairs and the fragment image in one CU's LDS");
   __host__ __device__ static constexpr size_t lds_bytes(int pairs) { return ((size_t)OFF_PAIR + (size_t)pairs * PAIR_DOUBLES) * sizeof(double); }
@@ -531,6 +532,7 @@ struct Fast4IO {
     ua = *(const lds_vf64*)(e + 1); ub = *(const lds_vf64*)(e + 2);
     return t0 == (uint32_t)iter && t1 == blk;
   }
+  __device__ __forceinline__ void write_h0(double v) const { if (rep == 0) *(lds_vf64*)(pr + G::P_H0 + x) = v; }
   __device__ __forceinline__ void write_gen(size_t row, double v) const {
     if (rep == 0) prm->samples[((size_t)cl * (prm->numIter + 1) + row) * prm->dg + 1] = v;
   }
@@ -736,8 +738,20 @@ __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, co
     RMsg m;
     m.ku = 0u; m.w = RM_DEAD; m.iter = 1u; m.zwant = 0u;  // (lanes without a pair: nothing to do, finished)
     if (pq < npairs) m = msgbuf[t3 * 4 + x];
+    // the second leaf pair of a doubling: its first leaf (tick t-1) is certified here, from the T wave's sums, one tick before the retire
+    // side would (wn_fast.h IssueBook::wants_early: two idle ticks per doubling otherwise).  Rare: one tick per doubling and chain.
+    bool early = false;
+    {
+      const bool we = inrange && bk.wants_early(t + 1u, m);
+      if (__any(we)) {
+        if (!seq_wait2(lds_words(pr + G::P_SEQ), t, seqQ + 6)) { if (lane == 0) atomicExch(abort_flag, 1); break; }  // the T wave has finished tick t-1
+        const double* spe = pr + G::P_SUMS + (t3 == 0 ? 2 : t3 - 1) * (G::NB * 16);                                  // slot (t - 1) % 3
+        const double elp = *(const lds_vf64*)(spe + x), eke = *(const lds_vf64*)(spe + 4 + x), eh0 = *(const lds_vf64*)(pr + G::P_H0 + x);
+        early = we && IssueBook::early_certain(prm, elp, eke, eh0);
+      }
+    }
     WN4_STAMP(1);
-    Cmd c = bk.tick(prm, io, t + 1u, m);
+    Cmd c = bk.tick(prm, io, t + 1u, m, early);
     WN4_STAMP(2);
     // ---- every chain of the quad has finished: all its waves leave (the quads of a workgroup do not wait for each other) ----
     bool done = anyrare && __all(bk.finished());  // (finished() needs ST_DEAD, which was part of this tick's one vote, or shows at the next)
