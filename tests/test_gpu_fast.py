@@ -225,3 +225,48 @@ def test_pair_kernel_per_step_states_at_4096_chains(wa):
         assert tn[k] == n
         m = min(n, 1400)
         close(tr[j, :m], o["trace"][:m], what=f"chain {k} trace rows")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_pair_kernel_random_configurations(wa, seed):
+    """A short run of tools/fuzz_fast4.py inside the suite: random dimension (all four register geometries), chain count (one, two,
+    four T waves per workgroup; ragged last quads and groups), depth (incl. M = 1, 2: orbits that end inside the bookkeeper's lag),
+    step size, conditioning, generated kind, overflowing energies (stop code 999, zero / infinite weights), traced or not -- every
+    diagnostics column, every draw and every trace row of the checked chains against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    for it in range(14):
+        D = int(rng.choice([5, 16, 17, 32, 33, 64, 65, 96, 97, 100]))
+        C = int(rng.choice([1, 3, 4, 5, 17, 70, 300, 1100, 2500]))
+        M = int(rng.integers(1, 8))
+        numIter = int(rng.integers(1, 5))
+        Q, _ = np.linalg.qr(rng.normal(size=(D, D))); lam = np.logspace(0, rng.uniform(0.0, 4.0), D)
+        A = (Q * (1.0 / lam)) @ Q.T; A = 0.5 * (A + A.T)
+        q0 = rng.normal(size=(C, D)) @ (Q * np.sqrt(lam)).T
+        if rng.random() < 0.15:
+            q0[: max(1, C // 7)] *= 10.0 ** rng.uniform(100, 200)
+        H0 = float(rng.uniform(0.2, 1.1))
+        gen, gk = (ol.G_IDENTITY, 0) if rng.random() < 0.4 else ((ol.G_Q0_SUMSQ, 0) if rng.random() < 0.5 else (ol.G_FIRSTK, int(rng.integers(1, 4))))
+        traced = rng.random() < 0.4 and C <= 300
+        cap = numIter * (1 << M) + 8
+        off = int(rng.integers(0, 1 << 20))
+        e = wa.Engine(D, C, integrator=ol.I_FIXED, H0=H0, M=M, generated=gen, gen_k=gk, chain_offset=off)
+        e.set_target(ol.T_DENSEGAUSS, A)
+        assert "wn_fast4_kernel" in e.kernel_name, e.kernel_name
+        out = e.run(q0, 99 + it, numIter, trace_cap=cap if traced else 0)
+        s = out[0].transpose(1, 2).cpu().numpy(); d = out[1].cpu().numpy()
+        tr, tn = (out[2].cpu().numpy(), out[3].cpu().numpy()) if traced else (None, None)
+        e.close()
+        what = f"seed {seed} it {it}: D={D} C={C} M={M} iters={numIter} gen={gen} traced={traced}"
+        for k in sorted({0, C - 1, C // 2, min(C - 1, 4), int(rng.integers(0, C))}):
+            o = ol.walnuts(ol.T_DENSEGAUSS, q0[k], integrator=ol.I_FIXED, tpar=A.ravel(), H0=H0, numIter=numIter, M=M, seed=99 + it,
+                           chain=off + k, generated=gen, gen_k=gk, trace_cap=cap if traced else 0)
+            for col in INT_DIAG:
+                np.testing.assert_array_equal(d[k][:, col], o["diagnostics"][:, col], err_msg=f"{what} chain {k} diag col {col}")
+            with np.errstate(all="ignore"):
+                sc = np.nanmax(np.abs(o["samples"])) if np.isfinite(o["samples"]).any() else 1.0
+            close(d[k][:, [2, 3, 15, 23]], o["diagnostics"][:, [2, 3, 15, 23]], rtol=1e-6, atol=1e-9, what=what + f" chain {k} diag")
+            close(s[k], o["samples"], rtol=1e-6, atol=1e-9 + 1e-6 * (sc if np.isfinite(sc) else 1.0), what=what + f" chain {k} draws")
+            if traced:
+                m = o["ncalls"]
+                assert tn[k] == m, (what, k, tn[k], m)
+                np.testing.assert_array_equal(tr[k, :m][:, [0, 1, 2, 10]], o["trace"][:m][:, [0, 1, 2, 10]], err_msg=what + f" chain {k} trace integers")

@@ -17,9 +17,12 @@ other = 0
 
 
 def close(a, b, tol=1e-6):
+    # (overflowing energies: the engine's dot products are FMA chains, the oracle's -- as the reference's -- separate multiplications
+    # and additions; where a product overflows, fma(q, g, -inf) is -inf and q*g + -inf is NaN.  Both are "not finite", which is all the
+    # sampler asks of them (stop code 999): non-finite values of either kind compare equal here.)
     with np.errstate(all="ignore"):
         scale = np.nanmax(np.abs(b), axis=0, keepdims=True) if b.size else 1.0
-        return bool(((np.isnan(a) & np.isnan(b)) | (np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))) |
+        return bool(((~np.isfinite(a) & ~np.isfinite(b)) |
                      (np.abs(a - b) <= 1e-9 + tol * np.maximum(np.abs(b), scale))).all())
 
 
