@@ -1,7 +1,8 @@
-"""GPU tests of the role-split headline kernel (wn_k_fast.hip: four T waves + one bookkeeper wave per 16-chain
-group) through the C ABI: against the oracle on seeded inputs, against the one-stream kernel of the same
-layout (WN_COOP_LEGACY=1: identical integers, draws to 1e-9) at full BASELINE size, and the
-edge cases of tests/test_fast_book.py on the device."""
+"""GPU tests of the headline kernels through the C ABI -- wn_k_fast4.hip (dense Gaussian, D <= 100: one T wave per four chains, a
+retire and an issue wave per eight) and wn_k_fast.hip (std / diagonal Gaussians, D <= 112: seven T waves + one bookkeeper wave per
+16-chain group): against the oracle on seeded inputs, per-step states of traced runs, against the one-stream kernel of the same layout
+(WN_COOP_LEGACY=1: identical integers, draws to 1e-9) at full BASELINE size, the edge cases of tests/test_fast_book.py on the device,
+and random configurations."""
 import os
 
 import numpy as np

@@ -170,16 +170,6 @@ __device__ __forceinline__ void cmd_read(const double* rec, uint64_t& w, double&
   hs = *(const lds_vf64*)rec;
 }
 __device__ __forceinline__ bool cmd_is_for(uint64_t w, uint32_t tick) { return (((uint32_t)w >> CMD_TAG_SHIFT) & 0xFFFFu) == (tick & 0xFFFFu); }
-__device__ __forceinline__ bool seq_wait(const lds_vu32* p, uint32_t want) {
-  uint32_t spins = 0;
-  while ((int32_t)(*p - want) < 0) {
-    __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1u << 23)) return false;
-  }
-  asm volatile("" ::: "memory");
-  return true;
-}
-
 template <class G, bool TRACE>
 __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* lds, double* pr, const int grp, int* abort_flag) {
   constexpr int NS = G::NS, NFAST = G::NFAST;
