@@ -83,14 +83,15 @@ def test_fast_diag_matches_oracle(wa, D, tk):
     q0 = np.random.default_rng(D).normal(size=(35, D)) * (np.sqrt(lam) if a is not None else 1.0)
     H0 = 0.5 if a is not None else 1.4 * D ** -0.25
     kw = dict(H0=H0, M=9, generated=ol.G_Q0_SUMSQ, chain_offset=0, numIter=6, seed=SEED)
-    s, d, name, _ = run(wa, tk, a, q0, **kw)
-    assert "wn_fast_kernel" in name and "diag" in name, name
-    for k in (0, 16, 34):
-        o = ol.walnuts(tk, q0[k], integrator=ol.I_FIXED, tpar=a, H0=H0, numIter=6, M=9, seed=SEED, chain=k, generated=ol.G_Q0_SUMSQ)
-        for col in INT_DIAG:
-            np.testing.assert_array_equal(d[k][:, col], o["diagnostics"][:, col], err_msg=f"chain {k} diag col {col}")
-        close(d[k], o["diagnostics"], what=f"chain {k} diagnostics")
-        close(s[k], o["samples"], what=f"chain {k} draws")
+    for seven in (False, True):  # the T / R / I kernel (default) and the seven-T-wave kernel (WN_FAST_LEGACY=1)
+        s, d, name, _ = run(wa, tk, a, q0, seven=seven, **kw)
+        assert ("wn_fast_kernel" if seven else "wn_fast4_kernel") in name and "diag" in name, name
+        for k in (0, 16, 34):
+            o = ol.walnuts(tk, q0[k], integrator=ol.I_FIXED, tpar=a, H0=H0, numIter=6, M=9, seed=SEED, chain=k, generated=ol.G_Q0_SUMSQ)
+            for col in INT_DIAG:
+                np.testing.assert_array_equal(d[k][:, col], o["diagnostics"][:, col], err_msg=f"{name} chain {k} diag col {col}")
+            close(d[k], o["diagnostics"], what=f"{name} chain {k} diagnostics")
+            close(s[k], o["samples"], what=f"{name} chain {k} draws")
 
 
 def test_fast_equals_one_stream_kernel_at_baseline_size(wa):
@@ -134,7 +135,7 @@ def test_fast_huge_energies_on_device(wa, scale, H0):
     q0[4:] = np.random.default_rng(4).normal(size=(2, D))  # ordinary chains in the same group are not disturbed
     kw = dict(H0=H0, M=8, generated=ol.G_Q0_SUMSQ, chain_offset=3, numIter=8, seed=11)
     s, d, name, _ = run(wa, ol.T_STDGAUSS, None, q0, **kw)
-    assert "wn_fast_kernel" in name
+    assert "wn_fast4_kernel" in name, name
     for k in range(6):
         o = ol.walnuts(ol.T_STDGAUSS, q0[k], integrator=ol.I_FIXED, H0=H0, numIter=8, M=8, seed=11, chain=3 + k, generated=ol.G_Q0_SUMSQ)
         for col in INT_DIAG:

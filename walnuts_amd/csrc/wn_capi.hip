@@ -477,9 +477,9 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
     (void)NT;
     // dense, D <= 100: wave pairs of four chains (wn_k_fast4.hip), traced runs too.  (4096 chains: 1.24e9 steps/s against the
     // seven-wave kernel's 1.12e9; 1024 chains are 256 pairs, one per CU, where that kernel fills 64 CUs: 3.9e8 against 2.8e8.)
-    if (kc.p1 == CK_DENSE && D <= 100 && !getenv("WN_FAST_LEGACY"))
-      snprintf(kc.name, sizeof(kc.name), "wn_fast4_kernel<NS=%d%s,dense,pairs=%d>", D <= 32 ? 2 : D <= 64 ? 4 : D <= 96 ? 6 : 7, D > 96 ? ",tail" : "",
-               fast4_pairs(e->cfg.n_chains));
+    if ((kc.p1 != CK_DENSE || D <= 100) && !getenv("WN_FAST_LEGACY"))
+      snprintf(kc.name, sizeof(kc.name), "wn_fast4_kernel<NS=%d%s,%s,pairs=%d>", D <= 32 ? 2 : D <= 64 ? 4 : D <= 96 ? 6 : 7, (kc.p1 == CK_DENSE && D > 96) ? ",tail" : "",
+               kc.p1 == CK_DENSE ? "dense" : "diag", fast4_pairs(e->cfg.n_chains));
   }
   e->kc = kc;
   e->have_kc = true;

@@ -44,8 +44,9 @@
 namespace wn {
 using namespace fast;
 
-template <int NS_, bool TAIL_>
+template <int NS_, bool TAIL_, bool DENSE_ = true>
 struct Fast4Geom {
+  static constexpr bool DENSE = DENSE_;          // dense precision matrix (MFMA gradient); false: diagonal / standard Gaussian, g = -a .* q
   static constexpr int NS = NS_;                 // registers per lane and vector: coordinate 16 s + 4 b + r
   static constexpr bool TAIL = TAIL_;            // the last k-step holds <= 4 coordinates (block 0 only): tail MFMA
   static constexpr int KF = TAIL ? NS - 1 : NS;  // full k-steps of the main loop
@@ -59,8 +60,8 @@ struct Fast4Geom {
   static constexpr int NSR = TAIL ? NS - 1 : NS;                  // 16-row sets computed with replicated operands
   static constexpr int NK = TAIL ? 4 * (NS - 1) + 1 : 4 * NS;     // k-steps of four coordinates
   static constexpr int NMAIN = NK * NSR;
-  static constexpr int NFR = NMAIN + (TAIL ? NS : 0);
-  static_assert(NSR % 2 == 0, "two fragments per 16-byte LDS read");
+  static constexpr int NFR = DENSE ? NMAIN + (TAIL ? NS : 0) : 0;
+  static_assert(!DENSE || NSR % 2 == 0, "two fragments per 16-byte LDS read");
   // LDS, in doubles: the fragment image, then one region per pair
   static constexpr int OFF_A = 0;
   static constexpr int P_LC = 0;                        // level-2 left endpoint: q, v
@@ -200,6 +201,9 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
 #pragma unroll
   for (int s = 0; s < NS; ++s) { X0[s] = X1[s] = v[s] = g[s] = VL[s] = 0.0; pq0[s] = pv0[s] = pq1[s] = pv1[s] = 0.0; }
   int ntr = 0;  // trace rows written (TRACE)
+  double adiag[NS];  // (diagonal / standard Gaussian) the precisions of this lane's coordinates; tpar is all ones for the standard Gaussian
+#pragma unroll
+  for (int s = 0; s < NS; ++s) adiag[s] = (!G::DENSE && coord(s) < D) ? prm.tpar[coord(s)] : 0.0;
 
   // one batch of four per-chain sums: lanes r = 0 hold [block b'][chain x] = 16 consecutive doubles
   auto put4 = [&](double* dst, double a0, double a1, double a2, double a3) {
@@ -227,11 +231,13 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
 #pragma unroll
       for (int j = 0; j < NP; ++j) f[j] = *reinterpret_cast<const d2_t*>(img + (kap * NP + j) * 128);
     };
+    if (G::DENSE) {
 #pragma unroll
-    for (int k0 = 0; k0 < 3; ++k0) if (k0 < NK) load_k(k0, fa[k0]);
+      for (int k0 = 0; k0 < 3; ++k0) if (k0 < NK) load_k(k0, fa[k0]);
+    }
     d2_t fx[(NS - 1) / 2 > 0 ? (NS - 1) / 2 : 1];
     double ftail = 0.0;
-    if (G::TAIL) {
+    if (G::DENSE && G::TAIL) {
 #pragma unroll
       for (int j = 0; j < (NS - 1) / 2; ++j) fx[j] = *reinterpret_cast<const d2_t*>(img + G::NMAIN * 64 + j * 128);
       ftail = lds[G::OFF_A + (G::NMAIN + NS - 1) * 64 + lane];
@@ -350,8 +356,14 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
         }
       }
     }
+    if (!G::DENSE) {  // diagonal / standard Gaussian: g = -(a .* q)  (targetDistr.py stdGauss; SURVEY 8d "diagonal variant")
+#pragma unroll
+      for (int s = 0; s < NS; ++s) g[s] = -(adiag[s] * qn[s]);
+      WN4_STAMP(0);
+    }
     // the position goes to LDS: k-step kappa's B operand (coordinates 4 kappa .. + 3 in EVERY block) is read back from there with the
     // block index replaced -- one LDS read per k-step instead of six DPP moves (FP64 MFMAs and vector instructions share the SIMD)
+    if (G::DENSE) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) stage[s * 64 + lane] = qn[s];
     WN4_STAMP(0);
@@ -380,6 +392,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
 #pragma unroll
       for (int S = 0; S < NSR; ++S) g[S] = acc[S];
       if (G::TAIL) g[NS - 1] = b == 0 ? gx : 0.0;  // blocks 1..3 of the last register are padding
+    }
     }
     WN4_STAMP(1);
     // the passive orbit end lives in memory (once per doubling: the whole-orbit check at its last leaf, and the end swaps): requested
@@ -796,9 +809,9 @@ __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, co
   WN4_STAMP_OUT(prm)
 }
 
-template <int NS, bool TAIL, bool TRACE>
+template <int NS, bool TAIL, bool TRACE, bool DENSE>
 __global__ __launch_bounds__(512) void wn_fast4_kernel(Params prm, int* abort_flag, int pairs) {
-  using G = Fast4Geom<NS, TAIL>;
+  using G = Fast4Geom<NS, TAIL, DENSE>;
   extern __shared__ double lds[];
   // the -A fragment image (see the header): fragment f, lane (r, b, x)
   const int D = prm.D;
@@ -863,43 +876,51 @@ __global__ __launch_bounds__(512) void wn_fast4_kernel(Params prm, int* abort_fl
   }
 }
 
-// can the pair kernel run this launch?  fixedLeapFrog sampling on a dense Gaussian, D <= 100, no warm-up / orbit statistics
+// can this kernel run the launch?  fixedLeapFrog sampling (traced or not, no warm-up / orbit statistics) on a dense Gaussian with
+// D <= 100 or a diagonal / standard one with D <= 112
 bool fast4_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm) {
   if (kc.layout != 1 || adapt != 0 || warm || prm.mode != MODE_SAMPLE) return false;
-  if (prm.omin || prm.M > 11 || prm.D > 100 || kc.p1 != 0 /* CK_DENSE */) return false;
-  return true;
+  if (prm.omin || prm.M > 11) return false;
+  return kc.p1 == 0 /* CK_DENSE */ ? prm.D <= 100 : prm.D <= 112;
 }
 
-int fast4_pairs(int C) {  // pairs per workgroup: fill the chip's 256 CUs before stacking pairs on a CU
+int fast4_pairs(int C) {  // T waves per workgroup: fill the chip's 256 CUs before stacking them on a CU
   const int groups = (C + 3) / 4;
   return groups >= 4 * 256 ? 4 : groups >= 2 * 256 ? 2 : 1;
 }
 
-template <int NS, bool TAIL>
+template <int NS, bool TAIL, bool DENSE>
 static hipError_t fast4_go(const Params& prm, int* abort_flag, hipStream_t st) {
-  using G = Fast4Geom<NS, TAIL>;
+  using G = Fast4Geom<NS, TAIL, DENSE>;
   const int pairs = fast4_pairs(prm.C), groups = (prm.C + 3) / 4;
   dim3 grid((groups + pairs - 1) / pairs), block(64 * (pairs + 2 * ((pairs + 1) / 2)));
   const size_t shm = G::lds_bytes(pairs);
   hipError_t r;
   if (prm.trace_n) {
-    r = hipFuncSetAttribute((const void*)wn_fast4_kernel<NS, TAIL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    r = hipFuncSetAttribute((const void*)wn_fast4_kernel<NS, TAIL, true, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (r != hipSuccess) return r;
-    hipLaunchKernelGGL((wn_fast4_kernel<NS, TAIL, true>), grid, block, shm, st, prm, abort_flag, pairs);
+    hipLaunchKernelGGL((wn_fast4_kernel<NS, TAIL, true, DENSE>), grid, block, shm, st, prm, abort_flag, pairs);
   } else {
-    r = hipFuncSetAttribute((const void*)wn_fast4_kernel<NS, TAIL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    r = hipFuncSetAttribute((const void*)wn_fast4_kernel<NS, TAIL, false, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (r != hipSuccess) return r;
-    hipLaunchKernelGGL((wn_fast4_kernel<NS, TAIL, false>), grid, block, shm, st, prm, abort_flag, pairs);
+    hipLaunchKernelGGL((wn_fast4_kernel<NS, TAIL, false, DENSE>), grid, block, shm, st, prm, abort_flag, pairs);
   }
   return hipGetLastError();
 }
 
-hipError_t launch_fast4(const KernelChoice&, const Params& prm, int* abort_flag, hipStream_t st) {
+hipError_t launch_fast4(const KernelChoice& kc, const Params& prm, int* abort_flag, hipStream_t st) {
   const int D = prm.D;
-  if (D <= 32) return fast4_go<2, false>(prm, abort_flag, st);
-  if (D <= 64) return fast4_go<4, false>(prm, abort_flag, st);
-  if (D <= 96) return fast4_go<6, false>(prm, abort_flag, st);
-  if (D <= 100) return fast4_go<7, true>(prm, abort_flag, st);
+  if (kc.p1 == 0 /* CK_DENSE */) {
+    if (D <= 32) return fast4_go<2, false, true>(prm, abort_flag, st);
+    if (D <= 64) return fast4_go<4, false, true>(prm, abort_flag, st);
+    if (D <= 96) return fast4_go<6, false, true>(prm, abort_flag, st);
+    if (D <= 100) return fast4_go<7, true, true>(prm, abort_flag, st);
+    return hipErrorInvalidValue;
+  }
+  if (D <= 32) return fast4_go<2, false, false>(prm, abort_flag, st);
+  if (D <= 64) return fast4_go<4, false, false>(prm, abort_flag, st);
+  if (D <= 96) return fast4_go<6, false, false>(prm, abort_flag, st);
+  if (D <= 112) return fast4_go<7, false, false>(prm, abort_flag, st);
   return hipErrorInvalidValue;
 }
 
