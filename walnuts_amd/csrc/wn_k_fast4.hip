@@ -196,10 +196,12 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
   // X[t & 1] still holds P(t-2); the drift overwrites it with P(t), and P(t-1) stays for the level-1 check behind the gradient.  No
   // register copies.  A multinomial pick commanded at tick t copies P(t-3) (wn_fast.h, LAG = 3): P(t-2) goes to LDS at the top of every
   // tick (`pk`) and is read from there one tick later.
-  double X0[NS], X1[NS], v[NS], g[NS], VL[NS];
+  // ... and the velocity alternates the same way: the first half step of tick t writes V[t & 1] from V[(t-1) & 1], which therefore still
+  // holds the velocity the previous tick ended with -- the left endpoint's of a leaf pair at its second leaf (level-1 check).  No copy.
+  double X0[NS], X1[NS], V0[NS], V1[NS], g[NS];
   double pq0[NS], pv0[NS], pq1[NS], pv1[NS];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) { X0[s] = X1[s] = v[s] = g[s] = VL[s] = 0.0; pq0[s] = pv0[s] = pq1[s] = pv1[s] = 0.0; }
+  for (int s = 0; s < NS; ++s) { X0[s] = X1[s] = V0[s] = V1[s] = g[s] = 0.0; pq0[s] = pv0[s] = pq1[s] = pv1[s] = 0.0; }
   int ntr = 0;  // trace rows written (TRACE)
   double adiag[NS];  // (diagonal / standard Gaussian) the precisions of this lane's coordinates; tpar is all ones for the standard Gaussian
 #pragma unroll
@@ -215,7 +217,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
   // One tick.  PAR = t & 1 is a compile-time constant (the loop below is unrolled by two): the bookkeeper starts leaf pairs on even
   // ticks, so a stepping chain's leaf index has the tick's parity -- sub-tree checks (odd leaves), their prefetches, iteration starts
   // (odd ticks) and endpoint stores (even leaves) each live in one of the two bodies only.  Returns false when the run is over.
-  auto tick = [&](auto par_tag, double (&qc)[NS], double (&qn)[NS], const uint32_t t, const int t3) -> bool {  // t3 = t % 3
+  auto tick = [&](auto par_tag, double (&qc)[NS], double (&qn)[NS], double (&vi)[NS], double (&v)[NS], const uint32_t t, const int t3) -> bool {  // t3 = t % 3
     constexpr int PAR = decltype(par_tag)::value;
     constexpr int NSR = G::NSR, NK = G::NK, NP = NSR / 2;
     typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -296,7 +298,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     // ---- first half of the leapfrog step (adaptiveIntegrators.py:51-52 with hs = xi*h; v stays forward-time) ----
     const double hs = step ? c.hs : 0.0, hs2 = 0.5 * hs;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) { v[s] = v[s] + hs2 * g[s]; qn[s] = qc[s] + hs * v[s]; }
+    for (int s = 0; s < NS; ++s) { v[s] = vi[s] + hs2 * g[s]; qn[s] = qc[s] + hs * v[s]; }
     // iteration starts and end swaps replace the position this tick produces (qn; such ticks do not step: hs = 0).  qc is left alone: it
     // is the position of tick t-1, which a pick commanded at tick t+2 copies (the last leaf of a doubling can be picked while the end swap
     // of the next doubling is already under way)
@@ -441,7 +443,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     if (PAR == 1) {
       if (__any(nchk > 1)) {  // levels 1 (the leaf pair: registers) and 2 (LDS)
         double a1, a2, b1 = 0.0, b2 = 0.0;
-        dots(qc, VL, a1, a2);
+        dots(qc, vi, a1, a2);
         if (__any(nchk > 2)) {
           double qo[NS], vo[NS];
 #pragma unroll
@@ -479,8 +481,6 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     WN4_STAMP(2);
     // ---- statePush (:431,518): only sub-tree left endpoints are ever read back; they are even leaves ----
     if (PAR == 0) {
-#pragma unroll
-      for (int s = 0; s < NS; ++s) VL[s] = v[s];  // (a chain that does not step now sets VL again before its next odd leaf reads it)
       const bool ep = step && i >= 2 && (n & 3) == 0;
       if (__any(ep)) {
         if (ep) {
@@ -504,9 +504,9 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
   };
   int t3 = 0;
   for (uint32_t t = 0;; t += 2) {
-    if (!tick(std::integral_constant<int, 0>{}, X1, X0, t, t3)) break;
+    if (!tick(std::integral_constant<int, 0>{}, X1, X0, V1, V0, t, t3)) break;
     t3 = t3 == 2 ? 0 : t3 + 1;
-    if (!tick(std::integral_constant<int, 1>{}, X0, X1, t + 1u, t3)) break;
+    if (!tick(std::integral_constant<int, 1>{}, X0, X1, V0, V1, t + 1u, t3)) break;
     t3 = t3 == 2 ? 0 : t3 + 1;
   }
   WN4_STAMP_OUT(prm)
