@@ -66,8 +66,18 @@ struct Vecs {
   double* lds;  // null: the chain's vectors live in the workspace, strided by B; else: [V_NVEC][D] in LDS (one chain per workgroup)
   __device__ double& operator()(int v, int j) const { return lds ? lds[v * c.D + j] : c.vec[((size_t)v * c.D + j) * c.B + b]; }
 };
+// the same for wstep_auto_kernel, whose vectors are ALWAYS in LDS: an LDS-address-space pointer (ds_read / ds_write; through `Vecs` the
+// compiler has a generic pointer and every access of the kernel's hot loops was a FLAT instruction -- 373 of them)
+typedef __attribute__((address_space(3))) double lds_f64;
+struct VecsL {
+  const WCtx& c;
+  lds_f64* lds;
+  static constexpr int b = 0;  // (the kernel hands every function a one-chain view of the handle)
+  __device__ lds_f64& operator()(int v, int j) const { return lds[v * c.D + j]; }
+};
 
-__device__ double ke_of(const WCtx& c, const Vecs& V, int vr) {  // 0.5*dot(inv_mass, rho**2)  (:124)
+template <class VT>
+__device__ double ke_of(const WCtx& c, const VT& V, int vr) {  // 0.5*dot(inv_mass, rho**2)  (:124)
   double s = 0.0;
   for (int i = 0; i < c.D; ++i) s += c.im[i] * (V(vr, i) * V(vr, i));
   return 0.5 * s;
@@ -77,7 +87,8 @@ __device__ double mlogp(int ell, int es) {  // micro_steps_logp :197-208
 }
 
 // start one pass of stable_steps (:163-170) from (TH0, sgn*RH0) with (lp0, G0) known; TH = next evaluation point
-__device__ void stable_setup(const WCtx& c, const Vecs& V, WScal& s, double sgn) {
+template <class VT>
+__device__ void stable_setup(const WCtx& c, const VT& V, WScal& s, double sgn) {
   s.ell = 1 << s.n;
   s.step = c.macro_step / (double)s.ell;
   s.half = 0.5 * s.step;
@@ -88,21 +99,24 @@ __device__ void stable_setup(const WCtx& c, const Vecs& V, WScal& s, double sgn)
   s.k = 0;
   for (int i = 0; i < c.D; ++i) V(V_TH, i) = V(V_TH, i) + (s.step * c.im[i]) * V(V_RH, i);
 }
-__device__ void leap_setup(const WCtx& c, const Vecs& V, WScal& s) {  // leapfrog :88-91 (ell == 0 -> infinite step, Q9)
+template <class VT>
+__device__ void leap_setup(const WCtx& c, const VT& V, WScal& s) {  // leapfrog :88-91 (ell == 0 -> infinite step, Q9)
   s.step = c.macro_step / (double)s.lf_ell;
   s.half = 0.5 * s.step;
   for (int i = 0; i < c.D; ++i) { V(V_TH, i) = V(V_TH0, i); V(V_RH, i) = V(V_RH0, i) + s.half * V(V_G0, i); }
   s.k = 0;
   for (int i = 0; i < c.D; ++i) V(V_TH, i) = V(V_TH, i) + (s.step * c.im[i]) * V(V_RH, i);
 }
-__device__ void macro_setup(const WCtx& c, const Vecs& V, WScal& s) {  // :252-253
+template <class VT>
+__device__ void macro_setup(const WCtx& c, const VT& V, WScal& s) {  // :252-253
   s.p0 = s.lp0 - ke_of(c, V, V_RH0);
   s.stage = ST_SF; s.n = 0;
   stable_setup(c, V, s, 1.0);
 }
 
 // (lp, G) = (logp, grad) at TH have arrived: advance to the next evaluation point (true) or to the end (false)
-__device__ bool advance(const WCtx& c, const Vecs& V, WScal& s) {
+template <class VT>
+__device__ bool advance(const WCtx& c, const VT& V, WScal& s) {
   const int D = c.D;
   if (s.stage == ST_INIT) {  // logp / grad of the initial state (:326): orbit = [(theta, rho)], weights = [-H]
     for (int i = 0; i < D; ++i) {
@@ -176,7 +190,8 @@ __device__ bool advance(const WCtx& c, const Vecs& V, WScal& s) {
 
 // first evaluation point of an extension (:242-248): from the orbit's first state with the momentum negated, or
 // from its last state
-__device__ void extend_setup(const WCtx& c, const Vecs& V, WScal& s, int backward, int nmacro) {
+template <class VT>
+__device__ void extend_setup(const WCtx& c, const VT& V, WScal& s, int backward, int nmacro) {
   s.backward = backward; s.nmacro = nmacro; s.m = 0; s.sub_uturn = 0;
   for (int i = 0; i < c.D; ++i) {
     V(V_TH0, i) = backward ? V(V_THL, i) : V(V_THR, i);
@@ -249,9 +264,10 @@ __device__ void run_machine(const WCtx& c, const Vecs& V, WScal& s) {
 
 // the same with the chain's vectors contiguous in LDS (wstep_auto_kernel): evaluated in place, no private arrays (a kernel with
 // per-thread arrays in scratch memory runs only a fraction of its waves at a time)
-__device__ void run_machine_lds(const WCtx& c, const Vecs& V, WScal& s) {
+template <class VT>
+__device__ void run_machine_lds(const WCtx& c, const VT& V, WScal& s) {
   for (;;) {
-    s.lp = wn_target_eval(c.kind, c.D, c.tpar, &V(V_TH, 0), &V(V_G, 0));
+    s.lp = wn_target_eval_p(c.kind, c.D, c.tpar, &V(V_TH, 0), &V(V_G, 0));
     if (!advance(c, V, s)) break;
   }
 }
@@ -387,7 +403,7 @@ __global__ void wstep_auto_kernel(WCtx c0, int* lottery, uint64_t seed, uint32_t
   int* const lot = lottery + (size_t)b * c0.nmax;
   // the chain's vectors and scalars in LDS (D <= 64: checked on the host)
   WScal& s = sl;
-  Vecs V{c, 0, vl};
+  VecsL V{c, (lds_f64*)vl};
   const uint32_t chain = chain0 + (uint32_t)b;
   int sub1 = 0;
   double lse2[2] = {0.0, 0.0};
@@ -414,7 +430,7 @@ __global__ void wstep_auto_kernel(WCtx c0, int* lottery, uint64_t seed, uint32_t
       const double logu = log(rng_uniform(seed, chain, it, k++));
       const bool acc = logu < lse2[0] - lse2[1];
       const double uc = acc ? rng_uniform(seed, chain, it, k++) : 0.0;
-      if (commit_chain(c, 0, s, acc, uc, V.lds)) break;
+      if (commit_chain(c, 0, s, acc, uc, vl)) break;
     }
     for (int i = 0; i < c.D; ++i) {
       const double th = V(V_SEL, i);

@@ -11,7 +11,10 @@ namespace wn {
 // lpFun(q) -> lp, grad for any target kind, scalar loops (test / plumbing entry points; the
 // samplers evaluate their targets inside the fused kernels)
 enum { T_TT_CORRNORMAL = 8, T_TT_FUNNEL = 9 };
-__device__ inline double wn_target_eval(int kind, int D, const double* tpar, const double* x, double* g) {
+// (XP / GP: pointer types of the position and the gradient -- plain `double*`, or LDS-address-space pointers: through a generic pointer
+// to LDS every access is a FLAT instruction)
+template <class XP, class GP>
+__device__ inline double wn_target_eval_p(int kind, int D, const double* tpar, XP x, GP g) {
   const double logC = 0.91893853320467274178, log3 = 1.09861228866810969140;
   double r = 0.0;
   switch (kind) {
@@ -80,6 +83,8 @@ __device__ inline double wn_target_eval(int kind, int D, const double* tpar, con
   }
   return r;
 }
-
+__device__ inline double wn_target_eval(int kind, int D, const double* tpar, const double* x, double* g) {
+  return wn_target_eval_p<const double*, double*>(kind, D, tpar, x, g);
+}
 
 }  // namespace wn
