@@ -147,35 +147,51 @@ def python_reference_cpu(key):
         return None
 
 
-def cpu_baseline(spec, budget_s=10.0, max_procs=None):
-    """Time the CPU oracle on the host cores, one chain per process, on a bounded sample of the same workload."""
+def cpu_baselines(specs, budgets):
+    """Time the CPU oracle on ALL host cores -- the same worker-process count for every configuration, so the GPU/CPU ratios
+    of different configurations compare -- one chain per process at a time, on a bounded sample of each workload (`budgets`
+    seconds each).  One pool serves every configuration.  Returns {spec name: record}; every record states the all-core rate
+    (`value`, `cores`) and the per-core rate beside it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     ol.build()
     cores = os.cpu_count() or 1
-    if max_procs:
-        cores = min(cores, max_procs)
-    q0, iters = spec["q0"], spec["iters"]
-    okw = dict(spec["oracle"])
-    s1, t1 = _cpu_worker((spec["target"], spec["tpar"], q0[0], 0, 1, okw))  # calibrate on one chain, one iteration
-    per_iter = max(t1, 1e-5)
-    n_it = int(max(1, min(iters, budget_s / per_iter)))
-    # chains per core: enough of them to fill the budget when a whole run of one chain is shorter than it
-    k = int(max(1, min(budget_s / (n_it * per_iter), (q0.shape[0] + cores - 1) // cores)))
-    nproc = min(cores, q0.shape[0])
-    nchain = min(q0.shape[0], nproc * k)
-    with mp.get_context("fork").Pool(nproc) as pool:
-        pool.map(_cpu_worker, [(spec["target"], spec["tpar"], q0[c], c, 1, dict(okw, M=min(3, okw.get("M", 10)))) for c in range(nproc)])  # start the workers
-        t0 = time.perf_counter()
-        res = pool.map(_cpu_worker, [(spec["target"], spec["tpar"], q0[c], c, n_it, okw) for c in range(nchain)], chunksize=1)
-        wall = time.perf_counter() - t0
-    units = sum(r[0] for r in res)
-    C_all = q0.shape[0]
-    return {"value": units / wall, "unit": spec["unit"], "cores": nproc, "kind": "port",
-            "sample": f"the first {nchain} of the {C_all} chains ({100.0 * nchain / C_all:.2f} %) x {n_it} of the {iters} iterations "
-                      f"({units:.3g} units, {wall:.1f} s), {nproc} worker processes, one chain at a time each (oracle/libwalnuts_oracle.so, the C "
-                      f"restatement pinned to the Python reference)",
-            "python_reference": python_reference_cpu(spec.get("pyref"))}
+    out = {}
+    with mp.get_context("fork").Pool(cores) as pool:
+        sp0 = specs[0]
+        pool.map(_cpu_worker, [(sp0["target"], sp0["tpar"], sp0["q0"][c % sp0["q0"].shape[0]], c % sp0["q0"].shape[0], 1,
+                                dict(sp0["oracle"], M=min(3, sp0["oracle"].get("M", 10)))) for c in range(cores)])  # start the workers
+        for spec, budget_s in zip(specs, budgets):
+            try:
+                q0, iters = spec["q0"], spec["iters"]
+                okw = dict(spec["oracle"])
+                s1, t1 = _cpu_worker((spec["target"], spec["tpar"], q0[0], 0, 1, okw))  # calibrate on one chain, one iteration
+                per_iter = max(t1, 1e-5)
+                n_it = int(max(1, min(iters, budget_s / per_iter)))
+                # chains per core: enough of them to fill the budget when a whole run of one chain is shorter than it
+                k = int(max(1, min(budget_s / (n_it * per_iter), (q0.shape[0] + cores - 1) // cores)))
+                nproc = min(cores, q0.shape[0])
+                nchain = min(q0.shape[0], nproc * k)
+                t0 = time.perf_counter()
+                res = pool.map(_cpu_worker, [(spec["target"], spec["tpar"], q0[c], c, n_it, okw) for c in range(nchain)], chunksize=1)
+                wall = time.perf_counter() - t0
+                units = sum(r[0] for r in res)
+                busy = sum(r[1] for r in res)  # summed in-worker seconds: units / busy = the rate of ONE core working alone on its chain
+                C_all = q0.shape[0]
+                out[spec["name"]] = {
+                    "value": units / wall, "unit": spec["unit"], "cores": nproc, "kind": "port",
+                    "per_core": units / busy, "per_core_note": "units / summed in-worker seconds (one chain at a time per worker process)",
+                    "sample": f"the first {nchain} of the {C_all} chains ({100.0 * nchain / C_all:.2f} %) x {n_it} of the {iters} iterations "
+                              f"({units:.3g} units, {wall:.1f} s), {nproc} worker processes = every host thread, one chain at a time each "
+                              f"(oracle/libwalnuts_oracle.so, the C restatement pinned to the Python reference)",
+                    "python_reference": python_reference_cpu(spec.get("pyref"))}
+            except Exception as ex:
+                out[spec["name"]] = {"error": repr(ex)}
+    return out
+
+
+def cpu_baseline(spec, budget_s=10.0):
+    return cpu_baselines([spec], [budget_s])[spec["name"]]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -224,10 +240,12 @@ def side_traffic(key, field):
 def _self_launch(args):
     """`python bench.py --gpus N` without torchrun: this process has not touched torch or HIP yet, so it
     may start children.  Starts one fresh child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the
-    same command line), after one single-GPU child of the same workload whose value becomes the N = 1
-    reference of `weak_scaling_eff`; relays rank 0's JSON line.  Every child is polled: the first one that
+    same command line) and relays rank 0's JSON line.  Every child is polled: the first one that
     exits non-zero (or the time limit) ends the others -- a crashed rank would otherwise leave its siblings in
-    init_process_group / all_reduce until the collective's own timeout -- and the parent exits non-zero."""
+    init_process_group / all_reduce until the collective's own timeout -- and the parent exits non-zero.
+    The N = 1 reference of `weak_scaling_eff` is `--n1-value`, or (`--n1-ref`) one more single-GPU child of the same
+    workload started AFTER the N ranks have finished: the N-rank line never waits for it, and if it fails or runs
+    out of time the line is printed without the two fields."""
     import socket
     import subprocess
     n = args.gpus
@@ -236,22 +254,12 @@ def _self_launch(args):
         port = s_.getsockname()[1]
     base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
-    if not args.no_n1_ref:
-        try:
-            r = subprocess.run(argv + ["--gpus", "1", "--no-extras", "--no-cpu-baseline"], env=dict(base, WN_BENCH_CHILD="1"),
-                               stdout=subprocess.PIPE, text=True, timeout=args.child_timeout)
-            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if r.returncode == 0 and lines:
-                base["WN_BENCH_N1_VALUE"] = repr(float(json.loads(lines[-1])["value"]))
-            else:
-                print(f"bench.py: the N=1 reference run failed (rc {r.returncode}); continuing without it", file=sys.stderr)
-        except subprocess.TimeoutExpired:
-            print("bench.py: the N=1 reference run timed out; continuing without it", file=sys.stderr)
+    t_begin = time.monotonic()
     procs = []
     for rank in range(n):
         env = dict(base, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), WN_BENCH_CHILD="1")
         procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if rank == 0 else sys.stderr, text=True))
-    deadline = time.monotonic() + args.child_timeout
+    deadline = t_begin + args.child_timeout
     bad = None
     while True:
         rcs = [p_.poll() for p_ in procs]
@@ -279,13 +287,42 @@ def _self_launch(args):
               else f"bench.py: the ranks did not finish within {args.child_timeout:.0f} s and were ended", file=sys.stderr)
         sys.exit(abs(bad[1]) or 1)
     out0 = procs[0].stdout.read()
+    n1 = args.n1_value
+    if n1 is None and args.n1_ref:
+        left = deadline - time.monotonic()
+        try:
+            r = subprocess.run(argv + ["--gpus", "1", "--no-extras", "--no-cpu-baseline"], env=dict(base, WN_BENCH_CHILD="1"),
+                               stdout=subprocess.PIPE, text=True, timeout=max(1.0, left))
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode == 0 and lines:
+                n1 = float(json.loads(lines[-1])["value"])
+            else:
+                print(f"bench.py: the N=1 reference run failed (rc {r.returncode}); the line goes out without it", file=sys.stderr)
+        except subprocess.TimeoutExpired:
+            print("bench.py: the N=1 reference run timed out; the line goes out without it", file=sys.stderr)
+    if n1 is not None:
+        keep = []
+        for l in out0.splitlines():
+            if l.startswith("{"):
+                try:
+                    o = json.loads(l)
+                    o["n1_value_same_invocation"] = n1
+                    if isinstance(o.get("value"), (int, float)) and n1 > 0:
+                        o["weak_scaling_eff"] = o["value"] / (n * n1)
+                    l = json.dumps(o)
+                except Exception:
+                    pass
+            keep.append(l)
+        out0 = "\n".join(keep) + "\n"
     sys.stdout.write(out0)
     sys.stdout.flush()
     sys.exit(0)
 
 
-def _dist_setup():
-    """One process per GPU (torch.distributed.run env); returns rank, world, device, collective device, dist."""
+def _dist_setup(force=False):
+    """One process per GPU (torch.distributed.run env); returns rank, world, device, collective device, dist.
+    `force`: initialise the process group (RCCL) also when WORLD_SIZE is 1 -- the one-GPU box then runs ncclCommInitRank and
+    every collective of the N-rank path on device tensors."""
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -294,18 +331,24 @@ def _dist_setup():
     ndev = torch.cuda.device_count()
     if ndev < 1:
         sys.exit("bench.py needs a ROCm GPU (the product has no CPU path)")
-    if world > 1:
+    if world > 1 or force:
         if backend == "nccl" and local_rank >= ndev:
             print(f"bench.py: LOCAL_RANK {local_rank} but only {ndev} device(s) are visible", file=sys.stderr)
             sys.exit(2)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_PORT" not in os.environ:  # plain `python bench.py --force-collectives`: a one-rank group of its own
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank % ndev)
         fail = os.environ.get("WN_BENCH_FAIL_RANK")  # test hook: this rank dies before the rendezvous (tests/test_host_logic.py)
         if fail is not None and int(fail) == rank:
             sys.exit(3)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % ndev))
         else:
             dist.init_process_group(backend)
     else:
@@ -314,21 +357,17 @@ def _dist_setup():
     return rank, world, dev, (dev if backend == "nccl" else torch.device("cpu")), dist
 
 
-def _scaling_fields(dist, world, cdev, value, kernel_ms_avg, units_rank):
+def _scaling_fields(dist, world, cdev, value, kernel_ms_avg, units_rank, coll=False):
     """Per-rank kernel time and work (one small all_gather outside the timed region) and, when bench.py
     launched the ranks itself, the weak-scaling efficiency against the single-GPU run of the same invocation."""
     import torch
-    if world == 1:
+    if world == 1 and not coll:
         return {}
     mine = torch.tensor([kernel_ms_avg, units_rank], dtype=torch.float64, device=cdev)
     allr = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allr, mine)
     out = {"per_rank_kernel_ms": [float(a[0].item()) for a in allr],
            "per_rank_units": [float(a[1].item()) for a in allr]}
-    n1 = os.environ.get("WN_BENCH_N1_VALUE")
-    if n1:
-        out["n1_value_same_invocation"] = float(n1)
-        out["weak_scaling_eff"] = value / (world * float(n1))
     return out
 
 
@@ -451,8 +490,15 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements (BASELINE configs 3, 4, 5 at SURVEY 8d size; C = 1024; diagonal precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-n1-ref", action="store_true",
-                    help="self-launched --gpus N > 1: skip the single-GPU run that weak_scaling_eff refers to")
+    ap.add_argument("--n1-ref", action="store_true",
+                    help="self-launched --gpus N > 1: AFTER the N ranks have finished, also run the same workload on one GPU and add "
+                         "n1_value_same_invocation / weak_scaling_eff to the line (off by default: it doubles the time of the invocation, "
+                         "and the driver computes efficiency from its own N = 1 run)")
+    ap.add_argument("--n1-value", type=float, default=None, help="the N = 1 value of this workload measured elsewhere (fills weak_scaling_eff)")
+    ap.add_argument("--no-n1-ref", action="store_true", help="(accepted for compatibility; the N = 1 reference run is opt-in now: --n1-ref)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="initialise the process group (RCCL) and run every collective of the N-rank path -- barrier, MAX / SUM all_reduce, "
+                         "all_gather of per-rank fields, the final gather of draws -- also with ONE rank: exercises RCCL on a one-GPU box")
     ap.add_argument("--gather", default="generated", choices=["generated", "identity"],
                     help="what the final gather moves: generated(q) = [q0, sum q^2] (kilobytes) or the identity draws "
                          "(SURVEY 8e: 0.83 GB per GPU for config 4 at 100 iterations)")
@@ -485,21 +531,20 @@ def main():
                       workload_spec("stockwatson", sw_run="fixed"), workload_spec("stockwatson", sw_run="R2P")]
     cpu = None
     side_cpu = {}
-    if world == 1 and not args.no_cpu_baseline:  # forks workers: before any GPU init
+    if rank == 0 and not args.no_cpu_baseline:  # forks workers: before any GPU init (N > 1: rank 0 only; the others wait in the rendezvous)
         t_ = time.perf_counter()
-        cpu = cpu_baseline(spec, 12.0)
-        for sp in side_specs:  # (a bounded sample on at most 64 worker processes each: the default run must stay within minutes)
-            try:
-                side_cpu[sp["name"]] = cpu_baseline(sp, 3.0, max_procs=64)
-            except Exception as ex:
-                side_cpu[sp["name"]] = {"error": repr(ex)}
+        # every configuration on every host thread (one pool); side configurations get a shorter sample: the default run must stay within minutes
+        recs = cpu_baselines([spec] + side_specs, [12.0] + [3.0] * len(side_specs))
+        cpu = recs[spec["name"]]
+        side_cpu = {sp["name"]: recs[sp["name"]] for sp in side_specs}
         print(f"bench.py: CPU baselines took {time.perf_counter() - t_:.1f} s", file=sys.stderr)
 
     import torch
-    rank, world, dev, cdev, dist = _dist_setup()
+    rank, world, dev, cdev, dist = _dist_setup(args.force_collectives)
+    coll = world > 1 or args.force_collectives  # the collectives run (RCCL also with one rank when forced)
 
     def barrier():
-        if world > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -510,19 +555,19 @@ def main():
     elapsed = m["elapsed"]
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     tot = torch.tensor([m["units"]], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if coll:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
     units_all = float(tot.item())
     avg_ms = float(np.mean(m["kernel_ms"]))
-    scal = _scaling_fields(dist, world, cdev, units_all / elapsed, avg_ms, m["units"])
+    scal = _scaling_fields(dist, world, cdev, units_all / elapsed, avg_ms, m["units"], coll)
 
     # final gather of draws to rank 0 (the only data collective; RCCL over xGMI), timed apart
     gather_ms = 0.0
     gather_bytes = 0
     draws = m["draws"]
-    if world > 1:
+    if coll:
         from walnuts_amd.dist import gather_draws
         torch.cuda.synchronize(dev)
         g0 = time.perf_counter()
@@ -545,12 +590,16 @@ def main():
                        "kernel": eng.kernel_name, "sharding": f"chains x{world}, no data-path collective"},
             ("leapfrog_steps_per_launch_per_gpu" if spec["bound"] == "mfma" else "gradient_evaluations_per_launch_per_gpu"): upl,
             "kernel_ms_avg": avg_ms, "kernel_ms": m["kernel_ms"], "gather_ms": gather_ms, "gather_bytes_per_rank": gather_bytes,
+            "collectives": (os.environ.get("WN_DIST_BACKEND", "nccl") + (" (forced with one rank)" if world == 1 else "")) if coll else None,
             **scal, "roofline": roof,
         }
         if not headline:
             out.update({k: v for k, v in side_record(spec, m, eng.kernel_name, None).items()
                         if k in ("min", "max", "launch_values", "busiest_chain_evals", "chain_occupancy", "tick_us", "tick_over_floor",
                                  "split_ticks_per_launch", "kernel_launches_per_s")})
+        if world > 1 and args.n1_value:  # (the self-launcher's parent fills these itself; this is the torch.distributed.run form)
+            out["n1_value_same_invocation"] = args.n1_value
+            out["weak_scaling_eff"] = out["value"] / (world * args.n1_value)
         out["ess_per_sec"] = ess_of(spec, draws, elapsed / args.steps)
         import hashlib
         out["draws_sha256"] = hashlib.sha256(np.ascontiguousarray(draws.cpu().numpy()).tobytes()).hexdigest()  # of the gathered draws [C_total, iters+1, dg]
@@ -603,7 +652,7 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if coll:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -617,6 +666,9 @@ def main_dry_run():
     fail = os.environ.get("WN_BENCH_FAIL_RANK")
     if fail is not None and int(fail) == rank:
         sys.exit(3)
+    slp = os.environ.get("WN_BENCH_SLEEP_RANK")  # test hook: this rank sleeps through the rendezvous, so nobody finishes
+    if slp is not None and int(slp) == rank:
+        time.sleep(600.0)
     if world > 1:
         dist.init_process_group("gloo")
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
@@ -626,7 +678,7 @@ def main_dry_run():
         g = gather_draws(g, dst=0)
     if rank == 0:
         print(json.dumps({"metric": "dry run", "value": float(t.item()), "n_gpus": world, "gathered_rows": int(g.shape[0]),
-                          "n1_value_same_invocation": float(os.environ.get("WN_BENCH_N1_VALUE", "nan"))}), flush=True)
+                          }), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

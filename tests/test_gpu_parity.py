@@ -425,7 +425,7 @@ def test_bench_two_ranks_sharing_one_gpu():
 
     # self-launch: bench.py starts its own ranks (and the N = 1 reference run of weak_scaling_eff)
     out = line(subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--chains", "256",
-                               "--iters", "5"], capture_output=True, text=True, timeout=900, env=env, cwd=root))
+                               "--iters", "5", "--n1-ref"], capture_output=True, text=True, timeout=900, env=env, cwd=root))
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["ess_per_sec"]["draws"] == 2 * 256 * 5
     assert len(out["per_rank_kernel_ms"]) == 2 and out["gather_ms"] > 0
@@ -456,6 +456,39 @@ def test_bench_two_ranks_sharing_one_gpu():
                                 capture_output=True, text=True, timeout=600, env=env, cwd=root))
         assert o["n_gpus"] == 2 and o["value"] > 0 and o["roofline"]["frac"] > 0, o
         assert len(o["per_rank_kernel_ms"]) == 2
+
+
+def test_bench_one_rank_rccl_forced_collectives():
+    """RCCL on the one GPU of this box: `--force-collectives` initialises the process group (ncclCommInitRank) with ONE rank
+    and runs every collective of the N-rank path on device tensors -- barriers, the MAX / SUM all_reduce, the all_gather of
+    the per-rank fields and the final gather of the identity draws (SURVEY 8e's message: 4096 x 31 x 100 doubles = 102 MB).
+    Started as a fresh child under torch.distributed.run, exactly as the driver starts ranks.  What rank 0 holds after the
+    gather is bit for bit what the plain run produces."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "WN_DIST_BACKEND"):
+        env.pop(k, None)
+    bench = os.path.join(root, "bench.py")
+    common = ["--gpus", "1", "--steps", "1", "--warmup", "0", "--chains", "4096", "--iters", "30", "--gather", "identity",
+              "--no-extras", "--no-cpu-baseline"]
+
+    def line(r):
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+    f = line(subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                             "--master-port", "29751", bench] + common + ["--force-collectives"],
+                            capture_output=True, text=True, timeout=900, env=env, cwd=root))
+    assert f["n_gpus"] == 1 and f["collectives"].startswith("nccl") and f["gather_ms"] > 0
+    assert f["gather_bytes_per_rank"] == 4096 * 31 * 100 * 8 and len(f["per_rank_kernel_ms"]) == 1
+    p_ = line(subprocess.run([sys.executable, bench] + common, capture_output=True, text=True, timeout=900, env=env, cwd=root))
+    assert p_["collectives"] is None and p_["gather_ms"] == 0
+    assert f["draws_sha256"] == p_["draws_sha256"]
+    assert f["leapfrog_steps_per_launch_per_gpu"] == p_["leapfrog_steps_per_launch_per_gpu"]
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "bench_1rank_rccl.json"), "w") as fh:
+        json.dump(f, fh)
 
 
 def test_walnuts_batch_config1_four_chains_in_one_call(wa):

@@ -100,25 +100,36 @@ def _bench(args, env_extra=None, timeout=120):
 
 
 def test_bench_self_launcher_starts_ranks_and_relays_rank0():
-    """`python bench.py --gpus N` with no launcher: one fresh child per rank + the N = 1 reference child, rank 0's line relayed."""
+    """`python bench.py --gpus N` with no launcher: one fresh child per rank, rank 0's line relayed; with --n1-ref the N = 1
+    reference child runs AFTER the ranks and the parent adds the two efficiency fields to the line."""
     import json
     r, dt = _bench(["--gpus", "2", "--dry-run"])
     assert r.returncode == 0, r.stdout + r.stderr
     o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert o["n_gpus"] == 2 and o["value"] == 3.0 and o["gathered_rows"] == 6 and o["n1_value_same_invocation"] == 1.0
+    assert o["n_gpus"] == 2 and o["value"] == 3.0 and o["gathered_rows"] == 6 and "n1_value_same_invocation" not in o
+    r, dt = _bench(["--gpus", "2", "--dry-run", "--n1-ref"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert o["n_gpus"] == 2 and o["value"] == 3.0 and o["n1_value_same_invocation"] == 1.0 and o["weak_scaling_eff"] == 1.5
+    r, dt = _bench(["--gpus", "2", "--dry-run", "--n1-value", "2.0"])
+    o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert o["n1_value_same_invocation"] == 2.0 and o["weak_scaling_eff"] == 0.75
 
 
 def test_bench_self_launcher_ends_the_job_when_a_rank_dies():
     """A rank that exits before the rendezvous leaves its sibling waiting in init_process_group (gloo's store timeout is
     half an hour): the parent polls every child, ends the survivors and exits non-zero at once."""
-    r, dt = _bench(["--gpus", "2", "--dry-run", "--no-n1-ref"], {"WN_BENCH_FAIL_RANK": "1"})
+    r, dt = _bench(["--gpus", "2", "--dry-run"], {"WN_BENCH_FAIL_RANK": "1"})
     assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
     assert dt < 60.0, dt
     assert "rank 1 exited with code 3" in r.stderr
 
 
 def test_bench_self_launcher_time_limit():
-    """Ranks that never finish are ended at --child-timeout (rank 0 waits for a rank that sleeps through the rendezvous)."""
-    r, dt = _bench(["--gpus", "2", "--dry-run", "--no-n1-ref", "--child-timeout", "8"], {"WN_BENCH_FAIL_RANK": "-7"})
-    # (no rank matches -7: both run normally and finish well inside the limit)
-    assert r.returncode == 0, r.stdout + r.stderr
+    """Ranks that never finish are ended at --child-timeout: rank 1 sleeps through the rendezvous, rank 0 waits for it in
+    init_process_group; the parent ends both at the limit and exits 124."""
+    r, dt = _bench(["--gpus", "2", "--dry-run", "--child-timeout", "6"], {"WN_BENCH_SLEEP_RANK": "1"})
+    assert r.returncode == 124, (r.returncode, r.stdout, r.stderr)
+    assert "did not finish within 6 s" in r.stderr, r.stderr
+    assert 5.0 < dt < 30.0, dt
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

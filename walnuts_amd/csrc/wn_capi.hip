@@ -675,6 +675,7 @@ static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
   HIPCHK(e, hipMemsetAsync(e->kabort, 0, sizeof(int), st));
   hipError_t r = (!coop_legacy && !fast_legacy && fast4_eligible(e->kc, adapt, warm, p_)) ? launch_fast4(e->kc, p_, e->kabort, st)
                : (!coop_legacy && fast_eligible(e->kc, adapt, warm, p_)) ? launch_fast(e->kc, p_, e->kabort, st)
+               : orbit_eligible(e->kc, adapt, warm, p_) ? launch_orbit(e->kc, p_, st)
                : e->kc.layout == 0 ? launch_lane(e->kc, adapt, warm, p_, st)
                : e->kc.layout == 1 ? launch_coop(e->kc, adapt, warm, p_, st) : launch_wave(e->kc, adapt, warm, p_, st);
   if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }

@@ -1,0 +1,623 @@
+// wn_k_orbit.hip -- one chain per wavefront for targets of at most 16 dimensions (funnel10: BASELINE config 3; the 2-D toys of
+// targetDistr.py), plain sampling runs with adaptLeapFrogD / adaptLeapFrogR2P / fixedLeapFrog: TRAJECTORY FIRST, BOOKKEEPING IN BATCHES.
+//
+// What bounds these launches is one wave's serial latency: the launch lasts as long as its busiest chain (config 3: 3.9e5 gradient
+// evaluations against a median of 2.2e4), and that chain is NOT a deep-refinement chain -- 94 % of its macro steps have If = 0 and
+// take one evaluation (or four when adaptLeapFrogR2P re-integrates at c = 1); it is a LONG-ORBIT chain, ~580 leaves per iteration.
+// In the one-stream engine (wn_chain.h run_nested) 4.8 k of the 6.9 k cycles of such a macro step are the NUTS bookkeeping of
+// WALNUTS.py:392-587 -- weights, exp, the multinomial draw, U-turn dots, diagnostics -- executed as scalar code replicated over the
+// wave, one instruction per ~5 cycles, between two macro steps of a trajectory that does not depend on it.
+//
+// Here the wave alternates two phases over a BLOCK of 16 leaves (leaf n of a doubling is entry n & 15 of a ring in LDS):
+//   T phase   the integrator calls of up to 16 consecutive leaves back to back (adaptiveIntegrators.py:49-59 / 65-137 / 361-475):
+//             step sizes and the R2P uniform come out of the wave's window of uniforms at the index the reference's draw order gives
+//             them, assuming every leaf takes its multinomial draw exactly like the leaf before it did (WALNUTS.py:426: the uniform is
+//             drawn only when WnewSum > exp(-699)); each leaf's (q', v', lp, H, If, Ib, c, lwt, nEval, h, its multinomial uniform)
+//             goes to the ring.
+//   R phase   the bookkeeping of those leaves LANE-PARALLEL, lane k = leaf k: the running sums the reference builds leaf by leaf
+//             (lwtSum, orbitLen_, timeLen, WnewSum) are serial prefix sums in the reference's order -- x_k + (prefix of k-1), one DPP
+//             row shift per leaf, three quantities in three rows of the register -- so every partial sum has the reference's
+//             bits; exp, the acceptance ratio's division and the draw test run once for 16 leaves; the sub-tree U-turn checks of
+//             levels 1..4 (subTreePlan, WALNUTS.py:22-41: 8 + 4 + 2 + 1 per block, all of them between ring entries), the deeper
+//             levels of the block's last leaf (left states from the slot store) and the full-orbit check are one lane each; wavefront
+//             ballots turn them into "first leaf whose check fired", "first non-finite energy", "first leaf whose draw differed from
+//             the prediction" and "last leaf picked".  Leaves behind the first such event are discarded: a sub-U-turn or a non-finite
+//             energy ends the iteration there exactly as WALNUTS.py:316-319 / 597-605 do; a mispredicted draw restarts the T phase
+//             at the next leaf with the corrected draw index (the state is in the ring).
+// Draw order, nevalF / nevalB, If / Ib / c and every diagnostic are the reference's: leaves the T phase ran ahead of an event are
+// never counted.  The arithmetic of a micro step and of every sum is the one-stream engine's, so the two kernels agree bit for bit
+// (tests/test_gpu_orbit.py) -- WN_ORBIT_LEGACY=1 runs the old kernel.
+//
+// LDS per chain (doubles): ring q / v 2 x 256, ring scalars 80 + 48 (ints), passive orbit end (q, v, g) 48, two proposals (q) 32,
+// sub-tree slots (levels >= 5 and leaf 0) 32 (M + 1): 9.1 KB at M = 12 -- 16 chains per CU, all 4096 resident.
+// The proposal keeps q only: the gradient at the start of an iteration is re-evaluated, as the reference does (WALNUTS.py:249).
+#include "wn_launch.h"
+#include "wn_policy_wave.h"
+
+namespace wn {
+
+namespace orbit {
+typedef __attribute__((address_space(3))) double lds_d;
+typedef __attribute__((address_space(3))) int lds_i;
+enum {
+  RQ = 0, RV = 256, SH = 512, SLP = 528, SLW = 544, SHH = 560, SUP = 576, SI = 592 /* 5 x 16 ints */, COLDQ = 640, COLDV = 656, COLDG = 672,
+  PROP = 688, SLOT = 720
+};
+__host__ __device__ constexpr int lds_doubles(int M) { return SLOT + 32 * (M + 1); }
+
+// row_shr:1 with zero fill at the first lane of each row of 16
+__device__ __forceinline__ double shr1(double x) { return wn_dpp0<0x111>(x); }
+
+template <int CTRL>
+__device__ __forceinline__ int dppi(int x, int oob) { return __builtin_amdgcn_update_dpp(oob, x, CTRL, 0xF, 0xF, false); }
+// reductions over each row of 16 lanes (every lane of a row gets its row's result)
+__device__ __forceinline__ int rowsum_i(int x) {
+  x += dppi<0xB1>(x, 0); x += dppi<0x4E>(x, 0); x += dppi<0x141>(x, 0); x += dppi<0x140>(x, 0);
+  return x;
+}
+__device__ __forceinline__ int rowmin_i(int x) {
+  x = min(x, dppi<0xB1>(x, x)); x = min(x, dppi<0x4E>(x, x)); x = min(x, dppi<0x141>(x, x)); x = min(x, dppi<0x140>(x, x));
+  return x;
+}
+__device__ __forceinline__ double rowmin_d(double x) {  // fmin: a NaN operand is ignored (Hn < Hmin ? Hn : Hmin)
+  x = fmin(x, wn_dpp<0xB1>(x)); x = fmin(x, wn_dpp<0x4E>(x)); x = fmin(x, wn_dpp<0x141>(x)); x = fmin(x, wn_dpp<0x140>(x));
+  return x;
+}
+__device__ __forceinline__ int rl_i(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ __forceinline__ int uni_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
+}  // namespace orbit
+
+template <class Tgt, int INTEG>
+__global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
+  using namespace orbit;
+  extern __shared__ double wn_orbit_lds[];
+  lds_d* const L = (lds_d*)wn_orbit_lds;
+  lds_i* const LI = (lds_i*)(L + SI);
+  const int lane = threadIdx.x;
+  const int k16 = lane & 15;
+  const int row = lane >> 4;
+  const int cl = blockIdx.x;
+  const uint32_t cg = prm.chain0 + (uint32_t)cl;
+  const uint32_t seedlo = (uint32_t)prm.seed, seedhi = (uint32_t)(prm.seed >> 32);
+  const int D = prm.D, M = prm.M, minC = prm.minC, maxC = prm.maxC;
+  Tgt tgt;
+  tgt.init(prm, lane, nullptr);
+  for (int k = lane; k < lds_doubles(M); k += 64) L[k] = 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- the wave's window of uniforms: lane l holds uniform 2 * rb_base + l of iteration rb_iter (wn_rng.h stream 0) ----
+  uint32_t rb_iter = 0xFFFFFFFFu, rb_base = 0u;
+  double ru0 = 0.0;
+  auto rng_ensure = [&](uint32_t it, uint32_t k) {  // uniforms k .. k+7 inside the window afterwards
+    const uint32_t blk = (uint32_t)uni_i((int)(k >> 1));
+    if (it != rb_iter || blk - rb_base > 28u) {
+      rb_iter = it; rb_base = blk;
+      Philox4 r = philox4x32_10(blk + (uint32_t)(lane >> 1), it, cg, 0u, seedlo, seedhi);
+      ru0 = (lane & 1) ? u53(r.w[2], r.w[3]) : u53(r.w[0], r.w[1]);
+    }
+  };
+  auto uni = [&](uint32_t k) -> double { return wn_readlane(ru0, (int)((uint32_t)uni_i((int)k) - 2u * rb_base)); };
+  // the sums of a micro step, exactly as the one-stream engine forms them (WavePolicy::reduce<2>, VLDS): two quantities in the
+  // rows of one register, one row reduction
+  auto reduce2 = [&](double& a, double& b) {
+    double r = wn_pack32(a, b);
+    r = wn_rowsum16(r);
+    a = wn_readlane(r, 0) + 0.0;
+    b = wn_readlane(r, 32) + 0.0;
+  };
+  auto reduce1 = [&](double a) -> double { return wn_readlane(wn_rowsum16(a), 0) + 0.0; };
+
+  // ---- chain state ----
+  // vectors: one element per lane (rows 1..3 hold copies of row 0); active end of the orbit, v in forward-time orientation
+  double qa, va = 0.0, ga;
+  // scalars of WALNUTS.py:189-695 (uniform over the wave)
+  double H0 = 0.0, Ha = 0.0, Hb = 0.0, lp0, WoldSum = 1.0, WnewSum = 0.0, lwtSumf = 0.0, lwtSumb = 0.0, h2 = 0.0;
+  double orbitLen_ = 0.0, orbitLenSam_ = 0.0, indexStat_ = 0.0, indexStatOld_ = 0.0, timeLenF_ = 0.0, timeLenB_ = 0.0;
+  double minlw = INFINITY, maxlw = -INFINITY, Hmin = INFINITY, Hmax = -INFINITY, lpP = 0.0, lpPL = 0.0;
+  double gen_sum = 0.0;
+  int iter = 1, i = 0, xi = 1, a = 0, b = 0, n = 0, nleaf = 1;
+  uint32_t Bbits = 0, ku = 0;
+  int nevalF = 0, nevalB = 0, L_ = 0, Lold_ = 0, NdS = 0, NdC = 0, maxFint = 0, maxBint = 0, stopCode = 0;
+  int minIf = 1 << 30, maxIf = -(1 << 30), minc = 1 << 30, maxc = -(1 << 30), nneq = 0, nzero = 0, nused = 0;
+  int ip = 0, ipl = 0;
+  bool Hnan = false, bothEndsPassive = false;
+  bool predF = true, predB = true;  // "the next leaf in this direction takes its multinomial draw"
+  const bool inrange = cl < prm.C;
+  const int clc = inrange ? cl : 0;
+  const double dlt = prm.delta, Hc = prm.H;
+
+  auto draw_h = [&](uint32_t k) -> double {  // numpy legacy uniform(low, high) = low + (high-low)*U  (WALNUTS.py:298,395)
+    const double low = Hc * (1 - prm.s), high = Hc * (1 + prm.s);
+    return low + (high - low) * uni(k);
+  };
+  auto row0_store = [&](int off, double x) { if (lane < 16) L[off + lane] = x; };
+  auto row_load = [&](int off) -> double { return L[off + k16]; };
+
+  // samples[:, it] = generated(q)
+  auto emit_generated = [&](int it, double qP) {
+    double* rowp = prm.samples + ((size_t)clc * (prm.numIter + 1) + it) * prm.dg;
+    if (prm.generated == G_Q0_SUMSQ) {
+      const double s = reduce1(qP * qP);
+      if (lane == 0) { rowp[0] = qP; rowp[1] = s; }
+    } else {
+      // (arithmetic, not a select of the two kernel arguments: hipcc turned the select into a two-entry array in scratch)
+      const int fk = (int)(prm.generated == G_FIRSTK);
+      const int kk = fk * prm.gen_k + (1 - fk) * D;
+      if (lane < 16 && lane < kk && lane < D) rowp[lane] = qP;
+    }
+  };
+
+  // ---- q_c = q0; f0, grad0 = lpFun(q0)  (WALNUTS.py:177,249) ----
+  qa = (k16 < D && inrange) ? prm.q0[(size_t)clc * D + k16] : 0.0;
+  {
+    double lp_part = tgt.grad(&qa, &ga, lane);
+    lpP = reduce1(lp_part);
+    row0_store(PROP + 16 * ip, qa);
+    if (inrange) emit_generated(0, qa);  // samples[:,0] = generated(q0)  (:164)
+  }
+  bool live = inrange && prm.numIter >= 1;
+
+  // one micro pass of 2**cc leapfrog steps (adaptiveIntegrators.py:72-94) from (qs, vs, gs); returns "the pass is accepted"
+  double hcur = 0.0;  // step size h of the running macro step
+  auto run_pass = [&](double qs, double vs, double gs, double HamStart, int cc, double& q, double& v, double& g, double& lpC, double& HC,
+                      int& nev) -> bool {
+    q = qs; v = vs; g = gs;
+    const double hh = ldexp(hcur, -cc);  // h / 2**c (exact scaling either way)
+    const int nstep = 1 << cc;
+    bool allfin = isfinite(HamStart);
+    const double hh2 = 0.5 * hh, hq = hh;
+#pragma unroll 1
+    for (int s = 0; s < nstep; ++s) {
+      v = v + hh2 * g; q = q + hq * v;
+      double lpp = tgt.grad(&q, &g, lane);
+      double ke = 0.0;
+      v = v + hh2 * g; ke += v * v;
+      reduce2(lpp, ke);
+      const double Hi = -lpp + 0.5 * ke;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
+      lpC = lpp; HC = Hi;
+      if (!isfinite(Hi)) allfin = false;
+    }
+    nev += nstep;
+    return allfin && (fabs(HamStart - HC) < dlt);  // all(isfinite(Hams)) and abs(Hams[0]-Hams[-1]) < delta  (:87-94)
+  };
+
+  while (__any(live)) {  // ---- iterations (WALNUTS.py:189) ----
+    // ---- iteration start (:196-276) ----
+    rng_ensure((uint32_t)iter, 0u);  // uniforms 0..63: the M <= 24 direction bits and the first steps
+    Bbits = 0;
+#pragma unroll 1
+    for (uint32_t k = 0; k < (uint32_t)M; ++k)  // :216  B = floor(uniform(0,2,size=M))
+      if ((int)floor(0.0 + (2.0 - 0.0) * uni(k)) != 0) Bbits |= (1u << k);
+    Bbits = (uint32_t)uni_i((int)Bbits);
+    ku = (uint32_t)M;
+    a = 0; b = 0; maxFint = 0; maxBint = 0;
+    {
+      qa = row_load(PROP + 16 * ip);
+      double lpp = tgt.grad(&qa, &ga, lane);  // f0, grad0 = lpFun(qc)  (:249); its value is lpP already
+      (void)lpp;
+      const double z = (k16 < D) ? rng_normal(prm.seed, cg, (uint32_t)iter, (uint32_t)k16) : 0.0;  // :236  v = normal(size=d)
+      va = z;
+      row0_store(COLDQ, qa); row0_store(COLDV, va); row0_store(COLDG, ga);
+      double kp = 0.0; kp += z * z;
+      double gp = 0.0;
+      reduce2(kp, gp);
+      lp0 = lpP;
+      H0 = -lp0 + 0.5 * kp;  // Hs[I0] = -f0 + 0.5*sum(v**2)  (:256); multinomialLscale (:259)
+      Ha = Hb = H0;
+      Hnan = isnan(H0); Hmin = Hmax = H0;
+    }
+    WoldSum = 1.0; WnewSum = 0.0; lwtSumb = 0.0; lwtSumf = 0.0;  // :260-264
+    stopCode = 0; bothEndsPassive = false;
+    nevalF = nevalB = 0; Lold_ = L_ = 0; orbitLen_ = orbitLenSam_ = 0.0; NdS = NdC = 0;
+    indexStat_ = indexStatOld_ = 0.0; timeLenF_ = timeLenB_ = 0.0;
+    minIf = minc = 1 << 30; maxIf = maxc = -(1 << 30); nneq = nzero = nused = 0;
+    minlw = INFINITY; maxlw = -INFINITY;
+    predF = predB = true;
+    i = 0;
+    xi = (Bbits & 1u) ? -1 : 1;
+    bool endIter = false;
+
+    while (!endIter) {  // ---- doublings (:281) ----
+      {  // start of doubling i (:283-294)
+        const int nxi = ((Bbits >> i) & 1u) ? -1 : 1;
+        if (nxi != xi) {  // the other end of the orbit becomes the active one
+          const double tq = row_load(COLDQ), tv = row_load(COLDV), tg = row_load(COLDG);
+          row0_store(COLDQ, qa); row0_store(COLDV, va); row0_store(COLDG, ga);
+          qa = tq; va = tv; ga = tg;
+          const double th = Ha; Ha = Hb; Hb = th;
+          xi = nxi;
+        }
+        n = 0; nleaf = 1 << i;
+        ipl = ip; lpPL = lpP; Lold_ = L_; indexStatOld_ = indexStat_;
+        if (i > 0) WnewSum = 0.0;  // :390
+      }
+      const bool fw = xi > 0;
+      bool fire0 = false;  // full-orbit U-turn (:622), due at the last leaf of the doubling
+      bool sub = false;
+
+      while (n < nleaf) {  // ---- blocks of the doubling ----
+        const int nb0 = n & ~15;
+        const int k0 = n & 15;
+        int k1 = nleaf - nb0 < 16 ? nleaf - nb0 : 16;
+        // =========================== T phase: the integrator calls of leaves k0 .. k1-1 ===========================
+        {
+          uint32_t kuT = ku;
+          const bool pred = fw ? predF : predB;
+          int kdone = k0;
+#pragma unroll 1
+          for (int k = k0; k < k1; ++k) {
+            const int nk = nb0 + k;
+            const bool first = (i == 0) || !(nk & 1);
+            rng_ensure((uint32_t)iter, kuT);
+            if (first) {  // :298: one draw; :395: size=2, before the first step of a leaf pair
+              hcur = draw_h(kuT++);
+              if (i != 0) h2 = draw_h(kuT++);
+            } else hcur = h2;
+            const double Ham0 = Ha;  // Hs[] of the neighbouring stored index = energy at the active end (:302,400,443,487,530)
+            int nEvF = 0, nEvB = 0, If, Ib, cret;
+            double lwt, lpn, Hn;
+            double qw, vw, gw, lpC, HC;
+            const double vin = (double)xi * va;  // vh = xi*v + ...
+            if (INTEG == I_FIXED) {  // adaptiveIntegrators.py:49-59
+              run_pass(qa, vin, ga, Ham0, 0, qw, vw, gw, lpC, HC, nEvF);
+              If = Ib = cret = 0; lwt = 0.0; lpn = lpC; Hn = HC;
+            } else {
+              int cc = minC;  // forward search (:69-94 / 366-389)
+              bool ok;
+              for (;;) {
+                ok = __any(run_pass(qa, vin, ga, Ham0, cc, qw, vw, gw, lpC, HC, nEvF));
+                if (ok || cc >= maxC) break;
+                ++cc;
+              }
+              If = ok ? cc : maxC;  // Q5: the last computed state is used silently
+              int cSim, maxTry;
+              double lwtf;
+              if (INTEG == I_ADAPT_R2P) {
+                const double u = uni(kuT++);  // :392
+                if (__any(u < prm.R2Pprob0)) {  // :393-399, 430-433
+                  cSim = If; maxTry = If - 1; Ib = If; lwtf = prm.logP;
+                } else {  // :400-424, 434-437: re-integrate at c = If+1
+                  run_pass(qa, vin, ga, Ham0, If + 1, qw, vw, gw, lpC, HC, nEvF);
+                  cSim = If + 1; maxTry = maxC; Ib = maxC; lwtf = prm.log1mP;
+                }
+              } else {  // adaptLeapFrogD :96-111
+                cSim = If; maxTry = If - 1; Ib = If; lwtf = 0.0;
+              }
+              lpn = lpC; Hn = HC;
+              if (maxTry >= minC) {  // backward search from (qOut, -vOut, gOut)  (:107-132 / 440-464)
+                const double qo = qw, vo = vw, go = gw;
+                double lpB, HB;
+                for (cc = minC;; ++cc) {
+                  ok = __any(run_pass(qo, -vo, go, Hn, cc, qw, vw, gw, lpB, HB, nEvB));
+                  if (ok) { Ib = cc; break; }
+                  if (cc >= maxTry) break;
+                }
+                qw = qo; vw = vo; gw = go;
+              }
+              if (INTEG == I_ADAPT_R2P) {  // :466-475
+                double lwtb = WN_LOGZERO;
+                if (cSim == Ib) lwtb = prm.logP;
+                else if (cSim == Ib + 1) lwtb = prm.log1mP;
+                cret = cSim;
+                lwt = lwtb - lwtf;
+              } else {  // :135-137
+                cret = If;
+                lwt = (If != Ib) ? WN_LOGZERO : 0.0;
+              }
+            }
+            // the leaf's multinomial uniform (:426) sits behind its step sizes and its R2P draw -- if it is drawn at all
+            const double up = uni(kuT);
+            if (pred && i != 0) kuT++;
+            // intOut.v is in forward-time orientation (adaptiveIntegrators.py:57,135,473); the new state becomes the active end
+            qa = qw; va = (double)xi * vw; ga = gw; Ha = Hn;
+            if (lane < 16) {
+              L[RQ + 16 * k + lane] = qa; L[RV + 16 * k + lane] = va;
+              if (lane == 0) {
+                L[SH + k] = Hn; L[SLP + k] = lpn; L[SLW + k] = lwt; L[SHH + k] = hcur; L[SUP + k] = up;
+                LI[k] = If; LI[16 + k] = Ib; LI[32 + k] = cret; LI[48 + k] = nEvF; LI[64 + k] = nEvB;
+              }
+            }
+            // left endpoint of the sub-trees of 2**j leaves, j >= 5, that start here (levels 1..4 stay inside the ring)
+            if (k == 0 && (nk == 0 ? i >= 5 : __builtin_ctz((unsigned)nk) >= 5)) {
+              const int sl = nk == 0 ? 0 : __builtin_ctz((unsigned)nk);
+              if (lane < 16) { L[SLOT + 32 * sl + lane] = qa; L[SLOT + 32 * sl + 16 + lane] = va; }
+            }
+            kdone = k + 1;
+            if (__any(!isfinite(Hn))) break;  // forced reject (:316-319): nothing behind this leaf will be used
+          }
+          k1 = kdone;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // =========================== R phase: bookkeeping of leaves k0 .. k1-1, lane k = leaf k ===========================
+        const int k = k16;
+        const bool inb = k >= k0 && k < k1;
+        const double Hn_k = L[SH + k], lw_k = L[SLW + k], h_k = L[SHH + k], up_k = L[SUP + k], lp_k = L[SLP + k];
+        const int If_k = LI[k], Ib_k = LI[16 + k], c_k = LI[32 + k], ef_k = LI[48 + k], eb_k = LI[64 + k];
+        const int nk = nb0 + k;
+        const bool first_k = (i == 0) || !(nk & 1);
+        const int nbat = k1 - k0;
+        // serial prefix sums in the reference's order: row 0 lwtSum of this direction (:321,354,420,507,550; Q2: on the backward
+        // side only the first leaf of a pair adds), row 1 timeLen of this direction, row 2 orbitLen_
+        double P1;
+        {
+          const bool upd = (i == 0) || first_k || fw;
+          const double x = row == 0 ? (upd ? lw_k : 0.0) : h_k;
+          const double carry = row == 0 ? ((i == 0) ? 0.0 : (fw ? lwtSumf : lwtSumb)) : row == 1 ? (fw ? timeLenF_ : timeLenB_) : orbitLen_;
+          double s = inb ? x : 0.0;
+          s = (k == k0) ? carry + s : s;
+          const double xs = s;
+#pragma unroll 1
+          for (int t = 1; t < nbat; ++t) s = xs + shr1(s);
+          P1 = s;
+        }
+        const double Wn = exp(-Hn_k + H0 + P1);  // Wnew = exp(-H + H0 + lwtSum)  (row 0)
+        double WS;
+        {
+          double s = inb ? Wn : 0.0;
+          const double carry = (i == 0) ? 0.0 : WnewSum;
+          s = (k == k0) ? carry + s : s;
+          const double xs = s;
+#pragma unroll 1
+          for (int t = 1; t < nbat; ++t) s = xs + shr1(s);
+          WS = s;
+        }
+        const bool inb0 = inb && lane < 16;
+        const bool drawn_k = (i != 0) && (WS > prm.wtSumThresh);
+        // :426  take this state with probability Wnew / WnewSum; i == 0 (:322-328): unconditional, no uniform
+        const bool pick_k = (i == 0) ? true : (drawn_k && up_k < Wn / WS);
+        const uint64_t m_in = __ballot(inb0);
+        const uint64_t m_nf = __ballot(inb0 && !isfinite(Hn_k));
+        const uint64_t m_dr = __ballot(inb0 && drawn_k);
+        const uint64_t m_pk = __ballot(inb0 && pick_k);
+        const bool pred = fw ? predF : predB;
+        const uint64_t m_bad = (i != 0) ? ((pred ? ~m_dr : m_dr) & m_in) : 0ull;
+
+        // ---- U-turn checks, one lane each (stopCondition, WALNUTS.py:95-97, with the older state on the side opposite to xi) ----
+        uint64_t m_fire = 0ull;  // leaves at which a sub-tree check fired
+        bool f0_now = false;
+        {
+#pragma clang fp contract(off)
+          int r = -1, lq = 0, lv = 0, lvl = 0;  // right leaf (ring entry), LDS offsets of the left state
+          if (lane < 8) { r = 2 * lane + 1; lvl = 1; }
+          else if (lane < 12) { r = 4 * (lane - 8) + 3; lvl = 2; }
+          else if (lane < 14) { r = 8 * (lane - 12) + 7; lvl = 3; }
+          else if (lane == 14) { r = 15; lvl = 4; }
+          else if (lane == 15) { r = (nleaf - 1) & 15; lvl = 0; }
+          else if (lane - 16 + 5 <= M) { r = 15; lvl = lane - 16 + 5; }
+          bool act = r >= k0 && r < k1;
+          const int nr = nb0 + r;
+          if (lvl == 0) {
+            act = act && nr == nleaf - 1;
+            lq = COLDQ; lv = COLDV;
+          } else if (lvl <= 4) {
+            act = act && i >= 1;
+            lq = RQ + 16 * (r + 1 - (1 << lvl)); lv = lq + (RV - RQ);
+          } else {
+            act = act && i >= 1 && lvl <= __builtin_ctz((unsigned)(nr + 1));
+            const int nl = nr + 1 - (1 << lvl);  // left leaf of the sub-tree
+            const int sl = nl == 0 ? 0 : __builtin_ctz((unsigned)nl);
+            lq = SLOT + 32 * sl; lv = lq + 16;
+          }
+          bool fire = false;
+          if (act) {
+            const int rq = RQ + 16 * r, rv = RV + 16 * r;
+            double s1[4], s2[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              double p1[4], p2[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int d = 4 * g4 + e;
+                const double dq = L[rq + d] - L[lq + d];
+                p1[e] = L[rv + d] * dq;
+                p2[e] = L[lv + d] * dq;
+              }
+              s1[g4] = (p1[0] + p1[1]) + (p1[2] + p1[3]);
+              s2[g4] = (p2[0] + p2[1]) + (p2[2] + p2[3]);
+            }
+            const double d1 = ((s1[0] + s1[1]) + (s1[2] + s1[3])) + 0.0, d2 = ((s2[0] + s2[1]) + (s2[2] + s2[3])) + 0.0;
+            fire = ((double)xi * d1 < 0.0) || ((double)xi * d2 < 0.0);
+          }
+          const uint64_t m_chk = __ballot(act && fire);
+          if (m_chk) {
+            uint64_t m = m_chk;
+            while (m) {
+              const int c = __builtin_ctzll(m);
+              m &= m - 1;
+              if (c == 15) { f0_now = true; continue; }
+              const int rr = c < 8 ? 2 * c + 1 : c < 12 ? 4 * (c - 8) + 3 : c < 14 ? 8 * (c - 12) + 7 : 15;
+              m_fire |= 1ull << rr;
+            }
+          }
+        }
+        // ---- the first event decides how many leaves of the batch stand ----
+        const int t_nf = m_nf ? __builtin_ctzll(m_nf) : 64;
+        const int t_sub = m_fire ? __builtin_ctzll(m_fire) : 64;
+        const int t_bad = m_bad ? __builtin_ctzll(m_bad) : 64;  // leaves behind it used wrong draw indices
+        const int t_ev = t_nf < t_sub ? t_nf : t_sub;
+        bool end_nf = false, end_sub = false, redo = false;
+        int Lfull;  // last leaf whose bookkeeping is complete
+        if (t_ev <= t_bad && t_ev < k1) {
+          end_nf = t_nf <= t_sub;  // the non-finite test comes first (:316-319 before any U-turn test)
+          end_sub = !end_nf;
+          Lfull = end_nf ? t_ev - 1 : t_ev;
+        } else if (t_bad < k1 - 1) {
+          redo = true;
+          Lfull = t_bad;
+        } else {
+          Lfull = k1 - 1;
+        }
+        const int A_end = end_nf ? t_ev : Lfull;  // last leaf that reached the accumulators at the top of the reference's step
+        // ---- accumulators over leaves k0 .. A_end ----
+        {
+          const bool macc = inb && k <= A_end;
+          // nevalF, nevalB, #(If != Ib), #(If == 0): four rows of one register
+          int v4 = row == 0 ? ef_k : row == 1 ? eb_k : row == 2 ? (int)(If_k != Ib_k) : (int)(If_k == 0);
+          v4 = rowsum_i(macc ? v4 : 0);
+          nevalF += rl_i(v4, 0); nevalB += rl_i(v4, 16); nneq += rl_i(v4, 32); nzero += rl_i(v4, 48);
+          nused += A_end - k0 + 1;
+          if (INTEG != I_FIXED) {
+            int m4 = row == 0 ? If_k : row == 1 ? c_k : row == 2 ? -If_k : -c_k;
+            m4 = rowmin_i(macc ? m4 : (1 << 30));
+            const int a0 = rl_i(m4, 0), a1 = rl_i(m4, 16), a2 = -rl_i(m4, 32), a3 = -rl_i(m4, 48);
+            minIf = a0 < minIf ? a0 : minIf; minc = a1 < minc ? a1 : minc; maxIf = a2 > maxIf ? a2 : maxIf; maxc = a3 > maxc ? a3 : maxc;
+          } else {
+            minIf = minc = maxIf = maxc = 0;
+          }
+          double d4 = row == 0 ? lw_k : row == 1 ? -lw_k : row == 2 ? Hn_k : -Hn_k;
+          d4 = rowmin_d(macc ? d4 : INFINITY);
+          const double b0 = wn_readlane(d4, 0), b1 = -wn_readlane(d4, 16), b2 = wn_readlane(d4, 32), b3 = -wn_readlane(d4, 48);
+          minlw = b0 < minlw ? b0 : minlw; maxlw = b1 > maxlw ? b1 : maxlw;
+          Hmin = b2 < Hmin ? b2 : Hmin; Hmax = b3 > Hmax ? b3 : Hmax;
+          if (__ballot(macc && lane < 16 && isnan(Hn_k))) Hnan = true;
+          const double tl = wn_readlane(P1, 16 + A_end);
+          const int idxA = fw ? b + 1 + (nb0 + A_end) : a - 1 - (nb0 + A_end);
+          if (fw) { timeLenF_ = tl; maxFint = idxA; } else { timeLenB_ = tl; maxBint = idxA; }
+          // orbitLen_ += h: i == 0 before the integrator call (:300), else behind the non-finite test (:432 / 471 / 519 / 561)
+          const int o_end = (end_nf && i != 0) ? t_ev - 1 : A_end;
+          if (o_end >= k0) orbitLen_ = wn_readlane(P1, 32 + o_end);
+          if (Lfull >= k0) {
+            const double ls = wn_readlane(P1, Lfull);
+            if (fw) lwtSumf = ls; else lwtSumb = ls;
+            WnewSum = wn_readlane(WS, Lfull);
+            const uint64_t mp = m_pk & ((2ull << Lfull) - 1ull);
+            if (mp) {  // the last leaf that took the multinomial draw is the proposal
+              const int Pk = 63 - __builtin_clzll(mp);
+              if (ip == ipl) ip ^= 1;  // keep qPropLast intact
+              const double qp = L[RQ + 16 * Pk + k16];
+              row0_store(PROP + 16 * ip, qp);
+              lpP = wn_readlane(lp_k, Pk);
+              L_ = fw ? b + 1 + (nb0 + Pk) : a - 1 - (nb0 + Pk);
+              const double tp = wn_readlane(P1, 16 + Pk);
+              indexStat_ = fw ? tp : -tp;
+            }
+            if (i != 0) {  // the draws these leaves consumed, and what the next leaf is expected to do
+              const uint64_t rng = m_in & ((2ull << Lfull) - 1ull);
+              // leaves with an even index drew the pair's two step sizes
+              const uint64_t evn = (nb0 & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
+              ku += 2u * (uint32_t)__builtin_popcountll(rng & evn) + (INTEG == I_ADAPT_R2P ? (uint32_t)__builtin_popcountll(rng) : 0u) +
+                    (uint32_t)__builtin_popcountll(rng & m_dr);
+              const bool dl = (m_dr >> Lfull) & 1ull;
+              if (fw) predF = dl; else predB = dl;
+            } else {
+              ku += 1u + (INTEG == I_ADAPT_R2P ? 1u : 0u);
+            }
+            Ha = wn_readlane(Hn_k, Lfull);
+          }
+        }
+        if (f0_now && !end_nf && !end_sub && !redo) fire0 = true;
+        n = nb0 + Lfull + 1;
+        if (end_nf) {  // :316-319, 414-417, 457-459 (Q3, Q4)
+          const bool first_e = (i == 0) || !((nb0 + t_ev) & 1);
+          if (first_e) stopCode = 999;
+          endIter = true;
+          break;
+        }
+        if (end_sub) { sub = true; break; }
+        if (redo) {  // restart behind the mispredicted leaf: its state is in the ring
+          qa = L[RQ + 16 * Lfull + k16]; va = L[RV + 16 * Lfull + k16];
+          double lpp = tgt.grad(&qa, &ga, lane);
+          (void)lpp;
+          if (n & 1) {  // the pair's second step size was drawn with the first (:395)
+            const uint32_t kh = ku - 1u - (INTEG == I_ADAPT_R2P ? 1u : 0u) - (uint32_t)((m_dr >> Lfull) & 1ull);
+            rng_ensure((uint32_t)iter, kh);
+            h2 = draw_h(kh);
+          }
+        }
+      }
+      if (endIter) break;
+      // ---- end of the doubling (:590-648) ----
+      indexStat_ = indexStat_ / (timeLenF_ + timeLenB_);  // :595 (Q6)
+      if (sub) {  // :597-605
+        ip = ipl; lpP = lpPL; L_ = Lold_; indexStat_ = indexStatOld_;
+        NdS = i; NdC = i + 1; stopCode = 5;
+        endIter = true;
+        break;
+      }
+      rng_ensure((uint32_t)iter, ku);
+      if (!__any(uni(ku++) < WnewSum / WoldSum)) { ip = ipl; lpP = lpPL; L_ = Lold_; indexStat_ = indexStatOld_; }  // :613-616
+      bothEndsPassive = (lwtSumb < WN_LOGZERO + 1.0) && (lwtSumf < WN_LOGZERO + 1.0);  // :624
+      if (__any(fire0 || bothEndsPassive)) {  // :625-634
+        stopCode = fire0 ? 4 : -4;
+        NdS = NdC = i + 1;
+        orbitLenSam_ = orbitLen_;
+        endIter = true;
+        break;
+      }
+      WoldSum += WnewSum;  // :641-648
+      orbitLenSam_ = orbitLen_;
+      NdS = NdC = i + 1;
+      if (fw) b += nleaf; else a -= nleaf;
+      i++;
+      if (i == M) { endIter = true; break; }
+    }
+    // ---- end of the iteration (:653-695) ----
+    {
+      const double qP = row_load(PROP + 16 * ip);
+      emit_generated(iter, qP);  // samples[:,iterN] = generated(qc), qc = qProp
+      double d[NDIAG];
+      d[0] = L_; d[1] = NdS; d[2] = orbitLen_; d[3] = orbitLenSam_; d[4] = maxFint; d[5] = maxBint;
+      d[6] = nevalF; d[7] = nevalB;
+      const bool AD = INTEG != I_FIXED;
+      d[8] = AD ? minIf : 0; d[9] = AD ? maxIf : 0; d[10] = AD ? minlw : 0.0; d[11] = AD ? maxlw : 0.0;
+      d[12] = bothEndsPassive ? 1.0 : 0.0;
+      d[13] = ((lwtSumb < WN_LOGZERO + 1.0) || (lwtSumf < WN_LOGZERO + 1.0)) ? 1.0 : 0.0;
+      d[14] = AD ? (double)nneq / (double)nused : 0.0;
+      d[15] = Hc;
+      d[16] = AD ? (double)nzero / (double)nused : 1.0;
+      d[17] = Hnan ? NAN : (Hmax - Hmin);
+      d[18] = dlt; d[19] = (double)stopCode; d[20] = NdC; d[21] = AD ? minc : 0; d[22] = AD ? maxc : 0;
+      d[23] = indexStat_;
+      double vv = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < NDIAG; ++kk) vv = lane == kk ? d[kk] : vv;
+      if (lane < NDIAG) prm.diag[((size_t)clc * prm.numIter + (iter - 1)) * NDIAG + lane] = vv;
+    }
+    iter++;
+    if (iter > prm.numIter) live = false;
+  }
+  (void)gen_sum;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+// plain sampling runs (no trace, no warm-up, no orbit statistics) of the three leapfrog integrators on the <= 16-D targets of the
+// one-chain-per-wave layout; WN_ORBIT_LEGACY=1 keeps the one-stream engine (A/B tests)
+bool orbit_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm) {
+  if (kc.layout != 2 || kc.p0 != 1 || kc.W != 1 || kc.G != 1) return false;
+  if (warm || prm.mode != MODE_SAMPLE || prm.trace_n || prm.trace || prm.omin) return false;
+  if (adapt == 2) return false;
+  if (prm.integrator != I_FIXED && prm.integrator != I_ADAPT_D && prm.integrator != I_ADAPT_R2P) return false;
+  if (prm.M < 1 || prm.M > MAX_M || prm.D > 16) return false;
+  if (prm.generated != G_IDENTITY && prm.generated != G_FIRSTK && prm.generated != G_Q0_SUMSQ) return false;
+  if (getenv("WN_ORBIT_LEGACY")) return false;
+  switch (kc.p1) {
+    case T_FUNNEL10: case T_CORRGAUSS: case T_SMILE: case T_FUNNEL1: case T_MODFUNNEL: return true;
+  }
+  return false;
+}
+
+template <class Tgt>
+static hipError_t go_orbit(const Params& prm, hipStream_t st) {
+  const size_t dyn = (size_t)orbit::lds_doubles(prm.M) * sizeof(double);
+  dim3 grid(prm.C), block(64);
+  if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_R2P>), grid, block, dyn, st, prm);
+  else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_D>), grid, block, dyn, st, prm);
+  else hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_FIXED>), grid, block, dyn, st, prm);
+  return hipGetLastError();
+}
+
+hipError_t launch_orbit(const KernelChoice& kc, const Params& prm, hipStream_t st) {
+  switch (kc.p1) {
+    case T_FUNNEL10: return go_orbit<WTgtFunnel10>(prm, st);
+    case T_CORRGAUSS: return go_orbit<WTgtPair<TgtCorrGauss>>(prm, st);
+    case T_SMILE: return go_orbit<WTgtPair<TgtSmile>>(prm, st);
+    case T_FUNNEL1: return go_orbit<WTgtPair<TgtFunnel1>>(prm, st);
+    case T_MODFUNNEL: return go_orbit<WTgtPair<TgtModFunnel>>(prm, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace wn

@@ -34,6 +34,9 @@ hipError_t launch_fast(const KernelChoice& kc, const Params& prm, int* abort_fla
 bool fast4_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm);
 hipError_t launch_fast4(const KernelChoice& kc, const Params& prm, int* abort_flag, hipStream_t st);
 int fast4_pairs(int C);
+// trajectory-first / batched-bookkeeping kernel of the one-chain-per-wave layout for <= 16-D targets (wn_k_orbit.hip)
+bool orbit_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm);
+hipError_t launch_orbit(const KernelChoice& kc, const Params& prm, hipStream_t st);
 size_t fast4_work_doubles(int C, int M);
 size_t wave_work_doubles(int NE, int C, int M, int G);
 size_t split_work_doubles(int NE, int C, int M);
