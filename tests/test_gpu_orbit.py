@@ -1,0 +1,139 @@
+"""The trajectory-first kernel (wn_k_orbit.hip: integrator calls of up to 16 leaves back to back, their NUTS bookkeeping
+lane-parallel) against the CPU oracle and against the one-stream engine of the same layout (WN_ORBIT_LEGACY=1), through the C ABI.
+
+The reference path it stands for: WALNUTSpy/WALNUTS.py:189-695 with adaptiveIntegrators.py:49-59 / 65-137 / 361-475."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import oracle_lib as ol  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20251121
+INT_COLS = [0, 1, 4, 5, 6, 7, 8, 9, 12, 13, 19, 20, 21, 22]
+
+
+@pytest.fixture(scope="module")
+def wa():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import walnuts_amd
+    return walnuts_amd
+
+
+def funnel_q0(C, seed=3):
+    rng = np.random.default_rng(seed)
+    q0 = np.zeros((C, 11)); q0[:, 0] = 3.0 * rng.normal(size=C)
+    q0[:, 1:] = np.exp(0.5 * q0[:, :1]) * rng.normal(size=(C, 10))
+    return q0
+
+
+def run_engine(wa, target, q0, iters, legacy=False, seed=SEED, **kw):
+    from walnuts_amd import _lib as L
+    old = os.environ.pop("WN_ORBIT_LEGACY", None)
+    if legacy:
+        os.environ["WN_ORBIT_LEGACY"] = "1"
+    try:
+        e = wa.Engine(q0.shape[1], q0.shape[0], **kw)
+        e.set_target(target, None)
+        name = e.kernel_name
+        s, d = e.run(q0, seed, iters)
+        s = s.cpu().numpy(); d = d.cpu().numpy()
+        e.close()
+    finally:
+        os.environ.pop("WN_ORBIT_LEGACY", None)
+        if old is not None:
+            os.environ["WN_ORBIT_LEGACY"] = old
+    return s, d, name
+
+
+def same(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+CASES = [
+    # integrator, M, H0, delta0, minC, iters, generated, gen_k
+    (ol.I_ADAPT_R2P, 12, 0.3, 0.3, 0, 40, ol.G_IDENTITY, 0),
+    (ol.I_ADAPT_R2P, 8, 0.3, 0.3, 0, 60, ol.G_FIRSTK, 2),
+    (ol.I_ADAPT_D, 10, 0.3, 0.3, 0, 40, ol.G_Q0_SUMSQ, 0),
+    (ol.I_ADAPT_D, 6, 0.5, 0.1, 1, 40, ol.G_IDENTITY, 0),
+    (ol.I_FIXED, 9, 0.2, 0.3, 0, 40, ol.G_IDENTITY, 0),
+    (ol.I_ADAPT_R2P, 3, 0.3, 0.3, 0, 80, ol.G_IDENTITY, 0),
+    (ol.I_ADAPT_R2P, 1, 0.3, 0.3, 0, 50, ol.G_IDENTITY, 0),
+    (ol.I_ADAPT_R2P, 5, 1.5, 0.05, 0, 40, ol.G_IDENTITY, 0),  # large steps: deep refinement, passive ends, stop code -4
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"integ{c[0]}_M{c[1]}_H{c[2]}_gen{c[6]}" for c in CASES])
+def test_orbit_kernel_equals_the_one_stream_engine(wa, case):
+    """Same arithmetic per micro step and per sum, different control structure: draws and all 24 diagnostics bit for bit."""
+    integ, M, H0, delta0, minC, iters, gen, gk = case
+    C = 384
+    q0 = funnel_q0(C, seed=11 + M)
+    kw = dict(integrator=integ, H0=H0, delta0=delta0, M=M, minC=minC, generated=gen, gen_k=gk)
+    s_new, d_new, name = run_engine(wa, ol.T_FUNNEL10, q0, iters, **kw)
+    assert "wn_orbit_kernel" in name, name
+    s_old, d_old, name_old = run_engine(wa, ol.T_FUNNEL10, q0, iters, legacy=True, **kw)
+    assert "wn_wave_kernel" in name_old, name_old
+    bad = [c for c in range(C) if not (same(d_new[c], d_old[c]) and same(s_new[c], s_old[c]))]
+    if bad:
+        c = bad[0]
+        it = next(t for t in range(iters) if not (same(d_new[c, t], d_old[c, t]) and same(s_new[c, t + 1], s_old[c, t + 1])))
+        cols = [k for k in range(24) if not same(d_new[c, it, k], d_old[c, it, k])]
+        raise AssertionError(f"{len(bad)} of {C} chains differ; first: chain {c} iteration {it} diag columns {cols}\n new {d_new[c, it]}\n old {d_old[c, it]}\n"
+                             f" draw new {s_new[c, it + 1]}\n draw old {s_old[c, it + 1]}")
+    codes = set(np.unique(d_new[:, :, 19]).astype(int).tolist())
+    assert 4 in codes or M <= 1
+
+
+@pytest.mark.parametrize("integ,M", [(ol.I_ADAPT_R2P, 12), (ol.I_ADAPT_D, 8), (ol.I_FIXED, 10), (ol.I_ADAPT_R2P, 4)])
+def test_orbit_kernel_matches_oracle(wa, integ, M):
+    """Per-chain draws and diagnostics against the CPU oracle (the restatement pinned to the Python reference)."""
+    C, iters = 64, 12
+    q0 = funnel_q0(C, seed=5)
+    kw = dict(integrator=integ, H0=0.3, delta0=0.3, M=M)
+    s, d, name = run_engine(wa, ol.T_FUNNEL10, q0, iters, **kw)
+    assert "wn_orbit_kernel" in name
+    for c in (0, 7, 19, 33, 63):
+        o = ol.walnuts(ol.T_FUNNEL10, q0[c], integrator=integ, H0=0.3, delta0=0.3, numIter=iters, M=M, seed=SEED, chain=c)
+        np.testing.assert_array_equal(d[c][:, INT_COLS], o["diagnostics"][:, INT_COLS], err_msg=f"chain {c}")
+        np.testing.assert_allclose(s[c].T, o["samples"], rtol=1e-6, atol=1e-9, err_msg=f"chain {c}")
+        np.testing.assert_allclose(d[c], o["diagnostics"], rtol=1e-6, atol=1e-9, err_msg=f"chain {c}")
+
+
+@pytest.mark.parametrize("target", [ol.T_CORRGAUSS, ol.T_SMILE, ol.T_FUNNEL1, ol.T_MODFUNNEL])
+def test_orbit_kernel_two_dimensional_targets(wa, target):
+    """The 2-D targets of targetDistr.py in the one-chain-per-wave layout: oracle parity and identity with the one-stream engine."""
+    C, iters, M = 128, 25, 7
+    q0 = np.random.default_rng(9).normal(size=(C, 2))
+    kw = dict(integrator=ol.I_ADAPT_R2P, H0=0.4, delta0=0.2, M=M)
+    s, d, name = run_engine(wa, target, q0, iters, **kw)
+    assert "wn_orbit_kernel" in name, name
+    s_old, d_old, _ = run_engine(wa, target, q0, iters, legacy=True, **kw)
+    assert same(d, d_old) and same(s, s_old)
+    for c in (0, 50, 127):
+        o = ol.walnuts(target, q0[c], integrator=ol.I_ADAPT_R2P, H0=0.4, delta0=0.2, numIter=iters, M=M, seed=SEED, chain=c)
+        np.testing.assert_array_equal(d[c][:, INT_COLS], o["diagnostics"][:, INT_COLS])
+        np.testing.assert_allclose(s[c].T, o["samples"], rtol=1e-6, atol=1e-9)
+
+
+def test_orbit_kernel_config3_size(wa):
+    """BASELINE config 3 at its size for a shorter run: 4096 chains, adaptLeapFrogR2P, M = 12; every chain's gradient-evaluation
+    counts equal the one-stream engine's, a few chains against the oracle."""
+    C, iters = 4096, 20
+    q0 = funnel_q0(C, seed=21)
+    kw = dict(integrator=ol.I_ADAPT_R2P, H0=0.3, delta0=0.3, M=12, generated=ol.G_FIRSTK, gen_k=2)
+    s, d, name = run_engine(wa, ol.T_FUNNEL10, q0, iters, **kw)
+    s_old, d_old, _ = run_engine(wa, ol.T_FUNNEL10, q0, iters, legacy=True, **kw)
+    assert same(d, d_old) and same(s, s_old)
+    busiest = int(np.argmax((d[:, :, 6] + d[:, :, 7]).sum(1)))
+    for c in (0, 1234, busiest):
+        o = ol.walnuts(ol.T_FUNNEL10, q0[c], integrator=ol.I_ADAPT_R2P, H0=0.3, delta0=0.3, numIter=iters, M=12, seed=SEED, chain=c,
+                       generated=ol.G_FIRSTK, gen_k=2)
+        np.testing.assert_array_equal(d[c][:, INT_COLS], o["diagnostics"][:, INT_COLS])
+        np.testing.assert_allclose(s[c].T, o["samples"], rtol=1e-6, atol=1e-9)

@@ -229,6 +229,32 @@ def test_stockwatson_matches_oracle(wa, ig, kw):
         compare_chain(out, k, o["trace"], o["samples"], o["diagnostics"], f"SW chain {k}")
 
 
+@pytest.mark.parametrize("name", ["D", "R2P", "fixed"])
+def test_stockwatson_engine_matches_reference_sampler_at_config5_size(wa, name):
+    """The three runs of mainSW.py:41-80 at their size (D = 756, minC = 3, M = 14; the fixedLeapFrog run at M = 7) against
+    the UNMODIFIED Python reference sampler driven by the NumPy restatement of sw_innov.stan
+    (tests/golden/stockwatson_sampler.npz, made by tests/golden/make_golden_sw_sampler.py): every integrator call's
+    If / Ib / c / nEval exactly, the stored (q, v) rows, draws and diagnostics to rtol 1e-6."""
+    from test_stockwatson import sw_sampler_case
+    kw, chain, seed, ref = sw_sampler_case(name)
+    assert seed == SEED
+    ncall = len(ref["trace_scalars"])
+    c = dict(target=ol.T_STOCKWATSON, integrator=kw["integrator"], H0=kw["H0"], s=0.2, delta0=kw["delta0"], M=kw["M"],
+             numIter=kw["numIter"], minC=kw["minC"], maxC=10, R2Pprob0=2.0 / 3.0, generated=0, gen_k=0, tpar=SW_TPAR)
+    out = run_engine(wa, c, np.zeros((1, 3 * SW_T)), ncall + 8, chain_offset=chain)
+    assert "stockwatson" in out["kernel"]
+    assert out["trace_n"][0] == ncall
+    tr = out["trace"][0, :ncall]
+    for col in (0, 2, 6, 7, 8, 10, 11):
+        np.testing.assert_array_equal(tr[:, col], ref["trace_scalars"][:, col], err_msg=f"trace col {col}")
+    close(tr[:, [3, 4, 5, 9]], ref["trace_scalars"][:, [3, 4, 5, 9]], what="h / Ham0 / lp / lwt")
+    close(tr[ref["trace_rows"], 12:], ref["trace_qv"], what="(q, v) of the stored integrator calls")
+    d = out["diagnostics"][0]
+    np.testing.assert_array_equal(d[:, [6, 7, 8, 9, 19, 20, 21, 22]], ref["diagnostics"][:, [6, 7, 8, 9, 19, 20, 21, 22]])
+    close(d, ref["diagnostics"], what="diagnostics")
+    close(out["samples"][0], ref["samples"], what="samples")
+
+
 def test_stockwatson_python_api(wa):
     from walnuts_amd import adaptiveIntegrators as ai, targetDistr as td
     s, d = wa.WALNUTS(td.stockWatson(_SW["y"]), np.zeros((2, 3 * SW_T)), integrator=ai.adaptLeapFrogD, H0=0.1, delta0=0.3,

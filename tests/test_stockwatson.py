@@ -68,3 +68,37 @@ def test_oracle_stockwatson_sampler_runs():
     assert (o["diagnostics"][:, 21] >= 3).all()  # min c >= minC
     with pytest.raises(ValueError):  # d must be 3T
         ol.lpfun(ol.T_STOCKWATSON, np.zeros(5), TPAR)
+
+
+# ---- the reference SAMPLER at config 5's size (D = 756, minC = 3, M = 14) -------------------------------------------
+# tests/golden/stockwatson_sampler.npz: the unmodified Python reference (WALNUTS() + its integrators) run with the NumPy
+# restatement of sw_innov.stan as lpFun and the engine's random stream on tape (tests/golden/make_golden_sw_sampler.py).
+# The target itself stays unpinned against Stan; the sampler at this size is pinned against the reference.
+SWS = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stockwatson_sampler.npz"))
+INT_COLS = (0, 1, 4, 5, 6, 7, 8, 9, 12, 13, 19, 20, 21, 22)
+
+
+def sw_sampler_case(name):
+    p = f"sw756_{name}_"
+    cfg = SWS[p + "cfg"]
+    kw = dict(integrator=int(cfg[0]), H0=float(cfg[1]), delta0=float(cfg[2]), numIter=int(cfg[3]), M=int(cfg[4]), minC=int(cfg[5]))
+    return kw, int(cfg[6]), int(cfg[7]), {k: SWS[p + k] for k in ("samples", "diagnostics", "trace_scalars", "trace_rows", "trace_qv", "tape_u", "tape_z", "n_u")}
+
+
+@pytest.mark.parametrize("name", ["D", "R2P", "fixed"])
+@pytest.mark.parametrize("tape", [True, False], ids=["tape", "philox"])
+def test_oracle_matches_reference_sampler_at_config5_size(name, tape):
+    kw, chain, seed, ref = sw_sampler_case(name)
+    ncall = len(ref["trace_scalars"])
+    extra = dict(tape_u=np.nan_to_num(ref["tape_u"], nan=0.5), tape_z=ref["tape_z"]) if tape else dict(seed=seed, chain=chain)
+    o = ol.walnuts(ol.T_STOCKWATSON, np.zeros(3 * T), tpar=TPAR, trace_cap=ncall + 8, **kw, **extra)
+    assert o["ncalls"] == ncall
+    np.testing.assert_array_equal(o["n_u"], ref["n_u"])
+    tr = o["trace"]
+    for col in (0, 2, 6, 7, 8, 10, 11):  # iter, xi, If, Ib, c, nEvalF, nEvalB of every integrator call
+        np.testing.assert_array_equal(tr[:, col], ref["trace_scalars"][:, col], err_msg=f"trace col {col}")
+    np.testing.assert_allclose(tr[:, [3, 4, 5, 9]], ref["trace_scalars"][:, [3, 4, 5, 9]], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(tr[ref["trace_rows"], 12:], ref["trace_qv"], rtol=1e-7, atol=1e-9)  # (q, v) of the stored calls
+    np.testing.assert_array_equal(o["diagnostics"][:, INT_COLS], ref["diagnostics"][:, INT_COLS])
+    np.testing.assert_allclose(o["diagnostics"], ref["diagnostics"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(o["samples"], ref["samples"], rtol=1e-7, atol=1e-9)

@@ -481,6 +481,12 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
       snprintf(kc.name, sizeof(kc.name), "wn_fast4_kernel<NS=%d%s,%s,pairs=%d>", D <= 32 ? 2 : D <= 64 ? 4 : D <= 96 ? 6 : 7, (kc.p1 == CK_DENSE && D > 96) ? ",tail" : "",
                kc.p1 == CK_DENSE ? "dense" : "diag", fast4_pairs(e->cfg.n_chains));
   }
+  if (kc.layout == 2 && kc.p0 == 1 && kc.W == 1 && kc.G == 1 && e->cfg.warmup_iter == 0 && e->cfg.M >= 1 &&
+      (e->cfg.integrator == WN_I_FIXED || e->cfg.integrator == WN_I_ADAPT_D || e->cfg.integrator == WN_I_ADAPT_R2P) && !getenv("WN_ORBIT_LEGACY")) {
+    // plain sampling runs go to the trajectory-first kernel (wn_k_orbit.hip); traced / orbit-statistics runs and
+    // wn_integrator_step use the one-stream engine of the same layout
+    snprintf(kc.name, sizeof(kc.name), "wn_orbit_kernel<target=%d,integrator=%d>", kc.p1, e->cfg.integrator);
+  }
   e->kc = kc;
   e->have_kc = true;
   e->target = kind;
