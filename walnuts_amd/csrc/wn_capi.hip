@@ -755,6 +755,29 @@ int wn_run(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, do
       }
       return rc;
     }
+    if (strstr(e->kc.name, "wn_orbit_kernel")) {  // one row per chain
+      const char* on[16] = {"T_draws", "T_forward", "T_r2p+backward", "T_finish+ring", "R_scans+exp", "R_checks", "macro_steps", "R_events+accumulators",
+                            "iteration_start", "doubling/iteration_end", "blocks", "evals_run", "redos", "", "", ""};
+      auto row = [&](const char* what, const double* a) {
+        fprintf(stderr, "[WN_STAMPS orbit] %s: cycles per macro step:", what);
+        for (int k = 0; k < 10; ++k) if (k != 6) fprintf(stderr, " %s=%.0f", on[k], a[k] / a[6]);
+        double c = 0; for (int k = 0; k < 10; ++k) if (k != 6) c += a[k];
+        fprintf(stderr, " | total=%.0f macro steps=%.0f leaves/block=%.2f evals run/macro step=%.2f redos/block=%.4f cycles/eval run=%.0f\n", c / a[6], a[6], a[6] / a[10], a[11] / a[6],
+                a[12] / a[10], c / a[11]);
+      };
+      double tot2[16] = {0};
+      size_t wmax = 0; double cmax = -1;
+      for (int c = 0; c < p.C; ++c) {
+        double cc = 0;
+        for (int k = 0; k < 16; ++k) { tot2[k] += (double)h[(size_t)c * 16 + k]; if (k < 10 && k != 6) cc += (double)h[(size_t)c * 16 + k]; }
+        if (cc > cmax) { cmax = cc; wmax = c; }
+      }
+      row("all chains", tot2);
+      double am[16]; for (int k = 0; k < 16; ++k) am[k] = (double)h[wmax * 16 + k];
+      char nm[64]; snprintf(nm, sizeof nm, "longest chain %zu", wmax);
+      row(nm, am);
+      return rc;
+    }
     if (strstr(e->kc.name, "wn_fast_kernel")) {  // rows: 8 waves per 16-chain group (T waves 0..6, B wave 7)
       const size_t groups = (size_t)(p.C + 15) / 16;
       for (int w = 0; w < 8; ++w) {

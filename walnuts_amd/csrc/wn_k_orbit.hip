@@ -28,8 +28,16 @@
 // never counted.  The arithmetic of a micro step and of every sum is the one-stream engine's, so the two kernels agree bit for bit
 // (tests/test_gpu_orbit.py) -- WN_ORBIT_LEGACY=1 runs the old kernel.
 //
-// LDS per chain (doubles): ring q / v 2 x 256, ring scalars 80 + 48 (ints), passive orbit end (q, v, g) 48, two proposals (q) 32,
-// sub-tree slots (levels >= 5 and leaf 0) 32 (M + 1): 9.1 KB at M = 12 -- 16 chains per CU, all 4096 resident.
+// A wave that has its SIMD to itself pays 25-55 cycles for EVERY branch, taken or not (tools/branch_cost.hip,
+// profiles/r04_branch_cost.txt: a not-taken s_cbranch 26, an exec-mask region 37, v_cmp -> vcc -> branch 40-55, against 5.75 for a
+// dependent v_fma_f64), so the T phase is written to be straight: the draws of a whole batch are made lane-parallel before it (one
+// Philox block per lane, three ds_bpermute gathers), a leaf's scalars go into lane k of a few registers with selects (the R phase
+// reads them where they are), the ring stores need no exec mask (lanes >= 16 write to a dump area), a non-finite energy shortens
+// the batch through a scalar select, and the common macro step (first pass accepted, no R2P re-integration, no backward search) is
+// one branch away from its end.
+//
+// LDS per chain (doubles): ring q / v 2 x 256, dump 64, passive orbit end (q, v, g) 48, two proposals (q) 32, sub-tree slots
+// (levels >= 5 and leaf 0) 32 (M + 1): 8.4 KB at M = 12 -- 16 chains per CU, all 4096 resident.
 // The proposal keeps q only: the gradient at the start of an iteration is re-evaluated, as the reference does (WALNUTS.py:249).
 #include "wn_launch.h"
 #include "wn_policy_wave.h"
@@ -39,10 +47,7 @@ namespace wn {
 namespace orbit {
 typedef __attribute__((address_space(3))) double lds_d;
 typedef __attribute__((address_space(3))) int lds_i;
-enum {
-  RQ = 0, RV = 256, SH = 512, SLP = 528, SLW = 544, SHH = 560, SUP = 576, SI = 592 /* 5 x 16 ints */, COLDQ = 640, COLDV = 656, COLDG = 672,
-  PROP = 688, SLOT = 720
-};
+enum { RQ = 0, RV = 256, DUMP = 512, COLDQ = 576, COLDV = 592, COLDG = 608, PROP = 624, SLOT = 656 };
 __host__ __device__ constexpr int lds_doubles(int M) { return SLOT + 32 * (M + 1); }
 
 // row_shr:1 with zero fill at the first lane of each row of 16
@@ -63,8 +68,22 @@ __device__ __forceinline__ double rowmin_d(double x) {  // fmin: a NaN operand i
   x = fmin(x, wn_dpp<0xB1>(x)); x = fmin(x, wn_dpp<0x4E>(x)); x = fmin(x, wn_dpp<0x141>(x)); x = fmin(x, wn_dpp<0x140>(x));
   return x;
 }
+// serial prefix sum over a row, in order: after t steps lane k holds x_k + (prefix of lane k-1) for every k <= t; further steps change
+// nothing.  Straight code (a loop pays a branch per step): 3 steps cover batches of up to 4 leaves, 15 every batch.
+__device__ __forceinline__ double scan_steps(double s, double xs, int nbat) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t) s = xs + shr1(s);
+  if (nbat > 4) {
+#pragma unroll
+    for (int t = 0; t < 12; ++t) s = xs + shr1(s);
+  }
+  return s;
+}
 __device__ __forceinline__ int rl_i(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
 __device__ __forceinline__ int uni_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// a condition that is the same in every lane, as a SCALAR branch condition (v_cmp -> vcc -> s_cbranch_vccnz costs a lone wave 40-55 cycles,
+// a scalar compare and branch 26-35: tools/branch_cost.hip)
+__device__ __forceinline__ bool uni_b(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 }  // namespace orbit
 
 template <class Tgt, int INTEG>
@@ -72,7 +91,6 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
   using namespace orbit;
   extern __shared__ double wn_orbit_lds[];
   lds_d* const L = (lds_d*)wn_orbit_lds;
-  lds_i* const LI = (lds_i*)(L + SI);
   const int lane = threadIdx.x;
   const int k16 = lane & 15;
   const int row = lane >> 4;
@@ -112,12 +130,12 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
   // vectors: one element per lane (rows 1..3 hold copies of row 0); active end of the orbit, v in forward-time orientation
   double qa, va = 0.0, ga;
   // scalars of WALNUTS.py:189-695 (uniform over the wave)
-  double H0 = 0.0, Ha = 0.0, Hb = 0.0, lp0, WoldSum = 1.0, WnewSum = 0.0, lwtSumf = 0.0, lwtSumb = 0.0, h2 = 0.0;
+  double H0 = 0.0, Ha = 0.0, Hb = 0.0, lp0, WoldSum = 1.0, WnewSum = 0.0, lwtSumf = 0.0, lwtSumb = 0.0;
   double orbitLen_ = 0.0, orbitLenSam_ = 0.0, indexStat_ = 0.0, indexStatOld_ = 0.0, timeLenF_ = 0.0, timeLenB_ = 0.0;
   double minlw = INFINITY, maxlw = -INFINITY, Hmin = INFINITY, Hmax = -INFINITY, lpP = 0.0, lpPL = 0.0;
   double gen_sum = 0.0;
   int iter = 1, i = 0, xi = 1, a = 0, b = 0, n = 0, nleaf = 1;
-  uint32_t Bbits = 0, ku = 0;
+  uint32_t Bbits = 0, ku = 0, khc = 0;
   int nevalF = 0, nevalB = 0, L_ = 0, Lold_ = 0, NdS = 0, NdC = 0, maxFint = 0, maxBint = 0, stopCode = 0;
   int minIf = 1 << 30, maxIf = -(1 << 30), minc = 1 << 30, maxc = -(1 << 30), nneq = 0, nzero = 0, nused = 0;
   int ip = 0, ipl = 0;
@@ -127,10 +145,6 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
   const int clc = inrange ? cl : 0;
   const double dlt = prm.delta, Hc = prm.H;
 
-  auto draw_h = [&](uint32_t k) -> double {  // numpy legacy uniform(low, high) = low + (high-low)*U  (WALNUTS.py:298,395)
-    const double low = Hc * (1 - prm.s), high = Hc * (1 + prm.s);
-    return low + (high - low) * uni(k);
-  };
   auto row0_store = [&](int off, double x) { if (lane < 16) L[off + lane] = x; };
   auto row_load = [&](int off) -> double { return L[off + k16]; };
 
@@ -157,8 +171,15 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
     if (inrange) emit_generated(0, qa);  // samples[:,0] = generated(q0)  (:164)
   }
   bool live = inrange && prm.numIter >= 1;
+  unsigned long long st_[16], st_last_ = 0;  // diagnostic builds (-DWN_STAMPS): cycles per phase
+#pragma unroll
+  for (int k = 0; k < 16; ++k) st_[k] = 0;
+#if defined(WN_STAMPS)
+  st_last_ = __builtin_readcyclecounter();
+#endif
 
   // one micro pass of 2**cc leapfrog steps (adaptiveIntegrators.py:72-94) from (qs, vs, gs); returns "the pass is accepted"
+  // (the sums are the same in every lane)
   double hcur = 0.0;  // step size h of the running macro step
   auto run_pass = [&](double qs, double vs, double gs, double HamStart, int cc, double& q, double& v, double& g, double& lpC, double& HC,
                       int& nev) -> bool {
@@ -167,8 +188,9 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
     const int nstep = 1 << cc;
     bool allfin = isfinite(HamStart);
     const double hh2 = 0.5 * hh, hq = hh;
+    int s = nstep;
 #pragma unroll 1
-    for (int s = 0; s < nstep; ++s) {
+    do {  // one branch per micro step
       v = v + hh2 * g; q = q + hq * v;
       double lpp = tgt.grad(&q, &g, lane);
       double ke = 0.0;
@@ -176,13 +198,22 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
       reduce2(lpp, ke);
       const double Hi = -lpp + 0.5 * ke;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
       lpC = lpp; HC = Hi;
-      if (!isfinite(Hi)) allfin = false;
-    }
+      allfin = allfin && isfinite(Hi);
+    } while (--s);
     nev += nstep;
-    return allfin && (fabs(HamStart - HC) < dlt);  // all(isfinite(Hams)) and abs(Hams[0]-Hams[-1]) < delta  (:87-94)
+    return uni_b(allfin && (fabs(HamStart - HC) < dlt));  // all(isfinite(Hams)) and abs(Hams[0]-Hams[-1]) < delta  (:87-94)
   };
+  // ---- per-leaf records of the running block, lane k (of every row) = leaf k: written by the T phase with selects, read by the R
+  // phase where they are ----
+  double HnV = 0.0, lpV = 0.0, hV = 0.0, upV = 0.0, urV = 0.0;
+  int iA = 0, iB = 0;  // If | Ib << 8 | c << 16;  nEvalF | nEvalB << 16
+  // ring stores without an exec mask: lanes >= 16 write to the dump area
+  const int ring_base = lane < 16 ? RQ + lane : DUMP + lane;
+  const int ring_step = lane < 16 ? 16 : 0;
+  const int ring_vofs = lane < 16 ? RV - RQ : 0;
 
   while (__any(live)) {  // ---- iterations (WALNUTS.py:189) ----
+    WN_STAMP(9);
     // ---- iteration start (:196-276) ----
     rng_ensure((uint32_t)iter, 0u);  // uniforms 0..63: the M <= 24 direction bits and the first steps
     Bbits = 0;
@@ -217,6 +248,7 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
     i = 0;
     xi = (Bbits & 1u) ? -1 : 1;
     bool endIter = false;
+    WN_STAMP(8);
 
     while (!endIter) {  // ---- doublings (:281) ----
       {  // start of doubling i (:283-294)
@@ -240,102 +272,125 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
         const int nb0 = n & ~15;
         const int k0 = n & 15;
         int k1 = nleaf - nb0 < 16 ? nleaf - nb0 : 16;
+        // =========================== the draws of leaves k0 .. k1-1, lane-parallel ===========================
+        // In the reference's order an even leaf of a doubling i >= 1 draws the pair's two step sizes (:395), every leaf its
+        // R2P uniform (adaptiveIntegrators.py:392) and -- when WnewSum > exp(-699) -- its multinomial uniform (:426); the single leaf
+        // of doubling 0 draws one step size (:298) and its R2P uniform.  With "every leaf of the batch takes / skips the multinomial
+        // draw" (pred) the index of every draw is a closed form of the leaf's position; the R phase checks the assumption.
+        {
+          const bool pred = fw ? predF : predB;
+          const uint32_t r_ = INTEG == I_ADAPT_R2P ? 1u : 0u, p_ = (pred && i != 0) ? 1u : 0u;
+          const uint32_t ce = (i != 0 ? 2u : 1u) + r_ + p_, co = r_ + p_;
+          // (an odd first leaf -- restart inside a pair -- takes the step size drawn with its partner: index khc, just below ku)
+          const uint32_t klow = (k0 & 1) ? khc : ku;
+          const uint32_t base = (uint32_t)uni_i((int)(klow >> 1));
+          {
+            Philox4 r = philox4x32_10(base + (uint32_t)(lane >> 1), (uint32_t)iter, cg, 0u, seedlo, seedhi);
+            ru0 = (lane & 1) ? u53(r.w[2], r.w[3]) : u53(r.w[0], r.w[1]);
+            rb_iter = (uint32_t)iter; rb_base = base;
+          }
+          const uint32_t j = (uint32_t)k16;
+          const uint32_t nE = ((j + 1u) >> 1) - (((uint32_t)k0 + 1u) >> 1), nO = (j >> 1) - ((uint32_t)k0 >> 1);  // even / odd leaves in [k0, j)
+          const uint32_t kuS = ku + ce * nE + co * nO;  // the leaf's first draw
+          const bool evn = (i == 0) || !(j & 1u);
+          uint32_t ih = evn ? kuS : kuS - ce + 1u;  // the second step size of the pair was drawn with the first
+          ih = (j == (uint32_t)k0 && (k0 & 1)) ? khc : ih;
+          const uint32_t ir = evn ? kuS + (i != 0 ? 2u : 1u) : kuS;
+          const uint32_t ipk = ir + r_;
+          const uint32_t off = 2u * base;
+          const double uh = __shfl(ru0, (int)((ih - off) & 63u)), ur = __shfl(ru0, (int)((ir - off) & 63u)), up = __shfl(ru0, (int)((ipk - off) & 63u));
+          const double low = Hc * (1 - prm.s), high = Hc * (1 + prm.s);
+          hV = low + (high - low) * uh;  // numpy legacy uniform(low, high) = low + (high-low)*U  (WALNUTS.py:298,395)
+          urV = ur; upV = up;
+        }
         // =========================== T phase: the integrator calls of leaves k0 .. k1-1 ===========================
         {
-          uint32_t kuT = ku;
-          const bool pred = fw ? predF : predB;
-          int kdone = k0;
+          int kend = k1;
 #pragma unroll 1
-          for (int k = k0; k < k1; ++k) {
-            const int nk = nb0 + k;
-            const bool first = (i == 0) || !(nk & 1);
-            rng_ensure((uint32_t)iter, kuT);
-            if (first) {  // :298: one draw; :395: size=2, before the first step of a leaf pair
-              hcur = draw_h(kuT++);
-              if (i != 0) h2 = draw_h(kuT++);
-            } else hcur = h2;
+          for (int k = k0; k < kend; ++k) {
+            hcur = wn_readlane(hV, k);
+            WN_STAMP(0);
             const double Ham0 = Ha;  // Hs[] of the neighbouring stored index = energy at the active end (:302,400,443,487,530)
             int nEvF = 0, nEvB = 0, If, Ib, cret;
-            double lwt, lpn, Hn;
+            double lpn, Hn;
             double qw, vw, gw, lpC, HC;
             const double vin = (double)xi * va;  // vh = xi*v + ...
             if (INTEG == I_FIXED) {  // adaptiveIntegrators.py:49-59
               run_pass(qa, vin, ga, Ham0, 0, qw, vw, gw, lpC, HC, nEvF);
-              If = Ib = cret = 0; lwt = 0.0; lpn = lpC; Hn = HC;
+              If = Ib = cret = 0; lpn = lpC; Hn = HC;
             } else {
               int cc = minC;  // forward search (:69-94 / 366-389)
               bool ok;
               for (;;) {
-                ok = __any(run_pass(qa, vin, ga, Ham0, cc, qw, vw, gw, lpC, HC, nEvF));
+                ok = run_pass(qa, vin, ga, Ham0, cc, qw, vw, gw, lpC, HC, nEvF);
                 if (ok || cc >= maxC) break;
                 ++cc;
               }
               If = ok ? cc : maxC;  // Q5: the last computed state is used silently
-              int cSim, maxTry;
-              double lwtf;
-              if (INTEG == I_ADAPT_R2P) {
-                const double u = uni(kuT++);  // :392
-                if (__any(u < prm.R2Pprob0)) {  // :393-399, 430-433
-                  cSim = If; maxTry = If - 1; Ib = If; lwtf = prm.logP;
-                } else {  // :400-424, 434-437: re-integrate at c = If+1
-                  run_pass(qa, vin, ga, Ham0, If + 1, qw, vw, gw, lpC, HC, nEvF);
-                  cSim = If + 1; maxTry = maxC; Ib = maxC; lwtf = prm.log1mP;
-                }
-              } else {  // adaptLeapFrogD :96-111
-                cSim = If; maxTry = If - 1; Ib = If; lwtf = 0.0;
-              }
+              WN_STAMP(1);
+              // adaptLeapFrogR2P :392: with probability R2Pprob0 keep c = If, else re-integrate at c = If+1
+              const bool keep = INTEG != I_ADAPT_R2P || uni_b(wn_readlane(urV, k) < prm.R2Pprob0);
+              int cSim = If, maxTry = If - 1;
+              Ib = If;
               lpn = lpC; Hn = HC;
-              if (maxTry >= minC) {  // backward search from (qOut, -vOut, gOut)  (:107-132 / 440-464)
-                const double qo = qw, vo = vw, go = gw;
-                double lpB, HB;
-                for (cc = minC;; ++cc) {
-                  ok = __any(run_pass(qo, -vo, go, Hn, cc, qw, vw, gw, lpB, HB, nEvB));
-                  if (ok) { Ib = cc; break; }
-                  if (cc >= maxTry) break;
+              if (!keep || maxTry >= minC) {  // (the common macro step -- first pass accepted, kept -- skips all of this)
+                if (!keep) {  // :400-424, 434-437
+                  run_pass(qa, vin, ga, Ham0, If + 1, qw, vw, gw, lpC, HC, nEvF);
+                  cSim = If + 1; maxTry = maxC; Ib = maxC;
+                  lpn = lpC; Hn = HC;
                 }
-                qw = qo; vw = vo; gw = go;
+                if (maxTry >= minC) {  // backward search from (qOut, -vOut, gOut)  (:107-132 / 440-464)
+                  const double qo = qw, vo = vw, go = gw;
+                  double lpB, HB;
+                  for (cc = minC;; ++cc) {
+                    ok = run_pass(qo, -vo, go, Hn, cc, qw, vw, gw, lpB, HB, nEvB);
+                    if (ok) { Ib = cc; break; }
+                    if (cc >= maxTry) break;
+                  }
+                  qw = qo; vw = vo; gw = go;
+                }
               }
-              if (INTEG == I_ADAPT_R2P) {  // :466-475
-                double lwtb = WN_LOGZERO;
-                if (cSim == Ib) lwtb = prm.logP;
-                else if (cSim == Ib + 1) lwtb = prm.log1mP;
-                cret = cSim;
-                lwt = lwtb - lwtf;
-              } else {  // :135-137
-                cret = If;
-                lwt = (If != Ib) ? WN_LOGZERO : 0.0;
-              }
+              cret = INTEG == I_ADAPT_R2P ? cSim : If;  // :135-137 / 466-475 (lwt follows from If, Ib, c: the R phase forms it)
             }
-            // the leaf's multinomial uniform (:426) sits behind its step sizes and its R2P draw -- if it is drawn at all
-            const double up = uni(kuT);
-            if (pred && i != 0) kuT++;
+            WN_STAMP(2);
             // intOut.v is in forward-time orientation (adaptiveIntegrators.py:57,135,473); the new state becomes the active end
             qa = qw; va = (double)xi * vw; ga = gw; Ha = Hn;
-            if (lane < 16) {
-              L[RQ + 16 * k + lane] = qa; L[RV + 16 * k + lane] = va;
-              if (lane == 0) {
-                L[SH + k] = Hn; L[SLP + k] = lpn; L[SLW + k] = lwt; L[SHH + k] = hcur; L[SUP + k] = up;
-                LI[k] = If; LI[16 + k] = Ib; LI[32 + k] = cret; LI[48 + k] = nEvF; LI[64 + k] = nEvB;
-              }
+            L[ring_base + ring_step * k] = qa; L[ring_base + ring_vofs + ring_step * k] = va;
+            {
+              const bool mk = k16 == k;
+              HnV = mk ? Hn : HnV; lpV = mk ? lpn : lpV;
+              iA = mk ? (If | (Ib << 8) | (cret << 16)) : iA;
+              iB = mk ? (nEvF | (nEvB << 16)) : iB;
             }
-            // left endpoint of the sub-trees of 2**j leaves, j >= 5, that start here (levels 1..4 stay inside the ring)
-            if (k == 0 && (nk == 0 ? i >= 5 : __builtin_ctz((unsigned)nk) >= 5)) {
-              const int sl = nk == 0 ? 0 : __builtin_ctz((unsigned)nk);
-              if (lane < 16) { L[SLOT + 32 * sl + lane] = qa; L[SLOT + 32 * sl + 16 + lane] = va; }
-            }
-            kdone = k + 1;
-            if (__any(!isfinite(Hn))) break;  // forced reject (:316-319): nothing behind this leaf will be used
+            // forced reject (:316-319): nothing behind a non-finite energy will be used -- the batch ends here
+            kend = uni_b(isfinite(Hn)) ? kend : k + 1;
+            st_[6] += 1; st_[11] += (unsigned long long)(nEvF + nEvB);
+            WN_STAMP(3);
           }
-          k1 = kdone;
+          k1 = kend;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // left endpoint of the sub-trees of 2**j leaves, j >= 5, that start at this block's first leaf (levels 1..4 stay inside the ring)
+        if (k0 == 0 && (nb0 == 0 ? i >= 5 : __builtin_ctz((unsigned)nb0) >= 5)) {
+          const int sl = nb0 == 0 ? 0 : __builtin_ctz((unsigned)nb0);
+          const double tq = L[RQ + k16], tv = L[RV + k16];
+          L[(lane < 16 ? SLOT + 32 * sl : DUMP) + lane] = tq; L[(lane < 16 ? SLOT + 32 * sl + 16 : DUMP) + lane] = tv;
+        }
         // =========================== R phase: bookkeeping of leaves k0 .. k1-1, lane k = leaf k ===========================
         const int k = k16;
         const bool inb = k >= k0 && k < k1;
-        const double Hn_k = L[SH + k], lw_k = L[SLW + k], h_k = L[SHH + k], up_k = L[SUP + k], lp_k = L[SLP + k];
-        const int If_k = LI[k], Ib_k = LI[16 + k], c_k = LI[32 + k], ef_k = LI[48 + k], eb_k = LI[64 + k];
+        const double Hn_k = HnV, h_k = hV, up_k = upV, lp_k = lpV;
+        const int If_k = iA & 255, Ib_k = (iA >> 8) & 255, c_k = iA >> 16, ef_k = iB & 0xFFFF, eb_k = iB >> 16;
+        double lw_k;  // lwt of the macro step (adaptiveIntegrators.py:57-59 / 135-137 / 466-475)
+        if (INTEG == I_ADAPT_R2P) {
+          const double lwtf = c_k == If_k ? prm.logP : prm.log1mP;
+          const double lwtb = c_k == Ib_k ? prm.logP : (c_k == Ib_k + 1 ? prm.log1mP : WN_LOGZERO);
+          lw_k = lwtb - lwtf;
+        } else if (INTEG == I_ADAPT_D) {
+          lw_k = (If_k != Ib_k) ? WN_LOGZERO : 0.0;
+        } else lw_k = 0.0;
         const int nk = nb0 + k;
         const bool first_k = (i == 0) || !(nk & 1);
         const int nbat = k1 - k0;
@@ -349,8 +404,7 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
           double s = inb ? x : 0.0;
           s = (k == k0) ? carry + s : s;
           const double xs = s;
-#pragma unroll 1
-          for (int t = 1; t < nbat; ++t) s = xs + shr1(s);
+          s = scan_steps(s, xs, nbat);
           P1 = s;
         }
         const double Wn = exp(-Hn_k + H0 + P1);  // Wnew = exp(-H + H0 + lwtSum)  (row 0)
@@ -360,10 +414,10 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
           const double carry = (i == 0) ? 0.0 : WnewSum;
           s = (k == k0) ? carry + s : s;
           const double xs = s;
-#pragma unroll 1
-          for (int t = 1; t < nbat; ++t) s = xs + shr1(s);
+          s = scan_steps(s, xs, nbat);
           WS = s;
         }
+        WN_STAMP(4);
         const bool inb0 = inb && lane < 16;
         const bool drawn_k = (i != 0) && (WS > prm.wtSumThresh);
         // :426  take this state with probability Wnew / WnewSum; i == 0 (:322-328): unconditional, no uniform
@@ -433,6 +487,7 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
             }
           }
         }
+        WN_STAMP(5);
         // ---- the first event decides how many leaves of the batch stand ----
         const int t_nf = m_nf ? __builtin_ctzll(m_nf) : 64;
         const int t_sub = m_fire ? __builtin_ctzll(m_fire) : 64;
@@ -508,6 +563,8 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
             Ha = wn_readlane(Hn_k, Lfull);
           }
         }
+        st_[10] += 1; st_[12] += redo ? 1 : 0;
+        WN_STAMP(7);
         if (f0_now && !end_nf && !end_sub && !redo) fire0 = true;
         n = nb0 + Lfull + 1;
         if (end_nf) {  // :316-319, 414-417, 457-459 (Q3, Q4)
@@ -521,11 +578,8 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
           qa = L[RQ + 16 * Lfull + k16]; va = L[RV + 16 * Lfull + k16];
           double lpp = tgt.grad(&qa, &ga, lane);
           (void)lpp;
-          if (n & 1) {  // the pair's second step size was drawn with the first (:395)
-            const uint32_t kh = ku - 1u - (INTEG == I_ADAPT_R2P ? 1u : 0u) - (uint32_t)((m_dr >> Lfull) & 1ull);
-            rng_ensure((uint32_t)iter, kh);
-            h2 = draw_h(kh);
-          }
+          // the second step size of a pair was drawn with the first (:395): its index, for a restart at the pair's second leaf
+          khc = ku - 1u - (INTEG == I_ADAPT_R2P ? 1u : 0u) - (uint32_t)((m_dr >> Lfull) & 1ull);
         }
       }
       if (endIter) break;
@@ -580,6 +634,13 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
     if (iter > prm.numIter) live = false;
   }
   (void)gen_sum;
+#if defined(WN_STAMPS)
+  WN_STAMP(9);
+  if (prm.stamps && lane == 0) {
+    unsigned long long* o = prm.stamps + (size_t)blockIdx.x * 16;
+    for (int k = 0; k < 16; ++k) o[k] = st_[k];
+  }
+#endif
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
@@ -590,7 +651,7 @@ bool orbit_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& 
   if (warm || prm.mode != MODE_SAMPLE || prm.trace_n || prm.trace || prm.omin) return false;
   if (adapt == 2) return false;
   if (prm.integrator != I_FIXED && prm.integrator != I_ADAPT_D && prm.integrator != I_ADAPT_R2P) return false;
-  if (prm.M < 1 || prm.M > MAX_M || prm.D > 16) return false;
+  if (prm.M < 1 || prm.M > MAX_M || prm.D > 16 || prm.maxC > 12 || prm.minC < 0 || prm.minC > prm.maxC) return false;
   if (prm.generated != G_IDENTITY && prm.generated != G_FIRSTK && prm.generated != G_Q0_SUMSQ) return false;
   if (getenv("WN_ORBIT_LEGACY")) return false;
   switch (kc.p1) {

@@ -25,11 +25,13 @@ struct EmptyVecW {};
 #define WN_CL_SLEEP 8  // 64-cycle units between polls of a cluster's arrival counter
 #endif
 
+// (every CTRL used with wn_dpp is a permutation inside the row -- quad_perm, row_mirror, row_half_mirror: no lane reads out of
+//  bounds.  bound_ctrl = true tells the compiler so: with `false` it materialised the unused `old` operand, two v_mov_b32 per step.)
 template <int CTRL>
 __device__ __forceinline__ double wn_dpp(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 // sum over the 64 lanes, same bits everywhere: xor-1, xor-2 inside quads, mirrored halves and rows
@@ -340,7 +342,11 @@ struct WTgtFunnel10 {
     // (q0 / 9 and q0^2 / 18 as multiplications by the rounded reciprocals: two f64 divisions were a fifth of the
     // instructions of an evaluation; the result differs from the division's by at most one ulp, as the device exp()
     // differs from libm's)
-    g[0] = lane == 0 ? (-5.0 - q0 * (1.0 / 9.0) + 0.5 * emq * ss) : (lane < 11 ? -q[0] * emq : 0.0);
+    // (select form: both arms computed by every lane.  As `lane == 0 ? <expr> : <expr>` the compiler built a divergent if / else --
+    //  two exec-mask regions and a branch per evaluation, ~100 cycles for a wave alone on its SIMD, tools/branch_cost.hip)
+    double g_first = -5.0 - q0 * (1.0 / 9.0) + 0.5 * emq * ss, g_rest = -q[0] * emq;
+    asm volatile("" : "+v"(g_first), "+v"(g_rest));  // (opaque: the compiler sank the two expressions back into an if / else)
+    g[0] = lane == 0 ? g_first : (lane < 11 ? g_rest : 0.0);
     const double lp = (-(q0 * q0) * (1.0 / 18.0) - logC - log3) + (-0.5 * emq * ss - 10.0 * logC - 5.0 * q0);
     // s = np.exp(0.5*q0) overflowing makes the reference's lp -inf (targetDistr.py:75, WALNUTS.py:316)
     const double r = (0.5 * q0 > 709.782712893384) ? -INFINITY : lp;
