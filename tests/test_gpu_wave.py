@@ -317,10 +317,19 @@ def test_nested_driver_is_bit_identical_to_the_tick_loop(wa, tk, D, ig, minC):
     for traced in (False, True):
         e = wa.Engine(D, C, integrator=ig, H0=kw["H0"], delta0=kw["delta0"], M=kw["M"], minC=minC, chain_offset=123)
         e.set_target(tk, tpar)
-        assert "wave" in e.kernel_name, e.kernel_name
+        assert "wave" in e.kernel_name or "orbit" in e.kernel_name, e.kernel_name
         r = e.run(q0, SEED, kw["numIter"], trace_cap=4 if traced else 0)
         outs.append((r[0].cpu().numpy(), r[1].cpu().numpy()))
+        orbit = "orbit" in e.kernel_name
         e.close()
-    np.testing.assert_array_equal(outs[0][1], outs[1][1], err_msg="diagnostics")
+    if orbit:
+        # <= 16-D targets: the plain run is the trajectory-first kernel (wn_k_orbit.hip), the traced run the tick loop.  Same
+        # arithmetic per micro step and per sum; the orbit energy error of the FIRST iteration alone may differ in the last bit
+        # (its H0 comes from lp(q0), evaluated at another inlined code site: tests/test_gpu_orbit.py same_run)
+        k = [c for c in range(24) if c != 17]
+        np.testing.assert_array_equal(outs[0][1][:, :, k], outs[1][1][:, :, k], err_msg="diagnostics")
+        np.testing.assert_allclose(outs[0][1][:, :, 17], outs[1][1][:, :, 17], rtol=1e-12, atol=1e-13)
+    else:
+        np.testing.assert_array_equal(outs[0][1], outs[1][1], err_msg="diagnostics")
     np.testing.assert_array_equal(outs[0][0], outs[1][0], err_msg="draws")
     assert outs[0][1][:, :, 6].sum() > 0

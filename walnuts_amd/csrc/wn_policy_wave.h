@@ -82,6 +82,37 @@ __device__ __forceinline__ double wn_rowsum0(double x) {
 }
 
 
+// exp(x) with the device library's own algorithm and constants (dn = rint(x log2 e), t = x - dn ln2 in two pieces, a
+// degree-11 polynomial, ldexp; ocml expD) -- but with the Horner steps as THREE-operand v_fma_f64: the compiler turns
+// `fma(t, p, c)` into v_mov_b64 acc, c + v_fmac_f64 (two instructions per step: 11 extra moves per exp, and the wave
+// kernels are bound by the instruction count of one wave).  The steps are opaque to the compiler (inline asm), so an
+// exp of a uniform argument is still computed per lane -- what the callers want.
+__device__ __forceinline__ double wn_fma3(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ double wn_exp(double x) {
+  const double dn = rint(x * 0x1.71547652b82fep+0);
+  double t = wn_fma3(dn, -0x1.62e42fefa39efp-1, x);
+  t = wn_fma3(dn, -0x1.abc9e3b39803fp-56, t);
+  double p = wn_fma3(t, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+  p = wn_fma3(t, p, 0x1.71dee623fde64p-19);
+  p = wn_fma3(t, p, 0x1.a01997c89e6b0p-16);
+  p = wn_fma3(t, p, 0x1.a01a014761f6ep-13);
+  p = wn_fma3(t, p, 0x1.6c16c1852b7b0p-10);
+  p = wn_fma3(t, p, 0x1.1111111122322p-7);
+  p = wn_fma3(t, p, 0x1.55555555502a1p-5);
+  p = wn_fma3(t, p, 0x1.5555555555511p-3);
+  p = wn_fma3(t, p, 0x1.000000000000bp-1);
+  p = wn_fma3(t, p, 1.0);
+  p = wn_fma3(t, p, 1.0);
+  double z = ldexp(p, (int)dn);
+  z = x > 0x1.62e42fefa39efp+9 ? INFINITY : z;
+  z = x < -0x1.74910d52d3051p+9 ? 0.0 : z;
+  return z;  // (a NaN argument gives NaN: both comparisons are false)
+}
+
 template <int CTRL>
 __device__ __forceinline__ double wn_dpp0(double x) {  // out-of-row sources read as zero
   int lo = __double2loint(x), hi = __double2hiint(x);
@@ -151,90 +182,113 @@ struct WTgtExt {
 };
 
 
+// ---- wave scans on DPP only (GFX9 DPP: wave_shr / wave_shl / row_bcast exist on gfx950) ----
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double wn_dppm(double x) {  // lanes outside ROWMASK, and out-of-range sources, read as zero
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// lane l gets lane l-1's value (lane 0: zero) / lane l+1's value (lane 63: zero): one DPP move per half, no LDS round trip
+__device__ __forceinline__ double wn_wave_shr1(double x) { return wn_dpp0<0x138>(x); }
+__device__ __forceinline__ double wn_wave_shl1(double x) { return wn_dpp0<0x130>(x); }
+// inclusive prefix sum over the 64 lanes: row_shr 1, 2, 4, 8 inside the rows, then row_bcast:15 into rows 1 and 3 and
+// row_bcast:31 into rows 2 and 3 (six DPP steps, no v_readlane)
+__device__ __forceinline__ double wn_scan_up_b(double x) {
+  x += wn_dpp0<0x111>(x);
+  x += wn_dpp0<0x112>(x);
+  x += wn_dpp0<0x114>(x);
+  x += wn_dpp0<0x118>(x);
+  x += wn_dppm<0x142, 0xA>(x);  // row_bcast:15
+  x += wn_dppm<0x143, 0xC>(x);  // row_bcast:31
+  return x;
+}
+
 // StockWatson stochastic volatility (BASELINE.json config 5; WALNUTSpy_examples/StockWatson/
 // sw_innov.stan:7-51 as bridgestan's log_density_gradient would evaluate it: unconstrained
 // parameters, constants dropped).  D = 3T, parameter order tSigma, z1, zinn[T-2], x1, xinn[T-1],
 // tau1, tauinn[T-1]; tpar = [T, y[1..T]], T <= 256.
 //
-// The three latent series are cumulative sums over time, so the gradient is evaluated in a
-// time-major mapping -- lane l owns t = 4l+1 .. 4l+4 of every series -- reached from the striped
-// register layout through a 6 KB LDS transpose; forward (z, x, tau) and backward (adjoint) sums are
-// lane-local runs of four plus DPP wave scans of the lane totals (wn_scan_up / wn_scan_down).
+// The three latent series are cumulative sums over time, so the chain's vectors live in a TIME-MAJOR register layout
+// (MAPPED: the policy asks the target where an element sits): lane l owns t = 4l+1 .. 4l+4, register 4s+k holds series s
+// (0 = the z block, 1 = x, 2 = tau) at t = 4l+k+1; tSigma, which belongs to no series, sits in the z block's unused slot
+// t = T.  The engine's vector arithmetic is element-wise and its sums are over all lanes, so it does not care; the
+// gradient needs no transpose (round 3 moved q and g through a 6 KB LDS transpose and back on every evaluation: 48 LDS
+// accesses and three fences), forward (z, x, tau) and backward (adjoint) sums are lane-local runs of four plus wave scans
+// of the lane totals on DPP alone (wn_scan_up_b, wn_wave_shr1: round 3 used ds_bpermute shifts and v_readlane row
+// totals), every conditional is a select (a lone wave pays 25-55 cycles per branch or exec-mask region), and exp() is
+// wn_exp.
 template <int NE>
 struct WTgtStockWatson {
+  static_assert(NE == 12, "three series x four time points per lane");
   static constexpr int EXT = EXT_NONE;
   static constexpr int TPL = 4;              // time points per lane
-  static constexpr int LDS_DOUBLES = 64 * NE;
+  static constexpr int LDS_DOUBLES = 0;
   static constexpr int VEC_LDS = 0;
   static constexpr bool SPEC_ENGINE = true;  // tick-latency bound: plain sampling runs get the specialised engine (wn_k_wave.hip go())
-  int T;
+  static constexpr bool MAPPED = true;
+  int T, laneT, kT;
   double y[TPL];
-  double* lds;
-  __device__ __forceinline__ void init(const Params& prm, int lane, double* lds_) {
+  __device__ __forceinline__ void init(const Params& prm, int lane, double*) {
     T = (int)prm.tpar[0];
-    lds = lds_;
+    laneT = (T - 1) >> 2; kT = (T - 1) & 3;
 #pragma unroll
     for (int k = 0; k < TPL; ++k) { const int t = TPL * lane + k + 1; y[k] = t <= T ? prm.tpar[t] : 0.0; }
   }
+  // element held by register e of lane `lane` (parameter index), or -1
+  __device__ __forceinline__ int map_gidx(int e, int lane) const {
+    const int s = e >> 2, t = TPL * lane + (e & 3) + 1;
+    if (t > T) return -1;
+    if (s == 0) return t == T ? 0 : t;
+    return s * T + t - 1;
+  }
   __device__ __forceinline__ static double lp_finish(double r) { return r; }
-  __device__ __forceinline__ static double shup(double v, int d, int lane) {
-    const double o = __shfl_up(v, d);
-    return lane >= d ? o : 0.0;
-  }
-  __device__ __forceinline__ static double shdn(double v, int d, int lane) {
-    const double o = __shfl_down(v, d);
-    return lane + d < 64 ? o : 0.0;
-  }
-  // sum of the totals of all lower / higher lanes: shift by one lane, then an inclusive DPP scan
-  __device__ __forceinline__ static double excl_below(double tot, int lane) { return wn_scan_up(shup(tot, 1, lane), lane); }
-  __device__ __forceinline__ static double excl_above(double tot, int lane) { return wn_scan_down(shdn(tot, 1, lane), lane); }
+  __device__ __forceinline__ static double sel4(const double* a, int k) { return k == 0 ? a[0] : k == 1 ? a[1] : k == 2 ? a[2] : a[3]; }
   __device__ __forceinline__ double grad(const double* q, double* g, int lane) const {
-#pragma unroll
-    for (int e = 0; e < NE; ++e) lds[e * 64 + lane] = q[e];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const double tS = lds[0];
-    const double sigma = exp(-0.5 * tS), gpri = exp(tS);
-    double uz[TPL], ux[TPL], tin[TPL], z[TPL], x[TPL], tau[TPL];
+    const double tS = wn_readlane(sel4(q, kT), laneT);
+    const double sigma = wn_exp(-0.5 * tS), gpri = wn_exp(tS);
     const int t0 = TPL * lane + 1;  // first time point of this lane (1-based)
+    double rz[TPL], rx[TPL], tin[TPL], uz[TPL], ux[TPL], z[TPL], x[TPL], tau[TPL];
 #pragma unroll
     for (int k = 0; k < TPL; ++k) {
       const int t = t0 + k;
-      // raw parameters of the three blocks at time t (first entry of a block = initial state)
-      const double rz = t <= T - 1 ? lds[t] : 0.0;           // z1 | zinn[t-1]
-      const double rx = t <= T ? lds[T + t - 1] : 0.0;       // x1 | xinn[t-1]
-      tin[k] = t <= T ? lds[2 * T + t - 1] : 0.0;            // tau1 | tauinn[t-1]
-      uz[k] = t == 1 ? rz : sigma * rz;
-      ux[k] = t == 1 ? rx : sigma * rx;
+      // raw parameters of the three blocks at time t (first entry of a block = initial state; slots beyond the series hold zeros,
+      // the z slot t = T holds tSigma)
+      rz[k] = t <= T - 1 ? q[k] : 0.0;       // z1 | zinn[t-1]
+      rx[k] = q[4 + k];                      // x1 | xinn[t-1]
+      tin[k] = q[8 + k];                     // tau1 | tauinn[t-1]
+      uz[k] = t == 1 ? rz[k] : sigma * rz[k];
+      ux[k] = t == 1 ? rx[k] : sigma * rx[k];
     }
     // z[t], x[t]: inclusive sums over time (sw_innov.stan:27-31)
     double run = 0.0;
 #pragma unroll
     for (int k = 0; k < TPL; ++k) { run += uz[k]; z[k] = run; }
-    double base = excl_below(run, lane);
+    double base = wn_scan_up_b(wn_wave_shr1(run));
 #pragma unroll
     for (int k = 0; k < TPL; ++k) z[k] += base;
     run = 0.0;
 #pragma unroll
     for (int k = 0; k < TPL; ++k) { run += ux[k]; x[k] = run; }
-    base = excl_below(run, lane);
+    base = wn_scan_up_b(wn_wave_shr1(run));
 #pragma unroll
     for (int k = 0; k < TPL; ++k) x[k] += base;
     // tau[t] = tau[t-1] + exp(z[t-1]/2) * tauinn[t-1]  (:33-34): needs z one step back
     double zprev[TPL], ezp[TPL];
-    zprev[0] = shup(z[TPL - 1], 1, lane);
+    zprev[0] = wn_wave_shr1(z[TPL - 1]);
 #pragma unroll
     for (int k = 1; k < TPL; ++k) zprev[k] = z[k - 1];
     run = 0.0;
 #pragma unroll
     for (int k = 0; k < TPL; ++k) {
       const int t = t0 + k;
-      ezp[k] = (t >= 2 && t <= T) ? exp(0.5 * zprev[k]) : 0.0;
+      const double e_ = wn_exp(0.5 * zprev[k]);
+      ezp[k] = (t >= 2 && t <= T) ? e_ : 0.0;
       run += t == 1 ? tin[k] : ezp[k] * tin[k];
       tau[k] = run;
     }
-    base = excl_below(run, lane);
+    base = wn_scan_up_b(wn_wave_shr1(run));
 #pragma unroll
     for (int k = 0; k < TPL; ++k) tau[k] += base;
     // log density (:40-49) and the adjoints of tau[t], x[t]
@@ -243,7 +297,7 @@ struct WTgtStockWatson {
     for (int k = 0; k < TPL; ++k) {
       const int t = t0 + k;
       const bool on = t <= T;
-      const double w = exp(-x[k]), res = y[k] - tau[k];
+      const double w = wn_exp(-x[k]), res = y[k] - tau[k];
       const double rt = (t >= 2 && on) ? tin[k] : 0.0;
       lp += on ? (-0.5 * x[k] - 0.5 * (res * res) * w) : 0.0;
       lp += -0.5 * (rt * rt);
@@ -254,71 +308,55 @@ struct WTgtStockWatson {
 #pragma unroll
     for (int k = 0; k < TPL; ++k) {
       const int t = t0 + k;
-      const double rz = (t >= 2 && t <= T - 1) ? lds[t] : 0.0;
-      const double rx = (t >= 2 && t <= T) ? lds[T + t - 1] : 0.0;
-      lp += -0.5 * (rz * rz) - 0.5 * (rx * rx);
+      const double pz = (t >= 2) ? rz[k] : 0.0;
+      const double px = (t >= 2) ? rx[k] : 0.0;
+      lp += -0.5 * (pz * pz) - 0.5 * (px * px);
     }
-    if (lane == 0) lp += 5.0 * tS - 0.5 * gpri;
+    lp += lane == 0 ? 5.0 * tS - 0.5 * gpri : 0.0;
     // backward: A[t] = sum_{t' >= t} a[t'], B[t] = sum_{t' >= t} b[t']
     double A[TPL], B[TPL];
     run = 0.0;
 #pragma unroll
     for (int k = TPL - 1; k >= 0; --k) { run += a[k]; A[k] = run; }
-    base = excl_above(run, lane);
+    base = wn_scan_down(wn_wave_shl1(run), lane);
 #pragma unroll
     for (int k = 0; k < TPL; ++k) A[k] += base;
     run = 0.0;
 #pragma unroll
     for (int k = TPL - 1; k >= 0; --k) { run += b[k]; B[k] = run; }
-    base = excl_above(run, lane);
+    base = wn_scan_down(wn_wave_shl1(run), lane);
 #pragma unroll
     for (int k = 0; k < TPL; ++k) B[k] += base;
     // cc[t] = d/dz[t-1] = 1/2 exp(z[t-1]/2) tauinn[t-1] A[t]  (t = 2..T); CS[t] = sum_{t' > t} cc[t']
     double cc[TPL], CS[TPL], dsig = 0.0;
 #pragma unroll
-    for (int k = 0; k < TPL; ++k) {
-      const int t = t0 + k;
-      cc[k] = (t >= 2 && t <= T) ? 0.5 * ezp[k] * tin[k] * A[k] : 0.0;
-    }
+    for (int k = 0; k < TPL; ++k) cc[k] = 0.5 * ezp[k] * tin[k] * A[k];  // (ezp = 0 outside t = 2..T)
     run = 0.0;
 #pragma unroll
     for (int k = TPL - 1; k >= 0; --k) { CS[k] = run; run += cc[k]; }
-    base = excl_above(run, lane);
+    base = wn_scan_down(wn_wave_shl1(run), lane);
 #pragma unroll
     for (int k = 0; k < TPL; ++k) CS[k] += base;
     const double z1 = wn_readlane(z[0], 0), x1 = wn_readlane(x[0], 0);
 #pragma unroll
     for (int k = 0; k < TPL; ++k) {
-      const int t = t0 + k;
-      if (t >= 2 && t <= T) dsig += cc[k] * (zprev[k] - z1);
-      if (t <= T) dsig += b[k] * (x[k] - x1);
+      dsig += cc[k] * (zprev[k] - z1);      // (cc = 0 outside t = 2..T)
+      dsig += b[k] * (x[k] - x1);           // (b = 0 beyond T)
     }
     dsig = wn_wavesum(dsig);
-    __builtin_amdgcn_wave_barrier();
-    // gradients back to the parameter order, through the LDS transpose
+    // gradients, where the parameters are
+    const double gS = 5.0 - 0.5 * gpri - 0.5 * dsig;
 #pragma unroll
     for (int k = 0; k < TPL; ++k) {
       const int t = t0 + k;
-      if (t <= T - 1) lds[t] = t == 1 ? CS[k] : sigma * CS[k] - lds[t];
-      if (t <= T) {
-        const double rx = lds[T + t - 1];
-        lds[T + t - 1] = t == 1 ? B[k] : sigma * B[k] - rx;
-        lds[2 * T + t - 1] = t == 1 ? A[k] : ezp[k] * A[k] - tin[k];
-      }
+      const double gz = t == 1 ? CS[k] : sigma * CS[k] - rz[k];
+      g[k] = t <= T - 1 ? gz : (t == T ? gS : 0.0);
+      const double gx = t == 1 ? B[k] : sigma * B[k] - rx[k];
+      g[4 + k] = t <= T ? gx : 0.0;
+      const double gt = t == 1 ? A[k] : ezp[k] * A[k] - tin[k];
+      g[8 + k] = t <= T ? gt : 0.0;
     }
-    if (lane == 0) lds[0] = 5.0 - 0.5 * gpri - 0.5 * dsig;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll
-    for (int e = 0; e < NE; ++e) g[e] = (e * 64 + lane) < 3 * T ? lds[e * 64 + lane] : 0.0;
-    __builtin_amdgcn_wave_barrier();
     return lp;
-  }
-  __device__ __forceinline__ static double wavesum_(double x) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
-    return x;
   }
 };
 
@@ -337,7 +375,7 @@ struct WTgtFunnel10 {
     const double log3 = 1.09861228866810969140;
     const double q0 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(q[0])),
                                        __builtin_amdgcn_readfirstlane(__double2loint(q[0])));  // lane 0 holds q_0
-    const double emq = exp(-q0);
+    const double emq = wn_exp(-q0);
     const double ss = wn_rowsum0((lane >= 1 && lane < 11) ? q[0] * q[0] : 0.0);
     // (q0 / 9 and q0^2 / 18 as multiplications by the rounded reciprocals: two f64 divisions were a fifth of the
     // instructions of an evaluation; the result differs from the division's by at most one ulp, as the device exp()
@@ -465,9 +503,18 @@ struct WavePolicy {
     }
   }
 
-  __device__ __forceinline__ bool valid(int e) const { return goff + e * ES + l0 < D; }
+  // (a MAPPED target says itself which element register e of a lane holds: time-major layout of the StockWatson series)
+  template <class T_, class = void> struct is_mapped { static constexpr bool value = false; };
+  template <class T_> struct is_mapped<T_, typename std::enable_if<T_::MAPPED>::type> { static constexpr bool value = true; };
+  __device__ __forceinline__ bool valid(int e) const {
+    if constexpr (is_mapped<Tgt>::value) return tgt.map_gidx(e, lane) >= 0;
+    else return goff + e * ES + l0 < D;
+  }
   __device__ __forceinline__ bool owner(int) const { return true; }
-  __device__ __forceinline__ int gidx(int e) const { return goff + e * ES + l0; }
+  __device__ __forceinline__ int gidx(int e) const {
+    if constexpr (is_mapped<Tgt>::value) return tgt.map_gidx(e, lane);
+    else return goff + e * ES + l0;
+  }
   __device__ __forceinline__ bool writer() const { return l0 == 0 && slice == 0; }
   // per-workgroup writer and slot of per-chain scratch that every replica recomputes (warm-up quantile store)
   __device__ __forceinline__ bool wg_writer() const { return l0 == 0; }
