@@ -81,9 +81,11 @@ def test_funnel_wave_kernel_does_not_read_stale_lds(wa):
     q0 = np.zeros((4096, 11)); q0[:, 0] = 3.0 * rng.normal(size=4096)
     q0[:, 1:] = np.exp(0.5 * q0[:, :1]) * rng.normal(size=(4096, 10))
     mk = lambda: wa.Engine(11, 4096, integrator=ol.I_ADAPT_R2P, H0=0.3, delta0=0.3, M=12, generated=ol.G_FIRSTK, gen_k=2).set_target(ol.T_FUNNEL10)
-    assert "funnel10" in _three_runs(wa, mk, q0, 6)
+    assert "wn_orbit_kernel<funnel10" in _three_runs(wa, mk, q0, 6)  # the trajectory-first kernel: ring, slots, proposals in LDS
+    assert "wn_wave_kernel<NE=1,funnel10" in _three_runs(wa, mk, q0, 6, env={"WN_ORBIT_LEGACY": "1"})  # the one-stream engine
     mkd = lambda: wa.Engine(11, 4096, integrator=ol.I_ADAPT_D, H0=0.3, delta0=0.3, M=8).set_target(ol.T_FUNNEL10)
     assert "funnel10" in _three_runs(wa, mkd, q0, 4)
+    assert "wn_wave_kernel" in _three_runs(wa, mkd, q0, 4, env={"WN_ORBIT_LEGACY": "1"})
 
 
 def test_stockwatson_wave_kernel_does_not_read_stale_lds(wa):

@@ -485,7 +485,8 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
       (e->cfg.integrator == WN_I_FIXED || e->cfg.integrator == WN_I_ADAPT_D || e->cfg.integrator == WN_I_ADAPT_R2P) && !getenv("WN_ORBIT_LEGACY")) {
     // plain sampling runs go to the trajectory-first kernel (wn_k_orbit.hip); traced / orbit-statistics runs and
     // wn_integrator_step use the one-stream engine of the same layout
-    snprintf(kc.name, sizeof(kc.name), "wn_orbit_kernel<target=%d,integrator=%d>", kc.p1, e->cfg.integrator);
+    const char* tn = kc.p1 == T_FUNNEL10 ? "funnel10" : kc.p1 == T_CORRGAUSS ? "corrGauss" : kc.p1 == T_SMILE ? "smile" : kc.p1 == T_FUNNEL1 ? "funnel1" : "modFunnel";
+    snprintf(kc.name, sizeof(kc.name), "wn_orbit_kernel<%s,%s>", tn, e->cfg.integrator == WN_I_FIXED ? "fixedLeapFrog" : e->cfg.integrator == WN_I_ADAPT_D ? "adaptLeapFrogD" : "adaptLeapFrogR2P");
   }
   e->kc = kc;
   e->have_kc = true;
