@@ -158,7 +158,8 @@ int wn_split_done(wn_engine *e, int32_t *n_done, void *stream);
 /* wn_run with recordOrbitStats=True (WALNUTS.py:128,182-184,724-725): additionally fills
  * orbit_min_dev / orbit_max_dev [C][n_iter][dg] with the per-iteration minimum / maximum of
  * generated(q) over the states of the orbit: identity, first-k and [q0, sum q^2].  WN_G_SW_CONSTRAIN is applied to the
- * draws only, so this call returns WN_E_UNSUPPORTED for it (run the identity kind and transform the bounds). */
+ * draws only, so this call returns WN_E_UNSUPPORTED for it: that combination is NOT SUPPORTED (the transform is not monotone per
+ * coordinate -- exp and cumulative sums -- so bounds of the identity kind cannot be transformed afterwards either). */
 int wn_run_orbit_stats(wn_engine *e, const double *q0_dev, uint64_t seed, int32_t n_iter,
                        double *samples_dev, double *diag_dev, double *orbit_min_dev,
                        double *orbit_max_dev, void *stream);
@@ -246,6 +247,12 @@ int wn_rng_tape(wn_engine *e, uint64_t seed, int32_t iter, int32_t n_u, double *
 /* Kernel time of the last wn_run in milliseconds, measured with HIP events recorded on the
  * launch stream (synchronises on the stop event). */
 int wn_last_run_ms(wn_engine *e, float *ms);
+/* (new) Waits for the last wn_run / wn_run_orbit_stats of this engine and reports whether it completed: WN_E_HIP when a kernel's
+ * bounded loop gave up (internal error; the samples of that run are incomplete).  wn_run itself stays asynchronous -- it only
+ * reports an earlier run that has already finished -- so a caller that wants the verdict of a run asks here (or through
+ * wn_last_run_ms, which waits anyway); wn_destroy reports a run nobody asked about.  Replaces nothing in the reference: its
+ * Python loop cannot fail this way. */
+int wn_check_run(wn_engine *e);
 
 /* Split mode (dense Gaussian with 128 < D <= 1024, SURVEY 8d cfg 4): chain-kernel ticks the last wn_run launched -- each one
  * {batched gradient kernel, one tick of every chain}, in batches of 64 captured into a hipGraph.  0 for fused kernels.  (New:

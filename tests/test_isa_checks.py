@@ -1,0 +1,58 @@
+"""Static checks of the compiled gfx950 code of the two kernels whose hand-off / hot loops rely on what the compiler emitted
+(ADVICE round 3): the headline kernel's LDS hand-off is ordered only if data and flag are both LDS instructions of the wave --
+a FLAT load or store there would be a silent race -- and the one-chain-per-wave orbit kernel must not use scratch (scratch-using
+waves are admitted 64 per XCD on this stack).  hipcc cross-compiles without a GPU: this runs in the CPU suite."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "walnuts_amd", "csrc")
+FLAGS = ["-O3", "-std=c++17", "-fno-strict-aliasing", "--offload-arch=gfx950", "-Wno-unused-result", "-Wno-unused-value",
+         "--cuda-device-only", "-S"]
+
+
+def kernels_of(unit, tmp_path):
+    out = tmp_path / (unit + ".s")
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["-o", str(out), os.path.join(CSRC, unit + ".hip")],
+                          stderr=subprocess.DEVNULL)
+    txt = out.read_text()
+    ks = {}
+    for m in re.finditer(r"^(_ZN2wn\w+_kernel\w*):", txt, re.M):  # each kernel: from its label to its s_endpgm
+        ks[m.group(1)] = txt[m.start():txt.index("s_endpgm", m.start())]
+    meta = {}
+    for m in re.finditer(r"- \.agpr_count:.*?\.wavefront_size: *\d+", txt, re.S):
+        blk = m.group(0)
+        g = lambda k: int((re.search(r"\." + k + r": *(\d+)", blk) or [None, "0"])[1])
+        name = re.search(r"\.name: *(\S+)", blk).group(1)
+        meta[name] = dict(scratch=g("private_segment_fixed_size"), vgpr_spill=g("vgpr_spill_count"), sgpr_spill=g("sgpr_spill_count"))
+    return ks, meta
+
+
+@pytest.mark.timeout(900)
+def test_headline_kernel_has_no_flat_or_scratch_instructions(tmp_path):
+    ks, meta = kernels_of("wn_k_fast4", tmp_path)
+    hot = [k for k in ks if "wn_fast4_kernel" in k]
+    assert hot
+    for k in hot:
+        body = ks[k]
+        assert not re.search(r"\bflat_(load|store|atomic)", body), k
+    # the plain (untraced) instantiations: no scratch, no vector-register spills
+    for name, m in meta.items():
+        if "wn_fast4_kernel" in name and re.search(r"wn_fast4_kernelILi\dELb[01]ELb0E", name):
+            assert m["scratch"] == 0 and m["vgpr_spill"] == 0, (name, m)
+
+
+@pytest.mark.timeout(900)
+def test_orbit_kernel_has_no_flat_or_scratch_instructions(tmp_path):
+    ks, meta = kernels_of("wn_k_orbit", tmp_path)
+    hot = [k for k in ks if "wn_orbit_kernel" in k]
+    assert len(hot) >= 15  # five targets x three integrators
+    for k in hot:
+        assert not re.search(r"\bflat_(load|store|atomic)", ks[k]), k
+        assert not re.search(r"\bscratch_", ks[k]), k
+    for name, m in meta.items():
+        if "wn_orbit_kernel" in name:
+            assert m["scratch"] == 0 and m["vgpr_spill"] == 0, (name, m)

@@ -39,7 +39,7 @@ class WnConfig(C.Structure):
 # every symbol include/walnuts_amd.h declares
 SYMBOLS = ["wn_abi_version", "wn_create", "wn_set_target", "wn_run", "wn_run_orbit_stats", "wn_split_ld", "wn_split_begin", "wn_split_tick", "wn_split_done", "wn_integrator_step",
            "wn_lpfun", "wn_lpfun_kind", "wn_wstep_create", "wn_wstep_begin", "wn_wstep_extend", "wn_wstep_commit", "wn_wstep_result", "wn_wstep_run_device_rng",
-           "wn_wstep_ext_bind", "wn_wstep_ext_pending", "wn_wstep_ext_waiting", "wn_wstep_ext_feed", "wn_wstep_last_error", "wn_wstep_destroy", "wn_rng_tape", "wn_last_run_ms", "wn_last_split_ticks", "wn_debug_poison_lds", "wn_kernel_name", "wn_last_error",
+           "wn_wstep_ext_bind", "wn_wstep_ext_pending", "wn_wstep_ext_waiting", "wn_wstep_ext_feed", "wn_wstep_last_error", "wn_wstep_destroy", "wn_rng_tape", "wn_last_run_ms", "wn_check_run", "wn_last_split_ticks", "wn_debug_poison_lds", "wn_kernel_name", "wn_last_error",
            "wn_destroy"]
 
 _lib = None
@@ -101,6 +101,8 @@ def lib():
     L.wn_wstep_destroy.argtypes = [vp]
     L.wn_rng_tape.restype = C.c_int
     L.wn_rng_tape.argtypes = [vp, C.c_uint64, C.c_int32, C.c_int32, vp, vp, vp]
+    L.wn_check_run.restype = C.c_int
+    L.wn_check_run.argtypes = [vp]
     L.wn_last_run_ms.restype = C.c_int
     L.wn_last_run_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.wn_last_split_ticks.restype = C.c_int

@@ -286,8 +286,12 @@ struct wn_engine {
   hipStream_t sp_main = nullptr;  // split mode: stands in for the (uncapturable) legacy default stream
   hipEvent_t sp_fork0 = nullptr;
   int* kabort = nullptr;  // device flag: a kernel's bounded loop gave up (internal error)
-  bool kabort_pending = false;  // a launch since the flag was last read
-  hipStream_t kabort_stream = nullptr;
+  // The flag is latched into a run counter on the device behind every launch and copied to a pinned word in stream order
+  // (asynchronously): nothing of the caller's stream is kept, and a later launch does not wait for an earlier one.
+  int* h_abort = nullptr;         // pinned: number of runs that gave up so far, as of the last completed copy
+  hipEvent_t ev_abort = nullptr;  // recorded behind the last copy
+  bool kabort_pending = false;    // a launch since the counter was last read
+  int aborts_reported = 0;
   bool timed = false;
   std::string err;
 };
@@ -356,14 +360,23 @@ int wn_create(const wn_config* cfg, wn_engine** out) {
   if (r != hipSuccess) { g_create_err = std::string("hipEventCreate: ") + hipGetErrorString(r); delete e; return WN_E_HIP; }
   r = hipMalloc((void**)&e->kabort, 64);
   if (r == hipSuccess) r = hipMemset(e->kabort, 0, 64);
+  if (r == hipSuccess) r = hipHostMalloc((void**)&e->h_abort, 64);
+  if (r == hipSuccess) { e->h_abort[0] = 0; r = hipEventCreateWithFlags(&e->ev_abort, hipEventDisableTiming); }
   if (r != hipSuccess) { g_create_err = std::string("hipMalloc: ") + hipGetErrorString(r); (void)hipGetLastError(); delete e; return r == hipErrorOutOfMemory ? WN_E_ALLOC : WN_E_HIP; }
   *out = e;
   return WN_OK;
 }
 
+static int check_abort(wn_engine* e, bool wait);
+
 int wn_destroy(wn_engine* e) {
   if (!e) return WN_OK;
   hipSetDevice(e->cfg.device);
+  // a run that gave up and was never asked about (wn_check_run / wn_last_run_ms) is reported here: the handle is released all the same
+  const int rc_abort = e->kabort_pending ? check_abort(e, true) : WN_OK;
+  if (rc_abort) { g_create_err = e->err; fprintf(stderr, "walnuts_amd: %s\n", e->err.c_str()); }
+  if (e->h_abort) hipHostFree(e->h_abort);
+  if (e->ev_abort) hipEventDestroy(e->ev_abort);
   if (e->tpar) hipFree(e->tpar);
   if (e->work) hipFree(e->work);
   if (e->facs) hipFree(e->facs);
@@ -381,7 +394,7 @@ int wn_destroy(wn_engine* e) {
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   delete e;
-  return WN_OK;
+  return rc_abort;
 }
 
 int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n_params) {
@@ -494,14 +507,20 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
   return WN_OK;
 }
 
-// reads the abort flag of the last launch (synchronises its stream); WN_E_HIP when that run gave up
-static int check_abort(wn_engine* e) {
+// the fast kernels' bounded loops set kabort[0]; this one-thread kernel, enqueued behind every launch, counts such runs in kabort[1]
+__global__ void wn_abort_latch_kernel(int* f) {
+  if (f[0]) { f[1] += 1; f[0] = 0; }
+}
+
+// Has a run given up?  wait = false: only if the copy behind the last launch has completed (no synchronisation: used in front of a
+// new launch, which must stay asynchronous); wait = true: waits for it (wn_check_run, wn_last_run_ms, wn_destroy).
+static int check_abort(wn_engine* e, bool wait) {
+  if (wait) { HIPCHK(e, hipEventSynchronize(e->ev_abort)); }
+  else if (hipEventQuery(e->ev_abort) != hipSuccess) return WN_OK;  // still running: stays pending
   e->kabort_pending = false;
-  int ab = 0;
-  HIPCHK(e, hipStreamSynchronize(e->kabort_stream));
-  HIPCHK(e, hipMemcpy(&ab, e->kabort, sizeof(int), hipMemcpyDeviceToHost));
-  if (ab) {
-    (void)hipMemset(e->kabort, 0, sizeof(int));
+  const int n = e->h_abort[0];
+  if (n != e->aborts_reported) {
+    e->aborts_reported = n;
     e->err = "a kernel's tick loop exceeded its bound and gave up (internal error); the results of that run are incomplete";
     return WN_E_HIP;
   }
@@ -678,16 +697,18 @@ static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
   const bool fast_legacy = getenv("WN_FAST_LEGACY") != nullptr;  // diagnostic / A-B tests: the seven-T-wave kernel for dense targets too
   // the tick-bound abort flag of the fast kernels belongs to THIS run: cleared in stream order before the launch; wn_last_run_ms,
   // the next wn_run and wn_destroy report a run that gave up
-  if (e->kabort_pending) { int rc_ = check_abort(e); if (rc_) return rc_; }
-  HIPCHK(e, hipMemsetAsync(e->kabort, 0, sizeof(int), st));
+  if (e->kabort_pending) { int rc_ = check_abort(e, false); if (rc_) return rc_; }
   hipError_t r = (!coop_legacy && !fast_legacy && fast4_eligible(e->kc, adapt, warm, p_)) ? launch_fast4(e->kc, p_, e->kabort, st)
                : (!coop_legacy && fast_eligible(e->kc, adapt, warm, p_)) ? launch_fast(e->kc, p_, e->kabort, st)
                : orbit_eligible(e->kc, adapt, warm, p_) ? launch_orbit(e->kc, p_, st)
                : e->kc.layout == 0 ? launch_lane(e->kc, adapt, warm, p_, st)
                : e->kc.layout == 1 ? launch_coop(e->kc, adapt, warm, p_, st) : launch_wave(e->kc, adapt, warm, p_, st);
   if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
+  hipLaunchKernelGGL(wn_abort_latch_kernel, dim3(1), dim3(1), 0, st, e->kabort);
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipMemcpyAsync(e->h_abort, e->kabort + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(e, hipEventRecord(e->ev_abort, st));
   e->kabort_pending = true;
-  e->kabort_stream = st;
   if (e->cfg.generated == WN_G_SW_CONSTRAIN && p.mode == MODE_SAMPLE) {
     const size_t nrows = (size_t)p.C * (p.numIter + 1);
     hipLaunchKernelGGL(wn_sw_constrain_kernel, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, st, p.samples, nrows, p.D / 3);
@@ -958,21 +979,29 @@ int wn_last_run_ms(wn_engine* e, float* ms) {
   if (!e->timed) { e->err = "no timed run yet"; return WN_E_ARG; }
   HIPCHK(e, hipEventSynchronize(e->ev1));
   HIPCHK(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
-  if (e->kabort_pending) return check_abort(e);
+  if (e->kabort_pending) return check_abort(e, true);
   return WN_OK;
+}
+
+int wn_check_run(wn_engine* e) {
+  if (!e) return WN_E_ARG;
+  HIPCHK(e, hipSetDevice(e->cfg.device));
+  return e->kabort_pending ? check_abort(e, true) : WN_OK;
 }
 
 int wn_debug_poison_lds(int32_t device, uint64_t pattern, void* stream) {
   hipError_t r = hipSetDevice(device);
   if (r != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(r); return WN_E_HIP; }
-  static unsigned long long* sink = nullptr;
-  if (!sink && hipMalloc((void**)&sink, 64) != hipSuccess) { g_create_err = "hipMalloc failed"; return WN_E_ALLOC; }
+  unsigned long long* sink = nullptr;  // (allocated on THIS device, for this call)
+  if (hipMalloc((void**)&sink, 64) != hipSuccess) { g_create_err = "hipMalloc failed"; return WN_E_ALLOC; }
   hipDeviceProp_t prop;
   r = hipGetDeviceProperties(&prop, device);
   if (r == hipSuccess) r = hipFuncSetAttribute((const void*)wn_poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (r != hipSuccess) { g_create_err = std::string("wn_debug_poison_lds: ") + hipGetErrorString(r); return WN_E_HIP; }
   hipLaunchKernelGGL(wn_poison_lds_kernel, dim3(4 * prop.multiProcessorCount), dim3(256), 160 * 1024, (hipStream_t)stream, (unsigned long long)pattern, sink);
   r = hipGetLastError();
+  if (r == hipSuccess) r = hipStreamSynchronize((hipStream_t)stream);
+  hipFree(sink);
   if (r != hipSuccess) { g_create_err = std::string("wn_debug_poison_lds launch: ") + hipGetErrorString(r); return WN_E_HIP; }
   return WN_OK;
 }

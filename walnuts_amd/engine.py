@@ -153,6 +153,10 @@ class Engine:
         self._keep = [q0, xq, xg, xlp]
         return samples, diag
 
+    def check(self):
+        """Waits for the last run and raises WalnutsError if a kernel's bounded loop gave up (wn_check_run)."""
+        self._check(self.lib.wn_check_run(self.h))
+
     def last_run_ms(self):
         ms = C.c_float()
         self._check(self.lib.wn_last_run_ms(self.h, C.byref(ms)))
@@ -202,8 +206,10 @@ class Engine:
     def close(self):
         if getattr(self, "h", None):
             self.torch.cuda.synchronize(self.device)
-            self.lib.wn_destroy(self.h)
-            self.h = None
+            h, self.h = self.h, None
+            rc = self.lib.wn_destroy(h)  # reports a run that gave up and was never asked about
+            if rc:
+                raise WalnutsError(f"rc={rc}: {self.lib.wn_last_error(None).decode()}")
 
     def __del__(self):
         try:
