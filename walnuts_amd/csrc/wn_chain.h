@@ -1450,7 +1450,7 @@ struct Engine : ChainScalars {
   // the program counter is the state.  Same arithmetic, same reductions, same draw order: bit-identical to run().
   // ------------------------------------------------------------------------------------------
   WN_HD void run_nested() {
-    static_assert(ADAPT && !FLOW && !WARM && SPEC >= 0, "run_nested: adaptive integrators, plain sampling");
+    static_assert(!FLOW && !WARM && SPEC >= 0, "run_nested: leapfrog integrators, plain sampling");
     const bool inrange = p.chain_local() < prm.C;
     init_scalars(inrange);
     const int cl = inrange ? p.chain_local() : 0;
@@ -1482,7 +1482,7 @@ struct Engine : ChainScalars {
         finish_generated(part[3]);
         H0 = -lp0 + 0.5 * part[2];
         Ha = Hb = H0; Ham0 = H0;
-        HamPass0 = H0; allfin = isfinite(H0);
+        if (ADAPT) { HamPass0 = H0; allfin = isfinite(H0); }
         Hnan = isnan(H0); Hmin = Hmax = H0;
         needKE = false; keinit_part = 0.0;
       }
@@ -1517,7 +1517,17 @@ struct Engine : ChainScalars {
             // pass complete: all(isfinite(Hams)) and abs(Hams[0]-Hams[-1]) < delta   (:87-94)
             return allfin && (fabs(HamPass0 - HCur) < dc);
           };
-          {
+          if constexpr (!ADAPT) {      // fixedLeapFrog (adaptiveIntegrators.py:49-59): the macro step is one leapfrog step, in place
+            const double hh2 = 0.5 * hh, hq = hh;
+            WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; Q.x[e] = Q.x[e] + hq * V.x[e]; }
+            p.grad(Q, G, part[0]);
+            double ke = 0.0;
+            WN_VFOR(e) { V.x[e] = V.x[e] + hh2 * G.x[e]; ke += V.x[e] * V.x[e]; }
+            part[1] = ke;
+            p.template reduce<2>(part);
+            after_micro(p.lp_finish(part[0]), part[1]);
+            WN_STAMP(3);
+          } else {
             int cc = cmin();             // forward search (:69-94 / 366-389); ph = PH_FWD from setup_macro()
             bool ok;
             for (;;) {

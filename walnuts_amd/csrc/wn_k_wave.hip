@@ -26,6 +26,12 @@ static hipError_t go(int adapt, bool warm, const Params& prm, hipStream_t st) {
   const size_t dyn = WavePolicy<NE, Tgt, W, CL>::dyn_lds_bytes(prm.M);
   // the small targets (one register per vector) and StockWatson are tick-latency bound: plain sampling runs of the two integrators the
   // reference's experiments use on them get an engine with the run-time switches compiled out (Engine SPEC)
+  // (round 4: StockWatson's fixedLeapFrog run too -- mainSW.py:55-62, 2047 leaves of one evaluation each per iteration: the tick loop's
+  //  flag tests are branches, and a wave alone on its SIMD pays 25-55 cycles for each, tools/branch_cost.hip)
+  if constexpr (wave_spec_engine<Tgt>::value) if (adapt == 0 && !warm && prm.mode == MODE_SAMPLE && !prm.trace_n && !prm.omin && prm.integrator == I_FIXED) {
+    hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, false, false, false, W, CL, I_FIXED>), grid, block, dyn, st, prm);
+    return hipGetLastError();
+  }
   if constexpr (WavePolicy<NE, Tgt, W, CL>::VLDS || wave_spec_engine<Tgt>::value) if (adapt == 1 && !warm && prm.mode == MODE_SAMPLE && !prm.trace_n && !prm.omin) {
     if (prm.integrator == I_ADAPT_R2P) {
       hipLaunchKernelGGL((wn_wave_kernel<NE, Tgt, true, false, false, W, CL, I_ADAPT_R2P>), grid, block, dyn, st, prm);
