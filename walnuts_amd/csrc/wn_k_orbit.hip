@@ -36,7 +36,7 @@
 // the batch through a scalar select, and the common macro step (first pass accepted, no R2P re-integration, no backward search) is
 // one branch away from its end.
 //
-// LDS per chain (doubles): ring q / v 2 x 256, dump 64, passive orbit end (q, v, g) 48, two proposals (q) 32, sub-tree slots
+// LDS per chain (doubles): ring q / v 2 x 16 x 17, dump 64, passive orbit end (q, v, g) 48, two proposals (q) 32, sub-tree slots
 // (levels >= 5 and leaf 0) 32 (M + 1): 8.4 KB at M = 12 -- 16 chains per CU, all 4096 resident.
 // The proposal keeps q only: the gradient at the start of an iteration is re-evaluated, as the reference does (WALNUTS.py:249).
 #include "wn_launch.h"
@@ -47,7 +47,9 @@ namespace wn {
 namespace orbit {
 typedef __attribute__((address_space(3))) double lds_d;
 typedef __attribute__((address_space(3))) int lds_i;
-enum { RQ = 0, RV = 256, DUMP = 512, COLDQ = 576, COLDV = 592, COLDG = 608, PROP = 624, SLOT = 656 };
+// RS: doubles between consecutive ring entries -- 17, not 16: the R phase's check lanes read element d of DIFFERENT entries at once (lane c:
+// entry r(c)), and at a stride of 16 doubles = 128 bytes all of them hit the same LDS banks (a 16-way conflict on every read)
+enum { RS = 17, RQ = 0, RV = 16 * RS, DUMP = 32 * RS, COLDQ = DUMP + 64, COLDV = COLDQ + 16, COLDG = COLDV + 16, PROP = COLDG + 16, SLOT = PROP + 32 };
 __host__ __device__ constexpr int lds_doubles(int M) { return SLOT + 32 * (M + 1); }
 
 // row_shr:1 with zero fill at the first lane of each row of 16
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
   int iA = 0, iB = 0;  // If | Ib << 8 | c << 16;  nEvalF | nEvalB << 16
   // ring stores without an exec mask: lanes >= 16 write to the dump area
   const int ring_base = lane < 16 ? RQ + lane : DUMP + lane;
-  const int ring_step = lane < 16 ? 16 : 0;
+  const int ring_step = lane < 16 ? RS : 0;
   const int ring_vofs = lane < 16 ? RV - RQ : 0;
 
   while (__any(live)) {  // ---- iterations (WALNUTS.py:189) ----
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
             lq = COLDQ; lv = COLDV;
           } else if (lvl <= 4) {
             act = act && i >= 1;
-            lq = RQ + 16 * (r + 1 - (1 << lvl)); lv = lq + (RV - RQ);
+            lq = RQ + RS * (r + 1 - (1 << lvl)); lv = lq + (RV - RQ);
           } else {
             act = act && i >= 1 && lvl <= __builtin_ctz((unsigned)(nr + 1));
             const int nl = nr + 1 - (1 << lvl);  // left leaf of the sub-tree
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
           }
           bool fire = false;
           if (act) {
-            const int rq = RQ + 16 * r, rv = RV + 16 * r;
+            const int rq = RQ + RS * r, rv = RV + RS * r;
             double s1[4], s2[4];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
             if (mp) {  // the last leaf that took the multinomial draw is the proposal
               const int Pk = 63 - __builtin_clzll(mp);
               if (ip == ipl) ip ^= 1;  // keep qPropLast intact
-              const double qp = L[RQ + 16 * Pk + k16];
+              const double qp = L[RQ + RS * Pk + k16];
               row0_store(PROP + 16 * ip, qp);
               lpP = wn_readlane(lp_k, Pk);
               L_ = fw ? b + 1 + (nb0 + Pk) : a - 1 - (nb0 + Pk);
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
         }
         if (end_sub) { sub = true; break; }
         if (redo) {  // restart behind the mispredicted leaf: its state is in the ring
-          qa = L[RQ + 16 * Lfull + k16]; va = L[RV + 16 * Lfull + k16];
+          qa = L[RQ + RS * Lfull + k16]; va = L[RV + RS * Lfull + k16];
           double lpp = tgt.grad(&qa, &ga, lane);
           (void)lpp;
           // the second step size of a pair was drawn with the first (:395): its index, for a restart at the pair's second leaf
