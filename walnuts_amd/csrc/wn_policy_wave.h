@@ -132,7 +132,9 @@ __device__ __forceinline__ double wn_scan_up(double x, int lane) {
   x += wn_dpp0<0x118>(x);
   const double t0 = wn_readlane(x, 15), t1 = wn_readlane(x, 31), t2 = wn_readlane(x, 47);
   const int row = lane >> 4;
-  const double add = row == 0 ? 0.0 : row == 1 ? t0 : row == 2 ? t0 + t1 : (t0 + t1) + t2;
+  double s01 = t0 + t1, s012 = (t0 + t1) + t2;  // (select form: see wn_scan_down)
+  asm volatile("" : "+v"(s01), "+v"(s012));
+  const double add = row == 0 ? 0.0 : row == 1 ? t0 : row == 2 ? s01 : s012;
   return x + add;
 }
 // inclusive suffix sum (lane l gets the sum over lanes >= l)
@@ -143,7 +145,11 @@ __device__ __forceinline__ double wn_scan_down(double x, int lane) {
   x += wn_dpp0<0x108>(x);
   const double t1 = wn_readlane(x, 16), t2 = wn_readlane(x, 32), t3 = wn_readlane(x, 48);
   const int row = lane >> 4;
-  const double add = row == 3 ? 0.0 : row == 2 ? t3 : row == 1 ? t2 + t3 : t1 + (t2 + t3);
+  // (select form over sums every lane computes: as nested conditional expressions the compiler built divergent if / else regions --
+  //  five exec-mask regions and two branches per scan, ~170 cycles for a wave alone on its SIMD, tools/branch_cost.hip)
+  double s23 = t2 + t3, s123 = t1 + (t2 + t3);
+  asm volatile("" : "+v"(s23), "+v"(s123));
+  const double add = row == 3 ? 0.0 : row == 2 ? t3 : row == 1 ? s23 : s123;
   return x + add;
 }
 
