@@ -132,9 +132,12 @@ __device__ __forceinline__ double wn_scan_up(double x, int lane) {
   x += wn_dpp0<0x118>(x);
   const double t0 = wn_readlane(x, 15), t1 = wn_readlane(x, 31), t2 = wn_readlane(x, 47);
   const int row = lane >> 4;
-  double s01 = t0 + t1, s012 = (t0 + t1) + t2;  // (select form: see wn_scan_down)
-  asm volatile("" : "+v"(s01), "+v"(s012));
-  const double add = row == 0 ? 0.0 : row == 1 ? t0 : row == 2 ? s01 : s012;
+  double s0 = t0, s01 = t0 + t1, s012 = (t0 + t1) + t2;  // (select form: see wn_scan_down)
+  asm volatile("" : "+v"(s0), "+v"(s01), "+v"(s012));
+  double add = s012;
+  add = row == 2 ? s01 : add;
+  add = row == 1 ? s0 : add;
+  add = row == 0 ? 0.0 : add;
   return x + add;
 }
 // inclusive suffix sum (lane l gets the sum over lanes >= l)
@@ -147,9 +150,12 @@ __device__ __forceinline__ double wn_scan_down(double x, int lane) {
   const int row = lane >> 4;
   // (select form over sums every lane computes: as nested conditional expressions the compiler built divergent if / else regions --
   //  five exec-mask regions and two branches per scan, ~170 cycles for a wave alone on its SIMD, tools/branch_cost.hip)
-  double s23 = t2 + t3, s123 = t1 + (t2 + t3);
-  asm volatile("" : "+v"(s23), "+v"(s123));
-  const double add = row == 3 ? 0.0 : row == 2 ? t3 : row == 1 ? s23 : s123;
+  double s3 = t3, s23 = t2 + t3, s123 = t1 + (t2 + t3);
+  asm volatile("" : "+v"(s3), "+v"(s23), "+v"(s123));
+  double add = s123;
+  add = row == 1 ? s23 : add;
+  add = row == 2 ? s3 : add;
+  add = row == 3 ? 0.0 : add;
   return x + add;
 }
 
