@@ -33,11 +33,15 @@ def funnel_q0(C, seed=3):
     return q0
 
 
-def run_engine(wa, target, q0, iters, legacy=False, seed=SEED, **kw):
+def run_engine(wa, target, q0, iters, legacy=False, exact=True, seed=SEED, **kw):
+    """exact: the orbit kernel with the micro-step arithmetic of the one-stream engine (WN_ORBIT_EXACT=1; funnel10's default is a
+    micro step of its own with one row reduction instead of two -- the same values, not the same bits)"""
     from walnuts_amd import _lib as L
     old = os.environ.pop("WN_ORBIT_LEGACY", None)
     if legacy:
         os.environ["WN_ORBIT_LEGACY"] = "1"
+    if exact:
+        os.environ["WN_ORBIT_EXACT"] = "1"
     try:
         e = wa.Engine(q0.shape[1], q0.shape[0], **kw)
         e.set_target(target, None)
@@ -47,6 +51,7 @@ def run_engine(wa, target, q0, iters, legacy=False, seed=SEED, **kw):
         e.close()
     finally:
         os.environ.pop("WN_ORBIT_LEGACY", None)
+        os.environ.pop("WN_ORBIT_EXACT", None)
         if old is not None:
             os.environ["WN_ORBIT_LEGACY"] = old
     return s, d, name
@@ -115,7 +120,7 @@ def test_orbit_kernel_matches_oracle(wa, integ, M):
     C, iters = 64, 12
     q0 = funnel_q0(C, seed=5)
     kw = dict(integrator=integ, H0=0.3, delta0=0.3, M=M)
-    s, d, name = run_engine(wa, ol.T_FUNNEL10, q0, iters, **kw)
+    s, d, name = run_engine(wa, ol.T_FUNNEL10, q0, iters, exact=False, **kw)  # the default: funnel10's own micro step
     assert "wn_orbit_kernel" in name
     for c in (0, 7, 19, 33, 63):
         o = ol.walnuts(ol.T_FUNNEL10, q0[c], integrator=integ, H0=0.3, delta0=0.3, numIter=iters, M=M, seed=SEED, chain=c)
@@ -153,8 +158,11 @@ def test_orbit_kernel_config3_size(wa):
     s_old, d_old, _ = run_engine(wa, ol.T_FUNNEL10, q0, iters, legacy=True, **kw)
     assert same_run(s, d, s_old, d_old)
     busiest = int(np.argmax((d[:, :, 6] + d[:, :, 7]).sum(1)))
+    s_f, d_f, _ = run_engine(wa, ol.T_FUNNEL10, q0, iters, exact=False, **kw)  # the default arithmetic (one reduction per micro step)
+    assert same(d_f[..., [6, 7, 19, 20]], d[..., [6, 7, 19, 20]]) or (d_f[..., [6, 7, 19, 20]] != d[..., [6, 7, 19, 20]]).any(axis=(1, 2)).sum() <= 2
     for c in (0, 1234, busiest):
         o = ol.walnuts(ol.T_FUNNEL10, q0[c], integrator=ol.I_ADAPT_R2P, H0=0.3, delta0=0.3, numIter=iters, M=12, seed=SEED, chain=c,
                        generated=ol.G_FIRSTK, gen_k=2)
-        np.testing.assert_array_equal(d[c][:, INT_COLS], o["diagnostics"][:, INT_COLS])
-        np.testing.assert_allclose(s[c].T, o["samples"], rtol=1e-6, atol=1e-9)
+        for dd, ss in ((d, s), (d_f, s_f)):
+            np.testing.assert_array_equal(dd[c][:, INT_COLS], o["diagnostics"][:, INT_COLS])
+            np.testing.assert_allclose(ss[c].T, o["samples"], rtol=1e-6, atol=1e-9)

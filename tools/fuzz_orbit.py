@@ -34,7 +34,7 @@ for it in range(n):
     s, d = e.run(q0, 4242, numIter)
     s = s.transpose(1, 2).cpu().numpy(); d = d.cpu().numpy(); e.close()
     # the one-stream engine of the same layout on the same chains: the control logic must agree EXACTLY (integers), whatever the dynamics do
-    os.environ["WN_ORBIT_LEGACY"] = "1"
+    os.environ["WN_ORBIT_LEGACY"] = "1"  # (funnel10: the default kernel has a micro step of its own -- same values, other bits -- so this comparison is to rtol 1e-6 too)
     e = wa.Engine(D, C, integrator=ig, H0=H0, delta0=delta, M=M, minC=minC, maxC=maxC, generated=gen, gen_k=gk, chain_offset=1000 * it)
     e.set_target(tk, None)
     sl, dl = e.run(q0, 4242, numIter)

@@ -88,7 +88,7 @@ __device__ __forceinline__ int uni_i(int x) { return __builtin_amdgcn_readfirstl
 __device__ __forceinline__ bool uni_b(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 }  // namespace orbit
 
-template <class Tgt, int INTEG>
+template <class Tgt, int INTEG, bool FUSED = false>
 __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
   using namespace orbit;
   extern __shared__ double wn_orbit_lds[];
@@ -193,11 +193,16 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
     int s = nstep;
 #pragma unroll 1
     do {  // one branch per micro step
-      v = v + hh2 * g; q = q + hq * v;
-      double lpp = tgt.grad(&q, &g, lane);
-      double ke = 0.0;
-      v = v + hh2 * g; ke += v * v;
-      reduce2(lpp, ke);
+      double lpp, ke;
+      if constexpr (FUSED) {  // the target's own micro step: one row reduction instead of two (WTgtFunnel10::leap)
+        tgt.leap(q, v, g, hh2, hq, lane, lpp, ke);
+      } else {
+        v = v + hh2 * g; q = q + hq * v;
+        lpp = tgt.grad(&q, &g, lane);
+        ke = 0.0;
+        v = v + hh2 * g; ke += v * v;
+        reduce2(lpp, ke);
+      }
       const double Hi = -lpp + 0.5 * ke;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
       lpC = lpp; HC = Hi;
       allfin = allfin && isfinite(Hi);
@@ -662,10 +667,21 @@ bool orbit_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& 
   return false;
 }
 
+template <class T_, class = void> struct has_fused_step { static constexpr bool value = false; };
+template <class T_> struct has_fused_step<T_, typename std::enable_if<T_::FUSED_STEP>::type> { static constexpr bool value = true; };
+
 template <class Tgt>
 static hipError_t go_orbit(const Params& prm, hipStream_t st) {
   const size_t dyn = (size_t)orbit::lds_doubles(prm.M) * sizeof(double);
   dim3 grid(prm.C), block(64);
+  // a target with a micro step of its own (one reduction instead of two) runs it unless WN_ORBIT_EXACT=1 asks for the arithmetic of
+  // the one-stream engine (the bit-for-bit comparisons of tests/test_gpu_orbit.py)
+  if constexpr (has_fused_step<Tgt>::value) if (!getenv("WN_ORBIT_EXACT")) {
+    if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_R2P, true>), grid, block, dyn, st, prm);
+    else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_D, true>), grid, block, dyn, st, prm);
+    else hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_FIXED, true>), grid, block, dyn, st, prm);
+    return hipGetLastError();
+  }
   if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_R2P>), grid, block, dyn, st, prm);
   else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_D>), grid, block, dyn, st, prm);
   else hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_FIXED>), grid, block, dyn, st, prm);

@@ -402,6 +402,32 @@ struct WTgtFunnel10 {
     const double r = (0.5 * q0 > 709.782712893384) ? -INFINITY : lp;
     return lane == 0 ? r : 0.0;
   }
+  // One whole leapfrog micro step (adaptiveIntegrators.py:72-84) with ONE row reduction (wn_k_orbit.hip): only lane 0's gradient needs
+  // ss = sum q_i^2, so the kinetic energy of lanes 1..10 -- their second kick needs exp(-q0) alone -- rides in the same packed
+  // reduction as ss, and lane 0's share is added afterwards.  Returns lp and KE complete (the same in every lane).  The sums are
+  // associated differently from grad() + a separate (lp, KE) reduction: same values to the last bits, not the same bits.
+  static constexpr bool FUSED_STEP = true;
+  __device__ __forceinline__ void leap(double& q, double& v, double& g, double hh2, double hq, int lane, double& lp_out, double& ke_out) const {
+    const double logC = 0.91893853320467274178, log3 = 1.09861228866810969140;
+    v = v + hh2 * g; q = q + hq * v;
+    const double q0 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(q)), __builtin_amdgcn_readfirstlane(__double2loint(q)));
+    const double emq = wn_exp(-q0);
+    const bool rest = lane >= 1 && lane < 11;
+    const double g_rest = rest ? -q * emq : 0.0;
+    const double v_rest = v + hh2 * g_rest;
+    double r = wn_pack32(rest ? q * q : 0.0, rest ? v_rest * v_rest : 0.0);
+    r = wn_rowsum16(r);
+    const double ss = wn_readlane(r, 0) + 0.0, ke_rest = wn_readlane(r, 32) + 0.0;
+    const double g_first = -5.0 - q0 * (1.0 / 9.0) + 0.5 * emq * ss;
+    double v_first = v + hh2 * g_first;  // (lane 0's value is the one that counts)
+    asm volatile("" : "+v"(v_first));
+    g = lane == 0 ? g_first : g_rest;
+    v = lane == 0 ? v_first : v_rest;
+    const double v0 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+    ke_out = ke_rest + v0 * v0;
+    const double lp = (-(q0 * q0) * (1.0 / 18.0) - logC - log3) + (-0.5 * emq * ss - 10.0 * logC - 5.0 * q0);
+    lp_out = (0.5 * q0 > 709.782712893384) ? -INFINITY : lp;
+  }
 };
 
 // W waves (one workgroup) serve a chain: register e of wave w, lane l holds element (e*W + w)*64 + l.
