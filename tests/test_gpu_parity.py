@@ -580,3 +580,25 @@ def test_walnuts_device_whole_transitions_on_the_device(wa):
     h = wa.walnuts_batch(rngs, th0, td.stdGauss, td.stdGauss, np.ones(10), 2.0, 10, 0.1, 0, 1)[:, 0]
     one = wa.walnuts_device(5, th0, td.stdGauss, np.ones(10), 2.0, 10, 0.1, 0, 1)[:, 0]
     assert abs(h.var() - one.var()) < 0.15 * h.var(), (h.var(), one.var())
+
+
+def test_walnuts_device_wave_kernel_matches_the_one_lane_kernel(wa):
+    """Round 4: whole transitions of Gaussian targets run with the wave doing the work (lane = element, wstep_wave_kernel); the one-lane
+    state machine (wstep_auto_kernel, WN_WSTEP_LEGACY=1) is the same transition kernel (walnuts.py:279-359) on the same random stream.
+    The two associate their sums differently, so a chain agrees to rounding until a comparison at the edge of a threshold goes the
+    other way (stable_steps' `<= max_error`, the acceptance test): nearly every chain must agree, and the moments must."""
+    from walnuts_amd import targetDistr as td
+    for D, tgt, im, C, n in ((10, td.stdGauss, np.ones(10), 384, 16), (24, td.diagGauss(1.0 / np.logspace(0, 1, 24)), np.logspace(0, 1, 24), 128, 8)):
+        th0 = np.random.default_rng(3).normal(size=(C, D))
+        args = (tgt, im, 2.0, 8, 0.1, 0, n)
+        new = wa.walnuts_device(91, th0, *args)
+        os.environ["WN_WSTEP_LEGACY"] = "1"
+        try:
+            old = wa.walnuts_device(91, th0, *args)
+        finally:
+            del os.environ["WN_WSTEP_LEGACY"]
+        assert np.isfinite(new).all()
+        same = np.abs(new - old).max(axis=(1, 2)) < 1e-8
+        assert same.mean() > 0.95, same.mean()
+        first = np.abs(new[:, 0] - old[:, 0]).max(axis=1) < 1e-9  # the first transition alone: hardly any threshold is that close
+        assert first.mean() > 0.99, first.mean()

@@ -440,6 +440,238 @@ __global__ void wstep_auto_kernel(WCtx c0, int* lottery, uint64_t seed, uint32_t
   }
 }
 
+}  // namespace (reopened below)
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same whole transitions with the WAVE doing the work -- lane i holds element i of every vector (D <= 64), vectors
+// in registers, one wave reduction per energy, branch-lean (wstep_auto_kernel above lets lane 0 walk scalar loops over D with the
+// vectors in LDS through a generic state machine: ~100x the instructions per gradient evaluation).  Gaussian targets (standard /
+// diagonal: BASELINE configs[0]'s target), whose log density and gradient are element-wise; every other built-in target keeps the
+// kernel above.  Same transition kernel (walnuts.py:279-359), same random stream and the same order of draws as the kernel above
+// (direction bit, the extension's lottery indices, the acceptance uniform, the categorical uniform; momentum normals), so the two
+// produce the same chains up to the association of their sums (tests/test_gpu_parity.py).
+// ------------------------------------------------------------------------------------------------------------------------
+#include "wn_policy_wave.h"  // wave sums, readlane helpers
+
+namespace {
+
+template <bool SMALL>  // SMALL: D <= 16 -- sums over one row of 16 lanes
+__device__ __forceinline__ double wt_sum(double x) {
+  if constexpr (SMALL) return wn_readlane(wn_rowsum16(x), 0);
+  else return wn_wavesum(x);
+}
+// two sums at once
+template <bool SMALL>
+__device__ __forceinline__ void wt_sum2(double& a, double& b) {
+  if constexpr (SMALL) {
+    double r = wn_pack32(a, b);
+    r = wn_rowsum16(r);
+    a = wn_readlane(r, 0); b = wn_readlane(r, 32);
+  } else { a = wn_wavesum(a); b = wn_wavesum(b); }
+}
+
+template <bool SMALL>
+__global__ __launch_bounds__(64) void wstep_wave_kernel(WCtx c0, int* lottery, uint64_t seed, uint32_t chain0, int it0, int n_trans, int max_depth,
+                                                        double* theta_io, double* draws) {
+  const int b = blockIdx.x, lane = threadIdx.x, D = c0.D;
+  if (b >= c0.B) return;
+  const bool in = lane < D;
+  const int li = in ? lane : 0;
+  double* const eorb = c0.eorb + (size_t)b * c0.nmax * 2 * D;  // [m][2][D] states of the extension in integration order
+  double* const ew = c0.ew + (size_t)b * c0.nmax;
+  double* const logw = c0.logw + (size_t)b * 2 * c0.nmax;
+  extern __shared__ int wt_lot_lds[];  // the extension's lottery indices, [nmax] (LDS operations of one wave execute in order)
+  typedef __attribute__((address_space(3))) int lds_int;
+  lds_int* const lot = (lds_int*)wt_lot_lds;
+  (void)lottery;
+  const uint32_t chain = chain0 + (uint32_t)b;
+  const double im = in ? c0.im[li] : 0.0;                                                    // inverse mass (0 beyond D: those lanes add nothing)
+  const double aa = in ? (c0.kind == T_DIAGGAUSS ? c0.tpar[li] : 1.0) : 0.0;                 // precision of this lane's coordinate
+  const double macro = c0.macro_step, maxerr = c0.max_error;
+  const uint32_t seedlo = (uint32_t)seed, seedhi = (uint32_t)(seed >> 32);
+  // window of uniforms: lane l holds uniform 2 * ub + l of transition uit
+  uint32_t uit = 0xFFFFFFFFu, ub = 0;
+  double uw = 0.0;
+  auto uni = [&](uint32_t it, uint32_t k) -> double {
+    const uint32_t blk = k >> 1;
+    if (it != uit || blk - ub >= 32u) {
+      uit = it; ub = blk;
+      Philox4 r = philox4x32_10(blk + (uint32_t)(lane >> 1), it, chain, 0u, seedlo, seedhi);
+      uw = (lane & 1) ? u53(r.w[2], r.w[3]) : u53(r.w[0], r.w[1]);
+    }
+    return wn_readlane(uw, (int)(k - 2u * ub));
+  };
+  auto ke_of = [&](double rho) -> double { return 0.5 * wt_sum<SMALL>(im * (rho * rho)); };  // 0.5*dot(inv_mass, rho**2)  (:124)
+  // log density and gradient at theta (element-wise targets): lp = 1/2 sum theta_i g_i
+  auto eval = [&](double th, double& g) -> double { g = -(aa * th); return 0.5 * wt_sum<SMALL>(th * g); };
+  auto mlogp = [](int ell, int es) -> double { return (ell == es || ell == es / 2 || ell == es * 2) ? -1.0986122886681098 : -INFINITY; };
+
+  // stable_steps (:144-182) from (th0, sgn * rh0) with (lp0, g0) known: the smallest 2**n <= 1024 micro steps whose Hamiltonians
+  // stay within max_error of each other (2**10 if none does).  One wave sum per micro step: H = sum_i (1/2 im rho_i^2 - 1/2 theta_i g_i).
+  auto stable = [&](double th0, double rh0, double g0, double lp0, double sgn) -> int {
+    const double r0 = sgn * rh0;
+    const double H0 = -lp0 + ke_of(r0);
+    int ell = 1;
+#pragma unroll 1
+    for (int n = 0;; ++n) {
+      ell = 1 << n;
+      const double step = macro / (double)ell, half = 0.5 * step;
+      double th = th0, rh = r0 + half * g0;
+      th = th + (step * im) * rh;
+      double Hmin = H0, Hmax = H0;
+      int k = ell;
+#pragma unroll 1
+      do {
+        const double g = -(aa * th);
+        rh = rh + half * g;
+        const double Hc = wt_sum<SMALL>(0.5 * (im * (rh * rh)) - 0.5 * (th * g));
+        Hmin = (Hc < Hmin) ? Hc : Hmin; Hmax = (Hc > Hmax) ? Hc : Hmax;  // Python min() / max() order
+        rh = rh + half * g;
+        th = th + (step * im) * rh;   // (one drift too many after the last step: nothing reads it)
+      } while (--k);
+      if (__builtin_amdgcn_readfirstlane((int)(Hmax - Hmin <= maxerr)) || n >= 10) break;
+    }
+    return ell;
+  };
+
+  for (int tr = 0; tr < n_trans; ++tr) {
+    const uint32_t it = (uint32_t)(it0 + tr);
+    uint32_t k = 0;
+    double th = in ? theta_io[(size_t)b * D + li] : 0.0;
+    double rh = in ? rng_normal(seed, chain, it, (uint32_t)li) / sqrt(im) : 0.0;  // rho ~ mvnormal(0, inverse(inv_mass))  (:325)
+    double g;
+    double lp = eval(th, g);
+    // the orbit's two ends and the selected state
+    double thL = th, rhL = rh, gL = g, thR = th, rhR = rh, gR = g, sel = th;
+    double lpL = lp, lpR = lp;
+    double wL = lp - ke_of(rh), wR = wL;
+    if (lane == 0) logw[0] = wL;
+    int nw = 1;
+#pragma unroll 1
+    for (int depth = 0; depth < max_depth; ++depth) {
+      const int n = 1 << depth;
+      const int backward = uni(it, k++) < 0.5 ? 1 : 0;  // :330
+      for (int m0 = 0; m0 < n; m0 += 32) {               // one lottery index per macro step (:194), drawn before the extension as the kernel above does
+        uit = 0xFFFFFFFFu;                               // a fresh window that STARTS at the block of uniform k + m0: its first 62 uniforms are inside
+        (void)uni(it, k + (uint32_t)m0);
+        const int off = (int)(k + (uint32_t)m0 - 2u * ub);
+        const double u = __shfl(uw, (off + lane) & 63);
+        const int idx = (int)(3.0 * u);
+        if (lane < 32 && m0 + lane < n) lot[m0 + lane] = idx > 2 ? 2 : idx;
+      }
+      k += (uint32_t)n;
+      // extend_orbit (:211-276): from the orbit's first state with the momentum negated, or from its last state
+      double t0 = backward ? thL : thR, r0 = backward ? -rhL : rhR, g0 = backward ? gL : gR;
+      double lp0 = backward ? lpL : lpR, weight = backward ? wL : wR;
+#pragma unroll 1
+      for (int m = 0; m < n; ++m) {
+        const double p0 = lp0 - ke_of(r0);
+        const int es = stable(t0, r0, g0, lp0, 1.0);
+        const int idx = __builtin_amdgcn_readfirstlane((int)lot[m]);
+        const int ell = idx == 0 ? es / 2 : idx == 1 ? es : es * 2;  // choose_micro_steps (:194); es == 1 can give 0 (Q9): an infinite step
+        {  // leapfrog (:74-95)
+          const double step = macro / (double)ell, half = 0.5 * step;
+          double t = t0, r = r0 + half * g0;
+          t = t + (step * im) * r;
+          double gg = -(aa * t);
+#pragma unroll 1
+          for (int j = 1; j < ell; ++j) {
+            r = r + step * gg;
+            t = t + (step * im) * r;
+            gg = -(aa * t);
+          }
+          r0 = r + half * gg; t0 = t; g0 = gg;
+        }
+        double gchk;
+        lp0 = eval(t0, gchk);
+        const int en = stable(t0, r0, g0, lp0, -1.0);
+        const double p1 = lp0 - ke_of(r0);
+        weight = p1 - p0 + mlogp(ell, en) - mlogp(ell, es) + weight;  // :264-271
+        if (in) { eorb[(size_t)m * 2 * D + li] = t0; eorb[(size_t)m * 2 * D + D + li] = r0; }
+        if (lane == 0) ew[m] = weight;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      // sub_uturn (:62-70) over the extension in LIST order (time order: integration order reversed when going backward): check c of
+      // the n-1 (span n >> l, i-th block) is lane c's; any order gives the same answer
+      bool su = false;
+      for (int c1 = 0; c1 < n - 1; c1 += 64) {
+        const int cc = c1 + lane;
+        bool f = false;
+        if (cc < n - 1) {
+          const int l = 31 - __builtin_clz((unsigned)(cc + 1)), i = cc + 1 - (1 << l), span = n >> l;
+          const int x = span * i, y = span * (i + 1) - 1;
+          const int ix = backward ? n - 1 - x : x, iy = backward ? n - 1 - y : y;
+          const double *sx = eorb + (size_t)ix * 2 * D, *sy = eorb + (size_t)iy * 2 * D;
+          double d1 = 0.0, d2 = 0.0;
+          for (int j = 0; j < D; ++j) {
+            const double diff = c0.im[j] * (sy[j] - sx[j]);
+            d1 += sx[D + j] * diff;
+            d2 += sy[D + j] * diff;
+          }
+          f = d1 < 0 || d2 < 0;
+        }
+        su = su || __any(f);
+      }
+      if (su) break;
+      // logsumexp of the extension's weights and of the orbit's so far (:345, scipy.special.logsumexp)
+      auto lse = [&](const double* a, int cnt) -> double {
+        double mx = -INFINITY; bool nan = false;
+        for (int j = lane; j < cnt; j += 64) { const double x = a[j]; nan = nan || isnan(x); mx = x > mx ? x : mx; }
+        mx = WavePolicy<1, WTgtDiag<1>>::wavemax(mx);
+        if (__any(nan)) mx = NAN;
+        if (!isfinite(mx)) mx = 0.0;
+        double sm = 0.0;
+        for (int j = lane; j < cnt; j += 64) sm += exp(a[j] - mx);
+        return log(wn_wavesum(sm)) + mx;
+      };
+      const double lse_ext = lse(ew, n), lse_old = lse(logw, nw);
+      const double logu = log(uni(it, k++));  // :346
+      const bool acc = logu < lse_ext - lse_old;
+      if (acc) {  // :347-350: p = softmax(log_weights_ext) in LIST order; Generator.choice: cdf = p.cumsum(); cdf /= cdf[-1]; searchsorted(u, 'right')
+        const double uc = uni(it, k++);
+        double mx = -INFINITY;
+        for (int j = 0; j < n; ++j) { const double x = ew[j]; mx = x > mx ? x : mx; }
+        double tot = 0.0;
+        for (int j = 0; j < n; ++j) tot += exp(ew[j] - mx);
+        double cs = 0.0;
+        for (int pp = 0; pp < n; ++pp) { const int j = backward ? n - 1 - pp : pp; cs += exp(ew[j] - mx) / tot; }
+        const double last = cs;
+        cs = 0.0;
+        int idx = n - 1;
+        for (int pp = 0; pp < n; ++pp) {
+          const int j = backward ? n - 1 - pp : pp;
+          cs += exp(ew[j] - mx) / tot;
+          if (uc < cs / last) { idx = pp; break; }
+        }
+        const int ii = __builtin_amdgcn_readfirstlane(backward ? n - 1 - idx : idx);
+        sel = in ? eorb[(size_t)ii * 2 * D + li] : 0.0;
+      }
+      // orbit = orbit_ext + orbit / orbit + orbit_ext (:351): the new end is the LAST computed state
+      {
+        const double we = ew[n - 1];
+        if (backward) { thL = t0; rhL = r0; gL = g0; lpL = lp0; wL = we; }
+        else { thR = t0; rhR = r0; gR = g0; lpR = lp0; wR = we; }
+        for (int j = lane; j < n; j += 64) logw[nw + j] = ew[j];
+        nw += n;
+      }
+      double d1 = im * (thR - thL), d2 = rhR * d1;  // uturn(orbit[0], orbit[-1], inv_mass) (:352)
+      d1 = rhL * d1;
+      wt_sum2<SMALL>(d1, d2);
+      if (__builtin_amdgcn_readfirstlane((int)(d1 < 0 || d2 < 0))) break;
+    }
+    if (in) {
+      theta_io[(size_t)b * D + li] = sel;
+      if (draws) draws[((size_t)b * n_trans + tr) * D + li] = sel;
+    }
+  }
+}
+
+}  // namespace
+
+namespace {
+
 __global__ void wstep_result_kernel(WCtx c, double* theta_sel) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= c.B) return;
@@ -625,6 +857,16 @@ int wn_wstep_run_device_rng(wn_wstep* h, uint64_t seed, int64_t chain_offset, in
   if (h->c.D > 64) { h->err = "wn_wstep_run_device_rng: dim <= 64 (the chain's vectors live in LDS)"; return WN_E_UNSUPPORTED; }
   if (chain_offset < 0 || (uint64_t)chain_offset + (uint64_t)h->c.B > (1ull << 32)) { h->err = "chain_offset + B must stay within [0, 2^32)"; return WN_E_ARG; }
   WCHK(hipSetDevice(h->device));
+  // element-wise targets: the wave-parallel kernel (lane = element); WN_WSTEP_LEGACY=1 keeps the one-lane kernel (A/B tests)
+  if ((h->c.kind == T_STDGAUSS || h->c.kind == T_DIAGGAUSS) && h->c.nmax <= 8192 && !getenv("WN_WSTEP_LEGACY")) {
+    const size_t dyn = (size_t)h->c.nmax * sizeof(int);
+    if (h->c.D <= 16) hipLaunchKernelGGL(wstep_wave_kernel<true>, dim3(h->c.B), dim3(64), dyn, (hipStream_t)stream, h->c, h->lot, seed, (uint32_t)chain_offset,
+                                         (int)iter0, (int)n_transitions, h->max_depth, theta_dev, draws_dev);
+    else hipLaunchKernelGGL(wstep_wave_kernel<false>, dim3(h->c.B), dim3(64), dyn, (hipStream_t)stream, h->c, h->lot, seed, (uint32_t)chain_offset,
+                            (int)iter0, (int)n_transitions, h->max_depth, theta_dev, draws_dev);
+    WCHK(hipGetLastError());
+    return WN_OK;
+  }
   hipLaunchKernelGGL(wstep_auto_kernel, dim3(h->c.B), dim3(64), 0, (hipStream_t)stream, h->c, h->lot, seed, (uint32_t)chain_offset,
                      (int)iter0, (int)n_transitions, h->max_depth, theta_dev, draws_dev);
   WCHK(hipGetLastError());
