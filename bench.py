@@ -648,6 +648,14 @@ def main():
                     oc[f"cfg{sp['cfg']}_{sp['name']}"] = {"error": repr(ex)}
                 print(f"bench.py: side configuration {sp['name']} took {time.perf_counter() - t_:.1f} s", file=sys.stderr)
             extras["other_configs"] = oc
+            try:  # BASELINE configs[0]'s sampler as whole transitions on the device (1 untimed + 2 timed calls)
+                t_ = time.perf_counter()
+                w = walnuts10_record(4096, 20, 2, 1, host_form=False)
+                extras["walnuts10_device"] = {k: w[k] for k in ("value", "unit", "ms_per_step", "config", "note", "draws_mean_abs_max", "draws_var_mean",
+                                                                   "reference_python_transitions_per_s_per_core")}
+                print(f"bench.py: walnuts10 took {time.perf_counter() - t_:.1f} s", file=sys.stderr)
+            except Exception as ex:
+                extras["walnuts10_device"] = {"error": repr(ex)}
             out["extras"] = extras
         if cpu is not None:
             out["cpu_baseline"] = cpu
@@ -684,49 +692,52 @@ def main_dry_run():
         dist.destroy_process_group()
 
 
-def main_walnuts10(args):
+def walnuts10_record(C, iters, steps, warmup, host_form=True):
     """BASELINE configs[0]'s target (10-D standard normal, test/test.py:11-18 parameters: macro_step 2.0, max_nuts_depth 10,
     max_error 0.1) as whole transitions on the device (`walnuts_device`: walnuts/walnuts.py:279-359 with the engine's random
-    stream): transitions/s of `--chains` chains.  Beside it, the host-Generator form (`walnuts_batch`, the reference's contract)
-    on a small batch.  The reference runs ~1.2e3 transitions/s on one core."""
+    stream): transitions/s of C chains, `iters` transitions per call.  The time is the whole API call (handle set-up, H2D of the
+    start, the launch, D2H of the draws).  Beside it, the host-Generator form (`walnuts_batch`, the reference's contract) on a
+    small batch.  The reference runs ~1.2e3 transitions/s on one core."""
     import torch
     from walnuts_amd import targetDistr as td
     import walnuts_amd as wa
-    C = args.chains or 4096
-    iters = args.iters or 20
     D = 10
     theta = np.zeros((C, D))
     t_all = []
     d = None
-    for k in range(args.warmup + args.steps):
+    for k in range(warmup + steps):
         t0 = time.perf_counter()
         d = wa.walnuts_device(SEED + k, theta, td.stdGauss, np.ones(D), 2.0, 10, 0.1, 0, iters, transitions_per_launch=iters)
         torch.cuda.synchronize()
-        if k >= args.warmup:
+        if k >= warmup:
             t_all.append(time.perf_counter() - t0)
     el = float(np.sum(t_all))
-    # the host-Generator form on 64 chains, 2 transitions
-    rngs = [np.random.default_rng(1000 + c) for c in range(64)]
-    t0 = time.perf_counter()
-    wa.walnuts_batch(rngs, np.zeros((64, D)), td.stdGauss, td.stdGauss, np.ones(D), 2.0, 10, 0.1, 0, 2)
-    host_rate = 64 * 2 / (time.perf_counter() - t0)
+    host_rate = None
+    if host_form:  # the host-Generator form on 64 chains, 2 transitions
+        rngs = [np.random.default_rng(1000 + c) for c in range(64)]
+        t0 = time.perf_counter()
+        wa.walnuts_batch(rngs, np.zeros((64, D)), td.stdGauss, td.stdGauss, np.ones(D), 2.0, 10, 0.1, 0, 2)
+        host_rate = 64 * 2 / (time.perf_counter() - t0)
     from walnuts_amd.ess import ess
-    per = el / args.steps
-    print(json.dumps({"metric": "transitions/sec across chains, walnuts() on the 10-D standard normal", "value": C * iters * args.steps / el,
-                      "unit": "transitions/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per * 1e3,
-                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                      "config": {"workload": f"walnuts_device: {C} chains x {iters} transitions per step, D=10 standard normal, macro_step=2.0, "
-                                             f"max_nuts_depth=10, max_error=0.1 (BASELINE configs[0]'s target, test/test.py:11-18)",
-                                 "kernel": "wstep_auto_kernel (wn_k_wstep.hip): one thread per chain, whole transitions on the device, Philox stream of wn_rng.h"},
-                      "note": "a launch lasts as long as its slowest chain, and the cost of a transition of this sampler has a heavy tail (a macro step whose "
-                              "energy error stays above max_error runs stable_steps to 2^10 micro steps, walnuts.py:144-181; an orbit can reach 2^10 macro "
-                              "steps): 256 chains x 100 transitions measured 0.15 s to 5.1 s depending on which chains they were; one chain alone makes ~500 "
-                              "typical transitions/s",
-                      "draws_mean_abs_max": float(np.abs(d.mean(axis=(0, 1))).max()), "draws_var_mean": float(d.var(axis=(0, 1)).mean()),
-                      "ess_per_sec": {"q0": ess(d[:, :, 0]) / per, "method": "rank-normalised split bulk ESS over all chains of one step"},
-                      "host_generator_form": {"value": host_rate, "unit": "transitions/s", "what": "walnuts_batch, 64 chains x 2 transitions, one numpy Generator per chain "
-                                              "consumed on the host in the reference's order (the reference's contract)"},
-                      "reference_python_transitions_per_s_per_core": 1.2e3}), flush=True)
+    per = el / steps
+    return {"metric": "transitions/sec across chains, walnuts() on the 10-D standard normal", "value": C * iters * steps / el,
+            "unit": "transitions/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": per * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"walnuts_device: {C} chains x {iters} transitions per step, D=10 standard normal, macro_step=2.0, "
+                                   f"max_nuts_depth=10, max_error=0.1 (BASELINE configs[0]'s target, test/test.py:11-18)",
+                       "kernel": "wstep_wave_kernel (wn_k_wstep.hip): one chain per wavefront, lane = element, whole transitions on the device, Philox stream of wn_rng.h"},
+            "note": "a launch lasts as long as its slowest chain, and the cost of a transition of this sampler has a heavy tail (81 gradient evaluations in "
+                    "the median, 75 332 at the maximum of 12 000 transitions of the reference itself: profiles/r04_walnuts_tail.txt), so more transitions "
+                    "per launch average better; round 3's one-lane kernel made 2.7e4 transitions/s on this workload",
+            "draws_mean_abs_max": float(np.abs(d.mean(axis=(0, 1))).max()), "draws_var_mean": float(d.var(axis=(0, 1)).mean()),
+            "ess_per_sec": {"q0": ess(d[:, :, 0]) / per, "method": "rank-normalised split bulk ESS over all chains of one step"},
+            "host_generator_form": None if host_rate is None else {"value": host_rate, "unit": "transitions/s", "what": "walnuts_batch, 64 chains x 2 transitions, one numpy Generator per chain "
+                                    "consumed on the host in the reference's order (the reference's contract)"},
+            "reference_python_transitions_per_s_per_core": 1.2e3}
+
+
+def main_walnuts10(args):
+    print(json.dumps(walnuts10_record(args.chains or 4096, args.iters or 20, args.steps, args.warmup)), flush=True)
 
 
 if __name__ == "__main__":
