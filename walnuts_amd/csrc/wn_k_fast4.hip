@@ -77,9 +77,17 @@ struct Fast4Geom {
   static constexpr int P_SEQ = P_URING + 4 * 16 * 3;
   static constexpr int P_H0 = P_SEQ + 8;               // the running iteration's initial Hamiltonian per chain (R wave -> I wave)
   static constexpr int PAIR_DOUBLES = P_H0 + 4;
+  // "halves" (one 4-chain group on TWO T waves, configs[1]'s 1024 chains: fast4_halves): a second position stage (the two waves of a group
+  // are a tick apart at most), the second wave's sums, two hand-off words
+  static constexpr int P_STAGE2 = PAIR_DOUBLES;
+  static constexpr int P_SUMS2 = P_STAGE2 + VEC;
+  static constexpr int P_XSEQ = P_SUMS2 + 3 * NB * 16;
+  static constexpr int PAIR_DOUBLES_H = P_XSEQ + 2;
+  static constexpr int NSPLIT = NSR / 2;  // register sets 0 .. NSPLIT-1 belong to the first wave, the rest (and the tail rows) to the second
   static constexpr int OFF_PAIR = NFR * 64;
   static_assert(((size_t)OFF_PAIR + 4 * (size_t)PAIR_DOUBLES) * sizeof(double) <= 160 * 1024, "four pairs and the fragment image in one CU's LDS");
   __host__ __device__ static constexpr size_t lds_bytes(int pairs) { return ((size_t)OFF_PAIR + (size_t)pairs * PAIR_DOUBLES) * sizeof(double); }
+  __host__ __device__ static constexpr size_t lds_bytes_halves() { return ((size_t)OFF_PAIR + (size_t)PAIR_DOUBLES_H) * sizeof(double); }
   // workspace of one 4-chain group, in doubles: (M+1) slots x (q, v), 2 proposals, the passive orbit end (q, v), momentum normals [chain][DPAD]
   __host__ __device__ static constexpr size_t group_doubles(int M) { return (size_t)((M + 1) * 2 + 4) * VEC + (size_t)4 * DPAD; }
 };
@@ -171,9 +179,16 @@ __device__ __forceinline__ void cmd_read(const double* rec, uint64_t& w, double&
   hs = *(const lds_vf64*)rec;
 }
 __device__ __forceinline__ bool cmd_is_for(uint64_t w, uint32_t tick) { return (((uint32_t)w >> CMD_TAG_SHIFT) & 0xFFFFu) == (tick & 0xFFFFu); }
-template <class G, bool TRACE>
+// HALF: 0 = the wave owns the whole group (every register set); 1 / 2 = the group's two T waves of the halves mode: register sets
+// [0, NSPLIT) / [NSPLIT, NS).  Each computes the gradient rows of its own sets -- the B operands (ALL coordinates) come from the LDS
+// stage, which both fill: one LDS hand-off per tick -- and the partial sums of its own coordinates; the R wave adds the two.
+template <class G, bool TRACE, int HALF = 0>
 __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* lds, double* pr, const int grp, int* abort_flag) {
   constexpr int NS = G::NS, NFAST = G::NFAST;
+  constexpr int S0 = HALF == 2 ? G::NSPLIT : 0, S1 = HALF == 1 ? G::NSPLIT : NS;          // own register sets
+  constexpr int R0 = HALF == 2 ? G::NSPLIT : 0, R1 = HALF == 1 ? G::NSPLIT : G::NSR;      // own 16-row sets of the MFMA phase
+  constexpr bool OWN_TAIL = G::TAIL && HALF != 1;
+  static_assert(HALF == 0 || G::DENSE, "halves: dense targets");
   const int lane = threadIdx.x & 63, x = lane & 3, b = (lane >> 2) & 3, r = lane >> 4;
   const int cl = grp * 4 + x;
   const bool inrange = cl < prm.C;
@@ -187,10 +202,11 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
   const int vprop = (prm.M + 1) * 2, vcold = vprop + 2;
   const double* const znext = wbase + (size_t)((prm.M + 1) * 2 + 4) * G::VEC + (size_t)x * G::DPAD;
   double* const lc = pr + G::P_LC + lane;
-  double* const stage = pr + G::P_STAGE;
+  double* const stage0 = pr + G::P_STAGE;
   double* const pk = pr + G::P_PK + lane;
-  double* const sums = pr + G::P_SUMS;
-  lds_vu32* const seq = lds_words(pr + G::P_SEQ);  // [0]: ticks finished by T
+  double* const sums = pr + (HALF == 2 ? G::P_SUMS2 : G::P_SUMS);
+  lds_vu32* const seq = lds_words(pr + G::P_SEQ) + (HALF == 2 ? 1 : 0);  // [0]: ticks finished by T ([1]: by the group's second T wave)
+  lds_vu32* const xseq = lds_words(pr + G::P_XSEQ);  // halves: [w] = ticks whose position wave w has staged
 
   // P(t) = the position after the drift of tick t lives in X[t & 1]: at the start of tick t, X[(t-1) & 1] is the current position and
   // X[t & 1] still holds P(t-2); the drift overwrites it with P(t), and P(t-1) stays for the level-1 check behind the gradient.  No
@@ -239,7 +255,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     }
     d2_t fx[(NS - 1) / 2 > 0 ? (NS - 1) / 2 : 1];
     double ftail = 0.0;
-    if (G::DENSE && G::TAIL) {
+    if (G::DENSE && OWN_TAIL) {
 #pragma unroll
       for (int j = 0; j < (NS - 1) / 2; ++j) fx[j] = *reinterpret_cast<const d2_t*>(img + G::NMAIN * 64 + j * 128);
       ftail = lds[G::OFF_A + (G::NMAIN + NS - 1) * 64 + lane];
@@ -275,30 +291,30 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
           const int sl = slot_of_leaf(n + 1 - (1 << NFAST));
           const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
 #pragma unroll
-          for (int s = 0; s < NS; ++s) { pq0[s] = sq[s * 16]; pv0[s] = sv[s * 16]; }
+          for (int s = S0; s < S1; ++s) { pq0[s] = sq[s * 16]; pv0[s] = sv[s * 16]; }
         }
         if (deep1) {
           const int sl = slot_of_leaf(n + 1 - (2 << NFAST));
           const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
 #pragma unroll
-          for (int s = 0; s < NS; ++s) { pq1[s] = sq[s * 16]; pv1[s] = sv[s * 16]; }
+          for (int s = S0; s < S1; ++s) { pq1[s] = sq[s * 16]; pv1[s] = sv[s * 16]; }
         }
       }
       if (__any((op & OP_PICK) != 0)) {  // `pk` holds the position of tick t-3
         if (op & OP_PICK) {
           double* dst = gvec(vprop + ((op & OP_IPPICK) ? 1 : 0));
 #pragma unroll
-          for (int s = 0; s < NS; ++s) dst[s * 16] = pk[s * 64];
+          for (int s = S0; s < S1; ++s) dst[s * 16] = pk[s * 64];
         }
       }
       if (TRACE) { ntr -= ((op & OP_UNDO) ? 1 : 0) + ((op & OP_UNDO2) ? 1 : 0); }  // the leaves in flight when the iteration ended
     }
 #pragma unroll
-    for (int s = 0; s < NS; ++s) pk[s * 64] = qn[s];  // P(t-2): a pick commanded at the next tick copies it (same wave: after the read above)
+    for (int s = S0; s < S1; ++s) pk[s * 64] = qn[s];  // P(t-2): a pick commanded at the next tick copies it (same wave: after the read above)
     // ---- first half of the leapfrog step (adaptiveIntegrators.py:51-52 with hs = xi*h; v stays forward-time) ----
     const double hs = step ? c.hs : 0.0, hs2 = 0.5 * hs;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) { v[s] = vi[s] + hs2 * g[s]; qn[s] = qc[s] + hs * v[s]; }
+    for (int s = S0; s < S1; ++s) { v[s] = vi[s] + hs2 * g[s]; qn[s] = qc[s] + hs * v[s]; }
     // iteration starts and end swaps replace the position this tick produces (qn; such ticks do not step: hs = 0).  qc is left alone: it
     // is the position of tick t-1, which a pick commanded at tick t+2 copies (the last leaf of a doubling can be picked while the end swap
     // of the next doubling is already under way)
@@ -308,32 +324,32 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
           if (op & OP_INIT) {
             double* dst = gvec(vprop);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
+            for (int s = S0; s < S1; ++s) {
               qn[s] = coord(s) < D ? prm.q0[(size_t)cl * D + coord(s)] : 0.0;
               dst[s * 16] = qn[s];
             }
           } else {
             const double* src = gvec(vprop + ((op & OP_IPNEW) ? 1 : 0));
 #pragma unroll
-            for (int s = 0; s < NS; ++s) qn[s] = src[s * 16];
+            for (int s = S0; s < S1; ++s) qn[s] = src[s * 16];
           }
           // samples[:, row] = generated(q)  (WALNUTS.py:164,695)
           double* row = prm.samples + ((size_t)cl * (prm.numIter + 1) + c.n) * prm.dg;
           if (prm.generated == G_Q0_SUMSQ) {
-            if (lane < 4) row[0] = qn[0];  // coordinate 0: register 0 of lane (r = 0, b = 0, x)
+            if (S0 == 0 && lane < 4) row[0] = qn[0];  // coordinate 0: register 0 of lane (r = 0, b = 0, x)
             double s2 = 0.0;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) s2 += qn[s] * qn[s];
+            for (int s = S0; s < S1; ++s) s2 += qn[s] * qn[s];
             gen_part = s2;
           } else {
             const int k = prm.generated == G_FIRSTK ? prm.gen_k : D;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) if (coord(s) < k) row[coord(s)] = qn[s];
+            for (int s = S0; s < S1; ++s) if (coord(s) < k) row[coord(s)] = qn[s];
           }
           if (!(op & (OP_INIT | OP_LAST))) {  // v = normal(size=d); both ends start at (qc, v)  (:236-253)
             double kp = 0.0;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
+            for (int s = S0; s < S1; ++s) {
               const double z = znext[coord(s)];
               v[s] = z;
               kp += z * z;
@@ -341,7 +357,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
             keinit_part = kp;
             double *dq_ = gvec(vcold), *dv_ = gvec(vcold + 1);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) { dq_[s * 16] = qn[s]; dv_[s * 16] = v[s]; }
+            for (int s = S0; s < S1; ++s) { dq_[s * 16] = qn[s]; dv_[s * 16] = v[s]; }
           }
           __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): waited for HERE, not on the common path (wn_k_fast.hip)
         }
@@ -351,29 +367,39 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
           double *dq_ = gvec(vcold), *dv_ = gvec(vcold + 1);
           double tq[NS], tv[NS];
 #pragma unroll
-          for (int s = 0; s < NS; ++s) { tq[s] = dq_[s * 16]; tv[s] = dv_[s * 16]; }
+          for (int s = S0; s < S1; ++s) { tq[s] = dq_[s * 16]; tv[s] = dv_[s * 16]; }
 #pragma unroll
-          for (int s = 0; s < NS; ++s) { dq_[s * 16] = qc[s]; dv_[s * 16] = v[s]; qn[s] = tq[s]; v[s] = tv[s]; }  // (no step on this tick)
+          for (int s = S0; s < S1; ++s) { dq_[s * 16] = qc[s]; dv_[s * 16] = v[s]; qn[s] = tq[s]; v[s] = tv[s]; }  // (no step on this tick)
           __builtin_amdgcn_s_waitcnt(0x0F70);
         }
       }
     }
     if (!G::DENSE) {  // diagonal / standard Gaussian: g = -(a .* q)  (targetDistr.py stdGauss; SURVEY 8d "diagonal variant")
 #pragma unroll
-      for (int s = 0; s < NS; ++s) g[s] = -(adiag[s] * qn[s]);
+      for (int s = S0; s < S1; ++s) g[s] = -(adiag[s] * qn[s]);
       WN4_STAMP(0);
     }
     // the position goes to LDS: k-step kappa's B operand (coordinates 4 kappa .. + 3 in EVERY block) is read back from there with the
     // block index replaced -- one LDS read per k-step instead of six DPP moves (FP64 MFMAs and vector instructions share the SIMD)
     if (G::DENSE) {
+    double* const stage = HALF == 0 ? stage0 : (PAR ? pr + G::P_STAGE2 : stage0);  // (halves: two buffers -- the partner may still read tick t-1's)
 #pragma unroll
-    for (int s = 0; s < NS; ++s) stage[s * 64 + lane] = qn[s];
+    for (int s = S0; s < S1; ++s) stage[s * 64 + lane] = qn[s];
+    if (HALF != 0) {  // the partner's coordinates are the other half of every B operand: wait until it has staged tick t
+      if (lane == 0) xseq[HALF - 1] = t + 1u;  // (same wave, in order: behind the stage writes)
+      uint32_t spins = 0;
+      while ((int32_t)(xseq[2 - HALF] - (t + 1u)) < 0) {
+        if (++spins > (1u << 24)) { if (lane == 0) atomicExch(abort_flag, 1); return false; }
+      }
+      asm volatile("" ::: "memory");
+    }
     WN4_STAMP(0);
     // ---- G = -A Q ----
     {
       const double* const st0 = stage + 16 * r + x;  // + s * 64 + 4 * b'
       double accx = 0.0, gx = 0.0;
       double acc[NSR];  // (set by the first k-step, whose accumulator operand is the literal 0: no register zeroing)
+      const double* const stl = stage + lane;  // a register set of the PARTNER, in its own layout (tail rows: K split over the register sets)
       double qks[3];  // the B operands of three k-steps in flight / in use
 #pragma unroll
       for (int k0 = 0; k0 < 2; ++k0) if (k0 < NK) qks[k0] = st0[(k0 >> 2) * 64 + 4 * (k0 & 3)];
@@ -384,16 +410,19 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
         const double qk = qks[kap % 3];
         const d2_t* f = fa[kap & 3];
 #pragma unroll
-        for (int S = 0; S < NSR; ++S) acc[S] = kap == 0 ? mfma4(f[S >> 1][S & 1], qk, 0.0) : mfma4(f[S >> 1][S & 1], qk, acc[S]);
-        if (G::TAIL) {
-          if (kap < NS - 1) accx = kap == 0 ? mfma4(fx[0][0], qn[0], 0.0) : mfma4(fx[kap >> 1][kap & 1], qn[kap], accx);
+        for (int S = R0; S < R1; ++S) acc[S] = kap == 0 ? mfma4(f[S >> 1][S & 1], qk, 0.0) : mfma4(f[S >> 1][S & 1], qk, acc[S]);
+        if (OWN_TAIL) {
+          if (kap < NS - 1) {
+            const double qx = (kap >= S0 && kap < S1) ? qn[kap] : stl[kap * 64];
+            accx = kap == 0 ? mfma4(fx[0][0], qx, 0.0) : mfma4(fx[kap >> 1][kap & 1], qx, accx);
+          }
           if (kap == NS + 1) gx = blocks_sum(accx);          // (two k-steps behind its last MFMA)
           if (kap == NK - 1) gx = mfma4(ftail, qk, gx);      // columns 16 (NS-1) .. + 3
         }
       }
 #pragma unroll
-      for (int S = 0; S < NSR; ++S) g[S] = acc[S];
-      if (G::TAIL) g[NS - 1] = b == 0 ? gx : 0.0;  // blocks 1..3 of the last register are padding
+      for (int S = R0; S < R1; ++S) g[S] = acc[S];
+      if (OWN_TAIL) g[NS - 1] = b == 0 ? gx : 0.0;  // blocks 1..3 of the last register are padding
     }
     }
     WN4_STAMP(1);
@@ -402,25 +431,25 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     const bool anyl0 = __any(l0due);
     double cq[NS], cv[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) asm volatile("" : "=v"(cq[s]), "=v"(cv[s]));  // (whatever the registers hold: the level-0 sums of a chain that is not at its last leaf are never read)
+    for (int s = S0; s < S1; ++s) asm volatile("" : "=v"(cq[s]), "=v"(cv[s]));  // (whatever the registers hold: the level-0 sums of a chain that is not at its last leaf are never read)
     if (anyl0) {
       if (l0due) {
         const double *sq = gvec(vcold), *sv = gvec(vcold + 1);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) { cq[s] = sq[s * 16]; cv[s] = sv[s * 16]; }
+        for (int s = S0; s < S1; ++s) { cq[s] = sq[s * 16]; cv[s] = sv[s * 16]; }
       }
     }
     // ---- second half step; lp = 1/2 q.g, KE = 1/2 v.v ----
     double pl = 0.0, pk = 0.0;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) pl += qn[s] * g[s];
+    for (int s = S0; s < S1; ++s) pl += qn[s] * g[s];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) { v[s] = v[s] + hs2 * g[s]; pk += v[s] * v[s]; }
+    for (int s = S0; s < S1; ++s) { v[s] = v[s] + hs2 * g[s]; pk += v[s] * v[s]; }
     if (TRACE) {  // one row per integrator call: the state (q', v') goes here, the scalars come from the bookkeeper
       if (step && prm.trace && ntr < prm.trace_cap && ntr >= 0) {
         double* tr = prm.trace + ((size_t)cl * prm.trace_cap + ntr) * (TRACE_NSCAL + 2 * D) + TRACE_NSCAL;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) if (coord(s) < D) { tr[coord(s)] = qn[s]; tr[D + coord(s)] = v[s]; }
+        for (int s = S0; s < S1; ++s) if (coord(s) < D) { tr[coord(s)] = qn[s]; tr[D + coord(s)] = v[s]; }
       }
       if (step) ntr += 1;
     }
@@ -428,7 +457,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     auto dots = [&](const double* qo, const double* vo, double& d1, double& d2) {
       double a1 = 0.0, a2 = 0.0;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
+      for (int s = S0; s < S1; ++s) {
         const double dq = qn[s] - qo[s];
         a1 += v[s] * dq;
         a2 += vo[s] * dq;
@@ -447,7 +476,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
         if (__any(nchk > 2)) {
           double qo[NS], vo[NS];
 #pragma unroll
-          for (int s = 0; s < NS; ++s) { qo[s] = lc[s * 64]; vo[s] = lc[G::VEC + s * 64]; }
+          for (int s = S0; s < S1; ++s) { qo[s] = lc[s * 64]; vo[s] = lc[G::VEC + s * 64]; }
           dots(qo, vo, b1, b2);
         }
         put4(sp + 16, a1, a2, b1, b2);
@@ -468,7 +497,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
               const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
               double qo[NS], vo[NS];
 #pragma unroll
-              for (int s = 0; s < NS; ++s) { qo[s] = sq[s * 16]; vo[s] = sv[s * 16]; }
+              for (int s = S0; s < S1; ++s) { qo[s] = sq[s * 16]; vo[s] = sv[s * 16]; }
               dots(qo, vo, e[2 * h], e[2 * h + 1]);
             }
           }
@@ -485,12 +514,12 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
       if (__any(ep)) {
         if (ep) {
 #pragma unroll
-          for (int s = 0; s < NS; ++s) { lc[s * 64] = qn[s]; lc[G::VEC + s * 64] = v[s]; }
+          for (int s = S0; s < S1; ++s) { lc[s * 64] = qn[s]; lc[G::VEC + s * 64] = v[s]; }
           if (n == 0 ? (i >= NFAST) : (__builtin_ctz((unsigned)n) >= NFAST)) {
             const int sl = slot_of_leaf(n);
             double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) { sq[s * 16] = qn[s]; sv[s * 16] = v[s]; }
+            for (int s = S0; s < S1; ++s) { sq[s * 16] = qn[s]; sv[s * 16] = v[s]; }
           }
         }
       }
@@ -568,15 +597,17 @@ __device__ __forceinline__ bool seq_wait2(const lds_vu32* p, uint32_t want, cons
   return true;
 }
 
-template <class G, bool TRACE>
+// HALVES: the group's vectors are on two T waves -- the R wave waits for both (odd replicas watch the second wave's word) and adds their sums
+template <class G, bool TRACE, bool HALVES = false>
 __device__ __forceinline__ void fast4_r_wave(const Params& prm, double* quad, const int grp0, const int npairs, int* abort_flag) {
   const int lane = threadIdx.x & 63, c8 = lane & 7, pq = c8 >> 2, x = c8 & 3, rep = lane >> 3;
+  constexpr int H2 = G::P_SUMS2 - G::P_SUMS;  // from a sum of the first T wave to the same sum of the second
   const int cl = (grp0 + pq) * 4 + x;
   const bool inrange = pq < npairs && cl < prm.C;
   double* const pr = quad + (size_t)(pq < npairs ? pq : 0) * G::PAIR_DOUBLES;  // (lanes without a pair look at pair 0 and do nothing)
   const Cmd* const cmdbuf = reinterpret_cast<const Cmd*>(pr + G::P_CMD);
   RMsg* const msgbuf = reinterpret_cast<RMsg*>(pr + G::P_MSG);
-  const lds_vu32* const seqT = lds_words(pr + G::P_SEQ);
+  const lds_vu32* const seqT = lds_words(pr + G::P_SEQ) + (HALVES ? (rep & 1) : 0);
   lds_vu32* const seqQ = lds_words(quad + G::P_SEQ);  // [4]: R ticks finished, [6]: over
   RetireBook bk;
   bk.init(prm.chain0 + (uint32_t)cl, inrange, prm.numIter);
@@ -603,9 +634,13 @@ __device__ __forceinline__ void fast4_r_wave(const Params& prm, double* quad, co
     const bool haschk = retiring && ((cn & 1) != 0 || cn == (1 << bk.i) - 1);  // odd leaves close sub-trees, the last leaf the orbit
     const unsigned long long vote = __ballot(haschk) | (__ballot((c.op & OP_NEWITER) != 0) ? 1ull << 63 : 0ull);  // (one branch for both)
     io.lp = sp[x]; io.ke = sp[4 + x];
+    if (HALVES) { io.lp += sp[H2 + x]; io.ke += sp[H2 + 4 + x]; }
     io.fire = 0u;
     if (vote) {
-      if (vote >> 63) { io.keinit = sp[16 * (G::NB - 1) + x]; io.gen = sp[16 * (G::NB - 1) + 4 + x]; }
+      if (vote >> 63) {
+        io.keinit = sp[16 * (G::NB - 1) + x]; io.gen = sp[16 * (G::NB - 1) + 4 + x];
+        if (HALVES) { io.keinit += sp[H2 + 16 * (G::NB - 1) + x]; io.gen += sp[H2 + 16 * (G::NB - 1) + 4 + x]; }
+      }
       if (vote << 1) {  // verdict of check level j (wn_fast.h fire_of) by replica j & 7, then OR over the replicas of the chain
         uint32_t f = 0u;
 #pragma unroll
@@ -613,7 +648,8 @@ __device__ __forceinline__ void fast4_r_wave(const Params& prm, double* quad, co
           const int j = rep + 8 * pass;
           const int jl = j <= G::MP ? j : G::MP;
           const double* dp = sp + (jl == 0 ? 8 : 16 * ((jl + 1) >> 1) + ((jl & 1) ? 0 : 8)) + x;
-          const double d1 = dp[0], d2 = dp[4];
+          double d1 = dp[0], d2 = dp[4];
+          if (HALVES) { d1 += dp[H2]; d2 += dp[H2 + 4]; }
           if (retiring && j <= G::MP && need_check(bk.i, cn, j)) {
             const double xi = (double)bk.xi;
             if ((xi * d1 < 0.0) || (xi * d2 < 0.0)) f |= 1u << j;
@@ -641,7 +677,7 @@ __device__ __forceinline__ void fast4_r_wave(const Params& prm, double* quad, co
   if (TRACE && prm.trace_n && inrange && rep == 0) prm.trace_n[cl] = io.ntrace;
 }
 
-template <class G, bool TRACE>
+template <class G, bool TRACE, bool HALVES = false>
 __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, const int grp0, const int npairs, int* abort_flag) {
   const int lane = threadIdx.x & 63, c8 = lane & 7, pq = c8 >> 2, x = c8 & 3, rep = lane >> 3;
   const int cl = (grp0 + pq) * 4 + x;
@@ -747,9 +783,11 @@ __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, co
     {
       const bool we = inrange && bk.wants_early(t + 1u, m);
       if (__any(we)) {
-        if (!seq_wait2(lds_words(pr + G::P_SEQ), t, seqQ + 6)) { if (lane == 0) atomicExch(abort_flag, 1); break; }  // the T wave has finished tick t-1
+        if (!seq_wait2(lds_words(pr + G::P_SEQ) + (HALVES ? (rep & 1) : 0), t, seqQ + 6)) { if (lane == 0) atomicExch(abort_flag, 1); break; }  // the T wave(s) finished tick t-1
         const double* spe = pr + G::P_SUMS + (t3 == 0 ? 2 : t3 - 1) * (G::NB * 16);                                  // slot (t - 1) % 3
-        const double elp = *(const lds_vf64*)(spe + x), eke = *(const lds_vf64*)(spe + 4 + x), eh0 = *(const lds_vf64*)(pr + G::P_H0 + x);
+        double elp = *(const lds_vf64*)(spe + x), eke = *(const lds_vf64*)(spe + 4 + x);
+        if (HALVES) { elp += *(const lds_vf64*)(spe + (G::P_SUMS2 - G::P_SUMS) + x); eke += *(const lds_vf64*)(spe + (G::P_SUMS2 - G::P_SUMS) + 4 + x); }
+        const double eh0 = *(const lds_vf64*)(pr + G::P_H0 + x);
         early = we && IssueBook::early_certain(prm, elp, eke, eh0);
       }
     }
@@ -809,7 +847,7 @@ __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, co
   WN4_STAMP_OUT(prm)
 }
 
-template <int NS, bool TAIL, bool TRACE, bool DENSE>
+template <int NS, bool TAIL, bool TRACE, bool DENSE, bool HALVES = false>
 __global__ __launch_bounds__(512) void wn_fast4_kernel(Params prm, int* abort_flag, int pairs) {
   using G = Fast4Geom<NS, TAIL, DENSE>;
   extern __shared__ double lds[];
@@ -831,7 +869,7 @@ __global__ __launch_bounds__(512) void wn_fast4_kernel(Params prm, int* abort_fl
     lds[G::OFF_A + dst] = (row < D && col < D) ? -prm.tpar[(size_t)row * D + col] : 0.0;
   }
   // LDS keeps what the previous kernel on this CU left there: every control area starts from zero
-  for (int idx = threadIdx.x; idx < pairs * G::PAIR_DOUBLES; idx += blockDim.x) lds[G::OFF_PAIR + idx] = 0.0;
+  for (int idx = threadIdx.x; idx < (HALVES ? G::PAIR_DOUBLES_H : pairs * G::PAIR_DOUBLES); idx += blockDim.x) lds[G::OFF_PAIR + idx] = 0.0;
   __syncthreads();
   // tick 0 is not commanded by anybody: every chain loads q0 (the R wave reads the record when it retires the tick)
   for (int idx = threadIdx.x; idx < pairs * 4; idx += blockDim.x) {
@@ -843,6 +881,14 @@ __global__ __launch_bounds__(512) void wn_fast4_kernel(Params prm, int* abort_fl
   // Waves: quads = ceil(pairs / 2) bookkeeper pairs (R, I) first, then the T waves.  With four pairs: R0 I0 R1 I1 T0 T1 T2 T3, and waves
   // w, w + 4 share a SIMD (speed only): every SIMD runs one T wave and one half of a bookkeeper, which serves the quad's two T waves.
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if constexpr (HALVES) {  // one group per workgroup: R I Ta Tb, a SIMD each
+    double* pr = lds + G::OFF_PAIR;
+    if (wave == 0) fast4_r_wave<G, TRACE, true>(prm, pr, (int)blockIdx.x, 1, abort_flag);
+    else if (wave == 1) fast4_i_wave<G, TRACE, true>(prm, pr, (int)blockIdx.x, 1, abort_flag);
+    else if (wave == 2) fast4_t_wave<G, TRACE, 1>(prm, lds, pr, (int)blockIdx.x, abort_flag);
+    else fast4_t_wave<G, TRACE, 2>(prm, lds, pr, (int)blockIdx.x, abort_flag);
+    return;
+  }
   const int quads = (pairs + 1) >> 1;
 #if defined(WN4_TFIRST)  // diagnostic: the T waves are the older ones
   const bool is_t = wave < pairs;
@@ -893,9 +939,25 @@ template <int NS, bool TAIL, bool DENSE>
 static hipError_t fast4_go(const Params& prm, int* abort_flag, hipStream_t st) {
   using G = Fast4Geom<NS, TAIL, DENSE>;
   const int pairs = fast4_pairs(prm.C), groups = (prm.C + 3) / 4;
+  hipError_t r;
+  // fewer groups than two per CU (BASELINE configs[1]'s literal 1024 chains = 256 groups): the group's vectors on TWO T waves (halves), so
+  // that a CU's four SIMDs run R, I and two half-tick T waves instead of R, I, one T wave and nothing
+  if constexpr (DENSE && NS == 7) if (pairs == 1 && !getenv("WN_FAST4_WHOLE")) {
+    dim3 grid(groups), block(256);
+    const size_t shm = G::lds_bytes_halves();
+    if (prm.trace_n) {
+      r = hipFuncSetAttribute((const void*)wn_fast4_kernel<NS, TAIL, true, DENSE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      if (r != hipSuccess) return r;
+      hipLaunchKernelGGL((wn_fast4_kernel<NS, TAIL, true, DENSE, true>), grid, block, shm, st, prm, abort_flag, 1);
+    } else {
+      r = hipFuncSetAttribute((const void*)wn_fast4_kernel<NS, TAIL, false, DENSE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      if (r != hipSuccess) return r;
+      hipLaunchKernelGGL((wn_fast4_kernel<NS, TAIL, false, DENSE, true>), grid, block, shm, st, prm, abort_flag, 1);
+    }
+    return hipGetLastError();
+  }
   dim3 grid((groups + pairs - 1) / pairs), block(64 * (pairs + 2 * ((pairs + 1) / 2)));
   const size_t shm = G::lds_bytes(pairs);
-  hipError_t r;
   if (prm.trace_n) {
     r = hipFuncSetAttribute((const void*)wn_fast4_kernel<NS, TAIL, true, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (r != hipSuccess) return r;
