@@ -762,7 +762,7 @@ int wn_run(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, do
     if (strstr(e->kc.name, "wn_fast4_kernel")) {  // rows: up to 8 waves per workgroup (T waves 0..pairs-1, then the B waves)
       const int pairs = fast4_pairs(p.C);
       const size_t groups = ((size_t)(p.C + 3) / 4 + pairs - 1) / pairs;
-      for (int w = 0; w < pairs + 2 * ((pairs + 1) / 2); ++w) {
+      for (int w = 0; w < pairs + 2 * ((pairs + 1) / 2) + (pairs == 1 ? 1 : 0); ++w) {  // (+1: the second T wave of the halves mode)
         double a[8] = {0};
         for (size_t gI = 0; gI < groups; ++gI) for (int k = 0; k < 8; ++k) a[k] += (double)h[(gI * 8 + w) * 16 + k];
         if (a[6] <= 0) continue;

@@ -244,14 +244,18 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     uint64_t cw = 0;
     double chs = 0.0;
     if (t != 0) cmd_read(rec, cw, chs);
-    d2_t fa[4][NP];
+    // fragments in flight: 3 k-steps ahead (six MFMAs = 96 cycles each: an LDS round trip is covered); a half wave issues three MFMAs
+    // per k-step and has the register file of a SIMD to itself: 6 ahead, and only the pairs of its own row sets
+    constexpr int AHEAD = HALF ? 6 : 3, NF = HALF ? 8 : 4, QAHEAD = HALF ? 4 : 2, NQ = HALF ? 8 : 3;
+    constexpr int P0 = R0 >> 1, P1 = (R1 + 1) >> 1;
+    d2_t fa[NF][NP];
     auto load_k = [&](int kap, d2_t* f) {
 #pragma unroll
-      for (int j = 0; j < NP; ++j) f[j] = *reinterpret_cast<const d2_t*>(img + (kap * NP + j) * 128);
+      for (int j = P0; j < P1; ++j) f[j] = *reinterpret_cast<const d2_t*>(img + (kap * NP + j) * 128);
     };
     if (G::DENSE) {
 #pragma unroll
-      for (int k0 = 0; k0 < 3; ++k0) if (k0 < NK) load_k(k0, fa[k0]);
+      for (int k0 = 0; k0 < AHEAD; ++k0) if (k0 < NK) load_k(k0, fa[k0]);
     }
     d2_t fx[(NS - 1) / 2 > 0 ? (NS - 1) / 2 : 1];
     double ftail = 0.0;
@@ -400,15 +404,15 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
       double accx = 0.0, gx = 0.0;
       double acc[NSR];  // (set by the first k-step, whose accumulator operand is the literal 0: no register zeroing)
       const double* const stl = stage + lane;  // a register set of the PARTNER, in its own layout (tail rows: K split over the register sets)
-      double qks[3];  // the B operands of three k-steps in flight / in use
+      double qks[NQ];  // the B operands of the k-steps in flight / in use
 #pragma unroll
-      for (int k0 = 0; k0 < 2; ++k0) if (k0 < NK) qks[k0] = st0[(k0 >> 2) * 64 + 4 * (k0 & 3)];
+      for (int k0 = 0; k0 < QAHEAD; ++k0) if (k0 < NK) qks[k0] = st0[(k0 >> 2) * 64 + 4 * (k0 & 3)];
 #pragma unroll
       for (int kap = 0; kap < NK; ++kap) {
-        if (kap + 3 < NK) load_k(kap + 3, fa[(kap + 3) & 3]);
-        if (kap + 2 < NK) qks[(kap + 2) % 3] = st0[((kap + 2) >> 2) * 64 + 4 * ((kap + 2) & 3)];
-        const double qk = qks[kap % 3];
-        const d2_t* f = fa[kap & 3];
+        if (kap + AHEAD < NK) load_k(kap + AHEAD, fa[(kap + AHEAD) % NF]);
+        if (kap + QAHEAD < NK) qks[(kap + QAHEAD) % NQ] = st0[((kap + QAHEAD) >> 2) * 64 + 4 * ((kap + QAHEAD) & 3)];
+        const double qk = qks[kap % NQ];
+        const d2_t* f = fa[kap % NF];
 #pragma unroll
         for (int S = R0; S < R1; ++S) acc[S] = kap == 0 ? mfma4(f[S >> 1][S & 1], qk, 0.0) : mfma4(f[S >> 1][S & 1], qk, acc[S]);
         if (OWN_TAIL) {
@@ -848,7 +852,7 @@ __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, co
 }
 
 template <int NS, bool TAIL, bool TRACE, bool DENSE, bool HALVES = false>
-__global__ __launch_bounds__(512) void wn_fast4_kernel(Params prm, int* abort_flag, int pairs) {
+__global__ __launch_bounds__(HALVES ? 256 : 512) void wn_fast4_kernel(Params prm, int* abort_flag, int pairs) {
   using G = Fast4Geom<NS, TAIL, DENSE>;
   extern __shared__ double lds[];
   // the -A fragment image (see the header): fragment f, lane (r, b, x)
@@ -942,7 +946,7 @@ static hipError_t fast4_go(const Params& prm, int* abort_flag, hipStream_t st) {
   hipError_t r;
   // fewer groups than two per CU (BASELINE configs[1]'s literal 1024 chains = 256 groups): the group's vectors on TWO T waves (halves), so
   // that a CU's four SIMDs run R, I and two half-tick T waves instead of R, I, one T wave and nothing
-  if constexpr (DENSE && NS == 7) if (pairs == 1 && !getenv("WN_FAST4_WHOLE")) {
+  if constexpr (DENSE && NS >= 6) if (pairs == 1 && !getenv("WN_FAST4_WHOLE")) {
     dim3 grid(groups), block(256);
     const size_t shm = G::lds_bytes_halves();
     if (prm.trace_n) {
