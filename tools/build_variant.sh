@@ -15,5 +15,5 @@ for f in wn_capi wn_k_lane wn_k_coop wn_k_fast wn_k_fast4 wn_k_wave wn_k_orbit w
   ( /opt/rocm/bin/hipcc $FL -c $f.hip -o build_$NAME/$f.o ) &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libwalnuts_amd_$NAME.so build_$NAME/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o ../libwalnuts_amd_$NAME.so build_$NAME/*.o
 echo built ../libwalnuts_amd_$NAME.so

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/walnuts_amd.h"
@@ -282,7 +283,12 @@ struct wn_engine {
   bool have_kc = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int* h_poll = nullptr;          // pinned host words the split-mode loop polls the finished-chain counter through
-  hipEvent_t ev_poll[2] = {nullptr, nullptr};
+  hipEvent_t ev_poll[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [part][batch parity]
+  hipStream_t sp_side[3] = {nullptr, nullptr, nullptr};  // split mode: the streams of parts 1..3
+  int* sp_done_side[3] = {nullptr, nullptr, nullptr};     // ... their finished-chain counters and pinned poll words: allocations of their own
+  int* h_poll_side[3] = {nullptr, nullptr, nullptr};      // (copies on two streams that touch one allocation are ordered by the runtime: the parts ran one after the other)
+  hipEvent_t sp_join[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t sp_fork1 = nullptr;
   hipStream_t sp_main = nullptr;  // split mode: stands in for the (uncapturable) legacy default stream
   hipEvent_t sp_fork0 = nullptr;
   int* kabort = nullptr;  // device flag: a kernel's bounded loop gave up (internal error)
@@ -390,6 +396,11 @@ int wn_destroy(wn_engine* e) {
   if (e->h_poll) hipHostFree(e->h_poll);
   for (hipEvent_t ev : e->ev_poll) if (ev) hipEventDestroy(ev);
   if (e->sp_main) hipStreamDestroy(e->sp_main);
+  for (hipStream_t ss : e->sp_side) if (ss) hipStreamDestroy(ss);
+  for (int* d : e->sp_done_side) if (d) hipFree(d);
+  for (int* h : e->h_poll_side) if (h) hipHostFree(h);
+  for (hipEvent_t ev : e->sp_join) if (ev) hipEventDestroy(ev);
+  if (e->sp_fork1) hipEventDestroy(e->sp_fork1);
   if (e->sp_fork0) hipEventDestroy(e->sp_fork0);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -553,6 +564,10 @@ static void fill_params(const wn_engine* e, Params* p) {
 // split mode with the built-in dense-Gaussian gradient: begin, then {batched -A q, one tick of every
 // chain} until every chain has finished.  The host polls the finished-chain counter once per batch
 // of ticks; a launch whose chains have all finished is a few microseconds of early exits.
+// the finished-chain counter goes to its pinned poll word by a one-thread kernel: a hipMemcpyAsync of four bytes held the HOST until
+// the stream had drained (the kernel trace of a two-part run showed the parts taking turns, batch by batch)
+__global__ void wn_poll_word_kernel(const int* src, int* dst) { *dst = *src; }
+
 static int run_split_dense(wn_engine* e, Params p, hipStream_t st, int adapt, bool warm) {
   if (p.mode != MODE_SAMPLE) { e->err = "wn_integrator_step is not available in split mode"; return WN_E_UNSUPPORTED; }
   if (st == nullptr) {
@@ -567,17 +582,76 @@ static int run_split_dense(wn_engine* e, Params p, hipStream_t st, int adapt, bo
     HIPCHK(e, hipStreamWaitEvent(e->sp_main, e->sp_fork0, 0));
     st = e->sp_main;
   }
-  p.xq = e->xq; p.xg = e->xg; p.xlp = nullptr; p.sp_done = e->sp_done;
+  // PARTS (opt-in: WN_SPLIT_PARTS=2 [WN_SPLIT_KS=1|2]; measured in round 4).  The chains are independent, so the run
+  // can be cut into sub-batches, each with its own stream, exchange rows, workspace, finished-chain counter and host thread, and
+  // the chain kernel of one (HBM-bound) can run while the other is inside its gradient GEMM (matrix-pipe-bound).  Two parts with
+  // 64 x 64 tiles (128 workgroups per GEMM, the two GEMMs side by side): +2.4 %, bit-identical draws -- each part's own
+  // GEMM -> chain kernel -> GEMM sequence is as long as before and half the CUs idle during its chain kernel.  Two parts whose GEMMs
+  // each fill the chip (k of a tile split over two workgroups that ADD into rows of xg the chain kernel leaves zeroed: KS = 2,
+  // Params::xzero): -24 % -- the two GEMMs interleave instead of alternating (30 + 55 us) and a chain kernel that shares SIMDs with
+  // FP64 MFMA waves takes 40 us instead of 13, at any s_setprio.  The default stays one part.
+  int NP = 1;
+  {
+    static const int parts_env = getenv("WN_SPLIT_PARTS") ? atoi(getenv("WN_SPLIT_PARTS")) : 0;
+    int want = parts_env > 0 ? parts_env : 1;
+#if defined(WN_STAMPS) || defined(WN_SPAN)
+    want = 1;  // (the diagnostic rows are indexed by the local chain)
+#endif
+    const bool plain = !warm && !p.trace && !p.trace_n && !p.omin && !p.omax;
+    while (want > 1 && !(plain && p.C % (64 * want) == 0 && want <= 4)) want >>= 1;
+    NP = want < 1 ? 1 : want;
+  }
+  const int Cp = p.C / NP;
+  static const int ks_env = getenv("WN_SPLIT_KS") ? atoi(getenv("WN_SPLIT_KS")) : 0;
+  const int KS = NP > 1 && ks_env == 2 ? 2 : 1;
+  struct Part { Params p; hipStream_t st; hipGraph_t graph; hipGraphExec_t gexec; int* done_dev; int* h_poll; const double* xq; double* xg; };
+  Part part[4];
+  for (int k = 0; k < NP; ++k) {
+    Part& q = part[k];
+    q.graph = nullptr; q.gexec = nullptr;
+    q.st = st;
+    if (k > 0) {
+      if (!e->sp_side[k - 1]) {
+        HIPCHK(e, hipStreamCreateWithFlags(&e->sp_side[k - 1], hipStreamNonBlocking));
+        HIPCHK(e, hipEventCreateWithFlags(&e->sp_join[k - 1], hipEventDisableTiming));
+        HIPALLOC(e, e->sp_done_side[k - 1], 64);
+        HIPCHK(e, hipHostMalloc((void**)&e->h_poll_side[k - 1], 2 * sizeof(int), hipHostMallocDefault));
+      }
+      q.st = e->sp_side[k - 1];
+    }
+    q.done_dev = k == 0 ? e->sp_done : e->sp_done_side[k - 1];
+    q.h_poll = nullptr;
+    q.p = p;
+    const size_t c0 = (size_t)k * Cp;
+    q.p.C = Cp;
+    q.p.chain0 = p.chain0 + (uint32_t)c0;
+    q.p.q0 = p.q0 + c0 * p.D;
+    q.p.samples = p.samples + c0 * (size_t)(p.numIter + 1) * p.dg;
+    q.p.diag = p.diag + c0 * (size_t)p.numIter * NDIAG;
+    q.p.work = p.work + (size_t)k * kernel_work_doubles(e->kc, Cp, p.M);  // (the workspace is linear in the number of chains)
+    q.xq = e->xq + c0 * e->DP; q.xg = e->xg + c0 * e->DP;
+    q.p.xq = const_cast<double*>(q.xq); q.p.xg = q.xg; q.p.xlp = nullptr; q.p.sp_done = q.done_dev; q.p.xzero = KS > 1;
+  }
+  const int Cpad_p = NP == 1 ? e->Cpad : Cp;
   HIPCHK(e, hipMemsetAsync(e->sp_done, 0, 64, st));
-  hipError_t r = launch_split_begin(e->kc, adapt, warm, p, st);
+  if (KS > 1) HIPCHK(e, hipMemsetAsync(e->xg, 0, (size_t)e->Cpad * e->DP * sizeof(double), st));
+  if (NP > 1) {  // the side streams start behind everything queued so far
+    if (!e->sp_fork1) HIPCHK(e, hipEventCreateWithFlags(&e->sp_fork1, hipEventDisableTiming));
+    HIPCHK(e, hipEventRecord(e->sp_fork1, st));
+    for (int k = 1; k < NP; ++k) {
+      HIPCHK(e, hipStreamWaitEvent(part[k].st, e->sp_fork1, 0));
+      HIPCHK(e, hipMemsetAsync(part[k].done_dev, 0, 64, part[k].st));
+    }
+  }
+  hipError_t r = hipSuccess;
+  for (int k = 0; k < NP && r == hipSuccess; ++k) r = launch_split_begin(e->kc, adapt, warm, part[k].p, part[k].st);
   if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
-  int done = 0;
   e->sp_ticks = 0;
 #if defined(WN_STAMPS) || defined(WN_SPAN)
   static unsigned long long* sbuf = nullptr;
   if (!sbuf) hipMalloc((void**)&sbuf, (size_t)p.C * 16 * sizeof(unsigned long long));
   hipMemset(sbuf, 0, (size_t)p.C * 16 * sizeof(unsigned long long));
-  p.stamps = sbuf;
+  p.stamps = sbuf; part[0].p.stamps = sbuf;
 #endif
   // every chain needs at most numIter * (2^M - 1) macro steps of at most 3 * 2^(maxC+2) gradient
   // evaluations (forward search, R2P re-integration, backward search; x3 Yoshida, x2 FlowD)
@@ -589,53 +663,75 @@ static int run_split_dense(wn_engine* e, Params p, hipStream_t st, int adapt, bo
   // when the last chain finishes is a few hundred early exits.
   if (!e->h_poll) {
     HIPCHK(e, hipHostMalloc((void**)&e->h_poll, 2 * sizeof(int), hipHostMallocDefault));
-    HIPCHK(e, hipEventCreateWithFlags(&e->ev_poll[0], hipEventDisableTiming));
-    HIPCHK(e, hipEventCreateWithFlags(&e->ev_poll[1], hipEventDisableTiming));
+    for (hipEvent_t& ev : e->ev_poll) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   }
-  // One batch = 64 ticks = 128 launches.  By default the batch is captured ONCE per run into a hipGraph and replayed: the GPU
-  // then paces the ticks itself, whatever the host thread is doing (round 2's driver-run number for this path, 1.29e7 steps/s
+  // One batch = 64 ticks = 128 launches.  By default the batch is captured ONCE per run (and per part) into a hipGraph and replayed:
+  // the GPU then paces the ticks itself, whatever the host thread is doing (round 2's driver-run number for this path, 1.29e7 steps/s
   // against 1.9e7 in the builder's runs, was eager launches falling behind on a busy host).  WN_SPLIT_EAGER=1: eager launches.
   static const bool eager = getenv("WN_SPLIT_EAGER") != nullptr;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t gexec = nullptr;
-  auto enqueue_batch = [&]() -> hipError_t {
+  auto grad = [&](const Part& q) { return launch_dense_grad(e->apad, q.xq, q.xg, e->DP, p.D, Cpad_p, q.done_dev, q.p.C, q.st, NP > 1 ? (KS > 1 ? 42 : 4) : 0); };
+  auto enqueue_batch = [&](const Part& q) -> hipError_t {
     hipError_t rr = hipSuccess;
     for (int k = 0; k < 64 && rr == hipSuccess; ++k) {
-      rr = launch_dense_grad(e->apad, e->xq, e->xg, e->DP, p.D, e->Cpad, e->sp_done, p.C, st);
-      if (rr == hipSuccess) rr = launch_split_tick(e->kc, adapt, warm, p, st);
+      rr = grad(q);
+      if (rr == hipSuccess) rr = launch_split_tick(e->kc, adapt, warm, q.p, q.st);
     }
     return rr;
   };
-  if (!eager) {
-    hipError_t rg = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-    if (rg == hipSuccess) {
-      const hipError_t rl = enqueue_batch();
-      rg = hipStreamEndCapture(st, &graph);
-      if (rg == hipSuccess && rl != hipSuccess) rg = rl;
+  // Each part is driven by a host thread of its own (part 0 by the caller's): one thread queues about 80 000 kernels per second,
+  // graph replay or not, which is what ONE part consumes -- with a single thread the parts took turns batch by batch (kernel trace).
+  const int device = e->cfg.device;
+  auto drive = [&, device](int k, std::string* err) -> int {
+    Part& q = part[k];
+    if (hipSetDevice(device) != hipSuccess) { *err = "hipSetDevice"; return WN_E_HIP; }
+    struct Guard { Part& q; ~Guard() { if (q.gexec) hipGraphExecDestroy(q.gexec); if (q.graph) hipGraphDestroy(q.graph); q.gexec = nullptr; q.graph = nullptr; } } guard{q};
+    if (!eager) {
+      hipError_t rg = hipStreamBeginCapture(q.st, hipStreamCaptureModeThreadLocal);
+      if (rg == hipSuccess) {
+        const hipError_t rl = enqueue_batch(q);
+        rg = hipStreamEndCapture(q.st, &q.graph);
+        if (rg == hipSuccess && rl != hipSuccess) rg = rl;
+      }
+      if (rg == hipSuccess) rg = hipGraphInstantiate(&q.gexec, q.graph, nullptr, nullptr, 0);
+      if (getenv("WN_SPLIT_DEBUG")) fprintf(stderr, "[wn split] part %d of %d: hipGraph of 64 ticks: %s\n", k, NP, rg == hipSuccess ? "captured" : hipGetErrorString(rg));
+      if (rg != hipSuccess) {  // (fall back to eager launches)
+        (void)hipGetLastError();
+        if (q.gexec) { hipGraphExecDestroy(q.gexec); q.gexec = nullptr; }
+        if (q.graph) { hipGraphDestroy(q.graph); q.graph = nullptr; }
+      }
     }
-    if (rg == hipSuccess) rg = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
-    if (getenv("WN_SPLIT_DEBUG")) fprintf(stderr, "[wn split] hipGraph of 64 ticks: %s\n", rg == hipSuccess ? "captured" : hipGetErrorString(rg));
-    if (rg != hipSuccess) {  // (fall back to eager launches)
-      (void)hipGetLastError();
-      if (gexec) { hipGraphExecDestroy(gexec); gexec = nullptr; }
-      if (graph) { hipGraphDestroy(graph); graph = nullptr; }
+    int* const hp = k == 0 ? e->h_poll : e->h_poll_side[k - 1];
+    double ticks = 0.0;
+    for (int batch = 0;; ++batch) {
+      if (ticks > cap) { *err = "split run exceeded its tick bound (internal error)"; return WN_E_HIP; }
+      hipError_t rr = q.gexec ? hipGraphLaunch(q.gexec, q.st) : enqueue_batch(q);
+      if (rr == hipSuccess) { hipLaunchKernelGGL(wn_poll_word_kernel, dim3(1), dim3(1), 0, q.st, q.done_dev, hp + (batch & 1)); rr = hipGetLastError(); }
+      if (rr == hipSuccess) rr = hipEventRecord(e->ev_poll[2 * k + (batch & 1)], q.st);
+      if (rr != hipSuccess) { *err = std::string("kernel launch: ") + hipGetErrorString(rr); return WN_E_HIP; }
+      ticks += 64;
+      if (k == 0) e->sp_ticks += 64;
+      if (batch >= 1) {
+        rr = hipEventSynchronize(e->ev_poll[2 * k + ((batch - 1) & 1)]);
+        if (rr != hipSuccess) { *err = std::string("hipEventSynchronize: ") + hipGetErrorString(rr); return WN_E_HIP; }
+        if (hp[(batch - 1) & 1] >= q.p.C) break;
+      }
     }
+    return WN_OK;
+  };
+  {
+    std::string errs[4];
+    int rcs[4] = {0, 0, 0, 0};
+    std::vector<std::thread> th;
+    for (int k = 1; k < NP; ++k) th.emplace_back([&, k]() { rcs[k] = drive(k, &errs[k]); });
+    rcs[0] = drive(0, &errs[0]);
+    for (std::thread& t : th) t.join();
+    for (int k = 0; k < NP; ++k) if (rcs[k]) { e->err = errs[k]; hipDeviceSynchronize(); return rcs[k]; }
   }
-  struct GraphGuard { hipGraph_t& g; hipGraphExec_t& x; ~GraphGuard() { if (x) hipGraphExecDestroy(x); if (g) hipGraphDestroy(g); } } guard{graph, gexec};
-  for (int batch = 0;; ++batch) {
-    if ((double)e->sp_ticks > cap) { e->err = "split run exceeded its tick bound (internal error)"; return WN_E_HIP; }
-    r = gexec ? hipGraphLaunch(gexec, st) : enqueue_batch();
-    if (r != hipSuccess) { e->err = std::string("kernel launch: ") + hipGetErrorString(r); return WN_E_HIP; }
-    e->sp_ticks += 64;
-    HIPCHK(e, hipMemcpyAsync(e->h_poll + (batch & 1), e->sp_done, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(e, hipEventRecord(e->ev_poll[batch & 1], st));
-    if (batch >= 1) {
-      HIPCHK(e, hipEventSynchronize(e->ev_poll[(batch - 1) & 1]));
-      done = e->h_poll[(batch - 1) & 1];
-      if (done >= p.C) break;
-    }
+  for (int k = 1; k < NP; ++k) {  // results are complete when wn_run returns, and the caller's stream is behind every part
+    HIPCHK(e, hipEventRecord(e->sp_join[k - 1], part[k].st));
+    HIPCHK(e, hipStreamWaitEvent(st, e->sp_join[k - 1], 0));
   }
-  HIPCHK(e, hipStreamSynchronize(st));  // results are complete when wn_run returns, as before
+  HIPCHK(e, hipStreamSynchronize(st));
 #if defined(WN_STAMPS) || defined(WN_SPAN)
   {
     std::vector<unsigned long long> h((size_t)p.C * 16);

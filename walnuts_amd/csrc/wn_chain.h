@@ -72,6 +72,7 @@ struct Params {
   double *xq, *xg;
   const double* xlp;
   int* sp_done;
+  int xzero;  // the chain kernel leaves its rows of xg zeroed: the gradient kernel ADDS into them (k split over two workgroups)
   // cluster layout (several workgroups per chain): workgroups per chain, partials, arrival counters, abort flag
   int cl_g;
   double* cl_red;

@@ -248,6 +248,11 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     // per k-step and has the register file of a SIMD to itself: 6 ahead, and only the pairs of its own row sets
     constexpr int AHEAD = HALF ? 6 : 3, NF = HALF ? 8 : 4, QAHEAD = HALF ? 4 : 2, NQ = HALF ? 8 : 3;
     constexpr int P0 = R0 >> 1, P1 = (R1 + 1) >> 1;
+    // halves: a wave's MFMA chain starts with the k-steps whose B operand is its OWN part of the position (its own stage writes, no
+    // hand-off needed) and meets the partner's part IWAIT k-steps later -- by then the partner's stage is there and nobody waits
+    constexpr int KB = HALF == 2 ? 4 * S0 : 0;                                      // the second wave starts at its first own k-step
+    constexpr int IWAIT = HALF == 0 ? -1 : (HALF == 1 ? 4 * S1 : NK - KB) - QAHEAD;  // iteration whose B-operand prefetch is the first of the partner's
+    auto kmap = [](int i) { return HALF == 2 ? (i + KB) % NK : i; };
     d2_t fa[NF][NP];
     auto load_k = [&](int kap, d2_t* f) {
 #pragma unroll
@@ -255,7 +260,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     };
     if (G::DENSE) {
 #pragma unroll
-      for (int k0 = 0; k0 < AHEAD; ++k0) if (k0 < NK) load_k(k0, fa[k0]);
+      for (int k0 = 0; k0 < AHEAD; ++k0) if (k0 < NK) load_k(kmap(k0), fa[k0]);
     }
     d2_t fx[(NS - 1) / 2 > 0 ? (NS - 1) / 2 : 1];
     double ftail = 0.0;
@@ -389,39 +394,51 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     double* const stage = HALF == 0 ? stage0 : (PAR ? pr + G::P_STAGE2 : stage0);  // (halves: two buffers -- the partner may still read tick t-1's)
 #pragma unroll
     for (int s = S0; s < S1; ++s) stage[s * 64 + lane] = qn[s];
-    if (HALF != 0) {  // the partner's coordinates are the other half of every B operand: wait until it has staged tick t
-      if (lane == 0) xseq[HALF - 1] = t + 1u;  // (same wave, in order: behind the stage writes)
-      uint32_t spins = 0;
-      while ((int32_t)(xseq[2 - HALF] - (t + 1u)) < 0) {
-        if (++spins > (1u << 24)) { if (lane == 0) atomicExch(abort_flag, 1); return false; }
-      }
-      asm volatile("" ::: "memory");
-    }
+    if (HALF != 0 && lane == 0) xseq[HALF - 1] = t + 1u;  // (same wave, in order: behind the stage writes; the partner waits for it IWAIT k-steps into its chain)
     WN4_STAMP(0);
     // ---- G = -A Q ----
     {
       const double* const st0 = stage + 16 * r + x;  // + s * 64 + 4 * b'
-      double accx = 0.0, gx = 0.0;
+      double accx = 0.0, gx = 0.0, qlast = 0.0;
       double acc[NSR];  // (set by the first k-step, whose accumulator operand is the literal 0: no register zeroing)
       const double* const stl = stage + lane;  // a register set of the PARTNER, in its own layout (tail rows: K split over the register sets)
       double qks[NQ];  // the B operands of the k-steps in flight / in use
+      // the tail rows' K split over the register sets: own sets first, the partner's once its stage is known to be there
+      constexpr int NOWN_T = HALF == 2 ? (NS - 1) - S0 : NS - 1;
+      auto tail_iter = [](int j) { return (HALF == 2 && j >= NOWN_T) ? IWAIT + (j - NOWN_T) : j; };
+      auto tail_reg = [](int j) { return HALF == 2 ? (j < NOWN_T ? S0 + j : j - NOWN_T) : j; };
+      constexpr int ISUM = HALF == 2 ? IWAIT + (NS - 2 - NOWN_T) + 3 : NS + 1;  // blocks_sum: behind the last of those MFMAs
+      static_assert(!OWN_TAIL || ISUM < NK - 1, "the tail's block sum must precede its last MFMA");
 #pragma unroll
-      for (int k0 = 0; k0 < QAHEAD; ++k0) if (k0 < NK) qks[k0] = st0[(k0 >> 2) * 64 + 4 * (k0 & 3)];
+      for (int k0 = 0; k0 < QAHEAD; ++k0) if (k0 < NK) qks[k0] = st0[(kmap(k0) >> 2) * 64 + 4 * (kmap(k0) & 3)];
 #pragma unroll
-      for (int kap = 0; kap < NK; ++kap) {
-        if (kap + AHEAD < NK) load_k(kap + AHEAD, fa[(kap + AHEAD) % NF]);
-        if (kap + QAHEAD < NK) qks[(kap + QAHEAD) % NQ] = st0[((kap + QAHEAD) >> 2) * 64 + 4 * ((kap + QAHEAD) & 3)];
-        const double qk = qks[kap % NQ];
-        const d2_t* f = fa[kap % NF];
-#pragma unroll
-        for (int S = R0; S < R1; ++S) acc[S] = kap == 0 ? mfma4(f[S >> 1][S & 1], qk, 0.0) : mfma4(f[S >> 1][S & 1], qk, acc[S]);
-        if (OWN_TAIL) {
-          if (kap < NS - 1) {
-            const double qx = (kap >= S0 && kap < S1) ? qn[kap] : stl[kap * 64];
-            accx = kap == 0 ? mfma4(fx[0][0], qx, 0.0) : mfma4(fx[kap >> 1][kap & 1], qx, accx);
+      for (int it = 0; it < NK; ++it) {
+        const int kap = kmap(it);
+        if (HALF != 0 && it == IWAIT) {  // from here on the partner's coordinates are read: it must have staged tick t
+          uint32_t spins = 0;
+          while ((int32_t)(xseq[2 - HALF] - (t + 1u)) < 0) {
+            if (++spins > (1u << 24)) { if (lane == 0) atomicExch(abort_flag, 1); return false; }
           }
-          if (kap == NS + 1) gx = blocks_sum(accx);          // (two k-steps behind its last MFMA)
-          if (kap == NK - 1) gx = mfma4(ftail, qk, gx);      // columns 16 (NS-1) .. + 3
+          asm volatile("" ::: "memory");
+        }
+        if (it + AHEAD < NK) load_k(kmap(it + AHEAD), fa[(it + AHEAD) % NF]);
+        if (it + QAHEAD < NK) qks[(it + QAHEAD) % NQ] = st0[(kmap(it + QAHEAD) >> 2) * 64 + 4 * (kmap(it + QAHEAD) & 3)];
+        const double qk = qks[it % NQ];
+        const d2_t* f = fa[it % NF];
+#pragma unroll
+        for (int S = R0; S < R1; ++S) acc[S] = it == 0 ? mfma4(f[S >> 1][S & 1], qk, 0.0) : mfma4(f[S >> 1][S & 1], qk, acc[S]);
+        if (OWN_TAIL) {
+          if (kap == NK - 1) qlast = qk;
+#pragma unroll
+          for (int j = 0; j < NS - 1; ++j) {
+            if (tail_iter(j) == it) {
+              const int sr = tail_reg(j);
+              const double qx = (sr >= S0 && sr < S1) ? qn[sr] : stl[sr * 64];
+              accx = j == 0 ? mfma4(fx[sr >> 1][sr & 1], qx, 0.0) : mfma4(fx[sr >> 1][sr & 1], qx, accx);
+            }
+          }
+          if (it == ISUM) gx = blocks_sum(accx);            // (two k-steps behind its last MFMA)
+          if (it == NK - 1) gx = mfma4(ftail, qlast, gx);   // columns 16 (NS-1) .. + 3
         }
       }
 #pragma unroll

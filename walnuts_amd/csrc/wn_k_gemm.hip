@@ -3,6 +3,7 @@
 // as v_mfma_f64_16x16x4_f64 with M = output index d, N = chain, K = k.  Built with
 // -mllvm -amdgpu-mfma-vgpr-form (Makefile): with accumulators homed in AGPRs the compiler moved all
 // 128 of them through VGPRs on every trip of the k-loop.
+#include <hip/hip_runtime.h>
 #include <stdlib.h>
 
 #include "wn_launch.h"
@@ -32,25 +33,29 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // NJ = 16-chain blocks per tile: 4 (64 x 64 tiles), or 2 (64 x 32 tiles) when 64 x 64 tiles would leave
 // CUs without a workgroup (measured, 1024 chains: D = 1000 44 vs 55 us -- the wider tile's register reuse
 // wins once every CU has one; D = 300 15.6 vs 11.3 us -- 128 wide tiles fill half the chip).
-template <int NJ>
+// KS = 2: two workgroups share a tile, each with half of k, and ADD their halves into xg (which the chain kernel has zeroed:
+// Params::xzero): a sub-batch of half the chains then still has a workgroup for every CU (wn_capi.hip, run_split_dense).  The sum of
+// two numbers does not depend on which arrives first, so the result is as reproducible as the one-workgroup form's.
+template <int NJ, int KS = 1>
 __global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __restrict__ A, const double* __restrict__ xq,
                                                             double* __restrict__ xg, int DP, int Kr, int tiles_d,
                                                             int tiles_c, const int* done, int C) {
   if (*done >= C) return;  // every chain has finished: nothing reads the result
   __shared__ double red[4 * 3 * 4 * NJ * 64];  // [owner wave][partial accumulator of a contributor][lane]
-  const int T = tiles_d * tiles_c, per = (T + 7) / 8;
+  const int T = tiles_d * tiles_c * KS, per = (T + 7) / 8;
   // consecutive blocks go to different XCDs: give each XCD a contiguous range of tiles (same chains,
   // neighbouring rows of A) so its L2 sees each operand row once
-  const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= per || t >= T) return;
+  const int tv = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || tv >= T) return;
+  const int t = tv / KS, ks = tv % KS;
   const int ct = t / tiles_d, dt = t % tiles_d;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int d0 = dt * 64, c0 = ct * 16 * NJ;
   const int r = lane & 15;
   // this wave's k-range [wave*Kq, (wave+1)*Kq): a multiple of 16 long; beyond Kr both operands are zero
-  const int Kq = ((Kr + 3) / 4 + 15) / 16 * 16;
-  const double* ap = A + (size_t)(d0 + r) * DP + wave * Kq + 2 * (lane >> 4);   // + i * 16 rows
-  const double* bp = xq + (size_t)(c0 + r) * DP + wave * Kq + 2 * (lane >> 4);  // + j * 16 rows
+  const int Kq = ((Kr + 4 * KS - 1) / (4 * KS) + 15) / 16 * 16;
+  const double* ap = A + (size_t)(d0 + r) * DP + (ks * 4 + wave) * Kq + 2 * (lane >> 4);   // + i * 16 rows
+  const double* bp = xq + (size_t)(c0 + r) * DP + (ks * 4 + wave) * Kq + 2 * (lane >> 4);  // + j * 16 rows
   const size_t rs = (size_t)16 * DP;
   d4_t acc[4][NJ];
 #pragma unroll
@@ -90,7 +95,8 @@ __global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __rest
           double v = acc[i][j][q];
 #pragma unroll
           for (int sl = 0; sl < 3; ++sl) v += red[((i * 3 + sl) * 4 * NJ + j * 4 + q) * 64 + lane];
-          o[4 * q] = -v;
+          if (KS == 1) o[4 * q] = -v;
+          else unsafeAtomicAdd(o + 4 * q, -v);
         }
       }
     }
@@ -98,12 +104,16 @@ __global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __rest
 }
 
 hipError_t launch_dense_grad(const double* A, const double* xq, double* xg, int DP, int D, int Cpad, const int* done, int C,
-                             hipStream_t st) {
+                             hipStream_t st, int nj) {
   const int Kr = (D + 15) / 16 * 16;
   const int tiles_d = DP / 64;
   static const int narrow_env = getenv("WN_GEMM_NJ") ? atoi(getenv("WN_GEMM_NJ")) : 0;  // diagnostic override
-  const bool narrow = narrow_env ? narrow_env == 2 : (tiles_d * (Cpad / 64) < 256);
-  if (narrow) {
+  // nj = 4: the caller runs several sub-batches side by side and wants one workgroup per CU from each (wn_capi.hip, run_split_dense)
+  const bool narrow = (nj == 2 || nj == 4) ? nj == 2 : narrow_env ? narrow_env == 2 : (tiles_d * (Cpad / 64) < 256);
+  if (nj == 42) {  // 64 x 64 tiles, k split over two workgroups
+    const int tiles_c = Cpad / 64, T = tiles_d * tiles_c * 2, per = (T + 7) / 8;
+    hipLaunchKernelGGL((wn_dense_grad_kernel<4, 2>), dim3(8 * per), dim3(256), 0, st, A, xq, xg, DP, Kr, tiles_d, tiles_c, done, C);
+  } else if (narrow) {
     const int tiles_c = Cpad / 32, T = tiles_d * tiles_c, per = (T + 7) / 8;
     hipLaunchKernelGGL(wn_dense_grad_kernel<2>, dim3(8 * per), dim3(256), 0, st, A, xq, xg, DP, Kr, tiles_d, tiles_c, done, C);
   } else {

@@ -40,6 +40,7 @@ __global__ __launch_bounds__((SplitShape<ADAPT, WARM>::THREADS)) void wn_split_t
 #endif
   const bool was_done = p.sc->sp_stage == 2;
   const bool more = eng.split_tick();
+  if (prm.xzero) p.ext_zero_g();
   const bool first_lane = CPW > 1 ? (threadIdx.x & 63) == 0 : threadIdx.x == 0;
   if (!more && !was_done && first_lane) atomicAdd(prm.sp_done, 1);
 #ifdef WN_SPAN

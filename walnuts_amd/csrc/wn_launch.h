@@ -26,7 +26,7 @@ hipError_t launch_wave(const KernelChoice& kc, int adapt /* 0 fixed, 1 adaptive,
 hipError_t launch_split_begin(const KernelChoice& kc, int adapt /* 0 fixed, 1 adaptive, 2 adaptLeapFrogFlowD */, bool warm, const Params& prm, hipStream_t st);
 hipError_t launch_split_tick(const KernelChoice& kc, int adapt /* 0 fixed, 1 adaptive, 2 adaptLeapFrogFlowD */, bool warm, const Params& prm, hipStream_t st);
 hipError_t launch_dense_grad(const double* A, const double* xq, double* xg, int DP, int D, int Cpad, const int* done, int C,
-                             hipStream_t st);
+                             hipStream_t st, int nj = 0);
 // role-split form of the fixedLeapFrog coop path (wn_k_fast.hip)
 bool fast_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm);
 hipError_t launch_fast(const KernelChoice& kc, const Params& prm, int* abort_flag, hipStream_t st);

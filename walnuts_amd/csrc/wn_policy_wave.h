@@ -787,6 +787,10 @@ struct WavePolicy {
 #pragma unroll
     for (int e = 0; e < NE; ++e) q.x[e] = xq[e * ES];
   }
+  __device__ __forceinline__ void ext_zero_g() const {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) xg[e * ES] = 0.0;
+  }
   // gradient (and log density) of the position sent out by the previous launch
   __device__ __forceinline__ void ext_load_g(Vec& g) const {
 #pragma unroll
