@@ -99,3 +99,39 @@ def test_cfg5_stockwatson_adaptd_256_chains(wa):
         np.testing.assert_array_equal(d[k][:, INT_COLS], o["diagnostics"][:, INT_COLS], err_msg=f"chain {k}")
         close(s[k], o["samples"], what=f"chain {k} draws")
         close(d[k], o["diagnostics"], what=f"chain {k} diagnostics")
+
+
+@pytest.mark.parametrize("D,C", [(1000, 256), (600, 384)])
+def test_split_mode_in_two_parts_is_the_same_run(wa, D, C):
+    """Split mode cut into two sub-batches, each on a stream and a host thread of its own (WN_SPLIT_PARTS=2; opt-in):
+    the chains are independent and keyed by their global index, so the draws are the one-part run's bit for bit; with the k range of
+    a GEMM tile split over two workgroups that add into zeroed rows (WN_SPLIT_KS=2) the gradient's sum is associated differently:
+    integers identical, reals to 1e-9."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_dense_problem
+    IT = 3
+    A, q0 = make_dense_problem(D, 100.0, C, SEED)
+
+    def go(parts, ks):
+        os.environ["WN_SPLIT_PARTS"] = str(parts)
+        os.environ["WN_SPLIT_KS"] = str(ks)
+        try:
+            e = wa.Engine(D, C, integrator=ol.I_FIXED, H0=0.5, M=8, generated=ol.G_IDENTITY).set_target(ol.T_DENSEGAUSS, A)
+            assert "split" in e.kernel_name
+            s, d = e.run(q0, SEED, IT)
+            s = s.cpu().numpy(); d = d.cpu().numpy(); e.close()
+        finally:
+            os.environ.pop("WN_SPLIT_PARTS", None)
+            os.environ.pop("WN_SPLIT_KS", None)
+        return s, d
+
+    s1, d1 = go(1, 1)
+    s2, d2 = go(2, 1)
+    np.testing.assert_array_equal(s2, s1)
+    np.testing.assert_array_equal(d2, d1)
+    s3, d3 = go(2, 2)
+    np.testing.assert_array_equal(d3[:, :, INT_COLS], d1[:, :, INT_COLS])
+    close(s3, s1, rtol=1e-9, atol=1e-10, what="draws, k split over two workgroups")
+    s4, d4 = go(1, 1)  # (and the one-part run after them: the zeroed exchange rows and the side streams leave nothing behind)
+    np.testing.assert_array_equal(s4, s1)

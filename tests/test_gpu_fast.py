@@ -272,3 +272,32 @@ def test_pair_kernel_random_configurations(wa, seed):
                 m = o["ncalls"]
                 assert tn[k] == m, (what, k, tn[k], m)
                 np.testing.assert_array_equal(tr[k, :m][:, [0, 1, 2, 10]], o["trace"][:m][:, [0, 1, 2, 10]], err_msg=what + f" chain {k} trace integers")
+
+
+@pytest.mark.parametrize("D,C", [(100, 1024), (96, 1000), (80, 517), (100, 3)])
+def test_pair_kernel_two_position_waves_per_group(wa, D, C):
+    """Fewer than two groups per CU (BASELINE configs[1] at its literal 1024 chains): a group's register sets are cut over TWO T waves
+    (wn_k_fast4.hip, halves mode).  Against the whole-group form of the same kernel (WN_FAST4_WHOLE=1: the second wave sums its k-steps
+    in another order -- integers identical, reals to 1e-9), against the one-stream kernel and, chain by chain, against the oracle."""
+    A, q0 = dense_problem(D, 1e4, C)
+    kw = dict(H0=0.5, M=10, generated=ol.G_Q0_SUMSQ, chain_offset=0, numIter=10, seed=SEED)
+    s, d, name, ms = run(wa, ol.T_DENSEGAUSS, A, q0, **kw)
+    assert "wn_fast4_kernel" in name, name
+    os.environ["WN_FAST4_WHOLE"] = "1"
+    try:
+        s0, d0, name0, ms0 = run(wa, ol.T_DENSEGAUSS, A, q0, **kw)
+    finally:
+        os.environ.pop("WN_FAST4_WHOLE", None)
+    s1, d1, name1, _ = run(wa, ol.T_DENSEGAUSS, A, q0, legacy=True, **kw)
+    assert "wn_coop_kernel" in name1, name1
+    for ref_d, ref_s, what in ((d0, s0, "whole-group form"), (d1, s1, "one-stream kernel")):
+        for col in INT_DIAG:
+            np.testing.assert_array_equal(d[:, :, col], ref_d[:, :, col], err_msg=f"diag col {col} vs {what}")
+        close(d, ref_d, rtol=1e-9, atol=1e-10, what=f"diagnostics vs {what}")
+        close(s, ref_s, rtol=1e-9, atol=1e-10, what=f"draws vs {what}")
+    for k in sorted({0, C - 1, C // 2, C // 3}):
+        o = ol.walnuts(ol.T_DENSEGAUSS, q0[k], integrator=ol.I_FIXED, tpar=A.ravel(), H0=0.5, numIter=10, M=10, seed=SEED, chain=k,
+                       generated=ol.G_Q0_SUMSQ)
+        np.testing.assert_array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]], err_msg=f"chain {k}")
+        close(s[k], o["samples"], what=f"chain {k}")
+    print(f"two T waves per group {ms:.1f} ms, one {ms0:.1f} ms")

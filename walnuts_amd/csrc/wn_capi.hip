@@ -592,7 +592,7 @@ static int run_split_dense(wn_engine* e, Params p, hipStream_t st, int adapt, bo
   // FP64 MFMA waves takes 40 us instead of 13, at any s_setprio.  The default stays one part.
   int NP = 1;
   {
-    static const int parts_env = getenv("WN_SPLIT_PARTS") ? atoi(getenv("WN_SPLIT_PARTS")) : 0;
+    const int parts_env = getenv("WN_SPLIT_PARTS") ? atoi(getenv("WN_SPLIT_PARTS")) : 0;  // (read per run: tests switch it)
     int want = parts_env > 0 ? parts_env : 1;
 #if defined(WN_STAMPS) || defined(WN_SPAN)
     want = 1;  // (the diagnostic rows are indexed by the local chain)
@@ -602,7 +602,7 @@ static int run_split_dense(wn_engine* e, Params p, hipStream_t st, int adapt, bo
     NP = want < 1 ? 1 : want;
   }
   const int Cp = p.C / NP;
-  static const int ks_env = getenv("WN_SPLIT_KS") ? atoi(getenv("WN_SPLIT_KS")) : 0;
+  const int ks_env = getenv("WN_SPLIT_KS") ? atoi(getenv("WN_SPLIT_KS")) : 0;
   const int KS = NP > 1 && ks_env == 2 ? 2 : 1;
   struct Part { Params p; hipStream_t st; hipGraph_t graph; hipGraphExec_t gexec; int* done_dev; int* h_poll; const double* xq; double* xg; };
   Part part[4];
