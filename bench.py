@@ -165,16 +165,24 @@ def cpu_baselines(specs, budgets):
             try:
                 q0, iters = spec["q0"], spec["iters"]
                 okw = dict(spec["oracle"])
-                s1, t1 = _cpu_worker((spec["target"], spec["tpar"], q0[0], 0, 1, okw))  # calibrate on one chain, one iteration
-                per_iter = max(t1, 1e-5)
-                n_it = int(max(1, min(iters, budget_s / per_iter)))
-                # chains per core: enough of them to fill the budget when a whole run of one chain is shorter than it
-                k = int(max(1, min(budget_s / (n_it * per_iter), (q0.shape[0] + cores - 1) // cores)))
+                # size the sample from a PILOT under full load (one chain per worker, a few iterations): a single chain timed
+                # alone on an idle host ran up to ten times faster than 256 of them side by side, and the "12 s" sample took 84
                 nproc = min(cores, q0.shape[0])
-                nchain = min(q0.shape[0], nproc * k)
+                s1, t1 = _cpu_worker((spec["target"], spec["tpar"], q0[0], 0, 1, okw))
+                it0 = int(max(1, min(iters, 0.25 / max(t1, 1e-5))))
                 t0 = time.perf_counter()
-                res = pool.map(_cpu_worker, [(spec["target"], spec["tpar"], q0[c], c, n_it, okw) for c in range(nchain)], chunksize=1)
+                res = pool.map(_cpu_worker, [(spec["target"], spec["tpar"], q0[c], c, it0, okw) for c in range(nproc)], chunksize=1)
                 wall = time.perf_counter() - t0
+                n_it, nchain = it0, nproc
+                if wall < 0.5 * budget_s:
+                    f = budget_s / max(wall, 1e-3)
+                    n_it = int(max(it0, min(iters, it0 * f)))
+                    f /= n_it / it0
+                    k = int(max(1, min(f, (q0.shape[0] + cores - 1) // cores)))
+                    nchain = min(q0.shape[0], nproc * k)
+                    t0 = time.perf_counter()
+                    res = pool.map(_cpu_worker, [(spec["target"], spec["tpar"], q0[c], c, n_it, okw) for c in range(nchain)], chunksize=1)
+                    wall = time.perf_counter() - t0
                 units = sum(r[0] for r in res)
                 busy = sum(r[1] for r in res)  # summed in-worker seconds: units / busy = the rate of ONE core working alone on its chain
                 C_all = q0.shape[0]
