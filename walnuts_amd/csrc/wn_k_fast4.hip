@@ -223,6 +223,26 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
 #pragma unroll
   for (int s = 0; s < NS; ++s) adiag[s] = (!G::DENSE && coord(s) < D) ? prm.tpar[coord(s)] : 0.0;
 
+  // Halves: a half wave is alone on its SIMD (all 512 registers of a lane are its own) and needs 75 + 7 fragments: they are read from
+  // the image ONCE and stay in registers -- no fragment traffic in the tick at all (the whole-group wave needs 157 and re-reads them
+  // from LDS every tick, three k-steps ahead of their use)
+  constexpr bool RESIDENT = G::DENSE && HALF != 0;
+  constexpr int NOWN = RESIDENT ? R1 - R0 : 1, NKR = RESIDENT ? G::NK : 1;
+  double frag[NKR][NOWN];
+  if constexpr (RESIDENT) {
+    const double* const img0 = lds + G::OFF_A + 2 * lane;
+#pragma unroll
+    for (int k = 0; k < G::NK; ++k)
+#pragma unroll
+      for (int S = R0; S < R1; ++S) frag[k][S - R0] = img0[(k * (G::NSR / 2) + (S >> 1)) * 128 + (S & 1)];
+  }
+  double fxr[NS > 1 ? NS - 1 : 1], ftailr = 0.0;  // ... and the tail rows' (K split over the register sets + columns 16 (NS-1) ..)
+  if constexpr (RESIDENT && OWN_TAIL) {
+    const double* const img0 = lds + G::OFF_A + 2 * lane;
+#pragma unroll
+    for (int j = 0; j < NS - 1; ++j) fxr[j] = img0[G::NMAIN * 64 + (j >> 1) * 128 + (j & 1)];
+    ftailr = lds[G::OFF_A + (G::NMAIN + NS - 1) * 64 + lane];
+  }
   // one batch of four per-chain sums: lanes r = 0 hold [block b'][chain x] = 16 consecutive doubles
   auto put4 = [&](double* dst, double a0, double a1, double a2, double a3) {
     const double z = rows_sum(blocks_reduce_scatter(a0, a1, a2, a3));
@@ -258,16 +278,22 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
 #pragma unroll
       for (int j = P0; j < P1; ++j) f[j] = *reinterpret_cast<const d2_t*>(img + (kap * NP + j) * 128);
     };
-    if (G::DENSE) {
+    if (G::DENSE && !RESIDENT) {
 #pragma unroll
       for (int k0 = 0; k0 < AHEAD; ++k0) if (k0 < NK) load_k(kmap(k0), fa[k0]);
     }
     d2_t fx[(NS - 1) / 2 > 0 ? (NS - 1) / 2 : 1];
     double ftail = 0.0;
     if (G::DENSE && OWN_TAIL) {
+      if constexpr (RESIDENT) {
 #pragma unroll
-      for (int j = 0; j < (NS - 1) / 2; ++j) fx[j] = *reinterpret_cast<const d2_t*>(img + G::NMAIN * 64 + j * 128);
-      ftail = lds[G::OFF_A + (G::NMAIN + NS - 1) * 64 + lane];
+        for (int j = 0; j < (NS - 1) / 2; ++j) { fx[j][0] = fxr[2 * j]; fx[j][1] = fxr[2 * j + 1]; }
+        ftail = ftailr;
+      } else {
+#pragma unroll
+        for (int j = 0; j < (NS - 1) / 2; ++j) fx[j] = *reinterpret_cast<const d2_t*>(img + G::NMAIN * 64 + j * 128);
+        ftail = lds[G::OFF_A + (G::NMAIN + NS - 1) * 64 + lane];
+      }
     }
     Cmd c;
     if (t == 0) { c.hs = 0.0; c.op = inrange ? (OP_NEWITER | OP_INIT) : 0u; c.n = 0u; }
@@ -421,12 +447,15 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
           }
           asm volatile("" ::: "memory");
         }
-        if (it + AHEAD < NK) load_k(kmap(it + AHEAD), fa[(it + AHEAD) % NF]);
+        if (!RESIDENT) if (it + AHEAD < NK) load_k(kmap(it + AHEAD), fa[(it + AHEAD) % NF]);
         if (it + QAHEAD < NK) qks[(it + QAHEAD) % NQ] = st0[(kmap(it + QAHEAD) >> 2) * 64 + 4 * (kmap(it + QAHEAD) & 3)];
         const double qk = qks[it % NQ];
         const d2_t* f = fa[it % NF];
 #pragma unroll
-        for (int S = R0; S < R1; ++S) acc[S] = it == 0 ? mfma4(f[S >> 1][S & 1], qk, 0.0) : mfma4(f[S >> 1][S & 1], qk, acc[S]);
+        for (int S = R0; S < R1; ++S) {
+          const double fs = RESIDENT ? frag[RESIDENT ? kap : 0][RESIDENT ? S - R0 : 0] : f[S >> 1][S & 1];
+          acc[S] = it == 0 ? mfma4(fs, qk, 0.0) : mfma4(fs, qk, acc[S]);
+        }
         if (OWN_TAIL) {
           if (kap == NK - 1) qlast = qk;
 #pragma unroll
