@@ -243,6 +243,8 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     for (int j = 0; j < NS - 1; ++j) fxr[j] = img0[G::NMAIN * 64 + (j >> 1) * 128 + (j & 1)];
     ftailr = lds[G::OFF_A + (G::NMAIN + NS - 1) * 64 + lane];
   }
+  uint64_t cw_pre = 0;   // the command record of the NEXT tick, read early (tag 0 never matches a tick >= 1 that has not been issued)
+  double chs_pre = 0.0;
   // one batch of four per-chain sums: lanes r = 0 hold [block b'][chain x] = 16 consecutive doubles
   auto put4 = [&](double* dst, double a0, double a1, double a2, double a3) {
     const double z = rows_sum(blocks_reduce_scatter(a0, a1, a2, a3));
@@ -261,9 +263,12 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     // the command record is asked for first, the fragments of the first k-steps (which do not depend on it) right behind: LDS returns in
     // order, so an ordinary tick has its command after one round trip and the fragments arrive while it is decoded
     const double* const rec = pr + G::P_CMD + ((t & 3u) * 4 + x) * 2;
-    uint64_t cw = 0;
-    double chs = 0.0;
-    if (t != 0) cmd_read(rec, cw, chs);
+    // (the record of this tick was asked for behind the MFMA phase of the tick before -- the issue wave is a tick ahead: it is
+    // usually there, and an ordinary tick starts without an LDS round trip; the poll below catches the other case)
+    // (halves only: with a second wave on the SIMD the round trip is hidden and the extra read costs 1.5 %)
+    uint64_t cw = cw_pre;
+    double chs = chs_pre;
+    if (HALF == 0 && t != 0) cmd_read(rec, cw, chs);
     // fragments in flight: 3 k-steps ahead (six MFMAs = 96 cycles each: an LDS round trip is covered); a half wave issues three MFMAs
     // per k-step and has the register file of a SIMD to itself: 6 ahead, and only the pairs of its own row sets
     constexpr int AHEAD = HALF ? 6 : 3, NF = HALF ? 8 : 4, QAHEAD = HALF ? 4 : 2, NQ = HALF ? 8 : 3;
@@ -476,6 +481,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     }
     }
     WN4_STAMP(1);
+    if (HALF != 0) cmd_read(pr + G::P_CMD + (((t + 1u) & 3u) * 4 + x) * 2, cw_pre, chs_pre);
     // the passive orbit end lives in memory (once per doubling: the whole-orbit check at its last leaf, and the end swaps): requested
     // here, in the registers the fragments have left, used after the half step
     const bool anyl0 = __any(l0due);
