@@ -248,7 +248,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
   // one batch of four per-chain sums: lanes r = 0 hold [block b'][chain x] = 16 consecutive doubles
   auto put4 = [&](double* dst, double a0, double a1, double a2, double a3) {
     const double z = rows_sum(blocks_reduce_scatter(a0, a1, a2, a3));
-    if (lane < 16) dst[lane] = z;
+    dst[lane & 15] = z;  // (every row holds the same sums: all lanes store -- an exec-mask region costs a wave ~37 cycles, tools/branch_cost.hip)
   };
   WN4_STAMP_DECL
 
@@ -425,7 +425,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     double* const stage = HALF == 0 ? stage0 : (PAR ? pr + G::P_STAGE2 : stage0);  // (halves: two buffers -- the partner may still read tick t-1's)
 #pragma unroll
     for (int s = S0; s < S1; ++s) stage[s * 64 + lane] = qn[s];
-    if (HALF != 0 && lane == 0) xseq[HALF - 1] = t + 1u;  // (same wave, in order: behind the stage writes; the partner waits for it IWAIT k-steps into its chain)
+    if (HALF != 0) xseq[HALF - 1] = t + 1u;  // (all lanes, one word: no exec-mask region)  // (same wave, in order: behind the stage writes; the partner waits for it IWAIT k-steps into its chain)
     WN4_STAMP(0);
     // ---- G = -A Q ----
     {
@@ -537,13 +537,13 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
         }
         put4(sp + 16, a1, a2, b1, b2);
       }
-      if (anyrare && __any(nchk > 3)) {  // levels 3, 4: prefetched
-        double a1, a2, b1, b2;
-        dots(pq0, pv0, a1, a2);
-        dots(pq1, pv1, b1, b2);
-        put4(sp + 32, a1, a2, b1, b2);
-      }
       if (anyrare) {
+        if (__any(nchk > 3)) {  // levels 3, 4: prefetched
+          double a1, a2, b1, b2;
+          dots(pq0, pv0, a1, a2);
+          dots(pq1, pv1, b1, b2);
+          put4(sp + 32, a1, a2, b1, b2);
+        }
         for (int j = 5; __any(nchk > j); j += 2) {  // still deeper levels (one leaf in 32): fetched here
           double e[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -562,7 +562,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
       }
     }
     if ((PAR == 1 || t == 0) && anyrare && __any((op & OP_NEWITER) != 0)) put4(sp + 16 * (G::NB - 1), keinit_part, gen_part, 0.0, 0.0);
-    if (lane == 0) seq[0] = t + 1u;  // the sums of tick t are in LDS (same wave, in order)
+    seq[0] = t + 1u;  // the sums of tick t are in LDS (same wave, in order; all lanes store the one word)
     WN4_STAMP(2);
     // ---- statePush (:431,518): only sub-tree left endpoints are ever read back; they are even leaves ----
     if (PAR == 0) {
