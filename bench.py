@@ -626,7 +626,12 @@ def main():
                 e2.run(q0d[:1024], SEED + 77, spec["iters"])
                 s2, d2 = e2.run(q0d[:1024], SEED, spec["iters"])
                 st = float((d2[:, :, 6].sum() + d2[:, :, 7].sum()).item())
-                extras["dense_1024_chains"] = {"value": st / (e2.last_run_ms() * 1e-3), "unit": "leapfrog steps/s", "kernel": e2.kernel_name}
+                v2 = st / (e2.last_run_ms() * 1e-3)
+                tf2 = v2 * spec["per_unit"] / 1e12
+                extras["dense_1024_chains"] = {"value": v2, "unit": "leapfrog steps/s", "kernel": e2.kernel_name, "ms_per_step": e2.last_run_ms(),
+                                               "roofline": {"bound": "mfma", "achieved": tf2, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                            "frac": tf2 / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                                                            "flop_per_leapfrog_step": spec["per_unit"]}}
                 e2.close()
                 lam = np.logspace(0.0, np.log10(args.kappa), D)
                 e3 = wa.Engine(D, C, integrator=L.I_FIXED, H0=args.H0, stepSizeRandScale=0.2, M=args.M,

@@ -502,8 +502,12 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
     // dense, D <= 100: wave pairs of four chains (wn_k_fast4.hip), traced runs too.  (4096 chains: 1.24e9 steps/s against the
     // seven-wave kernel's 1.12e9; 1024 chains are 256 pairs, one per CU, where that kernel fills 64 CUs: 3.9e8 against 2.8e8.)
     if ((kc.p1 != CK_DENSE || D <= 100) && !getenv("WN_FAST_LEGACY"))
-      snprintf(kc.name, sizeof(kc.name), "wn_fast4_kernel<NS=%d%s,%s,pairs=%d>", D <= 32 ? 2 : D <= 64 ? 4 : D <= 96 ? 6 : 7, (kc.p1 == CK_DENSE && D > 96) ? ",tail" : "",
-               kc.p1 == CK_DENSE ? "dense" : "diag", fast4_pairs(e->cfg.n_chains));
+    {
+      const int pr_ = fast4_pairs(e->cfg.n_chains);
+      const bool halves = kc.p1 == CK_DENSE && D > 64 && pr_ == 1 && !getenv("WN_FAST4_WHOLE");  // (fast4_go: a group on two T waves)
+      snprintf(kc.name, sizeof(kc.name), "wn_fast4_kernel<NS=%d%s,%s,pairs=%d%s>", D <= 32 ? 2 : D <= 64 ? 4 : D <= 96 ? 6 : 7, (kc.p1 == CK_DENSE && D > 96) ? ",tail" : "",
+               kc.p1 == CK_DENSE ? "dense" : "diag", pr_, halves ? ",halves" : "");
+    }
   }
   if (kc.layout == 2 && kc.p0 == 1 && kc.W == 1 && kc.G == 1 && e->cfg.warmup_iter == 0 && e->cfg.M >= 1 &&
       (e->cfg.integrator == WN_I_FIXED || e->cfg.integrator == WN_I_ADAPT_D || e->cfg.integrator == WN_I_ADAPT_R2P) && !getenv("WN_ORBIT_LEGACY")) {
