@@ -247,7 +247,9 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
   double chs_pre = 0.0;
   // one batch of four per-chain sums: lanes r = 0 hold [block b'][chain x] = 16 consecutive doubles
   auto put4 = [&](double* dst, double a0, double a1, double a2, double a3) {
-    const double z = rows_sum(blocks_reduce_scatter(a0, a1, a2, a3));
+    // the sum over the four rows r is one MFMA with an all-ones A operand: D[b][i][j] = sum_k B[b][k][j], i.e. lane (i, b, x) gets the
+    // sum over r of lanes (r, b, x) -- in every row, which is what the four permlane swaps and two additions of rows_sum() produce
+    const double z = mfma4(1.0, blocks_reduce_scatter(a0, a1, a2, a3), 0.0);
     dst[lane & 15] = z;  // (every row holds the same sums: all lanes store -- an exec-mask region costs a wave ~37 cycles, tools/branch_cost.hip)
   };
   WN4_STAMP_DECL
