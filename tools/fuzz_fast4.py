@@ -14,6 +14,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 INT = (0, 1, 4, 5, 6, 7, 8, 9, 12, 13, 19, 20, 21, 22)
 bad = 0
 other = 0
+ONLY = int(os.environ.get("FUZZ_ONLY", "-1"))  # replay one configuration of a run (same n and seed), with details
 
 
 def close(a, b, tol=1e-6):
@@ -41,6 +42,9 @@ for it in range(n):
     traced = rng.random() < 0.35 and C <= 300
     cap = numIter * (1 << M) + 8
     off = int(rng.integers(0, 1 << 20))
+    if ONLY >= 0 and it != ONLY:  # (replay: the random stream is consumed as in a full run, nothing is run)
+        rng.integers(0, C)
+        continue
     e = wa.Engine(D, C, integrator=ol.I_FIXED, H0=H0, M=M, generated=gen, gen_k=gk, chain_offset=off)
     e.set_target(ol.T_DENSEGAUSS, A)
     name = e.kernel_name
@@ -57,6 +61,13 @@ for it in range(n):
         if traced and ok:
             m = o["ncalls"]
             ok = tn[k] == m and close(tr[k, :m], o["trace"][:m])
+        if not ok and ONLY >= 0:
+            dd, od = d[k], o["diagnostics"]
+            print("  integer columns differing:", [c for c in INT if not np.array_equal(dd[:, c], od[:, c])])
+            with np.errstate(all="ignore"):
+                print("  max rel diff of diagnostics per column:", np.round(np.nanmax(np.abs(dd - od) / np.maximum(1e-300, np.abs(od)), axis=0), 12).tolist())
+                print("  engine rows:\n", dd[:, [2, 6, 7, 17, 19, 20]], "\n  oracle rows:\n", od[:, [2, 6, 7, 17, 19, 20]])
+                print("  draws max abs diff per iteration:", np.abs(s[k] - o["samples"]).max(axis=0).tolist())
         if not ok:
             bad += 1
             print(f"MISMATCH it={it} D={D} C={C} M={M} iters={numIter} gen={gen} H0={H0:.4f} traced={traced} chain={k} kernel={name}", flush=True)
