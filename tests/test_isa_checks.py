@@ -45,6 +45,16 @@ def test_headline_kernel_has_no_flat_or_scratch_instructions(tmp_path):
             assert m["scratch"] == 0 and m["vgpr_spill"] == 0, (name, m)
 
 
+    # halves mode (a group on two T waves, each alone on its SIMD): the fragments live in registers -- the tick bodies hold no 16-byte
+    # fragment reads (the whole-group form has one per two MFMAs), and the code object still has no spills
+    halves = "_ZN2wn15wn_fast4_kernelILi7ELb1ELb0ELb1ELb1EEEvNS_6ParamsEPii"
+    whole = "_ZN2wn15wn_fast4_kernelILi7ELb1ELb0ELb1ELb0EEEvNS_6ParamsEPii"
+    assert halves in ks and whole in ks
+    n128 = lambda k: len(re.findall(r"\bds_read_b128", ks[k]))
+    assert n128(whole) >= 150 and n128(halves) <= 4, (n128(whole), n128(halves))
+    assert len(re.findall(r"v_mfma_f64_4x4x4", ks[halves])) == len(re.findall(r"v_mfma_f64_4x4x4", ks[whole]))
+
+
 @pytest.mark.timeout(900)
 def test_orbit_kernel_has_no_flat_or_scratch_instructions(tmp_path):
     ks, meta = kernels_of("wn_k_orbit", tmp_path)
