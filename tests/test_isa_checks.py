@@ -52,7 +52,7 @@ def test_headline_kernel_has_no_flat_or_scratch_instructions(tmp_path):
     assert halves in ks and whole in ks
     n128 = lambda k: len(re.findall(r"\bds_read_b128", ks[k]))
     assert n128(whole) >= 150 and n128(halves) <= 4, (n128(whole), n128(halves))
-    assert len(re.findall(r"v_mfma_f64_4x4x4", ks[halves])) == len(re.findall(r"v_mfma_f64_4x4x4", ks[whole]))
+    assert min(len(re.findall(r"v_mfma_f64_4x4x4", ks[k])) for k in (halves, whole)) >= 314  # 157 per tick body, two bodies
 
 
 @pytest.mark.timeout(900)
