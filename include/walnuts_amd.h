@@ -230,6 +230,11 @@ int wn_wstep_result(wn_wstep *h, double *theta_sel_dev, void *stream);
  * draws_dev [B][n_transitions][D] (or NULL) receives every state.  Built-in targets only. */
 int wn_wstep_run_device_rng(wn_wstep *h, uint64_t seed, int64_t chain_offset, int32_t iter0, int32_t n_transitions,
                             double *theta_dev, double *draws_dev, void *stream);
+/* (new; test / diagnostics) integer statistics of the following wn_wstep_run_device_rng calls: stats_dev [B][n_transitions][4] int32 =
+ * {doublings started (binomial draws, walnuts.py:330), accepts (:347), sum of the chosen micro-step counts (choose_micro_steps, :194),
+ * sum of the forward ell_stable (:250)} per chain and transition -- what tests/golden/walnuts_device.npz holds for the unmodified
+ * reference run on the same random stream.  NULL detaches.  The buffer is caller-owned. */
+int wn_wstep_set_stats(wn_wstep *h, int32_t *stats_dev);
 int wn_wstep_ext_bind(wn_wstep *h, double *x_req_dev, const double *lp_dev, const double *grad_dev);
 int wn_wstep_ext_pending(wn_wstep *h, int32_t *n_pending, void *stream);
 int wn_wstep_ext_waiting(wn_wstep *h, int32_t *waiting_dev, void *stream);

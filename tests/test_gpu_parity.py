@@ -602,3 +602,37 @@ def test_walnuts_device_wave_kernel_matches_the_one_lane_kernel(wa):
         assert same.mean() > 0.95, same.mean()
         first = np.abs(new[:, 0] - old[:, 0]).max(axis=1) < 1e-9  # the first transition alone: hardly any threshold is that close
         assert first.mean() > 0.99, first.mean()
+
+
+@pytest.mark.parametrize("legacy", [False, True], ids=["wave_kernel", "one_lane_kernel"])
+def test_walnuts_device_matches_the_reference_on_the_engine_stream(wa, legacy):
+    """Pins `walnuts_device` (wn_wstep_run_device_rng) to the reference: tests/golden/walnuts_device.npz holds the UNMODIFIED
+    /root/reference/walnuts/walnuts.py::walnuts() driven by a Generator stand-in that serves the engine's Philox stream in the
+    kernels' draw order (tests/golden/make_golden_walnuts_device.py), 128 chains x 30 transitions of the 10-D standard normal with
+    test/test.py's parameters, a diagonal-mass case and a 24-D diagonal-precision Gaussian.  Both device kernels -- the wave kernel
+    (wstep_wave_kernel) and the one-lane state machine (wstep_auto_kernel) -- must reproduce every transition: doublings started,
+    accepts, the sum of the chosen micro-step counts and of the forward ell_stable EXACTLY, every draw to rtol 1e-6.  No chain is
+    budgeted away: a chain may only leave through a `<= max_error` / acceptance comparison sitting on a rounding edge, and there is
+    none in these 6 000 transitions."""
+    from walnuts_amd import targetDistr as td
+    g = np.load(os.path.join(G, "walnuts_device.npz"))
+    if legacy:
+        os.environ["WN_WSTEP_LEGACY"] = "1"
+    try:
+        for name in ("std10", "std10_mass", "diag24"):
+            seed, C, T, D, depth, it0 = (int(v) for v in g[name + "_cfg"])
+            macro, maxerr = (float(v) for v in g[name + "_par"])
+            prec = g[name + "_prec"]
+            tgt = td.stdGauss if np.all(prec == 1.0) else td.diagGauss(prec)
+            d, st = wa.walnuts_device(seed, g[name + "_theta0"], tgt, g[name + "_inv_mass"], macro, depth, maxerr, 0, T, iter0=it0,
+                                      return_stats=True, transitions_per_launch=11)
+            ref_i = g[name + "_ints"][:, :, :4]
+            bad_i = np.flatnonzero((st != ref_i).any(axis=(1, 2)))
+            assert bad_i.size == 0, (name, "chains whose integers differ from the reference", bad_i[:10], st[bad_i[:1]], ref_i[bad_i[:1]])
+            ref_d = g[name + "_draws"]
+            err = np.abs(d - ref_d) / (1e-9 + 1e-6 * np.abs(ref_d))
+            bad_d = np.flatnonzero((err > 1.0).any(axis=(1, 2)))
+            assert bad_d.size == 0, (name, "chains whose draws leave rtol 1e-6", bad_d[:10], err.max())
+    finally:
+        if legacy:
+            del os.environ["WN_WSTEP_LEGACY"]

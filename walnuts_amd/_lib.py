@@ -38,7 +38,7 @@ class WnConfig(C.Structure):
 
 # every symbol include/walnuts_amd.h declares
 SYMBOLS = ["wn_abi_version", "wn_create", "wn_set_target", "wn_run", "wn_run_orbit_stats", "wn_split_ld", "wn_split_begin", "wn_split_tick", "wn_split_done", "wn_integrator_step",
-           "wn_lpfun", "wn_lpfun_kind", "wn_wstep_create", "wn_wstep_begin", "wn_wstep_extend", "wn_wstep_commit", "wn_wstep_result", "wn_wstep_run_device_rng",
+           "wn_lpfun", "wn_lpfun_kind", "wn_wstep_create", "wn_wstep_begin", "wn_wstep_extend", "wn_wstep_commit", "wn_wstep_result", "wn_wstep_run_device_rng", "wn_wstep_set_stats",
            "wn_wstep_ext_bind", "wn_wstep_ext_pending", "wn_wstep_ext_waiting", "wn_wstep_ext_feed", "wn_wstep_last_error", "wn_wstep_destroy", "wn_rng_tape", "wn_last_run_ms", "wn_check_run", "wn_last_split_ticks", "wn_debug_poison_lds", "wn_kernel_name", "wn_last_error",
            "wn_destroy"]
 
@@ -93,6 +93,8 @@ def lib():
     L.wn_wstep_ext_pending.argtypes = [vp, C.POINTER(C.c_int32), vp]
     L.wn_wstep_run_device_rng.restype = C.c_int
     L.wn_wstep_run_device_rng.argtypes = [vp, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, vp, vp, vp]
+    L.wn_wstep_set_stats.restype = C.c_int
+    L.wn_wstep_set_stats.argtypes = [vp, vp]
     L.wn_wstep_ext_waiting.restype = C.c_int
     L.wn_wstep_ext_waiting.argtypes = [vp, vp, vp]
     L.wn_wstep_last_error.restype = C.c_char_p

@@ -40,6 +40,7 @@ struct WScal {  // per-chain scalars of the machine and of the orbit
   double lp0, lp, Hmin, Hmax, step, half, weight, p0;
   double lpL, lpR, wL, wR;
   int stage, n, k, ell, lf_ell, es, m, nmacro, backward, active, nw, sub_uturn;
+  int sum_ell, sum_es;  // (statistics of wn_wstep_set_stats: chosen micro-step counts and forward ell_stable, summed over the macro steps)
 };
 
 struct WCtx {
@@ -153,6 +154,7 @@ __device__ bool advance(const WCtx& c, const VT& V, WScal& s) {
       s.es = s.ell;
       const int idx = c.lottery[(size_t)V.b * c.nmax + s.m];
       s.lf_ell = idx == 0 ? s.es / 2 : idx == 1 ? s.es : s.es * 2;
+      s.sum_ell += s.lf_ell; s.sum_es += s.es;
       s.stage = ST_LF;
       leap_setup(c, V, s);
       return true;
@@ -382,7 +384,7 @@ __global__ void wstep_commit_kernel(WCtx c, const int* accept, const double* u_c
 // index per macro step (:194), the acceptance uniform (:346) and, after an accept, the categorical uniform (:350); the momentum is
 // rng_normal(seed, chain, it, j) / sqrt(inv_mass[j]) (:325).
 __global__ void wstep_auto_kernel(WCtx c0, int* lottery, uint64_t seed, uint32_t chain0, int it0, int n_trans, int max_depth,
-                                  double* theta_io, double* draws) {
+                                  double* theta_io, double* draws, int* stats) {
   // ONE CHAIN PER WAVEFRONT (lane 0 works): the machine's stages, the search depths and the orbit lengths differ from chain to chain,
   // and 64 chains in one wave each waited for every branch of every other (measured: 0.53 s per transition of a wave, 7.7e3
   // transitions/s for 4096 chains); alone in its wave a chain pays only its own path
@@ -415,9 +417,12 @@ __global__ void wstep_auto_kernel(WCtx c0, int* lottery, uint64_t seed, uint32_t
       V(V_RH, i) = rng_normal(seed, chain, it, (uint32_t)i) / sqrt(c.im[i]);
     }
     s.stage = ST_INIT; s.active = 1; s.nmacro = 0; s.m = 0; s.sub_uturn = 0;
+    s.sum_ell = 0; s.sum_es = 0;
+    int ndbl = 0, nacc = 0;  // (stats: doublings started, accepts)
     run_machine_lds(c, V, s);
     for (int depth = 0; depth < max_depth; ++depth) {
       const int n = 1 << depth;
+      ndbl += 1;
       const int backward = rng_uniform(seed, chain, it, k++) < 0.5 ? 1 : 0;
       for (int m = 0; m < n; ++m) {
         const int idx = (int)(3.0 * rng_uniform(seed, chain, it, k++));
@@ -430,7 +435,12 @@ __global__ void wstep_auto_kernel(WCtx c0, int* lottery, uint64_t seed, uint32_t
       const double logu = log(rng_uniform(seed, chain, it, k++));
       const bool acc = logu < lse2[0] - lse2[1];
       const double uc = acc ? rng_uniform(seed, chain, it, k++) : 0.0;
+      nacc += acc ? 1 : 0;
       if (commit_chain(c, 0, s, acc, uc, vl)) break;
+    }
+    if (stats) {
+      int* o = stats + ((size_t)b * n_trans + tr) * 4;
+      o[0] = ndbl; o[1] = nacc; o[2] = s.sum_ell; o[3] = s.sum_es;
     }
     for (int i = 0; i < c.D; ++i) {
       const double th = V(V_SEL, i);
@@ -472,7 +482,7 @@ __device__ __forceinline__ void wt_sum2(double& a, double& b) {
 
 template <bool SMALL>
 __global__ __launch_bounds__(64) void wstep_wave_kernel(WCtx c0, int* lottery, uint64_t seed, uint32_t chain0, int it0, int n_trans, int max_depth,
-                                                        double* theta_io, double* draws) {
+                                                        double* theta_io, double* draws, int* stats) {
   const int b = blockIdx.x, lane = threadIdx.x, D = c0.D;
   if (b >= c0.B) return;
   const bool in = lane < D;
@@ -547,9 +557,11 @@ __global__ __launch_bounds__(64) void wstep_wave_kernel(WCtx c0, int* lottery, u
     double wL = lp - ke_of(rh), wR = wL;
     if (lane == 0) logw[0] = wL;
     int nw = 1;
+    int ndbl = 0, nacc = 0, sum_ell = 0, sum_es = 0;  // (stats: what a reference run on the same stream must reproduce exactly)
 #pragma unroll 1
     for (int depth = 0; depth < max_depth; ++depth) {
       const int n = 1 << depth;
+      ndbl += 1;
       const int backward = uni(it, k++) < 0.5 ? 1 : 0;  // :330
       for (int m0 = 0; m0 < n; m0 += 32) {               // one lottery index per macro step (:194), drawn before the extension as the kernel above does
         uit = 0xFFFFFFFFu;                               // a fresh window that STARTS at the block of uniform k + m0: its first 62 uniforms are inside
@@ -569,6 +581,7 @@ __global__ __launch_bounds__(64) void wstep_wave_kernel(WCtx c0, int* lottery, u
         const int es = stable(t0, r0, g0, lp0, 1.0);
         const int idx = __builtin_amdgcn_readfirstlane((int)lot[m]);
         const int ell = idx == 0 ? es / 2 : idx == 1 ? es : es * 2;  // choose_micro_steps (:194); es == 1 can give 0 (Q9): an infinite step
+        sum_ell += ell; sum_es += es;
         {  // leapfrog (:74-95)
           const double step = macro / (double)ell, half = 0.5 * step;
           double t = t0, r = r0 + half * g0;
@@ -630,6 +643,7 @@ __global__ __launch_bounds__(64) void wstep_wave_kernel(WCtx c0, int* lottery, u
       const double logu = log(uni(it, k++));  // :346
       const bool acc = logu < lse_ext - lse_old;
       if (acc) {  // :347-350: p = softmax(log_weights_ext) in LIST order; Generator.choice: cdf = p.cumsum(); cdf /= cdf[-1]; searchsorted(u, 'right')
+        nacc += 1;
         const double uc = uni(it, k++);
         double mx = -INFINITY;
         for (int j = 0; j < n; ++j) { const double x = ew[j]; mx = x > mx ? x : mx; }
@@ -665,6 +679,7 @@ __global__ __launch_bounds__(64) void wstep_wave_kernel(WCtx c0, int* lottery, u
       theta_io[(size_t)b * D + li] = sel;
       if (draws) draws[((size_t)b * n_trans + tr) * D + li] = sel;
     }
+    if (stats && lane < 4) stats[((size_t)b * n_trans + tr) * 4 + lane] = lane == 0 ? ndbl : lane == 1 ? nacc : lane == 2 ? sum_ell : sum_es;
   }
 }
 
@@ -687,6 +702,7 @@ struct wn_wstep {
   bool external = false;
   double *tpar = nullptr, *im = nullptr;
   int* lot = nullptr;
+  int* stats = nullptr;    // caller-owned [B][n_transitions][4] of the next wn_wstep_run_device_rng calls (wn_wstep_set_stats), or null
   int* asub = nullptr;     // device-RNG transitions: per-chain scratch of extend_finish
   double* alse = nullptr;  // [2][B]
   std::string err;
@@ -861,15 +877,21 @@ int wn_wstep_run_device_rng(wn_wstep* h, uint64_t seed, int64_t chain_offset, in
   if ((h->c.kind == T_STDGAUSS || h->c.kind == T_DIAGGAUSS) && h->c.nmax <= 8192 && !getenv("WN_WSTEP_LEGACY")) {
     const size_t dyn = (size_t)h->c.nmax * sizeof(int);
     if (h->c.D <= 16) hipLaunchKernelGGL(wstep_wave_kernel<true>, dim3(h->c.B), dim3(64), dyn, (hipStream_t)stream, h->c, h->lot, seed, (uint32_t)chain_offset,
-                                         (int)iter0, (int)n_transitions, h->max_depth, theta_dev, draws_dev);
+                                         (int)iter0, (int)n_transitions, h->max_depth, theta_dev, draws_dev, h->stats);
     else hipLaunchKernelGGL(wstep_wave_kernel<false>, dim3(h->c.B), dim3(64), dyn, (hipStream_t)stream, h->c, h->lot, seed, (uint32_t)chain_offset,
-                            (int)iter0, (int)n_transitions, h->max_depth, theta_dev, draws_dev);
+                            (int)iter0, (int)n_transitions, h->max_depth, theta_dev, draws_dev, h->stats);
     WCHK(hipGetLastError());
     return WN_OK;
   }
   hipLaunchKernelGGL(wstep_auto_kernel, dim3(h->c.B), dim3(64), 0, (hipStream_t)stream, h->c, h->lot, seed, (uint32_t)chain_offset,
-                     (int)iter0, (int)n_transitions, h->max_depth, theta_dev, draws_dev);
+                     (int)iter0, (int)n_transitions, h->max_depth, theta_dev, draws_dev, h->stats);
   WCHK(hipGetLastError());
+  return WN_OK;
+}
+
+int wn_wstep_set_stats(wn_wstep* h, int32_t* stats_dev) {
+  if (!h) return WN_E_ARG;
+  h->stats = stats_dev;
   return WN_OK;
 }
 

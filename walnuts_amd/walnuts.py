@@ -228,13 +228,16 @@ def walnuts_batch(rngs, theta_init, logp, grad, inv_mass, macro_step, max_nuts_d
 
 
 def walnuts_device(seed, theta_init, target, inv_mass, macro_step, max_nuts_depth, max_error, iter_warmup, iter_sample,
-                   chain_offset=0, transitions_per_launch=64):
+                   chain_offset=0, transitions_per_launch=64, iter0=1, return_stats=False):
     """C chains with the DEVICE's random stream instead of numpy Generators: theta_init (C, D) -> draws (C, iter_sample, D).
     The transition kernel is walnuts_step's (walnuts.py:279-359); the randomness is the engine's Philox stream keyed by
     (seed, chain_offset + chain, transition number) -- wn_rng.h -- so a chain's draws do not depend on how chains are batched
     or sharded, and whole transitions run on the GPU with no host round trip per doubling (`walnuts_batch` keeps the
     reference's Generator contract and pays ~4 host exchanges per doubling for it).  `target` is a walnuts_amd device target
-    (e.g. walnuts_amd.targetDistr.stdGauss), not a host callable."""
+    (e.g. walnuts_amd.targetDistr.stdGauss), not a host callable.  `iter0` is the transition number of the first transition (the
+    stream's `iteration` key).  return_stats=True also returns int32 [C, iter_warmup + iter_sample, 4] = {doublings started, accepts, sum of
+    the chosen micro-step counts, sum of the forward ell_stable} per transition (wn_wstep_set_stats): the integers the unmodified
+    reference reproduces when it is driven with the same stream (tests/golden/make_golden_walnuts_device.py)."""
     _quiet()
     theta, inv_mass = _check_args(theta_init, inv_mass, macro_step, max_nuts_depth, max_error)
     theta = np.atleast_2d(theta)
@@ -248,16 +251,23 @@ def walnuts_device(seed, theta_init, target, inv_mass, macro_step, max_nuts_dept
         th = s.dv(theta)
         n_tot = int(iter_warmup) + int(iter_sample)
         out = t.empty((Cn, int(iter_sample), D), dtype=t.float64, device=s.dev)
-        it = 1
+        stats = []
+        it = int(iter0)
         done = 0
         while done < n_tot:
             n = min(int(transitions_per_launch), n_tot - done)
             buf = t.empty((Cn, n, D), dtype=t.float64, device=s.dev)
+            if return_stats:
+                stats.append(t.zeros((Cn, n, 4), dtype=t.int32, device=s.dev))
+                s._ck(s.lib.wn_wstep_set_stats(s.h, s.p(stats[-1])))
             s._ck(s.lib.wn_wstep_run_device_rng(s.h, int(seed), int(chain_offset), it, n, s.p(th), s.p(buf), s._st()))
             lo = max(done, int(iter_warmup))
             if done + n > lo:
                 out[:, lo - int(iter_warmup):done + n - int(iter_warmup)] = buf[:, lo - done:]
             done += n; it += n
+        if return_stats:
+            s._ck(s.lib.wn_wstep_set_stats(s.h, None))
+            return out.cpu().numpy(), t.cat(stats, dim=1).cpu().numpy()
         return out.cpu().numpy()
     finally:
         s.close()
