@@ -113,6 +113,19 @@ struct Fast4Geom {
 #define WN4_STAMP_OUT(prm)
 #endif
 
+// Control-flow switches of the tick (A/B builds: tools/variant_fast4_many.sh name:-DWN4_OPT=<mask> ...).  Round 5 measured each one alone
+// on the bench workload (gpurun_out/r05/ab2.txt, ab3.txt; 1.378e9 steps/s with none of them): the T wave's branches are NOT what its tick
+// is made of -- ten fewer branches and exec-mask regions per tick change nothing (1: 1.373e9, 4: 1.377e9, 8: 1.375e9) -- while 14-28 more
+// vector-memory instructions per odd tick cost 4 % (the levels 3 / 4 prefetched for every chain of the group behind one vote instead of
+// per chain under exec masks: 1.322e9, removed).  All four below together: 1.381e9.
+#if !defined(WN4_OPT)
+#define WN4_OPT (1 + 4 + 8 + 16)
+#endif
+constexpr bool OPT_POLL = (WN4_OPT & 1) != 0;    // the spin loop out of line, tick 0 no special case
+constexpr bool OPT_L12 = (WN4_OPT & 4) != 0;     // levels 1 / 2 on every odd tick without votes
+constexpr bool OPT_EP = (WN4_OPT & 8) != 0;      // endpoint pushes as predicated stores (no vote, no branch)
+constexpr bool OPT_SLIDE = (WN4_OPT & 16) != 0;  // I wave: a window refill slides the windows of ALL its chains (the Philox passes are paid per wave, not per chain)
+
 __device__ __forceinline__ double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 
 // DPP move of a double: lanes whose bank (= block b = (lane >> 2) & 3) is in BANKS take src moved by CTL inside their row of
@@ -152,6 +165,80 @@ __device__ __forceinline__ double rows_sum(double x) {
   a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
   b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
   return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Predicated stores WITHOUT a branch.  `if (lane predicate) { stores }` compiles to s_and_saveexec + s_cbranch_execz + the stores +
+// s_or exec, and the compiler always keeps the skip branch around LDS / memory instructions.  A T wave pays 25-55 cycles for every
+// branch, taken or not (tools/branch_cost.hip), and the endpoint pushes / picks below are due for SOME chain of the group on most
+// ticks: here exec is narrowed around the stores inside one asm block -- no vote, no branch; lanes outside `mask` issue nothing.
+// (The compiler does not count these stores in its s_waitcnt bookkeeping.  LDS operations and, on gfx9, vector memory operations
+// complete in issue order, so the extra outstanding operations can only make a later s_waitcnt N wait longer, never shorter.)
+// q[s] -> base[s * 64], v[s] -> base[(NSET + s) * 64]  (doubles; the level-2 endpoint in LDS)
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) double lds_f64;
+__device__ __forceinline__ uint32_t lds_addr(const double* p) { return (uint32_t)(uintptr_t)(const lds_f64*)p; }
+template <int NSET, int A, int B>
+__device__ __forceinline__ void lds_store_qv_masked(uint64_t mask, uint32_t addr, const double (&q)[NSET], const double (&v)[NSET]) {
+  constexpr int N = B - A;
+  static_assert(N >= 1 && N <= 4, "one asm block stores up to four register sets");
+  uint64_t sv;
+  if constexpr (N == 1)
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write2st64_b64 %2, %3, %4 offset0:%5 offset1:%6\n\ts_mov_b64 exec, %0"
+                 : "=&s"(sv) : "s"(mask), "v"(addr), "v"(q[A]), "v"(v[A]), "n"(A), "n"(NSET + A) : "memory", "scc");
+  else if constexpr (N == 2)
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write2st64_b64 %2, %3, %4 offset0:%7 offset1:%8\n\tds_write2st64_b64 %2, %5, %6 offset0:%9 offset1:%10\n\ts_mov_b64 exec, %0"
+                 : "=&s"(sv) : "s"(mask), "v"(addr), "v"(q[A]), "v"(v[A]), "v"(q[A + 1]), "v"(v[A + 1]), "n"(A), "n"(NSET + A), "n"(A + 1), "n"(NSET + A + 1) : "memory", "scc");
+  else if constexpr (N == 3)
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write2st64_b64 %2, %3, %4 offset0:%9 offset1:%10\n\tds_write2st64_b64 %2, %5, %6 offset0:%11 offset1:%12\n\t"
+                 "ds_write2st64_b64 %2, %7, %8 offset0:%13 offset1:%14\n\ts_mov_b64 exec, %0"
+                 : "=&s"(sv) : "s"(mask), "v"(addr), "v"(q[A]), "v"(v[A]), "v"(q[A + 1]), "v"(v[A + 1]), "v"(q[A + 2]), "v"(v[A + 2]),
+                   "n"(A), "n"(NSET + A), "n"(A + 1), "n"(NSET + A + 1), "n"(A + 2), "n"(NSET + A + 2) : "memory", "scc");
+  else
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write2st64_b64 %2, %3, %4 offset0:%11 offset1:%12\n\tds_write2st64_b64 %2, %5, %6 offset0:%13 offset1:%14\n\t"
+                 "ds_write2st64_b64 %2, %7, %8 offset0:%15 offset1:%16\n\tds_write2st64_b64 %2, %9, %10 offset0:%17 offset1:%18\n\ts_mov_b64 exec, %0"
+                 : "=&s"(sv) : "s"(mask), "v"(addr), "v"(q[A]), "v"(v[A]), "v"(q[A + 1]), "v"(v[A + 1]), "v"(q[A + 2]), "v"(v[A + 2]), "v"(q[A + 3]), "v"(v[A + 3]),
+                   "n"(A), "n"(NSET + A), "n"(A + 1), "n"(NSET + A + 1), "n"(A + 2), "n"(NSET + A + 2), "n"(A + 3), "n"(NSET + A + 3) : "memory", "scc");
+}
+template <int NSET, int S0, int S1>
+__device__ __forceinline__ void lds_store_qv_masked_all(uint64_t mask, const double* base, const double (&q)[NSET], const double (&v)[NSET]) {
+  const uint32_t addr = lds_addr(base);
+  constexpr int MID = S0 + ((S1 - S0) > 4 ? 4 : (S1 - S0));
+  lds_store_qv_masked<NSET, S0, MID>(mask, addr, q, v);
+  if constexpr (MID < S1) lds_store_qv_masked<NSET, MID, S1>(mask, addr, q, v);
+}
+// the same to memory: q[s] -> pq[s * 16], v[s] -> pv[s * 16]  (doubles; a chain-major vector of the workspace)
+template <int NSET, int A, int B>
+__device__ __forceinline__ void glb_store_qv_masked(uint64_t mask, double* pq, double* pv, const double (&q)[NSET], const double (&v)[NSET]) {
+  constexpr int N = B - A;
+  static_assert(N >= 1 && N <= 4, "one asm block stores up to four register sets");
+  uint64_t sv;
+  if constexpr (N == 1)
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dwordx2 %2, %4, off offset:%6\n\tglobal_store_dwordx2 %3, %5, off offset:%6\n\ts_mov_b64 exec, %0"
+                 : "=&s"(sv) : "s"(mask), "v"(pq), "v"(pv), "v"(q[A]), "v"(v[A]), "n"(A * 128) : "memory", "scc");
+  else if constexpr (N == 2)
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dwordx2 %2, %4, off offset:%8\n\tglobal_store_dwordx2 %3, %5, off offset:%8\n\t"
+                 "global_store_dwordx2 %2, %6, off offset:%9\n\tglobal_store_dwordx2 %3, %7, off offset:%9\n\ts_mov_b64 exec, %0"
+                 : "=&s"(sv) : "s"(mask), "v"(pq), "v"(pv), "v"(q[A]), "v"(v[A]), "v"(q[A + 1]), "v"(v[A + 1]), "n"(A * 128), "n"(A * 128 + 128) : "memory", "scc");
+  else if constexpr (N == 3)
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dwordx2 %2, %4, off offset:%10\n\tglobal_store_dwordx2 %3, %5, off offset:%10\n\t"
+                 "global_store_dwordx2 %2, %6, off offset:%11\n\tglobal_store_dwordx2 %3, %7, off offset:%11\n\t"
+                 "global_store_dwordx2 %2, %8, off offset:%12\n\tglobal_store_dwordx2 %3, %9, off offset:%12\n\ts_mov_b64 exec, %0"
+                 : "=&s"(sv) : "s"(mask), "v"(pq), "v"(pv), "v"(q[A]), "v"(v[A]), "v"(q[A + 1]), "v"(v[A + 1]), "v"(q[A + 2]), "v"(v[A + 2]),
+                   "n"(A * 128), "n"(A * 128 + 128), "n"(A * 128 + 256) : "memory", "scc");
+  else
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dwordx2 %2, %4, off offset:%12\n\tglobal_store_dwordx2 %3, %5, off offset:%12\n\t"
+                 "global_store_dwordx2 %2, %6, off offset:%13\n\tglobal_store_dwordx2 %3, %7, off offset:%13\n\t"
+                 "global_store_dwordx2 %2, %8, off offset:%14\n\tglobal_store_dwordx2 %3, %9, off offset:%14\n\t"
+                 "global_store_dwordx2 %2, %10, off offset:%15\n\tglobal_store_dwordx2 %3, %11, off offset:%15\n\ts_mov_b64 exec, %0"
+                 : "=&s"(sv) : "s"(mask), "v"(pq), "v"(pv), "v"(q[A]), "v"(v[A]), "v"(q[A + 1]), "v"(v[A + 1]), "v"(q[A + 2]), "v"(v[A + 2]), "v"(q[A + 3]), "v"(v[A + 3]),
+                   "n"(A * 128), "n"(A * 128 + 128), "n"(A * 128 + 256), "n"(A * 128 + 384) : "memory", "scc");
+}
+template <int NSET, int S0, int S1>
+__device__ __forceinline__ void glb_store_qv_masked_all(uint64_t mask, double* pq, double* pv, const double (&q)[NSET], const double (&v)[NSET]) {
+  constexpr int MID = S0 + ((S1 - S0) > 4 ? 4 : (S1 - S0));
+  glb_store_qv_masked<NSET, S0, MID>(mask, pq, pv, q, v);
+  if constexpr (MID < S1) glb_store_qv_masked<NSET, MID, S1>(mask, pq, pv, q, v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -270,7 +357,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     // (halves only: with a second wave on the SIMD the round trip is hidden and the extra read costs 1.5 %)
     uint64_t cw = cw_pre;
     double chs = chs_pre;
-    if (HALF == 0 && t != 0) cmd_read(rec, cw, chs);
+    if (HALF == 0 && (OPT_POLL || t != 0)) cmd_read(rec, cw, chs);  // (tick 0: the record the kernel's prologue wrote -- tag 0 -- so tick 0 is no special case)
     // fragments in flight: 3 k-steps ahead (six MFMAs = 96 cycles each: an LDS round trip is covered); a half wave issues three MFMAs
     // per k-step and has the register file of a SIMD to itself: 6 ahead, and only the pairs of its own row sets
     constexpr int AHEAD = HALF ? 6 : 3, NF = HALF ? 8 : 4, QAHEAD = HALF ? 4 : 2, NQ = HALF ? 8 : 3;
@@ -302,19 +389,32 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
         ftail = lds[G::OFF_A + (G::NMAIN + NS - 1) * 64 + lane];
       }
     }
+    WN4_STAMP(7);
     Cmd c;
-    if (t == 0) { c.hs = 0.0; c.op = inrange ? (OP_NEWITER | OP_INIT) : 0u; c.n = 0u; }
-    else {
-      WN4_STAMP(7);
-      uint32_t spins = 0;
-      while (!__all(cmd_is_for(cw, t))) {  // (bounded: a protocol error must not hang the GPU)
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 23)) { if (lane == 0) atomicExch(abort_flag, 1); return false; }
-        cmd_read(rec, cw, chs);
+    if constexpr (OPT_POLL) {
+      // the ordinary tick finds its record: ONE branch; the spin loop is out of the way
+      if (__builtin_expect(!__all(cmd_is_for(cw, t)), 0)) {
+        uint32_t spins = 0;
+        do {  // (bounded: a protocol error must not hang the GPU)
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 23)) { if (lane == 0) atomicExch(abort_flag, 1); return false; }
+          cmd_read(rec, cw, chs);
+        } while (!__all(cmd_is_for(cw, t)));
       }
       c.hs = chs; c.op = (uint32_t)cw & 0xFFFFu; c.n = (uint32_t)(cw >> 32);
-      WN4_STAMP(5);
+    } else {
+      if (t == 0) { c.hs = 0.0; c.op = inrange ? (OP_NEWITER | OP_INIT) : 0u; c.n = 0u; }
+      else {
+        uint32_t spins = 0;
+        while (!__all(cmd_is_for(cw, t))) {  // (bounded: a protocol error must not hang the GPU)
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 23)) { if (lane == 0) atomicExch(abort_flag, 1); return false; }
+          cmd_read(rec, cw, chs);
+        }
+        c.hs = chs; c.op = (uint32_t)cw & 0xFFFFu; c.n = (uint32_t)(cw >> 32);
+      }
     }
+    WN4_STAMP(5);
     const uint32_t op = c.op;
     double* const sp = sums + t3 * (G::NB * 16);
     const bool step = (op & OP_STEP) != 0;
@@ -324,24 +424,26 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     double keinit_part = 0.0, gen_part = 0.0;
     // ---- commands ----
     const bool deep0 = nchk > NFAST, deep1 = nchk > NFAST + 1;
-    // ONE vote for everything that does not happen on an ordinary leaf
+    // ONE vote for everything that does not happen on an ordinary leaf; `anydeep`: the sub-tree checks of levels >= 3 (SOME chain of the
+    // group closes such a sub-tree on two odd ticks in three)
     const bool anyrare = __any((op & (OP_PICK | OP_NEWITER | OP_SWAP | OP_UNDO | OP_DONE)) != 0 || deep0);
+    const bool anydeep = PAR == 1 && anyrare && __any(deep0);
+    if (anydeep) {  // (per chain, under exec masks: fetching both levels for every chain of the group cost 4 % -- vector-memory instructions are what a tick pays for)
+      if (deep0) {
+        const int sl = slot_of_leaf(n + 1 - (1 << NFAST));
+        const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
+#pragma unroll
+        for (int s = S0; s < S1; ++s) { pq0[s] = sq[s * 16]; pv0[s] = sv[s * 16]; }
+      }
+      if (deep1) {
+        const int sl = slot_of_leaf(n + 1 - (2 << NFAST));
+        const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
+#pragma unroll
+        for (int s = S0; s < S1; ++s) { pq1[s] = sq[s * 16]; pv1[s] = sv[s * 16]; }
+      }
+    }
     if (anyrare) {
       if (__any((op & OP_DONE) != 0)) return false;
-      if (PAR == 1 && __any(deep0)) {
-        if (deep0) {
-          const int sl = slot_of_leaf(n + 1 - (1 << NFAST));
-          const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
-#pragma unroll
-          for (int s = S0; s < S1; ++s) { pq0[s] = sq[s * 16]; pv0[s] = sv[s * 16]; }
-        }
-        if (deep1) {
-          const int sl = slot_of_leaf(n + 1 - (2 << NFAST));
-          const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
-#pragma unroll
-          for (int s = S0; s < S1; ++s) { pq1[s] = sq[s * 16]; pv1[s] = sv[s * 16]; }
-        }
-      }
       if (__any((op & OP_PICK) != 0)) {  // `pk` holds the position of tick t-3
         if (op & OP_PICK) {
           double* dst = gvec(vprop + ((op & OP_IPPICK) ? 1 : 0));
@@ -528,7 +630,16 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
       put4(sp, pl, pk, a1, a2);
     }
     if (PAR == 1) {
-      if (__any(nchk > 1)) {  // levels 1 (the leaf pair: registers) and 2 (LDS)
+      if constexpr (OPT_L12) {  // levels 1 (the leaf pair: registers) and 2 (LDS): on every odd tick, no vote (some chain of the group needs them on 15 odd ticks in 16;
+         // the sums of a chain that does not are never read)
+        double a1, a2, b1, b2;
+        dots(qc, vi, a1, a2);
+        double qo[NS], vo[NS];
+#pragma unroll
+        for (int s = S0; s < S1; ++s) { qo[s] = lc[s * 64]; vo[s] = lc[G::VEC + s * 64]; }
+        dots(qo, vo, b1, b2);
+        put4(sp + 16, a1, a2, b1, b2);
+      } else if (__any(nchk > 1)) {
         double a1, a2, b1 = 0.0, b2 = 0.0;
         dots(qc, vi, a1, a2);
         if (__any(nchk > 2)) {
@@ -539,8 +650,8 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
         }
         put4(sp + 16, a1, a2, b1, b2);
       }
-      if (anyrare) {
-        if (__any(nchk > 3)) {  // levels 3, 4: prefetched
+      if (anydeep) {
+        {  // levels 3, 4: prefetched
           double a1, a2, b1, b2;
           dots(pq0, pv0, a1, a2);
           dots(pq1, pv1, b1, b2);
@@ -568,12 +679,20 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     WN4_STAMP(2);
     // ---- statePush (:431,518): only sub-tree left endpoints are ever read back; they are even leaves ----
     if (PAR == 0) {
+      // the level-2 endpoint (LDS) is due for SOME chain of the group on 15 even ticks in 16: predicated stores, no vote, no branch
       const bool ep = step && i >= 2 && (n & 3) == 0;
-      if (__any(ep)) {
+      const bool epg = ep && (n == 0 ? (i >= NFAST) : (__builtin_ctz((unsigned)n) >= NFAST));  // ... levels >= 3 (memory) on two in three
+      if constexpr (OPT_EP) {
+        lds_store_qv_masked_all<NS, S0, S1>(__ballot(ep), lc, qn, v);
+        if (__any(epg)) {
+          const int sl = epg ? slot_of_leaf(n) : 0;
+          glb_store_qv_masked_all<NS, S0, S1>(__ballot(epg), gvec(sl * 2), gvec(sl * 2 + 1), qn, v);
+        }
+      } else if (__any(ep)) {
         if (ep) {
 #pragma unroll
           for (int s = S0; s < S1; ++s) { lc[s * 64] = qn[s]; lc[G::VEC + s * 64] = v[s]; }
-          if (n == 0 ? (i >= NFAST) : (__builtin_ctz((unsigned)n) >= NFAST)) {
+          if (epg) {
             const int sl = slot_of_leaf(n);
             double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
 #pragma unroll
@@ -589,6 +708,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
 #endif
     return true;
   };
+  if (HALF != 0 && OPT_POLL) cmd_read(pr + G::P_CMD + x * 2, cw_pre, chs_pre);  // tick 0's record (the kernel's prologue wrote it)
   int t3 = 0;
   for (uint32_t t = 0;; t += 2) {
     if (!tick(std::integral_constant<int, 0>{}, X1, X0, V1, V0, t, t3)) break;
@@ -807,12 +927,15 @@ __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, co
       // + 8).  Blocks 0..7 of the iteration stay (the direction bits of WALNUTS.py:216 are read until the last doubling).
       if (__any(need)) {
         const uint32_t nb = fresh ? 0u : (bk.ku >> 1);
+        // the two Philox passes below cost the WAVE the same whether one chain stores its sixteen blocks or all eight do: when one chain
+        // needs a refill, every chain slides its window to its own draw count (refills per wave: one in ~12 ticks instead of one in two)
+        const bool slide = OPT_SLIDE ? (inrange && bk.iter <= prm.numIter && (fresh || (bk.ku >> 1) > wbase + 1u)) : need;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
           const uint32_t blk = nb + (uint32_t)(rep + 8 * pass);
           const Philox4 p = philox4x32_10(blk, (uint32_t)bk.iter, bk.chain, 0u, (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32));
           const double u0 = u53(p.w[0], p.w[1]), u1 = u53(p.w[2], p.w[3]);
-          if (need) {
+          if (slide) {
             double* e = pr + G::P_URING + (x * 16 + (int)(blk & 15u)) * 3;
             e[1] = u0; e[2] = u1;
             asm volatile("" ::: "memory");  // values first, then the tag (the R wave reads the tag first)
@@ -825,7 +948,7 @@ __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, co
             }
           }
         }
-        if (need) { witer = bk.iter; wbase = nb; }
+        if (slide) { witer = bk.iter; wbase = nb; }
       }
     }
     WN4_STAMP(0);
