@@ -11,6 +11,7 @@ make_golden.py, and inputs + outputs are stored.  Run in the build container onl
 """
 import os
 import sys
+sys.dont_write_bytecode = True
 
 import numpy as np
 

@@ -136,3 +136,55 @@ def test_walnuts_argument_errors_match_reference():
             wa.walnuts_step(rng, np.zeros(2), lambda q: 0.0, lambda q: -q, np.ones(2), 1.0, 5, 0.1)
         with pytest.raises(ImportError):
             wa.walnuts_stan(rng, np.zeros(2), "model.stan", "data.json", np.ones(2), 1.0, 5, 0.1, 0, 1)  # no bridgestan here
+
+
+def test_hostrng_matches_generator_methods():
+    """walnuts_batch() consumes the callers' numpy Generators through numpy's own C distributions (csrc/wn_hostrng.c on libnpyrandom).
+    The contract (walnuts/walnuts.py:325,330,194,346,350): exactly the draws -- and the stream positions -- of per-chain
+    Generator.normal / binomial / choice / uniform / random calls in the reference's order, with the data-dependent skips (inactive
+    chains, no uniform after a sub-U-turn, random() only after an accept)."""
+    import ctypes as C
+    import importlib
+    W = importlib.import_module("walnuts_amd.walnuts")  # (the package exports the function `walnuts` under the same name)
+    hr = W._hostrng_lib()
+    assert hr is not None, "libwalnuts_hostrng.so is not built (make -C walnuts_amd/csrc)"
+    B, D = 37, 10
+    a = [np.random.default_rng(5 + c) for c in range(B)]
+    b = [np.random.default_rng(5 + c) for c in range(B)]
+    bg = W._bitgen_pointers(b)
+    assert bg is not None
+    assert W._bitgen_pointers([object()]) is None  # a stand-in without numpy's C interface: the per-chain Python calls are used
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    lm = np.geomspace(0.5, 2.0, D)
+    rho_py = np.stack([lm * a[c].normal(size=D) for c in range(B)])
+    rho_c = np.zeros((B, D))
+    hr.wn_hr_momentum(bg, B, D, vp(lm), vp(rho_c))
+    np.testing.assert_array_equal(rho_py, rho_c)
+    rng = np.random.default_rng(0)
+    for _ in range(120):
+        n = 1 << int(rng.integers(0, 7))
+        active = (rng.random(B) < 0.8).astype(np.int32)
+        bw_py = np.zeros(B, np.int32); lo_py = np.zeros((B, n), np.int32)
+        for c in range(B):
+            if active[c]:
+                bw_py[c] = int(bool(a[c].binomial(1, 0.5)))
+                lo_py[c] = [[0, 1, 2].index(int(a[c].choice([0, 1, 2]))) for _ in range(n)]  # the reference's call shape (:194)
+        bw_c = np.zeros(B, np.int32); lo_c = np.zeros((B, n), np.int32); scratch = np.zeros(n, np.uint64)
+        hr.wn_hr_extend_draws(bg, vp(active), B, n, vp(bw_c), vp(lo_c), vp(scratch))
+        np.testing.assert_array_equal(bw_py, bw_c)
+        np.testing.assert_array_equal(lo_py, lo_c)
+        sub = (rng.random(B) < 0.3).astype(np.int32)
+        u_py = np.zeros(B); u_c = np.zeros(B)
+        for c in range(B):
+            if active[c] and not sub[c]:
+                u_py[c] = a[c].uniform(0, 1)
+        hr.wn_hr_accept_uniforms(bg, vp(active), vp(sub), B, vp(u_c))
+        np.testing.assert_array_equal(u_py, u_c)
+        acc = ((rng.random(B) < 0.5) & (active == 1) & (sub == 0)).astype(np.int32)
+        r_py = np.zeros(B); r_c = np.zeros(B)
+        for c in range(B):
+            if acc[c]:
+                r_py[c] = a[c].random()
+        hr.wn_hr_choice_uniforms(bg, vp(acc), B, vp(r_c))
+        np.testing.assert_array_equal(r_py, r_c)
+    assert all(a[c].uniform() == b[c].uniform() for c in range(B))  # every stream at the same position

@@ -1,6 +1,8 @@
 """Cost distribution of one transition of the reference sampler walnuts/walnuts.py (gradient evaluations per walnuts_step call) on the 10-D
 standard normal with test/test.py parameters: run in the build container only (imports /root/reference).  profiles/r04_walnuts_tail.txt."""
-import importlib.util, sys, numpy as np, time
+import importlib.util, sys
+sys.dont_write_bytecode = True  # nothing is ever written into /root/reference (round 4 left a __pycache__ there: reported in DESIGN.md)
+import numpy as np, time
 spec = importlib.util.spec_from_file_location("walnuts_ref", "/root/reference/walnuts/walnuts.py")
 w = importlib.util.module_from_spec(spec); spec.loader.exec_module(w)
 D=10

@@ -15,6 +15,7 @@ reference (:379-380): the device then stops wherever the algorithm needs them, t
 waiting chain on the host, and the device carries on (the reference's contract at the reference's granularity).
 """
 import ctypes as C
+import os
 import warnings
 
 import numpy as np
@@ -57,6 +58,44 @@ def _resolve(logp, grad):
     if not (callable(logp) and callable(grad)):
         raise TypeError("logp and grad must be callables (theta -> float, theta -> (D,)) or walnuts_amd target descriptors")
     return None, (logp, grad)
+
+
+_HOSTRNG = None
+
+
+def _hostrng_lib():
+    """libwalnuts_hostrng.so (csrc/wn_hostrng.c): numpy's own C implementations of Generator.normal / binomial / integers / uniform /
+    random (libnpyrandom) called on the callers' bit generators -- the same streams as per-chain Python calls, without 4096 x 5
+    interpreter round trips per doubling.  None when it is not built (the per-chain Python calls below are then used: same draws)."""
+    global _HOSTRNG
+    if _HOSTRNG is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwalnuts_hostrng.so")
+        try:
+            lib = C.CDLL(path)
+            for name in ("wn_hr_momentum", "wn_hr_extend_draws", "wn_hr_accept_uniforms", "wn_hr_choice_uniforms"):
+                getattr(lib, name).restype = None
+            _HOSTRNG = lib
+        except OSError:
+            _HOSTRNG = False
+    return _HOSTRNG or None
+
+
+def _bitgen_pointers(rngs):
+    """(void*)[B] of the Generators' bitgen_t, or None when some `rng` is not a numpy Generator with a ctypes interface (stand-ins)."""
+    try:
+        ptrs = []
+        for g in rngs:
+            if not isinstance(g, np.random.Generator):
+                return None
+            a = g.bit_generator.ctypes.bit_generator
+            ptrs.append(a.value if hasattr(a, "value") else int(a))
+        return (C.c_void_p * len(ptrs))(*ptrs)
+    except Exception:
+        return None
+
+
+def _np(a):
+    return a.ctypes.data_as(C.c_void_p)
 
 
 class _Stepper:
@@ -126,40 +165,64 @@ class _Stepper:
         """One transition of every chain (walnuts.py:322-359); theta (B, D) -> next states (B, D)."""
         t, B, D = self.t, self.B, self.D
         L_mass = inv_mass ** -0.5
-        rho = np.stack([L_mass * rngs[b].normal(size=D) for b in range(B)])          # :325
+        hr = _hostrng_lib()
+        if hr is not None:  # the Generators' C interface: the same draws from the same streams, no per-chain interpreter calls
+            if getattr(self, "_bg_for", None) is not rngs:
+                self._bg, self._bg_for = _bitgen_pointers(rngs), rngs
+            if self._bg is None:
+                hr = None
+        bg = self._bg if hr is not None else None
+        if hr is not None:
+            rho = np.empty((B, D)); lm = np.ascontiguousarray(L_mass, dtype=np.float64)
+            hr.wn_hr_momentum(bg, B, D, _np(lm), _np(rho))                              # :325
+        else:
+            rho = np.stack([L_mass * rngs[b].normal(size=D) for b in range(B)])      # :325
         th_d, rho_d = self.dv(theta), self.dv(rho)
         self._ck(self.lib.wn_wstep_begin(self.h, self.p(th_d), self.p(rho_d), self._st()))
         self._serve(range(B))
         active = np.ones(B, dtype=np.int32)
         for depth in range(self.depth):                                               # :328
             n = 1 << depth
-            act = [b for b in range(B) if active[b]]
-            if not act:
+            if not active.any():
                 break
             backward = np.zeros(B, dtype=np.int32); lottery = np.zeros((B, n), dtype=np.int32)
-            for b in act:
-                backward[b] = int(bool(rngs[b].binomial(1, 0.5)))                     # :330
-                lottery[b] = [int(rngs[b].choice(3)) for _ in range(n)]              # :194, one per macro step (:256)
+            if hr is not None:
+                act = None
+                scratch = np.empty(n, dtype=np.uint64)
+                hr.wn_hr_extend_draws(bg, _np(active), B, n, _np(backward), _np(lottery), _np(scratch))  # :330, :194
+            else:
+                act = [b for b in range(B) if active[b]]
+                for b in act:
+                    backward[b] = int(bool(rngs[b].binomial(1, 0.5)))                     # :330
+                    lottery[b] = [int(rngs[b].choice(3)) for _ in range(n)]              # :194, one per macro step (:256)
             bw_d, lo_d, ac_d = self.dv(backward, t.int32), self.dv(lottery, t.int32), self.dv(active, t.int32)
             self._ck(self.lib.wn_wstep_extend(self.h, depth, self.p(bw_d), self.p(lo_d), self.p(ac_d), self.p(self.sub),
                                               self.p(self.lse_ext), self.p(self.lse_old), self._st()))
             self._serve(act)
             sub = self.sub.cpu().numpy(); le = self.lse_ext.cpu().numpy(); lo = self.lse_old.cpu().numpy()
             accept = np.zeros(B, dtype=np.int32); u_choice = np.zeros(B)
-            for b in act:
-                if sub[b]:                                                             # :343
-                    active[b] = 0
-                    continue
-                log_uniform = np.log(rngs[b].uniform(0, 1))                           # :346
-                if log_uniform < le[b] - lo[b]:                                       # :345-347
-                    accept[b] = 1
-                    u_choice[b] = rngs[b].random()                                    # Generator.choice(orbit_ext, p=p) :350
+            if hr is not None:
+                sub = np.ascontiguousarray(sub, dtype=np.int32)
+                u = np.ones(B)
+                hr.wn_hr_accept_uniforms(bg, _np(active), _np(sub), B, _np(u))         # :346 (not after a sub-U-turn, :343)
+                live = (active != 0) & (sub == 0)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    accept = (live & (np.log(u) < le - lo)).astype(np.int32)           # :345-347
+                hr.wn_hr_choice_uniforms(bg, _np(accept), B, _np(u_choice))            # Generator.choice(orbit_ext, p=p) :350
+                active[(active != 0) & (sub != 0)] = 0
+            else:
+                for b in act:
+                    if sub[b]:                                                             # :343
+                        active[b] = 0
+                        continue
+                    log_uniform = np.log(rngs[b].uniform(0, 1))                           # :346
+                    if log_uniform < le[b] - lo[b]:                                       # :345-347
+                        accept[b] = 1
+                        u_choice[b] = rngs[b].random()                                    # Generator.choice(orbit_ext, p=p) :350
             ac_d2, uc_d = self.dv(accept, t.int32), self.dv(u_choice)
             self._ck(self.lib.wn_wstep_commit(self.h, self.p(ac_d2), self.p(uc_d), self.p(self.uturn), self._st()))
             ut = self.uturn.cpu().numpy()
-            for b in act:
-                if active[b] and ut[b]:                                               # :352
-                    active[b] = 0
+            active[(active != 0) & (ut != 0)] = 0                                      # :352
         out = t.empty((B, D), dtype=t.float64, device=self.dev)
         self._ck(self.lib.wn_wstep_result(self.h, self.p(out), self._st()))
         return out.cpu().numpy()
