@@ -126,6 +126,11 @@ struct HostIO {
   int* ntrace;
   double* h0 = nullptr;  // (two-stream form) the iteration's initial Hamiltonian, retire side -> issue side
   void write_h0(double v) const { if (h0) *h0 = v; }
+  double* hc = nullptr;  // (two-stream form, warm-up) the adapted step size H, retire side -> issue side
+  void write_hc(double v) const { if (hc) *hc = v; }
+  double read_hc() const { return *hc; }
+  double* facs() const { return prm->facs ? prm->facs + (size_t)cl * 2 * (size_t)prm->warmupIter : nullptr; }
+  bool facs_writer() const { return true; }
   void trace_step(int iter, int i, int xi, double h, double ham0, double lpn) {
     const int row = (*ntrace)++;
     if (prm->trace && row < prm->trace_cap) {
@@ -201,6 +206,7 @@ static long run_lag(Params* prm, int target, int nlc, double* idle_frac) {
 }
 // the bookkeeper as two instruction streams (wn_fast.h RetireBook / IssueBook, wn_k_fast4.hip): per tick the retire side retires tick
 // t-2 from the command the T wave executed then and posts its message, the issue side applies it and issues tick t+1
+template <bool WARM>
 static long run_split(Params* prm, int target, int nlc, double* idle_frac) {
   constexpr int LAG = 3;
   const int D = prm->D;
@@ -213,10 +219,12 @@ static long run_split(Params* prm, int target, int nlc, double* idle_frac) {
     for (auto* x : {&T.q, &T.v, &T.g, &T.qb, &T.vb, &T.VL, &T.zn, &T.qhist[0], &T.qhist[1], &T.qhist[2], &T.prop[0], &T.prop[1]}) x->assign(D, 0.0);
     T.lq.assign(nlc + 1, std::vector<double>(D, 0.0)); T.lv = T.lq;
     T.sq.assign(prm->M + 2, std::vector<double>(D, 0.0)); T.sv = T.sq;
-    RetireBook R;
-    IssueBook I;
+    RetireBookT<WARM> R;  // (WARM: the instantiation of the kernels that run warm-up iterations, wn_k_fast4.hip -DWN4_WARM_TU)
+    IssueBookT<WARM> I;
     R.init(prm->chain0 + (uint32_t)cl, true, prm->numIter);
     I.init(prm->chain0 + (uint32_t)cl, true, prm->numIter);
+    R.init_warm(*prm);
+    I.init_warm(*prm);
     Cmd ring[4];  // the command of tick t in ring[t % 4]
     for (auto& c : ring) { c.hs = 0.0; c.n = 0; c.op = 0; }
     ring[0].op = OP_NEWITER | OP_INIT;
@@ -225,7 +233,7 @@ static long run_split(Params* prm, int target, int nlc, double* idle_frac) {
     const double cap = 64.0 + 1.3 * (double)prm->numIter * ((double)(1u << prm->M) + 6.0 * prm->M + 16.0);
     uint32_t t = 0;
     int ntrace = 0;
-    double h0_shared = 0.0;
+    double h0_shared = 0.0, hc_shared = prm->H;
     for (;; ++t) {
       if ((double)t > cap) return -1;
       if (I.zwant != I.zready && I.zwant >= 1) {  // momentum normals (the I wave)
@@ -236,7 +244,7 @@ static long run_split(Params* prm, int target, int nlc, double* idle_frac) {
       old.hs = 0.0; old.n = 0; old.op = 0;
       if (t + 1 >= (uint32_t)LAG) { memcpy(psums, hist[(t + 1 - LAG) % 3], sizeof(psums)); old = ring[(t + 1 - LAG) % 4]; }
       else memset(psums, 0, sizeof(psums));
-      HostIO io{prm, cl, psums, &ntrace, &h0_shared};
+      HostIO io{prm, cl, psums, &ntrace, &h0_shared, &hc_shared};
       const RMsg m = R.tick(*prm, io, old);           // retires tick t-2
       bool early = false;  // the first leaf of a doubling (tick t-1), certified by the issue side from the T wave's sums
       if (I.wants_early(t + 1, m)) early = IssueBook::early_certain(*prm, hist[(t - 1) % 3][Q_LP], hist[(t - 1) % 3][Q_KE], h0_shared);
@@ -256,7 +264,7 @@ static long run_split(Params* prm, int target, int nlc, double* idle_frac) {
 }
 // lag: 2, 3 = FastBookT<lag>; 4 = the two-stream form of lag 3
 extern "C" long fastsim_run2(Params* prm, int target, int nlc, double* idle_frac, int lag) {
-  if (lag == 4) return run_split(prm, target, nlc, idle_frac);
+  if (lag == 4) return prm->warmupIter > 0 ? run_split<true>(prm, target, nlc, idle_frac) : run_split<false>(prm, target, nlc, idle_frac);
   return lag == 3 ? run_lag<3>(prm, target, nlc, idle_frac) : run_lag<2>(prm, target, nlc, idle_frac);
 }
 extern "C" long fastsim_run(Params* prm, int target, int nlc, double* idle_frac) { return fastsim_run2(prm, target, nlc, idle_frac, 2); }

@@ -125,7 +125,8 @@ def fast_lib():
 
 
 def fast_walnuts(target, q0, tpar=None, H0=0.2, stepSizeRandScale=0.2, delta0=0.05, numIter=10, M=10, generated=0, gen_k=0,
-                 seed=0, chain0=0, nlc=2, trace_cap=0, lag=2):
+                 seed=0, chain0=0, nlc=2, trace_cap=0, lag=2, warmupIter=0, adaptH=True, adaptHtarget=0.8, adaptDelta=True,
+                 adaptDeltaTarget=0.6, adaptDeltaQuantile=0.9):
     """fixedLeapFrog on a std / diagonal / dense Gaussian through FastBookT<lag> + the scalar T-wave stand-in
     (lag 2: wn_k_fast.hip, lag 3: wn_k_fast4.hip)."""
     q0 = np.ascontiguousarray(np.atleast_2d(np.asarray(q0, float)))
@@ -147,6 +148,13 @@ def fast_walnuts(target, q0, tpar=None, H0=0.2, stepSizeRandScale=0.2, delta0=0.
         trace = np.zeros((Cn, trace_cap, 12 + 2 * D)); tn = np.zeros(Cn, dtype=np.int32)
         prm.trace = _p(trace); prm.trace_cap = trace_cap
         prm.trace_n = _p(tn, ip)
+    # warm-up adaptation of H and delta (WALNUTS.py:701-712): the two-stream form only (lag = 4, the headline kernel's bookkeeper)
+    assert warmupIter == 0 or lag == 4
+    prm.warmupIter = warmupIter if (adaptH or adaptDelta) else 0
+    prm.adaptH = int(adaptH); prm.adaptDelta = int(adaptDelta)
+    prm.adaptHtarget = adaptHtarget; prm.adaptDeltaTarget = adaptDeltaTarget; prm.adaptDeltaQuantile = adaptDeltaQuantile
+    facs = np.zeros((Cn, 2, max(warmupIter, 1)))
+    prm.facs = _p(facs)
     idle = C.c_double(0.0)
     ticks = fast_lib().fastsim_run2(C.byref(prm), target, nlc, C.byref(idle), lag)
     if ticks < 0:

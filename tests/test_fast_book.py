@@ -121,3 +121,22 @@ def test_bookkeeper_trace_rows_match_the_oracle(M, scale, lag):
         cols = [0, 1, 2, 6, 7, 8, 10, 11]
         np.testing.assert_array_equal(h["trace"][k, :n][:, cols], o["trace"][:n][:, cols])
         tg.close(h["trace"][k, :n], o["trace"][:n], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("adaptH,adaptDelta", [(True, True), (True, False), (False, True)])
+@pytest.mark.parametrize("D,warm,iters", [(7, 25, 32), (40, 60, 64)])
+def test_bookkeeper_warmup_adaptation_matches_the_oracle(D, warm, iters, adaptH, adaptDelta):
+    """Round 5: the headline kernel's bookkeeper runs the reference's DEFAULT call shape -- fixedLeapFrog with warm-up adaptation of
+    the step size H (P2 quantile of log igrConst, WALNUTS.py:313, P2quantile.py) and of the tolerance delta (np.quantile of the
+    energy-error factors, :701-712).  The retire side pushes and adapts, the issue side draws the next iteration's step sizes around
+    the new H: every draw, every diagnostics column (15 = H, 18 = delta of each iteration) as the oracle's."""
+    rng = np.random.default_rng(D + warm)
+    lam = np.logspace(0, 1.5, D)
+    q0 = rng.normal(size=(3, D)) * np.sqrt(lam)
+    kw = dict(H0=0.3, numIter=iters, M=6, generated=0, seed=31 + D, warmupIter=warm, adaptH=adaptH, adaptDelta=adaptDelta)
+    h = hs.fast_walnuts(ol.T_DIAGGAUSS, q0, tpar=1.0 / lam, chain0=5, lag=4, **kw)
+    for k in range(3):
+        o = ol.walnuts(ol.T_DIAGGAUSS, q0[k], integrator=ol.I_FIXED, tpar=1.0 / lam, chain=5 + k, **kw)
+        check(h, o, k, what=f"warm-up D={D} chain {k}")
+        if adaptH:
+            assert len(set(np.round(o["diagnostics"][:, 15], 12))) > 5  # H did adapt

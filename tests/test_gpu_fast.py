@@ -301,3 +301,36 @@ def test_pair_kernel_two_position_waves_per_group(wa, D, C):
         np.testing.assert_array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]], err_msg=f"chain {k}")
         close(s[k], o["samples"], what=f"chain {k}")
     print(f"two T waves per group {ms:.1f} ms, one {ms0:.1f} ms")
+
+
+@pytest.mark.parametrize("kind,D,C", [("dense", 100, 4096), ("dense", 100, 1024), ("dense", 40, 300), ("diag", 112, 2100), ("std", 10, 64)])
+def test_pair_kernel_runs_the_warmup_iterations(wa, kind, D, C):
+    """Round 5: the reference's DEFAULT call -- integrator=fixedLeapFrog with warm-up adaptation of H and delta
+    (WALNUTS.py:111-125, 313, 701-712) -- runs on the headline kernel: the retire wave pushes log(igrConst) into the P2 markers and adapts
+    H / delta at every warm-up iteration's end, the issue wave draws the next iteration's step sizes around the new H.  Per chain against
+    the oracle: H (col 15) and delta (col 18) of every iteration, the integer columns exactly, the draws.  With warm-up the two sides' D-term
+    sums are associated differently, and H is adapted from energy DIFFERENCES (DESIGN.md "Numerical note"): rtol 1e-5 on H / delta / draws."""
+    rng = np.random.default_rng(D + C)
+    if kind == "dense":
+        A, q0 = dense_problem(D, 1e2, C, 5)
+        tk, tp = ol.T_DENSEGAUSS, A.ravel()
+    elif kind == "diag":
+        lam = np.logspace(0, 1.5, D)
+        q0 = rng.normal(size=(C, D)) * np.sqrt(lam)
+        tk, tp = ol.T_DIAGGAUSS, 1.0 / lam
+    else:
+        q0 = rng.normal(size=(C, D))
+        tk, tp = ol.T_STDGAUSS, None
+    kw = dict(H0=0.3, delta0=0.05, M=6)
+    e = wa.Engine(D, C, integrator=ol.I_FIXED, warmupIter=14, chain_offset=50, **kw)
+    e.set_target(tk, tp)
+    assert "wn_fast4_kernel" in e.kernel_name, e.kernel_name
+    s, d = e.run(q0, SEED, 20)
+    s = s.transpose(1, 2).cpu().numpy(); d = d.cpu().numpy()
+    e.close()
+    for k in (0, 1, C // 2, C - 1):
+        o = ol.walnuts(tk, q0[k], integrator=ol.I_FIXED, tpar=tp, numIter=20, seed=SEED, chain=50 + k, warmupIter=14, **kw)
+        np.testing.assert_array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]], err_msg=f"{kind} chain {k}")
+        np.testing.assert_allclose(d[k][:, [15, 18]], o["diagnostics"][:, [15, 18]], rtol=1e-5, err_msg=f"H / delta, {kind} chain {k}")
+        assert len(set(np.round(d[k][:, 15], 12))) > 3  # H did adapt
+        np.testing.assert_allclose(s[k], o["samples"], rtol=1e-5, atol=1e-7, err_msg=f"draws, {kind} chain {k}")

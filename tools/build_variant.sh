@@ -14,6 +14,7 @@ for f in wn_capi wn_k_lane wn_k_coop wn_k_fast wn_k_fast4 wn_k_wave wn_k_orbit w
   [ $f = wn_k_gemm ] && FL="$FL -mllvm -amdgpu-mfma-vgpr-form"
   ( /opt/rocm/bin/hipcc $FL -c $f.hip -o build_$NAME/$f.o ) &
 done
+( /opt/rocm/bin/hipcc $FLAGS -DWN4_WARM_TU=1 -c wn_k_fast4.hip -o build_$NAME/wn_k_fast4w.o ) &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o ../libwalnuts_amd_$NAME.so build_$NAME/*.o
 echo built ../libwalnuts_amd_$NAME.so

@@ -492,7 +492,9 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
                             (size_t)D * sizeof(double), (size_t)D, hipMemcpyDeviceToDevice));
     }
   }
-  if (kc.layout == 1 && e->cfg.integrator == WN_I_FIXED && e->cfg.warmup_iter == 0 && e->cfg.M <= 11 && D <= 112 && !(kc.p1 == CK_DENSE && kc.p0 == 32) &&
+  const bool warm_run = e->cfg.warmup_iter > 0 && (e->cfg.adapt_h || e->cfg.adapt_delta);  // (otherwise nothing adapts: the plain kernels are exact)
+  const bool fast4_geom = (kc.p1 != CK_DENSE || D <= 100) && !getenv("WN_FAST_LEGACY");     // wn_k_fast4.hip also runs the warm-up iterations
+  if (kc.layout == 1 && e->cfg.integrator == WN_I_FIXED && (!warm_run || fast4_geom) && e->cfg.M <= 11 && D <= 112 && !(kc.p1 == CK_DENSE && kc.p0 == 32) &&
       !getenv("WN_COOP_LEGACY")) {
     // plain sampling runs of this engine go to the role-split kernel (wn_k_fast.hip); traced / orbit-statistics
     // runs and wn_integrator_step use the one-stream kernel of the same layout
@@ -501,7 +503,7 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
     (void)NT;
     // dense, D <= 100: wave pairs of four chains (wn_k_fast4.hip), traced runs too.  (4096 chains: 1.24e9 steps/s against the
     // seven-wave kernel's 1.12e9; 1024 chains are 256 pairs, one per CU, where that kernel fills 64 CUs: 3.9e8 against 2.8e8.)
-    if ((kc.p1 != CK_DENSE || D <= 100) && !getenv("WN_FAST_LEGACY"))
+    if (fast4_geom)
     {
       const int pr_ = fast4_pairs(e->cfg.n_chains);
       const bool halves = kc.p1 == CK_DENSE && D > 64 && pr_ == 1 && !getenv("WN_FAST4_WHOLE");  // (fast4_go: a group on two T waves)

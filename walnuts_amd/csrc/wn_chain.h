@@ -172,6 +172,101 @@ struct alignas(16) ChainScalars {
   WN_HD static void copy(ChainScalars& d_, const ChainScalars& s_) { WN_CS_FIELDS(WN_CS_COPY, WN_CS_COPYA) }
 };
 
+// ------------------------------------------------------------------------------------------
+// warm-up adaptation (WALNUTS.py:701-712), shared by the engine below and by the retire side of the headline kernel
+// (wn_fast.h).  P2quantile.py:41-86 on registers (every replica of a chain runs it identically); the exact quantile of
+// energyErrorInfFacs[0:iterN] (np.quantile, method "linear") reads a sorted copy in memory that only the writer lane
+// extends, into the other half of a double buffer, so readers never race with the insertion.
+// ------------------------------------------------------------------------------------------
+WN_HD bool wn_p2_after(double a, double b) { return a > b || (isnan(a) && !isnan(b)); }  // np.sort order
+WN_HD void wn_p2_cswap(double (&p2q)[5], int i, int j) {
+  // (select form everywhere below: a store through a run-time choice of two elements' addresses keeps the array -- and with it the
+  //  whole bookkeeper -- in scratch memory)
+  const double a = p2q[i], b = p2q[j];
+  const bool sw = wn_p2_after(a, b);
+  p2q[i] = sw ? b : a; p2q[j] = sw ? a : b;
+}
+WN_HD void wn_p2_push(const Params& prm, double (&p2q)[5], int (&p2m)[5], int& p2n, double xi) {
+  p2n++;
+  if (p2n <= 5) {  // self.x[npush-1] = xi; (quantile() is not read before npush > 10)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) p2q[j] = (j == p2n - 1) ? xi : p2q[j];
+    if (p2n == 5) {  // np.sort (9-comparator network), self.q = self.x
+      wn_p2_cswap(p2q, 0, 1); wn_p2_cswap(p2q, 3, 4); wn_p2_cswap(p2q, 2, 4); wn_p2_cswap(p2q, 2, 3); wn_p2_cswap(p2q, 0, 3);
+      wn_p2_cswap(p2q, 0, 2); wn_p2_cswap(p2q, 1, 4); wn_p2_cswap(p2q, 1, 3); wn_p2_cswap(p2q, 1, 2);
+    }
+    return;
+  }
+  int k;  // findInterval :31-38 (None when xi == q[4] or xi is NaN -> every marker moves)
+  if (xi < p2q[0]) k = 0;
+  else if (xi > p2q[4]) k = 5;
+  else k = xi < p2q[1] ? 1 : xi < p2q[2] ? 2 : xi < p2q[3] ? 3 : xi < p2q[4] ? 4 : -1;
+  p2q[0] = k == 0 ? xi : p2q[0];
+  p2q[4] = k == 5 ? xi : p2q[4];
+  k = k == 0 ? 1 : k == 5 ? 4 : k;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) p2m[j] += (j >= k) ? 1 : 0;  // self.n[k:5] += 1
+  const double nn = (double)p2n, pp = 1.0 - prm.adaptHtarget;
+  const double npp[5] = {1.0, 0.5 * (nn - 1) * pp + 1.0, (nn - 1) * pp + 1.0, (nn - 1) * (1 + pp) / 2.0 + 1, nn};
+#pragma unroll
+  for (int i = 2; i < 5; ++i) {  // :71-86
+    const int ni = p2m[i - 1], nip = p2m[i], nim = p2m[i - 2];
+    const double di = npp[i - 1] - (double)ni;
+    if ((di >= 1.0 && nip - ni > 1) || (di <= -1.0 && nim - ni < -1)) {
+      const int d = di > 0 ? 1 : -1;
+      const double qi = p2q[i - 1];
+      const double qip = qi + ((double)d / (double)(nip - nim)) *
+                                  ((double)(ni - nim + d) * (p2q[i] - qi) / (double)(nip - ni) +
+                                   (double)(nip - ni - d) * (qi - p2q[i - 2]) / (double)(ni - nim));
+      const double qn = d > 0 ? p2q[i] : p2q[i - 2];
+      const int mn = d > 0 ? p2m[i] : p2m[i - 2];
+      const double qlin = qi + (double)d * (qn - qi) / (double)(mn - p2m[i - 1]);
+      p2q[i - 1] = (p2q[i - 2] < qip && qip < p2q[i]) ? qip : qlin;
+      p2m[i - 1] += d;
+    }
+  }
+}
+// `fc`: this chain's (this workgroup's) sorted copies [2][warmupIter]; `writer`: the one lane that extends them
+WN_HD void wn_adapt_update(const Params& prm, int iter, double orbitEnergyError, double* fc, bool writer, double& dc, double& Hc,
+                                  const double (&p2q)[5], int p2n) {
+  if (prm.adaptDelta) {
+    const int n0 = iter - 1;  // values stored so far
+    const size_t W_ = (size_t)prm.warmupIter;
+    const double* cur = fc + (size_t)(n0 & 1) * W_;
+    double* nxt = fc + (size_t)((n0 + 1) & 1) * W_;
+    const double x = orbitEnergyError / dc;  // :704
+    // position of x in the sorted array (NaNs sort last): number of elements that stay before it
+    int lo = 0, hi = n0;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const double a = cur[mid];
+      if (wn_p2_after(x, a) || x == a) lo = mid + 1; else hi = mid;  // a <= x (NaN-last order)
+    }
+    const int pos = lo, n = n0 + 1;
+    if (iter > 10) {  // :705-707  delta = adaptDeltaTarget / np.quantile(facs[0:iterN], q)
+      auto elem = [&](int r) -> double { return r < pos ? cur[r] : (r == pos ? x : cur[r - 1]); };
+      double res;
+      if (isnan(elem(n - 1))) res = NAN;
+      else {
+        const double vi = (double)(n - 1) * prm.adaptDeltaQuantile;
+        int prev = (int)floor(vi), next = prev + 1;
+        double gamma = vi - (double)prev;
+        if (vi >= (double)(n - 1)) { prev = n - 1; next = n - 1; gamma = vi + 1.0; }
+        if (vi < 0) { prev = 0; next = 0; gamma = vi; }
+        const double A = elem(prev), B = elem(next), dba = B - A;
+        res = gamma >= 0.5 ? (B - dba * (1 - gamma)) : (A + dba * gamma);
+      }
+      dc = prm.adaptDeltaTarget / res;
+    }
+    if (writer) {  // extend the sorted copy into the other buffer
+      for (int r = 0; r < pos; ++r) nxt[r] = cur[r];
+      nxt[pos] = x;
+      for (int r = pos; r < n0; ++r) nxt[r + 1] = cur[r];
+    }
+  }
+  if (prm.adaptH && p2n > 10) Hc = pow(dc, 1.0 / 3.0) * exp(p2q[2]);  // :711-712
+}
+
 // FLOW: adaptLeapFrogFlowD (adaptiveIntegrators.py:246-356) -- the search of adaptLeapFrogD with
 // c = 0..maxC, two gradient evaluations per micro step (new position, then the midpoint of
 // adaptiveIntegrators.py:272) and the flow-error criterion max(Errs) < delta (:294).  Implies ADAPT.
@@ -826,94 +921,12 @@ struct Engine : ChainScalars {
   }
 
   // ------------------------------------------------------------------------------------------
-  // warm-up adaptation (WALNUTS.py:701-712).  P2quantile.py:41-86 on registers (every replica
-  // of a chain runs it identically); the exact quantile of energyErrorInfFacs[0:iterN]
-  // (np.quantile, method "linear") reads a sorted copy in memory that only the writer lane
-  // extends, into the other half of a double buffer, so readers never race with the insertion.
+  // warm-up adaptation (WALNUTS.py:701-712): wn_p2_push / wn_adapt_update above, on this chain's scalars
   // ------------------------------------------------------------------------------------------
-  WN_HD static bool p2_after(double a, double b) { return a > b || (isnan(a) && !isnan(b)); }  // np.sort order
-  WN_HD void p2_cswap(int i, int j) {
-    if (p2_after(p2q[i], p2q[j])) { double t = p2q[i]; p2q[i] = p2q[j]; p2q[j] = t; }
-  }
-  WN_HD void p2_push(double xi) {
-    p2n++;
-    if (p2n <= 5) {  // self.x[npush-1] = xi; (quantile() is not read before npush > 10)
-#pragma unroll
-      for (int j = 0; j < 5; ++j) if (j == p2n - 1) p2q[j] = xi;
-      if (p2n == 5) {  // np.sort (9-comparator network), self.q = self.x
-        p2_cswap(0, 1); p2_cswap(3, 4); p2_cswap(2, 4); p2_cswap(2, 3); p2_cswap(0, 3);
-        p2_cswap(0, 2); p2_cswap(1, 4); p2_cswap(1, 3); p2_cswap(1, 2);
-      }
-      return;
-    }
-    int k;  // findInterval :31-38 (None when xi == q[4] or xi is NaN -> every marker moves)
-    if (xi < p2q[0]) k = 0;
-    else if (xi > p2q[4]) k = 5;
-    else k = xi < p2q[1] ? 1 : xi < p2q[2] ? 2 : xi < p2q[3] ? 3 : xi < p2q[4] ? 4 : -1;
-    if (k == 0) { p2q[0] = xi; k = 1; }
-    else if (k == 5) { p2q[4] = xi; k = 4; }
-#pragma unroll
-    for (int j = 0; j < 5; ++j) if (j >= k) p2m[j] += 1;  // self.n[k:5] += 1
-    const double nn = (double)p2n, pp = 1.0 - prm.adaptHtarget;
-    const double npp[5] = {1.0, 0.5 * (nn - 1) * pp + 1.0, (nn - 1) * pp + 1.0, (nn - 1) * (1 + pp) / 2.0 + 1, nn};
-#pragma unroll
-    for (int i = 2; i < 5; ++i) {  // :71-86
-      const int ni = p2m[i - 1], nip = p2m[i], nim = p2m[i - 2];
-      const double di = npp[i - 1] - (double)ni;
-      if ((di >= 1.0 && nip - ni > 1) || (di <= -1.0 && nim - ni < -1)) {
-        const int d = di > 0 ? 1 : -1;
-        const double qi = p2q[i - 1];
-        const double qip = qi + ((double)d / (double)(nip - nim)) *
-                                    ((double)(ni - nim + d) * (p2q[i] - qi) / (double)(nip - ni) +
-                                     (double)(nip - ni - d) * (qi - p2q[i - 2]) / (double)(ni - nim));
-        if (p2q[i - 2] < qip && qip < p2q[i]) p2q[i - 1] = qip;
-        else {
-          const double qn = d > 0 ? p2q[i] : p2q[i - 2];
-          const int mn = d > 0 ? p2m[i] : p2m[i - 2];
-          p2q[i - 1] = qi + (double)d * (qn - qi) / (double)(mn - p2m[i - 1]);
-        }
-        p2m[i - 1] += d;
-      }
-    }
-  }
-
+  WN_HD void p2_push(double xi) { wn_p2_push(prm, p2q, p2m, p2n, xi); }
   WN_HD void adapt_update(double orbitEnergyError) {
-    if (prm.adaptDelta) {
-      const int n0 = iter - 1;  // values stored so far
-      const size_t W_ = (size_t)prm.warmupIter;
-      const double* cur = prm.facs + ((size_t)p.facs_slot() * 2 + (size_t)(n0 & 1)) * W_;
-      double* nxt = prm.facs + ((size_t)p.facs_slot() * 2 + (size_t)((n0 + 1) & 1)) * W_;
-      const double x = orbitEnergyError / dc;  // :704
-      // position of x in the sorted array (NaNs sort last): number of elements that stay before it
-      int lo = 0, hi = n0;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        const double a = cur[mid];
-        if (p2_after(x, a) || x == a) lo = mid + 1; else hi = mid;  // a <= x (NaN-last order)
-      }
-      const int pos = lo, n = n0 + 1;
-      if (iter > 10) {  // :705-707  delta = adaptDeltaTarget / np.quantile(facs[0:iterN], q)
-        auto elem = [&](int r) -> double { return r < pos ? cur[r] : (r == pos ? x : cur[r - 1]); };
-        double res;
-        if (isnan(elem(n - 1))) res = NAN;
-        else {
-          const double vi = (double)(n - 1) * prm.adaptDeltaQuantile;
-          int prev = (int)floor(vi), next = prev + 1;
-          double gamma = vi - (double)prev;
-          if (vi >= (double)(n - 1)) { prev = n - 1; next = n - 1; gamma = vi + 1.0; }
-          if (vi < 0) { prev = 0; next = 0; gamma = vi; }
-          const double A = elem(prev), B = elem(next), dba = B - A;
-          res = gamma >= 0.5 ? (B - dba * (1 - gamma)) : (A + dba * gamma);
-        }
-        dc = prm.adaptDeltaTarget / res;
-      }
-      if (p.wg_writer()) {  // extend the sorted copy into the other buffer
-        for (int r = 0; r < pos; ++r) nxt[r] = cur[r];
-        nxt[pos] = x;
-        for (int r = pos; r < n0; ++r) nxt[r + 1] = cur[r];
-      }
-    }
-    if (prm.adaptH && p2n > 10) Hc = pow(dc, 1.0 / 3.0) * exp(p2q[2]);  // :711-712
+    double* const fc = prm.facs ? prm.facs + (size_t)p.facs_slot() * 2 * (size_t)prm.warmupIter : nullptr;
+    wn_adapt_update(prm, iter, orbitEnergyError, fc, p.wg_writer(), dc, Hc, p2q, p2n);
   }
 
   WN_HD void end_iteration() {  // :653-695

@@ -489,7 +489,9 @@ struct BookUniforms {  // the chain's uniform stream (wn_rng.h stream 0) behind 
   }
 };
 
-struct RetireBook : BookUniforms {
+// WARM: the instantiation that also runs warm-up adaptation (a compile-time switch: the plain kernels carry none of it)
+template <bool WARM>
+struct RetireBookT : BookUniforms {
   double H0, Ha, Hb, lpP, lpPL, WoldSum, WnewSum;
   double orbitLen_, orbitLenSam_, indexStat_, indexStatOld_, timeLenF_, timeLenB_, Hmin, Hmax;
   int i, xi, a, b, nleaf, n_rt;
@@ -499,7 +501,17 @@ struct RetireBook : BookUniforms {
   int pick_ip, zwant;
   uint32_t ev;
   double pre_lpn, pre_Hn, pre_Wsum, pre_ratio;
+  // warm-up adaptation (WALNUTS.py:120-127, 313, 701-712; round 5): the chain's step size H and tolerance delta, the P2 markers of
+  // log(igrConst) -- wn_chain.h wn_p2_push / wn_adapt_update, the engine's own functions.  Runs without warm-up never touch them
+  // (prm.warmupIter = 0: Hc stays prm.H bit for bit).
+  double Hc, dc, p2q[5];
+  int p2m[5], p2n;
 
+  WN_HD void init_warm(const Params& prm) {
+    Hc = prm.H; dc = prm.delta; p2n = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { p2q[k] = 0.0; p2m[k] = k + 1; }
+  }
   WN_HD void init(uint32_t chain_global, bool inrange, int numIter) {
     chain = chain_global; iter = 1; cblk = 0xFFFFFFFFu; cu0 = cu1 = 0.0;
     H0 = Ha = Hb = lpP = lpPL = 0.0; WoldSum = 1.0; WnewSum = 0.0;
@@ -533,10 +545,14 @@ struct RetireBook : BookUniforms {
     d[6] = nevalF; d[7] = 0.0;
     d[8] = 0; d[9] = 0; d[10] = 0.0; d[11] = 0.0;  // fixedLeapFrog: If = Ib = c = 0, lwt = 0 (adaptiveIntegrators.py:57-59)
     d[12] = 0.0; d[13] = 0.0; d[14] = 0.0;
-    d[15] = prm.H; d[16] = 1.0;
+    d[15] = WARM ? Hc : prm.H; d[16] = 1.0;
     d[17] = Hnan ? NAN : (Hmax - Hmin);
-    d[18] = prm.delta; d[19] = (double)stopCode; d[20] = NdC; d[21] = 0; d[22] = 0;
+    d[18] = WARM ? dc : prm.delta; d[19] = (double)stopCode; d[20] = NdC; d[21] = 0; d[22] = 0;
     d[23] = indexStat_;
+    if constexpr (WARM) if (iter <= prm.warmupIter) {  // tuning parameter adaptation (:701-712) -- after the row is filled: it records the values this iteration ran with
+      wn_adapt_update(prm, iter, d[17], io.facs(), io.facs_writer(), dc, Hc, p2q, p2n);
+      io.write_hc(Hc);  // (the issue side draws the next iteration's step sizes around the new H; it reads this behind the RM_END message)
+    }
     io.write_diag((size_t)(iter - 1), d);
     iter++;
     discarding = true;  // the leaves in flight belong to the orbit that just ended: every step up to the next iteration start
@@ -578,6 +594,8 @@ struct RetireBook : BookUniforms {
     const bool first = (i == 0) || ((n & 1) == 0);
     const int idx = xi > 0 ? b + 1 + n : a - 1 - n;
     io.trace_step(iter, i, xi, h, Ha, lpn);
+    if constexpr (WARM) if (iter <= prm.warmupIter && prm.adaptH)  // igrConstQ.push(np.log(intOut.igrConst)) :313; igrConst of fixedLeapFrog: adaptiveIntegrators.py:59
+      wn_p2_push(prm, p2q, p2m, p2n, log(h * pow(fmax(1.0e-10, fabs(Ha - Hn)), -1.0 / 3.0)));
     if (i == 0) ku += 1;                 // :298  the step size was drawn before the step
     else if ((n & 1) == 0) ku += 2;      // :395  size=2, before the first step of the pair
     nevalF += 1;
@@ -663,14 +681,19 @@ struct RetireBook : BookUniforms {
   }
 };
 
-struct IssueBook : BookUniforms {
+using RetireBook = RetireBookT<false>;
+
+template <bool WARM>
+struct IssueBookT : BookUniforms {
   enum { ST_NEEDITER = 0, ST_FIRST, ST_RUN, ST_DRAIN, ST_DEAD };
   int st, i, xi, nleaf, n_is, n_rt;
   uint32_t ku;
   bool certain, swap_next, c1step, c2step, rdead;
   double h2;
   int zwant, zready, ip;
+  double Hc;  // the chain's step size H (warm-up adapts it on the retire side: read behind every RM_END of a warm-up iteration)
 
+  WN_HD void init_warm(const Params& prm) { Hc = prm.H; }
   WN_HD void init(uint32_t chain_global, bool inrange, int numIter) {
     chain = chain_global; iter = 1; cblk = 0xFFFFFFFFu; cu0 = cu1 = 0.0;
     st = inrange ? ST_NEEDITER : ST_DEAD;
@@ -679,8 +702,9 @@ struct IssueBook : BookUniforms {
     h2 = 0.0;
     zwant = (inrange && numIter >= 1) ? 1 : 0; zready = 0; ip = 0;
   }
-  WN_HD static double h_from(const Params& prm, double Uu) {  // numpy legacy uniform(low, high) = low + (high-low)*U
-    const double low = prm.H * (1 - prm.s), high = prm.H * (1 + prm.s);
+  WN_HD double h_from(const Params& prm, double Uu) const {  // numpy legacy uniform(low, high) = low + (high-low)*U
+    const double Hx = WARM ? Hc : prm.H;
+    const double low = Hx * (1 - prm.s), high = Hx * (1 + prm.s);
     return low + (high - low) * Uu;
   }
   template <class IO>
@@ -714,6 +738,7 @@ struct IssueBook : BookUniforms {
       const int u = (c1step ? 1 : 0) + (c2step ? 1 : 0);
       if (u > 0) c.op |= OP_UNDO | (u > 1 ? OP_UNDO2 : 0u);
       c1step = c2step = false;
+      if constexpr (WARM) if (iter <= prm.warmupIter) Hc = io.read_hc();  // (`iter` is still the iteration that just ended: warm-up adapted its H, :711-712)
       st = ST_NEEDITER; iter = (int)m.iter; ip = (m.w & RM_IP) ? 1 : 0;
       swap_next = false;
       cblk = 0xFFFFFFFFu;  // the uniform cache is keyed by block only
@@ -780,6 +805,7 @@ struct IssueBook : BookUniforms {
   }
   WN_HD bool finished() const { return st == ST_DEAD && rdead; }
 };
+using IssueBook = IssueBookT<false>;
 
 }  // namespace fast
 }  // namespace wn

@@ -76,7 +76,8 @@ struct Fast4Geom {
   // finished, [6] the run is over (the last two in the FIRST pair of a quad only)
   static constexpr int P_SEQ = P_URING + 4 * 16 * 3;
   static constexpr int P_H0 = P_SEQ + 8;               // the running iteration's initial Hamiltonian per chain (R wave -> I wave)
-  static constexpr int PAIR_DOUBLES = P_H0 + 4;
+  static constexpr int P_HC = P_H0 + 4;                // warm-up: the chain's adapted step size H (R wave -> I wave, behind an RM_END message)
+  static constexpr int PAIR_DOUBLES = P_HC + 4;
   // "halves" (one 4-chain group on TWO T waves, configs[1]'s 1024 chains: fast4_halves): a second position stage (the two waves of a group
   // are a tick apart at most), the second wave's sums, two hand-off words
   static constexpr int P_STAGE2 = PAIR_DOUBLES;
@@ -743,6 +744,12 @@ struct Fast4IO {
     return t0 == (uint32_t)iter && t1 == blk;
   }
   __device__ __forceinline__ void write_h0(double v) const { if (rep == 0) *(lds_vf64*)(pr + G::P_H0 + x) = v; }
+  // warm-up (WALNUTS.py:701-712): the adapted H goes to the issue side through LDS, written before the message that ends the iteration
+  // (same wave, in order); the sorted energy-error factors of the delta quantile live in memory, [chain][2][warmupIter], one writer
+  __device__ __forceinline__ void write_hc(double v) const { if (rep == 0) *(lds_vf64*)(pr + G::P_HC + x) = v; }
+  __device__ __forceinline__ double read_hc() const { return *(const lds_vf64*)(pr + G::P_HC + x); }
+  __device__ __forceinline__ double* facs() const { return prm->facs ? prm->facs + (size_t)cl * 2 * (size_t)prm->warmupIter : nullptr; }
+  __device__ __forceinline__ bool facs_writer() const { return rep == 0; }
   __device__ __forceinline__ void write_gen(size_t row, double v) const {
     if (rep == 0) prm->samples[((size_t)cl * (prm->numIter + 1) + row) * prm->dg + 1] = v;
   }
@@ -776,7 +783,7 @@ __device__ __forceinline__ bool seq_wait2(const lds_vu32* p, uint32_t want, cons
 }
 
 // HALVES: the group's vectors are on two T waves -- the R wave waits for both (odd replicas watch the second wave's word) and adds their sums
-template <class G, bool TRACE, bool HALVES = false>
+template <class G, bool TRACE, bool HALVES = false, bool WARM = false>
 __device__ __forceinline__ void fast4_r_wave(const Params& prm, double* quad, const int grp0, const int npairs, int* abort_flag) {
   const int lane = threadIdx.x & 63, c8 = lane & 7, pq = c8 >> 2, x = c8 & 3, rep = lane >> 3;
   constexpr int H2 = G::P_SUMS2 - G::P_SUMS;  // from a sum of the first T wave to the same sum of the second
@@ -787,8 +794,9 @@ __device__ __forceinline__ void fast4_r_wave(const Params& prm, double* quad, co
   RMsg* const msgbuf = reinterpret_cast<RMsg*>(pr + G::P_MSG);
   const lds_vu32* const seqT = lds_words(pr + G::P_SEQ) + (HALVES ? (rep & 1) : 0);
   lds_vu32* const seqQ = lds_words(quad + G::P_SEQ);  // [4]: R ticks finished, [6]: over
-  RetireBook bk;
+  RetireBookT<WARM> bk;
   bk.init(prm.chain0 + (uint32_t)cl, inrange, prm.numIter);
+  bk.init_warm(prm);
   Fast4IO<G, TRACE> io;
   io.prm = &prm; io.pr = pr; io.cl = cl; io.x = x; io.rep = rep;
   io.lp = io.ke = io.keinit = io.gen = 0.0; io.fire = 0u; io.ntrace = 0;
@@ -855,7 +863,7 @@ __device__ __forceinline__ void fast4_r_wave(const Params& prm, double* quad, co
   if (TRACE && prm.trace_n && inrange && rep == 0) prm.trace_n[cl] = io.ntrace;
 }
 
-template <class G, bool TRACE, bool HALVES = false>
+template <class G, bool TRACE, bool HALVES = false, bool WARM = false>
 __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, const int grp0, const int npairs, int* abort_flag) {
   const int lane = threadIdx.x & 63, c8 = lane & 7, pq = c8 >> 2, x = c8 & 3, rep = lane >> 3;
   const int cl = (grp0 + pq) * 4 + x;
@@ -863,8 +871,9 @@ __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, co
   double* const pr = quad + (size_t)(pq < npairs ? pq : 0) * G::PAIR_DOUBLES;
   const RMsg* const msgbuf = reinterpret_cast<const RMsg*>(pr + G::P_MSG);
   lds_vu32* const seqQ = lds_words(quad + G::P_SEQ);    // [4]: R ticks finished, [6]: over
-  IssueBook bk;
+  IssueBookT<WARM> bk;
   bk.init(prm.chain0 + (uint32_t)cl, inrange, prm.numIter);
+  bk.init_warm(prm);
   Fast4IO<G, TRACE> io;
   io.prm = &prm; io.pr = pr; io.cl = cl; io.x = x; io.rep = rep;
   io.lp = io.ke = io.keinit = io.gen = 0.0; io.fire = 0u; io.ntrace = 0;
@@ -1028,7 +1037,9 @@ __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, co
   WN4_STAMP_OUT(prm)
 }
 
-template <int NS, bool TAIL, bool TRACE, bool DENSE, bool HALVES = false>
+// WARM: the retire / issue waves also run warm-up adaptation of H and delta (wn_fast.h RetireBookT<true> / IssueBookT<true>); these
+// instantiations are compiled in a translation unit of their own (-DWN4_WARM_TU, csrc/Makefile: wn_k_fast4w.o)
+template <int NS, bool TAIL, bool TRACE, bool DENSE, bool HALVES = false, bool WARM = false>
 __global__ __launch_bounds__(HALVES ? 256 : 512) void wn_fast4_kernel(Params prm, int* abort_flag, int pairs) {
   using G = Fast4Geom<NS, TAIL, DENSE>;
   extern __shared__ double lds[];
@@ -1064,8 +1075,8 @@ __global__ __launch_bounds__(HALVES ? 256 : 512) void wn_fast4_kernel(Params prm
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if constexpr (HALVES) {  // one group per workgroup: R I Ta Tb, a SIMD each
     double* pr = lds + G::OFF_PAIR;
-    if (wave == 0) fast4_r_wave<G, TRACE, true>(prm, pr, (int)blockIdx.x, 1, abort_flag);
-    else if (wave == 1) fast4_i_wave<G, TRACE, true>(prm, pr, (int)blockIdx.x, 1, abort_flag);
+    if (wave == 0) fast4_r_wave<G, TRACE, true, WARM>(prm, pr, (int)blockIdx.x, 1, abort_flag);
+    else if (wave == 1) fast4_i_wave<G, TRACE, true, WARM>(prm, pr, (int)blockIdx.x, 1, abort_flag);
     else if (wave == 2) fast4_t_wave<G, TRACE, 1>(prm, lds, pr, (int)blockIdx.x, abort_flag);
     else fast4_t_wave<G, TRACE, 2>(prm, lds, pr, (int)blockIdx.x, abort_flag);
     return;
@@ -1098,15 +1109,18 @@ __global__ __launch_bounds__(HALVES ? 256 : 512) void wn_fast4_kernel(Params prm
     const int quad = bw >> 1;
     double* qd = lds + G::OFF_PAIR + (size_t)(2 * quad) * G::PAIR_DOUBLES;
     const int np = pairs - 2 * quad >= 2 ? 2 : 1;
-    if (bw & 1) fast4_i_wave<G, TRACE>(prm, qd, (int)blockIdx.x * pairs + 2 * quad, np, abort_flag);
-    else fast4_r_wave<G, TRACE>(prm, qd, (int)blockIdx.x * pairs + 2 * quad, np, abort_flag);
+    if (bw & 1) fast4_i_wave<G, TRACE, false, WARM>(prm, qd, (int)blockIdx.x * pairs + 2 * quad, np, abort_flag);
+    else fast4_r_wave<G, TRACE, false, WARM>(prm, qd, (int)blockIdx.x * pairs + 2 * quad, np, abort_flag);
   }
 }
 
-// can this kernel run the launch?  fixedLeapFrog sampling (traced or not, no warm-up / orbit statistics) on a dense Gaussian with
-// D <= 100 or a diagonal / standard one with D <= 112
+// can this kernel run the launch?  fixedLeapFrog sampling (traced or not; untraced also with warm-up adaptation of H and delta -- the
+// reference's default call, WALNUTS.py:111-125: integrator=fixedLeapFrog, warmupIter=1000 --, no orbit statistics) on a dense Gaussian
+// with D <= 100 or a diagonal / standard one with D <= 112
+#if !defined(WN4_WARM_TU)
 bool fast4_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm) {
-  if (kc.layout != 1 || adapt != 0 || warm || prm.mode != MODE_SAMPLE) return false;
+  if (kc.layout != 1 || adapt != 0 || prm.mode != MODE_SAMPLE) return false;
+  if (warm && (prm.trace || prm.trace_n)) return false;  // (traced warm-up runs: the one-stream kernel)
   if (prm.omin || prm.M > 11) return false;
   return kc.p1 == 0 /* CK_DENSE */ ? prm.D <= 100 : prm.D <= 112;
 }
@@ -1115,59 +1129,75 @@ int fast4_pairs(int C) {  // T waves per workgroup: fill the chip's 256 CUs befo
   const int groups = (C + 3) / 4;
   return groups >= 4 * 256 ? 4 : groups >= 2 * 256 ? 2 : 1;
 }
+#else
+int fast4_pairs(int C);
+#endif
 
-template <int NS, bool TAIL, bool DENSE>
+template <int NS, bool TAIL, bool DENSE, bool WARM>
 static hipError_t fast4_go(const Params& prm, int* abort_flag, hipStream_t st) {
   using G = Fast4Geom<NS, TAIL, DENSE>;
   const int pairs = fast4_pairs(prm.C), groups = (prm.C + 3) / 4;
   hipError_t r;
+  constexpr bool CAN_TRACE = !WARM;  // (WARM instantiations exist untraced only)
   // fewer groups than two per CU (BASELINE configs[1]'s literal 1024 chains = 256 groups): the group's vectors on TWO T waves (halves), so
   // that a CU's four SIMDs run R, I and two half-tick T waves instead of R, I, one T wave and nothing
   if constexpr (DENSE && NS >= 6) if (pairs == 1 && !getenv("WN_FAST4_WHOLE")) {
     dim3 grid(groups), block(256);
     const size_t shm = G::lds_bytes_halves();
-    if (prm.trace_n) {
-      r = hipFuncSetAttribute((const void*)wn_fast4_kernel<NS, TAIL, true, DENSE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (CAN_TRACE && prm.trace_n) {
+      r = hipFuncSetAttribute((const void*)wn_fast4_kernel<NS, TAIL, CAN_TRACE, DENSE, true, WARM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       if (r != hipSuccess) return r;
-      hipLaunchKernelGGL((wn_fast4_kernel<NS, TAIL, true, DENSE, true>), grid, block, shm, st, prm, abort_flag, 1);
+      hipLaunchKernelGGL((wn_fast4_kernel<NS, TAIL, CAN_TRACE, DENSE, true, WARM>), grid, block, shm, st, prm, abort_flag, 1);
     } else {
-      r = hipFuncSetAttribute((const void*)wn_fast4_kernel<NS, TAIL, false, DENSE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      r = hipFuncSetAttribute((const void*)wn_fast4_kernel<NS, TAIL, false, DENSE, true, WARM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       if (r != hipSuccess) return r;
-      hipLaunchKernelGGL((wn_fast4_kernel<NS, TAIL, false, DENSE, true>), grid, block, shm, st, prm, abort_flag, 1);
+      hipLaunchKernelGGL((wn_fast4_kernel<NS, TAIL, false, DENSE, true, WARM>), grid, block, shm, st, prm, abort_flag, 1);
     }
     return hipGetLastError();
   }
   dim3 grid((groups + pairs - 1) / pairs), block(64 * (pairs + 2 * ((pairs + 1) / 2)));
   const size_t shm = G::lds_bytes(pairs);
-  if (prm.trace_n) {
-    r = hipFuncSetAttribute((const void*)wn_fast4_kernel<NS, TAIL, true, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  if (CAN_TRACE && prm.trace_n) {
+    r = hipFuncSetAttribute((const void*)wn_fast4_kernel<NS, TAIL, CAN_TRACE, DENSE, false, WARM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (r != hipSuccess) return r;
-    hipLaunchKernelGGL((wn_fast4_kernel<NS, TAIL, true, DENSE>), grid, block, shm, st, prm, abort_flag, pairs);
+    hipLaunchKernelGGL((wn_fast4_kernel<NS, TAIL, CAN_TRACE, DENSE, false, WARM>), grid, block, shm, st, prm, abort_flag, pairs);
   } else {
-    r = hipFuncSetAttribute((const void*)wn_fast4_kernel<NS, TAIL, false, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    r = hipFuncSetAttribute((const void*)wn_fast4_kernel<NS, TAIL, false, DENSE, false, WARM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (r != hipSuccess) return r;
-    hipLaunchKernelGGL((wn_fast4_kernel<NS, TAIL, false, DENSE>), grid, block, shm, st, prm, abort_flag, pairs);
+    hipLaunchKernelGGL((wn_fast4_kernel<NS, TAIL, false, DENSE, false, WARM>), grid, block, shm, st, prm, abort_flag, pairs);
   }
   return hipGetLastError();
 }
 
-hipError_t launch_fast4(const KernelChoice& kc, const Params& prm, int* abort_flag, hipStream_t st) {
+template <bool WARM>
+static hipError_t fast4_dispatch(const KernelChoice& kc, const Params& prm, int* abort_flag, hipStream_t st) {
   const int D = prm.D;
   if (kc.p1 == 0 /* CK_DENSE */) {
-    if (D <= 32) return fast4_go<2, false, true>(prm, abort_flag, st);
-    if (D <= 64) return fast4_go<4, false, true>(prm, abort_flag, st);
-    if (D <= 96) return fast4_go<6, false, true>(prm, abort_flag, st);
-    if (D <= 100) return fast4_go<7, true, true>(prm, abort_flag, st);
+    if (D <= 32) return fast4_go<2, false, true, WARM>(prm, abort_flag, st);
+    if (D <= 64) return fast4_go<4, false, true, WARM>(prm, abort_flag, st);
+    if (D <= 96) return fast4_go<6, false, true, WARM>(prm, abort_flag, st);
+    if (D <= 100) return fast4_go<7, true, true, WARM>(prm, abort_flag, st);
     return hipErrorInvalidValue;
   }
-  if (D <= 32) return fast4_go<2, false, false>(prm, abort_flag, st);
-  if (D <= 64) return fast4_go<4, false, false>(prm, abort_flag, st);
-  if (D <= 96) return fast4_go<6, false, false>(prm, abort_flag, st);
-  if (D <= 112) return fast4_go<7, false, false>(prm, abort_flag, st);
+  if (D <= 32) return fast4_go<2, false, false, WARM>(prm, abort_flag, st);
+  if (D <= 64) return fast4_go<4, false, false, WARM>(prm, abort_flag, st);
+  if (D <= 96) return fast4_go<6, false, false, WARM>(prm, abort_flag, st);
+  if (D <= 112) return fast4_go<7, false, false, WARM>(prm, abort_flag, st);
   return hipErrorInvalidValue;
+}
+
+#if defined(WN4_WARM_TU)
+// (this translation unit: the warm-up instantiations only)
+hipError_t launch_fast4_warm(const KernelChoice& kc, const Params& prm, int* abort_flag, hipStream_t st) { return fast4_dispatch<true>(kc, prm, abort_flag, st); }
+#else
+hipError_t launch_fast4_warm(const KernelChoice& kc, const Params& prm, int* abort_flag, hipStream_t st);  // wn_k_fast4w.o
+hipError_t launch_fast4(const KernelChoice& kc, const Params& prm, int* abort_flag, hipStream_t st) {
+  if (prm.warmupIter > 0) return launch_fast4_warm(kc, prm, abort_flag, st);
+  return fast4_dispatch<false>(kc, prm, abort_flag, st);
 }
 
 // doubles of workspace per chain group, for wn_capi.hip's allocation (every geometry fits the role-split kernel's share)
 size_t fast4_work_doubles(int C, int M) { return (size_t)((C + 3) / 4) * Fast4Geom<7, true>::group_doubles(M); }
+#endif
 
 }  // namespace wn
