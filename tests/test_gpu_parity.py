@@ -636,3 +636,29 @@ def test_walnuts_device_matches_the_reference_on_the_engine_stream(wa, legacy):
     finally:
         if legacy:
             del os.environ["WN_WSTEP_LEGACY"]
+
+
+def test_walnuts_batch_wave_kernels_match_the_thread_per_chain_kernels(wa):
+    """Round 5: walnuts_batch() -- the reference's contract, one numpy Generator per chain consumed on the host -- runs its extensions
+    on the wave kernels (wstep_wv_*: lane = element, the chain's state in memory between the launches of a doubling) for the
+    element-wise Gaussian targets.  Same Generators, same draws as the thread-per-chain kernels (WN_WSTEP_LEGACY=1), which the
+    reference goldens pin for every target: D = 24 > 16 (full-wave sums), a diagonal mass matrix, ragged activity (chains stop at
+    different depths), and every Generator ends at the same stream position."""
+    from walnuts_amd import targetDistr as td
+    D, C, T = 24, 96, 6
+    prec = np.geomspace(0.5, 8.0, D)
+    im = np.geomspace(0.5, 2.0, D)
+    th0 = np.random.default_rng(4).normal(size=(C, D)) / np.sqrt(prec)
+    tgt = td.diagGauss(prec)
+    args = (tgt, tgt, im, 1.5, 7, 0.2, 0, T)
+    ra = [np.random.default_rng(900 + c) for c in range(C)]
+    rb = [np.random.default_rng(900 + c) for c in range(C)]
+    new = wa.walnuts_batch(ra, th0, *args)
+    os.environ["WN_WSTEP_LEGACY"] = "1"
+    try:
+        old = wa.walnuts_batch(rb, th0, *args)
+    finally:
+        del os.environ["WN_WSTEP_LEGACY"]
+    assert np.isfinite(new).all()
+    close(new, old, rtol=1e-9, atol=1e-12, what="wave host-protocol kernels vs thread-per-chain kernels")
+    assert all(ra[c].uniform() == rb[c].uniform() for c in range(C))

@@ -480,53 +480,48 @@ __device__ __forceinline__ void wt_sum2(double& a, double& b) {
   } else { a = wn_wavesum(a); b = wn_wavesum(b); }
 }
 
+// One chain of the wave layout: what every kernel below does with it.  Lane i holds element i of every vector.
 template <bool SMALL>
-__global__ __launch_bounds__(64) void wstep_wave_kernel(WCtx c0, int* lottery, uint64_t seed, uint32_t chain0, int it0, int n_trans, int max_depth,
-                                                        double* theta_io, double* draws, int* stats) {
-  const int b = blockIdx.x, lane = threadIdx.x, D = c0.D;
-  if (b >= c0.B) return;
-  const bool in = lane < D;
-  const int li = in ? lane : 0;
-  double* const eorb = c0.eorb + (size_t)b * c0.nmax * 2 * D;  // [m][2][D] states of the extension in integration order
-  double* const ew = c0.ew + (size_t)b * c0.nmax;
-  double* const logw = c0.logw + (size_t)b * 2 * c0.nmax;
-  extern __shared__ int wt_lot_lds[];  // the extension's lottery indices, [nmax] (LDS operations of one wave execute in order)
-  typedef __attribute__((address_space(3))) int lds_int;
-  lds_int* const lot = (lds_int*)wt_lot_lds;
-  (void)lottery;
-  const uint32_t chain = chain0 + (uint32_t)b;
-  const double im = in ? c0.im[li] : 0.0;                                                    // inverse mass (0 beyond D: those lanes add nothing)
-  const double aa = in ? (c0.kind == T_DIAGGAUSS ? c0.tpar[li] : 1.0) : 0.0;                 // precision of this lane's coordinate
-  const double macro = c0.macro_step, maxerr = c0.max_error;
-  const uint32_t seedlo = (uint32_t)seed, seedhi = (uint32_t)(seed >> 32);
-  // window of uniforms: lane l holds uniform 2 * ub + l of transition uit
-  uint32_t uit = 0xFFFFFFFFu, ub = 0;
-  double uw = 0.0;
-  auto uni = [&](uint32_t it, uint32_t k) -> double {
-    const uint32_t blk = k >> 1;
-    if (it != uit || blk - ub >= 32u) {
-      uit = it; ub = blk;
-      Philox4 r = philox4x32_10(blk + (uint32_t)(lane >> 1), it, chain, 0u, seedlo, seedhi);
-      uw = (lane & 1) ? u53(r.w[2], r.w[3]) : u53(r.w[0], r.w[1]);
-    }
-    return wn_readlane(uw, (int)(k - 2u * ub));
-  };
-  auto ke_of = [&](double rho) -> double { return 0.5 * wt_sum<SMALL>(im * (rho * rho)); };  // 0.5*dot(inv_mass, rho**2)  (:124)
+struct WvChain {
+  int lane, D, li;
+  bool in;
+  double im, aa, macro, maxerr;
+  const double* imv;          // inverse masses, all elements (the sub-U-turn checks walk whole states)
+  double *eorb, *ew, *logw;   // this chain's: [m][2][D] states of the extension in integration order, their log weights, the orbit's so far
+  // the orbit's two ends, the selected state, the number of log weights so far
+  double thL, rhL, gL, thR, rhR, gR, sel, lpL, lpR, wL, wR;
+  int nw;
+  // the last state of the running extension
+  double t0, r0, g0, lp0;
+  int sum_ell, sum_es;  // (wn_wstep_set_stats)
+
+  __device__ __forceinline__ void setup(const WCtx& c0, int b, int lane_) {
+    lane = lane_; D = c0.D; in = lane < D; li = in ? lane : 0;
+    eorb = c0.eorb + (size_t)b * c0.nmax * 2 * D;
+    ew = c0.ew + (size_t)b * c0.nmax;
+    logw = c0.logw + (size_t)b * 2 * c0.nmax;
+    imv = c0.im;
+    im = in ? c0.im[li] : 0.0;                                                    // inverse mass (0 beyond D: those lanes add nothing)
+    aa = in ? (c0.kind == T_DIAGGAUSS ? c0.tpar[li] : 1.0) : 0.0;                 // precision of this lane's coordinate
+    macro = c0.macro_step; maxerr = c0.max_error;
+    sum_ell = sum_es = 0;
+  }
+  __device__ __forceinline__ double ke_of(double rho) const { return 0.5 * wt_sum<SMALL>(im * (rho * rho)); }  // 0.5*dot(inv_mass, rho**2)  (:124)
   // log density and gradient at theta (element-wise targets): lp = 1/2 sum theta_i g_i
-  auto eval = [&](double th, double& g) -> double { g = -(aa * th); return 0.5 * wt_sum<SMALL>(th * g); };
-  auto mlogp = [](int ell, int es) -> double { return (ell == es || ell == es / 2 || ell == es * 2) ? -1.0986122886681098 : -INFINITY; };
+  __device__ __forceinline__ double eval(double th, double& g) const { g = -(aa * th); return 0.5 * wt_sum<SMALL>(th * g); }
+  __device__ __forceinline__ static double mlogp(int ell, int es) { return (ell == es || ell == es / 2 || ell == es * 2) ? -1.0986122886681098 : -INFINITY; }
 
   // stable_steps (:144-182) from (th0, sgn * rh0) with (lp0, g0) known: the smallest 2**n <= 1024 micro steps whose Hamiltonians
   // stay within max_error of each other (2**10 if none does).  One wave sum per micro step: H = sum_i (1/2 im rho_i^2 - 1/2 theta_i g_i).
-  auto stable = [&](double th0, double rh0, double g0, double lp0, double sgn) -> int {
-    const double r0 = sgn * rh0;
-    const double H0 = -lp0 + ke_of(r0);
+  __device__ __forceinline__ int stable(double th0, double rh0, double g0_, double lp0_, double sgn) const {
+    const double r0_ = sgn * rh0;
+    const double H0 = -lp0_ + ke_of(r0_);
     int ell = 1;
 #pragma unroll 1
     for (int n = 0;; ++n) {
       ell = 1 << n;
       const double step = macro / (double)ell, half = 0.5 * step;
-      double th = th0, rh = r0 + half * g0;
+      double th = th0, rh = r0_ + half * g0_;
       th = th + (step * im) * rh;
       double Hmin = H0, Hmax = H0;
       int k = ell;
@@ -542,28 +537,192 @@ __global__ __launch_bounds__(64) void wstep_wave_kernel(WCtx c0, int* lottery, u
       if (__builtin_amdgcn_readfirstlane((int)(Hmax - Hmin <= maxerr)) || n >= 10) break;
     }
     return ell;
-  };
+  }
 
+  // the transition's first state (:325-327): orbit = [(theta, rho)], log_weights = [-H(theta, rho)]
+  __device__ __forceinline__ void begin(double th, double rh) {
+    double g;
+    const double lp = eval(th, g);
+    thL = th; rhL = rh; gL = g; thR = th; rhR = rh; gR = g; sel = th;
+    lpL = lp; lpR = lp;
+    wL = lp - ke_of(rh); wR = wL;
+    if (lane == 0) logw[0] = wL;
+    nw = 1;
+    t0 = th; r0 = rh; g0 = g; lp0 = lp;
+  }
+
+  // extend_orbit (:211-276): n macro steps from the orbit's first state with the momentum negated, or from its last state;
+  // lot(m) in {0, 1, 2}: the m-th macro step's choose_micro_steps draw (:194)
+  template <class Lot>
+  __device__ __forceinline__ void extend(const int backward, const int n, Lot lot) {
+    t0 = backward ? thL : thR; r0 = backward ? -rhL : rhR; g0 = backward ? gL : gR;
+    lp0 = backward ? lpL : lpR;
+    double weight = backward ? wL : wR;
+#pragma unroll 1
+    for (int m = 0; m < n; ++m) {
+      const double p0 = lp0 - ke_of(r0);
+      const int es = stable(t0, r0, g0, lp0, 1.0);
+      const int idx = lot(m);
+      const int ell = idx == 0 ? es / 2 : idx == 1 ? es : es * 2;  // choose_micro_steps (:194); es == 1 can give 0 (Q9): an infinite step
+      sum_ell += ell; sum_es += es;
+      {  // leapfrog (:74-95)
+        const double step = macro / (double)ell, half = 0.5 * step;
+        double t = t0, r = r0 + half * g0;
+        t = t + (step * im) * r;
+        double gg = -(aa * t);
+#pragma unroll 1
+        for (int j = 1; j < ell; ++j) {
+          r = r + step * gg;
+          t = t + (step * im) * r;
+          gg = -(aa * t);
+        }
+        r0 = r + half * gg; t0 = t; g0 = gg;
+      }
+      double gchk;
+      lp0 = eval(t0, gchk);
+      const int en = stable(t0, r0, g0, lp0, -1.0);
+      const double p1 = lp0 - ke_of(r0);
+      weight = p1 - p0 + mlogp(ell, en) - mlogp(ell, es) + weight;  // :264-271
+      if (in) { eorb[(size_t)m * 2 * D + li] = t0; eorb[(size_t)m * 2 * D + D + li] = r0; }
+      if (lane == 0) ew[m] = weight;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+
+  // sub_uturn (:62-70) over the extension in LIST order (time order: integration order reversed when going backward): check c of
+  // the n-1 (span n >> l, i-th block) is lane c's; any order gives the same answer
+  __device__ __forceinline__ bool sub_uturn(const int backward, const int n) const {
+    bool su = false;
+    for (int c1 = 0; c1 < n - 1; c1 += 64) {
+      const int cc = c1 + lane;
+      bool f = false;
+      if (cc < n - 1) {
+        const int l = 31 - __builtin_clz((unsigned)(cc + 1)), i = cc + 1 - (1 << l), span = n >> l;
+        const int x = span * i, y = span * (i + 1) - 1;
+        const int ix = backward ? n - 1 - x : x, iy = backward ? n - 1 - y : y;
+        const double *sx = eorb + (size_t)ix * 2 * D, *sy = eorb + (size_t)iy * 2 * D;
+        double d1 = 0.0, d2 = 0.0;
+        for (int j = 0; j < D; ++j) {
+          const double diff = imv[j] * (sy[j] - sx[j]);
+          d1 += sx[D + j] * diff;
+          d2 += sy[D + j] * diff;
+        }
+        f = d1 < 0 || d2 < 0;
+      }
+      su = su || __any(f);
+    }
+    return su;
+  }
+  // logsumexp of the extension's weights and of the orbit's so far (:345, scipy.special.logsumexp)
+  __device__ __forceinline__ double lse(const double* a, int cnt) const {
+    double mx = -INFINITY; bool nan = false;
+    for (int j = lane; j < cnt; j += 64) { const double x = a[j]; nan = nan || isnan(x); mx = x > mx ? x : mx; }
+    mx = WavePolicy<1, WTgtDiag<1>>::wavemax(mx);
+    if (__any(nan)) mx = NAN;
+    if (!isfinite(mx)) mx = 0.0;
+    double sm = 0.0;
+    for (int j = lane; j < cnt; j += 64) sm += exp(a[j] - mx);
+    return log(wn_wavesum(sm)) + mx;
+  }
+  // after the acceptance draw: the categorical pick (:347-350) and the orbit merge (:351)
+  __device__ __forceinline__ void commit(const bool acc, const double uc, const int backward, const int n) {
+    if (acc) {  // p = softmax(log_weights_ext) in LIST order; Generator.choice: cdf = p.cumsum(); cdf /= cdf[-1]; searchsorted(u, 'right')
+      double mx = -INFINITY;
+      for (int j = 0; j < n; ++j) { const double x = ew[j]; mx = x > mx ? x : mx; }
+      double tot = 0.0;
+      for (int j = 0; j < n; ++j) tot += exp(ew[j] - mx);
+      double cs = 0.0;
+      for (int pp = 0; pp < n; ++pp) { const int j = backward ? n - 1 - pp : pp; cs += exp(ew[j] - mx) / tot; }
+      const double last = cs;
+      cs = 0.0;
+      int idx = n - 1;
+      for (int pp = 0; pp < n; ++pp) {
+        const int j = backward ? n - 1 - pp : pp;
+        cs += exp(ew[j] - mx) / tot;
+        if (uc < cs / last) { idx = pp; break; }
+      }
+      const int ii = __builtin_amdgcn_readfirstlane(backward ? n - 1 - idx : idx);
+      sel = in ? eorb[(size_t)ii * 2 * D + li] : 0.0;
+    }
+    // orbit = orbit_ext + orbit / orbit + orbit_ext (:351): the new end is the LAST computed state
+    const double we = ew[n - 1];
+    if (backward) { thL = t0; rhL = r0; gL = g0; lpL = lp0; wL = we; }
+    else { thR = t0; rhR = r0; gR = g0; lpR = lp0; wR = we; }
+    for (int j = lane; j < n; j += 64) logw[nw + j] = ew[j];
+    nw += n;
+  }
+  __device__ __forceinline__ bool uturn() const {  // uturn(orbit[0], orbit[-1], inv_mass) (:352)
+    double d1 = im * (thR - thL), d2 = rhR * d1;
+    d1 = rhL * d1;
+    wt_sum2<SMALL>(d1, d2);
+    return __builtin_amdgcn_readfirstlane((int)(d1 < 0 || d2 < 0)) != 0;
+  }
+
+  // ---- the chain between two launches of the host-driven protocol (wn_wstep_begin / extend / commit on the wave kernels):
+  // ten vectors of 64 doubles, then the scalars
+  enum { ST_VECS = 10, ST_SCAL = ST_VECS * 64, ST_DOUBLES = ST_SCAL + 16 };
+  __device__ __forceinline__ void store(double* st, int backward, int n, int active, int su) const {
+    const double v[ST_VECS] = {thL, rhL, gL, thR, rhR, gR, sel, t0, r0, g0};
+#pragma unroll
+    for (int k = 0; k < ST_VECS; ++k) st[k * 64 + lane] = v[k];
+    if (lane == 0) {
+      double* q = st + ST_SCAL;
+      q[0] = lpL; q[1] = lpR; q[2] = wL; q[3] = wR; q[4] = lp0;
+      int* qi = reinterpret_cast<int*>(q + 5);
+      qi[0] = nw; qi[1] = backward; qi[2] = n; qi[3] = active; qi[4] = su;
+    }
+  }
+  __device__ __forceinline__ void load(const double* st, int& backward, int& n, int& active, int& su) {
+    thL = st[0 * 64 + lane]; rhL = st[1 * 64 + lane]; gL = st[2 * 64 + lane]; thR = st[3 * 64 + lane]; rhR = st[4 * 64 + lane];
+    gR = st[5 * 64 + lane]; sel = st[6 * 64 + lane]; t0 = st[7 * 64 + lane]; r0 = st[8 * 64 + lane]; g0 = st[9 * 64 + lane];
+    const double* q = st + ST_SCAL;
+    lpL = q[0]; lpR = q[1]; wL = q[2]; wR = q[3]; lp0 = q[4];
+    const int* qi = reinterpret_cast<const int*>(q + 5);
+    nw = qi[0]; backward = qi[1]; n = qi[2]; active = qi[3]; su = qi[4];
+  }
+};
+
+template <bool SMALL>
+__global__ __launch_bounds__(64) void wstep_wave_kernel(WCtx c0, int* lottery, uint64_t seed, uint32_t chain0, int it0, int n_trans, int max_depth,
+                                                        double* theta_io, double* draws, int* stats) {
+  const int b = blockIdx.x, lane = threadIdx.x, D = c0.D;
+  if (b >= c0.B) return;
+  WvChain<SMALL> ch;
+  ch.setup(c0, b, lane);
+  extern __shared__ int wt_lot_lds[];  // the extension's lottery indices, [nmax] (LDS operations of one wave execute in order)
+  typedef __attribute__((address_space(3))) int lds_int;
+  lds_int* const lot = (lds_int*)wt_lot_lds;
+  (void)lottery;
+  const uint32_t chain = chain0 + (uint32_t)b;
+  const uint32_t seedlo = (uint32_t)seed, seedhi = (uint32_t)(seed >> 32);
+  // window of uniforms: lane l holds uniform 2 * ub + l of transition uit
+  uint32_t uit = 0xFFFFFFFFu, ub = 0;
+  double uw = 0.0;
+  auto uni = [&](uint32_t it, uint32_t k) -> double {
+    const uint32_t blk = k >> 1;
+    if (it != uit || blk - ub >= 32u) {
+      uit = it; ub = blk;
+      Philox4 r = philox4x32_10(blk + (uint32_t)(lane >> 1), it, chain, 0u, seedlo, seedhi);
+      uw = (lane & 1) ? u53(r.w[2], r.w[3]) : u53(r.w[0], r.w[1]);
+    }
+    return wn_readlane(uw, (int)(k - 2u * ub));
+  };
   for (int tr = 0; tr < n_trans; ++tr) {
     const uint32_t it = (uint32_t)(it0 + tr);
     uint32_t k = 0;
-    double th = in ? theta_io[(size_t)b * D + li] : 0.0;
-    double rh = in ? rng_normal(seed, chain, it, (uint32_t)li) / sqrt(im) : 0.0;  // rho ~ mvnormal(0, inverse(inv_mass))  (:325)
-    double g;
-    double lp = eval(th, g);
-    // the orbit's two ends and the selected state
-    double thL = th, rhL = rh, gL = g, thR = th, rhR = rh, gR = g, sel = th;
-    double lpL = lp, lpR = lp;
-    double wL = lp - ke_of(rh), wR = wL;
-    if (lane == 0) logw[0] = wL;
-    int nw = 1;
-    int ndbl = 0, nacc = 0, sum_ell = 0, sum_es = 0;  // (stats: what a reference run on the same stream must reproduce exactly)
+    const double th = ch.in ? theta_io[(size_t)b * D + ch.li] : 0.0;
+    const double rh = ch.in ? rng_normal(seed, chain, it, (uint32_t)ch.li) / sqrt(ch.im) : 0.0;  // rho ~ mvnormal(0, inverse(inv_mass))  (:325)
+    ch.begin(th, rh);
+    ch.sum_ell = ch.sum_es = 0;
+    int ndbl = 0, nacc = 0;  // (stats: what a reference run on the same stream must reproduce exactly)
 #pragma unroll 1
     for (int depth = 0; depth < max_depth; ++depth) {
       const int n = 1 << depth;
       ndbl += 1;
       const int backward = uni(it, k++) < 0.5 ? 1 : 0;  // :330
-      for (int m0 = 0; m0 < n; m0 += 32) {               // one lottery index per macro step (:194), drawn before the extension as the kernel above does
+      for (int m0 = 0; m0 < n; m0 += 32) {               // one lottery index per macro step (:194), drawn before the extension as the one-lane kernel does
         uit = 0xFFFFFFFFu;                               // a fresh window that STARTS at the block of uniform k + m0: its first 62 uniforms are inside
         (void)uni(it, k + (uint32_t)m0);
         const int off = (int)(k + (uint32_t)m0 - 2u * ub);
@@ -572,115 +731,78 @@ __global__ __launch_bounds__(64) void wstep_wave_kernel(WCtx c0, int* lottery, u
         if (lane < 32 && m0 + lane < n) lot[m0 + lane] = idx > 2 ? 2 : idx;
       }
       k += (uint32_t)n;
-      // extend_orbit (:211-276): from the orbit's first state with the momentum negated, or from its last state
-      double t0 = backward ? thL : thR, r0 = backward ? -rhL : rhR, g0 = backward ? gL : gR;
-      double lp0 = backward ? lpL : lpR, weight = backward ? wL : wR;
-#pragma unroll 1
-      for (int m = 0; m < n; ++m) {
-        const double p0 = lp0 - ke_of(r0);
-        const int es = stable(t0, r0, g0, lp0, 1.0);
-        const int idx = __builtin_amdgcn_readfirstlane((int)lot[m]);
-        const int ell = idx == 0 ? es / 2 : idx == 1 ? es : es * 2;  // choose_micro_steps (:194); es == 1 can give 0 (Q9): an infinite step
-        sum_ell += ell; sum_es += es;
-        {  // leapfrog (:74-95)
-          const double step = macro / (double)ell, half = 0.5 * step;
-          double t = t0, r = r0 + half * g0;
-          t = t + (step * im) * r;
-          double gg = -(aa * t);
-#pragma unroll 1
-          for (int j = 1; j < ell; ++j) {
-            r = r + step * gg;
-            t = t + (step * im) * r;
-            gg = -(aa * t);
-          }
-          r0 = r + half * gg; t0 = t; g0 = gg;
-        }
-        double gchk;
-        lp0 = eval(t0, gchk);
-        const int en = stable(t0, r0, g0, lp0, -1.0);
-        const double p1 = lp0 - ke_of(r0);
-        weight = p1 - p0 + mlogp(ell, en) - mlogp(ell, es) + weight;  // :264-271
-        if (in) { eorb[(size_t)m * 2 * D + li] = t0; eorb[(size_t)m * 2 * D + D + li] = r0; }
-        if (lane == 0) ew[m] = weight;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __builtin_amdgcn_s_waitcnt(0);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      // sub_uturn (:62-70) over the extension in LIST order (time order: integration order reversed when going backward): check c of
-      // the n-1 (span n >> l, i-th block) is lane c's; any order gives the same answer
-      bool su = false;
-      for (int c1 = 0; c1 < n - 1; c1 += 64) {
-        const int cc = c1 + lane;
-        bool f = false;
-        if (cc < n - 1) {
-          const int l = 31 - __builtin_clz((unsigned)(cc + 1)), i = cc + 1 - (1 << l), span = n >> l;
-          const int x = span * i, y = span * (i + 1) - 1;
-          const int ix = backward ? n - 1 - x : x, iy = backward ? n - 1 - y : y;
-          const double *sx = eorb + (size_t)ix * 2 * D, *sy = eorb + (size_t)iy * 2 * D;
-          double d1 = 0.0, d2 = 0.0;
-          for (int j = 0; j < D; ++j) {
-            const double diff = c0.im[j] * (sy[j] - sx[j]);
-            d1 += sx[D + j] * diff;
-            d2 += sy[D + j] * diff;
-          }
-          f = d1 < 0 || d2 < 0;
-        }
-        su = su || __any(f);
-      }
-      if (su) break;
-      // logsumexp of the extension's weights and of the orbit's so far (:345, scipy.special.logsumexp)
-      auto lse = [&](const double* a, int cnt) -> double {
-        double mx = -INFINITY; bool nan = false;
-        for (int j = lane; j < cnt; j += 64) { const double x = a[j]; nan = nan || isnan(x); mx = x > mx ? x : mx; }
-        mx = WavePolicy<1, WTgtDiag<1>>::wavemax(mx);
-        if (__any(nan)) mx = NAN;
-        if (!isfinite(mx)) mx = 0.0;
-        double sm = 0.0;
-        for (int j = lane; j < cnt; j += 64) sm += exp(a[j] - mx);
-        return log(wn_wavesum(sm)) + mx;
-      };
-      const double lse_ext = lse(ew, n), lse_old = lse(logw, nw);
+      ch.extend(backward, n, [&](int m) { return __builtin_amdgcn_readfirstlane((int)lot[m]); });
+      if (ch.sub_uturn(backward, n)) break;
+      const double lse_ext = ch.lse(ch.ew, n), lse_old = ch.lse(ch.logw, ch.nw);
       const double logu = log(uni(it, k++));  // :346
       const bool acc = logu < lse_ext - lse_old;
-      if (acc) {  // :347-350: p = softmax(log_weights_ext) in LIST order; Generator.choice: cdf = p.cumsum(); cdf /= cdf[-1]; searchsorted(u, 'right')
-        nacc += 1;
-        const double uc = uni(it, k++);
-        double mx = -INFINITY;
-        for (int j = 0; j < n; ++j) { const double x = ew[j]; mx = x > mx ? x : mx; }
-        double tot = 0.0;
-        for (int j = 0; j < n; ++j) tot += exp(ew[j] - mx);
-        double cs = 0.0;
-        for (int pp = 0; pp < n; ++pp) { const int j = backward ? n - 1 - pp : pp; cs += exp(ew[j] - mx) / tot; }
-        const double last = cs;
-        cs = 0.0;
-        int idx = n - 1;
-        for (int pp = 0; pp < n; ++pp) {
-          const int j = backward ? n - 1 - pp : pp;
-          cs += exp(ew[j] - mx) / tot;
-          if (uc < cs / last) { idx = pp; break; }
-        }
-        const int ii = __builtin_amdgcn_readfirstlane(backward ? n - 1 - idx : idx);
-        sel = in ? eorb[(size_t)ii * 2 * D + li] : 0.0;
-      }
-      // orbit = orbit_ext + orbit / orbit + orbit_ext (:351): the new end is the LAST computed state
-      {
-        const double we = ew[n - 1];
-        if (backward) { thL = t0; rhL = r0; gL = g0; lpL = lp0; wL = we; }
-        else { thR = t0; rhR = r0; gR = g0; lpR = lp0; wR = we; }
-        for (int j = lane; j < n; j += 64) logw[nw + j] = ew[j];
-        nw += n;
-      }
-      double d1 = im * (thR - thL), d2 = rhR * d1;  // uturn(orbit[0], orbit[-1], inv_mass) (:352)
-      d1 = rhL * d1;
-      wt_sum2<SMALL>(d1, d2);
-      if (__builtin_amdgcn_readfirstlane((int)(d1 < 0 || d2 < 0))) break;
+      double uc = 0.0;
+      if (acc) { nacc += 1; uc = uni(it, k++); }  // :347-350
+      ch.commit(acc, uc, backward, n);
+      if (ch.uturn()) break;
     }
-    if (in) {
-      theta_io[(size_t)b * D + li] = sel;
-      if (draws) draws[((size_t)b * n_trans + tr) * D + li] = sel;
+    if (ch.in) {
+      theta_io[(size_t)b * D + ch.li] = ch.sel;
+      if (draws) draws[((size_t)b * n_trans + tr) * D + ch.li] = ch.sel;
     }
-    if (stats && lane < 4) stats[((size_t)b * n_trans + tr) * 4 + lane] = lane == 0 ? ndbl : lane == 1 ? nacc : lane == 2 ? sum_ell : sum_es;
+    if (stats && lane < 4) stats[((size_t)b * n_trans + tr) * 4 + lane] = lane == 0 ? ndbl : lane == 1 ? nacc : lane == 2 ? ch.sum_ell : ch.sum_es;
   }
+}
+
+// ---- the host-driven protocol (wn_wstep_begin / extend / commit / result: the caller's numpy Generators decide, one exchange per
+// doubling) on the same wave code: the chain's state lives in `wst` between launches.  Round 4's thread-per-chain kernels made 2.4e3
+// transitions/s of walnuts_batch at 4096 chains (a lone thread walks every vector); the wave does an extension in microseconds.
+template <bool SMALL>
+__global__ __launch_bounds__(64) void wstep_wv_begin_kernel(WCtx c0, double* wst, const double* theta, const double* rho) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= c0.B) return;
+  WvChain<SMALL> ch;
+  ch.setup(c0, b, lane);
+  ch.begin(ch.in ? theta[(size_t)b * c0.D + ch.li] : 0.0, ch.in ? rho[(size_t)b * c0.D + ch.li] : 0.0);
+  ch.store(wst + (size_t)b * WvChain<SMALL>::ST_DOUBLES, 0, 0, 1, 0);
+}
+template <bool SMALL>
+__global__ __launch_bounds__(64) void wstep_wv_extend_kernel(WCtx c0, double* wst, const int* lottery, const int* backward_in, const int* active_in,
+                                                             int n, int* sub_out, double* lse_ext, double* lse_old) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= c0.B) return;
+  double* const st = wst + (size_t)b * WvChain<SMALL>::ST_DOUBLES;
+  int* const sti = reinterpret_cast<int*>(st + WvChain<SMALL>::ST_SCAL + 5);
+  if (!active_in[b]) { if (lane == 0) sti[3] = 0; return; }  // (the commit launch leaves an inactive chain alone)
+  extern __shared__ int wt_lot_lds[];
+  typedef __attribute__((address_space(3))) int lds_int;
+  lds_int* const lot = (lds_int*)wt_lot_lds;
+  for (int m = lane; m < n; m += 64) lot[m] = lottery[(size_t)b * c0.nmax + m];
+  WvChain<SMALL> ch;
+  ch.setup(c0, b, lane);
+  int bw_, n_, ac_, su_;
+  ch.load(st, bw_, n_, ac_, su_);
+  const int backward = backward_in[b];
+  ch.extend(backward, n, [&](int m) { return __builtin_amdgcn_readfirstlane((int)lot[m]); });
+  const bool su = ch.sub_uturn(backward, n);
+  double le = 0.0, lo = 0.0;
+  if (!su) { le = ch.lse(ch.ew, n); lo = ch.lse(ch.logw, ch.nw); }
+  if (lane == 0) { sub_out[b] = su ? 1 : 0; lse_ext[b] = le; lse_old[b] = lo; }
+  ch.store(st, backward, n, 1, su ? 1 : 0);
+}
+template <bool SMALL>
+__global__ __launch_bounds__(64) void wstep_wv_commit_kernel(WCtx c0, double* wst, const int* accept, const double* u_choice, int* uturn_out) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= c0.B) return;
+  double* const st = wst + (size_t)b * WvChain<SMALL>::ST_DOUBLES;
+  WvChain<SMALL> ch;
+  ch.setup(c0, b, lane);
+  int backward, n, active, su;
+  ch.load(st, backward, n, active, su);
+  if (!active || su) { if (lane == 0) uturn_out[b] = 0; return; }  // a sub-U-turn breaks out before the merge (:343)
+  ch.commit(accept[b] != 0, u_choice[b], backward, n);
+  const bool ut = ch.uturn();
+  if (lane == 0) uturn_out[b] = ut ? 1 : 0;
+  ch.store(st, backward, n, active, su);
+}
+__global__ void wstep_wv_result_kernel(int B, int D, const double* wst, int st_doubles, double* theta_sel) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b < B && lane < D) theta_sel[(size_t)b * D + lane] = wst[(size_t)b * st_doubles + 6 * 64 + lane];
 }
 
 }  // namespace
@@ -702,6 +824,7 @@ struct wn_wstep {
   bool external = false;
   double *tpar = nullptr, *im = nullptr;
   int* lot = nullptr;
+  double* wst = nullptr;   // wave kernels of the host-driven protocol: the chains' states between launches, [B][WvChain::ST_DOUBLES]
   int* stats = nullptr;    // caller-owned [B][n_transitions][4] of the next wn_wstep_run_device_rng calls (wn_wstep_set_stats), or null
   int* asub = nullptr;     // device-RNG transitions: per-chain scratch of extend_finish
   double* alse = nullptr;  // [2][B]
@@ -726,7 +849,7 @@ int wn_wstep_destroy(wn_wstep* h) {
   if (!h) return WN_OK;
   hipSetDevice(h->device);
   for (void* p : {(void*)h->tpar, (void*)h->im, (void*)h->lot, (void*)h->c.vec, (void*)h->c.eorb, (void*)h->c.ew, (void*)h->c.logw,
-                  (void*)h->c.sc, (void*)h->c.npend, (void*)h->c.waiting, (void*)h->asub, (void*)h->alse})
+                  (void*)h->c.sc, (void*)h->c.npend, (void*)h->c.waiting, (void*)h->asub, (void*)h->alse, (void*)h->wst})
     if (p) hipFree(p);
   delete h;
   return WN_OK;
@@ -790,6 +913,8 @@ int wn_wstep_create(int32_t device, int32_t target_kind, const double* tpar_dev,
   WALLOC(c.waiting, (size_t)B * sizeof(int));
   WALLOC(h->asub, (size_t)B * sizeof(int));
   WALLOC(h->alse, (size_t)2 * B * sizeof(double));
+  if (!ext && (target_kind == WN_T_STDGAUSS || target_kind == WN_T_DIAGGAUSS) && dim <= 64 && c.nmax <= 8192)  // (wave_path below)
+    WALLOC(h->wst, (size_t)B * WvChain<true>::ST_DOUBLES * sizeof(double));
 #undef WALLOC
   WCOPY(hipMemset(c.sc, 0, (size_t)B * sizeof(WScal)));
   WCOPY(hipMemset(c.vec, 0, (size_t)V_NVEC * dim * B * sizeof(double)));
@@ -798,6 +923,9 @@ int wn_wstep_create(int32_t device, int32_t target_kind, const double* tpar_dev,
   *out = h;
   return WN_OK;
 }
+
+// element-wise Gaussian targets run the host-driven protocol on the wave kernels too (WN_WSTEP_LEGACY=1: the thread-per-chain kernels)
+static bool wave_path(const wn_wstep* h) { return h->wst != nullptr && !getenv("WN_WSTEP_LEGACY"); }
 
 static int wstep_launch(wn_wstep* h, int mode, const double* theta, const double* rho, const int* backward, const int* active,
                         int nmacro, int* sub_out, double* lse_ext, double* lse_old, hipStream_t st) {
@@ -815,6 +943,12 @@ static int wstep_launch(wn_wstep* h, int mode, const double* theta, const double
 int wn_wstep_begin(wn_wstep* h, const double* theta_dev, const double* rho_dev, void* stream) {
   if (!h || !theta_dev || !rho_dev) { if (h) h->err = "null buffer"; return WN_E_ARG; }
   WCHK(hipSetDevice(h->device));
+  if (wave_path(h)) {
+    if (h->c.D <= 16) hipLaunchKernelGGL(wstep_wv_begin_kernel<true>, dim3(h->c.B), dim3(64), 0, (hipStream_t)stream, h->c, h->wst, theta_dev, rho_dev);
+    else hipLaunchKernelGGL(wstep_wv_begin_kernel<false>, dim3(h->c.B), dim3(64), 0, (hipStream_t)stream, h->c, h->wst, theta_dev, rho_dev);
+    WCHK(hipGetLastError());
+    return WN_OK;
+  }
   return wstep_launch(h, 0, theta_dev, rho_dev, nullptr, nullptr, 0, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
@@ -827,6 +961,15 @@ int wn_wstep_extend(wn_wstep* h, int32_t depth, const int32_t* backward_dev, con
   // lottery [B][n] -> the handle's [B][nmax]
   WCHK(hipMemcpy2DAsync(h->lot, (size_t)h->c.nmax * sizeof(int), lottery_dev, (size_t)n * sizeof(int), (size_t)n * sizeof(int), (size_t)h->c.B,
                         hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (wave_path(h)) {
+    const size_t dyn = (size_t)h->c.nmax * sizeof(int);
+    if (h->c.D <= 16) hipLaunchKernelGGL(wstep_wv_extend_kernel<true>, dim3(h->c.B), dim3(64), dyn, (hipStream_t)stream, h->c, h->wst, h->lot, backward_dev,
+                                         active_dev, n, sub_uturn_dev, lse_ext_dev, lse_old_dev);
+    else hipLaunchKernelGGL(wstep_wv_extend_kernel<false>, dim3(h->c.B), dim3(64), dyn, (hipStream_t)stream, h->c, h->wst, h->lot, backward_dev,
+                            active_dev, n, sub_uturn_dev, lse_ext_dev, lse_old_dev);
+    WCHK(hipGetLastError());
+    return WN_OK;
+  }
   return wstep_launch(h, 1, nullptr, nullptr, backward_dev, active_dev, n, sub_uturn_dev, lse_ext_dev, lse_old_dev, (hipStream_t)stream);
 }
 
@@ -861,6 +1004,12 @@ int wn_wstep_ext_feed(wn_wstep* h, int32_t* sub_uturn_dev, double* lse_ext_dev, 
 int wn_wstep_commit(wn_wstep* h, const int32_t* accept_dev, const double* u_choice_dev, int32_t* uturn_dev, void* stream) {
   if (!h || !accept_dev || !u_choice_dev || !uturn_dev) { if (h) h->err = "null buffer"; return WN_E_ARG; }
   WCHK(hipSetDevice(h->device));
+  if (wave_path(h)) {
+    if (h->c.D <= 16) hipLaunchKernelGGL(wstep_wv_commit_kernel<true>, dim3(h->c.B), dim3(64), 0, (hipStream_t)stream, h->c, h->wst, accept_dev, u_choice_dev, uturn_dev);
+    else hipLaunchKernelGGL(wstep_wv_commit_kernel<false>, dim3(h->c.B), dim3(64), 0, (hipStream_t)stream, h->c, h->wst, accept_dev, u_choice_dev, uturn_dev);
+    WCHK(hipGetLastError());
+    return WN_OK;
+  }
   hipLaunchKernelGGL(wstep_commit_kernel, dim3((h->c.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->c, accept_dev, u_choice_dev, uturn_dev);
   WCHK(hipGetLastError());
   return WN_OK;
@@ -898,6 +1047,12 @@ int wn_wstep_set_stats(wn_wstep* h, int32_t* stats_dev) {
 int wn_wstep_result(wn_wstep* h, double* theta_sel_dev, void* stream) {
   if (!h || !theta_sel_dev) { if (h) h->err = "null buffer"; return WN_E_ARG; }
   WCHK(hipSetDevice(h->device));
+  if (wave_path(h)) {
+    hipLaunchKernelGGL(wstep_wv_result_kernel, dim3(h->c.B), dim3(64), 0, (hipStream_t)stream, h->c.B, h->c.D, (const double*)h->wst,
+                       (int)WvChain<true>::ST_DOUBLES, theta_sel_dev);
+    WCHK(hipGetLastError());
+    return WN_OK;
+  }
   hipLaunchKernelGGL(wstep_result_kernel, dim3((h->c.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->c, theta_sel_dev);
   WCHK(hipGetLastError());
   return WN_OK;
