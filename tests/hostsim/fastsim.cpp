@@ -147,6 +147,10 @@ struct HostIO {
     ua = u53(r.w[0], r.w[1]); ub = u53(r.w[2], r.w[3]);
     return true;
   }
+  double u_direct(int iter, uint32_t k) const {  // (the device reads its window of uniforms without the tag checks: IssueBookT::tick_fast)
+    Philox4 r = philox4x32_10(k >> 1, (uint32_t)iter, prm->chain0 + (uint32_t)cl, 0u, (uint32_t)prm->seed, (uint32_t)(prm->seed >> 32));
+    return (k & 1u) ? u53(r.w[2], r.w[3]) : u53(r.w[0], r.w[1]);
+  }
   void write_gen(size_t row, double v) const { prm->samples[((size_t)cl * (prm->numIter + 1) + row) * prm->dg + 1] = v; }
   void write_diag(size_t row, const double* d) const {
     double* o = prm->diag + ((size_t)cl * prm->numIter + row) * NDIAG;
@@ -248,7 +252,8 @@ static long run_split(Params* prm, int target, int nlc, double* idle_frac) {
       const RMsg m = R.tick(*prm, io, old);           // retires tick t-2
       bool early = false;  // the first leaf of a doubling (tick t-1), certified by the issue side from the T wave's sums
       if (I.wants_early(t + 1, m)) early = IssueBook::early_certain(*prm, hist[(t - 1) % 3][Q_LP], hist[(t - 1) % 3][Q_KE], h0_shared);
-      const Cmd nxt = I.tick(*prm, io, t + 1, m, early);  // issues tick t+1
+      // (the straight-line form of the ordinary tick whenever the chain qualifies, as the kernel does when all its chains do)
+      const Cmd nxt = I.fast_ok(t + 1, m) ? I.tick_fast(*prm, io, t + 1, m) : I.tick(*prm, io, t + 1, m, early);  // issues tick t+1
       T.tick(t, ring[t % 4]);                         // tick t
       memcpy(hist[t % 3], T.sums, sizeof(psums));
       if (ring[t % 4].op & OP_STEP) steps += 1;

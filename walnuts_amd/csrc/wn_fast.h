@@ -726,6 +726,46 @@ struct IssueBookT : BookUniforms {
     const double Wnew = exp(-Hn + H0 + 0.0);
     return (0.0 + Wnew) > prm.wtSumThresh;
   }
+  // ---- the ordinary tick, straight-line (round 5) -------------------------------------------------------------------------------
+  // The issue wave's pass is what the kernel's tick is made of (wn_k_fast4.hip, -DWN4_PAD_I: every instruction added to it costs the
+  // tick ~1.7 quad-cycles; the T and retire waves' cost a third / a half of that), and most of its ticks are the same thing for all its
+  // chains: a chain in the middle of a doubling gets the next leaf of its pair.  fast_ok(): this tick is that for this chain --
+  // state RUN, the message carries no doubling / iteration end, an even tick starts a pair whose step sizes can be drawn (the draws of
+  // the leaves in flight are certain), an odd tick issues the second leaf and it is not the doubling's last.  tick_fast(): what tick()
+  // does in that case, bit for bit, in select form and without the uniform cache's branches (fast_kh() says which uniforms an even
+  // tick reads: the caller checks that its window holds them).  The kernel takes it when EVERY chain of the wave qualifies; the CPU
+  // harness takes it whenever the chain does (tests/hostsim/fastsim.cpp), so both paths run against the oracle.
+  WN_HD bool fast_ok(uint32_t tn, const RMsg& m) const {
+    const int nrt = (int)(m.w & RM_NRT_MASK);
+    const bool ev = (n_is & 1) == 0 && (n_is <= nrt || (m.w & RM_CERTAIN) != 0);
+    const bool od = (n_is & 1) != 0 && n_is + 1 < nleaf;
+    return st == ST_RUN && (m.w & (RM_END | RM_CONT)) == 0 && ((tn & 1u) ? od : ev);
+  }
+  WN_HD uint32_t fast_kh(const RMsg& m) const {  // first uniform of the pair's two step sizes (even ticks), with the message applied
+    const int nrt = (int)(m.w & RM_NRT_MASK);
+    const uint32_t ahead = m.ku + (uint32_t)(n_is - nrt) + 2u * (uint32_t)(((n_is + 1) >> 1) - ((nrt + 1) >> 1));
+    return n_is > nrt ? ahead : m.ku;
+  }
+  template <class IO>
+  WN_HD Cmd tick_fast(const Params& prm, IO& io, uint32_t tn, const RMsg& m) {
+    ku = m.ku; n_rt = (int)(m.w & RM_NRT_MASK); certain = (m.w & RM_CERTAIN) != 0;
+    zwant = (int)m.zwant; rdead = (m.w & RM_DEAD) != 0;
+    Cmd c;
+    c.op = OP_STEP | ((uint32_t)i << OP_I_SHIFT) | ((m.w & RM_PICK) ? (OP_PICK | ((m.w & RM_PICKIP) ? OP_IPPICK : 0u)) : 0u);
+    c.n = (uint32_t)n_is;
+    double h = h2;
+    if ((tn & 1u) == 0) {  // (the same for every chain of the wave: a scalar branch)
+      const uint32_t kh = fast_kh(m);
+      h = h_from(prm, io.u_direct(iter, kh));
+      h2 = h_from(prm, io.u_direct(iter, kh + 1u));  // :395
+    }
+    c.hs = (double)xi * h;
+    n_is++;
+    c2step = c1step;
+    c1step = true;
+    return c;
+  }
+
   // One tick: apply the retire side's message of this tick, issue tick `tn`.
   template <class IO>
   WN_HD Cmd tick(const Params& prm, IO& io, uint32_t tn, const RMsg& m, bool early = false) {

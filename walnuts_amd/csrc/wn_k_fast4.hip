@@ -125,7 +125,26 @@ struct Fast4Geom {
 constexpr bool OPT_POLL = (WN4_OPT & 1) != 0;    // the spin loop out of line, tick 0 no special case
 constexpr bool OPT_L12 = (WN4_OPT & 4) != 0;     // levels 1 / 2 on every odd tick without votes
 constexpr bool OPT_EP = (WN4_OPT & 8) != 0;      // endpoint pushes as predicated stores (no vote, no branch)
+constexpr bool OPT_PRE = (WN4_OPT & 64) != 0;    // T wave (whole-group form too): the next tick's command record requested behind the MFMA phase
+constexpr bool OPT_IFAST = (WN4_OPT & 32) != 0;  // I wave: the ordinary tick as straight-line code when every chain of the wave qualifies
 constexpr bool OPT_SLIDE = (WN4_OPT & 16) != 0;  // I wave: a window refill slides the windows of ALL its chains (the Philox passes are paid per wave, not per chain)
+
+// sensitivity diagnostic (tools/variant_fast4_many.sh padT:-DWN4_PAD_T=40 ...): N dependent vector instructions more per tick in one
+// kind of wave -- whose pass is the tick made of?
+template <int N>
+__device__ __forceinline__ void wn4_pad(double& sink) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(sink));
+}
+#if !defined(WN4_PAD_T)
+#define WN4_PAD_T 0
+#endif
+#if !defined(WN4_PAD_R)
+#define WN4_PAD_R 0
+#endif
+#if !defined(WN4_PAD_I)
+#define WN4_PAD_I 0
+#endif
 
 __device__ __forceinline__ double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 
@@ -358,7 +377,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     // (halves only: with a second wave on the SIMD the round trip is hidden and the extra read costs 1.5 %)
     uint64_t cw = cw_pre;
     double chs = chs_pre;
-    if (HALF == 0 && (OPT_POLL || t != 0)) cmd_read(rec, cw, chs);  // (tick 0: the record the kernel's prologue wrote -- tag 0 -- so tick 0 is no special case)
+    if (HALF == 0 && !OPT_PRE && (OPT_POLL || t != 0)) cmd_read(rec, cw, chs);  // (tick 0: the record the kernel's prologue wrote -- tag 0 -- so tick 0 is no special case)
     // fragments in flight: 3 k-steps ahead (six MFMAs = 96 cycles each: an LDS round trip is covered); a half wave issues three MFMAs
     // per k-step and has the register file of a SIMD to itself: 6 ahead, and only the pairs of its own row sets
     constexpr int AHEAD = HALF ? 6 : 3, NF = HALF ? 8 : 4, QAHEAD = HALF ? 4 : 2, NQ = HALF ? 8 : 3;
@@ -392,13 +411,15 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     }
     WN4_STAMP(7);
     Cmd c;
+    bool gaveup = false;  // (a bounded spin gave up: the tick runs to its end on whatever it has -- nothing it stores is read -- and leaves there:
+                          //  ONE exit from the tick body, at its end, instead of a return in the middle with its merge branches)
     if constexpr (OPT_POLL) {
       // the ordinary tick finds its record: ONE branch; the spin loop is out of the way
       if (__builtin_expect(!__all(cmd_is_for(cw, t)), 0)) {
         uint32_t spins = 0;
         do {  // (bounded: a protocol error must not hang the GPU)
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 23)) { if (lane == 0) atomicExch(abort_flag, 1); return false; }
+          if (++spins > (1u << 23)) { if (lane == 0) atomicExch(abort_flag, 1); gaveup = true; cw = 0; chs = 0.0; break; }
           cmd_read(rec, cw, chs);
         } while (!__all(cmd_is_for(cw, t)));
       }
@@ -427,6 +448,8 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     const bool deep0 = nchk > NFAST, deep1 = nchk > NFAST + 1;
     // ONE vote for everything that does not happen on an ordinary leaf; `anydeep`: the sub-tree checks of levels >= 3 (SOME chain of the
     // group closes such a sub-tree on two odd ticks in three)
+    // (no __builtin_expect on these votes: with `anyrare` / `anyl0` marked unlikely hipcc 7.2 produced a kernel that ran 15 % slower AND
+    //  returned wrong draws -- 70 mismatching chains in 120 fuzz configurations, gpurun_out/r05)
     const bool anyrare = __any((op & (OP_PICK | OP_NEWITER | OP_SWAP | OP_UNDO | OP_DONE)) != 0 || deep0);
     const bool anydeep = PAR == 1 && anyrare && __any(deep0);
     if (anydeep) {  // (per chain, under exec masks: fetching both levels for every chain of the group cost 4 % -- vector-memory instructions are what a tick pays for)
@@ -444,7 +467,6 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
       }
     }
     if (anyrare) {
-      if (__any((op & OP_DONE) != 0)) return false;
       if (__any((op & OP_PICK) != 0)) {  // `pk` holds the position of tick t-3
         if (op & OP_PICK) {
           double* dst = gvec(vprop + ((op & OP_IPPICK) ? 1 : 0));
@@ -553,7 +575,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
         if (HALF != 0 && it == IWAIT) {  // from here on the partner's coordinates are read: it must have staged tick t
           uint32_t spins = 0;
           while ((int32_t)(xseq[2 - HALF] - (t + 1u)) < 0) {
-            if (++spins > (1u << 24)) { if (lane == 0) atomicExch(abort_flag, 1); return false; }
+            if (++spins > (1u << 24)) { if (lane == 0) atomicExch(abort_flag, 1); gaveup = true; break; }
           }
           asm volatile("" ::: "memory");
         }
@@ -586,7 +608,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
     }
     }
     WN4_STAMP(1);
-    if (HALF != 0) cmd_read(pr + G::P_CMD + (((t + 1u) & 3u) * 4 + x) * 2, cw_pre, chs_pre);
+    if (HALF != 0 || OPT_PRE) cmd_read(pr + G::P_CMD + (((t + 1u) & 3u) * 4 + x) * 2, cw_pre, chs_pre);
     // the passive orbit end lives in memory (once per doubling: the whole-orbit check at its last leaf, and the end swaps): requested
     // here, in the registers the fragments have left, used after the half step
     const bool anyl0 = __any(l0due);
@@ -676,6 +698,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
       }
     }
     if ((PAR == 1 || t == 0) && anyrare && __any((op & OP_NEWITER) != 0)) put4(sp + 16 * (G::NB - 1), keinit_part, gen_part, 0.0, 0.0);
+    if constexpr (WN4_PAD_T > 0) { double sink_ = pl; wn4_pad<WN4_PAD_T>(sink_); asm volatile("" ::"v"(sink_)); }
     seq[0] = t + 1u;  // the sums of tick t are in LDS (same wave, in order; all lanes store the one word)
     WN4_STAMP(2);
     // ---- statePush (:431,518): only sub-tree left endpoints are ever read back; they are even leaves ----
@@ -707,9 +730,10 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
 #if defined(WN_STAMPS)
     fst_[6] += 1;
 #endif
-    return true;
+    // every chain of the group has finished (OP_DONE is issued to all four at once), or a spin gave up: the one way out
+    return !(gaveup || (anyrare && __any((op & OP_DONE) != 0)));
   };
-  if (HALF != 0 && OPT_POLL) cmd_read(pr + G::P_CMD + x * 2, cw_pre, chs_pre);  // tick 0's record (the kernel's prologue wrote it)
+  if ((HALF != 0 || OPT_PRE) && OPT_POLL) cmd_read(pr + G::P_CMD + x * 2, cw_pre, chs_pre);  // tick 0's record (the kernel's prologue wrote it)
   int t3 = 0;
   for (uint32_t t = 0;; t += 2) {
     if (!tick(std::integral_constant<int, 0>{}, X1, X0, V1, V0, t, t3)) break;
@@ -743,6 +767,16 @@ struct Fast4IO {
     ua = *(const lds_vf64*)(e + 1); ub = *(const lds_vf64*)(e + 2);
     return t0 == (uint32_t)iter && t1 == blk;
   }
+  // (issue wave) its own window of uniforms, read without the tag checks: the wave wrote the entries itself and knows what they hold --
+  // blocks 0..7 and [wbase, wbase + 16) of iteration witer (IssueBookT::tick_fast)
+  int witer;
+  uint32_t wbase;
+  __device__ __forceinline__ bool win_has(int iter, uint32_t k) const { const uint32_t blk = k >> 1; return iter == witer && (blk < 8u || blk - wbase < 16u); }
+  __device__ __forceinline__ double u_direct(int, uint32_t k) const {
+    const uint32_t blk = k >> 1;
+    const double* e = pr + (blk < 8u ? G::P_USTAT + (x * 8 + (int)blk) * 3 : G::P_URING + (x * 16 + (int)(blk & 15u)) * 3);
+    return *(const lds_vf64*)(e + 1 + (k & 1u));
+  }
   __device__ __forceinline__ void write_h0(double v) const { if (rep == 0) *(lds_vf64*)(pr + G::P_H0 + x) = v; }
   // warm-up (WALNUTS.py:701-712): the adapted H goes to the issue side through LDS, written before the message that ends the iteration
   // (same wave, in order); the sorted energy-error factors of the delta quantile live in memory, [chain][2][warmupIter], one writer
@@ -771,11 +805,14 @@ struct Fast4IO {
   }
 };
 
+#if !defined(WN4_BSLEEP)
+#define WN4_BSLEEP 1
+#endif
 // wait until *p >= want (every lane its own word) or the quad's run-is-over word is set; false: neither within the bound
 __device__ __forceinline__ bool seq_wait2(const lds_vu32* p, uint32_t want, const lds_vu32* over) {
   uint32_t spins = 0;
   while (__any((int32_t)(*p - want) < 0) && *over == 0u) {
-    __builtin_amdgcn_s_sleep(1);  // (coarser polling, up to s_sleep 16, changes nothing: gpurun_out/r03/ab30.txt)
+    __builtin_amdgcn_s_sleep(WN4_BSLEEP);  // (coarser polling, up to s_sleep 16, changes nothing: gpurun_out/r03/ab30.txt)
     if (++spins > (1u << 23)) return false;
   }
   asm volatile("" ::: "memory");
@@ -799,7 +836,7 @@ __device__ __forceinline__ void fast4_r_wave(const Params& prm, double* quad, co
   bk.init_warm(prm);
   Fast4IO<G, TRACE> io;
   io.prm = &prm; io.pr = pr; io.cl = cl; io.x = x; io.rep = rep;
-  io.lp = io.ke = io.keinit = io.gen = 0.0; io.fire = 0u; io.ntrace = 0;
+  io.lp = io.ke = io.keinit = io.gen = 0.0; io.fire = 0u; io.ntrace = 0; io.witer = 0; io.wbase = 0u;
   WN4_STAMP_DECL
   int t3 = 1;  // (t - 2) % 3: the slot of the sums this tick retires
   for (uint32_t t = 0;; ++t, t3 = t3 == 2 ? 0 : t3 + 1) {
@@ -851,6 +888,7 @@ __device__ __forceinline__ void fast4_r_wave(const Params& prm, double* quad, co
     }
     WN4_STAMP(1);
     const RMsg m = bk.tick(prm, io, c);
+    if constexpr (WN4_PAD_R > 0) { double sink_ = io.lp; wn4_pad<WN4_PAD_R>(sink_); asm volatile("" ::"v"(sink_)); }
     WN4_STAMP(2);
     if (rep == 0 && pq < npairs) msgbuf[t3 == 0 ? 2 * 4 + x : (t3 - 1) * 4 + x] = m;  // slot t % 3 = (t3 + 2) % 3
     if (lane == 0) seqQ[4] = t + 1u;  // message t is in LDS (same wave, in order)
@@ -877,11 +915,16 @@ __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, co
   Fast4IO<G, TRACE> io;
   io.prm = &prm; io.pr = pr; io.cl = cl; io.x = x; io.rep = rep;
   io.lp = io.ke = io.keinit = io.gen = 0.0; io.fire = 0u; io.ntrace = 0;
-  int witer = 0;          // iteration and first block of the uniform window
-  uint32_t wbase = 0u;
+  int& witer = io.witer;          // iteration and first block of the uniform window
+  uint32_t& wbase = io.wbase;
+  witer = 0; wbase = 0u;
   // every chain needs at most numIter * (2^M - 1 + idle ticks per doubling + start) ticks; twice that is an internal error
   const double cap = 256.0 + 2.0 * (double)prm.numIter * ((double)(1u << prm.M) + 6.0 * (double)prm.M + 16.0);
   WN4_STAMP_DECL
+  uint32_t tch[16];       // registers of the cache-touching loads in flight (below)
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tch[k] = 0u;
+  bool touched = false;
   int t3 = 0;  // t % 3
   for (uint32_t t = 0;; ++t, t3 = t3 == 2 ? 0 : t3 + 1) {
 #if defined(WN4_TONLY)  // diagnostic: the T waves alone, on a fixed stream of ordinary leaves
@@ -969,8 +1012,14 @@ __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, co
     if (pq < npairs) m = msgbuf[t3 * 4 + x];
     // the second leaf pair of a doubling: its first leaf (tick t-1) is certified here, from the T wave's sums, one tick before the retire
     // side would (wn_fast.h IssueBook::wants_early: two idle ticks per doubling otherwise).  Rare: one tick per doubling and chain.
+    // the ordinary tick -- every chain of the wave in the middle of a doubling, its uniforms in the window -- is straight-line code
+    // (wn_fast.h IssueBookT::tick_fast): no early-certification vote, no state machine, no tag checks
+    bool fl = bk.fast_ok(t + 1u, m);
+    if (((t + 1u) & 1u) == 0) { const uint32_t kh = bk.fast_kh(m); fl = fl && io.win_has(bk.iter, kh) && io.win_has(bk.iter, kh + 1u); }
+    const bool isdead = bk.st == IssueBookT<WARM>::ST_DEAD;
+    const bool allfast = OPT_IFAST && __all(fl || isdead);
     bool early = false;
-    {
+    if (!allfast) {
       const bool we = inrange && bk.wants_early(t + 1u, m);
       if (__any(we)) {
         if (!seq_wait2(lds_words(pr + G::P_SEQ) + (HALVES ? (rep & 1) : 0), t, seqQ + 6)) { if (lane == 0) atomicExch(abort_flag, 1); break; }  // the T wave(s) finished tick t-1
@@ -982,7 +1031,14 @@ __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, co
       }
     }
     WN4_STAMP(1);
-    Cmd c = bk.tick(prm, io, t + 1u, m, early);
+    Cmd c;
+    if (allfast) {
+      c = bk.tick_fast(prm, io, t + 1u, m);
+      c.op = isdead ? 0u : c.op; c.hs = isdead ? 0.0 : c.hs; c.n = isdead ? 0u : c.n;  // (a lane without a chain, or a finished one: tick() issues nothing)
+    } else {
+      c = bk.tick(prm, io, t + 1u, m, early);
+    }
+    if constexpr (WN4_PAD_I > 0) { double sink_ = c.hs; wn4_pad<WN4_PAD_I>(sink_); c.hs = sink_ == 12345.678 ? 0.0 : c.hs; }
     WN4_STAMP(2);
     // ---- every chain of the quad has finished: all its waves leave (the quads of a workgroup do not wait for each other) ----
     bool done = anyrare && __all(bk.finished());  // (finished() needs ST_DEAD, which was part of this tick's one vote, or shows at the next)
@@ -993,6 +1049,14 @@ __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, co
     if (done) { c.op |= OP_DONE; if (lane == 0) seqQ[6] = 1u; }
     if (rep == 0 && pq < npairs) cmd_publish(pr + G::P_CMD + (((t + 1u) & 3u) * 4 + x) * 2, c, t + 1u);
 #if !defined(WN4_NOTOUCH)
+    // (the values these loads return are never used, but the registers they land in must stay reserved until they have arrived: they are
+    //  "read" HERE, a whole tick after the loads were issued -- round 4 read them right behind the loads, and the issue wave, whose pass
+    //  is what the tick is made of (tools: -DWN4_PAD_I), stood still for a memory round trip on every tick that touched something)
+    if (touched) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { asm volatile("" ::"v"(tch[k])); tch[k] = 0u; }
+      touched = false;
+    }
     // ---- the vectors the T wave will fetch from memory in tick t+1 with nothing to do meanwhile -- the passive orbit end (last leaf of a
     // doubling, end swap) and the sub-tree endpoints of levels >= 5 (fetched when due) -- are pulled into the CU's vector cache now: one
     // 4-byte load per 128-byte line (replica s touches register s of the chain's vector); the values are not used.
@@ -1007,9 +1071,6 @@ __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, co
                                                                      x * (NS * 16) + (rep < NS ? rep : 0) * 16);
         const size_t vstride = (size_t)G::VEC * 2;  // (in 4-byte words)
         const int vcold = (prm.M + 1) * 2 + 2;
-        uint32_t tch[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) tch[k] = 0u;
         if (cold && rep < NS) { tch[0] = wb[vcold * vstride]; tch[1] = wb[(vcold + 1) * vstride]; }
 #pragma unroll
         for (int j = 5; j <= G::MP; ++j) {
@@ -1021,10 +1082,7 @@ __device__ __forceinline__ void fast4_i_wave(const Params& prm, double* quad, co
             }
           }
         }
-        uint32_t a = 0u;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a ^= tch[k];
-        asm volatile("" ::"v"(a));
+        touched = true;
       }
     }
 #endif
@@ -1090,9 +1148,12 @@ __global__ __launch_bounds__(HALVES ? 256 : 512) void wn_fast4_kernel(Params prm
   const int tw = wave - 2 * quads, bw = wave;
 #endif
   if (is_t) {
-    // the T waves go first: the bookkeeper waves have half a tick of slack and take the issue slots a T wave leaves (measured: T waves
-    // at priority 1 1.32e9 steps/s, equal priorities with the bookkeepers as the older waves 1.27e9; raising the R or I wave to the
-    // T waves' priority, or only while a T wave is about to need their command, was slower)
+    // Priorities.  Round 3: T waves at priority 1 over bookkeepers at 0 (1.32e9 steps/s against 1.27e9 with equal priorities; raising
+    // the R or I wave was slower THEN).  Round 5 measured whose pass the tick is made of -- N dependent vector instructions more per tick in
+    // one kind of wave (-DWN4_PAD_T / _R / _I = 40): T +1.5 %, R +2.1 %, I +4.1 % of the tick (gpurun_out/r05/ab4.txt) -- the ISSUE wave's,
+    // whose vector instructions get no slot during the 650 quad-cycles of its SIMD's MFMA phase.  With the bookkeepers ABOVE the T waves
+    // (I 3, R 2, T 1) their instructions slip in between the MFMAs: 1.375e9 -> 1.412e9 (ab7.txt / ab8.txt; every assignment with both
+    // bookkeepers above T gives 1.407-1.414e9, coarser polling changes nothing).
 #if !defined(WN4_TPRIO)
 #define WN4_TPRIO 1
 #endif
@@ -1100,12 +1161,14 @@ __global__ __launch_bounds__(HALVES ? 256 : 512) void wn_fast4_kernel(Params prm
     double* pr = lds + G::OFF_PAIR + (size_t)tw * G::PAIR_DOUBLES;
     fast4_t_wave<G, TRACE>(prm, lds, pr, (int)blockIdx.x * pairs + tw, abort_flag);
   } else {
-#if defined(WN4_RPRIO)
+#if !defined(WN4_RPRIO)
+#define WN4_RPRIO 2
+#endif
+#if !defined(WN4_IPRIO)
+#define WN4_IPRIO 3
+#endif
     if (!(bw & 1)) __builtin_amdgcn_s_setprio(WN4_RPRIO);
-#endif
-#if defined(WN4_IPRIO)
     if (bw & 1) __builtin_amdgcn_s_setprio(WN4_IPRIO);
-#endif
     const int quad = bw >> 1;
     double* qd = lds + G::OFF_PAIR + (size_t)(2 * quad) * G::PAIR_DOUBLES;
     const int np = pairs - 2 * quad >= 2 ? 2 : 1;
