@@ -125,6 +125,9 @@ struct Fast4Geom {
 constexpr bool OPT_POLL = (WN4_OPT & 1) != 0;    // the spin loop out of line, tick 0 no special case
 constexpr bool OPT_L12 = (WN4_OPT & 4) != 0;     // levels 1 / 2 on every odd tick without votes
 constexpr bool OPT_EP = (WN4_OPT & 8) != 0;      // endpoint pushes as predicated stores (no vote, no branch)
+// (measured and dropped, round 5, gpurun_out/r05/ab13.txt: an even tick's endpoint pushes issued in the shadow of the NEXT tick's MFMAs -- the
+//  state pushed is that tick's (qc, vi), which it only reads -- : -0.7 %; the level-2 endpoint read from LDS in the shadow of the tick's last MFMAs:
+//  -19 %, its fourteen registers spill.  The MFMA shadow is not free: with the bookkeepers above the T waves it is where THEY run.)
 constexpr bool OPT_PRE = (WN4_OPT & 64) != 0;    // T wave (whole-group form too): the next tick's command record requested behind the MFMA phase
 constexpr bool OPT_IFAST = (WN4_OPT & 32) != 0;  // I wave: the ordinary tick as straight-line code when every chain of the wave qualifies
 constexpr bool OPT_SLIDE = (WN4_OPT & 16) != 0;  // I wave: a window refill slides the windows of ALL its chains (the Philox passes are paid per wave, not per chain)
