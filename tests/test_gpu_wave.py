@@ -25,11 +25,15 @@ WAVE = [
     ("dense300_R2P_split", ol.T_DENSEGAUSS, 300, ol.I_ADAPT_R2P, dict(H0=1.2, delta0=0.3, M=5, numIter=3), 6, (0, 5)),
     ("dense520_D_split", ol.T_DENSEGAUSS, 520, ol.I_ADAPT_D, dict(H0=1.2, delta0=0.3, M=4, numIter=2), 3, (2,)),
     ("dense1000_fixed_split", ol.T_DENSEGAUSS, 1000, ol.I_FIXED, dict(H0=0.5, M=5, numIter=2), 5, (0, 4)),
-    # adaptLeapFrogFlowD (adaptiveIntegrators.py:246-356) has no cooperative-layout kernel: Gaussians beyond the
-    # lane layout run one chain per wavefront, dense ones in split mode (two exchanges per micro step)
-    ("std60_F_wave", ol.T_STDGAUSS, 60, ol.I_ADAPT_FLOWD, dict(H0=1.2, delta0=0.02, M=5, numIter=3), 3, (0, 2)),
+    # adaptLeapFrogFlowD (adaptiveIntegrators.py:246-356): Gaussians of up to 128 dimensions run in the cooperative MFMA layout (round 5: a
+    # micro step is two ticks of the group's machine -- std 60-D 3x, dense 40-D 20x the layouts below, tools/flowd_ab.py); beyond it one
+    # chain per wavefront, dense ones in split mode (two exchanges per micro step)
+    ("std60_F_coop", ol.T_STDGAUSS, 60, ol.I_ADAPT_FLOWD, dict(H0=1.2, delta0=0.02, M=5, numIter=3), 3, (0, 2)),
+    ("diag100_F_coop", ol.T_DIAGGAUSS, 100, ol.I_ADAPT_FLOWD, dict(H0=0.9, delta0=0.05, M=5, numIter=3), 20, (1, 19)),
     ("diag300_F_wave", ol.T_DIAGGAUSS, 300, ol.I_ADAPT_FLOWD, dict(H0=0.9, delta0=0.05, M=5, numIter=3), 3, (1,)),
-    ("dense40_F_split", ol.T_DENSEGAUSS, 40, ol.I_ADAPT_FLOWD, dict(H0=1.0, delta0=0.05, M=5, numIter=3), 5, (0, 4)),
+    ("dense40_F_coop", ol.T_DENSEGAUSS, 40, ol.I_ADAPT_FLOWD, dict(H0=1.0, delta0=0.05, M=5, numIter=3), 5, (0, 4)),
+    ("dense100_F_coop", ol.T_DENSEGAUSS, 100, ol.I_ADAPT_FLOWD, dict(H0=1.0, delta0=0.05, M=5, numIter=3), 37, (0, 16, 36)),
+    ("dense128_F_coop", ol.T_DENSEGAUSS, 128, ol.I_ADAPT_FLOWD, dict(H0=1.0, delta0=0.05, M=4, numIter=2), 17, (3, 16)),
     ("dense200_F_split", ol.T_DENSEGAUSS, 200, ol.I_ADAPT_FLOWD, dict(H0=1.0, delta0=0.05, M=4, numIter=2), 3, (2,)),
 ]
 
@@ -51,7 +55,7 @@ def test_wave_layout_matches_oracle(wa, case):
              numIter=kw["numIter"], minC=0, maxC=10, R2Pprob0=2.0 / 3.0, generated=0, gen_k=0, tpar=tpar)
     cap = 3 * (2 ** kw["M"]) * kw["numIter"] // 2
     out = run_engine(wa, c, q0, cap, chain_offset=9000)
-    assert ("wave" in out["kernel"]) or ("split" in out["kernel"]), out["kernel"]
+    assert name.rsplit("_", 1)[1] in out["kernel"], (name, out["kernel"])  # the layout the case is named after
     for k in check:
         o = ol.walnuts(tk, q0[k], integrator=ig, tpar=tpar, H0=c["H0"], delta0=c["delta0"],
                        numIter=c["numIter"], M=c["M"], seed=SEED, chain=9000 + k, trace_cap=cap)

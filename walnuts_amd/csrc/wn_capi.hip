@@ -39,7 +39,9 @@ static int lane_dmax(int target, int D) {
 
 int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_chains, KernelChoice* kc) {
   kc->G = 1;
-  const bool flow = integrator == I_ADAPT_FLOWD;  // no cooperative-layout kernels: its gradient holds barriers
+  const bool flow = integrator == I_ADAPT_FLOWD;  // (round 5: it runs in the cooperative MFMA layout too, one or two tiles per wave)
+  static const bool flow_nocoop = getenv("WN_FLOW_NOCOOP") != nullptr;       // diagnostic / A-B: FlowD as before round 5 (lane / wave / split)
+  const int flow_ksmax = getenv("WN_FLOW_KSMAX") ? atoi(getenv("WN_FLOW_KSMAX")) : 32;  // diagnostic: largest k-step count FlowD takes to the coop layout
   char* nm = kc->name;  // per-choice storage: the engine owns its kernel name
   nm[0] = 0;
   static const bool force_wave = getenv("WN_FORCE_WAVE") != nullptr;  // diagnostic: std / diagonal Gaussians on the wave layout
@@ -52,7 +54,7 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_
   // 64k chains against a flat 5.2e8; R2P crosses at 16k).  adaptLeapFrogFlowD has no MFMA-group kernel.
   static const bool lane_gauss = getenv("WN_LANE_GAUSS") != nullptr;  // diagnostic: always per lane
   if (!lane_gauss && waves_per_group != 64 && (target == T_STDGAUSS || target == T_DIAGGAUSS || target == T_DENSEGAUSS) &&
-      !(D <= 4 && integrator == I_FIXED) && !(target == T_DENSEGAUSS && integrator == I_ADAPT_FLOWD) &&
+      !(D <= 4 && integrator == I_FIXED) && !(target == T_DENSEGAUSS && flow && flow_nocoop) &&
       n_chains < (integrator == I_FIXED ? 8192 : 16384))
     dm = 0;
   if ((target == T_CORRGAUSS || target == T_SMILE || target == T_FUNNEL1 || target == T_MODFUNNEL) && D == 2 &&
@@ -94,7 +96,7 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_
     if (W != 4) return -1;
     const int ks = (D + 3) / 4;
     int KS = 0, NT = 0;
-    if (flow || (force_wave && target != T_DENSEGAUSS)) {
+    if ((flow && (flow_nocoop || ks > flow_ksmax)) || (force_wave && target != T_DENSEGAUSS)) {
     } else if (target == T_DENSEGAUSS) {
       if (ks <= 16) { KS = 16; NT = 1; }
       else if (ks <= 25) { KS = 25; NT = 2; }

@@ -6,18 +6,30 @@
 
 namespace wn {
 
-template <int NT, int W, int KS, int TK, bool ADAPT, bool WARM>
+// FLOW: adaptLeapFrogFlowD (adaptiveIntegrators.py:246-356; round 5): a micro step is two ticks of the same machine -- the leapfrog
+// half, then the gradient at the midpoint -- so the group's gradient (and its barriers) is still one call per tick for every chain
+template <int NT, int W, int KS, int TK, bool ADAPT, bool WARM, bool FLOW = false>
 __global__ __launch_bounds__(W * 64) void wn_coop_kernel(Params prm) {
   __shared__ double lds[CoopPolicy<NT, W, KS, TK>::LDS_DOUBLES];
   CoopPolicy<NT, W, KS, TK> p(prm, lds);
-  Engine<CoopPolicy<NT, W, KS, TK>, ADAPT, WARM> eng(p, prm);
+  Engine<CoopPolicy<NT, W, KS, TK>, ADAPT, WARM, FLOW> eng(p, prm);
   eng.run();
 }
 
 template <int NT, int W, int KS, int TK>
-static hipError_t go(bool adapt, bool warm, const Params& prm, hipStream_t st) {
+static hipError_t go(int adapt_, bool warm, const Params& prm, hipStream_t st) {
   dim3 grid((prm.C + 15) / 16), block(W * 64);
+  const bool adapt = adapt_ != 0;
 #ifndef WN_ONLY_FIXED
+  if (adapt_ == 2) {  // adaptLeapFrogFlowD
+    if constexpr (NT <= 2) {
+      if (warm) hipLaunchKernelGGL((wn_coop_kernel<NT, W, KS, TK, true, true, true>), grid, block, 0, st, prm);
+      else hipLaunchKernelGGL((wn_coop_kernel<NT, W, KS, TK, true, false, true>), grid, block, 0, st, prm);
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if (warm) {
     if (adapt) hipLaunchKernelGGL((wn_coop_kernel<NT, W, KS, TK, true, true>), grid, block, 0, st, prm);
     else hipLaunchKernelGGL((wn_coop_kernel<NT, W, KS, TK, false, true>), grid, block, 0, st, prm);
@@ -36,8 +48,8 @@ size_t coop_work_doubles(int NT, int W, int C, int M) {
 }
 
 hipError_t launch_coop(const KernelChoice& kc, int adapt_, bool warm, const Params& prm, hipStream_t st) {
-  if (kc.W != 4 || adapt_ == 2) return hipErrorInvalidValue;  // adaptLeapFrogFlowD runs in the lane / wave layouts
-  const bool adapt = adapt_ != 0;
+  if (kc.W != 4) return hipErrorInvalidValue;
+  const int adapt = adapt_;
   // p0 = k-steps (= ceil(D/4) rounded up to an instantiated value)
 #ifdef WN_EXP_W8  // experiment: eight waves per group, one 16-row tile each (two waves per SIMD)
   if (kc.p1 == CK_DENSE && kc.p0 == 25) return go<1, 8, 25, CK_DENSE>(adapt, warm, prm, st);

@@ -165,6 +165,42 @@ struct CoopPolicy {
     }
   }
 
+  // max over the 4*W lanes that serve a chain (NaN-free inputs; max is exact, so every replica agrees): the flow errors of
+  // adaptLeapFrogFlowD (adaptiveIntegrators.py:276-287)
+  __device__ __forceinline__ static double rowmax4(double x) {
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    u2_t a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    u2_t b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double y = fmax(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+    lo = __double2loint(y); hi = __double2hiint(y);
+    a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return fmax(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+  }
+  template <int N>
+  __device__ __forceinline__ void reduce_max(double* v) {
+    static_assert(N <= NRED, "reduce width");
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = rowmax4(v[k]);
+    if (W > 1) {
+      double* buf = ldsr + (redpar & 1) * (NRED * W * 16);
+      redpar++;
+      if (lg == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) buf[(k * W + wave) * 16 + cn] = v[k];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        double s = buf[(k * W) * 16 + cn];
+#pragma unroll
+        for (int w = 1; w < W; ++w) s = fmax(s, buf[(k * W + w) * 16 + cn]);
+        v[k] = s;
+      }
+    }
+  }
+
   // grad = -A q for the 16 chains of the group; lp partial = sum_e q_e g_e (lp = 1/2 q.g)
   __device__ __forceinline__ void grad(const Vec& q, Vec& g, double& lp_part) {
     if (TK == CK_DENSE) {
