@@ -157,9 +157,9 @@ int wn_split_done(wn_engine *e, int32_t *n_done, void *stream);
 
 /* wn_run with recordOrbitStats=True (WALNUTS.py:128,182-184,724-725): additionally fills
  * orbit_min_dev / orbit_max_dev [C][n_iter][dg] with the per-iteration minimum / maximum of
- * generated(q) over the states of the orbit: identity, first-k and [q0, sum q^2].  WN_G_SW_CONSTRAIN is applied to the
- * draws only, so this call returns WN_E_UNSUPPORTED for it: that combination is NOT SUPPORTED (the transform is not monotone per
- * coordinate -- exp and cumulative sums -- so bounds of the identity kind cannot be transformed afterwards either). */
+ * generated(q) over the states of the orbit: identity, first-k, [q0, sum q^2] and (round 5) WN_G_SW_CONSTRAIN -- StockWatson's
+ * param_constrain (mainSW.py:28-29) is applied to every orbit state inside the kernel, as the reference's recordOrbitStats does with
+ * any generated(). */
 int wn_run_orbit_stats(wn_engine *e, const double *q0_dev, uint64_t seed, int32_t n_iter,
                        double *samples_dev, double *diag_dev, double *orbit_min_dev,
                        double *orbit_max_dev, void *stream);

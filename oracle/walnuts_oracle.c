@@ -749,6 +749,7 @@ int wno_gen_dim(const wno_config *cfg) {
     case WNO_G_IDENTITY: return cfg->d;
     case WNO_G_Q0_SUMSQ: return 2;
     case WNO_G_FIRSTK: return cfg->gen_k;
+    case WNO_G_SW_CONSTRAIN: return (cfg->d % 3 == 0 && cfg->d >= 9) ? 2 * cfg->d + 1 : -1;
     default: return -1;
   }
 }
@@ -757,6 +758,24 @@ static void generated(const wno_config *cfg, const double *q, double *out) {
     case WNO_G_IDENTITY: memcpy(out, q, sizeof(double) * cfg->d); break;
     case WNO_G_Q0_SUMSQ: out[0] = q[0]; out[1] = seqdot(cfg->d, q, q); break; /* mainGaussESS.py:29-30 */
     case WNO_G_FIRSTK: memcpy(out, q, sizeof(double) * cfg->gen_k); break;
+    case WNO_G_SW_CONSTRAIN: { /* mainSW.py:28-29 generatedInnov(q) = param_constrain(q, include_tp=True) for sw_innov.stan: the 3T
+                                * unconstrained parameters, then the transformed parameters in declaration order -- sigma, gpri,
+                                * z[T-1], x[T], tau[T] (sw_innov.stan:17-35), the recursions in the model's own order */
+      const int T = cfg->d / 3;
+      memcpy(out, q, sizeof(double) * cfg->d);
+      const double tS = q[0], sigma = exp(-0.5 * tS), gpri = exp(tS);
+      const double *zinn = q + 2, *xinn = q + T + 1, *tin = q + 2 * T + 1;
+      double *o = out + 3 * T;
+      o[0] = sigma; o[1] = gpri;
+      double *z = o + 2, *x = z + (T - 1), *tau = x + T;
+      z[0] = q[1];
+      for (int t = 1; t < T - 1; ++t) z[t] = z[t - 1] + sigma * zinn[t - 1];
+      x[0] = q[T];
+      for (int t = 1; t < T; ++t) x[t] = x[t - 1] + sigma * xinn[t - 1];
+      tau[0] = q[2 * T];
+      for (int t = 1; t < T; ++t) tau[t] = tau[t - 1] + exp(0.5 * z[t - 1]) * tin[t - 1];
+      break;
+    }
   }
 }
 

@@ -51,7 +51,8 @@ enum {
 enum {
   WNO_G_IDENTITY = 0,  /* WALNUTS.py:113 default lambda q: q */
   WNO_G_Q0_SUMSQ = 1,  /* mainGaussESS.py:29-30  [q[0], sum(q*q)] */
-  WNO_G_FIRSTK = 2     /* mainFunnel.py:17-18    q[0:k] */
+  WNO_G_FIRSTK = 2,    /* mainFunnel.py:17-18    q[0:k] */
+  WNO_G_SW_CONSTRAIN = 3 /* mainSW.py:28-29  param_constrain(q, include_tp=True) of sw_innov.stan (:17-35): [q, sigma, gpri, z, x, tau] */
 };
 
 /* rng modes */

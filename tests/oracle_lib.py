@@ -15,7 +15,7 @@ ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 T_STDGAUSS, T_FUNNEL10, T_DENSEGAUSS, T_DIAGGAUSS, T_CORRGAUSS, T_SMILE, T_FUNNEL1, T_MODFUNNEL = range(8)
 T_STOCKWATSON = 11
 I_FIXED, I_ADAPT_D, I_ADAPT_R2P, I_ADAPT_YOSHIDA, I_ADAPT_FLOWD = range(5)
-G_IDENTITY, G_Q0_SUMSQ, G_FIRSTK = range(3)
+G_IDENTITY, G_Q0_SUMSQ, G_FIRSTK, G_SW_CONSTRAIN = range(4)
 RNG_PHILOX, RNG_TAPE = 0, 1
 NDIAG = 24
 TRACE_NSCAL = 12

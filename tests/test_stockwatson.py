@@ -102,3 +102,27 @@ def test_oracle_matches_reference_sampler_at_config5_size(name, tape):
     np.testing.assert_array_equal(o["diagnostics"][:, INT_COLS], ref["diagnostics"][:, INT_COLS])
     np.testing.assert_allclose(o["diagnostics"], ref["diagnostics"], rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(o["samples"], ref["samples"], rtol=1e-7, atol=1e-9)
+
+
+def test_oracle_param_constrain_generated_and_orbit_statistics():
+    """The oracle's generated kind WNO_G_SW_CONSTRAIN restates sw_innov.stan:17-35 (mainSW.py:28-29 param_constrain(q, include_tp=True)):
+    the draws equal the host form of the same transform applied to the identity draws of the same run (to the last bit of exp), and the orbit
+    statistics bracket every draw (WALNUTS.py:182-184: the draw is one of the orbit's states)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from walnuts_amd import targetDistr as td
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stockwatson_data.npz"))
+    for T in (int(g["T"][0]), 12):
+        y = g["y"][:T]
+        tp = np.concatenate([[float(T)], y])
+        q0 = 0.1 * np.random.default_rng(T).normal(size=3 * T)
+        kw = dict(integrator=ol.I_ADAPT_D, tpar=tp, H0=0.1, delta0=0.3, minC=2, numIter=4, M=4, seed=5)
+        o = ol.walnuts(ol.T_STOCKWATSON, q0, generated=ol.G_SW_CONSTRAIN, recordOrbitStats=True, **kw)
+        i = ol.walnuts(ol.T_STOCKWATSON, q0, generated=ol.G_IDENTITY, **kw)
+        gen = td.stockWatsonConstrain(y)
+        assert o["samples"].shape == (6 * T + 1, 5)
+        np.testing.assert_array_equal(o["samples"][:3 * T], i["samples"])
+        # (np.exp and libm's exp differ in the last bit: 1e-13 on the transformed part)
+        np.testing.assert_allclose(o["samples"], np.stack([gen(i["samples"][:, k]) for k in range(5)], axis=1), rtol=1e-13, atol=1e-15)
+        assert (o["orbitMin"] <= o["samples"][:, 1:]).all() and (o["orbitMax"] >= o["samples"][:, 1:]).all()
+        assert (o["orbitMax"][3 * T:] > o["orbitMin"][3 * T:]).mean() > 0.9

@@ -96,7 +96,7 @@ def WALNUTS(lpFun, q0, generated=identity, integrator=ai.fixedLeapFrog, H0=0.2,
     elif recordOrbitStats:
         eng.set_target(lpFun.kind, lpFun.params)
         if host_gen is not None:
-            raise NotImplementedError("recordOrbitStats needs a device form of generated (identity, firstk(k), q0_sumsq)")
+            raise NotImplementedError("recordOrbitStats needs a device form of generated (identity, firstk(k), q0_sumsq, sw_constrain)")
         samples, diag, omin, omax = eng.run_orbit_stats(q0a, seed, numIter)
         out = (samples, diag, omin.transpose(1, 2), omax.transpose(1, 2))  # (dg, numIter) per chain (WALNUTS.py:183-184)
     else:

@@ -938,12 +938,8 @@ int wn_run_orbit_stats(wn_engine* e, const double* q0_dev, uint64_t seed, int32_
   if (!e) return WN_E_ARG;
   if (!e->have_kc) { e->err = "wn_set_target has not been called"; return WN_E_NOTARGET; }
   if (!q0_dev || !samples_dev || !diag_dev || !orbit_min_dev || !orbit_max_dev || n_iter < 0) { e->err = "null buffer or negative n_iter"; return WN_E_ARG; }
-  if (e->cfg.generated == WN_G_SW_CONSTRAIN) {
-    // the sampler fills the identity part of each row and wn_sw_constrain_kernel the transformed parameters of the DRAWS only: the
-    // orbit minima / maxima of sigma, gpri, z, x, tau would stay zero
-    e->err = "orbit statistics are not available with generated = WN_G_SW_CONSTRAIN (use the identity kind and transform the bounds)";
-    return WN_E_UNSUPPORTED;
-  }
+  // (generated = WN_G_SW_CONSTRAIN, round 5: the wave kernel applies param_constrain to every orbit state -- Engine::orbit_stats ->
+  //  WTgtStockWatson::constrain --, as the reference's recordOrbitStats does with any generated(), WALNUTS.py:182-184,331-333)
   HIPCHK(e, hipSetDevice(e->cfg.device));
   Params p;
   fill_params(e, &p);
@@ -952,6 +948,7 @@ int wn_run_orbit_stats(wn_engine* e, const double* q0_dev, uint64_t seed, int32_
   p.warmupIter = (e->cfg.warmup_iter > 0 && (e->cfg.adapt_h || e->cfg.adapt_delta)) ? e->cfg.warmup_iter : 0;
   p.q0 = q0_dev; p.samples = samples_dev; p.diag = diag_dev;
   p.omin = orbit_min_dev; p.omax = orbit_max_dev;
+  if (e->cfg.generated == WN_G_SW_CONSTRAIN) p.generated = G_SW_CONSTRAIN;  // (identity draws as in wn_run; the orbit statistics see the transform)
   return launch(e, p, (hipStream_t)stream, true);
 }
 

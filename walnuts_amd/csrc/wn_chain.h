@@ -32,7 +32,7 @@ namespace wn {
 
 enum { T_STDGAUSS = 0, T_FUNNEL10, T_DENSEGAUSS, T_DIAGGAUSS, T_CORRGAUSS, T_SMILE, T_FUNNEL1, T_MODFUNNEL, T_STOCKWATSON = 11 };
 enum { I_FIXED = 0, I_ADAPT_D = 1, I_ADAPT_R2P = 2, I_ADAPT_YOSHIDA = 3, I_ADAPT_FLOWD = 4 };
-enum { G_IDENTITY = 0, G_Q0_SUMSQ = 1, G_FIRSTK = 2 };
+enum { G_IDENTITY = 0, G_Q0_SUMSQ = 1, G_FIRSTK = 2, G_SW_CONSTRAIN = 3 };
 enum { MODE_SAMPLE = 0, MODE_KAT = 1 };
 enum { NDIAG = 24, TRACE_NSCAL = 12 };
 enum { MAX_M = 24 };
@@ -766,6 +766,9 @@ struct Engine : ChainScalars {
     }
     const int k = prm.generated == G_FIRSTK ? prm.gen_k : prm.D;
     WN_VFOR(e) if (p.valid(e) && p.owner(e) && p.gidx(e) < k) orbit_minmax(row + p.gidx(e), q.x[e], init);
+    // generated = param_constrain(q, include_tp=True) of the StockWatson model (mainSW.py:28-29, sw_innov.stan:17-35): the transformed
+    // parameters of THIS orbit state -- sigma, gpri, z, x, tau behind the 3T unconstrained ones -- from the layout that holds the series
+    if (prm.generated == G_SW_CONSTRAIN) p.sw_constrained(q, [&](int idx, double x) { orbit_minmax(row + (size_t)idx, x, init); });
   }
   WN_HD void orbit_minmax(size_t at, double x, bool init) {
     double* mn = omin() + at;

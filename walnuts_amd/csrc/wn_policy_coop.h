@@ -165,6 +165,8 @@ struct CoopPolicy {
     }
   }
 
+  // (StockWatson's param_constrain for the orbit statistics: the one-chain-per-wavefront layout only)
+  template <class F> __device__ __forceinline__ void sw_constrained(const Vec&, F) const {}
   // max over the 4*W lanes that serve a chain (NaN-free inputs; max is exact, so every replica agrees): the flow errors of
   // adaptLeapFrogFlowD (adaptiveIntegrators.py:276-287)
   __device__ __forceinline__ static double rowmax4(double x) {

@@ -78,6 +78,9 @@ struct LanePolicy {
   WN_HD void reduce(double*) const {}
   template <int N>
   WN_HD void reduce_max(double*) const {}
+  // (StockWatson's param_constrain for the orbit statistics: the one-chain-per-wavefront layout only)
+  template <class F> WN_HD void sw_constrained(const Vec&, F) const {}
+
   WN_HD void grad(const Vec& q, Vec& g, double& lp) const { lp = Tgt::eval(q.x, g.x, D, tpar); }
   WN_HD double lp_finish(double lp) const { return lp; }
 

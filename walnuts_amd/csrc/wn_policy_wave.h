@@ -257,6 +257,59 @@ struct WTgtStockWatson {
   }
   __device__ __forceinline__ static double lp_finish(double r) { return r; }
   __device__ __forceinline__ static double sel4(const double* a, int k) { return k == 0 ? a[0] : k == 1 ? a[1] : k == 2 ? a[2] : a[3]; }
+  // The transformed parameters of sw_innov.stan:17-35 for the orbit statistics (generated = param_constrain, mainSW.py:28-29): the three
+  // series at this lane's four time points -- the forward sums of grad() below, same code -- and sigma, gpri.  `put(index in the
+  // (6T+1)-wide row of generated(), value)`: sigma, gpri at 3T, 3T+1; z[t], t = 1..T-1, at 3T+1+t; x[t] at 4T+t; tau[t] at 5T+t.
+  static constexpr bool HAS_CONSTRAIN = true;
+  template <class F>
+  __device__ __forceinline__ void constrain(const double* q, int lane, F put) const {
+    const double tS = wn_readlane(sel4(q, kT), laneT);
+    const double sigma = wn_exp(-0.5 * tS), gpri = wn_exp(tS);
+    const int t0 = TPL * lane + 1;
+    double uz[TPL], ux[TPL], tin[TPL], z[TPL], x[TPL], tau[TPL];
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) {
+      const int t = t0 + k;
+      const double rz = t <= T - 1 ? q[k] : 0.0, rx = q[4 + k];
+      tin[k] = q[8 + k];
+      uz[k] = t == 1 ? rz : sigma * rz;
+      ux[k] = t == 1 ? rx : sigma * rx;
+    }
+    double run = 0.0;
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) { run += uz[k]; z[k] = run; }
+    double base = wn_scan_up_b(wn_wave_shr1(run));
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) z[k] += base;
+    run = 0.0;
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) { run += ux[k]; x[k] = run; }
+    base = wn_scan_up_b(wn_wave_shr1(run));
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) x[k] += base;
+    double zprev[TPL];
+    zprev[0] = wn_wave_shr1(z[TPL - 1]);
+#pragma unroll
+    for (int k = 1; k < TPL; ++k) zprev[k] = z[k - 1];
+    run = 0.0;
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) {
+      const int t = t0 + k;
+      const double e_ = wn_exp(0.5 * zprev[k]);
+      run += t == 1 ? tin[k] : ((t >= 2 && t <= T) ? e_ : 0.0) * tin[k];
+      tau[k] = run;
+    }
+    base = wn_scan_up_b(wn_wave_shr1(run));
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) tau[k] += base;
+    if (lane == 0) { put(3 * T, sigma); put(3 * T + 1, gpri); }
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) {
+      const int t = t0 + k;
+      if (t <= T - 1) put(3 * T + 1 + t, z[k]);
+      if (t <= T) { put(4 * T + t, x[k]); put(5 * T + t, tau[k]); }
+    }
+  }
   __device__ __forceinline__ double grad(const double* q, double* g, int lane) const {
     const double tS = wn_readlane(sel4(q, kT), laneT);
     const double sigma = wn_exp(-0.5 * tS), gpri = wn_exp(tS);
@@ -773,6 +826,13 @@ struct WavePolicy {
   }
 
   // ---- split mode ---------------------------------------------------------------------------------
+  // StockWatson's param_constrain of an orbit state for the orbit statistics (Engine::orbit_stats): the target's own forward sums
+  template <class T_, class = void> struct has_constrain { static constexpr bool value = false; };
+  template <class T_> struct has_constrain<T_, typename std::enable_if<T_::HAS_CONSTRAIN>::type> { static constexpr bool value = true; };
+  template <class F>
+  __device__ __forceinline__ void sw_constrained(const Vec& q, F put) const {
+    if constexpr (has_constrain<Tgt>::value && W_ == 1) tgt.constrain(q.x, lane, put);
+  }
   template <int K> __device__ __forceinline__ void park_vec(const Vec& x) const { vput(2 * nslot + COLD_N + 4 + WARM_N + K, x); }
   template <int K> __device__ __forceinline__ void unpark_vec(Vec& x) const { vget(2 * nslot + COLD_N + 4 + WARM_N + K, x); }
   __device__ __forceinline__ double park_partial(double x) { double v[1] = {x}; reduce<1>(v); return v[0]; }
