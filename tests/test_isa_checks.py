@@ -14,14 +14,14 @@ FLAGS = ["-O3", "-std=c++17", "-fno-strict-aliasing", "--offload-arch=gfx950", "
          "--cuda-device-only", "-S"]
 
 
-def kernels_of(unit, tmp_path):
+def kernels_of(unit, tmp_path, extra=()):
     out = tmp_path / (unit + ".s")
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["-o", str(out), os.path.join(CSRC, unit + ".hip")],
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + list(extra) + ["-o", str(out), os.path.join(CSRC, unit + ".hip")],
                           stderr=subprocess.DEVNULL)
     txt = out.read_text()
     ks = {}
-    for m in re.finditer(r"^(_ZN2wn\w+_kernel\w*):", txt, re.M):  # each kernel: from its label to its s_endpgm
-        ks[m.group(1)] = txt[m.start():txt.index("s_endpgm", m.start())]
+    for m in re.finditer(r"^(_ZN2wn\w+_kernel\w*):", txt, re.M):  # each kernel: from its label to the end of the function
+        ks[m.group(1)] = txt[m.start():txt.index(".Lfunc_end", m.start())]  # (a kernel may hold more than one s_endpgm)
     meta = {}
     for m in re.finditer(r"- \.agpr_count:.*?\.wavefront_size: *\d+", txt, re.S):
         blk = m.group(0)
@@ -47,12 +47,27 @@ def test_headline_kernel_has_no_flat_or_scratch_instructions(tmp_path):
 
     # halves mode (a group on two T waves, each alone on its SIMD): the fragments live in registers -- the tick bodies hold no 16-byte
     # fragment reads (the whole-group form has one per two MFMAs), and the code object still has no spills
-    halves = "_ZN2wn15wn_fast4_kernelILi7ELb1ELb0ELb1ELb1EEEvNS_6ParamsEPii"
-    whole = "_ZN2wn15wn_fast4_kernelILi7ELb1ELb0ELb1ELb0EEEvNS_6ParamsEPii"
+    halves = "_ZN2wn15wn_fast4_kernelILi7ELb1ELb0ELb1ELb1ELb0EEEvNS_6ParamsEPii"
+    whole = "_ZN2wn15wn_fast4_kernelILi7ELb1ELb0ELb1ELb0ELb0EEEvNS_6ParamsEPii"
     assert halves in ks and whole in ks
     n128 = lambda k: len(re.findall(r"\bds_read_b128", ks[k]))
     assert n128(whole) >= 150 and n128(halves) <= 4, (n128(whole), n128(halves))
     assert min(len(re.findall(r"v_mfma_f64_4x4x4", ks[k])) for k in (halves, whole)) >= 314  # 157 per tick body, two bodies
+
+
+@pytest.mark.timeout(900)
+def test_headline_kernel_warmup_instantiations_have_no_scratch(tmp_path):
+    """Round 5: the instantiations that also run warm-up adaptation (wn_k_fast4w.o: -DWN4_WARM_TU; RetireBookT<true> with the P2 markers
+    in registers) -- no FLAT instruction in the hand-off, no scratch, no vector-register spills (the first form of wn_p2_push stored
+    through a run-time choice of two elements' addresses and kept the markers in scratch: select form now)."""
+    ks, meta = kernels_of("wn_k_fast4", tmp_path, extra=["-DWN4_WARM_TU=1"])
+    hot = [k for k in ks if "wn_fast4_kernel" in k]
+    assert hot and all(k.endswith("ELb1EEEvNS_6ParamsEPii") for k in hot), hot[:3]  # WARM = true, every one of them
+    for k in hot:
+        assert not re.search(r"\bflat_(load|store|atomic)", ks[k]), k
+    for name, m in meta.items():
+        if "wn_fast4_kernel" in name:
+            assert m["scratch"] == 0 and m["vgpr_spill"] == 0, (name, m)
 
 
 @pytest.mark.timeout(900)

@@ -734,7 +734,7 @@ struct IssueBookT : BookUniforms {
   // the leaves in flight are certain), an odd tick issues the second leaf and it is not the doubling's last.  tick_fast(): what tick()
   // does in that case, bit for bit, in select form and without the uniform cache's branches (fast_kh() says which uniforms an even
   // tick reads: the caller checks that its window holds them).  The kernel takes it when EVERY chain of the wave qualifies; the CPU
-  // harness takes it whenever the chain does (tests/hostsim/fastsim.cpp), so both paths run against the oracle.
+  // harness takes it whenever the chain does (the scalar T-wave stand-in under tests/), so both paths run against the oracle.
   WN_HD bool fast_ok(uint32_t tn, const RMsg& m) const {
     const int nrt = (int)(m.w & RM_NRT_MASK);
     const bool ev = (n_is & 1) == 0 && (n_is <= nrt || (m.w & RM_CERTAIN) != 0);

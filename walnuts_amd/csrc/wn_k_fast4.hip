@@ -128,7 +128,9 @@ constexpr bool OPT_EP = (WN4_OPT & 8) != 0;      // endpoint pushes as predicate
 // (measured and dropped, round 5, gpurun_out/r05/ab13.txt: an even tick's endpoint pushes issued in the shadow of the NEXT tick's MFMAs -- the
 //  state pushed is that tick's (qc, vi), which it only reads -- : -0.7 %; the level-2 endpoint read from LDS in the shadow of the tick's last MFMAs:
 //  -19 %, its fourteen registers spill.  The MFMA shadow is not free: with the bookkeepers above the T waves it is where THEY run.)
-constexpr bool OPT_PAIRED = (WN4_OPT & 512) != 0;  // T wave: workspace vectors with two registers of a lane side by side -- 16-byte memory accesses
+// (measured and dropped, gpurun_out/r05/ab14.txt: workspace vectors with two registers of a lane side by side in memory -- 16-byte accesses, 54 + 85
+//  dwordx4 in the code object, half the vector-memory instructions: +0.4 % (1.400e9 -> 1.406e9) for 4 VGPR spills and 20 B of scratch in the headline
+//  instantiation; even switched off its address helper cost the default build 2 spills.  Removed.)
 constexpr bool OPT_PRE = (WN4_OPT & 64) != 0;    // T wave (whole-group form too): the next tick's command record requested behind the MFMA phase
 constexpr bool OPT_IFAST = (WN4_OPT & 32) != 0;  // I wave: the ordinary tick as straight-line code when every chain of the wave qualifies
 constexpr bool OPT_SLIDE = (WN4_OPT & 16) != 0;  // I wave: a window refill slides the windows of ALL its chains (the Philox passes are paid per wave, not per chain)
@@ -309,14 +311,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
   // vectors in memory are chain-major: [chain x][register s][16 r-b lanes] -- a store by ONE chain of the group (an endpoint push, a pick)
   // then writes whole 128-byte lines (in [s][lane] order it scattered 8-byte pieces at a 32-byte stride over four times as many lines:
   // 178 GB of L2 write-backs per launch measured, profiles/r03_traffic_first.json)
-  // (OPT_PAIRED, whole-group form: registers 2p, 2p+1 of a lane are neighbours in memory -- [chain x][pair p][16 lanes][2], an odd last
-  //  register behind them as before -- so that a vector moves in 16-byte accesses: half the vector-memory instructions, and those are
-  //  what the T wave's tick pays for)
-  constexpr bool PAIRED = OPT_PAIRED && HALF == 0;
-  constexpr int NPR2 = PAIRED ? 2 * (NS / 2) : 0;
-  const int rb = 4 * r + b;
-  auto gvec = [&](int vec) { return wbase + (size_t)vec * G::VEC + x * (NS * 16); };  // the chain's vector; element of register s: + eo(s)
-  auto eo = [&](int s) { return (PAIRED && s < NPR2) ? (s >> 1) * 32 + 2 * rb + (s & 1) : s * 16 + rb; };
+  auto gvec = [&](int vec) { return wbase + (size_t)vec * G::VEC + x * (NS * 16) + 4 * r + b; };  // + s * 16
   const int vprop = (prm.M + 1) * 2, vcold = vprop + 2;
   const double* const znext = wbase + (size_t)((prm.M + 1) * 2 + 4) * G::VEC + (size_t)x * G::DPAD;
   double* const lc = pr + G::P_LC + lane;
@@ -468,13 +463,13 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
         const int sl = slot_of_leaf(n + 1 - (1 << NFAST));
         const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
 #pragma unroll
-        for (int s = S0; s < S1; ++s) { pq0[s] = sq[eo(s)]; pv0[s] = sv[eo(s)]; }
+        for (int s = S0; s < S1; ++s) { pq0[s] = sq[s * 16]; pv0[s] = sv[s * 16]; }
       }
       if (deep1) {
         const int sl = slot_of_leaf(n + 1 - (2 << NFAST));
         const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
 #pragma unroll
-        for (int s = S0; s < S1; ++s) { pq1[s] = sq[eo(s)]; pv1[s] = sv[eo(s)]; }
+        for (int s = S0; s < S1; ++s) { pq1[s] = sq[s * 16]; pv1[s] = sv[s * 16]; }
       }
     }
     if (anyrare) {
@@ -482,7 +477,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
         if (op & OP_PICK) {
           double* dst = gvec(vprop + ((op & OP_IPPICK) ? 1 : 0));
 #pragma unroll
-          for (int s = S0; s < S1; ++s) dst[eo(s)] = pk[s * 64];
+          for (int s = S0; s < S1; ++s) dst[s * 16] = pk[s * 64];
         }
       }
       if (TRACE) { ntr -= ((op & OP_UNDO) ? 1 : 0) + ((op & OP_UNDO2) ? 1 : 0); }  // the leaves in flight when the iteration ended
@@ -504,12 +499,12 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
 #pragma unroll
             for (int s = S0; s < S1; ++s) {
               qn[s] = coord(s) < D ? prm.q0[(size_t)cl * D + coord(s)] : 0.0;
-              dst[eo(s)] = qn[s];
+              dst[s * 16] = qn[s];
             }
           } else {
             const double* src = gvec(vprop + ((op & OP_IPNEW) ? 1 : 0));
 #pragma unroll
-            for (int s = S0; s < S1; ++s) qn[s] = src[eo(s)];
+            for (int s = S0; s < S1; ++s) qn[s] = src[s * 16];
           }
           // samples[:, row] = generated(q)  (WALNUTS.py:164,695)
           double* row = prm.samples + ((size_t)cl * (prm.numIter + 1) + c.n) * prm.dg;
@@ -535,7 +530,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
             keinit_part = kp;
             double *dq_ = gvec(vcold), *dv_ = gvec(vcold + 1);
 #pragma unroll
-            for (int s = S0; s < S1; ++s) { dq_[eo(s)] = qn[s]; dv_[eo(s)] = v[s]; }
+            for (int s = S0; s < S1; ++s) { dq_[s * 16] = qn[s]; dv_[s * 16] = v[s]; }
           }
           __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): waited for HERE, not on the common path (wn_k_fast.hip)
         }
@@ -545,9 +540,9 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
           double *dq_ = gvec(vcold), *dv_ = gvec(vcold + 1);
           double tq[NS], tv[NS];
 #pragma unroll
-          for (int s = S0; s < S1; ++s) { tq[s] = dq_[eo(s)]; tv[s] = dv_[eo(s)]; }
+          for (int s = S0; s < S1; ++s) { tq[s] = dq_[s * 16]; tv[s] = dv_[s * 16]; }
 #pragma unroll
-          for (int s = S0; s < S1; ++s) { dq_[eo(s)] = qc[s]; dv_[eo(s)] = v[s]; qn[s] = tq[s]; v[s] = tv[s]; }  // (no step on this tick)
+          for (int s = S0; s < S1; ++s) { dq_[s * 16] = qc[s]; dv_[s * 16] = v[s]; qn[s] = tq[s]; v[s] = tv[s]; }  // (no step on this tick)
           __builtin_amdgcn_s_waitcnt(0x0F70);
         }
       }
@@ -630,7 +625,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
       if (l0due) {
         const double *sq = gvec(vcold), *sv = gvec(vcold + 1);
 #pragma unroll
-        for (int s = S0; s < S1; ++s) { cq[s] = sq[eo(s)]; cv[s] = sv[eo(s)]; }
+        for (int s = S0; s < S1; ++s) { cq[s] = sq[s * 16]; cv[s] = sv[s * 16]; }
       }
     }
     // ---- second half step; lp = 1/2 q.g, KE = 1/2 v.v ----
@@ -700,7 +695,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
               const double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
               double qo[NS], vo[NS];
 #pragma unroll
-              for (int s = S0; s < S1; ++s) { qo[s] = sq[eo(s)]; vo[s] = sv[eo(s)]; }
+              for (int s = S0; s < S1; ++s) { qo[s] = sq[s * 16]; vo[s] = sv[s * 16]; }
               dots(qo, vo, e[2 * h], e[2 * h + 1]);
             }
           }
@@ -721,15 +716,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
         lds_store_qv_masked_all<NS, S0, S1>(__ballot(ep), lc, qn, v);
         if (__any(epg)) {
           const int sl = epg ? slot_of_leaf(n) : 0;
-          if constexpr (PAIRED) {
-            if (epg) {
-              double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
-#pragma unroll
-              for (int s = S0; s < S1; ++s) { sq[eo(s)] = qn[s]; sv[eo(s)] = v[s]; }
-            }
-          } else {
-            glb_store_qv_masked_all<NS, S0, S1>(__ballot(epg), gvec(sl * 2) + rb, gvec(sl * 2 + 1) + rb, qn, v);
-          }
+          glb_store_qv_masked_all<NS, S0, S1>(__ballot(epg), gvec(sl * 2), gvec(sl * 2 + 1), qn, v);
         }
       } else if (__any(ep)) {
         if (ep) {
@@ -739,7 +726,7 @@ __device__ __forceinline__ void fast4_t_wave(const Params& prm, const double* ld
             const int sl = slot_of_leaf(n);
             double *sq = gvec(sl * 2), *sv = gvec(sl * 2 + 1);
 #pragma unroll
-            for (int s = S0; s < S1; ++s) { sq[eo(s)] = qn[s]; sv[eo(s)] = v[s]; }
+            for (int s = S0; s < S1; ++s) { sq[s * 16] = qn[s]; sv[s * 16] = v[s]; }
           }
         }
       }
