@@ -82,6 +82,9 @@ __global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __rest
     }
   }
   __syncthreads();
+  // (round 5, tools/gemm_epi.hip: of the GEMM's 42.3 us alone, back to back, the k loop is 36.6 and this epilogue 5.7; storing whole 128-byte
+  //  lines after a transposition through LDS makes it 40.0 alone -- and the RUN 2.2 % slower (1.916e7 -> 1.874e7 steps/s, one more barrier per
+  //  tile): not taken.  The k loop's 36.6 us against 27.8 us of MFMA time is L2 bandwidth: a 64 x 64 tile loads 1 MB for 8.3 MFLOP, 7 TB/s chip-wide.)
   // C/D layout of v_mfma_f64_16x16x4_f64: register q of lane l holds row 4*q + l/16 (output index),
   // column l%16 (chain)
 #pragma unroll
