@@ -33,18 +33,19 @@ def funnel_q0(C, seed=3):
     return q0
 
 
-def run_engine(wa, target, q0, iters, legacy=False, exact=True, seed=SEED, **kw):
+def run_engine(wa, target, q0, iters, legacy=False, exact=True, seed=SEED, tpar=None, **kw):
     """exact: the orbit kernel with the micro-step arithmetic of the one-stream engine (WN_ORBIT_EXACT=1; funnel10's default is a
     micro step of its own with one row reduction instead of two -- the same values, not the same bits)"""
     from walnuts_amd import _lib as L
     old = os.environ.pop("WN_ORBIT_LEGACY", None)
+    os.environ["WN_ORBIT_WIDE_ADAPT"] = "1"  # (StockWatson: the adaptive integrators' plain runs stay on the one-stream engine by default)
     if legacy:
         os.environ["WN_ORBIT_LEGACY"] = "1"
     if exact:
         os.environ["WN_ORBIT_EXACT"] = "1"
     try:
         e = wa.Engine(q0.shape[1], q0.shape[0], **kw)
-        e.set_target(target, None)
+        e.set_target(target, tpar)
         name = e.kernel_name
         s, d = e.run(q0, seed, iters)
         s = s.cpu().numpy(); d = d.cpu().numpy()
@@ -52,6 +53,7 @@ def run_engine(wa, target, q0, iters, legacy=False, exact=True, seed=SEED, **kw)
     finally:
         os.environ.pop("WN_ORBIT_LEGACY", None)
         os.environ.pop("WN_ORBIT_EXACT", None)
+        os.environ.pop("WN_ORBIT_WIDE_ADAPT", None)
         if old is not None:
             os.environ["WN_ORBIT_LEGACY"] = old
     return s, d, name
@@ -166,3 +168,65 @@ def test_orbit_kernel_config3_size(wa):
         for dd, ss in ((d, s), (d_f, s_f)):
             np.testing.assert_array_equal(dd[c][:, INT_COLS], o["diagnostics"][:, INT_COLS])
             np.testing.assert_allclose(ss[c].T, o["samples"], rtol=1e-6, atol=1e-9)
+
+
+# ---- wide mode (round 5): StockWatson, vectors of 12 registers per lane, ring / slots / proposals in the chain's workspace ----
+def sw_tpar(T):
+    sw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stockwatson_data.npz"))
+    y = sw["y"][:T]
+    return np.concatenate([[float(T)], y])
+
+
+SW_CASES = [
+    # T, integrator, kwargs, iterations, rtol against the one-stream engine (0 = bit for bit)
+    (252, ol.I_ADAPT_D, dict(H0=0.1, delta0=0.3, M=8, minC=3), 4, 0.0),        # mainSW.py:41-47
+    (252, ol.I_ADAPT_R2P, dict(H0=0.1, delta0=0.3, M=8, minC=3), 4, 0.0),      # :64-71
+    (252, ol.I_FIXED, dict(H0=0.1 / 8, M=7), 4, 1e-7),                         # :56-62 (the one-stream fixedLeapFrog engine works in place: another instantiation)
+    (30, ol.I_ADAPT_R2P, dict(H0=0.25, delta0=0.2, M=9, minC=0), 12, 0.0),     # short series: long orbits, deep sub-tree levels, refinements
+    (30, ol.I_ADAPT_D, dict(H0=0.6, delta0=0.05, M=6, minC=0), 12, 0.0),       # large steps: refinement, backward searches, passive ends
+    (101, ol.I_FIXED, dict(H0=0.02, M=10), 5, 1e-7),                           # T - 1 a multiple of 4: tSigma alone in its lane
+]
+
+
+@pytest.mark.parametrize("case", SW_CASES, ids=[f"T{c[0]}_integ{c[1]}_M{c[2]['M']}" for c in SW_CASES])
+def test_wide_orbit_kernel_equals_the_one_stream_engine_and_the_oracle(wa, case):
+    """wn_orbit_kernel<stockwatson,NE=12,...> (BASELINE config 5's plain sampling runs) against the one-stream engine of the same layout
+    (WN_ORBIT_LEGACY=1: same micro-step arithmetic, same wave sums -- draws and diagnostics bit for bit for the adaptive integrators)
+    and against the CPU oracle (integers exactly, reals to 1e-6)."""
+    T, integ, kw, iters, rtol = case
+    C = 24
+    tpar = sw_tpar(T)
+    rng = np.random.default_rng(100 + T)
+    q0 = 0.1 * rng.normal(size=(C, 3 * T)); q0[0] = 0.0
+    s_new, d_new, name = run_engine(wa, ol.T_STOCKWATSON, q0, iters, tpar=tpar, integrator=integ, **kw)
+    assert "wn_orbit_kernel<stockwatson" in name, name
+    s_old, d_old, name_old = run_engine(wa, ol.T_STOCKWATSON, q0, iters, legacy=True, tpar=tpar, integrator=integ, **kw)
+    assert "wn_wave_kernel" in name_old, name_old
+    bad = [c for c in range(C) if not same_run(s_new[c], d_new[c], s_old[c], d_old[c], rtol)]
+    if bad:
+        c = bad[0]
+        it = next(t for t in range(iters) if not same_run(s_new[c, t + 1], d_new[c, t], s_old[c, t + 1], d_old[c, t], rtol))
+        cols = [k for k in range(24) if not same(d_new[c, it, k], d_old[c, it, k])]
+        raise AssertionError(f"{len(bad)} of {C} chains differ; first: chain {c} iteration {it} diag columns {cols}\n new {d_new[c, it]}\n old {d_old[c, it]}")
+    for c in (0, C - 1):
+        o = ol.walnuts(ol.T_STOCKWATSON, q0[c], integrator=integ, tpar=tpar, H0=kw["H0"], delta0=kw.get("delta0", 0.05), numIter=iters,
+                       M=kw["M"], minC=kw.get("minC", 0), seed=SEED, chain=c)
+        np.testing.assert_array_equal(d_new[c][:, INT_COLS], o["diagnostics"][:, INT_COLS], err_msg=f"chain {c}")
+        np.testing.assert_allclose(s_new[c].T, o["samples"], rtol=1e-6, atol=1e-9, err_msg=f"chain {c}")
+        np.testing.assert_allclose(d_new[c], o["diagnostics"], rtol=1e-6, atol=1e-9, err_msg=f"chain {c}")
+    assert (d_new[:, :, 6] + d_new[:, :, 7]).sum() > 0
+
+
+@pytest.mark.parametrize("gen,gk", [(ol.G_FIRSTK, 5), (ol.G_Q0_SUMSQ, 0)])
+def test_wide_orbit_kernel_generated_forms(wa, gen, gk):
+    """generated = first k / [q0, sum q^2] in the time-major register layout (Tgt::map_gidx says which register holds which parameter)."""
+    T, C, iters = 60, 8, 6
+    tpar = sw_tpar(T)
+    q0 = 0.1 * np.random.default_rng(4).normal(size=(C, 3 * T))
+    kw = dict(integrator=ol.I_ADAPT_D, H0=0.2, delta0=0.3, M=6, minC=1, generated=gen, gen_k=gk)
+    s_new, d_new, name = run_engine(wa, ol.T_STOCKWATSON, q0, iters, tpar=tpar, **kw)
+    assert "wn_orbit_kernel<stockwatson" in name, name
+    s_old, d_old, _ = run_engine(wa, ol.T_STOCKWATSON, q0, iters, legacy=True, tpar=tpar, **kw)
+    assert same(d_new[..., INT_COLS], d_old[..., INT_COLS])
+    assert near(s_new, s_old, 1e-12), np.abs(s_new - s_old).max()
+    assert s_new.shape[-1] == (gk if gen == ol.G_FIRSTK else 2)

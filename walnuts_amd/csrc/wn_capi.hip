@@ -147,7 +147,7 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_
 
 size_t kernel_work_doubles(const KernelChoice& kc, int C, int M) {
   if (kc.layout == 0) return lane_work_doubles(kc.p0, C, M);
-  if (kc.layout == 2) return wave_work_doubles(kc.p0, C, M, kc.G);
+  if (kc.layout == 2) return std::max(wave_work_doubles(kc.p0, C, M, kc.G), orbit_wide_geom(kc) ? orbit_wide_work_doubles(kc.p0, C, M) : (size_t)0);
   if (kc.layout == 3) return split_work_doubles(kc.p0, C, M);
   const int NT = kc.p0 <= 16 ? 1 : kc.p0 <= 32 ? 2 : 4;
   // the role-split kernel of the same layout (wn_k_fast.hip) pads every vector to 8 tiles x 4 registers x 64 lanes
@@ -519,6 +519,10 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
     // wn_integrator_step use the one-stream engine of the same layout
     const char* tn = kc.p1 == T_FUNNEL10 ? "funnel10" : kc.p1 == T_CORRGAUSS ? "corrGauss" : kc.p1 == T_SMILE ? "smile" : kc.p1 == T_FUNNEL1 ? "funnel1" : "modFunnel";
     snprintf(kc.name, sizeof(kc.name), "wn_orbit_kernel<%s,%s>", tn, e->cfg.integrator == WN_I_FIXED ? "fixedLeapFrog" : e->cfg.integrator == WN_I_ADAPT_D ? "adaptLeapFrogD" : "adaptLeapFrogR2P");
+  }
+  if (e->cfg.warmup_iter == 0 && e->cfg.M >= 1 && orbit_wide_run(kc, e->cfg.integrator)) {
+    // (round 5) StockWatson's plain sampling runs: the same kernel with vectors of 12 registers per lane
+    snprintf(kc.name, sizeof(kc.name), "wn_orbit_kernel<stockwatson,NE=12,%s>", e->cfg.integrator == WN_I_FIXED ? "fixedLeapFrog" : e->cfg.integrator == WN_I_ADAPT_D ? "adaptLeapFrogD" : "adaptLeapFrogR2P");
   }
   e->kc = kc;
   e->have_kc = true;

@@ -39,6 +39,16 @@
 // LDS per chain (doubles): ring q / v 2 x 16 x 17, dump 64, passive orbit end (q, v, g) 48, two proposals (q) 32, sub-tree slots
 // (levels >= 5 and leaf 0) 32 (M + 1): 8.4 KB at M = 12 -- 16 chains per CU, all 4096 resident.
 // The proposal keeps q only: the gradient at the start of an iteration is re-evaluated, as the reference does (WALNUTS.py:249).
+//
+// WIDE MODE (NE > 1; round 5, BASELINE config 5: StockWatson, D = 756 in NE = 12 registers per lane): the same kernel for a chain whose
+// vectors fill the wave.  What changes is where vectors live and how a U-turn check is formed, nothing in the bookkeeping:
+//   * q, v, g are NE registers per lane (element e of a lane: Tgt::map_gidx, or e * 64 + lane); sums are wave sums in the one-stream
+//     engine's order (WavePolicy::reduce), so energies have that engine's bits;
+//   * the ring, the passive orbit end, the proposals and the slots are in the chain's workspace ([vector][NE][64]: a register of the wave
+//     is 512 contiguous bytes), L2-resident: 16 x 2 ring entries + 3 + 2 + 2 (M + 1) vectors = 67 x 6 KB at M = 14;
+//   * a U-turn check is a wave-wide dot: the R phase walks the odd leaves of the batch (right state loaded once), the levels due at each
+//     (left state from the ring, levels >= 5 from the slots) and the full-orbit check -- scalar loop, uniform branches.
+// The one-stream engine spent 3.1 k of a fixedLeapFrog leaf's 7.3 k cycles on its replicated scalar bookkeeping (mainSW.py:56-62).
 #include "wn_launch.h"
 #include "wn_policy_wave.h"
 
@@ -51,6 +61,11 @@ typedef __attribute__((address_space(3))) int lds_i;
 // entry r(c)), and at a stride of 16 doubles = 128 bytes all of them hit the same LDS banks (a 16-way conflict on every read)
 enum { RS = 17, RQ = 0, RV = 16 * RS, DUMP = 32 * RS, COLDQ = DUMP + 64, COLDV = COLDQ + 16, COLDG = COLDV + 16, PROP = COLDG + 16, SLOT = PROP + 32 };
 __host__ __device__ constexpr int lds_doubles(int M) { return SLOT + 32 * (M + 1); }
+// wide mode: the chain's workspace, in vectors of NE * 64 doubles
+enum { W_RQ = 0, W_RV = 16, W_COLDQ = 32, W_COLDV = 33, W_COLDG = 34, W_PROP = 35, W_SLOT = 37 };
+__host__ __device__ constexpr size_t wide_doubles(int NE, int M) { return (size_t)(W_SLOT + 2 * (M + 1)) * NE * 64; }
+template <class T_, class = void> struct tgt_mapped { static constexpr bool value = false; };
+template <class T_> struct tgt_mapped<T_, typename std::enable_if<T_::MAPPED>::type> { static constexpr bool value = true; };
 
 // row_shr:1 with zero fill at the first lane of each row of 16
 __device__ __forceinline__ double shr1(double x) { return wn_dpp0<0x111>(x); }
@@ -88,9 +103,12 @@ __device__ __forceinline__ int uni_i(int x) { return __builtin_amdgcn_readfirstl
 __device__ __forceinline__ bool uni_b(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 }  // namespace orbit
 
-template <class Tgt, int INTEG, bool FUSED = false>
+template <class Tgt, int INTEG, bool FUSED = false, int NE = 1>
 __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
   using namespace orbit;
+  constexpr bool WIDE = NE > 1;
+  static_assert(!(WIDE && FUSED), "a target's own micro step is a one-register form");
+  constexpr int DP = NE * 64;
   extern __shared__ double wn_orbit_lds[];
   lds_d* const L = (lds_d*)wn_orbit_lds;
   const int lane = threadIdx.x;
@@ -102,9 +120,11 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
   const int D = prm.D, M = prm.M, minC = prm.minC, maxC = prm.maxC;
   Tgt tgt;
   tgt.init(prm, lane, nullptr);
-  for (int k = lane; k < lds_doubles(M); k += 64) L[k] = 0.0;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
+  if constexpr (!WIDE) {
+    for (int k = lane; k < lds_doubles(M); k += 64) L[k] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
 
   // ---- the wave's window of uniforms: lane l holds uniform 2 * rb_base + l of iteration rb_iter (wn_rng.h stream 0) ----
   uint32_t rb_iter = 0xFFFFFFFFu, rb_base = 0u;
@@ -121,16 +141,23 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
   // the sums of a micro step, exactly as the one-stream engine forms them (WavePolicy::reduce<2>, VLDS): two quantities in the
   // rows of one register, one row reduction
   auto reduce2 = [&](double& a, double& b) {
+    if constexpr (WIDE) { a = wn_wavesum(a); b = wn_wavesum(b); return; }
     double r = wn_pack32(a, b);
     r = wn_rowsum16(r);
     a = wn_readlane(r, 0) + 0.0;
     b = wn_readlane(r, 32) + 0.0;
   };
-  auto reduce1 = [&](double a) -> double { return wn_readlane(wn_rowsum16(a), 0) + 0.0; };
+  auto reduce1 = [&](double a) -> double {
+    if constexpr (WIDE) return wn_wavesum(a);
+    else return wn_readlane(wn_rowsum16(a), 0) + 0.0;
+  };
+#define WN_OV(e) _Pragma("unroll") for (int e = 0; e < NE; ++e)
 
   // ---- chain state ----
-  // vectors: one element per lane (rows 1..3 hold copies of row 0); active end of the orbit, v in forward-time orientation
-  double qa, va = 0.0, ga;
+  // vectors: one element per lane (rows 1..3 hold copies of row 0) -- wide mode: NE elements per lane; active end of the orbit, v in
+  // forward-time orientation
+  double qa[NE], va[NE], ga[NE];
+  WN_OV(e) va[e] = 0.0;
   // scalars of WALNUTS.py:189-695 (uniform over the wave)
   double H0 = 0.0, Ha = 0.0, Hb = 0.0, lp0, WoldSum = 1.0, WnewSum = 0.0, lwtSumf = 0.0, lwtSumb = 0.0;
   double orbitLen_ = 0.0, orbitLenSam_ = 0.0, indexStat_ = 0.0, indexStatOld_ = 0.0, timeLenF_ = 0.0, timeLenB_ = 0.0;
@@ -147,29 +174,65 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
   const int clc = inrange ? cl : 0;
   const double dlt = prm.delta, Hc = prm.H;
 
-  auto row0_store = [&](int off, double x) { if (lane < 16) L[off + lane] = x; };
-  auto row_load = [&](int off) -> double { return L[off + k16]; };
+  // element held by register e of this lane (parameter index), or -1
+  auto gidx = [&](int e) -> int {
+    if constexpr (!WIDE) return k16 < D ? k16 : -1;
+    else if constexpr (tgt_mapped<Tgt>::value) return tgt.map_gidx(e, lane);
+    else return e * 64 + lane < D ? e * 64 + lane : -1;
+  };
+  // the chain's stored vectors: LDS offsets (doubles) in the one-register form, vector numbers of the workspace in wide mode
+  // (a stored vector is [register pair][lane][2]: one 16-byte access per lane and pair of registers, 1 KB per wave instruction)
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  static_assert(!WIDE || NE % 2 == 0, "wide mode stores register pairs");
+  d2_t* const Wk = WIDE ? reinterpret_cast<d2_t*>(prm.work + (size_t)clc * wide_doubles(NE, M)) + lane : nullptr;
+  constexpr int O_COLDQ = WIDE ? W_COLDQ : COLDQ, O_COLDV = WIDE ? W_COLDV : COLDV, O_COLDG = WIDE ? W_COLDG : COLDG;
+  auto o_prop = [&](int w) -> int { return WIDE ? W_PROP + w : PROP + 16 * w; };
+  auto o_ringq = [&](int k) -> int { return WIDE ? W_RQ + k : RQ + RS * k; };
+  auto o_ringv = [&](int k) -> int { return WIDE ? W_RV + k : RV + RS * k; };
+  auto vst = [&](int off, const double* x) {
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int j = 0; j < NE / 2; ++j) { d2_t t; t[0] = x[2 * j]; t[1] = x[2 * j + 1]; Wk[(size_t)off * (DP / 2) + j * 64] = t; }
+    } else { if (lane < 16) L[off + lane] = x[0]; }
+  };
+  auto vld = [&](int off, double* x) {
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int j = 0; j < NE / 2; ++j) { const d2_t t = Wk[(size_t)off * (DP / 2) + j * 64]; x[2 * j] = t[0]; x[2 * j + 1] = t[1]; }
+    } else x[0] = L[off + k16];
+  };
 
   // samples[:, it] = generated(q)
-  auto emit_generated = [&](int it, double qP) {
+  auto emit_generated = [&](int it, const double* qP) {
     double* rowp = prm.samples + ((size_t)clc * (prm.numIter + 1) + it) * prm.dg;
-    if (prm.generated == G_Q0_SUMSQ) {
-      const double s = reduce1(qP * qP);
-      if (lane == 0) { rowp[0] = qP; rowp[1] = s; }
+    if constexpr (WIDE) {
+      // (arithmetic, not a select of the two kernel arguments: see below)
+      const int fk = (int)(prm.generated == G_FIRSTK), sq = (int)(prm.generated == G_Q0_SUMSQ);
+      const int kk = sq ? 1 : fk * prm.gen_k + (1 - fk) * D;
+      WN_OV(e) { const int gi = gidx(e); if (gi >= 0 && gi < kk) rowp[gi] = qP[e]; }
+      if (sq) {
+        double s = 0.0;
+        WN_OV(e) s += qP[e] * qP[e];
+        s = reduce1(s);
+        if (lane == 0) rowp[1] = s;
+      }
+    } else if (prm.generated == G_Q0_SUMSQ) {
+      const double s = reduce1(qP[0] * qP[0]);
+      if (lane == 0) { rowp[0] = qP[0]; rowp[1] = s; }
     } else {
       // (arithmetic, not a select of the two kernel arguments: hipcc turned the select into a two-entry array in scratch)
       const int fk = (int)(prm.generated == G_FIRSTK);
       const int kk = fk * prm.gen_k + (1 - fk) * D;
-      if (lane < 16 && lane < kk && lane < D) rowp[lane] = qP;
+      if (lane < 16 && lane < kk && lane < D) rowp[lane] = qP[0];
     }
   };
 
   // ---- q_c = q0; f0, grad0 = lpFun(q0)  (WALNUTS.py:177,249) ----
-  qa = (k16 < D && inrange) ? prm.q0[(size_t)clc * D + k16] : 0.0;
+  WN_OV(e) { const int gi = gidx(e); qa[e] = (gi >= 0 && inrange) ? prm.q0[(size_t)clc * D + gi] : 0.0; }
   {
-    double lp_part = tgt.grad(&qa, &ga, lane);
-    lpP = reduce1(lp_part);
-    row0_store(PROP + 16 * ip, qa);
+    double lp_part = tgt.grad(qa, ga, lane);
+    lpP = Tgt::lp_finish(reduce1(lp_part));
+    vst(o_prop(ip), qa);
     if (inrange) emit_generated(0, qa);  // samples[:,0] = generated(q0)  (:164)
   }
   bool live = inrange && prm.numIter >= 1;
@@ -183,9 +246,9 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
   // one micro pass of 2**cc leapfrog steps (adaptiveIntegrators.py:72-94) from (qs, vs, gs); returns "the pass is accepted"
   // (the sums are the same in every lane)
   double hcur = 0.0;  // step size h of the running macro step
-  auto run_pass = [&](double qs, double vs, double gs, double HamStart, int cc, double& q, double& v, double& g, double& lpC, double& HC,
-                      int& nev) -> bool {
-    q = qs; v = vs; g = gs;
+  auto run_pass = [&](const double* qs, const double* vs, const double* gs, double HamStart, int cc, double* q, double* v, double* g, double& lpC,
+                      double& HC, int& nev) -> bool {
+    WN_OV(e) { q[e] = qs[e]; v[e] = vs[e]; g[e] = gs[e]; }
     const double hh = ldexp(hcur, -cc);  // h / 2**c (exact scaling either way)
     const int nstep = 1 << cc;
     bool allfin = isfinite(HamStart);
@@ -195,13 +258,14 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
     do {  // one branch per micro step
       double lpp, ke;
       if constexpr (FUSED) {  // the target's own micro step: one row reduction instead of two (WTgtFunnel10::leap)
-        tgt.leap(q, v, g, hh2, hq, lane, lpp, ke);
+        tgt.leap(q[0], v[0], g[0], hh2, hq, lane, lpp, ke);
       } else {
-        v = v + hh2 * g; q = q + hq * v;
-        lpp = tgt.grad(&q, &g, lane);
+        WN_OV(e) { v[e] = v[e] + hh2 * g[e]; q[e] = q[e] + hq * v[e]; }
+        lpp = tgt.grad(q, g, lane);
         ke = 0.0;
-        v = v + hh2 * g; ke += v * v;
+        WN_OV(e) { v[e] = v[e] + hh2 * g[e]; ke += v[e] * v[e]; }
         reduce2(lpp, ke);
+        lpp = Tgt::lp_finish(lpp);
       }
       const double Hi = -lpp + 0.5 * ke;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
       lpC = lpp; HC = Hi;
@@ -231,13 +295,24 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
     ku = (uint32_t)M;
     a = 0; b = 0; maxFint = 0; maxBint = 0;
     {
-      qa = row_load(PROP + 16 * ip);
-      double lpp = tgt.grad(&qa, &ga, lane);  // f0, grad0 = lpFun(qc)  (:249); its value is lpP already
+      vld(o_prop(ip), qa);
+      double lpp = tgt.grad(qa, ga, lane);  // f0, grad0 = lpFun(qc)  (:249); its value is lpP already
       (void)lpp;
-      const double z = (k16 < D) ? rng_normal(prm.seed, cg, (uint32_t)iter, (uint32_t)k16) : 0.0;  // :236  v = normal(size=d)
-      va = z;
-      row0_store(COLDQ, qa); row0_store(COLDV, va); row0_store(COLDG, ga);
-      double kp = 0.0; kp += z * z;
+      // :236  v = normal(size=d)
+      if constexpr (NE > 4) {  // (rolled: one copy of Philox + Box-Muller in the code; the register is picked with selects, not a dynamic index)
+#pragma unroll 1
+        for (int e1 = 0; e1 < NE; ++e1) {
+          int gi = -1;
+          WN_OV(e) gi = e == e1 ? gidx(e) : gi;
+          const double z = gi >= 0 ? rng_normal(prm.seed, cg, (uint32_t)iter, (uint32_t)gi) : 0.0;
+          WN_OV(e) va[e] = e == e1 ? z : va[e];
+        }
+      } else {
+        WN_OV(e) { const int gi = gidx(e); va[e] = gi >= 0 ? rng_normal(prm.seed, cg, (uint32_t)iter, (uint32_t)gi) : 0.0; }
+      }
+      vst(O_COLDQ, qa); vst(O_COLDV, va); vst(O_COLDG, ga);
+      double kp = 0.0;
+      WN_OV(e) kp += va[e] * va[e];
       double gp = 0.0;
       reduce2(kp, gp);
       lp0 = lpP;
@@ -261,9 +336,10 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
       {  // start of doubling i (:283-294)
         const int nxi = ((Bbits >> i) & 1u) ? -1 : 1;
         if (nxi != xi) {  // the other end of the orbit becomes the active one
-          const double tq = row_load(COLDQ), tv = row_load(COLDV), tg = row_load(COLDG);
-          row0_store(COLDQ, qa); row0_store(COLDV, va); row0_store(COLDG, ga);
-          qa = tq; va = tv; ga = tg;
+          double tq[NE], tv[NE], tg[NE];
+          vld(O_COLDQ, tq); vld(O_COLDV, tv); vld(O_COLDG, tg);
+          vst(O_COLDQ, qa); vst(O_COLDV, va); vst(O_COLDG, ga);
+          WN_OV(e) { qa[e] = tq[e]; va[e] = tv[e]; ga[e] = tg[e]; }
           const double th = Ha; Ha = Hb; Hb = th;
           xi = nxi;
         }
@@ -279,6 +355,10 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
         const int nb0 = n & ~15;
         const int k0 = n & 15;
         int k1 = nleaf - nb0 < 16 ? nleaf - nb0 : 16;
+        // wide mode, adaptive integrators: a macro step is tens of evaluations of ~4 k cycles each and the bookkeeping of a leaf a
+        // twentieth of that, so nothing is gained by running ahead -- and a mispredicted draw (StockWatson: a fifth of the blocks: the
+        // first leaves of a doubling often have weight zero, If != Ib) or a sub-tree U-turn would throw whole macro steps away
+        if constexpr (WIDE && INTEG != I_FIXED) k1 = k0 + 1;
         // =========================== the draws of leaves k0 .. k1-1, lane-parallel ===========================
         // In the reference's order an even leaf of a doubling i >= 1 draws the pair's two step sizes (:395), every leaf its
         // R2P uniform (adaptiveIntegrators.py:392) and -- when WnewSum > exp(-699) -- its multinomial uniform (:426); the single leaf
@@ -320,8 +400,9 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
             const double Ham0 = Ha;  // Hs[] of the neighbouring stored index = energy at the active end (:302,400,443,487,530)
             int nEvF = 0, nEvB = 0, If, Ib, cret;
             double lpn, Hn;
-            double qw, vw, gw, lpC, HC;
-            const double vin = (double)xi * va;  // vh = xi*v + ...
+            double qw[NE], vw[NE], gw[NE], lpC, HC;
+            double vin[NE];
+            WN_OV(e) vin[e] = (double)xi * va[e];  // vh = xi*v + ...
             if (INTEG == I_FIXED) {  // adaptiveIntegrators.py:49-59
               run_pass(qa, vin, ga, Ham0, 0, qw, vw, gw, lpC, HC, nEvF);
               If = Ib = cret = 0; lpn = lpC; Hn = HC;
@@ -349,22 +430,25 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
                   lpn = lpC; Hn = HC;
                 }
                 if (maxTry >= minC) {  // backward search from (qOut, -vOut, gOut)  (:107-132 / 440-464)
-                  const double qo = qw, vo = vw, go = gw;
+                  double qo[NE], vo[NE], go[NE], vneg[NE];
+                  WN_OV(e) { qo[e] = qw[e]; vo[e] = vw[e]; go[e] = gw[e]; vneg[e] = -vw[e]; }
                   double lpB, HB;
                   for (cc = minC;; ++cc) {
-                    ok = run_pass(qo, -vo, go, Hn, cc, qw, vw, gw, lpB, HB, nEvB);
+                    ok = run_pass(qo, vneg, go, Hn, cc, qw, vw, gw, lpB, HB, nEvB);
                     if (ok) { Ib = cc; break; }
                     if (cc >= maxTry) break;
                   }
-                  qw = qo; vw = vo; gw = go;
+                  WN_OV(e) { qw[e] = qo[e]; vw[e] = vo[e]; gw[e] = go[e]; }
                 }
               }
               cret = INTEG == I_ADAPT_R2P ? cSim : If;  // :135-137 / 466-475 (lwt follows from If, Ib, c: the R phase forms it)
             }
             WN_STAMP(2);
             // intOut.v is in forward-time orientation (adaptiveIntegrators.py:57,135,473); the new state becomes the active end
-            qa = qw; va = (double)xi * vw; ga = gw; Ha = Hn;
-            L[ring_base + ring_step * k] = qa; L[ring_base + ring_vofs + ring_step * k] = va;
+            WN_OV(e) { qa[e] = qw[e]; va[e] = (double)xi * vw[e]; ga[e] = gw[e]; }
+            Ha = Hn;
+            if constexpr (WIDE) { vst(o_ringq(k), qa); vst(o_ringv(k), va); }
+            else { L[ring_base + ring_step * k] = qa[0]; L[ring_base + ring_vofs + ring_step * k] = va[0]; }
             {
               const bool mk = k16 == k;
               HnV = mk ? Hn : HnV; lpV = mk ? lpn : lpV;
@@ -384,8 +468,14 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
         // left endpoint of the sub-trees of 2**j leaves, j >= 5, that start at this block's first leaf (levels 1..4 stay inside the ring)
         if (k0 == 0 && (nb0 == 0 ? i >= 5 : __builtin_ctz((unsigned)nb0) >= 5)) {
           const int sl = nb0 == 0 ? 0 : __builtin_ctz((unsigned)nb0);
-          const double tq = L[RQ + k16], tv = L[RV + k16];
-          L[(lane < 16 ? SLOT + 32 * sl : DUMP) + lane] = tq; L[(lane < 16 ? SLOT + 32 * sl + 16 : DUMP) + lane] = tv;
+          if constexpr (WIDE) {
+            double tq[NE], tv[NE];
+            vld(o_ringq(0), tq); vld(o_ringv(0), tv);
+            vst(W_SLOT + 2 * sl, tq); vst(W_SLOT + 2 * sl + 1, tv);
+          } else {
+            const double tq = L[RQ + k16], tv = L[RV + k16];
+            L[(lane < 16 ? SLOT + 32 * sl : DUMP) + lane] = tq; L[(lane < 16 ? SLOT + 32 * sl + 16 : DUMP) + lane] = tv;
+          }
         }
         // =========================== R phase: bookkeeping of leaves k0 .. k1-1, lane k = leaf k ===========================
         const int k = k16;
@@ -441,7 +531,67 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
         // ---- U-turn checks, one lane each (stopCondition, WALNUTS.py:95-97, with the older state on the side opposite to xi) ----
         uint64_t m_fire = 0ull;  // leaves at which a sub-tree check fired
         bool f0_now = false;
-        {
+        if constexpr (WIDE) {
+          // wave-wide dots (the one-stream engine's uturn_dots: products summed over the lane's registers in order, then over the
+          // wave).  The checks of leaves r = k0 .. k1-1 in order -- the full-orbit check at the doubling's last leaf, the sub-tree
+          // checks at odd leaves: levels 1 .. ctz(leaf + 1) -- as a scalar walk; the loads of the NEXT check are in flight while this
+          // one is summed (a lone wave waits ~900 cycles for a load from L2; loads return in order).
+          struct Chk { int r, lvl; bool ok; };
+          auto nlv_of = [&](int r) -> int { const int nr = nb0 + r; return (i >= 1 && (nr & 1)) ? __builtin_ctz((unsigned)(nr + 1)) : 0; };
+          auto first_at = [&](int r) -> Chk {  // first check at or behind leaf r
+            Chk c; c.r = r; c.lvl = 0; c.ok = false;
+#pragma unroll 1
+            for (; c.r < k1; ++c.r) {
+              const bool full = nb0 + c.r == nleaf - 1;
+              if (full || nlv_of(c.r) > 0) { c.lvl = full ? 0 : 1; c.ok = true; break; }
+            }
+            return c;
+          };
+          auto advance = [&](const Chk& c) -> Chk {
+            if (c.lvl < nlv_of(c.r)) { Chk d = c; d.lvl = c.lvl + 1; return d; }
+            return first_at(c.r + 1);
+          };
+          auto issue = [&](const Chk& c, double* qr, double* vr, double* ql, double* vl) {
+            int lq, lv;
+            if (c.lvl == 0) { lq = W_COLDQ; lv = W_COLDV; }
+            else if (c.lvl <= 4) { lq = W_RQ + (c.r + 1 - (1 << c.lvl)); lv = lq + (W_RV - W_RQ); }
+            else {
+              const int nl = nb0 + c.r + 1 - (1 << c.lvl);  // left leaf of the sub-tree
+              const int sl = nl == 0 ? 0 : __builtin_ctz((unsigned)nl);
+              lq = W_SLOT + 2 * sl; lv = lq + 1;
+            }
+            vld(o_ringq(c.r), qr); vld(o_ringv(c.r), vr); vld(lq, ql); vld(lv, vl);
+          };
+          auto sum_up = [&](const Chk& c, const double* qr, const double* vr, const double* ql, const double* vl) {
+            double a1 = 0.0, a2 = 0.0;
+            WN_OV(e) {
+              const double dq = qr[e] - ql[e];
+              a1 += vr[e] * dq;
+              a2 += vl[e] * dq;
+            }
+            reduce2(a1, a2);
+            const bool fire = ((double)xi * a1 < 0.0) || ((double)xi * a2 < 0.0);
+            if (uni_b(fire)) {
+              if (c.lvl == 0) f0_now = true; else m_fire |= 1ull << c.r;
+            }
+          };
+          Chk ca = first_at(k0);
+          if (ca.ok) {
+            double aqr[NE], avr[NE], aql[NE], avl[NE], bqr[NE], bvr[NE], bql[NE], bvl[NE];
+            issue(ca, aqr, avr, aql, avl);
+#pragma unroll 1
+            for (;;) {
+              Chk cb = advance(ca);
+              if (cb.ok) issue(cb, bqr, bvr, bql, bvl);
+              sum_up(ca, aqr, avr, aql, avl);
+              if (!cb.ok) break;
+              ca = advance(cb);
+              if (ca.ok) issue(ca, aqr, avr, aql, avl);
+              sum_up(cb, bqr, bvr, bql, bvl);
+              if (!ca.ok) break;
+            }
+          }
+        } else {
 #pragma clang fp contract(off)
           int r = -1, lq = 0, lv = 0, lvl = 0;  // right leaf (ring entry), LDS offsets of the left state
           if (lane < 8) { r = 2 * lane + 1; lvl = 1; }
@@ -551,8 +701,9 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
             if (mp) {  // the last leaf that took the multinomial draw is the proposal
               const int Pk = 63 - __builtin_clzll(mp);
               if (ip == ipl) ip ^= 1;  // keep qPropLast intact
-              const double qp = L[RQ + RS * Pk + k16];
-              row0_store(PROP + 16 * ip, qp);
+              double qp[NE];
+              vld(o_ringq(Pk), qp);
+              vst(o_prop(ip), qp);
               lpP = wn_readlane(lp_k, Pk);
               L_ = fw ? b + 1 + (nb0 + Pk) : a - 1 - (nb0 + Pk);
               const double tp = wn_readlane(P1, 16 + Pk);
@@ -566,6 +717,9 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
                     (uint32_t)__builtin_popcountll(rng & m_dr);
               const bool dl = (m_dr >> Lfull) & 1ull;
               if (fw) predF = dl; else predB = dl;
+              // the second step size of a pair was drawn with the first (:395): its index, for a batch that starts at the pair's second leaf
+              // (wide mode's one-leaf batches; a restart behind a mispredicted draw sets it again below)
+              if constexpr (WIDE) khc = ku - 1u - (INTEG == I_ADAPT_R2P ? 1u : 0u) - (uint32_t)dl;
             } else {
               ku += 1u + (INTEG == I_ADAPT_R2P ? 1u : 0u);
             }
@@ -584,8 +738,8 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
         }
         if (end_sub) { sub = true; break; }
         if (redo) {  // restart behind the mispredicted leaf: its state is in the ring
-          qa = L[RQ + RS * Lfull + k16]; va = L[RV + RS * Lfull + k16];
-          double lpp = tgt.grad(&qa, &ga, lane);
+          vld(o_ringq(Lfull), qa); vld(o_ringv(Lfull), va);
+          double lpp = tgt.grad(qa, ga, lane);
           (void)lpp;
           // the second step size of a pair was drawn with the first (:395): its index, for a restart at the pair's second leaf
           khc = ku - 1u - (INTEG == I_ADAPT_R2P ? 1u : 0u) - (uint32_t)((m_dr >> Lfull) & 1ull);
@@ -619,7 +773,8 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
     }
     // ---- end of the iteration (:653-695) ----
     {
-      const double qP = row_load(PROP + 16 * ip);
+      double qP[NE];
+      vld(o_prop(ip), qP);
       emit_generated(iter, qP);  // samples[:,iterN] = generated(qc), qc = qProp
       double d[NDIAG];
       d[0] = L_; d[1] = NdS; d[2] = orbitLen_; d[3] = orbitLenSam_; d[4] = maxFint; d[5] = maxBint;
@@ -655,14 +810,27 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
 // ---- host side ----------------------------------------------------------------------------------------------------------
 // plain sampling runs (no trace, no warm-up, no orbit statistics) of the three leapfrog integrators on the <= 16-D targets of the
 // one-chain-per-wave layout; WN_ORBIT_LEGACY=1 keeps the one-stream engine (A/B tests)
+bool orbit_wide_geom(const KernelChoice& kc) { return kc.layout == 2 && kc.p0 == 12 && kc.W == 1 && kc.G == 1 && kc.p1 == T_STOCKWATSON; }
+size_t orbit_wide_work_doubles(int NE, int C, int M) { return (size_t)C * orbit::wide_doubles(NE, M); }
+// Which plain sampling runs of that geometry take the wide mode: fixedLeapFrog (mainSW.py:56-62: a leaf is ONE evaluation, the one-stream
+// engine spends 40 % of it on bookkeeping).  A macro step of the adaptive integrators is 8+ evaluations (minC = 3): its bookkeeping is a
+// twentieth of it in either kernel, and the one-stream engine's is the cheaper one (no ring, no batch draws); WN_ORBIT_WIDE_ADAPT=1 sends
+// them here all the same (tests/test_gpu_orbit.py: the generic kernel against that engine, bit for bit).
+bool orbit_wide_run(const KernelChoice& kc, int integrator) {
+  if (!orbit_wide_geom(kc) || getenv("WN_ORBIT_LEGACY") || getenv("WN_ORBIT_NOWIDE")) return false;
+  return integrator == I_FIXED || ((integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && getenv("WN_ORBIT_WIDE_ADAPT"));
+}
+
 bool orbit_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm) {
-  if (kc.layout != 2 || kc.p0 != 1 || kc.W != 1 || kc.G != 1) return false;
+  const bool wide = orbit_wide_geom(kc);
+  if (!wide && (kc.layout != 2 || kc.p0 != 1 || kc.W != 1 || kc.G != 1)) return false;
   if (warm || prm.mode != MODE_SAMPLE || prm.trace_n || prm.trace || prm.omin) return false;
   if (adapt == 2) return false;
   if (prm.integrator != I_FIXED && prm.integrator != I_ADAPT_D && prm.integrator != I_ADAPT_R2P) return false;
-  if (prm.M < 1 || prm.M > MAX_M || prm.D > 16 || prm.maxC > 12 || prm.minC < 0 || prm.minC > prm.maxC) return false;
+  if (prm.M < 1 || prm.M > MAX_M || (!wide && prm.D > 16) || prm.maxC > 12 || prm.minC < 0 || prm.minC > prm.maxC) return false;
   if (prm.generated != G_IDENTITY && prm.generated != G_FIRSTK && prm.generated != G_Q0_SUMSQ) return false;
   if (getenv("WN_ORBIT_LEGACY")) return false;
+  if (wide) return orbit_wide_run(kc, prm.integrator);
   switch (kc.p1) {
     case T_FUNNEL10: case T_CORRGAUSS: case T_SMILE: case T_FUNNEL1: case T_MODFUNNEL: return true;
   }
@@ -690,7 +858,18 @@ static hipError_t go_orbit(const Params& prm, hipStream_t st) {
   return hipGetLastError();
 }
 
+// wide mode: vectors in the chain's workspace, no LDS
+template <class Tgt, int NE>
+static hipError_t go_orbit_wide(const Params& prm, hipStream_t st) {
+  dim3 grid(prm.C), block(64);
+  if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_R2P, false, NE>), grid, block, 0, st, prm);
+  else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_D, false, NE>), grid, block, 0, st, prm);
+  else hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_FIXED, false, NE>), grid, block, 0, st, prm);
+  return hipGetLastError();
+}
+
 hipError_t launch_orbit(const KernelChoice& kc, const Params& prm, hipStream_t st) {
+  if (orbit_wide_geom(kc)) return go_orbit_wide<WTgtStockWatson<12>, 12>(prm, st);
   switch (kc.p1) {
     case T_FUNNEL10: return go_orbit<WTgtFunnel10>(prm, st);
     case T_CORRGAUSS: return go_orbit<WTgtPair<TgtCorrGauss>>(prm, st);
