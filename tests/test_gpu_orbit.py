@@ -33,7 +33,7 @@ def funnel_q0(C, seed=3):
     return q0
 
 
-def run_engine(wa, target, q0, iters, legacy=False, exact=True, seed=SEED, tpar=None, **kw):
+def run_engine(wa, target, q0, iters, legacy=False, exact=True, seed=SEED, tpar=None, onewave=False, **kw):
     """exact: the orbit kernel with the micro-step arithmetic of the one-stream engine (WN_ORBIT_EXACT=1; funnel10's default is a
     micro step of its own with one row reduction instead of two -- the same values, not the same bits)"""
     from walnuts_amd import _lib as L
@@ -41,6 +41,8 @@ def run_engine(wa, target, q0, iters, legacy=False, exact=True, seed=SEED, tpar=
     os.environ["WN_ORBIT_WIDE_ADAPT"] = "1"  # (StockWatson: the adaptive integrators' plain runs stay on the one-stream engine by default)
     if legacy:
         os.environ["WN_ORBIT_LEGACY"] = "1"
+    if onewave:  # (StockWatson's fixedLeapFrog run: the one-wave form of the wide mode instead of wn_k_orbit2.hip's two waves)
+        os.environ["WN_ORBIT_ONEWAVE"] = "1"
     if exact:
         os.environ["WN_ORBIT_EXACT"] = "1"
     try:
@@ -54,6 +56,7 @@ def run_engine(wa, target, q0, iters, legacy=False, exact=True, seed=SEED, tpar=
         os.environ.pop("WN_ORBIT_LEGACY", None)
         os.environ.pop("WN_ORBIT_EXACT", None)
         os.environ.pop("WN_ORBIT_WIDE_ADAPT", None)
+        os.environ.pop("WN_ORBIT_ONEWAVE", None)
         if old is not None:
             os.environ["WN_ORBIT_LEGACY"] = old
     return s, d, name
@@ -188,9 +191,13 @@ SW_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", SW_CASES, ids=[f"T{c[0]}_integ{c[1]}_M{c[2]['M']}" for c in SW_CASES])
-def test_wide_orbit_kernel_equals_the_one_stream_engine_and_the_oracle(wa, case):
-    """wn_orbit_kernel<stockwatson,NE=12,...> (BASELINE config 5's plain sampling runs) against the one-stream engine of the same layout
+SW_FORMS = [(c, w) for c in SW_CASES for w in ((False, True) if c[1] == ol.I_FIXED else (True,))]
+
+
+@pytest.mark.parametrize("case,onewave", SW_FORMS, ids=[f"T{c[0]}_integ{c[1]}_M{c[2]['M']}_{'one_wave' if w else 'two_waves'}" for c, w in SW_FORMS])
+def test_wide_orbit_kernel_equals_the_one_stream_engine_and_the_oracle(wa, case, onewave):
+    """The trajectory-first kernel's wide mode -- wn_orbit_kernel<stockwatson,NE=12,...> on one wave, and wn_orbit2_kernel (fixedLeapFrog:
+    trajectory and bookkeeping on a wave each; BASELINE config 5's fixedLeapFrog run) -- against the one-stream engine of the same layout
     (WN_ORBIT_LEGACY=1: same micro-step arithmetic, same wave sums -- draws and diagnostics bit for bit for the adaptive integrators)
     and against the CPU oracle (integers exactly, reals to 1e-6)."""
     T, integ, kw, iters, rtol = case
@@ -198,8 +205,8 @@ def test_wide_orbit_kernel_equals_the_one_stream_engine_and_the_oracle(wa, case)
     tpar = sw_tpar(T)
     rng = np.random.default_rng(100 + T)
     q0 = 0.1 * rng.normal(size=(C, 3 * T)); q0[0] = 0.0
-    s_new, d_new, name = run_engine(wa, ol.T_STOCKWATSON, q0, iters, tpar=tpar, integrator=integ, **kw)
-    assert "wn_orbit_kernel<stockwatson" in name, name
+    s_new, d_new, name = run_engine(wa, ol.T_STOCKWATSON, q0, iters, tpar=tpar, integrator=integ, onewave=onewave, **kw)
+    assert ("wn_orbit_kernel<stockwatson" if onewave else "wn_orbit2_kernel<stockwatson") in name, name
     s_old, d_old, name_old = run_engine(wa, ol.T_STOCKWATSON, q0, iters, legacy=True, tpar=tpar, integrator=integ, **kw)
     assert "wn_wave_kernel" in name_old, name_old
     bad = [c for c in range(C) if not same_run(s_new[c], d_new[c], s_old[c], d_old[c], rtol)]
@@ -230,3 +237,17 @@ def test_wide_orbit_kernel_generated_forms(wa, gen, gk):
     assert same(d_new[..., INT_COLS], d_old[..., INT_COLS])
     assert near(s_new, s_old, 1e-12), np.abs(s_new - s_old).max()
     assert s_new.shape[-1] == (gk if gen == ol.G_FIRSTK else 2)
+
+
+def test_two_wave_kernel_is_the_one_wave_kernel_bit_for_bit(wa):
+    """wn_k_orbit2.hip against wn_k_orbit.hip's wide mode on a longer fixedLeapFrog run (mainSW.py:56-62 shape: M = 11, orbits of up to 2047
+    leaves, many ring wrap-arounds, sub-tree levels up to 10): the same arithmetic on another schedule -- every draw and diagnostic equal."""
+    T, C, iters = 252, 64, 6
+    tpar = sw_tpar(T)
+    q0 = np.zeros((C, 3 * T))
+    kw = dict(integrator=ol.I_FIXED, H0=0.1 / 8, M=11)
+    s2, d2, name2 = run_engine(wa, ol.T_STOCKWATSON, q0, iters, tpar=tpar, **kw)
+    s1, d1, name1 = run_engine(wa, ol.T_STOCKWATSON, q0, iters, tpar=tpar, onewave=True, **kw)
+    assert "wn_orbit2_kernel" in name2 and "wn_orbit_kernel" in name1, (name2, name1)
+    assert same(d2, d1) and same(s2, s1), (np.argwhere(d2 != d1)[:5], np.abs(s2 - s1).max())
+    assert d2[:, :, 6].max() > 500  # long orbits

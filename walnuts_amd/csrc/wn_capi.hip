@@ -147,7 +147,7 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_
 
 size_t kernel_work_doubles(const KernelChoice& kc, int C, int M) {
   if (kc.layout == 0) return lane_work_doubles(kc.p0, C, M);
-  if (kc.layout == 2) return std::max(wave_work_doubles(kc.p0, C, M, kc.G), orbit_wide_geom(kc) ? orbit_wide_work_doubles(kc.p0, C, M) : (size_t)0);
+  if (kc.layout == 2) return std::max(wave_work_doubles(kc.p0, C, M, kc.G), orbit_wide_geom(kc) ? std::max(orbit_wide_work_doubles(kc.p0, C, M), orbit2_work_doubles(kc.p0, C, M)) : (size_t)0);
   if (kc.layout == 3) return split_work_doubles(kc.p0, C, M);
   const int NT = kc.p0 <= 16 ? 1 : kc.p0 <= 32 ? 2 : 4;
   // the role-split kernel of the same layout (wn_k_fast.hip) pads every vector to 8 tiles x 4 registers x 64 lanes
@@ -523,6 +523,8 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
   if (e->cfg.warmup_iter == 0 && e->cfg.M >= 1 && orbit_wide_run(kc, e->cfg.integrator)) {
     // (round 5) StockWatson's plain sampling runs: the same kernel with vectors of 12 registers per lane
     snprintf(kc.name, sizeof(kc.name), "wn_orbit_kernel<stockwatson,NE=12,%s>", e->cfg.integrator == WN_I_FIXED ? "fixedLeapFrog" : e->cfg.integrator == WN_I_ADAPT_D ? "adaptLeapFrogD" : "adaptLeapFrogR2P");
+    // fixedLeapFrog: trajectory and bookkeeping on a wave each (wn_k_orbit2.hip)
+    if (e->cfg.integrator == WN_I_FIXED && !getenv("WN_ORBIT_ONEWAVE")) snprintf(kc.name, sizeof(kc.name), "wn_orbit2_kernel<stockwatson,NE=12,fixedLeapFrog>");
   }
   e->kc = kc;
   e->have_kc = true;
@@ -808,6 +810,7 @@ static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
   if (e->kabort_pending) { int rc_ = check_abort(e, false); if (rc_) return rc_; }
   hipError_t r = (!coop_legacy && !fast_legacy && fast4_eligible(e->kc, adapt, warm, p_)) ? launch_fast4(e->kc, p_, e->kabort, st)
                : (!coop_legacy && fast_eligible(e->kc, adapt, warm, p_)) ? launch_fast(e->kc, p_, e->kabort, st)
+               : orbit2_eligible(e->kc, adapt, warm, p_) ? launch_orbit2(e->kc, p_, e->kabort, st)
                : orbit_eligible(e->kc, adapt, warm, p_) ? launch_orbit(e->kc, p_, st)
                : e->kc.layout == 0 ? launch_lane(e->kc, adapt, warm, p_, st)
                : e->kc.layout == 1 ? launch_coop(e->kc, adapt, warm, p_, st) : launch_wave(e->kc, adapt, warm, p_, st);

@@ -1,0 +1,644 @@
+// wn_k_orbit2.hip -- the trajectory-first kernel's wide mode (wn_k_orbit.hip: a chain whose vectors fill the wave, StockWatson D = 756 in
+// 12 registers per lane) on TWO wavefronts per chain, fixedLeapFrog runs (mainSW.py:56-62; BASELINE config 5's fixedLeapFrog run).
+//
+// Config 5 is 256 chains on 256 CUs: ONE wave per CU on a machine with four SIMDs per CU, and that wave's time per leaf is
+// 4.3 k cycles of leapfrog step + gradient (one instruction per ~4.8 cycles: a lone wave) plus 2.4-3 k cycles of NUTS bookkeeping in every
+// form tried so far -- replicated scalar code (one-stream engine), lane-parallel in batches of 16 (wn_k_orbit.hip's wide mode: the
+// batch form saves the scalar code but pays its U-turn dots with loads from L2, ~900 cycles of latency each for a lone wave).  The
+// bookkeeping does not feed the trajectory: for fixedLeapFrog the next leaf needs the previous leaf's state and a step size, nothing the
+// weights, the multinomial draws or the U-turn checks produce -- until the orbit stops.  So a SECOND wave on another SIMD does it:
+//
+//   T wave   one command -> one RUN: the leaves n0 .. 2**i - 1 of doubling i, back to back (step sizes from the wave's own lane-parallel
+//            draws, under the assumption "every leaf takes its multinomial draw like the one before": WALNUTS.py:395,426);
+//            each leaf's (q, v) to a ring of 32 entries in the chain's workspace, its (H, lp) to a record in LDS, the count of published
+//            leaves to an LDS word -- one leaf late, so that the release fence in front of it finds the stores long complete.
+//   R wave   retires whatever has been published, in sub-batches inside a block of 16, lane k = leaf k, exactly as wn_k_orbit.hip's R
+//            phase does (serial prefix sums in the reference's order, U-turn checks as wave-wide dots with the next check's loads in
+//            flight, ballots for the first event); it owns every scalar of WALNUTS.py:189-695, the proposals, the slots, the draws it
+//            verifies the T wave's assumption with.  On an event inside a doubling (sub-tree U-turn, non-finite energy, a draw that was
+//            not taken as assumed) it raises the abort word and sends the next command: NEWITER (proposal, lp), GO (next doubling: which
+//            end is active), REDO (restart behind leaf n with the corrected draw index; the state is in the ring), EXIT.
+// Leaves the T wave ran ahead of an event are never counted: draws, nevalF / nevalB and every diagnostic are the reference's.  The
+// arithmetic of a micro step, of every sum and of every dot is wn_k_orbit.hip's wide mode = the one-stream engine's (tests/test_gpu_orbit.py).
+// Every wait is bounded: a wave that gives up sets the DEAD word (and the engine's abort flag), both waves leave.
+#include "wn_launch.h"
+#include "wn_policy_wave.h"
+#include "wn_orbit.h"
+
+namespace wn {
+
+namespace orbit2 {
+// the chain's workspace, in vectors of NE * 64 doubles: ring of 32 leaves (two blocks of 16)
+enum { V_RQ = 0, V_RV = 32, V_COLDQ = 64, V_COLDV = 65, V_COLDG = 66, V_PROP = 67, V_SLOT = 69 };
+__host__ __device__ constexpr size_t wide_doubles(int NE, int M) { return (size_t)(V_SLOT + 2 * (M + 1)) * NE * 64; }
+// LDS, in doubles: records of the ring's leaves [entry][Hn, lp], then the words of the hand-off
+enum { L_REC = 0, L_PROD = 64, L_CONS = 65, L_ABORT = 66, L_DEAD = 67, L_ACK = 68, L_KP = 69, L_CMD = 72, L_TOTAL = 80 };
+enum { K_NEWITER = 1, K_GO = 2, K_REDO = 3, K_EXIT = 4 };
+typedef __attribute__((address_space(3))) double lds2_d;
+typedef __attribute__((address_space(3))) volatile unsigned long long lds_u64;
+#ifndef WN_O2_SPINS
+#define WN_O2_SPINS (1u << 24)
+#endif
+}  // namespace orbit2
+
+template <class Tgt, int NE>
+__global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort) {
+  using namespace orbit;
+  using namespace orbit2;
+  static_assert(NE % 2 == 0, "stored vectors are register pairs");
+  constexpr int DP = NE * 64;
+  __shared__ double wn_o2_lds[L_TOTAL];
+  lds2_d* const L = (lds2_d*)wn_o2_lds;
+  lds_u64* const LU = (lds_u64*)wn_o2_lds;
+  const int lane = threadIdx.x & 63;
+  const int role = threadIdx.x >> 6;  // 0: T wave, 1: R wave
+  const int k16 = lane & 15;
+  const int row = lane >> 4;
+  const int cl = blockIdx.x;
+  const uint32_t cg = prm.chain0 + (uint32_t)cl;
+  const uint32_t seedlo = (uint32_t)prm.seed, seedhi = (uint32_t)(prm.seed >> 32);
+  const int D = prm.D, M = prm.M;
+  const bool inrange = cl < prm.C;
+  const int clc = inrange ? cl : 0;
+  const double Hc = prm.H;
+  Tgt tgt;
+  tgt.init(prm, lane, nullptr);
+  if (threadIdx.x < L_TOTAL) L[threadIdx.x] = 0.0;
+  __syncthreads();
+
+#define WN_OV(e) _Pragma("unroll") for (int e = 0; e < NE; ++e)
+  auto reduce2 = [&](double& a, double& b) { a = wn_wavesum(a); b = wn_wavesum(b); };
+  auto reduce1 = [&](double a) -> double { return wn_wavesum(a); };
+  auto gidx = [&](int e) -> int {
+    if constexpr (tgt_mapped<Tgt>::value) return tgt.map_gidx(e, lane);
+    else return e * 64 + lane < D ? e * 64 + lane : -1;
+  };
+  // a stored vector is [register pair][lane][2]: one 16-byte access per lane and pair of registers
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  d2_t* const Wk = reinterpret_cast<d2_t*>(prm.work + (size_t)clc * orbit2::wide_doubles(NE, M)) + lane;
+  auto vst = [&](int off, const double* x) {
+#pragma unroll
+    for (int j = 0; j < NE / 2; ++j) { d2_t t; t[0] = x[2 * j]; t[1] = x[2 * j + 1]; Wk[(size_t)off * (DP / 2) + j * 64] = t; }
+  };
+  auto vld = [&](int off, double* x) {
+#pragma unroll
+    for (int j = 0; j < NE / 2; ++j) { const d2_t t = Wk[(size_t)off * (DP / 2) + j * 64]; x[2 * j] = t[0]; x[2 * j + 1] = t[1]; }
+  };
+  // ---- the hand-off words ----
+  auto dead = [&]() -> bool { return LU[L_DEAD] != 0ull; };
+  auto give_up = [&]() { LU[L_DEAD] = 1ull; if (lane == 0 && kabort) *kabort = 1; };
+  auto release = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); };
+  auto acquire = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
+
+  // ---- the draws of leaves k0 .. 15 of a block, lane-parallel (wn_k_orbit.hip): lane k (of every row) gets leaf k's step size and its
+  // multinomial uniform.  `ku` = the stream index of the first draw of leaf k0, `khc` = the index of the second step size of a pair when
+  // k0 is the pair's second leaf, `pred` = "every leaf takes its multinomial draw" ----
+  auto draws = [&](int i, int iter, int k0, uint32_t ku, uint32_t khc, bool pred, double& hV, double& upV) {
+    const uint32_t p_ = (pred && i != 0) ? 1u : 0u;
+    const uint32_t ce = (i != 0 ? 2u : 1u) + p_, co = p_;
+    const uint32_t klow = (k0 & 1) ? khc : ku;
+    const uint32_t base = (uint32_t)uni_i((int)(klow >> 1));
+    Philox4 r = philox4x32_10(base + (uint32_t)(lane >> 1), (uint32_t)iter, cg, 0u, seedlo, seedhi);
+    const double ru0 = (lane & 1) ? u53(r.w[2], r.w[3]) : u53(r.w[0], r.w[1]);
+    const uint32_t j = (uint32_t)k16;
+    const uint32_t nE = ((j + 1u) >> 1) - (((uint32_t)k0 + 1u) >> 1), nO = (j >> 1) - ((uint32_t)k0 >> 1);  // even / odd leaves in [k0, j)
+    const uint32_t kuS = ku + ce * nE + co * nO;  // the leaf's first draw
+    const bool evn = (i == 0) || !(j & 1u);
+    uint32_t ih = evn ? kuS : kuS - ce + 1u;  // the second step size of the pair was drawn with the first
+    ih = (j == (uint32_t)k0 && (k0 & 1)) ? khc : ih;
+    const uint32_t ipk = evn ? kuS + (i != 0 ? 2u : 1u) : kuS;
+    const uint32_t off = 2u * base;
+    const double uh = __shfl(ru0, (int)((ih - off) & 63u)), up = __shfl(ru0, (int)((ipk - off) & 63u));
+    const double low = Hc * (1 - prm.s), high = Hc * (1 + prm.s);
+    hV = low + (high - low) * uh;  // numpy legacy uniform(low, high) = low + (high-low)*U  (WALNUTS.py:298,395)
+    upV = up;
+  };
+  // the stream index behind the leaves [k0, k1) of a block when every one of them does what `pred` says
+  auto ku_behind = [&](int i, int k0, int k1, uint32_t ku, bool pred) -> uint32_t {
+    if (i == 0) return ku + 1u;
+    const uint32_t p_ = pred ? 1u : 0u;
+    const uint32_t nE = (((uint32_t)k1 + 1u) >> 1) - (((uint32_t)k0 + 1u) >> 1), nO = ((uint32_t)k1 >> 1) - ((uint32_t)k0 >> 1);
+    return ku + (2u + p_) * nE + p_ * nO;
+  };
+
+  if (role == 0) {
+    // =====================================================================================================================
+    // T wave: the trajectory
+    // =====================================================================================================================
+    double qa[NE], va[NE], ga[NE];
+    WN_OV(e) { qa[e] = 0.0; va[e] = 0.0; ga[e] = 0.0; }
+    uint32_t seq = 0;
+    for (;;) {
+      ++seq;
+      // ---- wait for command `seq` ----
+      unsigned long long w0 = 0;
+      {
+        unsigned spins = 0;
+        for (;;) {
+          w0 = LU[L_CMD];
+          if ((uint32_t)(w0 >> 32) == seq) break;
+          if (dead()) break;
+          if (++spins > WN_O2_SPINS) { give_up(); break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      if (dead()) break;
+      acquire();
+      const int kind = (int)(uint32_t)w0;
+      if (kind == K_EXIT) break;
+      const unsigned long long w1 = LU[L_CMD + 1], w2 = LU[L_CMD + 2], w3 = LU[L_CMD + 3], w4 = LU[L_CMD + 4];
+      const int ip = (int)(uint32_t)w1, iter = (int)(uint32_t)(w1 >> 32);
+      int n = uni_i((int)(uint32_t)w2);
+      const int i = uni_i((int)(uint32_t)(w2 >> 32));
+      uint32_t ku = (uint32_t)w3, khc = (uint32_t)(w3 >> 32);
+      const bool pred = ((uint32_t)w4 & 1u) != 0u, swap = ((uint32_t)w4 & 2u) != 0u;
+      const int xi = (int)(uint32_t)(w4 >> 32);
+      if (kind == K_NEWITER) {
+        vld(V_PROP + ip, qa);
+        double lpp = tgt.grad(qa, ga, lane);  // f0, grad0 = lpFun(qc)  (WALNUTS.py:249); the R wave holds its value
+        (void)lpp;
+        // :236  v = normal(size=d)  (rolled: one copy of Philox + Box-Muller in the code; the register is picked with selects)
+#pragma unroll 1
+        for (int e1 = 0; e1 < NE; ++e1) {
+          int gi = -1;
+          WN_OV(e) gi = e == e1 ? gidx(e) : gi;
+          const double z = gi >= 0 ? rng_normal(prm.seed, cg, (uint32_t)iter, (uint32_t)gi) : 0.0;
+          WN_OV(e) va[e] = e == e1 ? z : va[e];
+        }
+        vst(V_COLDQ, qa); vst(V_COLDV, va); vst(V_COLDG, ga);
+        double kp = 0.0;
+        WN_OV(e) kp += va[e] * va[e];
+        double gp = 0.0;
+        reduce2(kp, gp);
+        L[L_KP] = kp;
+        release();
+        LU[L_ACK] = (unsigned long long)seq;
+      } else if (kind == K_GO) {
+        if (swap) {  // the other end of the orbit becomes the active one (:283-294)
+          double tq[NE], tv[NE], tg[NE];
+          vld(V_COLDQ, tq); vld(V_COLDV, tv); vld(V_COLDG, tg);
+          vst(V_COLDQ, qa); vst(V_COLDV, va); vst(V_COLDG, ga);
+          WN_OV(e) { qa[e] = tq[e]; va[e] = tv[e]; ga[e] = tg[e]; }
+        }
+      } else {  // K_REDO: restart behind leaf n - 1, whose state is in the ring
+        vld(V_RQ + ((n - 1) & 31), qa); vld(V_RV + ((n - 1) & 31), va);
+        double lpp = tgt.grad(qa, ga, lane);
+        (void)lpp;
+      }
+      // ---- the run: leaves n .. nleaf-1 of doubling i ----
+      const int nleaf = 1 << i;
+      bool stop = false;
+      while (n < nleaf && !stop) {
+        const int nb0 = n & ~15, k0 = n & 15;
+        const int k1 = nleaf - nb0 < 16 ? nleaf - nb0 : 16;
+        if (k0 == 0 && n >= 32) {  // the ring entries of block (n >> 4) - 2 are about to be overwritten: the R wave must be through with it
+          release();
+          LU[L_PROD] = ((unsigned long long)seq << 32) | (unsigned)n;
+          unsigned spins = 0;
+          while ((int)(uint32_t)LU[L_CONS] < n - 16) {
+            if ((uint32_t)LU[L_ABORT] == seq || dead()) { stop = true; break; }
+            if (++spins > WN_O2_SPINS) { give_up(); stop = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+          }
+          if (stop) break;
+        }
+        double hV, upV;
+        draws(i, iter, k0, ku, khc, pred, hV, upV);
+        (void)upV;
+#pragma unroll 1
+        for (int k = k0; k < k1; ++k) {
+          const double hh = wn_readlane(hV, k);
+          const double hh2 = 0.5 * hh, hq = hh;
+          // fixedLeapFrog (adaptiveIntegrators.py:49-59) from (q, xi*v, g); intOut.v is in forward-time orientation (:57)
+          double vw[NE];
+          WN_OV(e) vw[e] = (double)xi * va[e];
+          WN_OV(e) { vw[e] = vw[e] + hh2 * ga[e]; qa[e] = qa[e] + hq * vw[e]; }
+          double lpp = tgt.grad(qa, ga, lane);
+          double ke = 0.0;
+          WN_OV(e) { vw[e] = vw[e] + hh2 * ga[e]; ke += vw[e] * vw[e]; }
+          reduce2(lpp, ke);
+          lpp = Tgt::lp_finish(lpp);
+          const double Hn = -lpp + 0.5 * ke;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
+          WN_OV(e) va[e] = (double)xi * vw[e];
+          // publish the leaves in front of this one (their stores were issued a whole evaluation ago), then store this one
+          release();
+          LU[L_PROD] = ((unsigned long long)seq << 32) | (unsigned)(nb0 + k);
+          const int ent = (nb0 + k) & 31;
+          vst(V_RQ + ent, qa); vst(V_RV + ent, va);
+          if (lane == 0) { L[L_REC + 2 * ent] = Hn; L[L_REC + 2 * ent + 1] = lpp; }
+          n = nb0 + k + 1;
+          // forced reject (:316-319): nothing behind a non-finite energy will be used; the R wave has raised the abort word: an event
+          // inside the doubling
+          if (!uni_b(isfinite(Hn)) || (uint32_t)LU[L_ABORT] == seq) { stop = true; break; }
+        }
+        ku = ku_behind(i, k0, k1, ku, pred);
+      }
+      release();
+      LU[L_PROD] = ((unsigned long long)seq << 32) | (unsigned)n;
+    }
+    return;
+  }
+
+  // =======================================================================================================================
+  // R wave: the bookkeeping (WALNUTS.py:189-695 minus the integrator calls)
+  // =======================================================================================================================
+  // the wave's window of uniforms: lane l holds uniform 2 * rb_base + l of iteration rb_iter (wn_rng.h stream 0)
+  uint32_t rb_iter = 0xFFFFFFFFu, rb_base = 0u;
+  double ru0 = 0.0;
+  auto rng_ensure = [&](uint32_t it, uint32_t k) {  // uniforms k .. k+7 inside the window afterwards
+    const uint32_t blk = (uint32_t)uni_i((int)(k >> 1));
+    if (it != rb_iter || blk - rb_base > 28u) {
+      rb_iter = it; rb_base = blk;
+      Philox4 r = philox4x32_10(blk + (uint32_t)(lane >> 1), it, cg, 0u, seedlo, seedhi);
+      ru0 = (lane & 1) ? u53(r.w[2], r.w[3]) : u53(r.w[0], r.w[1]);
+    }
+  };
+  auto uni = [&](uint32_t k) -> double { return wn_readlane(ru0, (int)((uint32_t)uni_i((int)k) - 2u * rb_base)); };
+
+  double H0 = 0.0, Ha = 0.0, Hb = 0.0, lp0, WoldSum = 1.0, WnewSum = 0.0, lwtSumf = 0.0, lwtSumb = 0.0;
+  double orbitLen_ = 0.0, orbitLenSam_ = 0.0, indexStat_ = 0.0, indexStatOld_ = 0.0, timeLenF_ = 0.0, timeLenB_ = 0.0;
+  double Hmin = INFINITY, Hmax = -INFINITY, lpP = 0.0, lpPL = 0.0;
+  int iter = 1, i = 0, xi = 1, a = 0, b = 0, n = 0, nleaf = 1;
+  uint32_t Bbits = 0, ku = 0, khc = 0;
+  int nevalF = 0, L_ = 0, Lold_ = 0, NdS = 0, NdC = 0, maxFint = 0, maxBint = 0, stopCode = 0;
+  int ip = 0, ipl = 0;
+  bool Hnan = false, bothEndsPassive = false;
+  bool predF = true, predB = true;  // "the next leaf in this direction takes its multinomial draw"
+  uint32_t seq = 0;
+  bool gone = false;  // a wait gave up
+
+  auto send = [&](int kind, int n_, bool pred_, bool swap_) {
+    ++seq;
+    LU[L_CONS] = (unsigned long long)(unsigned)n_;  // (leaves of the new run retired so far: the T wave's ring flow control)
+    LU[L_CMD + 1] = ((unsigned long long)(uint32_t)iter << 32) | (uint32_t)ip;
+    LU[L_CMD + 2] = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)n_;
+    LU[L_CMD + 3] = ((unsigned long long)khc << 32) | ku;
+    LU[L_CMD + 4] = ((unsigned long long)(uint32_t)xi << 32) | (pred_ ? 1u : 0u) | (swap_ ? 2u : 0u);
+    release();
+    LU[L_CMD] = ((unsigned long long)seq << 32) | (uint32_t)kind;
+  };
+  auto emit_generated = [&](int it, const double* qP) {
+    double* rowp = prm.samples + ((size_t)clc * (prm.numIter + 1) + it) * prm.dg;
+    // (arithmetic, not a select of the two kernel arguments: hipcc turned the select into a two-entry array in scratch)
+    const int fk = (int)(prm.generated == G_FIRSTK), sq = (int)(prm.generated == G_Q0_SUMSQ);
+    const int kk = sq ? 1 : fk * prm.gen_k + (1 - fk) * D;
+    WN_OV(e) { const int gi = gidx(e); if (gi >= 0 && gi < kk) rowp[gi] = qP[e]; }
+    if (sq) {
+      double s = 0.0;
+      WN_OV(e) s += qP[e] * qP[e];
+      s = reduce1(s);
+      if (lane == 0) rowp[1] = s;
+    }
+  };
+
+  // ---- q_c = q0; f0, grad0 = lpFun(q0)  (WALNUTS.py:177,249) ----
+  {
+    double q0v[NE], g0v[NE];
+    WN_OV(e) { const int gi = gidx(e); q0v[e] = (gi >= 0 && inrange) ? prm.q0[(size_t)clc * D + gi] : 0.0; }
+    double lp_part = tgt.grad(q0v, g0v, lane);
+    lpP = Tgt::lp_finish(reduce1(lp_part));
+    vst(V_PROP + ip, q0v);
+    if (inrange) emit_generated(0, q0v);  // samples[:,0] = generated(q0)  (:164)
+  }
+  bool live = inrange && prm.numIter >= 1;
+
+  while (__any(live) && !gone) {  // ---- iterations (WALNUTS.py:189) ----
+    // ---- iteration start (:196-276) ----
+    rng_ensure((uint32_t)iter, 0u);  // uniforms 0..63: the M <= 24 direction bits and the first steps
+    Bbits = 0;
+#pragma unroll 1
+    for (uint32_t k = 0; k < (uint32_t)M; ++k)  // :216  B = floor(uniform(0,2,size=M))
+      if ((int)floor(0.0 + (2.0 - 0.0) * uni(k)) != 0) Bbits |= (1u << k);
+    Bbits = (uint32_t)uni_i((int)Bbits);
+    ku = (uint32_t)M;
+    a = 0; b = 0; maxFint = 0; maxBint = 0;
+    predF = predB = true;
+    i = 0;
+    xi = (Bbits & 1u) ? -1 : 1;
+    send(K_NEWITER, 0, xi > 0 ? predF : predB, false);
+    WoldSum = 1.0; WnewSum = 0.0; lwtSumb = 0.0; lwtSumf = 0.0;  // :260-264
+    stopCode = 0; bothEndsPassive = false;
+    nevalF = 0; Lold_ = L_ = 0; orbitLen_ = orbitLenSam_ = 0.0; NdS = NdC = 0;
+    indexStat_ = indexStatOld_ = 0.0; timeLenF_ = timeLenB_ = 0.0;
+    {  // the T wave's momentum: Hs[I0] = -f0 + 0.5*sum(v**2)  (:256); multinomialLscale (:259)
+      unsigned spins = 0;
+      while ((uint32_t)LU[L_ACK] != seq) {
+        if (dead()) { gone = true; break; }
+        if (++spins > WN_O2_SPINS) { give_up(); gone = true; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (gone) break;
+      acquire();
+      const double kp = L[L_KP];
+      lp0 = lpP;
+      H0 = -lp0 + 0.5 * kp;
+      Ha = Hb = H0;
+      Hnan = isnan(H0); Hmin = Hmax = H0;
+    }
+    bool endIter = false;
+
+    while (!endIter) {  // ---- doublings (:281) ----
+      {  // start of doubling i (:283-294)
+        const int nxi = ((Bbits >> i) & 1u) ? -1 : 1;
+        const bool swap = nxi != xi;
+        if (swap) {  // the other end of the orbit becomes the active one (the T wave swaps the vectors)
+          const double th = Ha; Ha = Hb; Hb = th;
+          xi = nxi;
+        }
+        n = 0; nleaf = 1 << i;
+        ipl = ip; lpPL = lpP; Lold_ = L_; indexStatOld_ = indexStat_;
+        if (i > 0) WnewSum = 0.0;  // :390
+        if (i > 0) send(K_GO, 0, xi > 0 ? predF : predB, swap);
+      }
+      const bool fw = xi > 0;
+      bool predRun = fw ? predF : predB;  // what the T wave's running command assumes
+      bool fire0 = false;  // full-orbit U-turn (:622), due at the last leaf of the doubling
+      bool sub = false;
+
+      while (n < nleaf) {  // ---- sub-batches of the doubling's blocks ----
+        const int nb0 = n & ~15;
+        const int k0 = n & 15;
+        int k1;
+        {  // what the T wave has published of this run
+          unsigned spins = 0;
+          int npub = 0;
+          for (;;) {
+            const unsigned long long w = LU[L_PROD];
+            npub = (uint32_t)(w >> 32) == seq ? (int)(uint32_t)w : 0;
+            if (npub > n) break;
+            if (dead()) { gone = true; break; }
+            if (++spins > WN_O2_SPINS) { give_up(); gone = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (gone) break;
+          acquire();
+          npub = uni_i(npub);
+          k1 = npub - nb0 < 16 ? npub - nb0 : 16;
+        }
+        const int rb = nb0 & 16;  // the block's half of the ring
+        // the draws of leaves k0 .. k1-1 as the reference makes them, from the stream index the bookkeeping has reached
+        double hV, upV;
+        draws(i, iter, k0, ku, khc, predRun, hV, upV);
+        // left endpoint of the sub-trees of 2**j leaves, j >= 5, that start at this block's first leaf (levels 1..4 stay inside the ring)
+        if (k0 == 0 && (nb0 == 0 ? i >= 5 : __builtin_ctz((unsigned)nb0) >= 5)) {
+          const int sl = nb0 == 0 ? 0 : __builtin_ctz((unsigned)nb0);
+          double tq[NE], tv[NE];
+          vld(V_RQ + rb, tq); vld(V_RV + rb, tv);
+          vst(V_SLOT + 2 * sl, tq); vst(V_SLOT + 2 * sl + 1, tv);
+        }
+        // =========================== bookkeeping of leaves k0 .. k1-1, lane k = leaf k ===========================
+        const int k = k16;
+        const bool inb = k >= k0 && k < k1;
+        const double Hn_k = L[L_REC + 2 * (rb + k)], lp_k = L[L_REC + 2 * (rb + k) + 1];
+        const double h_k = hV, up_k = upV;
+        const double lw_k = 0.0;  // fixedLeapFrog: lwt = 0  (adaptiveIntegrators.py:57-59)
+        const int nk = nb0 + k;
+        const bool first_k = (i == 0) || !(nk & 1);
+        const int nbat = k1 - k0;
+        // serial prefix sums in the reference's order: row 0 lwtSum of this direction (:321,354,420,507,550; Q2: on the backward
+        // side only the first leaf of a pair adds), row 1 timeLen of this direction, row 2 orbitLen_
+        double P1;
+        {
+          const bool upd = (i == 0) || first_k || fw;
+          const double x = row == 0 ? (upd ? lw_k : 0.0) : h_k;
+          const double carry = row == 0 ? ((i == 0) ? 0.0 : (fw ? lwtSumf : lwtSumb)) : row == 1 ? (fw ? timeLenF_ : timeLenB_) : orbitLen_;
+          double s = inb ? x : 0.0;
+          s = (k == k0) ? carry + s : s;
+          const double xs = s;
+          s = scan_steps(s, xs, nbat);
+          P1 = s;
+        }
+        const double Wn = exp(-Hn_k + H0 + P1);  // Wnew = exp(-H + H0 + lwtSum)  (row 0)
+        double WS;
+        {
+          double s = inb ? Wn : 0.0;
+          const double carry = (i == 0) ? 0.0 : WnewSum;
+          s = (k == k0) ? carry + s : s;
+          const double xs = s;
+          s = scan_steps(s, xs, nbat);
+          WS = s;
+        }
+        const bool inb0 = inb && lane < 16;
+        const bool drawn_k = (i != 0) && (WS > prm.wtSumThresh);
+        // :426  take this state with probability Wnew / WnewSum; i == 0 (:322-328): unconditional, no uniform
+        const bool pick_k = (i == 0) ? true : (drawn_k && up_k < Wn / WS);
+        const uint64_t m_in = __ballot(inb0);
+        const uint64_t m_nf = __ballot(inb0 && !isfinite(Hn_k));
+        const uint64_t m_dr = __ballot(inb0 && drawn_k);
+        const uint64_t m_pk = __ballot(inb0 && pick_k);
+        const uint64_t m_bad = (i != 0) ? ((predRun ? ~m_dr : m_dr) & m_in) : 0ull;
+
+        // ---- U-turn checks (stopCondition, WALNUTS.py:95-97, with the older state on the side opposite to xi): wave-wide dots, the
+        // loads of the next check in flight while this one is summed (wn_k_orbit.hip, wide mode) ----
+        uint64_t m_fire = 0ull;  // leaves at which a sub-tree check fired
+        bool f0_now = false;
+        {
+          struct Chk { int r, lvl; bool ok; };
+          auto nlv_of = [&](int r) -> int { const int nr = nb0 + r; return (i >= 1 && (nr & 1)) ? __builtin_ctz((unsigned)(nr + 1)) : 0; };
+          auto first_at = [&](int r) -> Chk {  // first check at or behind leaf r
+            Chk c; c.r = r; c.lvl = 0; c.ok = false;
+#pragma unroll 1
+            for (; c.r < k1; ++c.r) {
+              const bool full = nb0 + c.r == nleaf - 1;
+              if (full || nlv_of(c.r) > 0) { c.lvl = full ? 0 : 1; c.ok = true; break; }
+            }
+            return c;
+          };
+          auto advance = [&](const Chk& c) -> Chk {
+            if (c.lvl < nlv_of(c.r)) { Chk d = c; d.lvl = c.lvl + 1; return d; }
+            return first_at(c.r + 1);
+          };
+          auto issue = [&](const Chk& c, double* qr, double* vr, double* ql, double* vl) {
+            int lq, lv;
+            if (c.lvl == 0) { lq = V_COLDQ; lv = V_COLDV; }
+            else if (c.lvl <= 4) { lq = V_RQ + rb + (c.r + 1 - (1 << c.lvl)); lv = lq + (V_RV - V_RQ); }
+            else {
+              const int nl = nb0 + c.r + 1 - (1 << c.lvl);  // left leaf of the sub-tree
+              const int sl = nl == 0 ? 0 : __builtin_ctz((unsigned)nl);
+              lq = V_SLOT + 2 * sl; lv = lq + 1;
+            }
+            vld(V_RQ + rb + c.r, qr); vld(V_RV + rb + c.r, vr); vld(lq, ql); vld(lv, vl);
+          };
+          auto sum_up = [&](const Chk& c, const double* qr, const double* vr, const double* ql, const double* vl) {
+            double a1 = 0.0, a2 = 0.0;
+            WN_OV(e) {
+              const double dq = qr[e] - ql[e];
+              a1 += vr[e] * dq;
+              a2 += vl[e] * dq;
+            }
+            reduce2(a1, a2);
+            const bool fire = ((double)xi * a1 < 0.0) || ((double)xi * a2 < 0.0);
+            if (uni_b(fire)) {
+              if (c.lvl == 0) f0_now = true; else m_fire |= 1ull << c.r;
+            }
+          };
+          Chk ca = first_at(k0);
+          if (ca.ok) {
+            double aqr[NE], avr[NE], aql[NE], avl[NE], bqr[NE], bvr[NE], bql[NE], bvl[NE];
+            issue(ca, aqr, avr, aql, avl);
+#pragma unroll 1
+            for (;;) {
+              Chk cb = advance(ca);
+              if (cb.ok) issue(cb, bqr, bvr, bql, bvl);
+              sum_up(ca, aqr, avr, aql, avl);
+              if (!cb.ok) break;
+              ca = advance(cb);
+              if (ca.ok) issue(ca, aqr, avr, aql, avl);
+              sum_up(cb, bqr, bvr, bql, bvl);
+              if (!ca.ok) break;
+            }
+          }
+        }
+        // ---- the first event decides how many leaves of the batch stand ----
+        const int t_nf = m_nf ? __builtin_ctzll(m_nf) : 64;
+        const int t_sub = m_fire ? __builtin_ctzll(m_fire) : 64;
+        const int t_bad = m_bad ? __builtin_ctzll(m_bad) : 64;  // leaves behind it used wrong draw indices
+        const int t_ev = t_nf < t_sub ? t_nf : t_sub;
+        bool end_nf = false, end_sub = false, redo = false;
+        int Lfull;  // last leaf whose bookkeeping is complete
+        if (t_ev <= t_bad && t_ev < k1) {
+          end_nf = t_nf <= t_sub;  // the non-finite test comes first (:316-319 before any U-turn test)
+          end_sub = !end_nf;
+          Lfull = end_nf ? t_ev - 1 : t_ev;
+        } else if (t_bad < k1 && nb0 + t_bad < nleaf - 1) {  // (the T wave runs on beyond this sub-batch: any leaf behind it is wrong)
+          redo = true;
+          Lfull = t_bad;
+        } else {
+          Lfull = k1 - 1;
+        }
+        const int A_end = end_nf ? t_ev : Lfull;  // last leaf that reached the accumulators at the top of the reference's step
+        // ---- accumulators over leaves k0 .. A_end ----
+        {
+          const bool macc = inb && k <= A_end;
+          nevalF += A_end - k0 + 1;  // one evaluation per leaf
+          double d4 = row == 2 ? Hn_k : -Hn_k;
+          d4 = rowmin_d((macc && row >= 2) ? d4 : INFINITY);
+          const double b2 = wn_readlane(d4, 32), b3 = -wn_readlane(d4, 48);
+          Hmin = b2 < Hmin ? b2 : Hmin; Hmax = b3 > Hmax ? b3 : Hmax;
+          if (__ballot(macc && lane < 16 && isnan(Hn_k))) Hnan = true;
+          const double tl = wn_readlane(P1, 16 + A_end);
+          const int idxA = fw ? b + 1 + (nb0 + A_end) : a - 1 - (nb0 + A_end);
+          if (fw) { timeLenF_ = tl; maxFint = idxA; } else { timeLenB_ = tl; maxBint = idxA; }
+          // orbitLen_ += h: i == 0 before the integrator call (:300), else behind the non-finite test (:432 / 471 / 519 / 561)
+          const int o_end = (end_nf && i != 0) ? t_ev - 1 : A_end;
+          if (o_end >= k0) orbitLen_ = wn_readlane(P1, 32 + o_end);
+          if (Lfull >= k0) {
+            const double ls = wn_readlane(P1, Lfull);
+            if (fw) lwtSumf = ls; else lwtSumb = ls;
+            WnewSum = wn_readlane(WS, Lfull);
+            const uint64_t mp = m_pk & ((2ull << Lfull) - 1ull);
+            if (mp) {  // the last leaf that took the multinomial draw is the proposal
+              const int Pk = 63 - __builtin_clzll(mp);
+              if (ip == ipl) ip ^= 1;  // keep qPropLast intact
+              double qp[NE];
+              vld(V_RQ + rb + Pk, qp);
+              vst(V_PROP + ip, qp);
+              lpP = wn_readlane(lp_k, Pk);
+              L_ = fw ? b + 1 + (nb0 + Pk) : a - 1 - (nb0 + Pk);
+              const double tp = wn_readlane(P1, 16 + Pk);
+              indexStat_ = fw ? tp : -tp;
+            }
+            if (i != 0) {  // the draws these leaves consumed, and what the next leaf is expected to do
+              const uint64_t rng = m_in & ((2ull << Lfull) - 1ull);
+              // leaves with an even index drew the pair's two step sizes
+              const uint64_t evn = (nb0 & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
+              ku += 2u * (uint32_t)__builtin_popcountll(rng & evn) + (uint32_t)__builtin_popcountll(rng & m_dr);
+              const bool dl = (m_dr >> Lfull) & 1ull;
+              if (fw) predF = dl; else predB = dl;
+              // the second step size of a pair was drawn with the first (:395): its index, for a sub-batch that starts at the pair's second leaf
+              khc = ku - 1u - (uint32_t)dl;
+            } else {
+              ku += 1u;
+            }
+            Ha = wn_readlane(Hn_k, Lfull);
+          }
+        }
+        if (f0_now && !end_nf && !end_sub && !redo) fire0 = true;
+        n = nb0 + Lfull + 1;
+        LU[L_CONS] = (unsigned long long)(unsigned)n;
+        if (end_nf) {  // :316-319, 414-417, 457-459 (Q3, Q4)
+          const bool first_e = (i == 0) || !((nb0 + t_ev) & 1);
+          if (first_e) stopCode = 999;
+          endIter = true;
+          LU[L_ABORT] = (unsigned long long)seq;
+          break;
+        }
+        if (end_sub) { sub = true; LU[L_ABORT] = (unsigned long long)seq; break; }
+        if (redo) {  // restart behind the mispredicted leaf: its state is in the ring, the T wave re-evaluates the gradient
+          LU[L_ABORT] = (unsigned long long)seq;
+          predRun = fw ? predF : predB;
+          send(K_REDO, n, predRun, false);
+        }
+      }
+      if (gone || endIter) break;
+      // ---- end of the doubling (:590-648) ----
+      indexStat_ = indexStat_ / (timeLenF_ + timeLenB_);  // :595 (Q6)
+      if (sub) {  // :597-605
+        ip = ipl; lpP = lpPL; L_ = Lold_; indexStat_ = indexStatOld_;
+        NdS = i; NdC = i + 1; stopCode = 5;
+        endIter = true;
+        break;
+      }
+      rng_ensure((uint32_t)iter, ku);
+      if (!__any(uni(ku++) < WnewSum / WoldSum)) { ip = ipl; lpP = lpPL; L_ = Lold_; indexStat_ = indexStatOld_; }  // :613-616
+      bothEndsPassive = (lwtSumb < WN_LOGZERO + 1.0) && (lwtSumf < WN_LOGZERO + 1.0);  // :624
+      if (__any(fire0 || bothEndsPassive)) {  // :625-634
+        stopCode = fire0 ? 4 : -4;
+        NdS = NdC = i + 1;
+        orbitLenSam_ = orbitLen_;
+        endIter = true;
+        break;
+      }
+      WoldSum += WnewSum;  // :641-648
+      orbitLenSam_ = orbitLen_;
+      NdS = NdC = i + 1;
+      if (fw) b += nleaf; else a -= nleaf;
+      i++;
+      if (i == M) { endIter = true; break; }
+    }
+    if (gone) break;
+    // ---- end of the iteration (:653-695) ----
+    {
+      double qP[NE];
+      vld(V_PROP + ip, qP);
+      emit_generated(iter, qP);  // samples[:,iterN] = generated(qc), qc = qProp
+      double d[NDIAG];
+      d[0] = L_; d[1] = NdS; d[2] = orbitLen_; d[3] = orbitLenSam_; d[4] = maxFint; d[5] = maxBint;
+      d[6] = nevalF; d[7] = 0;
+      d[8] = 0; d[9] = 0; d[10] = 0.0; d[11] = 0.0;
+      d[12] = bothEndsPassive ? 1.0 : 0.0;
+      d[13] = ((lwtSumb < WN_LOGZERO + 1.0) || (lwtSumf < WN_LOGZERO + 1.0)) ? 1.0 : 0.0;
+      d[14] = 0.0;
+      d[15] = Hc;
+      d[16] = 1.0;
+      d[17] = Hnan ? NAN : (Hmax - Hmin);
+      d[18] = prm.delta; d[19] = (double)stopCode; d[20] = NdC; d[21] = 0; d[22] = 0;
+      d[23] = indexStat_;
+      double vv = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < NDIAG; ++kk) vv = lane == kk ? d[kk] : vv;
+      if (lane < NDIAG) prm.diag[((size_t)clc * prm.numIter + (iter - 1)) * NDIAG + lane] = vv;
+    }
+    iter++;
+    if (iter > prm.numIter) live = false;
+  }
+  if (!gone) { i = 0; send(K_EXIT, 0, false, false); }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+size_t orbit2_work_doubles(int NE, int C, int M) { return (size_t)C * orbit2::wide_doubles(NE, M); }
+
+// plain sampling runs of fixedLeapFrog on the wide geometry (StockWatson); WN_ORBIT_ONEWAVE=1 keeps the one-wave form of wn_k_orbit.hip
+bool orbit2_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm) {
+  if (!orbit_eligible(kc, adapt, warm, prm) || !orbit_wide_geom(kc)) return false;
+  return prm.integrator == I_FIXED && !getenv("WN_ORBIT_ONEWAVE");
+}
+
+hipError_t launch_orbit2(const KernelChoice& kc, const Params& prm, int* kabort, hipStream_t st) {
+  (void)kc;
+  dim3 grid(prm.C), block(128);
+  hipLaunchKernelGGL((wn_orbit2_kernel<WTgtStockWatson<12>, 12>), grid, block, 0, st, prm, kabort);
+  return hipGetLastError();
+}
+
+}  // namespace wn
