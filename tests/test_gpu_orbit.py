@@ -39,6 +39,7 @@ def run_engine(wa, target, q0, iters, legacy=False, exact=True, seed=SEED, tpar=
     from walnuts_amd import _lib as L
     old = os.environ.pop("WN_ORBIT_LEGACY", None)
     os.environ["WN_ORBIT_WIDE_ADAPT"] = "1"  # (StockWatson: the adaptive integrators' plain runs stay on the one-stream engine by default)
+    os.environ["WN_ORBIT2_ADAPT"] = "1"
     if legacy:
         os.environ["WN_ORBIT_LEGACY"] = "1"
     if onewave:  # (StockWatson's fixedLeapFrog run: the one-wave form of the wide mode instead of wn_k_orbit2.hip's two waves)
@@ -56,6 +57,7 @@ def run_engine(wa, target, q0, iters, legacy=False, exact=True, seed=SEED, tpar=
         os.environ.pop("WN_ORBIT_LEGACY", None)
         os.environ.pop("WN_ORBIT_EXACT", None)
         os.environ.pop("WN_ORBIT_WIDE_ADAPT", None)
+        os.environ.pop("WN_ORBIT2_ADAPT", None)
         os.environ.pop("WN_ORBIT_ONEWAVE", None)
         if old is not None:
             os.environ["WN_ORBIT_LEGACY"] = old
@@ -191,13 +193,13 @@ SW_CASES = [
 ]
 
 
-SW_FORMS = [(c, w) for c in SW_CASES for w in ((False, True) if c[1] == ol.I_FIXED else (True,))]
+SW_FORMS = [(c, w) for c in SW_CASES for w in (False, True)]
 
 
 @pytest.mark.parametrize("case,onewave", SW_FORMS, ids=[f"T{c[0]}_integ{c[1]}_M{c[2]['M']}_{'one_wave' if w else 'two_waves'}" for c, w in SW_FORMS])
 def test_wide_orbit_kernel_equals_the_one_stream_engine_and_the_oracle(wa, case, onewave):
-    """The trajectory-first kernel's wide mode -- wn_orbit_kernel<stockwatson,NE=12,...> on one wave, and wn_orbit2_kernel (fixedLeapFrog:
-    trajectory and bookkeeping on a wave each; BASELINE config 5's fixedLeapFrog run) -- against the one-stream engine of the same layout
+    """The trajectory-first kernel's wide mode -- wn_orbit_kernel<stockwatson,NE=12,...> on one wave, and wn_orbit2_kernel (trajectory and
+    bookkeeping on a wave each: BASELINE config 5's plain sampling runs) -- against the one-stream engine of the same layout
     (WN_ORBIT_LEGACY=1: same micro-step arithmetic, same wave sums -- draws and diagnostics bit for bit for the adaptive integrators)
     and against the CPU oracle (integers exactly, reals to 1e-6)."""
     T, integ, kw, iters, rtol = case
@@ -231,12 +233,13 @@ def test_wide_orbit_kernel_generated_forms(wa, gen, gk):
     tpar = sw_tpar(T)
     q0 = 0.1 * np.random.default_rng(4).normal(size=(C, 3 * T))
     kw = dict(integrator=ol.I_ADAPT_D, H0=0.2, delta0=0.3, M=6, minC=1, generated=gen, gen_k=gk)
-    s_new, d_new, name = run_engine(wa, ol.T_STOCKWATSON, q0, iters, tpar=tpar, **kw)
-    assert "wn_orbit_kernel<stockwatson" in name, name
     s_old, d_old, _ = run_engine(wa, ol.T_STOCKWATSON, q0, iters, legacy=True, tpar=tpar, **kw)
-    assert same(d_new[..., INT_COLS], d_old[..., INT_COLS])
-    assert near(s_new, s_old, 1e-12), np.abs(s_new - s_old).max()
-    assert s_new.shape[-1] == (gk if gen == ol.G_FIRSTK else 2)
+    for onewave in (False, True):
+        s_new, d_new, name = run_engine(wa, ol.T_STOCKWATSON, q0, iters, tpar=tpar, onewave=onewave, **kw)
+        assert ("wn_orbit_kernel<stockwatson" if onewave else "wn_orbit2_kernel<stockwatson") in name, name
+        assert same(d_new[..., INT_COLS], d_old[..., INT_COLS])
+        assert near(s_new, s_old, 1e-12), np.abs(s_new - s_old).max()
+        assert s_new.shape[-1] == (gk if gen == ol.G_FIRSTK else 2)
 
 
 def test_two_wave_kernel_is_the_one_wave_kernel_bit_for_bit(wa):

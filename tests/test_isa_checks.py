@@ -74,10 +74,34 @@ def test_headline_kernel_warmup_instantiations_have_no_scratch(tmp_path):
 def test_orbit_kernel_has_no_flat_or_scratch_instructions(tmp_path):
     ks, meta = kernels_of("wn_k_orbit", tmp_path)
     hot = [k for k in ks if "wn_orbit_kernel" in k]
-    assert len(hot) >= 15  # five targets x three integrators
+    assert len(hot) >= 18  # five targets x three integrators + the wide mode (StockWatson, 12 registers per lane) x three
     for k in hot:
         assert not re.search(r"\bflat_(load|store|atomic)", ks[k]), k
-        assert not re.search(r"\bscratch_", ks[k]), k
+        # (the wide mode's adaptive instantiations hold three states of 36 doubles around a backward search: a few spills to scratch, measured
+        #  and not routed by default -- wn_k_orbit.hip orbit_wide_run; its fixedLeapFrog instantiation and every one-register one: none)
+        if "WTgtStockWatson" not in k or "EELi0ELb0ELi12EEEv" in k:
+            assert not re.search(r"\bscratch_", ks[k]), k
     for name, m in meta.items():
-        if "wn_orbit_kernel" in name:
+        if "wn_orbit_kernel" in name and "WTgtStockWatson" not in name:
             assert m["scratch"] == 0 and m["vgpr_spill"] == 0, (name, m)
+        if "wn_orbit_kernel" in name and "WTgtStockWatson" in name and "EELi0ELb0ELi12EEEv" in name:
+            assert m["scratch"] == 0, (name, m)
+
+
+@pytest.mark.timeout(900)
+def test_two_wave_orbit_kernel_hand_off_is_lds_and_scratch_free(tmp_path):
+    """wn_k_orbit2.hip (round 5: StockWatson's fixedLeapFrog run, trajectory and bookkeeping on a wave each): the hand-off words and the leaf
+    records are LDS-address-space accesses (a FLAT access there would wait on both counters and could be reordered against the fences),
+    and the default instantiation -- fixedLeapFrog -- keeps everything in registers."""
+    ks, meta = kernels_of("wn_k_orbit2", tmp_path)
+    hot = [k for k in ks if "wn_orbit2_kernel" in k]
+    assert len(hot) == 3, hot
+    for k in hot:
+        assert not re.search(r"\bflat_(load|store|atomic)", ks[k]), k
+        assert re.search(r"\bds_(read|write|load|store)", ks[k]), k
+    fixed = [k for k in hot if k.endswith("ELi12ELi0EEEvNS_6ParamsEPi")]
+    assert len(fixed) == 1, hot
+    assert not re.search(r"\bscratch_", ks[fixed[0]])
+    for name, m in meta.items():
+        if name.endswith("ELi12ELi0EEEvNS_6ParamsEPi"):
+            assert m["scratch"] == 0, (name, m)

@@ -523,8 +523,10 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
   if (e->cfg.warmup_iter == 0 && e->cfg.M >= 1 && orbit_wide_run(kc, e->cfg.integrator)) {
     // (round 5) StockWatson's plain sampling runs: the same kernel with vectors of 12 registers per lane
     snprintf(kc.name, sizeof(kc.name), "wn_orbit_kernel<stockwatson,NE=12,%s>", e->cfg.integrator == WN_I_FIXED ? "fixedLeapFrog" : e->cfg.integrator == WN_I_ADAPT_D ? "adaptLeapFrogD" : "adaptLeapFrogR2P");
-    // fixedLeapFrog: trajectory and bookkeeping on a wave each (wn_k_orbit2.hip)
-    if (e->cfg.integrator == WN_I_FIXED && !getenv("WN_ORBIT_ONEWAVE")) snprintf(kc.name, sizeof(kc.name), "wn_orbit2_kernel<stockwatson,NE=12,fixedLeapFrog>");
+  }
+  if (e->cfg.warmup_iter == 0 && e->cfg.M >= 1 && orbit2_run(kc, e->cfg.integrator)) {
+    // trajectory and bookkeeping on a wave each (wn_k_orbit2.hip)
+    snprintf(kc.name, sizeof(kc.name), "wn_orbit2_kernel<stockwatson,NE=12,%s>", e->cfg.integrator == WN_I_FIXED ? "fixedLeapFrog" : e->cfg.integrator == WN_I_ADAPT_D ? "adaptLeapFrogD" : "adaptLeapFrogR2P");
   }
   e->kc = kc;
   e->have_kc = true;
@@ -886,6 +888,15 @@ int wn_run(wn_engine* e, const double* q0_dev, uint64_t seed, int32_t n_iter, do
         else fprintf(stderr, "[WN_STAMPS fast4] R wave %d cycles/tick: wait for T=%.0f sums+verdicts=%.0f retire=%.0f message=%.0f\n",
                      w, a[5] / a[6], a[1] / a[6], a[2] / a[6], a[3] / a[6]);
       }
+      return rc;
+    }
+    if (strstr(e->kc.name, "wn_orbit2_kernel")) {  // two rows of 8 per chain: T wave, R wave
+      double t[8] = {0}, r[8] = {0};
+      for (int c = 0; c < p.C; ++c) for (int k = 0; k < 8; ++k) { t[k] += (double)h[((size_t)c * 2) * 8 + k]; r[k] += (double)h[((size_t)c * 2 + 1) * 8 + k]; }
+      fprintf(stderr, "[WN_STAMPS orbit2] T wave cycles/leaf: step+gradient+sums=%.0f publish+stores+abort poll=%.0f draws=%.0f wait for a command=%.0f wait for ring space=%.0f "
+              "command work + rest=%.0f (leaves %.0f)\n", t[0] / t[6], t[1] / t[6], t[5] / t[6], t[2] / t[6], t[3] / t[6], t[4] / t[6], t[6]);
+      fprintf(stderr, "[WN_STAMPS orbit2] R wave cycles/retired leaf: wait for leaves=%.0f draws+scans+ballots=%.0f checks=%.0f events+accumulators=%.0f rest=%.0f "
+              "(leaves %.0f, %.2f per sub-batch)\n", r[2] / r[6], r[0] / r[6], r[1] / r[6], r[3] / r[6], r[4] / r[6], r[6], r[6] / r[7]);
       return rc;
     }
     if (strstr(e->kc.name, "wn_orbit_kernel")) {  // one row per chain

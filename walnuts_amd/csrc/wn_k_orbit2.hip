@@ -31,17 +31,35 @@ namespace orbit2 {
 // the chain's workspace, in vectors of NE * 64 doubles: ring of 32 leaves (two blocks of 16)
 enum { V_RQ = 0, V_RV = 32, V_COLDQ = 64, V_COLDV = 65, V_COLDG = 66, V_PROP = 67, V_SLOT = 69 };
 __host__ __device__ constexpr size_t wide_doubles(int NE, int M) { return (size_t)(V_SLOT + 2 * (M + 1)) * NE * 64; }
-// LDS, in doubles: records of the ring's leaves [entry][Hn, lp], then the words of the hand-off
-enum { L_REC = 0, L_PROD = 64, L_CONS = 65, L_ABORT = 66, L_DEAD = 67, L_ACK = 68, L_KP = 69, L_CMD = 72, L_TOTAL = 80 };
+// LDS, in doubles: records of the ring's leaves [entry][Hn, lp, If | Ib << 8 | c << 16 | (nEvalF | nEvalB << 16) << 32, -], then the words of
+// the hand-off
+enum { L_REC = 0, L_PROD = 128, L_CONS = 129, L_ABORT = 130, L_DEAD = 131, L_ACK = 132, L_KP = 133, L_CMD = 136, L_TOTAL = 144 };
 enum { K_NEWITER = 1, K_GO = 2, K_REDO = 3, K_EXIT = 4 };
 typedef __attribute__((address_space(3))) double lds2_d;
 typedef __attribute__((address_space(3))) volatile unsigned long long lds_u64;
+// the R wave retires a sub-batch when this many leaves are there (or the block / the doubling / the T wave's run has ended): a sub-batch
+// has a fixed cost of ~2.5 k cycles (draws, scans, ballots) that a leaf at a time would make the R wave the slower of the two
+#ifndef WN_O2_BATCH
+#define WN_O2_BATCH 4
+#endif
+// diagnostic builds (-DWN_STAMPS): cycles per segment, summed per wave (no vmcnt wait: stores stay in flight as in the plain build)
+#if defined(WN_STAMPS)
+#define WN_O2STAMP(k)                                                                                   \
+  do {                                                                                                  \
+    unsigned long long _t;                                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                          \
+    o2st_[k] += _t - o2last_;                                                                           \
+    o2last_ = _t;                                                                                       \
+  } while (0)
+#else
+#define WN_O2STAMP(k) do {} while (0)
+#endif
 #ifndef WN_O2_SPINS
 #define WN_O2_SPINS (1u << 24)
 #endif
 }  // namespace orbit2
 
-template <class Tgt, int NE>
+template <class Tgt, int NE, int INTEG>
 __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort) {
   using namespace orbit;
   using namespace orbit2;
@@ -57,13 +75,15 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
   const int cl = blockIdx.x;
   const uint32_t cg = prm.chain0 + (uint32_t)cl;
   const uint32_t seedlo = (uint32_t)prm.seed, seedhi = (uint32_t)(prm.seed >> 32);
-  const int D = prm.D, M = prm.M;
+  const int D = prm.D, M = prm.M, minC = prm.minC, maxC = prm.maxC;
+  const double dlt = prm.delta;
+  constexpr uint32_t r_ = INTEG == I_ADAPT_R2P ? 1u : 0u;  // adaptLeapFrogR2P draws one uniform per macro step (adaptiveIntegrators.py:392)
   const bool inrange = cl < prm.C;
   const int clc = inrange ? cl : 0;
   const double Hc = prm.H;
   Tgt tgt;
   tgt.init(prm, lane, nullptr);
-  if (threadIdx.x < L_TOTAL) L[threadIdx.x] = 0.0;
+  for (int k = threadIdx.x; k < L_TOTAL; k += 128) L[k] = 0.0;
   __syncthreads();
 
 #define WN_OV(e) _Pragma("unroll") for (int e = 0; e < NE; ++e)
@@ -93,9 +113,9 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
   // ---- the draws of leaves k0 .. 15 of a block, lane-parallel (wn_k_orbit.hip): lane k (of every row) gets leaf k's step size and its
   // multinomial uniform.  `ku` = the stream index of the first draw of leaf k0, `khc` = the index of the second step size of a pair when
   // k0 is the pair's second leaf, `pred` = "every leaf takes its multinomial draw" ----
-  auto draws = [&](int i, int iter, int k0, uint32_t ku, uint32_t khc, bool pred, double& hV, double& upV) {
+  auto draws = [&](int i, int iter, int k0, uint32_t ku, uint32_t khc, bool pred, double& hV, double& urV, double& upV) {
     const uint32_t p_ = (pred && i != 0) ? 1u : 0u;
-    const uint32_t ce = (i != 0 ? 2u : 1u) + p_, co = p_;
+    const uint32_t ce = (i != 0 ? 2u : 1u) + r_ + p_, co = r_ + p_;
     const uint32_t klow = (k0 & 1) ? khc : ku;
     const uint32_t base = (uint32_t)uni_i((int)(klow >> 1));
     Philox4 r = philox4x32_10(base + (uint32_t)(lane >> 1), (uint32_t)iter, cg, 0u, seedlo, seedhi);
@@ -106,30 +126,46 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
     const bool evn = (i == 0) || !(j & 1u);
     uint32_t ih = evn ? kuS : kuS - ce + 1u;  // the second step size of the pair was drawn with the first
     ih = (j == (uint32_t)k0 && (k0 & 1)) ? khc : ih;
-    const uint32_t ipk = evn ? kuS + (i != 0 ? 2u : 1u) : kuS;
+    const uint32_t ir = evn ? kuS + (i != 0 ? 2u : 1u) : kuS;
+    const uint32_t ipk = ir + r_;
     const uint32_t off = 2u * base;
     const double uh = __shfl(ru0, (int)((ih - off) & 63u)), up = __shfl(ru0, (int)((ipk - off) & 63u));
+    urV = r_ ? __shfl(ru0, (int)((ir - off) & 63u)) : 0.0;
     const double low = Hc * (1 - prm.s), high = Hc * (1 + prm.s);
     hV = low + (high - low) * uh;  // numpy legacy uniform(low, high) = low + (high-low)*U  (WALNUTS.py:298,395)
     upV = up;
   };
   // the stream index behind the leaves [k0, k1) of a block when every one of them does what `pred` says
   auto ku_behind = [&](int i, int k0, int k1, uint32_t ku, bool pred) -> uint32_t {
-    if (i == 0) return ku + 1u;
+    if (i == 0) return ku + 1u + r_;
     const uint32_t p_ = pred ? 1u : 0u;
     const uint32_t nE = (((uint32_t)k1 + 1u) >> 1) - (((uint32_t)k0 + 1u) >> 1), nO = ((uint32_t)k1 >> 1) - ((uint32_t)k0 >> 1);
-    return ku + (2u + p_) * nE + p_ * nO;
+    return ku + (2u + r_ + p_) * nE + (r_ + p_) * nO;
   };
 
+  unsigned long long o2st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o2last_ = __builtin_readcyclecounter();
+  (void)o2st_; (void)o2last_;
+  auto stamps_out = [&]() {
+#if defined(WN_STAMPS)
+    if (prm.stamps && lane == 0) {
+      unsigned long long* o = prm.stamps + ((size_t)blockIdx.x * 2 + role) * 8;
+      for (int k = 0; k < 8; ++k) o[k] = o2st_[k];
+    }
+#endif
+  };
   if (role == 0) {
     // =====================================================================================================================
     // T wave: the trajectory
     // =====================================================================================================================
-    double qa[NE], va[NE], ga[NE];
-    WN_OV(e) { qa[e] = 0.0; va[e] = 0.0; ga[e] = 0.0; }
+    // active end of the orbit: q, g, and vi = xi * v (the integrator's orientation: xi is the same for every leaf of a run)
+    double qa[NE], vi[NE], ga[NE];
+    WN_OV(e) { qa[e] = 0.0; vi[e] = 0.0; ga[e] = 0.0; }
+    int xi_run = 1;  // the orientation vi is in
+    double Ha = 0.0;  // energy at the active end (the adaptive integrators' Ham0)
     uint32_t seq = 0;
     for (;;) {
       ++seq;
+      WN_O2STAMP(4);
       // ---- wait for command `seq` ----
       unsigned long long w0 = 0;
       {
@@ -144,6 +180,7 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
       }
       if (dead()) break;
       acquire();
+      WN_O2STAMP(2);
       const int kind = (int)(uint32_t)w0;
       if (kind == K_EXIT) break;
       const unsigned long long w1 = LU[L_CMD + 1], w2 = LU[L_CMD + 2], w3 = LU[L_CMD + 3], w4 = LU[L_CMD + 4];
@@ -153,11 +190,15 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
       uint32_t ku = (uint32_t)w3, khc = (uint32_t)(w3 >> 32);
       const bool pred = ((uint32_t)w4 & 1u) != 0u, swap = ((uint32_t)w4 & 2u) != 0u;
       const int xi = (int)(uint32_t)(w4 >> 32);
+      const double lpP_c = L[L_CMD + 5];
+      Ha = L[L_CMD + 6];
       if (kind == K_NEWITER) {
         vld(V_PROP + ip, qa);
         double lpp = tgt.grad(qa, ga, lane);  // f0, grad0 = lpFun(qc)  (WALNUTS.py:249); the R wave holds its value
         (void)lpp;
         // :236  v = normal(size=d)  (rolled: one copy of Philox + Box-Muller in the code; the register is picked with selects)
+        double va[NE];
+        WN_OV(e) va[e] = 0.0;
 #pragma unroll 1
         for (int e1 = 0; e1 < NE; ++e1) {
           int gi = -1;
@@ -168,20 +209,26 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
         vst(V_COLDQ, qa); vst(V_COLDV, va); vst(V_COLDG, ga);
         double kp = 0.0;
         WN_OV(e) kp += va[e] * va[e];
+        WN_OV(e) vi[e] = (double)xi * va[e];
+        xi_run = xi;
         double gp = 0.0;
         reduce2(kp, gp);
+        Ha = -lpP_c + 0.5 * kp;  // Hs[I0] = -f0 + 0.5*sum(v**2)  (:256): the R wave forms the same expression from the same two numbers
         L[L_KP] = kp;
         release();
         LU[L_ACK] = (unsigned long long)seq;
       } else if (kind == K_GO) {
-        if (swap) {  // the other end of the orbit becomes the active one (:283-294)
-          double tq[NE], tv[NE], tg[NE];
+        if (swap) {  // the other end of the orbit becomes the active one (:283-294); stored velocities are in forward-time orientation
+          double tq[NE], tv[NE], tg[NE], va[NE];
           vld(V_COLDQ, tq); vld(V_COLDV, tv); vld(V_COLDG, tg);
+          WN_OV(e) va[e] = (double)xi_run * vi[e];
           vst(V_COLDQ, qa); vst(V_COLDV, va); vst(V_COLDG, ga);
-          WN_OV(e) { qa[e] = tq[e]; va[e] = tv[e]; ga[e] = tg[e]; }
+          WN_OV(e) { qa[e] = tq[e]; vi[e] = (double)xi * tv[e]; ga[e] = tg[e]; }
+          xi_run = xi;
         }
       } else {  // K_REDO: restart behind leaf n - 1, whose state is in the ring
-        vld(V_RQ + ((n - 1) & 31), qa); vld(V_RV + ((n - 1) & 31), va);
+        vld(V_RQ + ((n - 1) & 31), qa); vld(V_RV + ((n - 1) & 31), vi);  // (the ring holds xi * v; a restart stays inside its doubling)
+        xi_run = xi;
         double lpp = tgt.grad(qa, ga, lane);
         (void)lpp;
       }
@@ -191,6 +238,7 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
       while (n < nleaf && !stop) {
         const int nb0 = n & ~15, k0 = n & 15;
         const int k1 = nleaf - nb0 < 16 ? nleaf - nb0 : 16;
+        WN_O2STAMP(4);
         if (k0 == 0 && n >= 32) {  // the ring entries of block (n >> 4) - 2 are about to be overwritten: the R wave must be through with it
           release();
           LU[L_PROD] = ((unsigned long long)seq << 32) | (unsigned)n;
@@ -202,40 +250,136 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
           }
           if (stop) break;
         }
-        double hV, upV;
-        draws(i, iter, k0, ku, khc, pred, hV, upV);
-        (void)upV;
+        WN_O2STAMP(3);
+        double hV, urV, upV;
+        draws(i, iter, k0, ku, khc, pred, hV, urV, upV);
+        (void)upV; (void)urV;
+        WN_O2STAMP(5);
+        if constexpr (INTEG != I_FIXED) {
+          // ---- adaptLeapFrogD / adaptLeapFrogR2P (adaptiveIntegrators.py:65-137 / 361-475): a macro step is 2**minC .. evaluations, so each
+          // leaf is published at once (the fence waits for its stores: ~1 k cycles of ~100 k) and the abort word is read at every pass --
+          // the R wave answers a leaf within ~3 k cycles, a draw that was not taken as assumed costs one pass, not the macro steps behind it
+          bool aborted = false;
+          double hcur = 0.0;
+          auto run_pass = [&](const double* qs, const double* vs, const double* gs, double HamStart, int cc, double* q, double* v, double* g, double& lpC,
+                              double& HC, int& nev) -> bool {
+            WN_OV(e) { q[e] = qs[e]; v[e] = vs[e]; g[e] = gs[e]; }
+            if (aborted || (uint32_t)LU[L_ABORT] == seq) { aborted = true; lpC = 0.0; HC = HamStart; return true; }
+            const double hh = ldexp(hcur, -cc);  // h / 2**c (exact scaling either way)
+            const int nstep = 1 << cc;
+            bool allfin = isfinite(HamStart);
+            const double hh2 = 0.5 * hh, hq = hh;
+            int st = nstep;
+#pragma unroll 1
+            do {  // one branch per micro step
+              WN_OV(e) { v[e] = v[e] + hh2 * g[e]; q[e] = q[e] + hq * v[e]; }
+              double lpp = tgt.grad(q, g, lane);
+              double ke = 0.0;
+              WN_OV(e) { v[e] = v[e] + hh2 * g[e]; ke += v[e] * v[e]; }
+              reduce2(lpp, ke);
+              lpp = Tgt::lp_finish(lpp);
+              const double Hi = -lpp + 0.5 * ke;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
+              lpC = lpp; HC = Hi;
+              allfin = allfin && isfinite(Hi);
+            } while (--st);
+            nev += nstep;
+            return uni_b(allfin && (fabs(HamStart - HC) < dlt));  // all(isfinite(Hams)) and abs(Hams[0]-Hams[-1]) < delta  (:87-94)
+          };
+#pragma unroll 1
+          for (int k = k0; k < k1; ++k) {
+            hcur = wn_readlane(hV, k);
+            const double Ham0 = Ha;  // Hs[] of the neighbouring stored index = energy at the active end (WALNUTS.py:302,400,443,487,530)
+            int nEvF = 0, nEvB = 0, If, Ib, cret;
+            double lpn, Hn;
+            double qw[NE], vw[NE], gw[NE], lpC, HC;
+            int cc = minC;  // forward search (:69-94 / 366-389)
+            bool ok = run_pass(qa, vi, ga, Ham0, cc, qw, vw, gw, lpC, HC, nEvF);
+            if (__builtin_expect(!ok && cc < maxC, 0)) {
+              do {
+                ++cc;
+                ok = run_pass(qa, vi, ga, Ham0, cc, qw, vw, gw, lpC, HC, nEvF);
+              } while (!ok && cc < maxC);
+            }
+            If = ok ? cc : maxC;  // Q5: the last computed state is used silently
+            // adaptLeapFrogR2P :392: with probability R2Pprob0 keep c = If, else re-integrate at c = If+1
+            const bool keep = INTEG != I_ADAPT_R2P || uni_b(wn_readlane(urV, k) < prm.R2Pprob0);
+            int cSim = If, maxTry = If - 1;
+            Ib = If;
+            lpn = lpC; Hn = HC;
+            if (!keep || maxTry >= minC) {
+              if (!keep) {  // :400-424, 434-437
+                run_pass(qa, vi, ga, Ham0, If + 1, qw, vw, gw, lpC, HC, nEvF);
+                cSim = If + 1; maxTry = maxC; Ib = maxC;
+                lpn = lpC; Hn = HC;
+              }
+              if (maxTry >= minC) {  // backward search from (qOut, -vOut, gOut)  (:107-132 / 440-464)
+                double qo[NE], vo[NE], go[NE], vneg[NE];
+                WN_OV(e) { qo[e] = qw[e]; vo[e] = vw[e]; go[e] = gw[e]; vneg[e] = -vw[e]; }
+                double lpB, HB;
+                for (cc = minC;; ++cc) {
+                  ok = run_pass(qo, vneg, go, Hn, cc, qw, vw, gw, lpB, HB, nEvB);
+                  if (ok) { Ib = cc; break; }
+                  if (cc >= maxTry) break;
+                }
+                WN_OV(e) { qw[e] = qo[e]; vw[e] = vo[e]; gw[e] = go[e]; }
+              }
+            }
+            cret = INTEG == I_ADAPT_R2P ? cSim : If;  // :135-137 / 466-475 (lwt follows from If, Ib, c: the R wave forms it)
+            if (aborted) { stop = true; break; }
+            WN_OV(e) { qa[e] = qw[e]; vi[e] = vw[e]; ga[e] = gw[e]; }
+            Ha = Hn;
+            WN_O2STAMP(0);
+            const int ent = (nb0 + k) & 31;
+            vst(V_RQ + ent, qa); vst(V_RV + ent, vi);  // (the ring holds xi * v: intOut.v (:135, :473) is formed by the R wave)
+            L[L_REC + 4 * ent] = Hn; L[L_REC + 4 * ent + 1] = lpn;
+            LU[L_REC + 4 * ent + 2] = ((unsigned long long)(uint32_t)(nEvF | (nEvB << 16)) << 32) | (uint32_t)(If | (Ib << 8) | (cret << 16));
+            n = nb0 + k + 1;
+            o2st_[6] += 1;
+            release();
+            LU[L_PROD] = ((unsigned long long)seq << 32) | (unsigned)n;
+            if (!uni_b(isfinite(Hn))) { stop = true; break; }  // forced reject (:316-319)
+            WN_O2STAMP(1);
+          }
+        } else
 #pragma unroll 1
         for (int k = k0; k < k1; ++k) {
           const double hh = wn_readlane(hV, k);
           const double hh2 = 0.5 * hh, hq = hh;
-          // fixedLeapFrog (adaptiveIntegrators.py:49-59) from (q, xi*v, g); intOut.v is in forward-time orientation (:57)
-          double vw[NE];
-          WN_OV(e) vw[e] = (double)xi * va[e];
-          WN_OV(e) { vw[e] = vw[e] + hh2 * ga[e]; qa[e] = qa[e] + hq * vw[e]; }
+          // fixedLeapFrog (adaptiveIntegrators.py:49-59) from (q, xi*v, g): `vi` IS xi*v for the whole run
+          WN_OV(e) { vi[e] = vi[e] + hh2 * ga[e]; qa[e] = qa[e] + hq * vi[e]; }
+          // the new position goes to the ring HERE, a whole gradient in front of the velocity: two bursts of 6 KB instead of one of 12
+          // (one burst: 490 cycles per leaf, two: tools/sw_nostore_ab.sh); the count word is published behind the NEXT leaf's gradient
+          const int ent = (nb0 + k) & 31;
+          vst(V_RQ + ent, qa);
           double lpp = tgt.grad(qa, ga, lane);
           double ke = 0.0;
-          WN_OV(e) { vw[e] = vw[e] + hh2 * ga[e]; ke += vw[e] * vw[e]; }
+          WN_OV(e) { vi[e] = vi[e] + hh2 * ga[e]; ke += vi[e] * vi[e]; }
           reduce2(lpp, ke);
           lpp = Tgt::lp_finish(lpp);
           const double Hn = -lpp + 0.5 * ke;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
-          WN_OV(e) va[e] = (double)xi * vw[e];
-          // publish the leaves in front of this one (their stores were issued a whole evaluation ago), then store this one
-          release();
-          LU[L_PROD] = ((unsigned long long)seq << 32) | (unsigned)(nb0 + k);
-          const int ent = (nb0 + k) & 31;
-          vst(V_RQ + ent, qa); vst(V_RV + ent, va);
-          if (lane == 0) { L[L_REC + 2 * ent] = Hn; L[L_REC + 2 * ent + 1] = lpp; }
+          WN_O2STAMP(0);
+          // every fourth leaf: publish the leaves in front of this one (their stores were issued at least a whole evaluation ago: the
+          // release fence does not wait), and look at the abort word -- the R wave has seen an event inside the doubling
+          if ((k & 3) == 0) {
+            release();
+            LU[L_PROD] = ((unsigned long long)seq << 32) | (unsigned)(nb0 + k);
+            if ((uint32_t)LU[L_ABORT] == seq) { stop = true; break; }
+          }
+          // (the ring holds xi * v, the integrator's orientation: intOut.v = xi * vv (adaptiveIntegrators.py:57) is formed by the R wave)
+          vst(V_RV + ent, vi);
+          L[L_REC + 4 * ent] = Hn; L[L_REC + 4 * ent + 1] = lpp;  // (every lane stores the same two words: no exec-mask region)
           n = nb0 + k + 1;
-          // forced reject (:316-319): nothing behind a non-finite energy will be used; the R wave has raised the abort word: an event
-          // inside the doubling
-          if (!uni_b(isfinite(Hn)) || (uint32_t)LU[L_ABORT] == seq) { stop = true; break; }
+          o2st_[6] += 1;
+          // forced reject (:316-319): nothing behind a non-finite energy will be used
+          if (!uni_b(isfinite(Hn))) { stop = true; break; }
+          WN_O2STAMP(1);
         }
         ku = ku_behind(i, k0, k1, ku, pred);
       }
       release();
-      LU[L_PROD] = ((unsigned long long)seq << 32) | (unsigned)n;
+      LU[L_PROD] = ((unsigned long long)seq << 32) | 0x80000000u | (unsigned)n;  // (bit 31: the run has ended)
     }
+    stamps_out();
     return;
   }
 
@@ -257,10 +401,11 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
 
   double H0 = 0.0, Ha = 0.0, Hb = 0.0, lp0, WoldSum = 1.0, WnewSum = 0.0, lwtSumf = 0.0, lwtSumb = 0.0;
   double orbitLen_ = 0.0, orbitLenSam_ = 0.0, indexStat_ = 0.0, indexStatOld_ = 0.0, timeLenF_ = 0.0, timeLenB_ = 0.0;
-  double Hmin = INFINITY, Hmax = -INFINITY, lpP = 0.0, lpPL = 0.0;
+  double minlw = INFINITY, maxlw = -INFINITY, Hmin = INFINITY, Hmax = -INFINITY, lpP = 0.0, lpPL = 0.0;
   int iter = 1, i = 0, xi = 1, a = 0, b = 0, n = 0, nleaf = 1;
   uint32_t Bbits = 0, ku = 0, khc = 0;
-  int nevalF = 0, L_ = 0, Lold_ = 0, NdS = 0, NdC = 0, maxFint = 0, maxBint = 0, stopCode = 0;
+  int nevalF = 0, nevalB = 0, L_ = 0, Lold_ = 0, NdS = 0, NdC = 0, maxFint = 0, maxBint = 0, stopCode = 0;
+  int minIf = 1 << 30, maxIf = -(1 << 30), minc = 1 << 30, maxc = -(1 << 30), nneq = 0, nzero = 0, nused = 0;
   int ip = 0, ipl = 0;
   bool Hnan = false, bothEndsPassive = false;
   bool predF = true, predB = true;  // "the next leaf in this direction takes its multinomial draw"
@@ -274,6 +419,7 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
     LU[L_CMD + 2] = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)n_;
     LU[L_CMD + 3] = ((unsigned long long)khc << 32) | ku;
     LU[L_CMD + 4] = ((unsigned long long)(uint32_t)xi << 32) | (pred_ ? 1u : 0u) | (swap_ ? 2u : 0u);
+    L[L_CMD + 5] = lpP; L[L_CMD + 6] = Ha;
     release();
     LU[L_CMD] = ((unsigned long long)seq << 32) | (uint32_t)kind;
   };
@@ -318,8 +464,10 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
     send(K_NEWITER, 0, xi > 0 ? predF : predB, false);
     WoldSum = 1.0; WnewSum = 0.0; lwtSumb = 0.0; lwtSumf = 0.0;  // :260-264
     stopCode = 0; bothEndsPassive = false;
-    nevalF = 0; Lold_ = L_ = 0; orbitLen_ = orbitLenSam_ = 0.0; NdS = NdC = 0;
+    nevalF = nevalB = 0; Lold_ = L_ = 0; orbitLen_ = orbitLenSam_ = 0.0; NdS = NdC = 0;
     indexStat_ = indexStatOld_ = 0.0; timeLenF_ = timeLenB_ = 0.0;
+    minIf = minc = 1 << 30; maxIf = maxc = -(1 << 30); nneq = nzero = nused = 0;
+    minlw = INFINITY; maxlw = -INFINITY;
     {  // the T wave's momentum: Hs[I0] = -f0 + 0.5*sum(v**2)  (:256); multinomialLscale (:259)
       unsigned spins = 0;
       while ((uint32_t)LU[L_ACK] != seq) {
@@ -359,13 +507,17 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
         const int nb0 = n & ~15;
         const int k0 = n & 15;
         int k1;
+        WN_O2STAMP(4);
         {  // what the T wave has published of this run
           unsigned spins = 0;
           int npub = 0;
+          const int blk_end = nleaf - nb0 < 16 ? nleaf : nb0 + 16;
+          const int want = n + WN_O2_BATCH < blk_end ? n + WN_O2_BATCH : blk_end;
           for (;;) {
             const unsigned long long w = LU[L_PROD];
-            npub = (uint32_t)(w >> 32) == seq ? (int)(uint32_t)w : 0;
-            if (npub > n) break;
+            const bool mine = (uint32_t)(w >> 32) == seq;
+            npub = mine ? (int)((uint32_t)w & 0x7FFFFFFFu) : 0;
+            if (npub >= want || (mine && ((uint32_t)w & 0x80000000u) && npub > n)) break;
             if (dead()) { gone = true; break; }
             if (++spins > WN_O2_SPINS) { give_up(); gone = true; break; }
             __builtin_amdgcn_s_sleep(1);
@@ -375,23 +527,39 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
           npub = uni_i(npub);
           k1 = npub - nb0 < 16 ? npub - nb0 : 16;
         }
+        WN_O2STAMP(2);
         const int rb = nb0 & 16;  // the block's half of the ring
         // the draws of leaves k0 .. k1-1 as the reference makes them, from the stream index the bookkeeping has reached
-        double hV, upV;
-        draws(i, iter, k0, ku, khc, predRun, hV, upV);
+        double hV, urV, upV;
+        draws(i, iter, k0, ku, khc, predRun, hV, urV, upV);
+        (void)urV;
         // left endpoint of the sub-trees of 2**j leaves, j >= 5, that start at this block's first leaf (levels 1..4 stay inside the ring)
         if (k0 == 0 && (nb0 == 0 ? i >= 5 : __builtin_ctz((unsigned)nb0) >= 5)) {
           const int sl = nb0 == 0 ? 0 : __builtin_ctz((unsigned)nb0);
           double tq[NE], tv[NE];
           vld(V_RQ + rb, tq); vld(V_RV + rb, tv);
+          WN_OV(e) tv[e] = (double)xi * tv[e];  // (ring: xi * v; slots and the passive end: v in forward-time orientation)
           vst(V_SLOT + 2 * sl, tq); vst(V_SLOT + 2 * sl + 1, tv);
         }
         // =========================== bookkeeping of leaves k0 .. k1-1, lane k = leaf k ===========================
         const int k = k16;
         const bool inb = k >= k0 && k < k1;
-        const double Hn_k = L[L_REC + 2 * (rb + k)], lp_k = L[L_REC + 2 * (rb + k) + 1];
+        const double Hn_k = L[L_REC + 4 * (rb + k)], lp_k = L[L_REC + 4 * (rb + k) + 1];
         const double h_k = hV, up_k = upV;
-        const double lw_k = 0.0;  // fixedLeapFrog: lwt = 0  (adaptiveIntegrators.py:57-59)
+        int iA = 0, iB = 1;  // If | Ib << 8 | c << 16;  nEvalF | nEvalB << 16  (fixedLeapFrog: 0, one evaluation)
+        if constexpr (INTEG != I_FIXED) {
+          const unsigned long long rr = LU[L_REC + 4 * (rb + k) + 2];
+          iA = (int)(uint32_t)rr; iB = (int)(uint32_t)(rr >> 32);
+        }
+        const int If_k = iA & 255, Ib_k = (iA >> 8) & 255, c_k = iA >> 16, ef_k = iB & 0xFFFF, eb_k = iB >> 16;
+        double lw_k;  // lwt of the macro step (adaptiveIntegrators.py:57-59 / 135-137 / 466-475)
+        if (INTEG == I_ADAPT_R2P) {
+          const double lwtf = c_k == If_k ? prm.logP : prm.log1mP;
+          const double lwtb = c_k == Ib_k ? prm.logP : (c_k == Ib_k + 1 ? prm.log1mP : WN_LOGZERO);
+          lw_k = lwtb - lwtf;
+        } else if (INTEG == I_ADAPT_D) {
+          lw_k = (If_k != Ib_k) ? WN_LOGZERO : 0.0;
+        } else lw_k = 0.0;
         const int nk = nb0 + k;
         const bool first_k = (i == 0) || !(nk & 1);
         const int nbat = k1 - k0;
@@ -428,6 +596,7 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
         const uint64_t m_pk = __ballot(inb0 && pick_k);
         const uint64_t m_bad = (i != 0) ? ((predRun ? ~m_dr : m_dr) & m_in) : 0ull;
 
+        WN_O2STAMP(0);
         // ---- U-turn checks (stopCondition, WALNUTS.py:95-97, with the older state on the side opposite to xi): wave-wide dots, the
         // loads of the next check in flight while this one is summed (wn_k_orbit.hip, wide mode) ----
         uint64_t m_fire = 0ull;  // leaves at which a sub-tree check fired
@@ -460,11 +629,14 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
             vld(V_RQ + rb + c.r, qr); vld(V_RV + rb + c.r, vr); vld(lq, ql); vld(lv, vl);
           };
           auto sum_up = [&](const Chk& c, const double* qr, const double* vr, const double* ql, const double* vl) {
+            // (ring entries hold xi * v: the right state always, the left one of levels 1..4; +-1 is exact, the products are the one-stream engine's)
+            const double sr = (double)xi, sl_ = (c.lvl >= 1 && c.lvl <= 4) ? (double)xi : 1.0;
             double a1 = 0.0, a2 = 0.0;
             WN_OV(e) {
               const double dq = qr[e] - ql[e];
-              a1 += vr[e] * dq;
-              a2 += vl[e] * dq;
+              const double vrf = sr * vr[e], vlf = sl_ * vl[e];
+              a1 += vrf * dq;
+              a2 += vlf * dq;
             }
             reduce2(a1, a2);
             const bool fire = ((double)xi * a1 < 0.0) || ((double)xi * a2 < 0.0);
@@ -489,6 +661,7 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
             }
           }
         }
+        WN_O2STAMP(1);
         // ---- the first event decides how many leaves of the batch stand ----
         const int t_nf = m_nf ? __builtin_ctzll(m_nf) : 64;
         const int t_sub = m_fire ? __builtin_ctzll(m_fire) : 64;
@@ -510,10 +683,23 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
         // ---- accumulators over leaves k0 .. A_end ----
         {
           const bool macc = inb && k <= A_end;
-          nevalF += A_end - k0 + 1;  // one evaluation per leaf
-          double d4 = row == 2 ? Hn_k : -Hn_k;
-          d4 = rowmin_d((macc && row >= 2) ? d4 : INFINITY);
-          const double b2 = wn_readlane(d4, 32), b3 = -wn_readlane(d4, 48);
+          if constexpr (INTEG == I_FIXED) {
+            nevalF += A_end - k0 + 1;  // one evaluation per leaf
+          } else {
+            // nevalF, nevalB, #(If != Ib), #(If == 0): four rows of one register
+            int v4 = row == 0 ? ef_k : row == 1 ? eb_k : row == 2 ? (int)(If_k != Ib_k) : (int)(If_k == 0);
+            v4 = rowsum_i(macc ? v4 : 0);
+            nevalF += rl_i(v4, 0); nevalB += rl_i(v4, 16); nneq += rl_i(v4, 32); nzero += rl_i(v4, 48);
+            nused += A_end - k0 + 1;
+            int m4 = row == 0 ? If_k : row == 1 ? c_k : row == 2 ? -If_k : -c_k;
+            m4 = rowmin_i(macc ? m4 : (1 << 30));
+            const int a0 = rl_i(m4, 0), a1 = rl_i(m4, 16), a2 = -rl_i(m4, 32), a3 = -rl_i(m4, 48);
+            minIf = a0 < minIf ? a0 : minIf; minc = a1 < minc ? a1 : minc; maxIf = a2 > maxIf ? a2 : maxIf; maxc = a3 > maxc ? a3 : maxc;
+          }
+          double d4 = row == 0 ? lw_k : row == 1 ? -lw_k : row == 2 ? Hn_k : -Hn_k;
+          d4 = rowmin_d(macc ? d4 : INFINITY);
+          const double b0 = wn_readlane(d4, 0), b1 = -wn_readlane(d4, 16), b2 = wn_readlane(d4, 32), b3 = -wn_readlane(d4, 48);
+          minlw = b0 < minlw ? b0 : minlw; maxlw = b1 > maxlw ? b1 : maxlw;
           Hmin = b2 < Hmin ? b2 : Hmin; Hmax = b3 > Hmax ? b3 : Hmax;
           if (__ballot(macc && lane < 16 && isnan(Hn_k))) Hnan = true;
           const double tl = wn_readlane(P1, 16 + A_end);
@@ -542,20 +728,22 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
               const uint64_t rng = m_in & ((2ull << Lfull) - 1ull);
               // leaves with an even index drew the pair's two step sizes
               const uint64_t evn = (nb0 & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
-              ku += 2u * (uint32_t)__builtin_popcountll(rng & evn) + (uint32_t)__builtin_popcountll(rng & m_dr);
+              ku += 2u * (uint32_t)__builtin_popcountll(rng & evn) + r_ * (uint32_t)__builtin_popcountll(rng) + (uint32_t)__builtin_popcountll(rng & m_dr);
               const bool dl = (m_dr >> Lfull) & 1ull;
               if (fw) predF = dl; else predB = dl;
               // the second step size of a pair was drawn with the first (:395): its index, for a sub-batch that starts at the pair's second leaf
-              khc = ku - 1u - (uint32_t)dl;
+              khc = ku - 1u - r_ - (uint32_t)dl;
             } else {
-              ku += 1u;
+              ku += 1u + r_;
             }
             Ha = wn_readlane(Hn_k, Lfull);
           }
         }
         if (f0_now && !end_nf && !end_sub && !redo) fire0 = true;
+        o2st_[6] += (unsigned long long)(Lfull + 1 - k0); o2st_[7] += 1;
         n = nb0 + Lfull + 1;
         LU[L_CONS] = (unsigned long long)(unsigned)n;
+        WN_O2STAMP(3);
         if (end_nf) {  // :316-319, 414-417, 457-459 (Q3, Q4)
           const bool first_e = (i == 0) || !((nb0 + t_ev) & 1);
           if (first_e) stopCode = 999;
@@ -604,15 +792,16 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
       emit_generated(iter, qP);  // samples[:,iterN] = generated(qc), qc = qProp
       double d[NDIAG];
       d[0] = L_; d[1] = NdS; d[2] = orbitLen_; d[3] = orbitLenSam_; d[4] = maxFint; d[5] = maxBint;
-      d[6] = nevalF; d[7] = 0;
-      d[8] = 0; d[9] = 0; d[10] = 0.0; d[11] = 0.0;
+      d[6] = nevalF; d[7] = nevalB;
+      const bool AD = INTEG != I_FIXED;
+      d[8] = AD ? minIf : 0; d[9] = AD ? maxIf : 0; d[10] = AD ? minlw : 0.0; d[11] = AD ? maxlw : 0.0;
       d[12] = bothEndsPassive ? 1.0 : 0.0;
       d[13] = ((lwtSumb < WN_LOGZERO + 1.0) || (lwtSumf < WN_LOGZERO + 1.0)) ? 1.0 : 0.0;
-      d[14] = 0.0;
+      d[14] = AD ? (double)nneq / (double)nused : 0.0;
       d[15] = Hc;
-      d[16] = 1.0;
+      d[16] = AD ? (double)nzero / (double)nused : 1.0;
       d[17] = Hnan ? NAN : (Hmax - Hmin);
-      d[18] = prm.delta; d[19] = (double)stopCode; d[20] = NdC; d[21] = 0; d[22] = 0;
+      d[18] = dlt; d[19] = (double)stopCode; d[20] = NdC; d[21] = AD ? minc : 0; d[22] = AD ? maxc : 0;
       d[23] = indexStat_;
       double vv = 0.0;
 #pragma unroll
@@ -623,21 +812,35 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
     if (iter > prm.numIter) live = false;
   }
   if (!gone) { i = 0; send(K_EXIT, 0, false, false); }
+  stamps_out();
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
 size_t orbit2_work_doubles(int NE, int C, int M) { return (size_t)C * orbit2::wide_doubles(NE, M); }
 
-// plain sampling runs of fixedLeapFrog on the wide geometry (StockWatson); WN_ORBIT_ONEWAVE=1 keeps the one-wave form of wn_k_orbit.hip
+// Plain sampling runs of fixedLeapFrog on the wide geometry (StockWatson): 8.1e7 -> 1.2e8 evaluations/s.  WN_ORBIT_ONEWAVE=1 keeps the
+// one-wave form (wn_k_orbit.hip's wide mode), WN_ORBIT_LEGACY=1 the one-stream engine.  The adaptive integrators run here too
+// (WN_ORBIT2_ADAPT=1; tests/test_gpu_orbit.py: bit for bit with the one-stream engine) but stay on that engine by default: their macro
+// step is ~26 evaluations on this target (minC = 3 and refinements), its bookkeeping 3 % of it -- nothing to hide behind a second wave --
+// and the first leaves of a doubling often have weight zero (If != Ib), so "every leaf takes its draw like the one before" fails twice
+// per doubling and the T wave has run a ~100 k-cycle leaf ahead each time: 7.3e7 against the engine's 9.1e7 (adaptLeapFrogD).
+bool orbit2_run(const KernelChoice& kc, int integrator) {
+  if (!orbit_wide_geom(kc) || getenv("WN_ORBIT_LEGACY") || getenv("WN_ORBIT_NOWIDE") || getenv("WN_ORBIT_ONEWAVE")) return false;
+  return integrator == I_FIXED || ((integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && getenv("WN_ORBIT2_ADAPT"));
+}
 bool orbit2_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm) {
-  if (!orbit_eligible(kc, adapt, warm, prm) || !orbit_wide_geom(kc)) return false;
-  return prm.integrator == I_FIXED && !getenv("WN_ORBIT_ONEWAVE");
+  if (!orbit2_run(kc, prm.integrator)) return false;
+  if (warm || prm.mode != MODE_SAMPLE || prm.trace_n || prm.trace || prm.omin || adapt == 2) return false;
+  if (prm.M < 1 || prm.M > MAX_M || prm.maxC > 12 || prm.minC < 0 || prm.minC > prm.maxC) return false;
+  return prm.generated == G_IDENTITY || prm.generated == G_FIRSTK || prm.generated == G_Q0_SUMSQ;
 }
 
 hipError_t launch_orbit2(const KernelChoice& kc, const Params& prm, int* kabort, hipStream_t st) {
   (void)kc;
   dim3 grid(prm.C), block(128);
-  hipLaunchKernelGGL((wn_orbit2_kernel<WTgtStockWatson<12>, 12>), grid, block, 0, st, prm, kabort);
+  if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit2_kernel<WTgtStockWatson<12>, 12, I_ADAPT_R2P>), grid, block, 0, st, prm, kabort);
+  else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit2_kernel<WTgtStockWatson<12>, 12, I_ADAPT_D>), grid, block, 0, st, prm, kabort);
+  else hipLaunchKernelGGL((wn_orbit2_kernel<WTgtStockWatson<12>, 12, I_FIXED>), grid, block, 0, st, prm, kabort);
   return hipGetLastError();
 }
 

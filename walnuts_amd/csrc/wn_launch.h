@@ -40,8 +40,9 @@ hipError_t launch_orbit(const KernelChoice& kc, const Params& prm, hipStream_t s
 bool orbit_wide_geom(const KernelChoice& kc);                   // wn_k_orbit.hip's wide mode (StockWatson: vectors of 12 registers per lane)
 size_t orbit_wide_work_doubles(int NE, int C, int M);
 bool orbit_wide_run(const KernelChoice& kc, int integrator);   // ... and which integrators' plain sampling runs take it
-bool orbit2_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm);  // wn_k_orbit2.hip: that mode on two waves per chain (fixedLeapFrog)
+bool orbit2_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm);  // wn_k_orbit2.hip: that mode on two waves per chain (the three leapfrog integrators)
 hipError_t launch_orbit2(const KernelChoice& kc, const Params& prm, int* kabort, hipStream_t st);
+bool orbit2_run(const KernelChoice& kc, int integrator);
 size_t orbit2_work_doubles(int NE, int C, int M);
 size_t fast4_work_doubles(int C, int M);
 size_t wave_work_doubles(int NE, int C, int M, int G);
