@@ -33,7 +33,9 @@ enum { V_RQ = 0, V_RV = 32, V_COLDQ = 64, V_COLDV = 65, V_COLDG = 66, V_PROP = 6
 __host__ __device__ constexpr size_t wide_doubles(int NE, int M) { return (size_t)(V_SLOT + 2 * (M + 1)) * NE * 64; }
 // LDS, in doubles: records of the ring's leaves [entry][Hn, lp, If | Ib << 8 | c << 16 | (nEvalF | nEvalB << 16) << 32, -], then the words of
 // the hand-off
-enum { L_REC = 0, L_PROD = 128, L_CONS = 129, L_ABORT = 130, L_DEAD = 131, L_ACK = 132, L_KP = 133, L_CMD = 136, L_TOTAL = 144 };
+enum { L_REC = 0, L_PROD = 128, L_CONS = 129, L_ABORT = 130, L_DEAD = 131, L_ACK = 132, L_KP = 133, L_CMD = 136, L_PART = 144, L_TOTAL = L_PART + 32 * 64 * 2 };
+// L_PART (fixedLeapFrog): [entry][lane][lp share, KE share] -- the T wave leaves the two wave sums of a leaf to the R wave (the same
+// wn_wavesum on the same 64 shares: the same bits); nothing the T wave does next needs the energy
 enum { K_NEWITER = 1, K_GO = 2, K_REDO = 3, K_EXIT = 4 };
 typedef __attribute__((address_space(3))) double lds2_d;
 typedef __attribute__((address_space(3))) volatile unsigned long long lds_u64;
@@ -351,12 +353,13 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
           // (one burst: 490 cycles per leaf, two: tools/sw_nostore_ab.sh); the count word is published behind the NEXT leaf's gradient
           const int ent = (nb0 + k) & 31;
           vst(V_RQ + ent, qa);
-          double lpp = tgt.grad(qa, ga, lane);
+          const double lpp = tgt.grad(qa, ga, lane);
           double ke = 0.0;
           WN_OV(e) { vi[e] = vi[e] + hh2 * ga[e]; ke += vi[e] * vi[e]; }
-          reduce2(lpp, ke);
-          lpp = Tgt::lp_finish(lpp);
-          const double Hn = -lpp + 0.5 * ke;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
+          {  // this lane's shares of lp and of the kinetic energy: summed over the wave by the R wave (36 instructions of a dependent chain less per leaf here)
+            d2_t pr; pr[0] = lpp; pr[1] = ke;
+            *reinterpret_cast<__attribute__((address_space(3))) d2_t*>(L + L_PART + ((size_t)ent * 64 + lane) * 2) = pr;
+          }
           WN_O2STAMP(0);
           // every fourth leaf: publish the leaves in front of this one (their stores were issued at least a whole evaluation ago: the
           // release fence does not wait), and look at the abort word -- the R wave has seen an event inside the doubling
@@ -367,11 +370,9 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
           }
           // (the ring holds xi * v, the integrator's orientation: intOut.v = xi * vv (adaptiveIntegrators.py:57) is formed by the R wave)
           vst(V_RV + ent, vi);
-          L[L_REC + 4 * ent] = Hn; L[L_REC + 4 * ent + 1] = lpp;  // (every lane stores the same two words: no exec-mask region)
           n = nb0 + k + 1;
           o2st_[6] += 1;
-          // forced reject (:316-319): nothing behind a non-finite energy will be used
-          if (!uni_b(isfinite(Hn))) { stop = true; break; }
+          // (a non-finite energy -- forced reject, :316-319 -- is the R wave's to see: it raises the abort word)
           WN_O2STAMP(1);
         }
         ku = ku_behind(i, k0, k1, ku, pred);
@@ -544,7 +545,21 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
         // =========================== bookkeeping of leaves k0 .. k1-1, lane k = leaf k ===========================
         const int k = k16;
         const bool inb = k >= k0 && k < k1;
-        const double Hn_k = L[L_REC + 4 * (rb + k)], lp_k = L[L_REC + 4 * (rb + k) + 1];
+        double Hn_k, lp_k;
+        if constexpr (INTEG == I_FIXED) {  // the energies of leaves k0 .. k1-1 from the T wave's shares: Hams[i] = -fnew + 0.5*sum(vv*vv)
+          Hn_k = 0.0; lp_k = 0.0;
+#pragma unroll 1
+          for (int j = k0; j < k1; ++j) {
+            const d2_t pr = *reinterpret_cast<__attribute__((address_space(3))) d2_t*>(L + L_PART + ((size_t)(rb + j) * 64 + lane) * 2);
+            double a_ = pr[0], b_ = pr[1];
+            reduce2(a_, b_);
+            a_ = Tgt::lp_finish(a_);
+            const double H_ = -a_ + 0.5 * b_;
+            Hn_k = k == j ? H_ : Hn_k; lp_k = k == j ? a_ : lp_k;
+          }
+        } else {
+          Hn_k = L[L_REC + 4 * (rb + k)]; lp_k = L[L_REC + 4 * (rb + k) + 1];
+        }
         const double h_k = hV, up_k = upV;
         int iA = 0, iB = 1;  // If | Ib << 8 | c << 16;  nEvalF | nEvalB << 16  (fixedLeapFrog: 0, one evaluation)
         if constexpr (INTEG != I_FIXED) {
