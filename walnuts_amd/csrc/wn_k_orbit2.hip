@@ -62,16 +62,25 @@ typedef __attribute__((address_space(3))) volatile unsigned long long lds_u64;
 }  // namespace orbit2
 
 template <class Tgt, int NE, int INTEG>
-__global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort) {
+__global__ __launch_bounds__(INTEG == I_FIXED ? 128 : 256) void wn_orbit2_kernel(Params prm, int* kabort) {
   using namespace orbit;
   using namespace orbit2;
   static_assert(NE % 2 == 0, "stored vectors are register pairs");
   constexpr int DP = NE * 64;
-  __shared__ double wn_o2_lds[L_TOTAL];
+  // adaptive integrators: two HELPER waves (roles 2, 3) run the refinement levels c+1, c+2 of a search while the T wave runs level c (see
+  // the T wave's macro step); their hand-off: a job word, the start state of the search (two buffers), each helper's end state and verdict
+  constexpr bool ADAPT = INTEG != I_FIXED;
+  constexpr int NH = 2;
+  constexpr int NWAVES = ADAPT ? 2 + NH : 2;
+  constexpr int L_SURE = L_CMD + 7;
+  constexpr int L_S = L_TOTAL, L_E = L_S + 2 * 3 * DP, L_JOB = L_E + NH * 3 * DP, L_JCANCEL = L_JOB + 1, L_JPAR = L_JOB + 2, L_HDONE = L_JPAR + 4,
+                L_HRES = L_HDONE + NH, LDS_N = ADAPT ? L_HRES + 2 * NH : L_TOTAL;
+  static_assert(LDS_N * 8 <= 160 * 1024, "LDS budget (160 KiB per CU)");
+  __shared__ double wn_o2_lds[LDS_N];
   lds2_d* const L = (lds2_d*)wn_o2_lds;
   lds_u64* const LU = (lds_u64*)wn_o2_lds;
   const int lane = threadIdx.x & 63;
-  const int role = threadIdx.x >> 6;  // 0: T wave, 1: R wave
+  const int role = threadIdx.x >> 6;  // 0: T wave, 1: R wave, 2 ..: helper waves (adaptive integrators)
   const int k16 = lane & 15;
   const int row = lane >> 4;
   const int cl = blockIdx.x;
@@ -85,7 +94,7 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
   const double Hc = prm.H;
   Tgt tgt;
   tgt.init(prm, lane, nullptr);
-  for (int k = threadIdx.x; k < L_TOTAL; k += 128) L[k] = 0.0;
+  for (int k = threadIdx.x; k < LDS_N; k += 64 * NWAVES) L[k] = 0.0;
   __syncthreads();
 
 #define WN_OV(e) _Pragma("unroll") for (int e = 0; e < NE; ++e)
@@ -145,6 +154,48 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
     return ku + (2u + r_ + p_) * nE + (r_ + p_) * nO;
   };
 
+  // one micro pass of 2**cc leapfrog steps (adaptiveIntegrators.py:72-94) on (q, v, g) in place; 1: accepted, 0: not, -1: `cancel()` said stop
+  auto pass_core = [&](double* q, double* v, double* g, double HamStart, double hcur, int cc, double& lpC, double& HC, auto cancel) -> int {
+    const double hh = ldexp(hcur, -cc);  // h / 2**c (exact scaling either way)
+    bool allfin = isfinite(HamStart);
+    const double hh2 = 0.5 * hh, hq = hh;
+    int st = 1 << cc;
+    lpC = 0.0; HC = HamStart;
+#pragma unroll 1
+    do {  // one branch per micro step
+      if (cancel()) return -1;
+      WN_OV(e) { v[e] = v[e] + hh2 * g[e]; q[e] = q[e] + hq * v[e]; }
+      double lpp = tgt.grad(q, g, lane);
+      double ke = 0.0;
+      WN_OV(e) { v[e] = v[e] + hh2 * g[e]; ke += v[e] * v[e]; }
+      reduce2(lpp, ke);
+      lpp = Tgt::lp_finish(lpp);
+      const double Hi = -lpp + 0.5 * ke;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
+      lpC = lpp; HC = Hi;
+      allfin = allfin && isfinite(Hi);
+    } while (--st);
+    return uni_b(allfin && (fabs(HamStart - HC) < dlt)) ? 1 : 0;  // all(isfinite(Hams)) and abs(Hams[0]-Hams[-1]) < delta  (:87-94)
+  };
+  // a state (q, v, g) in LDS: [vector][register pair][lane][2]
+  typedef __attribute__((address_space(3))) d2_t lds_d2;
+  auto lst = [&](int off, const double* q, const double* v, const double* g) {
+    lds_d2* b = reinterpret_cast<lds_d2*>(L + off) + lane;
+#pragma unroll
+    for (int j = 0; j < NE / 2; ++j) {
+      d2_t t; t[0] = q[2 * j]; t[1] = q[2 * j + 1]; b[j * 64] = t;
+      t[0] = v[2 * j]; t[1] = v[2 * j + 1]; b[(NE / 2 + j) * 64] = t;
+      t[0] = g[2 * j]; t[1] = g[2 * j + 1]; b[(NE + j) * 64] = t;
+    }
+  };
+  auto lld = [&](int off, double* q, double* v, double* g) {
+    const lds_d2* b = reinterpret_cast<const lds_d2*>(L + off) + lane;
+#pragma unroll
+    for (int j = 0; j < NE / 2; ++j) {
+      d2_t t = b[j * 64]; q[2 * j] = t[0]; q[2 * j + 1] = t[1];
+      t = b[(NE / 2 + j) * 64]; v[2 * j] = t[0]; v[2 * j + 1] = t[1];
+      t = b[(NE + j) * 64]; g[2 * j] = t[0]; g[2 * j + 1] = t[1];
+    }
+  };
   unsigned long long o2st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o2last_ = __builtin_readcyclecounter();
   (void)o2st_; (void)o2last_;
   auto stamps_out = [&]() {
@@ -155,6 +206,46 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
     }
 #endif
   };
+  if constexpr (ADAPT) if (role >= 2) {
+    // =====================================================================================================================
+    // helper wave hj: level base + 1 + hj of every search job the T wave posts
+    // =====================================================================================================================
+    const int hj = role - 2;
+    uint32_t last = 0;
+    for (;;) {
+      unsigned long long w = 0;
+      unsigned spins = 0;
+      bool out = false;
+      for (;;) {
+        w = LU[L_JOB];
+        const uint32_t js = (uint32_t)(w >> 32);
+        if (js == 0xFFFFFFFFu || dead()) { out = true; break; }
+        if (js != last) break;
+        if (++spins > 64u * WN_O2_SPINS) { out = true; break; }  // (no job for seconds: the T wave is gone)
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (out) break;
+      acquire();
+      const uint32_t js = (uint32_t)(w >> 32);
+      last = js;
+      const int base = (int)((uint32_t)w & 0xFFu), jmax = (int)(((uint32_t)w >> 8) & 0xFFu);
+      const bool need_state = (((uint32_t)w >> 16) & 1u) != 0u;
+      const int level = base + 1 + hj;
+      if (level > jmax) { LU[L_HDONE + hj] = ((unsigned long long)js << 32) | 8ull; continue; }  // not asked for
+      const int buf = (int)(js & 1u);
+      double q[NE], v[NE], g[NE], lpC, HC;
+      lld(L_S + buf * 3 * DP, q, v, g);
+      const double Ham = L[L_JPAR + 2 * buf], hcur = L[L_JPAR + 2 * buf + 1];
+      const int r = pass_core(q, v, g, Ham, hcur, level, lpC, HC, [&]() -> bool { return (uint32_t)LU[L_JCANCEL] == js || (uint32_t)(LU[L_JOB] >> 32) != js; });
+      if (r >= 0) {
+        if (need_state) lst(L_E + hj * 3 * DP, q, v, g);
+        L[L_HRES + 2 * hj] = lpC; L[L_HRES + 2 * hj + 1] = HC;
+      }
+      release();
+      LU[L_HDONE + hj] = ((unsigned long long)js << 32) | (r > 0 ? 1ull : 0ull) | 2ull | (r < 0 ? 4ull : 0ull);
+    }
+    return;
+  }
   if (role == 0) {
     // =====================================================================================================================
     // T wave: the trajectory
@@ -164,7 +255,9 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
     WN_OV(e) { qa[e] = 0.0; vi[e] = 0.0; ga[e] = 0.0; }
     int xi_run = 1;  // the orientation vi is in
     double Ha = 0.0;  // energy at the active end (the adaptive integrators' Ham0)
-    uint32_t seq = 0;
+    uint32_t seq = 0, jseq = 0;
+    int last_level = 0;
+    (void)jseq; (void)last_level;
     for (;;) {
       ++seq;
       WN_O2STAMP(4);
@@ -258,76 +351,128 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
         (void)upV; (void)urV;
         WN_O2STAMP(5);
         if constexpr (INTEG != I_FIXED) {
-          // ---- adaptLeapFrogD / adaptLeapFrogR2P (adaptiveIntegrators.py:65-137 / 361-475): a macro step is 2**minC .. evaluations, so each
-          // leaf is published at once (the fence waits for its stores: ~1 k cycles of ~100 k) and the abort word is read at every pass --
-          // the R wave answers a leaf within ~3 k cycles, a draw that was not taken as assumed costs one pass, not the macro steps behind it
+          // ---- adaptLeapFrogD / adaptLeapFrogR2P (adaptiveIntegrators.py:65-137 / 361-475).  A macro step is a SEARCH: passes of
+          // 2**c micro steps at c = minC, minC+1, .. from the same start state until one is accepted (here: 67 % of the macro steps at
+          // c = 3, 17 % at 4, 6 % at 5, ..), then the same search backwards from the result over c = minC .. If-1.  The passes of a
+          // search do not depend on each other, and this CU has idle SIMDs: the T wave posts the start state as a JOB, runs level c
+          // itself while the helper waves run c+1 and c+2, and takes the first accepted level in the reference's order -- the levels
+          // the reference would have tried are the ones counted (nEvalF / nEvalB), their arithmetic is the same whoever runs them.
+          // A leaf is published at once (the fence waits for its stores: ~1 k cycles of ~100 k).  While the R wave has not yet seen a
+          // positive weight in this doubling (the first leaves often have If != Ib: weight zero, no multinomial draw, WALNUTS.py:426),
+          // the T wave waits for its verdict on leaf n-1 before it starts leaf n (~3 k cycles): the stream index of leaf n's draws
+          // depends on it, and a macro step run on the wrong step size is 100 k cycles thrown away.
           bool aborted = false;
           double hcur = 0.0;
-          auto run_pass = [&](const double* qs, const double* vs, const double* gs, double HamStart, int cc, double* q, double* v, double* g, double& lpC,
-                              double& HC, int& nev) -> bool {
-            WN_OV(e) { q[e] = qs[e]; v[e] = vs[e]; g[e] = gs[e]; }
-            if (aborted || (uint32_t)LU[L_ABORT] == seq) { aborted = true; lpC = 0.0; HC = HamStart; return true; }
-            const double hh = ldexp(hcur, -cc);  // h / 2**c (exact scaling either way)
-            const int nstep = 1 << cc;
-            bool allfin = isfinite(HamStart);
-            const double hh2 = 0.5 * hh, hq = hh;
-            int st = nstep;
+          auto never = [&]() -> bool { return false; };
+          auto post_job = [&](const double* q, const double* v, const double* g, double Ham, int base, int jmax, bool need_state) -> uint32_t {
+            ++jseq;
+            const int buf = (int)(jseq & 1u);
+            lst(L_S + buf * 3 * DP, q, v, g);
+            L[L_JPAR + 2 * buf] = Ham; L[L_JPAR + 2 * buf + 1] = hcur;
+            release();
+            LU[L_JOB] = ((unsigned long long)jseq << 32) | (need_state ? 0x10000u : 0u) | ((uint32_t)jmax << 8) | (uint32_t)base;
+            return jseq;
+          };
+          auto wait_helper = [&](int hj, uint32_t js) -> uint32_t {  // the helper's verdict on job js: 1 accepted, 2 done, 4 abandoned, 8 not asked
+            unsigned spins = 0;
+            unsigned long long w;
+            for (;;) {
+              w = LU[L_HDONE + hj];
+              if ((uint32_t)(w >> 32) == js) break;
+              if (dead()) { aborted = true; return 4u; }
+              if (++spins > WN_O2_SPINS) { give_up(); aborted = true; return 4u; }
+              __builtin_amdgcn_s_sleep(1);
+            }
+            acquire();
+            return (uint32_t)w;
+          };
+          // levels lo .. hi of a search from (qs, vs, gs), in the reference's order: the first accepted level (or -1); `last` = the last level
+          // computed; its end state in (q, v, g) when want_state
+          auto search = [&](const double* qs, const double* vs, const double* gs, double Ham, int lo, int hi, bool want_state, bool also_next, double* q,
+                            double* v, double* g, double& lpC, double& HC, double* qn, double* vn, double* gn, double& lpN, double& HN, bool& have_next) -> int {
+            have_next = false;
+            int base = lo;
 #pragma unroll 1
-            do {  // one branch per micro step
-              WN_OV(e) { v[e] = v[e] + hh2 * g[e]; q[e] = q[e] + hq * v[e]; }
-              double lpp = tgt.grad(q, g, lane);
-              double ke = 0.0;
-              WN_OV(e) { v[e] = v[e] + hh2 * g[e]; ke += v[e] * v[e]; }
-              reduce2(lpp, ke);
-              lpp = Tgt::lp_finish(lpp);
-              const double Hi = -lpp + 0.5 * ke;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
-              lpC = lpp; HC = Hi;
-              allfin = allfin && isfinite(Hi);
-            } while (--st);
-            nev += nstep;
-            return uni_b(allfin && (fabs(HamStart - HC) < dlt));  // all(isfinite(Hams)) and abs(Hams[0]-Hams[-1]) < delta  (:87-94)
+            for (;;) {
+              const int top = base + NH < hi ? base + NH : hi;
+              const int jtop = (also_next && top - base < NH) ? top + 1 : top;  // (adaptLeapFrogR2P: the level behind the accepted one rides along when a helper is free)
+              const uint32_t js = jtop > base ? post_job(qs, vs, gs, Ham, base, jtop, want_state) : 0u;
+              WN_OV(e) { q[e] = qs[e]; v[e] = vs[e]; g[e] = gs[e]; }
+              if ((uint32_t)LU[L_ABORT] == seq) { aborted = true; return -1; }
+              int r = pass_core(q, v, g, Ham, hcur, base, lpC, HC, never);
+              int lvl = base, found = r > 0 ? base : -1;
+#pragma unroll 1
+              for (int hj = 0; found < 0 && base + 1 + hj <= top; ++hj) {
+                const uint32_t fl = wait_helper(hj, js);
+                if (aborted) return -1;
+                lvl = base + 1 + hj;
+                if ((fl & 1u) || lvl == hi) {  // accepted -- or the last level of the search: its state is used silently (Q5)
+                  if (want_state) lld(L_E + hj * 3 * DP, q, v, g);
+                  lpC = L[L_HRES + 2 * hj]; HC = L[L_HRES + 2 * hj + 1];
+                  if (fl & 1u) found = lvl;
+                }
+              }
+              if (found >= 0 && also_next) {  // the pass at found + 1 from the same start state (:400-424): a helper may have it
+                const int hn = found + 1 - base - 1;
+                if (hn >= 0 && hn < NH && found + 1 <= jtop) {
+                  const uint32_t fl = wait_helper(hn, js);
+                  if (aborted) return -1;
+                  if ((fl & 2u) && !(fl & 4u)) { lld(L_E + hn * 3 * DP, qn, vn, gn); lpN = L[L_HRES + 2 * hn]; HN = L[L_HRES + 2 * hn + 1]; have_next = true; }
+                }
+              }
+              if (js) LU[L_JCANCEL] = (unsigned long long)js;  // whoever is still running a level of this job may stop
+              if (found >= 0 || top >= hi) { last_level = found >= 0 ? found : hi; return found; }
+              base = top + 1;
+            }
           };
 #pragma unroll 1
           for (int k = k0; k < k1; ++k) {
+            if ((uint32_t)LU[L_SURE] != seq) {  // the R wave's verdict on the leaves in front of this one
+              unsigned spins = 0;
+              while ((int)(uint32_t)LU[L_CONS] < nb0 + k && (uint32_t)LU[L_SURE] != seq) {
+                if ((uint32_t)LU[L_ABORT] == seq || dead()) { aborted = true; break; }
+                if (++spins > WN_O2_SPINS) { give_up(); aborted = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+              }
+              if (aborted || (uint32_t)LU[L_ABORT] == seq) { stop = true; break; }
+            }
             hcur = wn_readlane(hV, k);
             const double Ham0 = Ha;  // Hs[] of the neighbouring stored index = energy at the active end (WALNUTS.py:302,400,443,487,530)
             int nEvF = 0, nEvB = 0, If, Ib, cret;
             double lpn, Hn;
-            double qw[NE], vw[NE], gw[NE], lpC, HC;
-            int cc = minC;  // forward search (:69-94 / 366-389)
-            bool ok = run_pass(qa, vi, ga, Ham0, cc, qw, vw, gw, lpC, HC, nEvF);
-            if (__builtin_expect(!ok && cc < maxC, 0)) {
-              do {
-                ++cc;
-                ok = run_pass(qa, vi, ga, Ham0, cc, qw, vw, gw, lpC, HC, nEvF);
-              } while (!ok && cc < maxC);
-            }
-            If = ok ? cc : maxC;  // Q5: the last computed state is used silently
+            double qw[NE], vw[NE], gw[NE], lpC = 0.0, HC = 0.0;
+            double qx[NE], vx[NE], gx[NE], lpX = 0.0, HX = 0.0;  // adaptLeapFrogR2P: the pass at If + 1
+            bool have_next = false;
             // adaptLeapFrogR2P :392: with probability R2Pprob0 keep c = If, else re-integrate at c = If+1
             const bool keep = INTEG != I_ADAPT_R2P || uni_b(wn_readlane(urV, k) < prm.R2Pprob0);
+            // forward search (:69-94 / 366-389)
+            const int fnd = search(qa, vi, ga, Ham0, minC, maxC, true, !keep, qw, vw, gw, lpC, HC, qx, vx, gx, lpX, HX, have_next);
+            if (aborted) { stop = true; break; }
+            If = fnd >= 0 ? fnd : maxC;  // Q5: the last computed state is used silently
+            nEvF = (2 << If) - (1 << minC);  // the levels minC .. If the reference tried: sum of 2**c
             int cSim = If, maxTry = If - 1;
             Ib = If;
             lpn = lpC; Hn = HC;
-            if (!keep || maxTry >= minC) {
-              if (!keep) {  // :400-424, 434-437
-                run_pass(qa, vi, ga, Ham0, If + 1, qw, vw, gw, lpC, HC, nEvF);
-                cSim = If + 1; maxTry = maxC; Ib = maxC;
-                lpn = lpC; Hn = HC;
+            if (!keep) {  // :400-424, 434-437
+              if (have_next) { WN_OV(e) { qw[e] = qx[e]; vw[e] = vx[e]; gw[e] = gx[e]; } lpC = lpX; HC = HX; }
+              else {
+                WN_OV(e) { qw[e] = qa[e]; vw[e] = vi[e]; gw[e] = ga[e]; }
+                pass_core(qw, vw, gw, Ham0, hcur, If + 1, lpC, HC, never);
               }
-              if (maxTry >= minC) {  // backward search from (qOut, -vOut, gOut)  (:107-132 / 440-464)
-                double qo[NE], vo[NE], go[NE], vneg[NE];
-                WN_OV(e) { qo[e] = qw[e]; vo[e] = vw[e]; go[e] = gw[e]; vneg[e] = -vw[e]; }
-                double lpB, HB;
-                for (cc = minC;; ++cc) {
-                  ok = run_pass(qo, vneg, go, Hn, cc, qw, vw, gw, lpB, HB, nEvB);
-                  if (ok) { Ib = cc; break; }
-                  if (cc >= maxTry) break;
-                }
-                WN_OV(e) { qw[e] = qo[e]; vw[e] = vo[e]; gw[e] = go[e]; }
-              }
+              nEvF += 2 << If;
+              cSim = If + 1; maxTry = maxC; Ib = maxC;
+              lpn = lpC; Hn = HC;
+            }
+            if (maxTry >= minC) {  // backward search from (qOut, -vOut, gOut)  (:107-132 / 440-464): only the verdicts count
+              double vneg[NE], qb[NE], vb[NE], gb[NE], lpB, HB, lpY, HY;
+              WN_OV(e) vneg[e] = -vw[e];
+              bool hn_;
+              const int fb = search(qw, vneg, gw, Hn, minC, maxTry, false, false, qb, vb, gb, lpB, HB, qb, vb, gb, lpY, HY, hn_);
+              if (aborted) { stop = true; break; }
+              if (fb >= 0) Ib = fb;
+              nEvB = (2 << (fb >= 0 ? fb : maxTry)) - (1 << minC);
             }
             cret = INTEG == I_ADAPT_R2P ? cSim : If;  // :135-137 / 466-475 (lwt follows from If, Ib, c: the R wave forms it)
-            if (aborted) { stop = true; break; }
             WN_OV(e) { qa[e] = qw[e]; vi[e] = vw[e]; ga[e] = gw[e]; }
             Ha = Hn;
             WN_O2STAMP(0);
@@ -380,6 +525,7 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
       release();
       LU[L_PROD] = ((unsigned long long)seq << 32) | 0x80000000u | (unsigned)n;  // (bit 31: the run has ended)
     }
+    if constexpr (ADAPT) LU[L_JOB] = 0xFFFFFFFF00000000ull;  // the helpers leave
     stamps_out();
     return;
   }
@@ -416,6 +562,8 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
   auto send = [&](int kind, int n_, bool pred_, bool swap_) {
     ++seq;
     LU[L_CONS] = (unsigned long long)(unsigned)n_;  // (leaves of the new run retired so far: the T wave's ring flow control)
+    // "every leaf of the rest of this doubling takes its multinomial draw": true once the doubling's weights sum to something (:426)
+    LU[L_SURE] = (i == 0 || WnewSum > prm.wtSumThresh) ? (unsigned long long)(seq) : 0ull;
     LU[L_CMD + 1] = ((unsigned long long)(uint32_t)iter << 32) | (uint32_t)ip;
     LU[L_CMD + 2] = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)n_;
     LU[L_CMD + 3] = ((unsigned long long)khc << 32) | ku;
@@ -513,7 +661,8 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
           unsigned spins = 0;
           int npub = 0;
           const int blk_end = nleaf - nb0 < 16 ? nleaf : nb0 + 16;
-          const int want = n + WN_O2_BATCH < blk_end ? n + WN_O2_BATCH : blk_end;
+          constexpr int BATCH = ADAPT ? 1 : WN_O2_BATCH;  // (a macro step of the adaptive integrators is ~100 k cycles: retire it at once)
+          const int want = n + BATCH < blk_end ? n + BATCH : blk_end;
           for (;;) {
             const unsigned long long w = LU[L_PROD];
             const bool mine = (uint32_t)(w >> 32) == seq;
@@ -757,6 +906,9 @@ __global__ __launch_bounds__(128) void wn_orbit2_kernel(Params prm, int* kabort)
         if (f0_now && !end_nf && !end_sub && !redo) fire0 = true;
         o2st_[6] += (unsigned long long)(Lfull + 1 - k0); o2st_[7] += 1;
         n = nb0 + Lfull + 1;
+        // (the abort word in front of the count: the T wave must not take "leaf n-1 retired" for "go on" when the verdict is a restart)
+        if (end_nf || end_sub || redo) LU[L_ABORT] = (unsigned long long)seq;
+        if (i == 0 || WnewSum > prm.wtSumThresh) LU[L_SURE] = (unsigned long long)seq;
         LU[L_CONS] = (unsigned long long)(unsigned)n;
         WN_O2STAMP(3);
         if (end_nf) {  // :316-319, 414-417, 457-459 (Q3, Q4)
@@ -852,9 +1004,9 @@ bool orbit2_eligible(const KernelChoice& kc, int adapt, bool warm, const Params&
 
 hipError_t launch_orbit2(const KernelChoice& kc, const Params& prm, int* kabort, hipStream_t st) {
   (void)kc;
-  dim3 grid(prm.C), block(128);
-  if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit2_kernel<WTgtStockWatson<12>, 12, I_ADAPT_R2P>), grid, block, 0, st, prm, kabort);
-  else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit2_kernel<WTgtStockWatson<12>, 12, I_ADAPT_D>), grid, block, 0, st, prm, kabort);
+  dim3 grid(prm.C), block(128), block4(256);  // adaptive integrators: T, R and two helper waves
+  if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit2_kernel<WTgtStockWatson<12>, 12, I_ADAPT_R2P>), grid, block4, 0, st, prm, kabort);
+  else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit2_kernel<WTgtStockWatson<12>, 12, I_ADAPT_D>), grid, block4, 0, st, prm, kabort);
   else hipLaunchKernelGGL((wn_orbit2_kernel<WTgtStockWatson<12>, 12, I_FIXED>), grid, block, 0, st, prm, kabort);
   return hipGetLastError();
 }
