@@ -79,22 +79,27 @@ def test_cfg4_dense1000_1024_chains(wa):
         close(d[k], o["diagnostics"], what=f"chain {k} diagnostics")
 
 
-def test_cfg5_stockwatson_adaptd_256_chains(wa):
-    """SURVEY 8d cfg 5, one GPU's shard: StockWatson (D = 756), 256 chains, adaptLeapFrogD minC = 3, H0 = 0.1, delta0 = 0.3,
-    M = 14, q0 = 0 -- the first of mainSW.py:41-80's runs; chains differ only by their random streams."""
+@pytest.mark.parametrize("name,integ,H0,minC", [("D", ol.I_ADAPT_D, 0.1, 3), ("R2P", ol.I_ADAPT_R2P, 0.1, 3), ("fixed", ol.I_FIXED, 0.002, 0)])
+def test_cfg5_stockwatson_256_chains(wa, name, integ, H0, minC):
+    """SURVEY 8d cfg 5, one GPU's shard: StockWatson (D = 756), 256 chains, M = 14, q0 = 0 -- the three runs of mainSW.py:41-80
+    (adaptLeapFrogD / adaptLeapFrogR2P with minC = 3, H0 = 0.1, delta0 = 0.3; fixedLeapFrog with H0 = 0.002); chains differ only by their
+    random streams.  Round 5: these plain sampling runs are wn_k_orbit2.hip's (trajectory, bookkeeping and -- adaptive integrators --
+    two helper waves that run the next refinement levels of a search, per chain)."""
     sw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stockwatson_data.npz"))
     T = int(sw["T"][0]); D = 3 * T; C, IT = 256, 2
     tpar = np.concatenate([[float(T)], sw["y"]])
     q0 = np.zeros((C, D))
-    e = wa.Engine(D, C, integrator=ol.I_ADAPT_D, H0=0.1, delta0=0.3, M=14, minC=3, generated=ol.G_FIRSTK, gen_k=2).set_target(ol.T_STOCKWATSON, tpar)
+    e = wa.Engine(D, C, integrator=integ, H0=H0, delta0=0.3, M=14, minC=minC, generated=ol.G_FIRSTK, gen_k=2).set_target(ol.T_STOCKWATSON, tpar)
+    assert "wn_orbit2_kernel<stockwatson" in e.kernel_name, e.kernel_name
     s, d = e.run(q0, SEED, IT)
     s = s.transpose(1, 2).cpu().numpy(); d = d.cpu().numpy(); e.close()
     assert np.isfinite(s).all()
     ok = np.isin(d[:, :, 19], [0, 4, -4])
-    assert (d[:, :, 21][ok] >= 3).all() and (d[:, :, 8][ok] >= 3).all()  # every accepted refinement level is >= minC
-    assert (d[:, :, 6][ok] >= 8 * (2.0 ** d[:, :, 20][ok] - 1)).all()     # >= 2^minC micro steps per macro step
+    if integ != ol.I_FIXED:
+        assert (d[:, :, 21][ok] >= 3).all() and (d[:, :, 8][ok] >= 3).all()  # every accepted refinement level is >= minC
+        assert (d[:, :, 6][ok] >= 8 * (2.0 ** d[:, :, 20][ok] - 1)).all()     # >= 2^minC micro steps per macro step
     for k in (0, 100, 200, 255):
-        o = ol.walnuts(ol.T_STOCKWATSON, q0[k], integrator=ol.I_ADAPT_D, tpar=tpar, H0=0.1, delta0=0.3, numIter=IT, M=14, minC=3,
+        o = ol.walnuts(ol.T_STOCKWATSON, q0[k], integrator=integ, tpar=tpar, H0=H0, delta0=0.3, numIter=IT, M=14, minC=minC,
                        seed=SEED, chain=k, generated=ol.G_FIRSTK, gen_k=2)
         np.testing.assert_array_equal(d[k][:, INT_COLS], o["diagnostics"][:, INT_COLS], err_msg=f"chain {k}")
         close(s[k], o["samples"], what=f"chain {k} draws")

@@ -39,7 +39,6 @@ def run_engine(wa, target, q0, iters, legacy=False, exact=True, seed=SEED, tpar=
     from walnuts_amd import _lib as L
     old = os.environ.pop("WN_ORBIT_LEGACY", None)
     os.environ["WN_ORBIT_WIDE_ADAPT"] = "1"  # (StockWatson: the adaptive integrators' plain runs stay on the one-stream engine by default)
-    os.environ["WN_ORBIT2_ADAPT"] = "1"
     if legacy:
         os.environ["WN_ORBIT_LEGACY"] = "1"
     if onewave:  # (StockWatson's fixedLeapFrog run: the one-wave form of the wide mode instead of wn_k_orbit2.hip's two waves)
@@ -57,7 +56,6 @@ def run_engine(wa, target, q0, iters, legacy=False, exact=True, seed=SEED, tpar=
         os.environ.pop("WN_ORBIT_LEGACY", None)
         os.environ.pop("WN_ORBIT_EXACT", None)
         os.environ.pop("WN_ORBIT_WIDE_ADAPT", None)
-        os.environ.pop("WN_ORBIT2_ADAPT", None)
         os.environ.pop("WN_ORBIT_ONEWAVE", None)
         if old is not None:
             os.environ["WN_ORBIT_LEGACY"] = old

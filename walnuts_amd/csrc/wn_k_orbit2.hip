@@ -985,15 +985,12 @@ __global__ __launch_bounds__(INTEG == I_FIXED ? 128 : 256) void wn_orbit2_kernel
 // ---- host side ----------------------------------------------------------------------------------------------------------
 size_t orbit2_work_doubles(int NE, int C, int M) { return (size_t)C * orbit2::wide_doubles(NE, M); }
 
-// Plain sampling runs of fixedLeapFrog on the wide geometry (StockWatson): 8.1e7 -> 1.2e8 evaluations/s.  WN_ORBIT_ONEWAVE=1 keeps the
-// one-wave form (wn_k_orbit.hip's wide mode), WN_ORBIT_LEGACY=1 the one-stream engine.  The adaptive integrators run here too
-// (WN_ORBIT2_ADAPT=1; tests/test_gpu_orbit.py: bit for bit with the one-stream engine) but stay on that engine by default: their macro
-// step is ~26 evaluations on this target (minC = 3 and refinements), its bookkeeping 3 % of it -- nothing to hide behind a second wave --
-// and the first leaves of a doubling often have weight zero (If != Ib), so "every leaf takes its draw like the one before" fails twice
-// per doubling and the T wave has run a ~100 k-cycle leaf ahead each time: 7.3e7 against the engine's 9.1e7 (adaptLeapFrogD).
+// Plain sampling runs of the three leapfrog integrators on the wide geometry (StockWatson).  WN_ORBIT_ONEWAVE=1 keeps the one-wave forms
+// (fixedLeapFrog: wn_k_orbit.hip's wide mode; the adaptive integrators: the one-stream engine, or that wide mode with
+// WN_ORBIT_WIDE_ADAPT=1), WN_ORBIT_LEGACY=1 the one-stream engine, WN_ORBIT2_NOADAPT=1 this kernel for fixedLeapFrog only.
 bool orbit2_run(const KernelChoice& kc, int integrator) {
   if (!orbit_wide_geom(kc) || getenv("WN_ORBIT_LEGACY") || getenv("WN_ORBIT_NOWIDE") || getenv("WN_ORBIT_ONEWAVE")) return false;
-  return integrator == I_FIXED || ((integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && getenv("WN_ORBIT2_ADAPT"));
+  return integrator == I_FIXED || ((integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && !getenv("WN_ORBIT2_NOADAPT"));
 }
 bool orbit2_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm) {
   if (!orbit2_run(kc, prm.integrator)) return false;
