@@ -389,8 +389,8 @@ __global__ __launch_bounds__(INTEG == I_FIXED ? 128 : 256) void wn_orbit2_kernel
           // levels lo .. hi of a search from (qs, vs, gs), in the reference's order: the first accepted level (or -1); `last` = the last level
           // computed; its end state in (q, v, g) when want_state
           auto search = [&](const double* qs, const double* vs, const double* gs, double Ham, int lo, int hi, bool want_state, bool also_next, double* q,
-                            double* v, double* g, double& lpC, double& HC, double* qn, double* vn, double* gn, double& lpN, double& HN, bool& have_next) -> int {
-            have_next = false;
+                            double* v, double* g, double& lpC, double& HC, int& next_hj) -> int {
+            next_hj = -1;  // (also_next: the helper whose end-state buffer holds the pass at the accepted level + 1, if one ran it)
             int base = lo;
 #pragma unroll 1
             for (;;) {
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(INTEG == I_FIXED ? 128 : 256) void wn_orbit2_kernel
                 if (hn >= 0 && hn < NH && found + 1 <= jtop) {
                   const uint32_t fl = wait_helper(hn, js);
                   if (aborted) return -1;
-                  if ((fl & 2u) && !(fl & 4u)) { lld(L_E + hn * 3 * DP, qn, vn, gn); lpN = L[L_HRES + 2 * hn]; HN = L[L_HRES + 2 * hn + 1]; have_next = true; }
+                  if ((fl & 2u) && !(fl & 4u)) next_hj = hn;
                 }
               }
               if (js) LU[L_JCANCEL] = (unsigned long long)js;  // whoever is still running a level of this job may stop
@@ -441,12 +441,11 @@ __global__ __launch_bounds__(INTEG == I_FIXED ? 128 : 256) void wn_orbit2_kernel
             int nEvF = 0, nEvB = 0, If, Ib, cret;
             double lpn, Hn;
             double qw[NE], vw[NE], gw[NE], lpC = 0.0, HC = 0.0;
-            double qx[NE], vx[NE], gx[NE], lpX = 0.0, HX = 0.0;  // adaptLeapFrogR2P: the pass at If + 1
-            bool have_next = false;
+            int next_hj = -1;  // adaptLeapFrogR2P: the helper that has the pass at If + 1
             // adaptLeapFrogR2P :392: with probability R2Pprob0 keep c = If, else re-integrate at c = If+1
             const bool keep = INTEG != I_ADAPT_R2P || uni_b(wn_readlane(urV, k) < prm.R2Pprob0);
             // forward search (:69-94 / 366-389)
-            const int fnd = search(qa, vi, ga, Ham0, minC, maxC, true, !keep, qw, vw, gw, lpC, HC, qx, vx, gx, lpX, HX, have_next);
+            const int fnd = search(qa, vi, ga, Ham0, minC, maxC, true, !keep, qw, vw, gw, lpC, HC, next_hj);
             if (aborted) { stop = true; break; }
             If = fnd >= 0 ? fnd : maxC;  // Q5: the last computed state is used silently
             nEvF = (2 << If) - (1 << minC);  // the levels minC .. If the reference tried: sum of 2**c
@@ -454,8 +453,10 @@ __global__ __launch_bounds__(INTEG == I_FIXED ? 128 : 256) void wn_orbit2_kernel
             Ib = If;
             lpn = lpC; Hn = HC;
             if (!keep) {  // :400-424, 434-437
-              if (have_next) { WN_OV(e) { qw[e] = qx[e]; vw[e] = vx[e]; gw[e] = gx[e]; } lpC = lpX; HC = HX; }
-              else {
+              if (next_hj >= 0) {  // (a cancelled helper writes nothing: its buffer holds that pass until its next job is through)
+                lld(L_E + next_hj * 3 * DP, qw, vw, gw);
+                lpC = L[L_HRES + 2 * next_hj]; HC = L[L_HRES + 2 * next_hj + 1];
+              } else {
                 WN_OV(e) { qw[e] = qa[e]; vw[e] = vi[e]; gw[e] = ga[e]; }
                 pass_core(qw, vw, gw, Ham0, hcur, If + 1, lpC, HC, never);
               }
@@ -464,10 +465,10 @@ __global__ __launch_bounds__(INTEG == I_FIXED ? 128 : 256) void wn_orbit2_kernel
               lpn = lpC; Hn = HC;
             }
             if (maxTry >= minC) {  // backward search from (qOut, -vOut, gOut)  (:107-132 / 440-464): only the verdicts count
-              double vneg[NE], qb[NE], vb[NE], gb[NE], lpB, HB, lpY, HY;
+              double vneg[NE], qb[NE], vb[NE], gb[NE], lpB, HB;
               WN_OV(e) vneg[e] = -vw[e];
-              bool hn_;
-              const int fb = search(qw, vneg, gw, Hn, minC, maxTry, false, false, qb, vb, gb, lpB, HB, qb, vb, gb, lpY, HY, hn_);
+              int hn_;
+              const int fb = search(qw, vneg, gw, Hn, minC, maxTry, false, false, qb, vb, gb, lpB, HB, hn_);
               if (aborted) { stop = true; break; }
               if (fb >= 0) Ib = fb;
               nEvB = (2 << (fb >= 0 ? fb : maxTry)) - (1 << minC);
