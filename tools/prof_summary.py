@@ -35,8 +35,8 @@ for k, g in grp.items():
           f"scratch={r.get('Scratch_Size')} wg={r.get('Workgroup_Size')}")
 print("== code-object metadata (tools/kernel_meta.sh; the trace's VGPR_Count column above is NOT the allocation: cite these) ==")
 import subprocess
-for unit in ("wn_k_fast", "wn_k_fast4", "wn_k_wave", "wn_k_orbit", "wn_k_split", "wn_k_gemm", "wn_k_coop"):
-    used = [k for k in grp if unit.replace("wn_k_", "wn_") in k or (unit == "wn_k_gemm" and "dense_grad" in k)]
+for unit in ("wn_k_fast", "wn_k_fast4", "wn_k_wave", "wn_k_orbit", "wn_k_orbit2", "wn_k_split", "wn_k_gemm", "wn_k_coop"):
+    used = [k for k in grp if unit.replace("wn_k_", "wn_") + "_kernel" in k or (unit == "wn_k_gemm" and "dense_grad" in k)]
     if not used:
         continue
     try:
