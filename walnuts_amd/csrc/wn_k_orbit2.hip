@@ -221,7 +221,7 @@ __global__ __launch_bounds__(INTEG == I_FIXED ? 128 : 256) void wn_orbit2_kernel
         const uint32_t js = (uint32_t)(w >> 32);
         if (js == 0xFFFFFFFFu || dead()) { out = true; break; }
         if (js != last) break;
-        if (++spins > 64u * WN_O2_SPINS) { out = true; break; }  // (no job for seconds: the T wave is gone)
+        if (++spins > 8u * WN_O2_SPINS) { out = true; break; }  // (no job for seconds: the T wave is gone)
         __builtin_amdgcn_s_sleep(1);
       }
       if (out) break;
