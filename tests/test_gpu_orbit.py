@@ -252,3 +252,34 @@ def test_two_wave_kernel_is_the_one_wave_kernel_bit_for_bit(wa):
     assert "wn_orbit2_kernel" in name2 and "wn_orbit_kernel" in name1, (name2, name1)
     assert same(d2, d1) and same(s2, s1), (np.argwhere(d2 != d1)[:5], np.abs(s2 - s1).max())
     assert d2[:, :, 6].max() > 500  # long orbits
+
+
+def test_two_wave_kernel_is_chosen_only_while_the_chains_leave_simds_idle(wa):
+    """wn_k_orbit2.hip spends 2 (fixedLeapFrog) or 4 (adaptive integrators) wavefronts and up to 107 KB of LDS on a chain to cut its
+    LATENCY -- BASELINE config 5 is one chain per CU.  With more chains than CUs the one-wave kernels fill the SIMDs themselves and win on
+    throughput (tools/sw_chains_ab.sh), so the choice depends on the number of chains; WN_ORBIT2_ANYC=1 lifts the bound (same draws)."""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    T = 30
+    tpar = sw_tpar(T)
+    names = {}
+    for integ in (ol.I_ADAPT_D, ol.I_FIXED):
+        for C in (cus, cus + 1, 2 * cus, 2 * cus + 1):
+            e = wa.Engine(3 * T, C, integrator=integ, H0=0.2, delta0=0.3, M=4, minC=1)
+            e.set_target(ol.T_STOCKWATSON, tpar)
+            names[(integ, C)] = e.kernel_name
+            e.close()
+    assert "wn_orbit2_kernel" in names[(ol.I_ADAPT_D, cus)] and "wn_wave_kernel" in names[(ol.I_ADAPT_D, cus + 1)], names
+    assert "wn_orbit2_kernel" in names[(ol.I_FIXED, 2 * cus)] and "wn_orbit_kernel" in names[(ol.I_FIXED, 2 * cus + 1)], names
+    # the same draws either way
+    C = cus + 40
+    q0 = 0.1 * np.random.default_rng(8).normal(size=(C, 3 * T))
+    kw = dict(integrator=ol.I_ADAPT_D, H0=0.2, delta0=0.3, M=5, minC=1)
+    s1, d1, n1 = run_engine(wa, ol.T_STOCKWATSON, q0, 3, tpar=tpar, legacy=True, **kw)
+    os.environ["WN_ORBIT2_ANYC"] = "1"
+    try:
+        s2, d2, n2 = run_engine(wa, ol.T_STOCKWATSON, q0, 3, tpar=tpar, **kw)
+    finally:
+        os.environ.pop("WN_ORBIT2_ANYC", None)
+    assert "wn_wave_kernel" in n1 and "wn_orbit2_kernel" in n2, (n1, n2)
+    assert same_run(s2, d2, s1, d1)

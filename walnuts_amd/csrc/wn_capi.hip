@@ -524,7 +524,7 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
     // (round 5) StockWatson's plain sampling runs: the same kernel with vectors of 12 registers per lane
     snprintf(kc.name, sizeof(kc.name), "wn_orbit_kernel<stockwatson,NE=12,%s>", e->cfg.integrator == WN_I_FIXED ? "fixedLeapFrog" : e->cfg.integrator == WN_I_ADAPT_D ? "adaptLeapFrogD" : "adaptLeapFrogR2P");
   }
-  if (e->cfg.warmup_iter == 0 && e->cfg.M >= 1 && orbit2_run(kc, e->cfg.integrator)) {
+  if (e->cfg.warmup_iter == 0 && e->cfg.M >= 1 && orbit2_run(kc, e->cfg.integrator, e->cfg.n_chains)) {
     // trajectory and bookkeeping on a wave each (wn_k_orbit2.hip)
     snprintf(kc.name, sizeof(kc.name), "wn_orbit2_kernel<stockwatson,NE=12,%s>", e->cfg.integrator == WN_I_FIXED ? "fixedLeapFrog" : e->cfg.integrator == WN_I_ADAPT_D ? "adaptLeapFrogD" : "adaptLeapFrogR2P");
   }

@@ -986,15 +986,27 @@ __global__ __launch_bounds__(INTEG == I_FIXED ? 128 : 256) void wn_orbit2_kernel
 // ---- host side ----------------------------------------------------------------------------------------------------------
 size_t orbit2_work_doubles(int NE, int C, int M) { return (size_t)C * orbit2::wide_doubles(NE, M); }
 
-// Plain sampling runs of the three leapfrog integrators on the wide geometry (StockWatson).  WN_ORBIT_ONEWAVE=1 keeps the one-wave forms
-// (fixedLeapFrog: wn_k_orbit.hip's wide mode; the adaptive integrators: the one-stream engine, or that wide mode with
-// WN_ORBIT_WIDE_ADAPT=1), WN_ORBIT_LEGACY=1 the one-stream engine, WN_ORBIT2_NOADAPT=1 this kernel for fixedLeapFrog only.
-bool orbit2_run(const KernelChoice& kc, int integrator) {
+// Plain sampling runs of the three leapfrog integrators on the wide geometry (StockWatson) WHEN THE CHAINS LEAVE SIMDs IDLE.  A chain here
+// is 2 waves (fixedLeapFrog) or 4 (adaptive: 107 KB of LDS, one chain per CU), and what it buys is latency: with more chains than that the
+// one-stream engine's one wave per chain fills the SIMDs itself and wins on throughput (tools/sw_chains_ab.sh, evaluations/s, this kernel
+// against the engine: adaptLeapFrogD 256 chains 9.4e7 / 7.2e7, 512: 1.1e8 / 1.4e8, 2048: 1.5e8 / 3.3e8; fixedLeapFrog 512: 2.1e8 / 1.4e8,
+// 1024: 2.2e8 / 2.5e8).  So: adaptive integrators up to one chain per CU, fixedLeapFrog up to two (WN_ORBIT2_ANYC=1 lifts the bound).
+// WN_ORBIT_ONEWAVE=1 keeps the one-wave forms (fixedLeapFrog: wn_k_orbit.hip's wide mode; the adaptive integrators: the one-stream
+// engine, or that wide mode with WN_ORBIT_WIDE_ADAPT=1), WN_ORBIT_LEGACY=1 the one-stream engine, WN_ORBIT2_NOADAPT=1 this kernel for
+// fixedLeapFrog only.
+static int device_cus() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  return n;
+}
+bool orbit2_run(const KernelChoice& kc, int integrator, int n_chains) {
   if (!orbit_wide_geom(kc) || getenv("WN_ORBIT_LEGACY") || getenv("WN_ORBIT_NOWIDE") || getenv("WN_ORBIT_ONEWAVE")) return false;
-  return integrator == I_FIXED || ((integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && !getenv("WN_ORBIT2_NOADAPT"));
+  const bool adaptive = integrator == I_ADAPT_D || integrator == I_ADAPT_R2P;
+  if (integrator != I_FIXED && !(adaptive && !getenv("WN_ORBIT2_NOADAPT"))) return false;
+  return getenv("WN_ORBIT2_ANYC") || n_chains <= device_cus() * (adaptive ? 1 : 2);
 }
 bool orbit2_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm) {
-  if (!orbit2_run(kc, prm.integrator)) return false;
+  if (!orbit2_run(kc, prm.integrator, prm.C)) return false;
   if (warm || prm.mode != MODE_SAMPLE || prm.trace_n || prm.trace || prm.omin || adapt == 2) return false;
   if (prm.M < 1 || prm.M > MAX_M || prm.maxC > 12 || prm.minC < 0 || prm.minC > prm.maxC) return false;
   return prm.generated == G_IDENTITY || prm.generated == G_FIRSTK || prm.generated == G_Q0_SUMSQ;

@@ -42,7 +42,7 @@ size_t orbit_wide_work_doubles(int NE, int C, int M);
 bool orbit_wide_run(const KernelChoice& kc, int integrator);   // ... and which integrators' plain sampling runs take it
 bool orbit2_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm);  // wn_k_orbit2.hip: that mode on two waves per chain (the three leapfrog integrators)
 hipError_t launch_orbit2(const KernelChoice& kc, const Params& prm, int* kabort, hipStream_t st);
-bool orbit2_run(const KernelChoice& kc, int integrator);
+bool orbit2_run(const KernelChoice& kc, int integrator, int n_chains);  // (only while the chains leave SIMDs idle)
 size_t orbit2_work_doubles(int NE, int C, int M);
 size_t fast4_work_doubles(int C, int M);
 size_t wave_work_doubles(int NE, int C, int M, int G);
