@@ -8,7 +8,7 @@ mkdir -p build_$NAME
 FLAGS="-O3 -std=c++17 -fPIC -fno-strict-aliasing --offload-arch=gfx950 -Wno-unused-result -Wno-unused-value $*"
 BASE="-O3 -std=c++17 -fPIC -fno-strict-aliasing --offload-arch=gfx950 -Wno-unused-result -Wno-unused-value"
 # PLAIN="wn_k_split wn_k_wave" compiles those translation units without the extra flags
-for f in wn_capi wn_k_lane wn_k_coop wn_k_fast wn_k_fast4 wn_k_wave wn_k_orbit wn_k_orbit2 wn_k_split wn_k_gemm wn_k_wstep; do
+for f in wn_capi wn_k_lane wn_k_coop wn_k_fast wn_k_fast4 wn_k_wave wn_k_wavelds wn_k_orbit wn_k_orbit2 wn_k_split wn_k_gemm wn_k_wstep; do
   FL="$FLAGS"
   case " ${PLAIN:-} " in *" $f "*) FL="$BASE";; esac
   [ $f = wn_k_gemm ] && FL="$FL -mllvm -amdgpu-mfma-vgpr-form"

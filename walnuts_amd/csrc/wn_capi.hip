@@ -91,6 +91,13 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_
     snprintf(nm, sizeof(kc->name), "wn_split_tick_kernel<NE=%d,external>", NE);
     return 0;
   }
+  if (target == T_DENSEGAUSS && D > 64 && D <= 128 && integrator != I_FIXED && !dm && !getenv("WN_DENSE_COOP")) {
+    // the adaptive integrators on the headline geometry (round 5): one chain per wavefront, the matrix in LDS shared by a workgroup's
+    // chains (wn_k_wavelds.hip) -- a macro step is per-chain control flow, not a wide tile; WN_DENSE_COOP=1: the cooperative layout below
+    kc->layout = 2; kc->p0 = 2; kc->p1 = T_DENSEGAUSS; kc->W = 1;
+    snprintf(nm, sizeof(kc->name), "wn_wavelds_kernel<NE=2,dense,K=8>");
+    return 0;
+  }
   if (target == T_DENSEGAUSS || target == T_DIAGGAUSS || target == T_STDGAUSS) {
     const int W = (waves_per_group && waves_per_group != 64) ? waves_per_group : 4;  // 64 = "one chain per lane if possible"
     if (W != 4) return -1;

@@ -60,11 +60,13 @@ static hipError_t go(int adapt, bool warm, const Params& prm, hipStream_t st) {
 size_t wave_work_doubles(int NE, int C, int M, int G) {
   if (NE == 64) return WavePolicy<16, WTgtDiag<16, 256>, 4>::work_doubles(C, M, G);  // four waves per workgroup, D <= 4096 * G
   if (NE == 1) return WavePolicy<1, WTgtFunnel10>::work_doubles(C, M);
+  if (NE == 2) return WavePolicy<2, WTgtDiag<2>>::work_doubles(C, M);  // (wn_k_wavelds.hip)
   if (NE == 12) return WavePolicy<12, WTgtDiag<12>>::work_doubles(C, M);
   return NE <= 8 ? WavePolicy<8, WTgtDiag<8>>::work_doubles(C, M) : WavePolicy<16, WTgtDiag<16>>::work_doubles(C, M);
 }
 
 hipError_t launch_wave(const KernelChoice& kc, int adapt, bool warm, const Params& prm, hipStream_t st) {
+  if (wavelds_geom(kc)) return launch_wavelds(kc, adapt, warm, prm, st);
   if (kc.p1 == T_DIAGGAUSS || kc.p1 == T_STDGAUSS) {
     if (kc.p0 == 8) return go<8, WTgtDiag<8>>(adapt, warm, prm, st);
     if (kc.p0 == 16) return go<16, WTgtDiag<16>>(adapt, warm, prm, st);

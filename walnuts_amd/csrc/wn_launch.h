@@ -46,6 +46,8 @@ bool orbit2_run(const KernelChoice& kc, int integrator, int n_chains);  // (only
 size_t orbit2_work_doubles(int NE, int C, int M);
 size_t fast4_work_doubles(int C, int M);
 size_t wave_work_doubles(int NE, int C, int M, int G);
+bool wavelds_geom(const KernelChoice& kc);  // wn_k_wavelds.hip: dense Gaussian 65 <= D <= 128, adaptive integrators, one chain per wave, the matrix in LDS
+hipError_t launch_wavelds(const KernelChoice& kc, int adapt, bool warm, const Params& prm, hipStream_t st);
 size_t split_work_doubles(int NE, int C, int M);
 
 }  // namespace wn
