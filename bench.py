@@ -488,6 +488,7 @@ def summary_line(out):
     parts = ["cfg2@%d=%s(%s)" % (out["config"].get("chains_per_gpu", 0), f(out["value"], "%.4g"), f(g(out, "roofline", "frac")))]
     parts.append("cfg2@1024=%s(%s,med3)" % (f(g(ex, "dense_1024_chains", "value")), f(g(ex, "dense_1024_chains", "roofline", "frac"))))
     parts.append("diag=%s" % f(g(ex, "diag_variant", "value")))
+    parts.append("cfg2adaptD/R2P=%s/%s" % (f(g(ex, "dense_adaptive", "adaptLeapFrogD", "value")), f(g(ex, "dense_adaptive", "adaptLeapFrogR2P", "value"))))
     c3 = oc.get("cfg3_funnel", {})
     parts.append("cfg3=%s/%s/%s,tick_us=%s" % (f(c3.get("min")), f(c3.get("value")), f(c3.get("max")), f(c3.get("tick_us"))))
     c4 = oc.get("cfg4_dense1000", {})
@@ -671,6 +672,18 @@ def main():
                 extras["diag_variant"] = {"value": st / (ms3 * 1e-3), "unit": "leapfrog steps/s", "kernel": e3.kernel_name,
                                           "hbm_roofline_GBps_at_48D_bytes_per_step": st * 48.0 * D / (ms3 * 1e-3) / 1e9}
                 e3.close()
+                # the reference's adaptive integrators on the same problem (adaptiveIntegrators.py:65-137 / 361-475; H0 1.0, delta0 0.3,
+                # 20 iterations per launch): one chain per wavefront, the matrix in LDS (wn_k_orbit.hip wide mode / wn_k_wavelds.hip)
+                ad = {}
+                for nm_, ig_ in (("adaptLeapFrogD", L.I_ADAPT_D), ("adaptLeapFrogR2P", L.I_ADAPT_R2P)):
+                    e4 = wa.Engine(D, C, integrator=ig_, H0=1.0, delta0=0.3, stepSizeRandScale=0.2, M=args.M, generated=L.G_Q0_SUMSQ,
+                                   device=dev.index).set_target(L.T_DENSEGAUSS, spec["tpar"])
+                    e4.run(q0d, SEED + 77, 20)
+                    s4, d4 = e4.run(q0d, SEED, 20)
+                    st = float((d4[:, :, 6].sum() + d4[:, :, 7].sum()).item())
+                    ad[nm_] = {"value": st / (e4.last_run_ms() * 1e-3), "unit": "gradient evaluations/s", "kernel": e4.kernel_name, "ms_per_step": e4.last_run_ms()}
+                    e4.close()
+                extras["dense_adaptive"] = ad
             except Exception as ex:
                 extras["error"] = repr(ex)
             # BASELINE configs 3, 4 (one GPU's shard), 5 (one GPU's shard; all three runs of mainSW.py:41-80) at SURVEY 8d's

@@ -283,3 +283,57 @@ def test_two_wave_kernel_is_chosen_only_while_the_chains_leave_simds_idle(wa):
         os.environ.pop("WN_ORBIT2_ANYC", None)
     assert "wn_wave_kernel" in n1 and "wn_orbit2_kernel" in n2, (n1, n2)
     assert same_run(s2, d2, s1, d1)
+
+
+# ---- the adaptive integrators on the headline geometry (round 5): dense Gaussian 65 <= D <= 128, one chain per wavefront, matrix in LDS ----
+def dense_case(D, C, kappa=1e3, seed=5):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_dense_problem
+    return make_dense_problem(D, kappa, C, seed)
+
+
+@pytest.mark.parametrize("D,integ,C", [(100, ol.I_ADAPT_R2P, 37), (100, ol.I_ADAPT_D, 24), (72, ol.I_ADAPT_R2P, 16), (128, ol.I_ADAPT_D, 9), (65, ol.I_ADAPT_R2P, 8)])
+def test_dense_adaptive_runs_one_chain_per_wave_matrix_in_lds(wa, D, integ, C):
+    """adaptLeapFrogD / adaptLeapFrogR2P (adaptiveIntegrators.py:65-137 / 361-475) on the dense Gaussian of BASELINE config 2's geometry:
+    plain sampling runs on the trajectory-first kernel's wide mode (wn_orbit_kernel<dense,NE=2,K=8>: eight chains per workgroup share the
+    matrix in LDS), everything else on the one-stream engine of the same layout (wn_wavelds_kernel).  The two against each other bit for
+    bit, both against the oracle (integers exactly, reals 1e-6), and against the cooperative MFMA layout they replace (WN_DENSE_COOP=1:
+    another summation order -- integers exactly, reals 1e-6)."""
+    A, q0 = dense_case(D, C)
+    iters = 4
+    kw = dict(integrator=integ, H0=0.8, delta0=0.2, M=6)
+    s_new, d_new, name = run_engine(wa, ol.T_DENSEGAUSS, q0, iters, tpar=A, **kw)
+    assert "wn_orbit_kernel<dense,NE=2,K=8" in name, name
+    s_eng, d_eng, name_eng = run_engine(wa, ol.T_DENSEGAUSS, q0, iters, tpar=A, legacy=True, **kw)
+    assert "wn_wavelds_kernel" in name_eng, name_eng
+    assert same_run(s_new, d_new, s_eng, d_eng), (np.argwhere(d_new != d_eng)[:4], np.abs(s_new - s_eng).max())
+    os.environ["WN_DENSE_COOP"] = "1"
+    try:
+        s_co, d_co, name_co = run_engine(wa, ol.T_DENSEGAUSS, q0, iters, tpar=A, **kw)
+    finally:
+        os.environ.pop("WN_DENSE_COOP", None)
+    assert "wn_coop_kernel" in name_co, name_co
+    assert same(d_new[..., INT_COLS], d_co[..., INT_COLS]) and near(s_new, s_co, 1e-6)
+    for c in sorted(set([0, C // 2, C - 1])):
+        o = ol.walnuts(ol.T_DENSEGAUSS, q0[c], integrator=integ, tpar=A.ravel(), H0=0.8, delta0=0.2, numIter=iters, M=6, seed=SEED, chain=c)
+        np.testing.assert_array_equal(d_new[c][:, INT_COLS], o["diagnostics"][:, INT_COLS], err_msg=f"chain {c}")
+        np.testing.assert_allclose(s_new[c].T, o["samples"], rtol=1e-6, atol=1e-9, err_msg=f"chain {c}")
+        np.testing.assert_allclose(d_new[c], o["diagnostics"], rtol=1e-6, atol=1e-9, err_msg=f"chain {c}")
+    assert (d_new[:, :, 6] + d_new[:, :, 7]).sum() > 0
+
+
+def test_dense_adaptive_warmup_and_yoshida_on_the_lds_engine(wa):
+    """What the trajectory-first kernel does not take -- warm-up adaptation, adaptYoshidaD -- runs on wn_wavelds_kernel (the one-stream
+    engine with the matrix in LDS): against the cooperative layout (integers exactly, reals 1e-6)."""
+    A, q0 = dense_case(100, 20)
+    for kw, it in ((dict(integrator=ol.I_ADAPT_R2P, H0=0.8, delta0=0.2, M=5, warmupIter=6), 8),
+                   (dict(integrator=ol.I_ADAPT_YOSHIDA, H0=0.8, delta0=0.1, M=5), 4)):
+        s_new, d_new, name = run_engine(wa, ol.T_DENSEGAUSS, q0, it, tpar=A, **kw)
+        assert "wn_wavelds_kernel" in name, name
+        os.environ["WN_DENSE_COOP"] = "1"
+        try:
+            s_co, d_co, name_co = run_engine(wa, ol.T_DENSEGAUSS, q0, it, tpar=A, **kw)
+        finally:
+            os.environ.pop("WN_DENSE_COOP", None)
+        assert "wn_coop_kernel" in name_co, name_co
+        assert same(d_new[..., INT_COLS], d_co[..., INT_COLS]) and near(s_new, s_co, 1e-6) and near(d_new, d_co, 1e-6)

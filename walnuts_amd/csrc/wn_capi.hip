@@ -91,7 +91,8 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_
     snprintf(nm, sizeof(kc->name), "wn_split_tick_kernel<NE=%d,external>", NE);
     return 0;
   }
-  if (target == T_DENSEGAUSS && D > 64 && D <= 128 && integrator != I_FIXED && !dm && !getenv("WN_DENSE_COOP")) {
+  if (target == T_DENSEGAUSS && D > 64 && D <= 128 && integrator != I_FIXED && integrator != I_ADAPT_FLOWD && !dm && !getenv("WN_DENSE_COOP")) {
+    // (adaptLeapFrogFlowD stays on the cooperative layout: 3.1e8 against 2.7e8 evaluations/s here)
     // the adaptive integrators on the headline geometry (round 5): one chain per wavefront, the matrix in LDS shared by a workgroup's
     // chains (wn_k_wavelds.hip) -- a macro step is per-chain control flow, not a wide tile; WN_DENSE_COOP=1: the cooperative layout below
     kc->layout = 2; kc->p0 = 2; kc->p1 = T_DENSEGAUSS; kc->W = 1;
@@ -529,7 +530,8 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
   }
   if (e->cfg.warmup_iter == 0 && e->cfg.M >= 1 && orbit_wide_run(kc, e->cfg.integrator)) {
     // (round 5) StockWatson's plain sampling runs: the same kernel with vectors of 12 registers per lane
-    snprintf(kc.name, sizeof(kc.name), "wn_orbit_kernel<stockwatson,NE=12,%s>", e->cfg.integrator == WN_I_FIXED ? "fixedLeapFrog" : e->cfg.integrator == WN_I_ADAPT_D ? "adaptLeapFrogD" : "adaptLeapFrogR2P");
+    snprintf(kc.name, sizeof(kc.name), "wn_orbit_kernel<%s,%s>", kc.p1 == T_DENSEGAUSS ? "dense,NE=2,K=8" : "stockwatson,NE=12",
+             e->cfg.integrator == WN_I_FIXED ? "fixedLeapFrog" : e->cfg.integrator == WN_I_ADAPT_D ? "adaptLeapFrogD" : "adaptLeapFrogR2P");
   }
   if (e->cfg.warmup_iter == 0 && e->cfg.M >= 1 && orbit2_run(kc, e->cfg.integrator, e->cfg.n_chains)) {
     // trajectory and bookkeeping on a wave each (wn_k_orbit2.hip)

@@ -52,27 +52,43 @@
 #include "wn_launch.h"
 #include "wn_policy_wave.h"
 #include "wn_orbit.h"
+#include "wn_target_denselds.h"
 
 namespace wn {
 
 
-template <class Tgt, int INTEG, bool FUSED = false, int NE = 1>
-__global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
+template <class T_, class = void> struct tgt_staged { static constexpr bool value = false; };
+template <class T_> struct tgt_staged<T_, typename std::enable_if<(T_::STAGE_DOUBLES > 0)>::type> { static constexpr bool value = true; };
+template <class T_, class = void> struct tgt_batches { static constexpr bool value = false; };
+template <class T_> struct tgt_batches<T_, typename std::enable_if<T_::BATCH_ADAPT>::type> { static constexpr bool value = true; };
+
+// K: chains (wavefronts) per workgroup -- wide mode with a target that stages data in LDS for the workgroup's chains (dense Gaussian)
+template <class Tgt, int INTEG, bool FUSED = false, int NE = 1, int K = 1>
+__global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
   using namespace orbit;
   constexpr bool WIDE = NE > 1;
   static_assert(!(WIDE && FUSED), "a target's own micro step is a one-register form");
   constexpr int DP = NE * 64;
   extern __shared__ double wn_orbit_lds[];
   lds_d* const L = (lds_d*)wn_orbit_lds;
-  const int lane = threadIdx.x;
+  static_assert(K == 1 || NE > 1, "several chains per workgroup: wide mode only (the one-register form keeps its vectors in dynamic LDS)");
+  const int lane = threadIdx.x & 63;
   const int k16 = lane & 15;
   const int row = lane >> 4;
-  const int cl = blockIdx.x;
+  const int cl = blockIdx.x * K + (int)(threadIdx.x >> 6);
   const uint32_t cg = prm.chain0 + (uint32_t)cl;
   const uint32_t seedlo = (uint32_t)prm.seed, seedhi = (uint32_t)(prm.seed >> 32);
   const int D = prm.D, M = prm.M, minC = prm.minC, maxC = prm.maxC;
   Tgt tgt;
-  tgt.init(prm, lane, nullptr);
+  if constexpr (tgt_staged<Tgt>::value) {
+    __shared__ double wn_orbit_stage[Tgt::STAGE_DOUBLES];
+    Tgt::stage(prm, wn_orbit_stage, (int)threadIdx.x, 64 * K);
+    __syncthreads();
+    if (cl >= prm.C) return;  // (no barrier behind this point in wide mode)
+    tgt.init(prm, lane, wn_orbit_stage);
+  } else {
+    tgt.init(prm, lane, nullptr);
+  }
   if constexpr (!WIDE) {
     for (int k = lane; k < lds_doubles(M); k += 64) L[k] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -311,7 +327,7 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
         // wide mode, adaptive integrators: a macro step is tens of evaluations of ~4 k cycles each and the bookkeeping of a leaf a
         // twentieth of that, so nothing is gained by running ahead -- and a mispredicted draw (StockWatson: a fifth of the blocks: the
         // first leaves of a doubling often have weight zero, If != Ib) or a sub-tree U-turn would throw whole macro steps away
-        if constexpr (WIDE && INTEG != I_FIXED) k1 = k0 + 1;
+        if constexpr (WIDE && INTEG != I_FIXED && !tgt_batches<Tgt>::value) k1 = k0 + 1;
         // =========================== the draws of leaves k0 .. k1-1, lane-parallel ===========================
         // In the reference's order an even leaf of a doubling i >= 1 draws the pair's two step sizes (:395), every leaf its
         // R2P uniform (adaptiveIntegrators.py:392) and -- when WnewSum > exp(-699) -- its multinomial uniform (:426); the single leaf
@@ -754,7 +770,7 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
 #if defined(WN_STAMPS)
   WN_STAMP(9);
   if (prm.stamps && lane == 0) {
-    unsigned long long* o = prm.stamps + (size_t)blockIdx.x * 16;
+    unsigned long long* o = prm.stamps + (size_t)cl * 16;
     for (int k = 0; k < 16; ++k) o[k] = st_[k];
   }
 #endif
@@ -763,7 +779,9 @@ __global__ __launch_bounds__(64) void wn_orbit_kernel(Params prm) {
 // ---- host side ----------------------------------------------------------------------------------------------------------
 // plain sampling runs (no trace, no warm-up, no orbit statistics) of the three leapfrog integrators on the <= 16-D targets of the
 // one-chain-per-wave layout; WN_ORBIT_LEGACY=1 keeps the one-stream engine (A/B tests)
-bool orbit_wide_geom(const KernelChoice& kc) { return kc.layout == 2 && kc.p0 == 12 && kc.W == 1 && kc.G == 1 && kc.p1 == T_STOCKWATSON; }
+// wide-mode geometries: StockWatson (12 registers per lane), the dense Gaussian of 65 .. 128 dimensions with its matrix in LDS (2 registers)
+static bool orbit_dense_geom(const KernelChoice& kc) { return kc.layout == 2 && kc.p0 == 2 && kc.W == 1 && kc.G == 1 && kc.p1 == T_DENSEGAUSS; }
+bool orbit_wide_geom(const KernelChoice& kc) { return (kc.layout == 2 && kc.p0 == 12 && kc.W == 1 && kc.G == 1 && kc.p1 == T_STOCKWATSON) || orbit_dense_geom(kc); }
 size_t orbit_wide_work_doubles(int NE, int C, int M) { return (size_t)C * orbit::wide_doubles(NE, M); }
 // Which plain sampling runs of that geometry take the wide mode: fixedLeapFrog (mainSW.py:56-62: a leaf is ONE evaluation, the one-stream
 // engine spends 40 % of it on bookkeeping).  A macro step of the adaptive integrators is 8+ evaluations (minC = 3): its bookkeeping is a
@@ -771,6 +789,8 @@ size_t orbit_wide_work_doubles(int NE, int C, int M) { return (size_t)C * orbit:
 // them here all the same (tests/test_gpu_orbit.py: the generic kernel against that engine, bit for bit).
 bool orbit_wide_run(const KernelChoice& kc, int integrator) {
   if (!orbit_wide_geom(kc) || getenv("WN_ORBIT_LEGACY") || getenv("WN_ORBIT_NOWIDE")) return false;
+  // the dense Gaussian is here for its adaptive runs (wn_k_wavelds.hip): a macro step is an evaluation or two, batches of 16 leaves pay
+  if (orbit_dense_geom(kc)) return integrator == I_ADAPT_D || integrator == I_ADAPT_R2P;
   return integrator == I_FIXED || ((integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && getenv("WN_ORBIT_WIDE_ADAPT"));
 }
 
@@ -821,7 +841,18 @@ static hipError_t go_orbit_wide(const Params& prm, hipStream_t st) {
   return hipGetLastError();
 }
 
+// ... several chains per workgroup: the target stages its data in LDS once for all of them
+template <class Tgt, int NE, int K>
+static hipError_t go_orbit_wide_k(const Params& prm, hipStream_t st) {
+  dim3 grid((prm.C + K - 1) / K), block(64 * K);
+  if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_R2P, false, NE, K>), grid, block, 0, st, prm);
+  else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_D, false, NE, K>), grid, block, 0, st, prm);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 hipError_t launch_orbit(const KernelChoice& kc, const Params& prm, hipStream_t st) {
+  if (orbit_dense_geom(kc)) return go_orbit_wide_k<WTgtDenseLDS<2>, 2, 8>(prm, st);
   if (orbit_wide_geom(kc)) return go_orbit_wide<WTgtStockWatson<12>, 12>(prm, st);
   switch (kc.p1) {
     case T_FUNNEL10: return go_orbit<WTgtFunnel10>(prm, st);
