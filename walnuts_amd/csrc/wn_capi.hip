@@ -161,7 +161,8 @@ size_t kernel_work_doubles(const KernelChoice& kc, int C, int M) {
   // the role-split kernel of the same layout (wn_k_fast.hip) pads every vector to 8 tiles x 4 registers x 64 lanes
   // whatever the dimension: (M+1) slots x (q, v) + 2 proposals + the momentum normals per 16-chain group
   const size_t fast = (((size_t)C + 15) / 16) * (size_t)((M + 1) * 2 + 3) * 2048;
-  return std::max(std::max(coop_work_doubles(NT, kc.W, C, M), fast), fast4_work_doubles(C, M));
+  const size_t wide = orbit_wide_geom(kc) ? orbit_wide_work_doubles(orbit_wide_ne(kc), C, M) : (size_t)0;  // (std / diagonal Gaussian: wn_k_orbit.hip's wide mode)
+  return std::max(std::max(std::max(coop_work_doubles(NT, kc.W, C, M), fast), fast4_work_doubles(C, M)), wide);
 }
 
 // sw_innov.stan:7-51, scalar form (wn_lpfun only; the sampler evaluates WTgtStockWatson in the wave kernel)
@@ -528,9 +529,10 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
     const char* tn = kc.p1 == T_FUNNEL10 ? "funnel10" : kc.p1 == T_CORRGAUSS ? "corrGauss" : kc.p1 == T_SMILE ? "smile" : kc.p1 == T_FUNNEL1 ? "funnel1" : "modFunnel";
     snprintf(kc.name, sizeof(kc.name), "wn_orbit_kernel<%s,%s>", tn, e->cfg.integrator == WN_I_FIXED ? "fixedLeapFrog" : e->cfg.integrator == WN_I_ADAPT_D ? "adaptLeapFrogD" : "adaptLeapFrogR2P");
   }
-  if (e->cfg.warmup_iter == 0 && e->cfg.M >= 1 && orbit_wide_run(kc, e->cfg.integrator)) {
-    // (round 5) StockWatson's plain sampling runs: the same kernel with vectors of 12 registers per lane
-    snprintf(kc.name, sizeof(kc.name), "wn_orbit_kernel<%s,%s>", kc.p1 == T_DENSEGAUSS ? "dense,NE=2,K=8" : "stockwatson,NE=12",
+  if (e->cfg.warmup_iter == 0 && e->cfg.M >= 1 && orbit_wide_run(kc, e->cfg.integrator) && (kc.layout != 1 || (e->cfg.dim > 16 && e->cfg.dim <= 128))) {
+    // (round 5) StockWatson's plain sampling runs -- and the adaptive ones of dense / std / diagonal Gaussians of up to 128 dimensions: the
+    // same kernel with vectors of 12 (2) registers per lane
+    snprintf(kc.name, sizeof(kc.name), "wn_orbit_kernel<%s,%s>", kc.layout == 1 ? "diag,NE=2,K=4" : kc.p1 == T_DENSEGAUSS ? "dense,NE=2,K=8" : "stockwatson,NE=12",
              e->cfg.integrator == WN_I_FIXED ? "fixedLeapFrog" : e->cfg.integrator == WN_I_ADAPT_D ? "adaptLeapFrogD" : "adaptLeapFrogR2P");
   }
   if (e->cfg.warmup_iter == 0 && e->cfg.M >= 1 && orbit2_run(kc, e->cfg.integrator, e->cfg.n_chains)) {

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
     if (cl >= prm.C) return;  // (no barrier behind this point in wide mode)
     tgt.init(prm, lane, wn_orbit_stage);
   } else {
+    if (K > 1 && cl >= prm.C) return;
     tgt.init(prm, lane, nullptr);
   }
   if constexpr (!WIDE) {
@@ -781,7 +782,12 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
 // one-chain-per-wave layout; WN_ORBIT_LEGACY=1 keeps the one-stream engine (A/B tests)
 // wide-mode geometries: StockWatson (12 registers per lane), the dense Gaussian of 65 .. 128 dimensions with its matrix in LDS (2 registers)
 static bool orbit_dense_geom(const KernelChoice& kc) { return kc.layout == 2 && kc.p0 == 2 && kc.W == 1 && kc.G == 1 && kc.p1 == T_DENSEGAUSS; }
-bool orbit_wide_geom(const KernelChoice& kc) { return (kc.layout == 2 && kc.p0 == 12 && kc.W == 1 && kc.G == 1 && kc.p1 == T_STOCKWATSON) || orbit_dense_geom(kc); }
+// ... and std / diagonal Gaussians of 17 .. 128 dimensions, whose adaptive runs otherwise sit in the cooperative layout (coop: layout 1, CK_DIAG = 1)
+static bool orbit_diag_geom(const KernelChoice& kc) { return kc.layout == 1 && kc.p1 == 1 && kc.W == 4 && kc.G == 1 && (kc.p0 == 16 || kc.p0 == 32); }
+bool orbit_wide_geom(const KernelChoice& kc) {
+  return (kc.layout == 2 && kc.p0 == 12 && kc.W == 1 && kc.G == 1 && kc.p1 == T_STOCKWATSON) || orbit_dense_geom(kc) || orbit_diag_geom(kc);
+}
+int orbit_wide_ne(const KernelChoice& kc) { return orbit_diag_geom(kc) ? 2 : kc.p0; }
 size_t orbit_wide_work_doubles(int NE, int C, int M) { return (size_t)C * orbit::wide_doubles(NE, M); }
 // Which plain sampling runs of that geometry take the wide mode: fixedLeapFrog (mainSW.py:56-62: a leaf is ONE evaluation, the one-stream
 // engine spends 40 % of it on bookkeeping).  A macro step of the adaptive integrators is 8+ evaluations (minC = 3): its bookkeeping is a
@@ -791,6 +797,8 @@ bool orbit_wide_run(const KernelChoice& kc, int integrator) {
   if (!orbit_wide_geom(kc) || getenv("WN_ORBIT_LEGACY") || getenv("WN_ORBIT_NOWIDE")) return false;
   // the dense Gaussian is here for its adaptive runs (wn_k_wavelds.hip): a macro step is an evaluation or two, batches of 16 leaves pay
   if (orbit_dense_geom(kc)) return integrator == I_ADAPT_D || integrator == I_ADAPT_R2P;
+  // std / diagonal Gaussian, 17 <= D <= 128: the same argument with a trivial gradient (the cooperative layout's tick machine is what costs)
+  if (orbit_diag_geom(kc)) return (integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && !getenv("WN_DIAG_COOP");
   return integrator == I_FIXED || ((integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && getenv("WN_ORBIT_WIDE_ADAPT"));
 }
 
@@ -803,7 +811,7 @@ bool orbit_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& 
   if (prm.M < 1 || prm.M > MAX_M || (!wide && prm.D > 16) || prm.maxC > 12 || prm.minC < 0 || prm.minC > prm.maxC) return false;
   if (prm.generated != G_IDENTITY && prm.generated != G_FIRSTK && prm.generated != G_Q0_SUMSQ) return false;
   if (getenv("WN_ORBIT_LEGACY")) return false;
-  if (wide) return orbit_wide_run(kc, prm.integrator);
+  if (wide) return orbit_wide_run(kc, prm.integrator) && (!orbit_diag_geom(kc) || (prm.D > 16 && prm.D <= 128));
   switch (kc.p1) {
     case T_FUNNEL10: case T_CORRGAUSS: case T_SMILE: case T_FUNNEL1: case T_MODFUNNEL: return true;
   }
@@ -853,6 +861,7 @@ static hipError_t go_orbit_wide_k(const Params& prm, hipStream_t st) {
 
 hipError_t launch_orbit(const KernelChoice& kc, const Params& prm, hipStream_t st) {
   if (orbit_dense_geom(kc)) return go_orbit_wide_k<WTgtDenseLDS<2>, 2, 8>(prm, st);
+  if (orbit_diag_geom(kc)) return go_orbit_wide_k<WTgtDiag<2>, 2, 4>(prm, st);
   if (orbit_wide_geom(kc)) return go_orbit_wide<WTgtStockWatson<12>, 12>(prm, st);
   switch (kc.p1) {
     case T_FUNNEL10: return go_orbit<WTgtFunnel10>(prm, st);

@@ -37,6 +37,7 @@ int fast4_pairs(int C);
 // trajectory-first / batched-bookkeeping kernel of the one-chain-per-wave layout for <= 16-D targets (wn_k_orbit.hip)
 bool orbit_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm);
 hipError_t launch_orbit(const KernelChoice& kc, const Params& prm, hipStream_t st);
+int orbit_wide_ne(const KernelChoice& kc);                      // registers per lane and vector of that mode
 bool orbit_wide_geom(const KernelChoice& kc);                   // wn_k_orbit.hip's wide mode (StockWatson: vectors of 12 registers per lane)
 size_t orbit_wide_work_doubles(int NE, int C, int M);
 bool orbit_wide_run(const KernelChoice& kc, int integrator);   // ... and which integrators' plain sampling runs take it
