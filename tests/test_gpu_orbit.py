@@ -285,14 +285,15 @@ def test_two_wave_kernel_is_chosen_only_while_the_chains_leave_simds_idle(wa):
     assert same_run(s2, d2, s1, d1)
 
 
-# ---- the adaptive integrators on the headline geometry (round 5): dense Gaussian 65 <= D <= 128, one chain per wavefront, matrix in LDS ----
+# ---- the adaptive integrators on the headline geometry (round 5): dense Gaussian 17 <= D <= 128, one chain per wavefront, matrix in LDS ----
 def dense_case(D, C, kappa=1e3, seed=5):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import make_dense_problem
     return make_dense_problem(D, kappa, C, seed)
 
 
-@pytest.mark.parametrize("D,integ,C", [(100, ol.I_ADAPT_R2P, 37), (100, ol.I_ADAPT_D, 24), (72, ol.I_ADAPT_R2P, 16), (128, ol.I_ADAPT_D, 9), (65, ol.I_ADAPT_R2P, 8)])
+@pytest.mark.parametrize("D,integ,C", [(100, ol.I_ADAPT_R2P, 37), (100, ol.I_ADAPT_D, 24), (72, ol.I_ADAPT_R2P, 16), (128, ol.I_ADAPT_D, 9), (65, ol.I_ADAPT_R2P, 8),
+                                       (40, ol.I_ADAPT_D, 19), (64, ol.I_ADAPT_R2P, 10), (17, ol.I_ADAPT_R2P, 12)])
 def test_dense_adaptive_runs_one_chain_per_wave_matrix_in_lds(wa, D, integ, C):
     """adaptLeapFrogD / adaptLeapFrogR2P (adaptiveIntegrators.py:65-137 / 361-475) on the dense Gaussian of BASELINE config 2's geometry:
     plain sampling runs on the trajectory-first kernel's wide mode (wn_orbit_kernel<dense,NE=2,K=8>: eight chains per workgroup share the

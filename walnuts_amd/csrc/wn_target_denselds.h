@@ -7,7 +7,7 @@ namespace wn {
 
 template <int NE>
 struct WTgtDenseLDS {
-  static_assert(NE == 2, "65 <= D <= 128: two registers per lane");
+  static_assert(NE == 2, "D <= 128: two registers per lane (the second one empty up to D = 64)");
   static constexpr int EXT = EXT_NONE;
   static constexpr int LDS_DOUBLES = 0;  // (the matrix is the kernel's own shared array, handed to init() as `lds`)
   static constexpr int VEC_LDS = 0;
@@ -26,6 +26,21 @@ struct WTgtDenseLDS {
     // staged matrix are zero, so the last block needs no mask).  Two accumulators per row half: the FMA chain is not the critical path.
     double g0a = 0.0, g0b = 0.0, g1a = 0.0, g1b = 0.0;
     const int dpad = (D + 7) & ~7;
+    if (D <= 64) {  // (uniform) rows 64 .. 127 are empty: half the LDS reads, which are what bounds this loop
+#pragma unroll 1
+      for (int j0 = 0; j0 < dpad; j0 += 8) {
+        double a0[8], qj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a0[u] = A[(j0 + u) * 128];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) qj[u] = wn_readlane(q[0], j0 + u);
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { g0a = fma(a0[u], qj[u], g0a); g0b = fma(a0[u + 1], qj[u + 1], g0b); }
+      }
+      const double g0 = g0a + g0b;
+      g[0] = g0; g[1] = 0.0;
+      return q[0] * g0;
+    }
 #pragma unroll 1
     for (int j0 = 0; j0 < dpad; j0 += 8) {
       double a0[8], a1[8], qj[8];
