@@ -73,7 +73,13 @@ def test_headline_kernels_do_not_read_stale_lds(wa):
 def test_one_stream_adaptive_kernel_does_not_read_stale_lds(wa):
     A, q0 = _dense(64, 512)
     mk = lambda: wa.Engine(64, 512, integrator=ol.I_ADAPT_R2P, H0=0.5, delta0=0.3, M=7).set_target(ol.T_DENSEGAUSS, A)
-    assert "wn_coop_kernel" in _three_runs(wa, mk, q0, 3)
+    assert "wn_coop_kernel" in _three_runs(wa, mk, q0, 3, env={"WN_DENSE_COOP": "1"})
+    # round 5: these runs are one chain per wavefront with the matrix staged in LDS (every word of the staging array is written)
+    assert "wn_orbit_kernel<dense" in _three_runs(wa, mk, q0, 3)
+    assert "wn_wavelds_kernel" in _three_runs(wa, mk, q0, 3, env={"WN_ORBIT_LEGACY": "1"})
+    A1, q1 = _dense(100, 300)
+    mk1 = lambda: wa.Engine(100, 300, integrator=ol.I_ADAPT_D, H0=0.5, delta0=0.3, M=6).set_target(ol.T_DENSEGAUSS, A1)
+    assert "wn_orbit_kernel<dense" in _three_runs(wa, mk1, q1, 3)
 
 
 def test_funnel_wave_kernel_does_not_read_stale_lds(wa):

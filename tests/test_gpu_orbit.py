@@ -341,11 +341,14 @@ def test_dense_adaptive_warmup_and_yoshida_on_the_lds_engine(wa):
 
 
 @pytest.mark.parametrize("target,D,integ,C", [(ol.T_STDGAUSS, 60, ol.I_ADAPT_R2P, 21), (ol.T_DIAGGAUSS, 100, ol.I_ADAPT_D, 13), (ol.T_DIAGGAUSS, 17, ol.I_ADAPT_R2P, 9),
-                                              (ol.T_STDGAUSS, 128, ol.I_ADAPT_D, 6), (ol.T_DIAGGAUSS, 64, ol.I_ADAPT_R2P, 5)])
+                                              (ol.T_STDGAUSS, 128, ol.I_ADAPT_D, 6), (ol.T_DIAGGAUSS, 64, ol.I_ADAPT_R2P, 5),
+                                              (ol.T_STDGAUSS, 200, ol.I_ADAPT_R2P, 7), (ol.T_DIAGGAUSS, 256, ol.I_ADAPT_D, 5), (ol.T_DIAGGAUSS, 300, ol.I_ADAPT_R2P, 6),
+                                              (ol.T_STDGAUSS, 512, ol.I_ADAPT_D, 3)])
 def test_std_and_diagonal_gaussians_adaptive_runs_one_chain_per_wave(wa, target, D, integ, C):
     """The reference's Gaussian scaling experiments (mainGaussESS.py / mainGaussTransient.py: stdGauss with the adaptive integrators over D):
-    plain adaptLeapFrogD / R2P runs of std / diagonal Gaussians of 17 .. 128 dimensions on the trajectory-first kernel's wide mode
-    (wn_orbit_kernel<diag,NE=2,K=4>; 2.4-3.5x the cooperative layout, tools/adapt_std.py) -- against that layout (WN_DIAG_COOP=1: another
+    plain adaptLeapFrogD / R2P runs of std / diagonal Gaussians of 17 .. 512 dimensions on the trajectory-first kernel's wide mode
+    (wn_orbit_kernel<diag,NE=2|4|8,K=4>; 2.4-3.5x the cooperative layout up to 128 dimensions, 2-2.5x / 1.1-1.3x the wave layout's one-stream
+    engine up to 256 / 512, tools/adapt_std.py) -- against that layout (WN_DIAG_COOP=1: another
     summation order: integers exactly, reals 1e-6) and against the oracle."""
     rng = np.random.default_rng(D)
     tpar = None if target == ol.T_STDGAUSS else np.geomspace(0.25, 6.0, D)
@@ -353,13 +356,13 @@ def test_std_and_diagonal_gaussians_adaptive_runs_one_chain_per_wave(wa, target,
     iters = 5
     kw = dict(integrator=integ, H0=1.3 * D ** -0.25, delta0=0.2, M=6)
     s_new, d_new, name = run_engine(wa, target, q0, iters, tpar=tpar, **kw)
-    assert "wn_orbit_kernel<diag,NE=2,K=4" in name, name
+    assert ("wn_orbit_kernel<diag,NE=%d,K=4" % (2 if D <= 128 else 4 if D <= 256 else 8)) in name, name
     os.environ["WN_DIAG_COOP"] = "1"
     try:
         s_co, d_co, name_co = run_engine(wa, target, q0, iters, tpar=tpar, **kw)
     finally:
         os.environ.pop("WN_DIAG_COOP", None)
-    assert "wn_coop_kernel" in name_co, name_co
+    assert ("wn_coop_kernel" if D <= 128 else "wn_wave_kernel<NE=8,diag>") in name_co, name_co  # (129 .. 512: the one-stream engine of the wave layout)
     assert same(d_new[..., INT_COLS], d_co[..., INT_COLS]) and near(s_new, s_co, 1e-6) and near(d_new, d_co, 1e-6)
     for c in sorted(set([0, C - 1])):
         o = ol.walnuts(target, q0[c], integrator=integ, tpar=tpar, H0=kw["H0"], delta0=0.2, numIter=iters, M=6, seed=SEED, chain=c)

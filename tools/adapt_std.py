@@ -8,7 +8,7 @@ import walnuts_amd as wa
 from walnuts_amd import _lib as L
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dev = torch.device("cuda", 0)
-for D in (32, 64, 100, 128):
+for D in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (32, 64, 100, 128)):
     q = torch.as_tensor(np.random.default_rng(1).normal(size=(C, D)), device=dev)
     for name, ig, kw in (("adaptLeapFrogD", L.I_ADAPT_D, dict(H0=1.4 * D ** -0.25, delta0=0.3)), ("adaptLeapFrogR2P", L.I_ADAPT_R2P, dict(H0=1.4 * D ** -0.25, delta0=0.3))):
         for env in ({}, {"WN_DIAG_COOP": "1"}):
