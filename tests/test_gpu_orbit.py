@@ -324,12 +324,14 @@ def test_dense_adaptive_runs_one_chain_per_wave_matrix_in_lds(wa, D, integ, C):
 
 
 def test_dense_adaptive_warmup_and_yoshida_on_the_lds_engine(wa):
-    """What the trajectory-first kernel does not take -- warm-up adaptation, adaptYoshidaD -- runs on wn_wavelds_kernel (the one-stream
-    engine with the matrix in LDS): against the cooperative layout (integers exactly, reals 1e-6)."""
+    """What the trajectory-first kernel does not take (adaptYoshidaD; traced runs, orbit statistics) runs on wn_wavelds_kernel, the one-stream
+    engine with the matrix in LDS -- and so does everything with WN_ORBIT_LEGACY=1, e.g. warm-up adaptation: against the cooperative layout
+    (integers exactly, reals 1e-6)."""
     A, q0 = dense_case(100, 20)
     for kw, it in ((dict(integrator=ol.I_ADAPT_R2P, H0=0.8, delta0=0.2, M=5, warmupIter=6), 8),
                    (dict(integrator=ol.I_ADAPT_YOSHIDA, H0=0.8, delta0=0.1, M=5), 4)):
-        s_new, d_new, name = run_engine(wa, ol.T_DENSEGAUSS, q0, it, tpar=A, **kw)
+        # (legacy: warm-up iterations of plain runs are the trajectory-first kernel's since its WARM instantiations -- the test below)
+        s_new, d_new, name = run_engine(wa, ol.T_DENSEGAUSS, q0, it, tpar=A, legacy=True, **kw)
         assert "wn_wavelds_kernel" in name, name
         os.environ["WN_DENSE_COOP"] = "1"
         try:
@@ -369,3 +371,70 @@ def test_std_and_diagonal_gaussians_adaptive_runs_one_chain_per_wave(wa, target,
         np.testing.assert_array_equal(d_new[c][:, INT_COLS], o["diagnostics"][:, INT_COLS], err_msg=f"chain {c}")
         np.testing.assert_allclose(s_new[c].T, o["samples"], rtol=1e-6, atol=1e-9, err_msg=f"chain {c}")
         np.testing.assert_allclose(d_new[c], o["diagnostics"], rtol=1e-6, atol=1e-9, err_msg=f"chain {c}")
+
+
+# ---- warm-up iterations on the trajectory-first kernel (round 5: WARM instantiations; mainFunnel.py:27-29, example.py:25-27 run
+# adaptLeapFrogR2P with warmupIter = 1000) ----
+def test_orbit_kernel_runs_the_warmup_iterations_funnel(wa):
+    """funnel10 / adaptLeapFrogR2P with warm-up adaptation of H and delta (WALNUTS.py:701-712; mainFunnel.py:27-29): the trajectory-first
+    kernel against the one-stream engine with the engine's micro-step arithmetic (WN_ORBIT_EXACT).  Not bit for bit: the first iteration's
+    energy error differs in its last bit between the two kernels (H0 comes from lp(q0), evaluated at another inlined site: same_run), the
+    warm-up feeds it into delta and H, and the funnel's dynamics amplify it -- 5e-13 in H at iteration 4, 1e-6 at iteration 17, with the
+    oracle's value in between.  So: integer diagnostics exactly over the whole run, the adapted H / delta to 1e-4 throughout; the default arithmetic (one reduction per micro step) against the oracle over the first iterations."""
+    C, iters, W = 96, 40, 25
+    q0 = funnel_q0(C, seed=31)
+    kw = dict(integrator=ol.I_ADAPT_R2P, H0=0.3, delta0=0.3, M=8, warmupIter=W)
+    s_new, d_new, name = run_engine(wa, ol.T_FUNNEL10, q0, iters, **kw)
+    assert "wn_orbit_kernel<funnel10" in name, name
+    s_old, d_old, name_old = run_engine(wa, ol.T_FUNNEL10, q0, iters, legacy=True, **kw)
+    assert "wn_wave_kernel" in name_old, name_old
+    assert same(d_new[..., INT_COLS], d_old[..., INT_COLS]), (np.argwhere(d_new[..., INT_COLS] != d_old[..., INT_COLS])[:5])
+    assert near(d_new[..., [15, 18]], d_old[..., [15, 18]], 1e-4)
+    assert len(np.unique(d_new[:, :W, 15])) > 10 and len(np.unique(d_new[:, :W, 18])) > 10  # H and delta do adapt
+    assert (d_new[:, W:, 15] == d_new[:, W:W + 1, 15]).all()                                 # and stay put behind the warm-up
+    s_f, d_f, _ = run_engine(wa, ol.T_FUNNEL10, q0, iters, exact=False, **kw)
+    for c in (0, 50, 95):
+        o = ol.walnuts(ol.T_FUNNEL10, q0[c], integrator=ol.I_ADAPT_R2P, H0=0.3, delta0=0.3, numIter=iters, warmupIter=W, M=8, seed=SEED, chain=c)
+        np.testing.assert_array_equal(d_f[c][:12, INT_COLS], o["diagnostics"][:12, INT_COLS], err_msg=f"chain {c}")
+        np.testing.assert_allclose(d_f[c][:12, [15, 18]], o["diagnostics"][:12, [15, 18]], rtol=1e-6, err_msg=f"chain {c}")
+        np.testing.assert_allclose(s_f[c].T[:, :4], o["samples"][:, :4], rtol=1e-6, atol=1e-9, err_msg=f"chain {c}")
+
+
+@pytest.mark.parametrize("what", ["std60_R2P", "diag100_D", "dense100_R2P", "std300_D", "smile_R2P"])
+def test_orbit_kernel_runs_the_warmup_iterations_wide_and_2d(wa, what):
+    """Warm-up on the wide-mode geometries (std / diagonal / dense Gaussians) and a 2-D target: against the kernels these
+    runs used before (cooperative layout / one-stream engines: integers exactly, reals 1e-6) and the oracle."""
+    rng = np.random.default_rng(7)
+    iters, W = 24, 16
+    env = {}
+    if what == "std60_R2P":
+        target, tpar, q0, kw, env, old = ol.T_STDGAUSS, None, rng.normal(size=(18, 60)), dict(integrator=ol.I_ADAPT_R2P, H0=0.5, delta0=0.2, M=6), {"WN_DIAG_COOP": "1"}, "wn_coop_kernel"
+    elif what == "diag100_D":
+        tpar = np.geomspace(0.3, 5.0, 100)
+        target, q0, kw, env, old = ol.T_DIAGGAUSS, rng.normal(size=(11, 100)) / np.sqrt(tpar), dict(integrator=ol.I_ADAPT_D, H0=0.4, delta0=0.2, M=6), {"WN_DIAG_COOP": "1"}, "wn_coop_kernel"
+    elif what == "dense100_R2P":
+        A, q0 = dense_case(100, 14)
+        target, tpar, kw, env, old = ol.T_DENSEGAUSS, A, dict(integrator=ol.I_ADAPT_R2P, H0=0.8, delta0=0.2, M=6), {"WN_ORBIT_LEGACY": "1"}, "wn_wavelds_kernel"
+    elif what == "std300_D":
+        target, tpar, q0, kw, env, old = ol.T_STDGAUSS, None, rng.normal(size=(6, 300)), dict(integrator=ol.I_ADAPT_D, H0=0.35, delta0=0.2, M=5), {"WN_DIAG_COOP": "1"}, "wn_wave_kernel"
+    else:
+        target, tpar, q0, kw, env, old = ol.T_SMILE, None, rng.normal(size=(40, 2)), dict(integrator=ol.I_ADAPT_R2P, H0=0.3, delta0=0.2, M=7), {"WN_ORBIT_LEGACY": "1"}, "wn_wave_kernel"
+    kw = dict(kw, warmupIter=W)
+    s_new, d_new, name = run_engine(wa, target, q0, iters, tpar=tpar, **kw)
+    assert "wn_orbit_kernel" in name, name
+    for k, v in env.items():
+        os.environ[k] = v
+    try:
+        s_old, d_old, name_old = run_engine(wa, target, q0, iters, tpar=tpar, legacy="WN_ORBIT_LEGACY" in env, **kw)
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+    assert old in name_old and "wn_orbit_kernel" not in name_old, name_old
+    assert same(d_new[..., INT_COLS], d_old[..., INT_COLS]), np.argwhere(d_new[..., INT_COLS] != d_old[..., INT_COLS])[:5]
+    assert near(s_new, s_old, 1e-6) and near(d_new, d_old, 1e-6)
+    assert len(np.unique(d_new[:, :W, 15])) > 5
+    c = q0.shape[0] - 1
+    o = ol.walnuts(target, q0[c], integrator=kw["integrator"], tpar=None if tpar is None else np.asarray(tpar).ravel(), H0=kw["H0"], delta0=kw.get("delta0", 0.05),
+                   numIter=iters, warmupIter=W, M=kw["M"], seed=SEED, chain=c)
+    np.testing.assert_array_equal(d_new[c][:, INT_COLS], o["diagnostics"][:, INT_COLS])
+    np.testing.assert_allclose(d_new[c], o["diagnostics"], rtol=1e-6, atol=1e-9)

@@ -72,20 +72,26 @@ def test_headline_kernel_warmup_instantiations_have_no_scratch(tmp_path):
 
 @pytest.mark.timeout(900)
 def test_orbit_kernel_has_no_flat_or_scratch_instructions(tmp_path):
+    """wn_orbit_kernel<Tgt, INTEG, FUSED, NE, K, WARM> (mangled: ...ELi<INTEG>ELb<FUSED>ELi<NE>ELi<K>ELb<WARM>EEEv...): no FLAT access anywhere
+    (ring, slots and proposals are LDS- or global-address-space accesses); the one-register instantiations (NE = 1: funnel10 and the 2-D
+    targets, BASELINE config 3) keep everything in registers, with or without the warm-up code; so do the plain wide ones of the Gaussians
+    up to 4 registers per lane.  Known and measured: StockWatson's adaptive one-wave instantiations (three states of 36 doubles around a
+    backward search: not routed by default), the dense Gaussian's WARM ones (256-register cap at two waves per SIMD: 2-4 spilled registers
+    outside the micro-step loop)."""
     ks, meta = kernels_of("wn_k_orbit", tmp_path)
     hot = [k for k in ks if "wn_orbit_kernel" in k]
-    assert len(hot) >= 18  # five targets x three integrators + the wide mode (StockWatson, 12 registers per lane) x three
+    assert len(hot) >= 40, len(hot)
+    one_reg = lambda k: re.search(r"ELb[01]ELi1ELi1ELb[01]EEEv", k) is not None
+    assert sum(one_reg(k) for k in hot) >= 30
     for k in hot:
         assert not re.search(r"\bflat_(load|store|atomic)", ks[k]), k
-        # (the wide mode's adaptive instantiations hold three states of 36 doubles around a backward search: a few spills to scratch, measured
-        #  and not routed by default -- wn_k_orbit.hip orbit_wide_run; its fixedLeapFrog instantiation and every one-register one: none)
-        if "WTgtStockWatson" not in k or "EELi0ELb0ELi12EEEv" in k:
+        plain_small_wide = re.search(r"(WTgtDiagILi[24]E|WTgtDenseLDS).*ELb0EEEv", k) is not None
+        sw_fixed = "WTgtStockWatson" in k and "EELi0ELb0ELi12E" in k
+        if one_reg(k) or plain_small_wide or sw_fixed:
             assert not re.search(r"\bscratch_", ks[k]), k
     for name, m in meta.items():
-        if "wn_orbit_kernel" in name and "WTgtStockWatson" not in name:
+        if "wn_orbit_kernel" in name and one_reg(name):
             assert m["scratch"] == 0 and m["vgpr_spill"] == 0, (name, m)
-        if "wn_orbit_kernel" in name and "WTgtStockWatson" in name and "EELi0ELb0ELi12EEEv" in name:
-            assert m["scratch"] == 0, (name, m)
 
 
 @pytest.mark.timeout(900)

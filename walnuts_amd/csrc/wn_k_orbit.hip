@@ -63,7 +63,9 @@ template <class T_, class = void> struct tgt_batches { static constexpr bool val
 template <class T_> struct tgt_batches<T_, typename std::enable_if<T_::BATCH_ADAPT>::type> { static constexpr bool value = true; };
 
 // K: chains (wavefronts) per workgroup -- wide mode with a target that stages data in LDS for the workgroup's chains (dense Gaussian)
-template <class Tgt, int INTEG, bool FUSED = false, int NE = 1, int K = 1>
+// WARM: the instantiation that also runs the warm-up iterations (WALNUTS.py:701-712: step size H from the P2 quantile of log(igrConst), delta
+// from the quantile of the orbits' energy errors -- wn_p2_push / wn_adapt_update of wn_chain.h, the functions every other kernel uses)
+template <class Tgt, int INTEG, bool FUSED = false, int NE = 1, int K = 1, bool WARM = false>
 __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
   using namespace orbit;
   constexpr bool WIDE = NE > 1;
@@ -142,7 +144,11 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
   bool predF = true, predB = true;  // "the next leaf in this direction takes its multinomial draw"
   const bool inrange = cl < prm.C;
   const int clc = inrange ? cl : 0;
-  const double dlt = prm.delta, Hc = prm.H;
+  double dlt = prm.delta, Hc = prm.H;  // (WARM: adapted at the end of every warm-up iteration)
+  double p2q[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  int p2m[5] = {1, 2, 3, 4, 5}, p2n = 0;
+  double igr_pass = 0.0;  // WARM: igrConst of the pass run_pass ran last (adaptiveIntegrators.py:101 / 399 / 424)
+  (void)p2q; (void)p2m; (void)p2n; (void)igr_pass;
 
   // element held by register e of this lane (parameter index), or -1
   auto gidx = [&](int e) -> int {
@@ -222,6 +228,8 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
     const double hh = ldexp(hcur, -cc);  // h / 2**c (exact scaling either way)
     const int nstep = 1 << cc;
     bool allfin = isfinite(HamStart);
+    double Hprev = HamStart, madv = -INFINITY;  // WARM: np.max(np.abs(np.diff(Hams))) of this pass
+    bool madnan = false;
     const double hh2 = 0.5 * hh, hq = hh;
     int s = nstep;
 #pragma unroll 1
@@ -240,13 +248,21 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
       const double Hi = -lpp + 0.5 * ke;  // Hams[i] = -fnew + 0.5*sum(vv*vv)
       lpC = lpp; HC = Hi;
       allfin = allfin && isfinite(Hi);
+      if constexpr (WARM) {
+        const double df = fabs(Hi - Hprev);
+        madnan = madnan || isnan(df);
+        madv = df > madv ? df : madv;  // (a NaN difference compares false: it is carried by madnan)
+        Hprev = Hi;
+      }
     } while (--s);
+    if constexpr (WARM) igr_pass = hh * pow(madnan ? NAN : madv, -1.0 / 3.0);
     nev += nstep;
     return uni_b(allfin && (fabs(HamStart - HC) < dlt));  // all(isfinite(Hams)) and abs(Hams[0]-Hams[-1]) < delta  (:87-94)
   };
   // ---- per-leaf records of the running block, lane k (of every row) = leaf k: written by the T phase with selects, read by the R
   // phase where they are ----
-  double HnV = 0.0, lpV = 0.0, hV = 0.0, upV = 0.0, urV = 0.0;
+  double HnV = 0.0, lpV = 0.0, hV = 0.0, upV = 0.0, urV = 0.0, lgV = 0.0;  // (lgV, WARM: log(igrConst) of the leaf, WALNUTS.py:313)
+  (void)lgV;
   int iA = 0, iB = 0;  // If | Ib << 8 | c << 16;  nEvalF | nEvalB << 16
   // ring stores without an exec mask: lanes >= 16 write to the dump area
   const int ring_base = lane < 16 ? RQ + lane : DUMP + lane;
@@ -376,6 +392,7 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
             if (INTEG == I_FIXED) {  // adaptiveIntegrators.py:49-59
               run_pass(qa, vin, ga, Ham0, 0, qw, vw, gw, lpC, HC, nEvF);
               If = Ib = cret = 0; lpn = lpC; Hn = HC;
+              if constexpr (WARM) igr_pass = hcur * pow(fmax(1.0e-10, fabs(Ham0 - Hn)), -1.0 / 3.0);  // adaptiveIntegrators.py:59
             } else {
               int cc = minC;  // forward search (:69-94 / 366-389); the first pass is peeled: it is accepted in 94 % of the busiest chains' macro
               // steps, and the likely path then falls through one not-taken branch instead of leaving a loop through two taken ones
@@ -393,11 +410,13 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
               int cSim = If, maxTry = If - 1;
               Ib = If;
               lpn = lpC; Hn = HC;
+              double igr_leaf = igr_pass;  // (the forward pass that is used -- or, below, the re-integration at If + 1; not the backward passes)
               if (__builtin_expect(!keep || maxTry >= minC, 0)) {  // (the common macro step -- first pass accepted, kept -- skips all of this)
                 if (!keep) {  // :400-424, 434-437
                   run_pass(qa, vin, ga, Ham0, If + 1, qw, vw, gw, lpC, HC, nEvF);
                   cSim = If + 1; maxTry = maxC; Ib = maxC;
                   lpn = lpC; Hn = HC;
+                  igr_leaf = igr_pass;
                 }
                 if (maxTry >= minC) {  // backward search from (qOut, -vOut, gOut)  (:107-132 / 440-464)
                   double qo[NE], vo[NE], go[NE], vneg[NE];
@@ -412,6 +431,7 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
                 }
               }
               cret = INTEG == I_ADAPT_R2P ? cSim : If;  // :135-137 / 466-475 (lwt follows from If, Ib, c: the R phase forms it)
+              igr_pass = igr_leaf;
             }
             WN_STAMP(2);
             // intOut.v is in forward-time orientation (adaptiveIntegrators.py:57,135,473); the new state becomes the active end
@@ -422,6 +442,7 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
             {
               const bool mk = k16 == k;
               HnV = mk ? Hn : HnV; lpV = mk ? lpn : lpV;
+              if constexpr (WARM) { const double lg = log(igr_pass); lgV = mk ? lg : lgV; }
               iA = mk ? (If | (Ib << 8) | (cret << 16)) : iA;
               iB = mk ? (nEvF | (nEvB << 16)) : iB;
             }
@@ -643,6 +664,10 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
           v4 = rowsum_i(macc ? v4 : 0);
           nevalF += rl_i(v4, 0); nevalB += rl_i(v4, 16); nneq += rl_i(v4, 32); nzero += rl_i(v4, 48);
           nused += A_end - k0 + 1;
+          if constexpr (WARM) if (iter <= prm.warmupIter && prm.adaptH) {  // igrConstQ.push(np.log(intOut.igrConst)), leaf by leaf (:313)
+#pragma unroll 1
+            for (int j = k0; j <= A_end; ++j) wn_p2_push(prm, p2q, p2m, p2n, wn_readlane(lgV, j));
+          }
           if (INTEG != I_FIXED) {
             int m4 = row == 0 ? If_k : row == 1 ? c_k : row == 2 ? -If_k : -c_k;
             m4 = rowmin_i(macc ? m4 : (1 << 30));
@@ -764,6 +789,11 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
       for (int kk = 0; kk < NDIAG; ++kk) vv = lane == kk ? d[kk] : vv;
       if (lane < NDIAG) prm.diag[((size_t)clc * prm.numIter + (iter - 1)) * NDIAG + lane] = vv;
     }
+    if constexpr (WARM) if (iter <= prm.warmupIter) {  // tuning parameter adaptation (:701-712), behind the diagnostics row: it holds the values this iteration ran with
+      double* const fc = prm.facs ? prm.facs + (size_t)clc * 2 * (size_t)prm.warmupIter : nullptr;
+      const double err = Hnan ? NAN : (Hmax - Hmin);
+      wn_adapt_update(prm, iter, err, fc, lane == 0, dlt, Hc, p2q, p2n);
+    }
     iter++;
     if (iter > prm.numIter) live = false;
   }
@@ -807,7 +837,9 @@ bool orbit_wide_run(const KernelChoice& kc, int integrator) {
 bool orbit_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm) {
   const bool wide = orbit_wide_geom(kc);
   if (!wide && (kc.layout != 2 || kc.p0 != 1 || kc.W != 1 || kc.G != 1)) return false;
-  if (warm || prm.mode != MODE_SAMPLE || prm.trace_n || prm.trace || prm.omin) return false;
+  // (warm-up iterations run here as well, except StockWatson's: its WARM instantiations are not built)
+  if (warm && kc.layout == 2 && kc.p1 == T_STOCKWATSON) return false;
+  if (prm.mode != MODE_SAMPLE || prm.trace_n || prm.trace || prm.omin) return false;
   if (adapt == 2) return false;
   if (prm.integrator != I_FIXED && prm.integrator != I_ADAPT_D && prm.integrator != I_ADAPT_R2P) return false;
   if (prm.M < 1 || prm.M > MAX_M || (!wide && prm.D > 16) || prm.maxC > 12 || prm.minC < 0 || prm.minC > prm.maxC) return false;
@@ -829,6 +861,19 @@ static hipError_t go_orbit(const Params& prm, hipStream_t st) {
   dim3 grid(prm.C), block(64);
   // a target with a micro step of its own (one reduction instead of two) runs it unless WN_ORBIT_EXACT=1 asks for the arithmetic of
   // the one-stream engine (the bit-for-bit comparisons of tests/test_gpu_orbit.py)
+  const bool warm = prm.warmupIter > 0;  // (the warm-up iterations run here too: WARM instantiations, each target's default arithmetic)
+  if (warm) {
+    if constexpr (has_fused_step<Tgt>::value) if (!getenv("WN_ORBIT_EXACT")) {
+      if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_R2P, true, 1, 1, true>), grid, block, dyn, st, prm);
+      else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_D, true, 1, 1, true>), grid, block, dyn, st, prm);
+      else hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_FIXED, true, 1, 1, true>), grid, block, dyn, st, prm);
+      return hipGetLastError();
+    }
+    if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_R2P, false, 1, 1, true>), grid, block, dyn, st, prm);
+    else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_D, false, 1, 1, true>), grid, block, dyn, st, prm);
+    else hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_FIXED, false, 1, 1, true>), grid, block, dyn, st, prm);
+    return hipGetLastError();
+  }
   if constexpr (has_fused_step<Tgt>::value) if (!getenv("WN_ORBIT_EXACT")) {
     if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_R2P, true>), grid, block, dyn, st, prm);
     else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_D, true>), grid, block, dyn, st, prm);
@@ -855,6 +900,12 @@ static hipError_t go_orbit_wide(const Params& prm, hipStream_t st) {
 template <class Tgt, int NE, int K>
 static hipError_t go_orbit_wide_k(const Params& prm, hipStream_t st) {
   dim3 grid((prm.C + K - 1) / K), block(64 * K);
+  if (prm.warmupIter > 0) {
+    if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_R2P, false, NE, K, true>), grid, block, 0, st, prm);
+    else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_D, false, NE, K, true>), grid, block, 0, st, prm);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_R2P, false, NE, K>), grid, block, 0, st, prm);
   else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_D, false, NE, K>), grid, block, 0, st, prm);
   else return hipErrorInvalidValue;
