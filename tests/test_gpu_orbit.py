@@ -345,11 +345,12 @@ def test_dense_adaptive_warmup_and_yoshida_on_the_lds_engine(wa):
 @pytest.mark.parametrize("target,D,integ,C", [(ol.T_STDGAUSS, 60, ol.I_ADAPT_R2P, 21), (ol.T_DIAGGAUSS, 100, ol.I_ADAPT_D, 13), (ol.T_DIAGGAUSS, 17, ol.I_ADAPT_R2P, 9),
                                               (ol.T_STDGAUSS, 128, ol.I_ADAPT_D, 6), (ol.T_DIAGGAUSS, 64, ol.I_ADAPT_R2P, 5),
                                               (ol.T_STDGAUSS, 200, ol.I_ADAPT_R2P, 7), (ol.T_DIAGGAUSS, 256, ol.I_ADAPT_D, 5), (ol.T_DIAGGAUSS, 300, ol.I_ADAPT_R2P, 6),
-                                              (ol.T_STDGAUSS, 512, ol.I_ADAPT_D, 3)])
+                                              (ol.T_STDGAUSS, 512, ol.I_ADAPT_D, 3), (ol.T_STDGAUSS, 10, ol.I_ADAPT_R2P, 33), (ol.T_DIAGGAUSS, 16, ol.I_ADAPT_D, 20),
+                                              (ol.T_DIAGGAUSS, 3, ol.I_ADAPT_R2P, 17)])
 def test_std_and_diagonal_gaussians_adaptive_runs_one_chain_per_wave(wa, target, D, integ, C):
     """The reference's Gaussian scaling experiments (mainGaussESS.py / mainGaussTransient.py: stdGauss with the adaptive integrators over D):
-    plain adaptLeapFrogD / R2P runs of std / diagonal Gaussians of 17 .. 512 dimensions on the trajectory-first kernel's wide mode
-    (wn_orbit_kernel<diag,NE=2|4|8,K=4>; 2.4-3.5x the cooperative layout up to 128 dimensions, 2-2.5x / 1.1-1.3x the wave layout's one-stream
+    adaptLeapFrogD / R2P runs of std / diagonal Gaussians of up to 512 dimensions on the trajectory-first kernel (one register per lane up to
+    16 dimensions: 3-5x the cooperative layout; beyond it the wide mode, wn_orbit_kernel<diag,NE=2|4|8,K=4>; 2.4-3.5x the cooperative layout up to 128 dimensions, 2-2.5x / 1.1-1.3x the wave layout's one-stream
     engine up to 256 / 512, tools/adapt_std.py) -- against that layout (WN_DIAG_COOP=1: another
     summation order: integers exactly, reals 1e-6) and against the oracle."""
     rng = np.random.default_rng(D)
@@ -358,7 +359,7 @@ def test_std_and_diagonal_gaussians_adaptive_runs_one_chain_per_wave(wa, target,
     iters = 5
     kw = dict(integrator=integ, H0=1.3 * D ** -0.25, delta0=0.2, M=6)
     s_new, d_new, name = run_engine(wa, target, q0, iters, tpar=tpar, **kw)
-    assert ("wn_orbit_kernel<diag,NE=%d,K=4" % (2 if D <= 128 else 4 if D <= 256 else 8)) in name, name
+    assert ("wn_orbit_kernel<diag,NE=1," if D <= 16 else "wn_orbit_kernel<diag,NE=%d,K=4" % (2 if D <= 128 else 4 if D <= 256 else 8)) in name, name
     os.environ["WN_DIAG_COOP"] = "1"
     try:
         s_co, d_co, name_co = run_engine(wa, target, q0, iters, tpar=tpar, **kw)

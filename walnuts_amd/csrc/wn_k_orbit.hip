@@ -845,7 +845,7 @@ bool orbit_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& 
   if (prm.M < 1 || prm.M > MAX_M || (!wide && prm.D > 16) || prm.maxC > 12 || prm.minC < 0 || prm.minC > prm.maxC) return false;
   if (prm.generated != G_IDENTITY && prm.generated != G_FIRSTK && prm.generated != G_Q0_SUMSQ) return false;
   if (getenv("WN_ORBIT_LEGACY")) return false;
-  if (wide) return orbit_wide_run(kc, prm.integrator) && (!orbit_diag_geom(kc) || (prm.D > 16 && prm.D <= 128)) && (!orbit_diag8_geom(kc) || (prm.D > 128 && prm.D <= 512));
+  if (wide) return orbit_wide_run(kc, prm.integrator) && (!orbit_diag_geom(kc) || prm.D <= 128) && (!orbit_diag8_geom(kc) || (prm.D > 128 && prm.D <= 512));
   switch (kc.p1) {
     case T_FUNNEL10: case T_CORRGAUSS: case T_SMILE: case T_FUNNEL1: case T_MODFUNNEL: return true;
   }
@@ -914,7 +914,7 @@ static hipError_t go_orbit_wide_k(const Params& prm, hipStream_t st) {
 
 hipError_t launch_orbit(const KernelChoice& kc, const Params& prm, hipStream_t st) {
   if (orbit_dense_geom(kc)) return go_orbit_wide_k<WTgtDenseLDS<2>, 2, 8>(prm, st);
-  if (orbit_diag_geom(kc)) return go_orbit_wide_k<WTgtDiag<2>, 2, 4>(prm, st);
+  if (orbit_diag_geom(kc)) return prm.D <= 16 ? go_orbit<WTgtDiagRow>(prm, st) : go_orbit_wide_k<WTgtDiag<2>, 2, 4>(prm, st);
   if (orbit_diag8_geom(kc)) return prm.D <= 256 ? go_orbit_wide_k<WTgtDiag<4>, 4, 4>(prm, st) : go_orbit_wide_k<WTgtDiag<8>, 8, 4>(prm, st);
   if (orbit_wide_geom(kc)) return go_orbit_wide<WTgtStockWatson<12>, 12>(prm, st);
   switch (kc.p1) {

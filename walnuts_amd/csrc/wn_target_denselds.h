@@ -73,4 +73,20 @@ struct WTgtDenseLDS {
 };
 
 
+
+// std / diagonal Gaussian of at most 16 dimensions in the trajectory-first kernel's one-register form (lane i < D of every row of 16 holds
+// element i: WTgtDiag's arithmetic, lp = 1/2 q.grad)
+struct WTgtDiagRow {
+  static constexpr int EXT = EXT_NONE;
+  static constexpr int LDS_DOUBLES = 0;
+  static constexpr int VEC_LDS = 16;
+  double a;
+  __device__ __forceinline__ void init(const Params& prm, int lane, double*) { a = (lane & 15) < prm.D ? prm.tpar[lane & 15] : 0.0; }
+  __device__ __forceinline__ double grad(const double* q, double* g, int) const {
+    g[0] = -(a * q[0]);
+    return q[0] * g[0];
+  }
+  __device__ __forceinline__ static double lp_finish(double r) { return 0.5 * r; }
+};
+
 }  // namespace wn
