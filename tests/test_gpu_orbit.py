@@ -293,7 +293,7 @@ def dense_case(D, C, kappa=1e3, seed=5):
 
 
 @pytest.mark.parametrize("D,integ,C", [(100, ol.I_ADAPT_R2P, 37), (100, ol.I_ADAPT_D, 24), (72, ol.I_ADAPT_R2P, 16), (128, ol.I_ADAPT_D, 9), (65, ol.I_ADAPT_R2P, 8),
-                                       (40, ol.I_ADAPT_D, 19), (64, ol.I_ADAPT_R2P, 10), (17, ol.I_ADAPT_R2P, 12)])
+                                       (40, ol.I_ADAPT_D, 19), (64, ol.I_ADAPT_R2P, 10), (17, ol.I_ADAPT_R2P, 12), (8, ol.I_ADAPT_R2P, 25), (3, ol.I_ADAPT_D, 11)])
 def test_dense_adaptive_runs_one_chain_per_wave_matrix_in_lds(wa, D, integ, C):
     """adaptLeapFrogD / adaptLeapFrogR2P (adaptiveIntegrators.py:65-137 / 361-475) on the dense Gaussian of BASELINE config 2's geometry:
     plain sampling runs on the trajectory-first kernel's wide mode (wn_orbit_kernel<dense,NE=2,K=8>: eight chains per workgroup share the

@@ -9,7 +9,7 @@ from walnuts_amd import _lib as L
 from bench import make_dense_problem
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dev = torch.device("cuda", 0)
-for D in (24, 40, 64):
+for D in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (24, 40, 64)):
     A, q0 = make_dense_problem(D, 1e3, C, 20251121)
     q = torch.as_tensor(q0, device=dev)
     for name, ig in (("adaptLeapFrogD", L.I_ADAPT_D), ("adaptLeapFrogR2P", L.I_ADAPT_R2P)):

@@ -91,7 +91,7 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_
     snprintf(nm, sizeof(kc->name), "wn_split_tick_kernel<NE=%d,external>", NE);
     return 0;
   }
-  if (target == T_DENSEGAUSS && D > 16 && D <= 128 && integrator != I_FIXED && integrator != I_ADAPT_FLOWD && !dm && !getenv("WN_DENSE_COOP")) {
+  if (target == T_DENSEGAUSS && D >= 2 && D <= 128 && integrator != I_FIXED && integrator != I_ADAPT_FLOWD && !dm && !getenv("WN_DENSE_COOP")) {
     // (adaptLeapFrogFlowD stays on the cooperative layout: 3.1e8 against 2.7e8 evaluations/s here)
     // the adaptive integrators on the headline geometry (round 5): one chain per wavefront, the matrix in LDS shared by a workgroup's
     // chains (wn_k_wavelds.hip) -- a macro step is per-chain control flow, not a wide tile; WN_DENSE_COOP=1: the cooperative layout below

@@ -1,4 +1,4 @@
-// wn_k_wavelds.hip -- dense Gaussian of 17 .. 128 dimensions with an ADAPTIVE integrator (adaptLeapFrogD / R2P / YoshidaD / FlowD, with or
+// wn_k_wavelds.hip -- dense Gaussian of 2 .. 128 dimensions with an ADAPTIVE integrator (adaptLeapFrogD / R2P / YoshidaD / FlowD, with or
 // without warm-up, traced runs, orbit statistics, wn_integrator_step): one chain per wavefront, the precision matrix in LDS, shared by
 // the K chains of a workgroup (round 5; the reference's adaptive integrators on the headline geometry,
 // adaptiveIntegrators.py:65-137 / 246-356 / 361-475 with lpFun = the dense Gaussian of SURVEY 8d cfg 2).
