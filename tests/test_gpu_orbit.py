@@ -346,7 +346,7 @@ def test_dense_adaptive_warmup_and_yoshida_on_the_lds_engine(wa):
                                               (ol.T_STDGAUSS, 128, ol.I_ADAPT_D, 6), (ol.T_DIAGGAUSS, 64, ol.I_ADAPT_R2P, 5),
                                               (ol.T_STDGAUSS, 200, ol.I_ADAPT_R2P, 7), (ol.T_DIAGGAUSS, 256, ol.I_ADAPT_D, 5), (ol.T_DIAGGAUSS, 300, ol.I_ADAPT_R2P, 6),
                                               (ol.T_STDGAUSS, 512, ol.I_ADAPT_D, 3), (ol.T_STDGAUSS, 10, ol.I_ADAPT_R2P, 33), (ol.T_DIAGGAUSS, 16, ol.I_ADAPT_D, 20),
-                                              (ol.T_DIAGGAUSS, 3, ol.I_ADAPT_R2P, 17)])
+                                              (ol.T_DIAGGAUSS, 3, ol.I_ADAPT_R2P, 17), (ol.T_STDGAUSS, 200, ol.I_FIXED, 9), (ol.T_DIAGGAUSS, 256, ol.I_FIXED, 4)])
 def test_std_and_diagonal_gaussians_adaptive_runs_one_chain_per_wave(wa, target, D, integ, C):
     """The reference's Gaussian scaling experiments (mainGaussESS.py / mainGaussTransient.py: stdGauss with the adaptive integrators over D):
     adaptLeapFrogD / R2P runs of std / diagonal Gaussians of up to 512 dimensions on the trajectory-first kernel (one register per lane up to
@@ -365,7 +365,8 @@ def test_std_and_diagonal_gaussians_adaptive_runs_one_chain_per_wave(wa, target,
         s_co, d_co, name_co = run_engine(wa, target, q0, iters, tpar=tpar, **kw)
     finally:
         os.environ.pop("WN_DIAG_COOP", None)
-    assert ("wn_coop_kernel" if D <= 128 else "wn_wave_kernel<NE=8,diag>") in name_co, name_co  # (129 .. 512: the one-stream engine of the wave layout)
+    # (adaptive runs of 129 .. 512 dimensions were the wave layout's one-stream engine's; fixedLeapFrog on 129 .. 256 -- also moved in round 5 -- the cooperative layout's)
+    assert ("wn_coop_kernel" if D <= 128 or integ == ol.I_FIXED else "wn_wave_kernel<NE=8,diag>") in name_co, name_co
     assert same(d_new[..., INT_COLS], d_co[..., INT_COLS]) and near(s_new, s_co, 1e-6) and near(d_new, d_co, 1e-6)
     for c in sorted(set([0, C - 1])):
         o = ol.walnuts(target, q0[c], integrator=integ, tpar=tpar, H0=kw["H0"], delta0=0.2, numIter=iters, M=6, seed=SEED, chain=c)

@@ -529,11 +529,11 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
     const char* tn = kc.p1 == T_FUNNEL10 ? "funnel10" : kc.p1 == T_CORRGAUSS ? "corrGauss" : kc.p1 == T_SMILE ? "smile" : kc.p1 == T_FUNNEL1 ? "funnel1" : "modFunnel";
     snprintf(kc.name, sizeof(kc.name), "wn_orbit_kernel<%s,%s>", tn, e->cfg.integrator == WN_I_FIXED ? "fixedLeapFrog" : e->cfg.integrator == WN_I_ADAPT_D ? "adaptLeapFrogD" : "adaptLeapFrogR2P");
   }
-  if ((e->cfg.warmup_iter == 0 || kc.p1 != T_STOCKWATSON || kc.layout != 2) && e->cfg.M >= 1 && orbit_wide_run(kc, e->cfg.integrator) && (kc.layout != 1 || e->cfg.dim <= 128) &&
+  if ((e->cfg.warmup_iter == 0 || kc.p1 != T_STOCKWATSON || kc.layout != 2) && e->cfg.M >= 1 && orbit_wide_run(kc, e->cfg.integrator) && (kc.layout != 1 || e->cfg.dim <= 128 || (kc.p0 == 64 && e->cfg.dim <= 256)) &&
       !(kc.layout == 2 && kc.p1 == T_DIAGGAUSS && !(kc.p0 == 8 && e->cfg.dim > 128 && e->cfg.dim <= 512))) {
     // (round 5) StockWatson's plain sampling runs -- and the adaptive ones of dense / std / diagonal Gaussians of up to 128 dimensions: the
     // same kernel with vectors of 12 (2) registers per lane
-    snprintf(kc.name, sizeof(kc.name), "wn_orbit_kernel<%s,%s>", kc.layout == 1 ? (e->cfg.dim <= 16 ? "diag,NE=1" : "diag,NE=2,K=4") : kc.p1 == T_DIAGGAUSS ? (e->cfg.dim <= 256 ? "diag,NE=4,K=4" : "diag,NE=8,K=4") : kc.p1 == T_DENSEGAUSS ? "dense,NE=2,K=8" : "stockwatson,NE=12",
+    snprintf(kc.name, sizeof(kc.name), "wn_orbit_kernel<%s,%s>", kc.layout == 1 ? (e->cfg.dim <= 16 ? "diag,NE=1" : e->cfg.dim <= 128 ? "diag,NE=2,K=4" : "diag,NE=4,K=4") : kc.p1 == T_DIAGGAUSS ? (e->cfg.dim <= 256 ? "diag,NE=4,K=4" : "diag,NE=8,K=4") : kc.p1 == T_DENSEGAUSS ? "dense,NE=2,K=8" : "stockwatson,NE=12",
              e->cfg.integrator == WN_I_FIXED ? "fixedLeapFrog" : e->cfg.integrator == WN_I_ADAPT_D ? "adaptLeapFrogD" : "adaptLeapFrogR2P");
   }
   if (e->cfg.warmup_iter == 0 && e->cfg.M >= 1 && orbit2_run(kc, e->cfg.integrator, e->cfg.n_chains)) {

@@ -816,10 +816,13 @@ static bool orbit_dense_geom(const KernelChoice& kc) { return kc.layout == 2 && 
 static bool orbit_diag_geom(const KernelChoice& kc) { return kc.layout == 1 && kc.p1 == 1 && kc.W == 4 && kc.G == 1 && (kc.p0 == 16 || kc.p0 == 32); }
 // ... and of 129 .. 512 dimensions, whose adaptive runs otherwise sit on the one-stream engine of the wave layout (layout 2, 8 registers per lane)
 static bool orbit_diag8_geom(const KernelChoice& kc) { return kc.layout == 2 && kc.p0 == 8 && kc.W == 1 && kc.G == 1 && kc.p1 == T_DIAGGAUSS; }
+// ... and fixedLeapFrog on 129 .. 256 dimensions (cooperative layout with four tiles per wave: layout 1, 64 k-steps)
+static bool orbit_diag64_geom(const KernelChoice& kc) { return kc.layout == 1 && kc.p1 == 1 && kc.W == 4 && kc.G == 1 && kc.p0 == 64; }
 bool orbit_wide_geom(const KernelChoice& kc) {
-  return (kc.layout == 2 && kc.p0 == 12 && kc.W == 1 && kc.G == 1 && kc.p1 == T_STOCKWATSON) || orbit_dense_geom(kc) || orbit_diag_geom(kc) || orbit_diag8_geom(kc);
+  return (kc.layout == 2 && kc.p0 == 12 && kc.W == 1 && kc.G == 1 && kc.p1 == T_STOCKWATSON) || orbit_dense_geom(kc) || orbit_diag_geom(kc) || orbit_diag8_geom(kc) ||
+         orbit_diag64_geom(kc);
 }
-int orbit_wide_ne(const KernelChoice& kc) { return orbit_diag_geom(kc) ? 2 : kc.p0; }
+int orbit_wide_ne(const KernelChoice& kc) { return orbit_diag_geom(kc) ? 2 : orbit_diag64_geom(kc) ? 4 : kc.p0; }
 size_t orbit_wide_work_doubles(int NE, int C, int M) { return (size_t)C * orbit::wide_doubles(NE, M); }
 // Which plain sampling runs of that geometry take the wide mode: fixedLeapFrog (mainSW.py:56-62: a leaf is ONE evaluation, the one-stream
 // engine spends 40 % of it on bookkeeping).  A macro step of the adaptive integrators is 8+ evaluations (minC = 3): its bookkeeping is a
@@ -830,7 +833,11 @@ bool orbit_wide_run(const KernelChoice& kc, int integrator) {
   // the dense Gaussian is here for its adaptive runs (wn_k_wavelds.hip): a macro step is an evaluation or two, batches of 16 leaves pay
   if (orbit_dense_geom(kc)) return integrator == I_ADAPT_D || integrator == I_ADAPT_R2P;
   // std / diagonal Gaussian, 17 <= D <= 128: the same argument with a trivial gradient (the cooperative layout's tick machine is what costs)
-  if (orbit_diag_geom(kc) || orbit_diag8_geom(kc)) return (integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && !getenv("WN_DIAG_COOP");
+  if (orbit_diag_geom(kc)) return (integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && !getenv("WN_DIAG_COOP");
+  // fixedLeapFrog on 129 .. 256 dimensions (3.7e8 -> 5.9e8 steps/s at D = 256; up to 112 dimensions the role-split kernels are faster, beyond 256 the
+  // wave layout's engine as fast: tools/fixed_diag8_ab.py)
+  if (orbit_diag64_geom(kc)) return integrator == I_FIXED && !getenv("WN_DIAG_COOP");
+  if (orbit_diag8_geom(kc)) return (integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && !getenv("WN_DIAG_COOP");
   return integrator == I_FIXED || ((integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && getenv("WN_ORBIT_WIDE_ADAPT"));
 }
 
@@ -845,7 +852,7 @@ bool orbit_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& 
   if (prm.M < 1 || prm.M > MAX_M || (!wide && prm.D > 16) || prm.maxC > 12 || prm.minC < 0 || prm.minC > prm.maxC) return false;
   if (prm.generated != G_IDENTITY && prm.generated != G_FIRSTK && prm.generated != G_Q0_SUMSQ) return false;
   if (getenv("WN_ORBIT_LEGACY")) return false;
-  if (wide) return orbit_wide_run(kc, prm.integrator) && (!orbit_diag_geom(kc) || prm.D <= 128) && (!orbit_diag8_geom(kc) || (prm.D > 128 && prm.D <= 512));
+  if (wide) return orbit_wide_run(kc, prm.integrator) && (!orbit_diag_geom(kc) || prm.D <= 128) && (!orbit_diag64_geom(kc) || (prm.D > 128 && prm.D <= 256)) && (!orbit_diag8_geom(kc) || (prm.D > 128 && prm.D <= 512));
   switch (kc.p1) {
     case T_FUNNEL10: case T_CORRGAUSS: case T_SMILE: case T_FUNNEL1: case T_MODFUNNEL: return true;
   }
@@ -897,17 +904,19 @@ static hipError_t go_orbit_wide(const Params& prm, hipStream_t st) {
 }
 
 // ... several chains per workgroup: the target stages its data in LDS once for all of them
-template <class Tgt, int NE, int K>
+template <class Tgt, int NE, int K, bool FIXED_TOO = false>
 static hipError_t go_orbit_wide_k(const Params& prm, hipStream_t st) {
   dim3 grid((prm.C + K - 1) / K), block(64 * K);
   if (prm.warmupIter > 0) {
     if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_R2P, false, NE, K, true>), grid, block, 0, st, prm);
     else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_D, false, NE, K, true>), grid, block, 0, st, prm);
+    else if (FIXED_TOO) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_FIXED, false, NE, K, true>), grid, block, 0, st, prm);
     else return hipErrorInvalidValue;
     return hipGetLastError();
   }
   if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_R2P, false, NE, K>), grid, block, 0, st, prm);
   else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_D, false, NE, K>), grid, block, 0, st, prm);
+  else if (FIXED_TOO) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_FIXED, false, NE, K>), grid, block, 0, st, prm);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -915,6 +924,7 @@ static hipError_t go_orbit_wide_k(const Params& prm, hipStream_t st) {
 hipError_t launch_orbit(const KernelChoice& kc, const Params& prm, hipStream_t st) {
   if (orbit_dense_geom(kc)) return go_orbit_wide_k<WTgtDenseLDS<2>, 2, 8>(prm, st);
   if (orbit_diag_geom(kc)) return prm.D <= 16 ? go_orbit<WTgtDiagRow>(prm, st) : go_orbit_wide_k<WTgtDiag<2>, 2, 4>(prm, st);
+  if (orbit_diag64_geom(kc)) return go_orbit_wide_k<WTgtDiag<4>, 4, 4, true>(prm, st);
   if (orbit_diag8_geom(kc)) return prm.D <= 256 ? go_orbit_wide_k<WTgtDiag<4>, 4, 4>(prm, st) : go_orbit_wide_k<WTgtDiag<8>, 8, 4>(prm, st);
   if (orbit_wide_geom(kc)) return go_orbit_wide<WTgtStockWatson<12>, 12>(prm, st);
   switch (kc.p1) {
