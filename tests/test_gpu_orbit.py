@@ -440,3 +440,40 @@ def test_orbit_kernel_runs_the_warmup_iterations_wide_and_2d(wa, what):
                    numIter=iters, warmupIter=W, M=kw["M"], seed=SEED, chain=c)
     np.testing.assert_array_equal(d_new[c][:, INT_COLS], o["diagnostics"][:, INT_COLS])
     np.testing.assert_allclose(d_new[c], o["diagnostics"], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("target,integ,gen,gk", [(ol.T_FUNNEL10, ol.I_ADAPT_R2P, ol.G_FIRSTK, 2), (ol.T_FUNNEL10, ol.I_ADAPT_D, ol.G_IDENTITY, 0),
+                                                  (ol.T_FUNNEL10, ol.I_FIXED, ol.G_IDENTITY, 0), (ol.T_SMILE, ol.I_ADAPT_R2P, ol.G_IDENTITY, 0)])
+def test_orbit_kernel_records_orbit_statistics(wa, target, integ, gen, gk):
+    """recordOrbitStats = True (WALNUTS.py:182-184, 274-276, 331-333; the funnel experiments mainFunnel.py:40, mainFunnelOrbitLen.py:40,
+    mainFunnelTransient.py:32 run this way) on the trajectory-first kernel: orbitMin / orbitMax of generated(q) over every state of the orbit,
+    against the one-stream engine (bit for bit: the same states) and -- through the recordOrbitStats goldens' entry point -- the oracle."""
+    from walnuts_amd import _lib as L
+    C, iters = 48, 10
+    q0 = funnel_q0(C, seed=23) if target == ol.T_FUNNEL10 else np.random.default_rng(2).normal(size=(C, 2))
+    kw = dict(integrator=integ, H0=0.3, delta0=0.3, M=8, generated=gen, gen_k=gk)
+    out = {}
+    for legacy in (False, True):
+        os.environ.pop("WN_ORBIT_LEGACY", None)
+        os.environ["WN_ORBIT_EXACT"] = "1"
+        if legacy:
+            os.environ["WN_ORBIT_LEGACY"] = "1"
+        try:
+            e = wa.Engine(q0.shape[1], C, **kw).set_target(target, None)
+            name = e.kernel_name
+            s, d, omin, omax = e.run_orbit_stats(q0, SEED, iters)
+            out[legacy] = (s.cpu().numpy(), d.cpu().numpy(), omin.cpu().numpy(), omax.cpu().numpy(), name)
+            e.close()
+        finally:
+            os.environ.pop("WN_ORBIT_LEGACY", None); os.environ.pop("WN_ORBIT_EXACT", None)
+    (s1, d1, mn1, mx1, n1), (s2, d2, mn2, mx2, n2) = out[False], out[True]
+    assert "wn_orbit_kernel" in n1 and "wn_wave_kernel" in n2, (n1, n2)
+    if integ == ol.I_FIXED:  # (another instantiation of the engine: integers exactly, reals to 1e-7)
+        assert same(d1[..., INT_COLS], d2[..., INT_COLS]) and near(s1, s2, 1e-7) and near(mn1, mn2, 1e-7) and near(mx1, mx2, 1e-7)
+    else:
+        assert same(mn1, mn2) and same(mx1, mx2) and same(s1, s2)
+    assert (mx1 >= mn1).all() and (mx1 > mn1).any()
+    for c in (0, C - 1):
+        o = ol.walnuts(target, q0[c], integrator=integ, H0=0.3, delta0=0.3, numIter=iters, M=8, seed=SEED, chain=c, generated=gen, gen_k=gk, recordOrbitStats=True)
+        np.testing.assert_allclose(mn1[c].T, o["orbitMin"], rtol=1e-6, atol=1e-9, err_msg=f"chain {c} orbitMin")
+        np.testing.assert_allclose(mx1[c].T, o["orbitMax"], rtol=1e-6, atol=1e-9, err_msg=f"chain {c} orbitMax")

@@ -282,6 +282,14 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
     a = 0; b = 0; maxFint = 0; maxBint = 0;
     {
       vld(o_prop(ip), qa);
+      // recordOrbitStats (WALNUTS.py:182-184, 274-276): orbitMin / orbitMax[:, iterN-1] start at generated(qc); the one-register form,
+      // generated = identity / first k (mainFunnel.py, mainFunnelOrbitLen.py, mainFunnelTransient.py run the funnel this way)
+      if constexpr (!WIDE) if (prm.omin) {
+        const int fk = (int)(prm.generated == G_FIRSTK);
+        const int kk = fk * prm.gen_k + (1 - fk) * D;
+        const size_t orow = ((size_t)clc * prm.numIter + (iter - 1)) * prm.dg;
+        if (lane < 16 && lane < kk && lane < D) { prm.omin[orow + lane] = qa[0]; prm.omax[orow + lane] = qa[0]; }
+      }
       double lpp = tgt.grad(qa, ga, lane);  // f0, grad0 = lpFun(qc)  (:249); its value is lpP already
       (void)lpp;
       // :236  v = normal(size=d)
@@ -723,6 +731,22 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
         }
         st_[10] += 1; st_[12] += redo ? 1 : 0;
         WN_STAMP(7);
+        // recordOrbitStats: np.minimum / np.maximum over generated(q) of the leaves that passed the non-finite test, k0 .. Lfull (:331-333, 364-366,
+        // 434-436, ..; a NaN stays: numpy's minimum / maximum propagate it) -- lane = element, one read-modify-write of the row per batch
+        if constexpr (!WIDE) if (prm.omin && Lfull >= k0) {
+          const int fk = (int)(prm.generated == G_FIRSTK);
+          const int kk = fk * prm.gen_k + (1 - fk) * D;
+          const size_t orow = ((size_t)clc * prm.numIter + (iter - 1)) * prm.dg;
+          const bool mine = lane < 16 && lane < kk && lane < D;
+          double mn = mine ? prm.omin[orow + lane] : 0.0, mx = mine ? prm.omax[orow + lane] : 0.0;
+#pragma unroll 1
+          for (int j = k0; j <= Lfull; ++j) {
+            const double x = L[RQ + RS * j + k16];
+            mn = (isnan(x) || isnan(mn)) ? NAN : (x < mn ? x : mn);
+            mx = (isnan(x) || isnan(mx)) ? NAN : (x > mx ? x : mx);
+          }
+          if (mine) { prm.omin[orow + lane] = mn; prm.omax[orow + lane] = mx; }
+        }
         if (f0_now && !end_nf && !end_sub && !redo) fire0 = true;
         n = nb0 + Lfull + 1;
         if (end_nf) {  // :316-319, 414-417, 457-459 (Q3, Q4)
@@ -846,7 +870,9 @@ bool orbit_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& 
   if (!wide && (kc.layout != 2 || kc.p0 != 1 || kc.W != 1 || kc.G != 1)) return false;
   // (warm-up iterations run here as well, except StockWatson's: its WARM instantiations are not built)
   if (warm && kc.layout == 2 && kc.p1 == T_STOCKWATSON) return false;
-  if (prm.mode != MODE_SAMPLE || prm.trace_n || prm.trace || prm.omin) return false;
+  if (prm.mode != MODE_SAMPLE || prm.trace_n || prm.trace) return false;
+  // orbit statistics: the one-register form (funnel10, the 2-D targets), generated = identity / first k
+  if (prm.omin && (wide || prm.generated == G_Q0_SUMSQ)) return false;
   if (adapt == 2) return false;
   if (prm.integrator != I_FIXED && prm.integrator != I_ADAPT_D && prm.integrator != I_ADAPT_R2P) return false;
   if (prm.M < 1 || prm.M > MAX_M || (!wide && prm.D > 16) || prm.maxC > 12 || prm.minC < 0 || prm.minC > prm.maxC) return false;
