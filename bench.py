@@ -489,6 +489,7 @@ def summary_line(out):
     parts.append("cfg2@1024=%s(%s,med3)" % (f(g(ex, "dense_1024_chains", "value")), f(g(ex, "dense_1024_chains", "roofline", "frac"))))
     parts.append("diag=%s" % f(g(ex, "diag_variant", "value")))
     parts.append("cfg2adaptD/R2P=%s/%s" % (f(g(ex, "dense_adaptive", "adaptLeapFrogD", "value")), f(g(ex, "dense_adaptive", "adaptLeapFrogR2P", "value"))))
+    parts.append("stdR2P=%s" % f(g(ex, "std_adaptive_R2P", "value")))
     c3 = oc.get("cfg3_funnel", {})
     parts.append("cfg3=%s/%s/%s,tick_us=%s" % (f(c3.get("min")), f(c3.get("value")), f(c3.get("max")), f(c3.get("tick_us"))))
     c4 = oc.get("cfg4_dense1000", {})
@@ -684,6 +685,16 @@ def main():
                     ad[nm_] = {"value": st / (e4.last_run_ms() * 1e-3), "unit": "gradient evaluations/s", "kernel": e4.kernel_name, "ms_per_step": e4.last_run_ms()}
                     e4.close()
                 extras["dense_adaptive"] = ad
+                # ... and on the standard Gaussian of the same dimension (the reference's Gaussian scaling experiments, mainGaussESS.py:47-48:
+                # adaptLeapFrogR2P, M = 10, generated = [q0, sum q^2]): the trajectory-first kernel's wide mode
+                e5 = wa.Engine(D, C, integrator=L.I_ADAPT_R2P, H0=1.4 * D ** -0.25, delta0=0.3, stepSizeRandScale=0.2, M=args.M, generated=L.G_Q0_SUMSQ,
+                               device=dev.index).set_target(L.T_STDGAUSS, None)
+                qs_ = torch.as_tensor(np.random.default_rng([SEED, 11]).normal(size=(C, D)), device=dev)
+                e5.run(qs_, SEED + 77, 20)
+                s5, d5 = e5.run(qs_, SEED, 20)
+                st = float((d5[:, :, 6].sum() + d5[:, :, 7].sum()).item())
+                extras["std_adaptive_R2P"] = {"value": st / (e5.last_run_ms() * 1e-3), "unit": "gradient evaluations/s", "kernel": e5.kernel_name, "ms_per_step": e5.last_run_ms(), "dim": D}
+                e5.close()
             except Exception as ex:
                 extras["error"] = repr(ex)
             # BASELINE configs 3, 4 (one GPU's shard), 5 (one GPU's shard; all three runs of mainSW.py:41-80) at SURVEY 8d's
