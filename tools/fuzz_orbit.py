@@ -13,6 +13,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 INT = [0, 1, 4, 5, 6, 7, 8, 9, 12, 13, 19, 20, 21, 22]
 bad = 0; badl = 0; codes = {}; nchains = 0
+ONLY = set(int(x) for x in os.environ.get("WN_FUZZ_ONLY", "").split(",") if x)  # replay switch: run only these configurations of the stream
 for it in range(n):
     tk = int(rng.choice([ol.T_FUNNEL10, ol.T_CORRGAUSS, ol.T_SMILE, ol.T_FUNNEL1, ol.T_MODFUNNEL], p=[.6, .1, .1, .1, .1]))
     ig = int(rng.choice([ol.I_FIXED, ol.I_ADAPT_D, ol.I_ADAPT_R2P], p=[.2, .3, .5]))
@@ -27,6 +28,8 @@ for it in range(n):
     else:
         D = 2; q0 = 1.5 * rng.normal(size=(C, 2))
     gen, gk = (ol.G_IDENTITY, 0) if rng.random() < 0.5 else ((ol.G_Q0_SUMSQ, 0) if rng.random() < 0.5 else (ol.G_FIRSTK, min(2, D)))
+    if ONLY and it not in ONLY:
+        continue
     e = wa.Engine(D, C, integrator=ig, H0=H0, delta0=delta, M=M, minC=minC, maxC=maxC, generated=gen, gen_k=gk, chain_offset=1000 * it)
     e.set_target(tk, None)
     if "wn_orbit_kernel" not in e.kernel_name:  # (2-D targets with fixedLeapFrog run one chain per lane)
@@ -46,6 +49,15 @@ for it in range(n):
     if not same_int or not (rel <= 1e-6 or np.isnan(rel)):
         badl += 1
         print(f"LEGACY MISMATCH cfg {it}: target {tk} integ {ig} M {M} H0 {H0:.4g} delta {delta} minC {minC} maxC {maxC} gen {gen} iters {numIter} C {C}: ints equal {same_int}, max rel diff of draws {rel:.3g}")
+        if ONLY:  # where the two kernels part: the first iteration whose draw differs, per chain, and by how much (last-bit class: ~1e-16 growing)
+            for k in range(C):
+                with np.errstate(all="ignore"):
+                    r = np.abs(s[k] - sl[k]) / np.maximum(1e-300, np.abs(sl[k])); r = np.where(np.isnan(r), 0.0, r).max(axis=0 if s[k].shape[0] == D else 1)
+                nz = np.flatnonzero(r > 0)
+                if nz.size:
+                    i0 = int(nz[0]); ib = int(np.argmax(np.any(d[k][:, INT] != dl[k][:, INT], axis=1))) if not np.array_equal(d[k][:, INT], dl[k][:, INT]) else -1
+                    print(f"   chain {k}: first differing draw at iteration {i0} (rel {r[i0]:.3g}; next {[float(f'{x:.2g}') for x in r[i0 + 1:i0 + 4]]}), first differing integer at iteration {ib};"
+                          f" |q| there {np.abs(sl[k]).max(axis=0 if s[k].shape[0] == D else 1)[i0]:.3g}, stop codes {sorted(set(dl[k][:, 19].astype(int).tolist()))}")
     # (absurd step sizes, H0 > 3: the dynamics amplify last-bit differences past any tolerance within a few leaves -- the two GPU kernels still
     #  agree with each other there, which is what the control logic is held to; the oracle comparison needs a trajectory that means something)
     for k in range(C if H0 <= 3.0 else 0):
