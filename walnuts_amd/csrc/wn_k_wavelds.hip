@@ -15,8 +15,8 @@
 //     g = -A q  as  sum_j (-A)[:, j] q_j :  q_j is a v_readlane (the loop index is uniform), column j of -A two 512-byte LDS reads (rows
 //     0..63 and 64..127, conflict-free), two FMAs: 6 instructions per column, ~600 per gradient at D = 100.
 // -A is staged ONCE per workgroup, column-major with 128 doubles per column (rows and columns >= D are zero: the lanes that hold no
-// element, and the last block of eight columns, need no mask): 128 KB, one workgroup of K = 8 chains per CU, two waves per SIMD.  The bound is the vector ALU (400 of the 600
-// instructions), not LDS bandwidth (12.8 KB per column pair and wave).
+// element, and the last block of eight columns, need no mask): 128 KB, one workgroup of K = 8 chains per CU, two waves per SIMD.  Neither the
+// LDS array (1.6 k cycles per gradient and SIMD) nor the vector ALU (1.8 k) is saturated: DESIGN 4.1b has the measured cost and what was tried.
 #include "wn_launch.h"
 #include "wn_policy_wave.h"
 #include "wn_target_denselds.h"
