@@ -17,6 +17,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 INT = [0, 1, 4, 5, 6, 7, 8, 9, 12, 13, 19, 20, 21, 22]
 sw = np.load(os.path.join(ROOT, "tests", "golden", "stockwatson_data.npz"))
 bad = 0; ndone = 0; nor = 0; t0 = time.time()
+ONLY = set(int(x) for x in os.environ.get("WN_FUZZ_ONLY", "").split(",") if x)  # replay switch: run only these configurations of the stream
 
 
 def run(env, T, C, tpar, q0, kw, numIter, off):
@@ -50,6 +51,8 @@ for it in range(n):
     q0 = 0.2 * rng.normal(size=(C, 3 * T)) if rng.random() < 0.7 else np.zeros((C, 3 * T))
     kw = dict(integrator=ig, H0=H0, delta0=delta, M=M, minC=minC, maxC=maxC, generated=gen, gen_k=gk)
     off = 1000 * it
+    if ONLY and it not in ONLY:
+        continue
     sl, dl, nl = run({"WN_ORBIT_LEGACY": "1"}, T, C, tpar, q0, kw, numIter, off)
     forms = [({}, "wn_orbit2_kernel"), ({"WN_ORBIT_ONEWAVE": "1", "WN_ORBIT_WIDE_ADAPT": "1"}, "wn_orbit_kernel")]
     for env, want in forms:
@@ -79,4 +82,16 @@ for it in range(n):
             if not ok:
                 bad += 1
                 print(f"ORACLE MISMATCH cfg {it} chain {k}: T {T} integ {ig} M {M} H0 {H0:.4g} delta {delta} minC {minC} maxC {maxC} gen {gen} iters {numIter}", flush=True)
+                if ONLY:  # where they part: integers or reals, which iteration, by how much
+                    od = o["diagnostics"]; os_ = o["samples"]
+                    with np.errstate(all="ignore"):
+                        rs = np.abs(s[k].T - os_) / np.maximum(1e-300, np.abs(os_)); rs = np.where(np.isnan(rs), 0.0, rs).max(axis=0 if os_.shape[1] == numIter else 1)
+                        rd = np.abs(d[k] - od) / np.maximum(1e-300, np.abs(od)); rd = np.where(np.isnan(rd), 0.0, rd)
+                    ib = int(np.argmax(np.any(d[k][:, INT] != od[:, INT], axis=1))) if not np.array_equal(d[k][:, INT], od[:, INT]) else -1
+                    print(f"   draws: max rel diff per iteration {[float(f'{x:.2g}') for x in rs]}; first differing integer at iteration {ib}"
+                          + (f" gpu {d[k][ib, INT]} oracle {od[ib, INT]}" if ib >= 0 else "") + f"; diagnostics columns over 1e-6: {sorted(set(np.argwhere(rd > 1e-6)[:, 1].tolist()))}"
+                          f" max {rd.max():.3g}; stop codes {sorted(set(od[:, 19].astype(int).tolist()))}", flush=True)
+                    if ib >= 0:
+                        np.set_printoptions(linewidth=250, precision=6)
+                        print("   gpu   ", d[k][ib], "\n   oracle", od[ib], "\n   |q| entering the iteration", float(np.abs(os_[:, ib - 1] if os_.shape[1] == numIter else os_[ib - 1]).max()) if ib > 0 else "q0", flush=True)
 print(f"fuzz_orbit2: {ndone} configurations x 2 kernel forms against the one-stream engine, {nor} chains against the oracle, {bad} mismatches, {time.time() - t0:.0f} s")
