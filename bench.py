@@ -478,6 +478,43 @@ def side_record(spec, m, kernel_name, cpu):
 
 
 # ---------------------------------------------------------------------------------------------
+# SURVEY 8e on ONE GPU: the R shards of an R-rank job, one after another
+# ---------------------------------------------------------------------------------------------
+def emulate_ranks(name, R, dev, steps, warmup, args=None, sw_run="D"):
+    """The R shards of an R-rank job of workload `name` (rank r: chains r*C .. (r+1)*C - 1 of the global chain numbering,
+    i.e. `chain_offset = r*C`, its own starting points, the same launch seeds as the real job), run one after another on
+    this one device.  Chains never interact (WALNUTS.py:701-712: even the adaptation is per chain) and the ranks of the real
+    job exchange nothing inside the timed region, so rank r of an R-GPU job executes exactly shard r's launches: the job's
+    time is the slowest shard's, and the only loss against N = 1 is the imbalance between shards.
+    predicted_weak_scaling_eff = (sum of the shards' units / (R * slowest shard's time)) / (shard 0's units / its time):
+    the figure the driver computes from its own N = 1 and N = R runs, here from R sequential runs on one GPU (it leaves
+    out what only R GPUs can show: the one barrier + gather at the end, clock / thermal differences between devices)."""
+    import torch
+    shards = []
+    for r in range(R):
+        sp = workload_spec(name, args, r, sw_run)
+        e = make_engine(sp, dev, r)
+        m = timed_launches(e, sp, dev, steps, warmup, lambda: torch.cuda.synchronize(dev))
+        e.close()
+        shards.append({"rank": r, "chain_offset": r * sp["C"], "kernel_ms": float(np.sum(m["kernel_ms"])), "units": m["units"],
+                       "busiest_chain_units": float(np.max(m["busiest"]))})
+    t = np.array([s_["kernel_ms"] for s_ in shards]); u = np.array([s_["units"] for s_ in shards])
+    n1 = u[0] / t[0]
+    return {"ranks": R, "launches_per_shard": steps, "iters_per_launch": sp["iters"], "chains_per_shard": sp["C"],
+            "per_shard_kernel_ms": [float(x) for x in t], "per_shard_units": [float(x) for x in u],
+            "per_shard_rate": [float(x) for x in u / t * 1e3],
+            "n1_value": float(n1 * 1e3), "predicted_value": float(u.sum() / t.max() * 1e3),
+            "predicted_weak_scaling_eff": float(u.sum() / (R * t.max()) / n1),
+            # the same against the MEAN shard's rate instead of shard 0's (takes out whether shard 0 happens to be a quick or a slow one)
+            "predicted_weak_scaling_eff_vs_mean_shard": float(u.sum() / (R * t.max()) / np.mean(u / t)),
+            "time_max_over_mean": float(t.max() / t.mean()), "units_max_over_mean": float(u.max() / u.mean()),
+            "busiest_chain_units": [s_["busiest_chain_units"] for s_ in shards], "workload": sp["workload"],
+            "what": "R shards of an R-rank job run sequentially on one GPU; eff = sum(units) / (R * max shard time) / (shard 0 rate)"}
+
+
+EMULATED = (("cfg2", "gauss100", "D"), ("cfg3", "funnel", "D"), ("cfg4", "dense1000", "D"), ("cfg5D", "stockwatson", "D"))
+
+
 def summary_line(out):
     """Every configuration's number (and its roofline fraction or serial time per unit) in one stderr line of at most 600 bytes, so that
     a log tail carries all of them (measurement hygiene)."""
@@ -497,8 +534,10 @@ def summary_line(out):
     for k in ("D", "fixed", "R2P"):
         c5 = oc.get("cfg5_stockwatson_" + k, {})
         parts.append("cfg5%s=%s,tick_us=%s" % (k, f(c5.get("value")), f(c5.get("tick_us"))))
-    parts.append("walnuts10_device=%s" % f(g(ex, "walnuts10_device", "value")))
-    parts.append("walnuts_batch=%s" % f(g(ex, "walnuts_batch", "value")))
+    parts.append("w10dev=%s" % f(g(ex, "walnuts10_device", "value")))
+    parts.append("w_batch=%s" % f(g(ex, "walnuts_batch", "value")))
+    em = ex.get("emulated_8_ranks", {})
+    parts.append("eff8emu=" + "/".join(f(g(em, k, "predicted_weak_scaling_eff"), "%.3f") for k, _, _ in EMULATED))
     return ("bench.py summary (units/s (roofline frac)): " + " ".join(parts))[:600]
 
 
@@ -537,6 +576,10 @@ def main():
     ap.add_argument("--child-timeout", type=float, default=1800.0, help="self-launched ranks: seconds before they are ended")
     ap.add_argument("--dry-run", action="store_true",
                     help="ranks only rendezvous (gloo), reduce and gather a small tensor and print a line: the launcher's own test, no GPU")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="run the R shards of an R-rank job of --workload (chain_offset = r * chains, the real job's seeds) one after another on "
+                         "ONE GPU and print per-shard kernel_ms and predicted_weak_scaling_eff (SURVEY 8e: the only loss is imbalance); the "
+                         "default invocation does this with R = 8 for configs 2-5 (extras.emulated_8_ranks)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (see profiles/)")
     args = ap.parse_args()
@@ -551,6 +594,16 @@ def main():
         return main_dry_run()
     if args.workload == "walnuts10":
         return main_walnuts10(args)
+    if args.emulate_ranks:
+        import torch
+        if torch.cuda.device_count() < 1:
+            sys.exit("bench.py needs a ROCm GPU (the product has no CPU path)")
+        torch.cuda.set_device(0)
+        rec = emulate_ranks(args.workload, args.emulate_ranks, torch.device("cuda", 0), args.steps, args.warmup, args, args.sw_run)
+        print(json.dumps({"metric": "predicted weak-scaling efficiency, %d emulated ranks on one GPU" % args.emulate_ranks,
+                          "value": rec["predicted_weak_scaling_eff"], "unit": "fraction", "n_gpus": 1, "steps": args.steps,
+                          "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "data": "synthetic", "dtype": "f64", **rec}), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -723,6 +776,16 @@ def main():
                 print(f"bench.py: walnuts10 took {time.perf_counter() - t_:.1f} s", file=sys.stderr)
             except Exception as ex:
                 extras["walnuts10_device"] = {"error": repr(ex)}
+            # SURVEY 8e's only loss term, measured on the one GPU: the 8 shards of an 8-rank job one after another
+            em = {}
+            t_ = time.perf_counter()
+            for key, nm_, run_ in EMULATED:
+                try:
+                    em[key] = emulate_ranks(nm_, 8, dev, 2, 1, args if nm_ == "gauss100" else None, run_)
+                except Exception as ex:
+                    em[key] = {"error": repr(ex)}
+            print(f"bench.py: 8 emulated ranks x 4 configurations took {time.perf_counter() - t_:.1f} s", file=sys.stderr)
+            extras["emulated_8_ranks"] = em
             out["extras"] = extras
         if cpu is not None:
             out["cpu_baseline"] = cpu
@@ -750,12 +813,14 @@ def main_dry_run():
         dist.init_process_group("gloo")
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     g = torch.full((3, 2), float(rank), dtype=torch.float64)
+    g[:, 1] = torch.arange(rank * 3, rank * 3 + 3, dtype=torch.float64)  # the GLOBAL chain ids of this rank's shard (chain_offset = rank * C)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         g = gather_draws(g, dst=0)
     if rank == 0:
         print(json.dumps({"metric": "dry run", "value": float(t.item()), "n_gpus": world, "gathered_rows": int(g.shape[0]),
-                          }), flush=True)
+                          "gathered_in_global_chain_order": bool((g[:, 1] == torch.arange(g.shape[0], dtype=torch.float64)).all().item()),
+                          "gathered_rank_of_row": [int(x) for x in g[:, 0].tolist()]}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -116,6 +116,17 @@ def test_bench_self_launcher_starts_ranks_and_relays_rank0():
     assert o["n1_value_same_invocation"] == 2.0 and o["weak_scaling_eff"] == 0.75
 
 
+def test_bench_self_launcher_eight_ranks():
+    """The node's full rank count (8 GPUs): eight fresh children rendezvous over gloo, reduce, and the final gather
+    lands every rank's shard at its global chain offset (`chain_offset = rank * C`) on rank 0."""
+    import json
+    r, dt = _bench(["--gpus", "8", "--dry-run"], timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert o["n_gpus"] == 8 and o["value"] == 36.0 and o["gathered_rows"] == 24
+    assert o["gathered_in_global_chain_order"] and o["gathered_rank_of_row"] == [k // 3 for k in range(24)]
+
+
 def test_bench_self_launcher_ends_the_job_when_a_rank_dies():
     """A rank that exits before the rendezvous leaves its sibling waiting in init_process_group (gloo's store timeout is
     half an hour): the parent polls every child, ends the survivors and exits non-zero at once."""
