@@ -118,6 +118,13 @@ def workload_spec(name, args=None, rank=0, sw_run="D"):
     raise ValueError(name)
 
 
+def _with_route(spec, a):
+    """--route / --split-parts / --split-ks of the command line -> the engine's keyword arguments (A/B runs only)"""
+    if a is not None and (getattr(a, "route", "") or getattr(a, "split_parts", 0) or getattr(a, "split_ks", 0)):
+        spec["eng_extra"] = dict(route=[r for r in a.route.split(",") if r], split_parts=a.split_parts, split_ks=a.split_ks)
+    return spec
+
+
 # ---------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (validated C restatement of the reference's path) on the host cores
 # ---------------------------------------------------------------------------------------------
@@ -384,7 +391,7 @@ def _scaling_fields(dist, world, cdev, value, kernel_ms_avg, units_rank, coll=Fa
 # ---------------------------------------------------------------------------------------------
 def make_engine(spec, dev, rank):
     import walnuts_amd as wa
-    e = wa.Engine(spec["D"], spec["C"], chain_offset=rank * spec["C"], device=dev.index, **spec["eng"])
+    e = wa.Engine(spec["D"], spec["C"], chain_offset=rank * spec["C"], device=dev.index, **spec["eng"], **spec.get("eng_extra", {}))
     return e.set_target(spec["target"], spec["tpar"])
 
 
@@ -492,7 +499,7 @@ def emulate_ranks(name, R, dev, steps, warmup, args=None, sw_run="D"):
     import torch
     shards = []
     for r in range(R):
-        sp = workload_spec(name, args, r, sw_run)
+        sp = _with_route(workload_spec(name, args, r, sw_run), args)
         e = make_engine(sp, dev, r)
         m = timed_launches(e, sp, dev, steps, warmup, lambda: torch.cuda.synchronize(dev))
         e.close()
@@ -576,6 +583,10 @@ def main():
     ap.add_argument("--child-timeout", type=float, default=1800.0, help="self-launched ranks: seconds before they are ended")
     ap.add_argument("--dry-run", action="store_true",
                     help="ranks only rendezvous (gloo), reduce and gather a small tensor and print a line: the launcher's own test, no GPU")
+    ap.add_argument("--route", default="", help="comma-separated WN_ROUTE_* names for the workload's engine (include/walnuts_amd.h; A/B runs: "
+                                                "FAST4_WHOLE, ORBIT_LEGACY, ...); default: the library chooses")
+    ap.add_argument("--split-parts", type=int, default=0, help="dense1000: wn_config.split_parts (0 / 1 = one part)")
+    ap.add_argument("--split-ks", type=int, default=0, help="dense1000: wn_config.split_ks")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="run the R shards of an R-rank job of --workload (chain_offset = r * chains, the real job's seeds) one after another on "
                          "ONE GPU and print per-shard kernel_ms and predicted_weak_scaling_eff (SURVEY 8e: the only loss is imbalance); the "
@@ -607,7 +618,7 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    spec = workload_spec(args.workload, args, rank, args.sw_run)
+    spec = _with_route(workload_spec(args.workload, args, rank, args.sw_run), args)
     headline = args.workload == "gauss100"
     extras_on = headline and world == 1 and not args.no_extras
     side_specs = []

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 4
+#define WN_ABI_VERSION 5
 #define WN_NDIAG 24      /* diagnostics columns, WALNUTSpy/WALNUTS.py:670-693 */
 #define WN_TRACE_NSCAL 12 /* trace row = 12 scalars + q[D] + v[D] */
 
@@ -81,6 +81,36 @@ enum {
   WN_G_SW_CONSTRAIN = 3
 };
 
+/* Kernel routing (wn_config.route, ABI 5).  The reference's boundary is keyword arguments (WALNUTS.py:111-129), not ambient
+ * state: which of several equivalent kernels runs a configuration is part of the engine's configuration too.  0 = WN_ROUTE_AUTO:
+ * the library chooses (what every caller should pass).  The bits below select the OTHER implementation of the same reference
+ * function where two exist -- the test suite compares them with each other and with the oracle -- and never change what is
+ * computed, only by which kernel (results agree to the bits or to rtol 1e-6, as tests/ states case by case).  Until ABI 4 these
+ * were environment variables of the same names (WN_ORBIT_LEGACY=1 ...), read inside the library on every wn_set_target /
+ * launch; the default build reads no environment variable any more (a -DWN_DIAG build ORs the old variables in at wn_create). */
+enum {
+  WN_ROUTE_AUTO = 0,
+  WN_ROUTE_ORBIT_LEGACY = 1 << 0,     /* plain runs of the one-chain-per-wave layouts on the one-stream engine (wn_wave_kernel /
+                                         wn_wavelds_kernel / wn_coop_kernel) instead of the trajectory-first kernels (wn_k_orbit*.hip) */
+  WN_ROUTE_ORBIT_NOWIDE = 1 << 1,     /* ... only the wide mode (vectors of NE registers per lane) off */
+  WN_ROUTE_ORBIT_WIDE_ADAPT = 1 << 2, /* StockWatson: adaptive integrators' plain runs on the one-wave wide mode too */
+  WN_ROUTE_ORBIT_ONEWAVE = 1 << 3,    /* StockWatson: no two-wave kernel (wn_k_orbit2.hip) */
+  WN_ROUTE_ORBIT_EXACT = 1 << 4,      /* trajectory-first kernels with the one-stream engine's micro-step arithmetic (two reductions
+                                         per micro step) instead of the fused step: bit-identical to that engine */
+  WN_ROUTE_ORBIT2_NOADAPT = 1 << 5,   /* wn_k_orbit2.hip for fixedLeapFrog only */
+  WN_ROUTE_ORBIT2_ANYC = 1 << 6,      /* wn_k_orbit2.hip whatever the chain count (default: only while chains leave SIMDs idle) */
+  WN_ROUTE_DIAG_COOP = 1 << 7,        /* std / diagonal Gaussians: the cooperative 16-chain layout instead of wn_orbit_kernel's wide mode */
+  WN_ROUTE_DENSE_COOP = 1 << 8,       /* dense Gaussian D <= 128, adaptive integrators: the cooperative MFMA layout instead of one chain per wave */
+  WN_ROUTE_FAST_LEGACY = 1 << 9,      /* fixedLeapFrog Gaussians: the seven-T-wave kernel (wn_k_fast.hip) instead of wn_k_fast4.hip */
+  WN_ROUTE_COOP_LEGACY = 1 << 10,     /* ... the one-stream cooperative kernel instead of either */
+  WN_ROUTE_FAST4_WHOLE = 1 << 11,     /* wn_k_fast4.hip: a group on ONE T wave also when the launch has < 2 groups per CU */
+  WN_ROUTE_FLOW_NOCOOP = 1 << 12,     /* adaptLeapFrogFlowD off the cooperative layout (lane / wave / split) */
+  WN_ROUTE_FORCE_WAVE = 1 << 13,      /* std / diagonal Gaussians on the one-chain-per-wave layout */
+  WN_ROUTE_LANE_GAUSS = 1 << 14,      /* small Gaussians one chain per lane whatever the chain count */
+  WN_ROUTE_SPLIT_EAGER = 1 << 15,     /* split mode: eager launches instead of the hipGraph of 64 ticks */
+  WN_ROUTE_WSTEP_LEGACY = 1 << 16     /* wn_wstep_*: the one-lane transition kernels instead of the wave kernels (wn_wstep_set_route) */
+};
+
 /* keyword arguments of WALNUTS(...) (WALNUTS.py:111-129) + integratorAuxPar
  * (adaptiveIntegrators.py:36-44) as a flat struct. */
 typedef struct wn_config {
@@ -108,6 +138,19 @@ typedef struct wn_config {
   double adapt_h_target;       /* WALNUTS.py:124 adaptHtarget: P2 quantile 1-target of log igrConst */
   double adapt_delta_target;   /* WALNUTS.py:126 */
   double adapt_delta_quantile; /* WALNUTS.py:127 */
+  /* ---- ABI 5 ---- */
+  uint32_t route;          /* WN_ROUTE_* bits; 0 = automatic (see above) */
+  int32_t split_parts;     /* split mode (dense Gaussian 128 < D <= 1024): 0 / 1 = one part (default), 2 / 4 = sub-batches on streams of
+                              their own (was WN_SPLIT_PARTS) */
+  int32_t split_ks;        /* ... 2 = k of a gradient tile split over two workgroups (was WN_SPLIT_KS); 0 / 1 = no */
+  int32_t adapt_quant_bits; /* 0 = the reference's arithmetic.  b in [8, 52] (opt-in, NOT the reference): the warm-up's adapted H and
+                               delta (WALNUTS.py:708-712) are rounded to b significant bits at the end of every warm-up iteration.
+                               With warm-up a run is a feedback loop through H / delta that amplifies last-bit differences of the
+                               energy sums by ~1e3 per iteration on ill-conditioned targets -- the reference's own result moves by
+                               more than 1e-6 within ~15 iterations when ONE input coordinate moves by one ulp
+                               (tests/studies/warmup_sensitivity.py) -- and rounding the loop variable cuts the loop: with b = 20 two
+                               implementations that differ in summation order stay within 1e-6 of each other through the warm-up
+                               ("warm-up tolerance contract").  The oracle has the same switch (adaptQuantBits). */
 } wn_config;
 
 typedef struct wn_engine wn_engine;
@@ -235,6 +278,8 @@ int wn_wstep_run_device_rng(wn_wstep *h, uint64_t seed, int64_t chain_offset, in
  * sum of the forward ell_stable (:250)} per chain and transition -- what tests/golden/walnuts_device.npz holds for the unmodified
  * reference run on the same random stream.  NULL detaches.  The buffer is caller-owned. */
 int wn_wstep_set_stats(wn_wstep *h, int32_t *stats_dev);
+/* (ABI 5) kernel routing of this handle: WN_ROUTE_WSTEP_LEGACY or 0 (was the environment variable WN_WSTEP_LEGACY). */
+int wn_wstep_set_route(wn_wstep *h, uint32_t route);
 int wn_wstep_ext_bind(wn_wstep *h, double *x_req_dev, const double *lp_dev, const double *grad_dev);
 int wn_wstep_ext_pending(wn_wstep *h, int32_t *n_pending, void *stream);
 int wn_wstep_ext_waiting(wn_wstep *h, int32_t *waiting_dev, void *stream);
@@ -268,6 +313,10 @@ int wn_last_split_ticks(wn_engine *e, int64_t *ticks);
  * LDS each).  LDS keeps what the previous kernel left there; the sampler kernels must not depend on it
  * (tests/test_gpu_lds.py runs every kernel family behind NaN and garbage patterns and compares bits). */
 int wn_debug_poison_lds(int32_t device, uint64_t pattern, void *stream);
+/* Test hook (ABI 5; was the environment variable WN_DEBUG_CLUSTER_DROP): cluster layout (D > 4096), the last slice of every chain skips
+ * its arrival at cross-workgroup exchange number `exchange` of the following runs (0 = never, the default): the siblings' bounded spins
+ * must give up and wn_run must report it (tests/test_gpu_sweep.py). */
+int wn_debug_cluster_drop(wn_engine *e, int32_t exchange);
 
 /* Which kernel the engine dispatches to: "wn_coop_kernel<NT=2,W=4,KS=25,dense>", "wn_lane_kernel<DMAX=..>" ...
  * The string is owned by the engine: valid until the next wn_set_target or wn_destroy of THIS engine;

@@ -80,6 +80,19 @@ void wno_rng_tape(uint64_t seed, uint32_t chain, uint32_t iter, int nu, double *
  * summation helpers
  * ---------------------------------------------------------------------------------------- */
 
+/* cfg->adaptQuantBits (opt-in; NOT in the reference): x rounded to b explicit mantissa bits, ties away from zero, by integer
+ * arithmetic on the bit pattern -- the same operation as the engine's wn_quant_bits (walnuts_amd/csrc/wn_chain.h) */
+static double quant_bits(double x, int b) {
+  unsigned long long u;
+  if (b <= 0 || b >= 52) return x;
+  memcpy(&u, &x, 8);
+  if (((u >> 52) & 0x7ffull) == 0x7ffull) return x; /* inf / nan: unchanged (an integer test: immune to floating-point contraction) */
+  u += 1ull << (51 - b);
+  u &= ~((1ull << (52 - b)) - 1ull);
+  memcpy(&x, &u, 8);
+  return x;
+}
+
 /* Python builtin sum(x*y): strict left to right (WALNUTS.py:97,256,308; adaptiveIntegrators.py:55) */
 static double seqdot(int n, const double *x, const double *y) {
   double s = 0.0;
@@ -1206,9 +1219,9 @@ int wno_walnuts(const wno_config *cfg, const double *q0, double *samples, double
     if (warmup) { /* :701-712 */
       if (cfg->adaptDelta) energyErrorInfFacs[iterN - 1] = orbitEnergyError / delta;
       if (cfg->adaptDelta && iterN > 10)
-        delta = cfg->adaptDeltaTarget / wno_np_quantile(energyErrorInfFacs, iterN, cfg->adaptDeltaQuantile);
+        delta = quant_bits(cfg->adaptDeltaTarget / wno_np_quantile(energyErrorInfFacs, iterN, cfg->adaptDeltaQuantile), cfg->adaptQuantBits);
       if (cfg->adaptH && igrConstQ.npush > 10)
-        H = pow(delta, 1.0 / 3.0) * exp(p2_quantile(&igrConstQ));
+        H = quant_bits(pow(delta, 1.0 / 3.0) * exp(p2_quantile(&igrConstQ)), cfg->adaptQuantBits);
     }
   }
   if (S.rng.overflow) rc = -30;

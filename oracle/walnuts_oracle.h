@@ -100,6 +100,11 @@ typedef struct {
   /* optional per-integrator-call trace */
   double *trace; /* [trace_cap][WNO_TRACE_NSCAL + 2*d] */
   int trace_cap;
+  /* NOT the reference (opt-in, 0 = off = WALNUTS.py:708-712 as written): the adapted delta and H rounded to this many explicit
+   * mantissa bits (8..52) whenever the warm-up recomputes them.  Cuts the feedback loop through H / delta that amplifies
+   * last-bit differences of the energy sums (tests/studies/warmup_sensitivity.py); the engine has the same switch
+   * (wn_config.adapt_quant_bits) and rounds with the same integer arithmetic. */
+  int adaptQuantBits;
 } wno_config;
 
 /* sizes */

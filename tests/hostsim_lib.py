@@ -33,7 +33,7 @@ class Params(C.Structure):
         ("kxi", ip), ("kq1", dp), ("kv1", dp), ("kg1", dp), ("kdout", dp), ("kiout", ip),
         ("warmupIter", C.c_int), ("adaptH", C.c_int), ("adaptDelta", C.c_int),
         ("adaptHtarget", C.c_double), ("adaptDeltaTarget", C.c_double), ("adaptDeltaQuantile", C.c_double),
-        ("facs", dp), ("omin", dp), ("omax", dp), ("xq", dp), ("xg", dp), ("xlp", dp), ("sp_done", C.c_void_p), ("cl_g", C.c_int), ("cl_red", dp), ("cl_cnt", C.c_void_p), ("cl_abort", C.c_void_p), ("cl_debug_drop", C.c_int), ("stamps", C.c_void_p),
+        ("facs", dp), ("adaptQuantBits", C.c_int), ("omin", dp), ("omax", dp), ("xq", dp), ("xg", dp), ("xlp", dp), ("sp_done", C.c_void_p), ("cl_g", C.c_int), ("cl_red", dp), ("cl_cnt", C.c_void_p), ("cl_abort", C.c_void_p), ("cl_debug_drop", C.c_int), ("stamps", C.c_void_p),
     ]
 
 
@@ -65,10 +65,11 @@ def _p(a, t=dp):
 def walnuts(target, q0, integrator=0, tpar=None, H0=0.2, stepSizeRandScale=0.2, delta0=0.05,
             numIter=10, M=10, minC=0, maxC=10, R2Pprob0=2.0 / 3.0, generated=0, gen_k=0, seed=0,
             chain0=0, trace_cap=0, warmupIter=0, adaptH=True, adaptHtarget=0.8, adaptDelta=True,
-            adaptDeltaTarget=0.6, adaptDeltaQuantile=0.9, recordOrbitStats=False):
+            adaptDeltaTarget=0.6, adaptDeltaQuantile=0.9, recordOrbitStats=False, adaptQuantBits=0):
     q0 = np.ascontiguousarray(np.atleast_2d(np.asarray(q0, float)))
     Cn, D = q0.shape
     prm = Params()
+    prm.adaptQuantBits = adaptQuantBits
     prm.D = D; prm.C = Cn; prm.mode = 0
     prm.integrator = integrator; prm.M = M; prm.numIter = numIter; prm.minC = minC; prm.maxC = maxC
     prm.generated = generated; prm.gen_k = gen_k
@@ -126,12 +127,13 @@ def fast_lib():
 
 def fast_walnuts(target, q0, tpar=None, H0=0.2, stepSizeRandScale=0.2, delta0=0.05, numIter=10, M=10, generated=0, gen_k=0,
                  seed=0, chain0=0, nlc=2, trace_cap=0, lag=2, warmupIter=0, adaptH=True, adaptHtarget=0.8, adaptDelta=True,
-                 adaptDeltaTarget=0.6, adaptDeltaQuantile=0.9):
+                 adaptDeltaTarget=0.6, adaptDeltaQuantile=0.9, adaptQuantBits=0):
     """fixedLeapFrog on a std / diagonal / dense Gaussian through FastBookT<lag> + the scalar T-wave stand-in
     (lag 2: wn_k_fast.hip, lag 3: wn_k_fast4.hip)."""
     q0 = np.ascontiguousarray(np.atleast_2d(np.asarray(q0, float)))
     Cn, D = q0.shape
     prm = Params()
+    prm.adaptQuantBits = adaptQuantBits
     prm.D = D; prm.C = Cn; prm.mode = 0
     prm.integrator = 0; prm.M = M; prm.numIter = numIter; prm.maxC = 10
     prm.generated = generated; prm.gen_k = gen_k

@@ -36,7 +36,7 @@ class WnoConfig(C.Structure):
         ("rng_mode", C.c_int), ("seed", C.c_uint64), ("chain", C.c_uint32),
         ("tape_u", c_double_p), ("tape_u_stride", C.c_int), ("tape_z", c_double_p),
         ("orbitMin", c_double_p), ("orbitMax", c_double_p),
-        ("trace", c_double_p), ("trace_cap", C.c_int),
+        ("trace", c_double_p), ("trace_cap", C.c_int), ("adaptQuantBits", C.c_int),
     ]
 
 
@@ -162,7 +162,7 @@ def walnuts(target, q0, integrator=I_FIXED, tpar=None, H0=0.2, stepSizeRandScale
             numIter=10, warmupIter=0, M=10, minC=0, maxC=10, R2Pprob0=2.0 / 3.0,
             generated=G_IDENTITY, gen_k=0, seed=0, chain=0, tape_u=None, tape_z=None,
             trace_cap=0, adaptH=True, adaptHtarget=0.8, adaptDelta=True, adaptDeltaTarget=0.6,
-            adaptDeltaQuantile=0.9, recordOrbitStats=False):
+            adaptDeltaQuantile=0.9, recordOrbitStats=False, adaptQuantBits=0):
     """One chain of the oracle's WALNUTS.  Returns dict(samples (dg,numIter+1), diagnostics
     (numIter,24), trace (ncalls, 12+2d), n_u (numIter,))."""
     q0 = _f64(q0); d = q0.size
@@ -178,6 +178,7 @@ def walnuts(target, q0, integrator=I_FIXED, tpar=None, H0=0.2, stepSizeRandScale
     cfg.adaptH = int(adaptH); cfg.adaptHtarget = adaptHtarget; cfg.adaptDelta = int(adaptDelta)
     cfg.adaptDeltaTarget = adaptDeltaTarget; cfg.adaptDeltaQuantile = adaptDeltaQuantile
     cfg.seed = seed; cfg.chain = chain
+    cfg.adaptQuantBits = int(adaptQuantBits)
     if tape_u is not None:
         tu = _f64(tape_u); tz = _f64(tape_z)
         assert tu.shape[0] == numIter and tz.shape == (numIter, d)

@@ -24,7 +24,51 @@ def test_c_abi_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(L, s), s
     assert L.wn_abi_version() == _lib.WN_ABI_VERSION
-    assert C.sizeof(_lib.WnConfig) == 120
+    assert C.sizeof(_lib.WnConfig) == 136  # ABI 5: + route, split_parts, split_ks, adapt_quant_bits
+
+
+def test_routing_is_configuration_not_environment():
+    """ABI 5 (Next #6): which of two equivalent kernels runs a configuration is `wn_config.route`, as the reference's
+    boundary is keyword arguments (WALNUTS.py:111-129).  The default build of the library reads NO environment variable: every getenv
+    left in walnuts_amd/csrc sits inside an `#ifdef WN_DIAG` region (diagnostic builds of tools/build_variant.sh), the shared object
+    does not import getenv, and wn_create validates the new fields before any HIP call."""
+    import subprocess
+    from walnuts_amd import _lib
+    src = os.path.join(ROOT, "walnuts_amd", "csrc")
+    for fn in sorted(os.listdir(src)):
+        if not fn.endswith((".hip", ".h")):
+            continue
+        depth_diag = []
+        for ln, line in enumerate(open(os.path.join(src, fn)), 1):
+            t = line.strip()
+            if t.startswith("#if"):
+                depth_diag.append("WN_DIAG" in t and "ifndef" not in t)
+            elif t.startswith("#else") and depth_diag:
+                depth_diag[-1] = False
+            elif t.startswith("#endif") and depth_diag:
+                depth_diag.pop()
+            elif "getenv(" in t and not t.startswith("//"):
+                assert any(depth_diag), f"{fn}:{ln}: getenv outside an #ifdef WN_DIAG region: {t[:90]}"
+    nm = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in nm, "libwalnuts_amd.so imports getenv"
+    hdr = open(os.path.join(ROOT, "include", "walnuts_amd.h")).read()
+    names = re.findall(r"WN_ROUTE_([A-Z0-9_]+) = 1 << (\d+)", hdr)
+    assert {n: 1 << int(k) for n, k in names} == _lib.ROUTE and len(names) == 17
+    assert _lib.route_bits(["ORBIT_LEGACY", "WN_ROUTE_DIAG_COOP"]) == (1 | 1 << 7) and _lib.route_bits(None) == 0 and _lib.route_bits(5) == 5
+    L = _lib.lib()
+    cfg = _lib.WnConfig()
+    cfg.abi_version = _lib.WN_ABI_VERSION
+    cfg.dim, cfg.n_chains, cfg.M, cfg.max_c = 3, 8, 5, 10
+    cfg.H0, cfg.delta0, cfg.step_size_rand_scale, cfg.r2p_prob0 = 0.2, 0.05, 0.2, 2.0 / 3.0
+    h = C.c_void_p()
+    for field, bad, msg in (("route", 1 << 17, b"WN_ROUTE"), ("adapt_quant_bits", 5, b"adapt_quant_bits"), ("adapt_quant_bits", 53, b"adapt_quant_bits"),
+                            ("split_parts", 5, b"split_parts"), ("split_ks", 3, b"split_parts")):
+        setattr(cfg, field, bad)
+        assert L.wn_create(C.byref(cfg), C.byref(h)) == _lib.E_ARG, field
+        assert msg in L.wn_last_error(None), (field, L.wn_last_error(None))
+        setattr(cfg, field, 0)
+    cfg.abi_version = 4  # a caller built against the previous header is refused, not misread
+    assert L.wn_create(C.byref(cfg), C.byref(h)) == _lib.E_ARG and b"abi_version" in L.wn_last_error(None)
 
 
 def test_wn_create_rejects_chain_ids_beyond_32_bits():

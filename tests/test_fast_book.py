@@ -140,3 +140,29 @@ def test_bookkeeper_warmup_adaptation_matches_the_oracle(D, warm, iters, adaptH,
         check(h, o, k, what=f"warm-up D={D} chain {k}")
         if adaptH:
             assert len(set(np.round(o["diagnostics"][:, 15], 12))) > 5  # H did adapt
+
+
+@pytest.mark.parametrize("bits", [20, 12])
+def test_adapt_quant_bits_rounds_the_adapted_step_size_like_the_oracle(bits):
+    """ABI 5's opt-in `adapt_quant_bits` (NOT the reference's arithmetic; DESIGN 9, warm-up tolerance contract): the adapted H and delta are
+    rounded to `bits` mantissa bits whenever the warm-up recomputes them -- by the engine's wn_quant_bits (here: the headline bookkeeper and
+    the generic state machine, compiled for the CPU) and by the oracle's quant_bits, the same integer operation on the bit pattern.  Every
+    adapted H / delta is a multiple of 2^(exponent - bits), equals the oracle's, and differs from the unrounded run's."""
+    D, warm, iters = 12, 30, 36
+    rng = np.random.default_rng(bits)
+    lam = np.logspace(0, 1.2, D)
+    q0 = rng.normal(size=(2, D)) * np.sqrt(lam)
+    kw = dict(H0=0.3, numIter=iters, M=6, generated=0, seed=77, warmupIter=warm)
+    h = hs.fast_walnuts(ol.T_DIAGGAUSS, q0, tpar=1.0 / lam, chain0=3, lag=4, adaptQuantBits=bits, **kw)
+    g = hs.walnuts(ol.T_DIAGGAUSS, q0, tpar=1.0 / lam, chain0=3, adaptQuantBits=bits, **kw)
+    for k in range(2):
+        o = ol.walnuts(ol.T_DIAGGAUSS, q0[k], integrator=ol.I_FIXED, tpar=1.0 / lam, chain=3 + k, adaptQuantBits=bits, **kw)
+        o0 = ol.walnuts(ol.T_DIAGGAUSS, q0[k], integrator=ol.I_FIXED, tpar=1.0 / lam, chain=3 + k, **kw)
+        check(h, o, k, what=f"quantised warm-up, bookkeeper, chain {k}")
+        np.testing.assert_array_equal(g["diagnostics"][k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]])
+        np.testing.assert_allclose(g["diagnostics"][k][:, [15, 18]], o["diagnostics"][:, [15, 18]], rtol=1e-12)
+        for col in (15, 18):
+            v = o["diagnostics"][12:warm, col]
+            m, e = np.frexp(v)
+            assert np.all(np.ldexp(m, bits + 1) == np.round(np.ldexp(m, bits + 1))), (col, v[:3])  # (frexp's mantissa is in [0.5, 1): bits + 1 binary places)
+            assert np.any(v != o0["diagnostics"][12:warm, col])

@@ -108,9 +108,9 @@ def test_cfg5_stockwatson_256_chains(wa, name, integ, H0, minC):
 
 @pytest.mark.parametrize("D,C", [(1000, 256), (600, 384)])
 def test_split_mode_in_two_parts_is_the_same_run(wa, D, C):
-    """Split mode cut into two sub-batches, each on a stream and a host thread of its own (WN_SPLIT_PARTS=2; opt-in):
+    """Split mode cut into two sub-batches, each on a stream and a host thread of its own (wn_config.split_parts = 2; opt-in):
     the chains are independent and keyed by their global index, so the draws are the one-part run's bit for bit; with the k range of
-    a GEMM tile split over two workgroups that add into zeroed rows (WN_SPLIT_KS=2) the gradient's sum is associated differently:
+    a GEMM tile split over two workgroups that add into zeroed rows (split_ks = 2) the gradient's sum is associated differently:
     integers identical, reals to 1e-9."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -119,16 +119,10 @@ def test_split_mode_in_two_parts_is_the_same_run(wa, D, C):
     A, q0 = make_dense_problem(D, 100.0, C, SEED)
 
     def go(parts, ks):
-        os.environ["WN_SPLIT_PARTS"] = str(parts)
-        os.environ["WN_SPLIT_KS"] = str(ks)
-        try:
-            e = wa.Engine(D, C, integrator=ol.I_FIXED, H0=0.5, M=8, generated=ol.G_IDENTITY).set_target(ol.T_DENSEGAUSS, A)
-            assert "split" in e.kernel_name
-            s, d = e.run(q0, SEED, IT)
-            s = s.cpu().numpy(); d = d.cpu().numpy(); e.close()
-        finally:
-            os.environ.pop("WN_SPLIT_PARTS", None)
-            os.environ.pop("WN_SPLIT_KS", None)
+        e = wa.Engine(D, C, integrator=ol.I_FIXED, H0=0.5, M=8, generated=ol.G_IDENTITY, split_parts=parts, split_ks=ks).set_target(ol.T_DENSEGAUSS, A)
+        assert "split" in e.kernel_name
+        s, d = e.run(q0, SEED, IT)
+        s = s.cpu().numpy(); d = d.cpu().numpy(); e.close()
         return s, d
 
     s1, d1 = go(1, 1)

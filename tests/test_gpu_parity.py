@@ -584,7 +584,7 @@ def test_walnuts_device_whole_transitions_on_the_device(wa):
 
 def test_walnuts_device_wave_kernel_matches_the_one_lane_kernel(wa):
     """Round 4: whole transitions of Gaussian targets run with the wave doing the work (lane = element, wstep_wave_kernel); the one-lane
-    state machine (wstep_auto_kernel, WN_WSTEP_LEGACY=1) is the same transition kernel (walnuts.py:279-359) on the same random stream.
+    state machine (wstep_auto_kernel, route WN_ROUTE_WSTEP_LEGACY) is the same transition kernel (walnuts.py:279-359) on the same random stream.
     The two associate their sums differently, so a chain agrees to rounding until a comparison at the edge of a threshold goes the
     other way (stable_steps' `<= max_error`, the acceptance test): nearly every chain must agree, and the moments must."""
     from walnuts_amd import targetDistr as td
@@ -592,11 +592,7 @@ def test_walnuts_device_wave_kernel_matches_the_one_lane_kernel(wa):
         th0 = np.random.default_rng(3).normal(size=(C, D))
         args = (tgt, im, 2.0, 8, 0.1, 0, n)
         new = wa.walnuts_device(91, th0, *args)
-        os.environ["WN_WSTEP_LEGACY"] = "1"
-        try:
-            old = wa.walnuts_device(91, th0, *args)
-        finally:
-            del os.environ["WN_WSTEP_LEGACY"]
+        old = wa.walnuts_device(91, th0, *args, route="WSTEP_LEGACY")
         assert np.isfinite(new).all()
         same = np.abs(new - old).max(axis=(1, 2)) < 1e-8
         assert same.mean() > 0.95, same.mean()
@@ -613,19 +609,17 @@ def test_walnuts_device_matches_the_reference_on_the_engine_stream(wa, legacy):
     (wstep_wave_kernel) and the one-lane state machine (wstep_auto_kernel) -- must reproduce every transition: doublings started,
     accepts, the sum of the chosen micro-step counts and of the forward ell_stable EXACTLY, every draw to rtol 1e-6.  No chain is
     budgeted away: a chain may only leave through a `<= max_error` / acceptance comparison sitting on a rounding edge, and there is
-    none in these 6 000 transitions."""
+    none in these 4 672 transitions (128 x 30 + 32 x 20 + 16 x 12)."""
     from walnuts_amd import targetDistr as td
     g = np.load(os.path.join(G, "walnuts_device.npz"))
-    if legacy:
-        os.environ["WN_WSTEP_LEGACY"] = "1"
-    try:
+    if True:
         for name in ("std10", "std10_mass", "diag24"):
             seed, C, T, D, depth, it0 = (int(v) for v in g[name + "_cfg"])
             macro, maxerr = (float(v) for v in g[name + "_par"])
             prec = g[name + "_prec"]
             tgt = td.stdGauss if np.all(prec == 1.0) else td.diagGauss(prec)
             d, st = wa.walnuts_device(seed, g[name + "_theta0"], tgt, g[name + "_inv_mass"], macro, depth, maxerr, 0, T, iter0=it0,
-                                      return_stats=True, transitions_per_launch=11)
+                                      return_stats=True, transitions_per_launch=11, route="WSTEP_LEGACY" if legacy else 0)
             ref_i = g[name + "_ints"][:, :, :4]
             bad_i = np.flatnonzero((st != ref_i).any(axis=(1, 2)))
             assert bad_i.size == 0, (name, "chains whose integers differ from the reference", bad_i[:10], st[bad_i[:1]], ref_i[bad_i[:1]])
@@ -633,15 +627,12 @@ def test_walnuts_device_matches_the_reference_on_the_engine_stream(wa, legacy):
             err = np.abs(d - ref_d) / (1e-9 + 1e-6 * np.abs(ref_d))
             bad_d = np.flatnonzero((err > 1.0).any(axis=(1, 2)))
             assert bad_d.size == 0, (name, "chains whose draws leave rtol 1e-6", bad_d[:10], err.max())
-    finally:
-        if legacy:
-            del os.environ["WN_WSTEP_LEGACY"]
 
 
 def test_walnuts_batch_wave_kernels_match_the_thread_per_chain_kernels(wa):
     """Round 5: walnuts_batch() -- the reference's contract, one numpy Generator per chain consumed on the host -- runs its extensions
     on the wave kernels (wstep_wv_*: lane = element, the chain's state in memory between the launches of a doubling) for the
-    element-wise Gaussian targets.  Same Generators, same draws as the thread-per-chain kernels (WN_WSTEP_LEGACY=1), which the
+    element-wise Gaussian targets.  Same Generators, same draws as the thread-per-chain kernels (route WN_ROUTE_WSTEP_LEGACY), which the
     reference goldens pin for every target: D = 24 > 16 (full-wave sums), a diagonal mass matrix, ragged activity (chains stop at
     different depths), and every Generator ends at the same stream position."""
     from walnuts_amd import targetDistr as td
@@ -654,11 +645,7 @@ def test_walnuts_batch_wave_kernels_match_the_thread_per_chain_kernels(wa):
     ra = [np.random.default_rng(900 + c) for c in range(C)]
     rb = [np.random.default_rng(900 + c) for c in range(C)]
     new = wa.walnuts_batch(ra, th0, *args)
-    os.environ["WN_WSTEP_LEGACY"] = "1"
-    try:
-        old = wa.walnuts_batch(rb, th0, *args)
-    finally:
-        del os.environ["WN_WSTEP_LEGACY"]
+    old = wa.walnuts_batch(rb, th0, *args, route="WSTEP_LEGACY")
     assert np.isfinite(new).all()
     close(new, old, rtol=1e-9, atol=1e-12, what="wave host-protocol kernels vs thread-per-chain kernels")
     assert all(ra[c].uniform() == rb[c].uniform() for c in range(C))

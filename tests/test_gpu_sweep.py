@@ -123,21 +123,21 @@ def test_cluster_layout_huge_gaussians(wa, D, ig):
         close(s[k], o["samples"], what=f"D={D} chain {k}")
 
 
-def test_cluster_abort_path_returns_an_error_without_hanging(wa, monkeypatch):
+def test_cluster_abort_path_returns_an_error_without_hanging(wa):
     """A workgroup of a cluster that never arrives at a cross-workgroup reduction (test hook
-    WN_DEBUG_CLUSTER_DROP = the exchange its last slice skips): the siblings' bounded spins give up, set the
+    wn_debug_cluster_drop = the exchange its last slice skips): the siblings' bounded spins give up, set the
     abort flag, every loop of every workgroup ends and wn_run reports an error."""
     import time
     D = 9000
     q0 = np.random.default_rng(1).normal(size=(2, D))
     e = wa.Engine(D, 2, integrator=ol.I_FIXED, H0=0.1, M=4, generated=ol.G_Q0_SUMSQ).set_target(ol.T_STDGAUSS)
     assert "cluster=3" in e.kernel_name
-    monkeypatch.setenv("WN_DEBUG_CLUSTER_DROP", "7")
+    assert e.lib.wn_debug_cluster_drop(e.h, 7) == 0
     t0 = time.time()
     with pytest.raises(wa.WalnutsError, match="timed out"):
         e.run(q0, SEED, 3)
     assert time.time() - t0 < 60.0
-    monkeypatch.delenv("WN_DEBUG_CLUSTER_DROP")
+    assert e.lib.wn_debug_cluster_drop(e.h, 0) == 0
     s, d = e.run(q0, SEED, 3)  # the engine is usable again: counters and the abort flag are reset per launch
     o = ol.walnuts(ol.T_STDGAUSS, q0[1], integrator=ol.I_FIXED, H0=0.1, numIter=3, M=4, seed=SEED, chain=1, generated=ol.G_Q0_SUMSQ)
     close(s.transpose(1, 2).cpu().numpy()[1], o["samples"], what="after an aborted launch")

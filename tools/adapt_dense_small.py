@@ -1,4 +1,4 @@
-"""adaptLeapFrogD / R2P on dense Gaussians of 24 .. 64 dimensions: the cooperative layout (WN_DENSE_COOP=1) against one chain per wavefront with
+"""adaptLeapFrogD / R2P on dense Gaussians of 24 .. 64 dimensions: the cooperative layout (route DENSE_COOP) against one chain per wavefront with
 the matrix in LDS.  python tools/adapt_dense_small.py   (GPU)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,12 +14,10 @@ for D in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (24
     q = torch.as_tensor(q0, device=dev)
     for name, ig in (("adaptLeapFrogD", L.I_ADAPT_D), ("adaptLeapFrogR2P", L.I_ADAPT_R2P)):
         for env in ({}, {"WN_DENSE_COOP": "1"}):
-            os.environ.pop("WN_DENSE_COOP", None); os.environ.update(env)
-            e = wa.Engine(D, C, integrator=ig, M=10, H0=0.5, delta0=0.3).set_target(L.T_DENSEGAUSS, A)
+            e = wa.Engine(D, C, integrator=ig, M=10, H0=0.5, delta0=0.3, route=[k[3:] for k in env]).set_target(L.T_DENSEGAUSS, A)
             e.run(q, 1, 20)
             s, d = e.run(q, 2, 20)
             ev = float((d[:, :, 6].sum() + d[:, :, 7].sum()).item())
             ms = e.last_run_ms()
             print("D=%-4d %-18s %-48s %.4g evaluations/s (%.1f ms)" % (D, name, e.kernel_name, ev / (ms * 1e-3), ms))
             e.close()
-os.environ.pop("WN_DENSE_COOP", None)

@@ -14,7 +14,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         A, q0 = make_dense_problem(D, 1e2, C, 7); tk, tp = L.T_DENSEGAUSS, A
     else:
         q0 = np.random.default_rng(1).normal(size=(C, D)); tk, tp = L.T_STDGAUSS, None
-    e = wa.Engine(D, C, integrator=L.I_ADAPT_FLOWD, H0=0.6, delta0=0.05, M=8).set_target(tk, tp)
+    e = wa.Engine(D, C, integrator=L.I_ADAPT_FLOWD, H0=0.6, delta0=0.05, M=8, route=sys.argv[5].split(",") if len(sys.argv) > 5 and sys.argv[5] else 0).set_target(tk, tp)
     q = torch.as_tensor(q0, device=dev)
     e.run(q, 1, 10)
     s, d = e.run(q, 2, 10)
@@ -23,7 +23,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.exit(0)
 for kind, D, C in (("dense", 40, 4096), ("dense", 100, 4096), ("std", 60, 4096), ("std", 100, 4096), ("dense", 100, 1024)):
     for env in ({}, {"WN_FLOW_NOCOOP": "1"}):
-        r = subprocess.run([sys.executable, __file__, "child", kind, str(D), str(C)], env=dict(os.environ, **env), capture_output=True, text=True)
+        r = subprocess.run([sys.executable, __file__, "child", kind, str(D), str(C), ",".join(k[3:] for k in env)], capture_output=True, text=True)
         try:
             j = json.loads(r.stdout.strip().splitlines()[-1])
             print("%-6s D=%-4d C=%-5d %-62s %.4g evaluations/s (%.1f ms)" % (kind, D, C, j["kernel"], j["evals_per_s"], j["ms"]))

@@ -18,18 +18,12 @@ bad = 0; badl = 0; done = 0; nor = 0; nwarm = 0; kernels = {}; t0 = time.time()
 
 
 def run(env, D, C, target, tpar, q0, kw, iters, off):
-    for k in ("WN_DIAG_COOP", "WN_DENSE_COOP", "WN_ORBIT_LEGACY"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    try:
-        e = wa.Engine(D, C, chain_offset=off, **kw)
-        e.set_target(target, tpar)
-        name = e.kernel_name
-        s, d = e.run(q0, 4711, iters)
-        s = s.cpu().numpy(); d = d.cpu().numpy(); e.close()
-    finally:
-        for k in env:
-            os.environ.pop(k, None)
+    # env: {"WN_<ROUTE>": "1"} -- the engine's route argument (wn_config.route), named as the environment switches of ABI <= 4 were
+    e = wa.Engine(D, C, chain_offset=off, route=[k[3:] for k in env], **kw)
+    e.set_target(target, tpar)
+    name = e.kernel_name
+    s, d = e.run(q0, 4711, iters)
+    s = s.cpu().numpy(); d = d.cpu().numpy(); e.close()
     return s, d, name
 
 

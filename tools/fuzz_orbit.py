@@ -37,12 +37,11 @@ for it in range(n):
     s, d = e.run(q0, 4242, numIter)
     s = s.transpose(1, 2).cpu().numpy(); d = d.cpu().numpy(); e.close()
     # the one-stream engine of the same layout on the same chains: the control logic must agree EXACTLY (integers), whatever the dynamics do
-    os.environ["WN_ORBIT_LEGACY"] = "1"  # (funnel10: the default kernel has a micro step of its own -- same values, other bits -- so this comparison is to rtol 1e-6 too)
-    e = wa.Engine(D, C, integrator=ig, H0=H0, delta0=delta, M=M, minC=minC, maxC=maxC, generated=gen, gen_k=gk, chain_offset=1000 * it)
+    # (funnel10: the default kernel has a micro step of its own -- same values, other bits -- so this comparison is to rtol 1e-6 too)
+    e = wa.Engine(D, C, integrator=ig, H0=H0, delta0=delta, M=M, minC=minC, maxC=maxC, generated=gen, gen_k=gk, chain_offset=1000 * it, route="ORBIT_LEGACY")
     e.set_target(tk, None)
     sl, dl = e.run(q0, 4242, numIter)
     sl = sl.transpose(1, 2).cpu().numpy(); dl = dl.cpu().numpy(); e.close()
-    del os.environ["WN_ORBIT_LEGACY"]
     with np.errstate(all="ignore"):
         same_int = np.array_equal(d[:, :, INT], dl[:, :, INT])
         rel = np.nanmax(np.abs(s - sl) / np.maximum(1e-3, np.abs(sl))) if s.size else 0.0

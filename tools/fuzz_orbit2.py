@@ -21,18 +21,12 @@ ONLY = set(int(x) for x in os.environ.get("WN_FUZZ_ONLY", "").split(",") if x)  
 
 
 def run(env, T, C, tpar, q0, kw, numIter, off):
-    for k in ("WN_ORBIT_LEGACY", "WN_ORBIT_ONEWAVE", "WN_ORBIT_WIDE_ADAPT"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    try:
-        e = wa.Engine(3 * T, C, chain_offset=off, **kw)
-        e.set_target(ol.T_STOCKWATSON, tpar)
-        name = e.kernel_name
-        s, d = e.run(q0, 777, numIter)
-        s = s.cpu().numpy(); d = d.cpu().numpy(); e.close()
-    finally:
-        for k in env:
-            os.environ.pop(k, None)
+    # env: {"WN_<ROUTE>": "1"} -- the engine's route argument (wn_config.route), named as the environment switches of ABI <= 4 were
+    e = wa.Engine(3 * T, C, chain_offset=off, route=[k[3:] for k in env], **kw)
+    e.set_target(ol.T_STOCKWATSON, tpar)
+    name = e.kernel_name
+    s, d = e.run(q0, 777, numIter)
+    s = s.cpu().numpy(); d = d.cpu().numpy(); e.close()
     return s, d, name
 
 

@@ -1,5 +1,5 @@
 """Runs WITH warm-up adaptation (the reference's mainFunnel.py:27-29 / example.py:25-27: adaptLeapFrogR2P, warmupIter = half of the run) on the
-trajectory-first kernel (default) against the kernels they used before its WARM instantiations (WN_ORBIT_LEGACY=1 / WN_DIAG_COOP=1).
+trajectory-first kernel (default) against the kernels they used before its WARM instantiations (routes ORBIT_LEGACY / DIAG_COOP / DENSE_COOP).
 python tools/warm_orbit_ab.py   (GPU)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,13 +19,10 @@ cases = [("funnel10 R2P M=12, 100 it (50 warm)", 11, L.T_FUNNEL10, None, qf, dic
 for name, D, tk, tpar, q0, kw, it, env in cases:
     q = torch.as_tensor(q0, device=dev)
     for en in ({}, env):
-        for k in ("WN_ORBIT_LEGACY", "WN_DIAG_COOP", "WN_DENSE_COOP"): os.environ.pop(k, None)
-        os.environ.update(en)
-        e = wa.Engine(D, C, **kw).set_target(tk, tpar)
+        e = wa.Engine(D, C, route=[k[3:] for k in en], **kw).set_target(tk, tpar)
         e.run(q, 1, it)
         s, d = e.run(q, 2, it)
         ev = float((d[:, :, 6].sum() + d[:, :, 7].sum()).item())
         ms = e.last_run_ms()
         print("%-38s %-50s %.4g evaluations/s (%.1f ms)" % (name, e.kernel_name, ev / (ms * 1e-3), ms))
         e.close()
-for k in ("WN_ORBIT_LEGACY", "WN_DIAG_COOP", "WN_DENSE_COOP"): os.environ.pop(k, None)

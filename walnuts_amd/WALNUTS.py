@@ -43,7 +43,10 @@ def WALNUTS(lpFun, q0, generated=identity, integrator=ai.fixedLeapFrog, H0=0.2,
             stepSizeRandScale=0.2, delta0=0.05, numIter=2000, warmupIter=1000, M=10,
             igrAux=None, adaptH=True, adaptHtarget=0.8, adaptDelta=True, adaptDeltaTarget=0.6,
             adaptDeltaQuantile=0.9, recordOrbitStats=False, *, seed=0, chain_offset=0, device=None,
-            return_torch=False, trace_cap=0):
+            return_torch=False, trace_cap=0, route=0, adaptQuantBits=0, split_parts=0, split_ks=0):
+    """Keyword-only extras: `route` (0 = the library chooses the kernel; WN_ROUTE_* names select the other implementation of the
+    same function, include/walnuts_amd.h), `adaptQuantBits` (0 = the reference's arithmetic; b: adapted H / delta rounded to b
+    mantissa bits, opt-in), `split_parts` / `split_ks` (split mode sub-batches)."""
     if igrAux is None:
         igrAux = ai.integratorAuxPar()
     if not isinstance(lpFun, (DeviceTarget, BatchedTarget)):
@@ -52,7 +55,7 @@ def WALNUTS(lpFun, q0, generated=identity, integrator=ai.fixedLeapFrog, H0=0.2,
         lpFun = host_callable(lpFun)  # the reference's plugin contract, evaluated on the host
     if not isinstance(integrator, ai.DeviceIntegrator):
         raise TypeError("integrator must be one of walnuts_amd.adaptiveIntegrators.{fixedLeapFrog,"
-                        "adaptLeapFrogD,adaptLeapFrogR2P,adaptYoshidaD}")
+                        "adaptLeapFrogD,adaptLeapFrogR2P,adaptYoshidaD,adaptLeapFrogFlowD}")
     # the reference sys.exit()s on bad adaptation targets whatever warmupIter is (WALNUTS.py:140,146)
     if adaptH and (adaptHtarget < 0.0 or adaptHtarget > 1.0):
         sys.exit("bad adaptHtarget")
@@ -78,7 +81,7 @@ def WALNUTS(lpFun, q0, generated=identity, integrator=ai.fixedLeapFrog, H0=0.2,
                       igrAux=igrAux, adaptH=adaptH, adaptHtarget=adaptHtarget, adaptDelta=adaptDelta,
                       adaptDeltaTarget=adaptDeltaTarget, adaptDeltaQuantile=adaptDeltaQuantile,
                       recordOrbitStats=recordOrbitStats, seed=seed, device=device, return_torch=return_torch,
-                      trace_cap=trace_cap)
+                      trace_cap=trace_cap, route=route, adaptQuantBits=adaptQuantBits)
             parts = [WALNUTS(lpFun, q0a[lo:lo + per], chain_offset=chain_offset + lo, **kw) for lo in range(0, C, per)]
             import torch as _t
             return tuple((_t.cat(list(x)) if return_torch else np.concatenate(list(x))) for x in zip(*parts))
@@ -87,7 +90,8 @@ def WALNUTS(lpFun, q0, generated=identity, integrator=ai.fixedLeapFrog, H0=0.2,
                  generated=generated.kind, gen_k=generated.k, warmupIter=warmupIter,
                  chain_offset=chain_offset, device=device, adaptH=adaptH, adaptHtarget=adaptHtarget,
                  adaptDelta=adaptDelta, adaptDeltaTarget=adaptDeltaTarget,
-                 adaptDeltaQuantile=adaptDeltaQuantile)
+                 adaptDeltaQuantile=adaptDeltaQuantile, route=route, adaptQuantBits=adaptQuantBits, split_parts=split_parts,
+                 split_ks=split_ks)
     if isinstance(lpFun, BatchedTarget):
         if recordOrbitStats or trace_cap:
             raise NotImplementedError("recordOrbitStats / trace need a device target descriptor")

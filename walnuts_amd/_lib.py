@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _VARIANT = os.environ.get("WN_LIB", "")
 LIB_PATH = os.path.join(_HERE, f"libwalnuts_amd_{_VARIANT}.so" if _VARIANT else "libwalnuts_amd.so")
 
-WN_ABI_VERSION = 4
+WN_ABI_VERSION = 5
 NDIAG = 24
 TRACE_NSCAL = 12
 
@@ -21,6 +21,24 @@ T_STOCKWATSON = 11
 I_FIXED, I_ADAPT_D, I_ADAPT_R2P, I_ADAPT_YOSHIDA, I_ADAPT_FLOWD = range(5)
 G_IDENTITY, G_Q0_SUMSQ, G_FIRSTK, G_SW_CONSTRAIN = range(4)
 E_ARG, E_UNSUPPORTED, E_HIP, E_NOTARGET, E_ALLOC = -1, -2, -3, -4, -5
+# WN_ROUTE_* (wn_config.route): which of two equivalent kernels runs a configuration; 0 = the library chooses
+ROUTE = {name: 1 << k for k, name in enumerate(
+    ["ORBIT_LEGACY", "ORBIT_NOWIDE", "ORBIT_WIDE_ADAPT", "ORBIT_ONEWAVE", "ORBIT_EXACT", "ORBIT2_NOADAPT", "ORBIT2_ANYC", "DIAG_COOP", "DENSE_COOP",
+     "FAST_LEGACY", "COOP_LEGACY", "FAST4_WHOLE", "FLOW_NOCOOP", "FORCE_WAVE", "LANE_GAUSS", "SPLIT_EAGER", "WSTEP_LEGACY"])}
+
+
+def route_bits(route):
+    """int, a name ("ORBIT_LEGACY"), or an iterable of names -> the WN_ROUTE_* bit mask"""
+    if route is None:
+        return 0
+    if isinstance(route, int):
+        return route
+    if isinstance(route, str):
+        route = [route]
+    r = 0
+    for name in route:
+        r |= ROUTE[name[9:] if name.startswith("WN_ROUTE_") else name]
+    return r
 
 
 class WnConfig(C.Structure):
@@ -33,13 +51,14 @@ class WnConfig(C.Structure):
         ("warmup_iter", C.c_int32), ("waves_per_group", C.c_int32),
         ("adapt_h", C.c_int32), ("adapt_delta", C.c_int32), ("adapt_h_target", C.c_double),
         ("adapt_delta_target", C.c_double), ("adapt_delta_quantile", C.c_double),
+        ("route", C.c_uint32), ("split_parts", C.c_int32), ("split_ks", C.c_int32), ("adapt_quant_bits", C.c_int32),
     ]
 
 
 # every symbol include/walnuts_amd.h declares
 SYMBOLS = ["wn_abi_version", "wn_create", "wn_set_target", "wn_run", "wn_run_orbit_stats", "wn_split_ld", "wn_split_begin", "wn_split_tick", "wn_split_done", "wn_integrator_step",
-           "wn_lpfun", "wn_lpfun_kind", "wn_wstep_create", "wn_wstep_begin", "wn_wstep_extend", "wn_wstep_commit", "wn_wstep_result", "wn_wstep_run_device_rng", "wn_wstep_set_stats",
-           "wn_wstep_ext_bind", "wn_wstep_ext_pending", "wn_wstep_ext_waiting", "wn_wstep_ext_feed", "wn_wstep_last_error", "wn_wstep_destroy", "wn_rng_tape", "wn_last_run_ms", "wn_check_run", "wn_last_split_ticks", "wn_debug_poison_lds", "wn_kernel_name", "wn_last_error",
+           "wn_lpfun", "wn_lpfun_kind", "wn_wstep_create", "wn_wstep_begin", "wn_wstep_extend", "wn_wstep_commit", "wn_wstep_result", "wn_wstep_run_device_rng", "wn_wstep_set_stats", "wn_wstep_set_route",
+           "wn_wstep_ext_bind", "wn_wstep_ext_pending", "wn_wstep_ext_waiting", "wn_wstep_ext_feed", "wn_wstep_last_error", "wn_wstep_destroy", "wn_rng_tape", "wn_last_run_ms", "wn_check_run", "wn_last_split_ticks", "wn_debug_poison_lds", "wn_debug_cluster_drop", "wn_kernel_name", "wn_last_error",
            "wn_destroy"]
 
 _lib = None
@@ -95,6 +114,8 @@ def lib():
     L.wn_wstep_run_device_rng.argtypes = [vp, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, vp, vp, vp]
     L.wn_wstep_set_stats.restype = C.c_int
     L.wn_wstep_set_stats.argtypes = [vp, vp]
+    L.wn_wstep_set_route.restype = C.c_int
+    L.wn_wstep_set_route.argtypes = [vp, C.c_uint32]
     L.wn_wstep_ext_waiting.restype = C.c_int
     L.wn_wstep_ext_waiting.argtypes = [vp, vp, vp]
     L.wn_wstep_last_error.restype = C.c_char_p
@@ -111,6 +132,8 @@ def lib():
     L.wn_last_split_ticks.argtypes = [vp, C.POINTER(C.c_int64)]
     L.wn_debug_poison_lds.restype = C.c_int
     L.wn_debug_poison_lds.argtypes = [C.c_int32, C.c_uint64, vp]
+    L.wn_debug_cluster_drop.restype = C.c_int
+    L.wn_debug_cluster_drop.argtypes = [vp, C.c_int32]
     L.wn_kernel_name.restype = C.c_char_p
     L.wn_kernel_name.argtypes = [vp]
     L.wn_last_error.restype = C.c_char_p

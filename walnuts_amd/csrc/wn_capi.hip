@@ -37,14 +37,19 @@ static int lane_dmax(int target, int D) {
   return 0;
 }
 
-int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_chains, KernelChoice* kc) {
+int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_chains, unsigned route, KernelChoice* kc) {
   kc->G = 1;
+  kc->route = route;
   const bool flow = integrator == I_ADAPT_FLOWD;  // (round 5: it runs in the cooperative MFMA layout too, one or two tiles per wave)
-  static const bool flow_nocoop = getenv("WN_FLOW_NOCOOP") != nullptr;       // diagnostic / A-B: FlowD as before round 5 (lane / wave / split)
+  const bool flow_nocoop = (route & WN_ROUTE_FLOW_NOCOOP) != 0;  // A-B: FlowD as before round 5 (lane / wave / split)
+#ifdef WN_DIAG
   const int flow_ksmax = getenv("WN_FLOW_KSMAX") ? atoi(getenv("WN_FLOW_KSMAX")) : 32;  // diagnostic: largest k-step count FlowD takes to the coop layout
+#else
+  const int flow_ksmax = 32;
+#endif
   char* nm = kc->name;  // per-choice storage: the engine owns its kernel name
   nm[0] = 0;
-  static const bool force_wave = getenv("WN_FORCE_WAVE") != nullptr;  // diagnostic: std / diagonal Gaussians on the wave layout
+  const bool force_wave = (route & WN_ROUTE_FORCE_WAVE) != 0;  // std / diagonal Gaussians on the wave layout
   int dm = lane_dmax(target, D);
   if (force_wave && (target == T_STDGAUSS || target == T_DIAGGAUSS)) dm = 0;
   // Gaussians small enough for one chain per lane use it only when there are chains to fill the chip's
@@ -52,7 +57,7 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_
   // 2-5x faster (std 16-D: fixedLeapFrog 5.4e8 vs 2.4e8, R2P 5.1e8 vs 9.5e7 evals/s; dense 16-D 7.7e8 vs 1.9e8),
   // while the lane kernel scales with the chain count (std 10-D fixedLeapFrog: 5.4e8 / 1.1e9 / 3.4e9 at 8k / 16k /
   // 64k chains against a flat 5.2e8; R2P crosses at 16k).  adaptLeapFrogFlowD has no MFMA-group kernel.
-  static const bool lane_gauss = getenv("WN_LANE_GAUSS") != nullptr;  // diagnostic: always per lane
+  const bool lane_gauss = (route & WN_ROUTE_LANE_GAUSS) != 0;  // always per lane
   if (!lane_gauss && waves_per_group != 64 && (target == T_STDGAUSS || target == T_DIAGGAUSS || target == T_DENSEGAUSS) &&
       !(D <= 4 && integrator == I_FIXED) && !(target == T_DENSEGAUSS && flow && flow_nocoop) &&
       n_chains < (integrator == I_FIXED ? 8192 : 16384))
@@ -91,10 +96,10 @@ int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_
     snprintf(nm, sizeof(kc->name), "wn_split_tick_kernel<NE=%d,external>", NE);
     return 0;
   }
-  if (target == T_DENSEGAUSS && D >= 2 && D <= 128 && integrator != I_FIXED && integrator != I_ADAPT_FLOWD && !dm && !getenv("WN_DENSE_COOP")) {
+  if (target == T_DENSEGAUSS && D >= 2 && D <= 128 && integrator != I_FIXED && integrator != I_ADAPT_FLOWD && !dm && !(route & WN_ROUTE_DENSE_COOP)) {
     // (adaptLeapFrogFlowD stays on the cooperative layout: 3.1e8 against 2.7e8 evaluations/s here)
     // the adaptive integrators on the headline geometry (round 5): one chain per wavefront, the matrix in LDS shared by a workgroup's
-    // chains (wn_k_wavelds.hip) -- a macro step is per-chain control flow, not a wide tile; WN_DENSE_COOP=1: the cooperative layout below
+    // chains (wn_k_wavelds.hip) -- a macro step is per-chain control flow, not a wide tile; WN_ROUTE_DENSE_COOP: the cooperative layout below
     kc->layout = 2; kc->p0 = 2; kc->p1 = T_DENSEGAUSS; kc->W = 1;
     snprintf(nm, sizeof(kc->name), "wn_wavelds_kernel<NE=2,dense,K=8>");
     return 0;
@@ -310,6 +315,7 @@ struct wn_engine {
   bool kabort_pending = false;    // a launch since the counter was last read
   int aborts_reported = 0;
   bool timed = false;
+  int debug_cluster_drop = 0;  // test hook (wn_debug_cluster_drop)
   std::string err;
 };
 
@@ -336,9 +342,31 @@ static std::string g_create_err;
     }                                                                          \
   } while (0)
 
+#ifdef WN_DIAG
+// diagnostic builds: the routing bits from the environment variables ABI <= 4 read inside the library (profiling scripts under tools/)
+static unsigned wn_diag_route_env() {
+  static const struct { const char* name; unsigned bit; } tab[] = {
+      {"WN_ORBIT_LEGACY", WN_ROUTE_ORBIT_LEGACY}, {"WN_ORBIT_NOWIDE", WN_ROUTE_ORBIT_NOWIDE}, {"WN_ORBIT_WIDE_ADAPT", WN_ROUTE_ORBIT_WIDE_ADAPT},
+      {"WN_ORBIT_ONEWAVE", WN_ROUTE_ORBIT_ONEWAVE}, {"WN_ORBIT_EXACT", WN_ROUTE_ORBIT_EXACT}, {"WN_ORBIT2_NOADAPT", WN_ROUTE_ORBIT2_NOADAPT},
+      {"WN_ORBIT2_ANYC", WN_ROUTE_ORBIT2_ANYC}, {"WN_DIAG_COOP", WN_ROUTE_DIAG_COOP}, {"WN_DENSE_COOP", WN_ROUTE_DENSE_COOP},
+      {"WN_FAST_LEGACY", WN_ROUTE_FAST_LEGACY}, {"WN_COOP_LEGACY", WN_ROUTE_COOP_LEGACY}, {"WN_FAST4_WHOLE", WN_ROUTE_FAST4_WHOLE},
+      {"WN_FLOW_NOCOOP", WN_ROUTE_FLOW_NOCOOP}, {"WN_FORCE_WAVE", WN_ROUTE_FORCE_WAVE}, {"WN_LANE_GAUSS", WN_ROUTE_LANE_GAUSS},
+      {"WN_SPLIT_EAGER", WN_ROUTE_SPLIT_EAGER}};
+  unsigned r = 0;
+  for (const auto& t : tab) if (getenv(t.name)) r |= t.bit;
+  return r;
+}
+#endif
+
 extern "C" {
 
 int wn_abi_version(void) { return WN_ABI_VERSION; }
+
+int wn_debug_cluster_drop(wn_engine* e, int32_t exchange) {
+  if (!e || exchange < 0) return WN_E_ARG;
+  e->debug_cluster_drop = exchange;
+  return WN_OK;
+}
 
 const char* wn_last_error(wn_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
 
@@ -360,6 +388,9 @@ int wn_create(const wn_config* cfg, wn_engine** out) {
   }
   if (!(cfg->r2p_prob0 > 0.0 && cfg->r2p_prob0 < 1.0)) { g_create_err = "R2Pprob0 must be in (0,1)"; return WN_E_ARG; }
   if (cfg->warmup_iter < 0) { g_create_err = "warmupIter must be >= 0"; return WN_E_ARG; }
+  if (cfg->adapt_quant_bits != 0 && (cfg->adapt_quant_bits < 8 || cfg->adapt_quant_bits > 52)) { g_create_err = "adapt_quant_bits must be 0 (off) or in [8, 52]"; return WN_E_ARG; }
+  if (cfg->split_parts < 0 || cfg->split_parts > 4 || cfg->split_ks < 0 || cfg->split_ks > 2) { g_create_err = "split_parts must be in [0, 4], split_ks in [0, 2]"; return WN_E_ARG; }
+  if (cfg->route >> 17) { g_create_err = "unknown WN_ROUTE_* bit"; return WN_E_ARG; }
   if (cfg->warmup_iter > 0) {  // WALNUTS.py:140,146 sys.exit("bad adaptHtarget") / ("bad adaptDeltaTarget")
     if (cfg->adapt_h && (cfg->adapt_h_target < 0.0 || cfg->adapt_h_target > 1.0)) { g_create_err = "bad adaptHtarget"; return WN_E_ARG; }
     if (cfg->adapt_delta && cfg->adapt_delta_target < 0.0) { g_create_err = "bad adaptDeltaTarget"; return WN_E_ARG; }
@@ -370,6 +401,11 @@ int wn_create(const wn_config* cfg, wn_engine** out) {
   if (cfg->generated == WN_G_FIRSTK && (cfg->gen_k < 1 || cfg->gen_k > cfg->dim)) { g_create_err = "gen_k out of range"; return WN_E_ARG; }
   wn_engine* e = new wn_engine();
   e->cfg = *cfg;
+#ifdef WN_DIAG
+  e->cfg.route |= wn_diag_route_env();  // diagnostic builds only (tools/build_variant.sh): the switches of ABI <= 4's environment
+  if (getenv("WN_SPLIT_PARTS")) e->cfg.split_parts = atoi(getenv("WN_SPLIT_PARTS"));
+  if (getenv("WN_SPLIT_KS")) e->cfg.split_ks = atoi(getenv("WN_SPLIT_KS"));
+#endif
   hipError_t r = hipSetDevice(cfg->device);
   if (r != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(r); delete e; return WN_E_HIP; }
   r = hipEventCreate(&e->ev0);
@@ -440,7 +476,7 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
   if (need && (n_params != need || !params_dev)) { e->err = "wrong parameter count for target"; return WN_E_ARG; }
   if (e->cfg.generated == WN_G_SW_CONSTRAIN && kind != WN_T_STOCKWATSON) { e->err = "generated = WN_G_SW_CONSTRAIN needs the StockWatson target"; return WN_E_ARG; }
   KernelChoice kc;
-  if (choose_kernel(kind, D, e->cfg.waves_per_group, e->cfg.integrator, e->cfg.n_chains, &kc)) {
+  if (choose_kernel(kind, D, e->cfg.waves_per_group, e->cfg.integrator, e->cfg.n_chains, e->cfg.route, &kc)) {
     e->err = "no device kernel for this (target, dim) yet";
     return WN_E_UNSUPPORTED;
   }
@@ -504,9 +540,9 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
     }
   }
   const bool warm_run = e->cfg.warmup_iter > 0 && (e->cfg.adapt_h || e->cfg.adapt_delta);  // (otherwise nothing adapts: the plain kernels are exact)
-  const bool fast4_geom = (kc.p1 != CK_DENSE || D <= 100) && !getenv("WN_FAST_LEGACY");     // wn_k_fast4.hip also runs the warm-up iterations
+  const bool fast4_geom = (kc.p1 != CK_DENSE || D <= 100) && !(kc.route & WN_ROUTE_FAST_LEGACY);     // wn_k_fast4.hip also runs the warm-up iterations
   if (kc.layout == 1 && e->cfg.integrator == WN_I_FIXED && (!warm_run || fast4_geom) && e->cfg.M <= 11 && D <= 112 && !(kc.p1 == CK_DENSE && kc.p0 == 32) &&
-      !getenv("WN_COOP_LEGACY")) {
+      !(kc.route & WN_ROUTE_COOP_LEGACY)) {
     // plain sampling runs of this engine go to the role-split kernel (wn_k_fast.hip); traced / orbit-statistics
     // runs and wn_integrator_step use the one-stream kernel of the same layout
     const int NT = kc.p0 <= 16 ? 1 : 2;
@@ -517,13 +553,13 @@ int wn_set_target(wn_engine* e, int32_t kind, const double* params_dev, size_t n
     if (fast4_geom)
     {
       const int pr_ = fast4_pairs(e->cfg.n_chains);
-      const bool halves = kc.p1 == CK_DENSE && D > 64 && pr_ == 1 && !getenv("WN_FAST4_WHOLE");  // (fast4_go: a group on two T waves)
+      const bool halves = kc.p1 == CK_DENSE && D > 64 && pr_ == 1 && !(kc.route & WN_ROUTE_FAST4_WHOLE);  // (fast4_go: a group on two T waves)
       snprintf(kc.name, sizeof(kc.name), "wn_fast4_kernel<NS=%d%s,%s,pairs=%d%s>", D <= 32 ? 2 : D <= 64 ? 4 : D <= 96 ? 6 : 7, (kc.p1 == CK_DENSE && D > 96) ? ",tail" : "",
                kc.p1 == CK_DENSE ? "dense" : "diag", pr_, halves ? ",halves" : "");
     }
   }
   if (kc.layout == 2 && kc.p0 == 1 && kc.W == 1 && kc.G == 1 && e->cfg.M >= 1 &&
-      (e->cfg.integrator == WN_I_FIXED || e->cfg.integrator == WN_I_ADAPT_D || e->cfg.integrator == WN_I_ADAPT_R2P) && !getenv("WN_ORBIT_LEGACY")) {
+      (e->cfg.integrator == WN_I_FIXED || e->cfg.integrator == WN_I_ADAPT_D || e->cfg.integrator == WN_I_ADAPT_R2P) && !(kc.route & WN_ROUTE_ORBIT_LEGACY)) {
     // plain sampling runs go to the trajectory-first kernel (wn_k_orbit.hip); traced / orbit-statistics runs and
     // wn_integrator_step use the one-stream engine of the same layout
     const char* tn = kc.p1 == T_FUNNEL10 ? "funnel10" : kc.p1 == T_CORRGAUSS ? "corrGauss" : kc.p1 == T_SMILE ? "smile" : kc.p1 == T_FUNNEL1 ? "funnel1" : "modFunnel";
@@ -587,6 +623,7 @@ static void fill_params(const wn_engine* e, Params* p) {
   p->adaptHtarget = c.adapt_h_target; p->adaptDeltaTarget = c.adapt_delta_target;
   p->adaptDeltaQuantile = c.adapt_delta_quantile;
   p->facs = e->facs;
+  p->adaptQuantBits = c.adapt_quant_bits;
 }
 
 // split mode with the built-in dense-Gaussian gradient: begin, then {batched -A q, one tick of every
@@ -610,7 +647,7 @@ static int run_split_dense(wn_engine* e, Params p, hipStream_t st, int adapt, bo
     HIPCHK(e, hipStreamWaitEvent(e->sp_main, e->sp_fork0, 0));
     st = e->sp_main;
   }
-  // PARTS (opt-in: WN_SPLIT_PARTS=2 [WN_SPLIT_KS=1|2]; measured in round 4).  The chains are independent, so the run
+  // PARTS (opt-in: wn_config.split_parts = 2 [split_ks = 1|2]; measured in round 4).  The chains are independent, so the run
   // can be cut into sub-batches, each with its own stream, exchange rows, workspace, finished-chain counter and host thread, and
   // the chain kernel of one (HBM-bound) can run while the other is inside its gradient GEMM (matrix-pipe-bound).  Two parts with
   // 64 x 64 tiles (128 workgroups per GEMM, the two GEMMs side by side): +2.4 %, bit-identical draws -- each part's own
@@ -620,7 +657,7 @@ static int run_split_dense(wn_engine* e, Params p, hipStream_t st, int adapt, bo
   // FP64 MFMA waves takes 40 us instead of 13, at any s_setprio.  The default stays one part.
   int NP = 1;
   {
-    const int parts_env = getenv("WN_SPLIT_PARTS") ? atoi(getenv("WN_SPLIT_PARTS")) : 0;  // (read per run: tests switch it)
+    const int parts_env = e->cfg.split_parts;
     int want = parts_env > 0 ? parts_env : 1;
 #if defined(WN_STAMPS) || defined(WN_SPAN)
     want = 1;  // (the diagnostic rows are indexed by the local chain)
@@ -630,7 +667,7 @@ static int run_split_dense(wn_engine* e, Params p, hipStream_t st, int adapt, bo
     NP = want < 1 ? 1 : want;
   }
   const int Cp = p.C / NP;
-  const int ks_env = getenv("WN_SPLIT_KS") ? atoi(getenv("WN_SPLIT_KS")) : 0;
+  const int ks_env = e->cfg.split_ks;
   const int KS = NP > 1 && ks_env == 2 ? 2 : 1;
   struct Part { Params p; hipStream_t st; hipGraph_t graph; hipGraphExec_t gexec; int* done_dev; int* h_poll; const double* xq; double* xg; };
   Part part[4];
@@ -695,8 +732,8 @@ static int run_split_dense(wn_engine* e, Params p, hipStream_t st, int adapt, bo
   }
   // One batch = 64 ticks = 128 launches.  By default the batch is captured ONCE per run (and per part) into a hipGraph and replayed:
   // the GPU then paces the ticks itself, whatever the host thread is doing (round 2's driver-run number for this path, 1.29e7 steps/s
-  // against 1.9e7 in the builder's runs, was eager launches falling behind on a busy host).  WN_SPLIT_EAGER=1: eager launches.
-  static const bool eager = getenv("WN_SPLIT_EAGER") != nullptr;
+  // against 1.9e7 in the builder's runs, was eager launches falling behind on a busy host).  WN_ROUTE_SPLIT_EAGER: eager launches.
+  const bool eager = (e->cfg.route & WN_ROUTE_SPLIT_EAGER) != 0;
   auto grad = [&](const Part& q) { return launch_dense_grad(e->apad, q.xq, q.xg, e->DP, p.D, Cpad_p, q.done_dev, q.p.C, q.st, NP > 1 ? (KS > 1 ? 42 : 4) : 0); };
   auto enqueue_batch = [&](const Part& q) -> hipError_t {
     hipError_t rr = hipSuccess;
@@ -721,7 +758,9 @@ static int run_split_dense(wn_engine* e, Params p, hipStream_t st, int adapt, bo
         if (rg == hipSuccess && rl != hipSuccess) rg = rl;
       }
       if (rg == hipSuccess) rg = hipGraphInstantiate(&q.gexec, q.graph, nullptr, nullptr, 0);
+#ifdef WN_DIAG
       if (getenv("WN_SPLIT_DEBUG")) fprintf(stderr, "[wn split] part %d of %d: hipGraph of 64 ticks: %s\n", k, NP, rg == hipSuccess ? "captured" : hipGetErrorString(rg));
+#endif
       if (rg != hipSuccess) {  // (fall back to eager launches)
         (void)hipGetLastError();
         if (q.gexec) { hipGraphExecDestroy(q.gexec); q.gexec = nullptr; }
@@ -813,12 +852,12 @@ static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
   Params pc = p;
   if (e->kc.G > 1) {
     pc.cl_g = e->kc.G; pc.cl_red = e->cl_red; pc.cl_cnt = e->cl_cnt; pc.cl_abort = (int*)(e->cl_cnt + e->cfg.n_chains);
-    if (const char* dd = getenv("WN_DEBUG_CLUSTER_DROP")) pc.cl_debug_drop = atoi(dd);  // test hook: tests/test_gpu_wave.py
+    pc.cl_debug_drop = e->debug_cluster_drop;  // test hook: wn_debug_cluster_drop (tests/test_gpu_sweep.py)
     HIPCHK(e, hipMemsetAsync(e->cl_cnt, 0, ((size_t)e->cfg.n_chains + 16) * sizeof(unsigned), st));
   }
   const Params& p_ = pc;
-  const bool coop_legacy = getenv("WN_COOP_LEGACY") != nullptr;  // diagnostic / A-B tests: one-stream kernel (read per launch)
-  const bool fast_legacy = getenv("WN_FAST_LEGACY") != nullptr;  // diagnostic / A-B tests: the seven-T-wave kernel for dense targets too
+  const bool coop_legacy = (e->cfg.route & WN_ROUTE_COOP_LEGACY) != 0;  // A-B tests: one-stream kernel
+  const bool fast_legacy = (e->cfg.route & WN_ROUTE_FAST_LEGACY) != 0;  // A-B tests: the seven-T-wave kernel for dense targets too
   // the tick-bound abort flag of the fast kernels belongs to THIS run: cleared in stream order before the launch; wn_last_run_ms,
   // the next wn_run and wn_destroy report a run that gave up
   if (e->kabort_pending) { int rc_ = check_abort(e, false); if (rc_) return rc_; }

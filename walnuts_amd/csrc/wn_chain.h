@@ -64,6 +64,7 @@ struct Params {
   int warmupIter, adaptH, adaptDelta;
   double adaptHtarget, adaptDeltaTarget, adaptDeltaQuantile;
   double* facs;  // [C][2][warmupIter] sorted energyErrorInfFacs, double-buffered
+  int adaptQuantBits;  // 0 = the reference's arithmetic; b: the adapted H / delta rounded to b mantissa bits (wn_config.adapt_quant_bits, opt-in)
   // recordOrbitStats (WALNUTS.py:128,182-184): [C][numIter][dg] min / max of generated(q) over the
   // orbit states of each iteration, or null (generated = identity / first-k only)
   double *omin, *omax;
@@ -226,6 +227,20 @@ WN_HD void wn_p2_push(const Params& prm, double (&p2q)[5], int (&p2m)[5], int& p
     }
   }
 }
+// wn_config.adapt_quant_bits (opt-in, not the reference): x rounded to b explicit mantissa bits, ties away from zero -- pure integer
+// arithmetic on the bit pattern, so the CPU checker (quant_bits under oracle/) and every kernel round identically
+WN_HD double wn_quant_bits(double x, int b) {
+  if (b <= 0 || b >= 52) return x;  // off, or nothing to drop
+  unsigned long long u;
+  __builtin_memcpy(&u, &x, 8);
+  // not finite: unchanged.  (An integer test: `x - x == 0.0` on a freshly computed product is contracted into fma(a, b, -(a * b)) by hipcc's
+  // default -ffp-contract=fast, i.e. into the product's rounding error -- round 6's first build left H unrounded for exactly that reason.)
+  if (((u >> 52) & 0x7ffull) == 0x7ffull) return x;
+  u += 1ull << (51 - b);
+  u &= ~((1ull << (52 - b)) - 1ull);
+  __builtin_memcpy(&x, &u, 8);
+  return x;
+}
 // `fc`: this chain's (this workgroup's) sorted copies [2][warmupIter]; `writer`: the one lane that extends them
 WN_HD void wn_adapt_update(const Params& prm, int iter, double orbitEnergyError, double* fc, bool writer, double& dc, double& Hc,
                                   const double (&p2q)[5], int p2n) {
@@ -256,7 +271,7 @@ WN_HD void wn_adapt_update(const Params& prm, int iter, double orbitEnergyError,
         const double A = elem(prev), B = elem(next), dba = B - A;
         res = gamma >= 0.5 ? (B - dba * (1 - gamma)) : (A + dba * gamma);
       }
-      dc = prm.adaptDeltaTarget / res;
+      dc = wn_quant_bits(prm.adaptDeltaTarget / res, prm.adaptQuantBits);
     }
     if (writer) {  // extend the sorted copy into the other buffer
       for (int r = 0; r < pos; ++r) nxt[r] = cur[r];
@@ -264,7 +279,7 @@ WN_HD void wn_adapt_update(const Params& prm, int iter, double orbitEnergyError,
       for (int r = pos; r < n0; ++r) nxt[r + 1] = cur[r];
     }
   }
-  if (prm.adaptH && p2n > 10) Hc = pow(dc, 1.0 / 3.0) * exp(p2q[2]);  // :711-712
+  if (prm.adaptH && p2n > 10) Hc = wn_quant_bits(pow(dc, 1.0 / 3.0) * exp(p2q[2]), prm.adaptQuantBits);  // :711-712
 }
 
 // FLOW: adaptLeapFrogFlowD (adaptiveIntegrators.py:246-356) -- the search of adaptLeapFrogD with

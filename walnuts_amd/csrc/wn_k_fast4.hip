@@ -1203,14 +1203,14 @@ int fast4_pairs(int C);
 #endif
 
 template <int NS, bool TAIL, bool DENSE, bool WARM>
-static hipError_t fast4_go(const Params& prm, int* abort_flag, hipStream_t st) {
+static hipError_t fast4_go(const Params& prm, int* abort_flag, hipStream_t st, bool whole) {
   using G = Fast4Geom<NS, TAIL, DENSE>;
   const int pairs = fast4_pairs(prm.C), groups = (prm.C + 3) / 4;
   hipError_t r;
   constexpr bool CAN_TRACE = !WARM;  // (WARM instantiations exist untraced only)
   // fewer groups than two per CU (BASELINE configs[1]'s literal 1024 chains = 256 groups): the group's vectors on TWO T waves (halves), so
   // that a CU's four SIMDs run R, I and two half-tick T waves instead of R, I, one T wave and nothing
-  if constexpr (DENSE && NS >= 6) if (pairs == 1 && !getenv("WN_FAST4_WHOLE")) {
+  if constexpr (DENSE && NS >= 6) if (pairs == 1 && !whole) {
     dim3 grid(groups), block(256);
     const size_t shm = G::lds_bytes_halves();
     if (CAN_TRACE && prm.trace_n) {
@@ -1241,17 +1241,18 @@ static hipError_t fast4_go(const Params& prm, int* abort_flag, hipStream_t st) {
 template <bool WARM>
 static hipError_t fast4_dispatch(const KernelChoice& kc, const Params& prm, int* abort_flag, hipStream_t st) {
   const int D = prm.D;
+  const bool whole = (kc.route & WN_ROUTE_FAST4_WHOLE) != 0;
   if (kc.p1 == 0 /* CK_DENSE */) {
-    if (D <= 32) return fast4_go<2, false, true, WARM>(prm, abort_flag, st);
-    if (D <= 64) return fast4_go<4, false, true, WARM>(prm, abort_flag, st);
-    if (D <= 96) return fast4_go<6, false, true, WARM>(prm, abort_flag, st);
-    if (D <= 100) return fast4_go<7, true, true, WARM>(prm, abort_flag, st);
+    if (D <= 32) return fast4_go<2, false, true, WARM>(prm, abort_flag, st, whole);
+    if (D <= 64) return fast4_go<4, false, true, WARM>(prm, abort_flag, st, whole);
+    if (D <= 96) return fast4_go<6, false, true, WARM>(prm, abort_flag, st, whole);
+    if (D <= 100) return fast4_go<7, true, true, WARM>(prm, abort_flag, st, whole);
     return hipErrorInvalidValue;
   }
-  if (D <= 32) return fast4_go<2, false, false, WARM>(prm, abort_flag, st);
-  if (D <= 64) return fast4_go<4, false, false, WARM>(prm, abort_flag, st);
-  if (D <= 96) return fast4_go<6, false, false, WARM>(prm, abort_flag, st);
-  if (D <= 112) return fast4_go<7, false, false, WARM>(prm, abort_flag, st);
+  if (D <= 32) return fast4_go<2, false, false, WARM>(prm, abort_flag, st, whole);
+  if (D <= 64) return fast4_go<4, false, false, WARM>(prm, abort_flag, st, whole);
+  if (D <= 96) return fast4_go<6, false, false, WARM>(prm, abort_flag, st, whole);
+  if (D <= 112) return fast4_go<7, false, false, WARM>(prm, abort_flag, st, whole);
   return hipErrorInvalidValue;
 }
 

@@ -36,6 +36,9 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // KS = 2: two workgroups share a tile, each with half of k, and ADD their halves into xg (which the chain kernel has zeroed:
 // Params::xzero): a sub-batch of half the chains then still has a workgroup for every CU (wn_capi.hip, run_split_dense).  The sum of
 // two numbers does not depend on which arrives first, so the result is as reproducible as the one-workgroup form's.
+#ifndef WN_GEMM_XD
+#define WN_GEMM_XD 2  // row-panel groups over the 8 XCDs (1 = the whole row range per XCD, 8 = the whole chain range per XCD)
+#endif
 template <int NJ, int KS = 1>
 __global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __restrict__ A, const double* __restrict__ xq,
                                                             double* __restrict__ xg, int DP, int Kr, int tiles_d,
@@ -43,12 +46,24 @@ __global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __rest
   if (*done >= C) return;  // every chain has finished: nothing reads the result
   __shared__ double red[4 * 3 * 4 * NJ * 64];  // [owner wave][partial accumulator of a contributor][lane]
   const int T = tiles_d * tiles_c * KS, per = (T + 7) / 8;
-  // consecutive blocks go to different XCDs: give each XCD a contiguous range of tiles (same chains,
-  // neighbouring rows of A) so its L2 sees each operand row once
-  const int tv = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= per || tv >= T) return;
-  const int t = tv / KS, ks = tv % KS;
-  const int ct = t / tiles_d, dt = t % tiles_d;
+  // consecutive blocks go to different XCDs (blockIdx.x & 7): give each XCD a RECTANGLE of tiles, XD row-panel groups x 8/XD chain-panel
+  // groups, so that its L2 (4 MB) holds what its 32 workgroups share.  D = 1000, 1024 chains (16 x 16 tiles): XD = 2 -> 8 row panels of A
+  // (4 MB, each used by 4 workgroups) + 4 chain panels of xq (2 MB, each used by 8) per XCD = 6 MB fetched per XCD and launch; the
+  // contiguous range of round 1 (2 chain panels x all 16 row panels) streamed all 8 MB of A through every L2 and used each panel twice: 9 MB.
+  int ct, dt, ks = 0;
+  const int xd = WN_GEMM_XD;
+  if (KS == 1 && tiles_d % xd == 0 && tiles_c % (8 / xd) == 0) {
+    const int nd = tiles_d / xd, nc = tiles_c / (8 / xd), x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    if (j >= nd * nc) return;
+    ct = (x / xd) * nc + j / nd;
+    dt = (x % xd) * nd + j % nd;
+  } else {
+    const int tv = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || tv >= T) return;
+    const int t = tv / KS;
+    ks = tv % KS;
+    ct = t / tiles_d; dt = t % tiles_d;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int d0 = dt * 64, c0 = ct * 16 * NJ;
   const int r = lane & 15;
@@ -110,7 +125,11 @@ hipError_t launch_dense_grad(const double* A, const double* xq, double* xg, int 
                              hipStream_t st, int nj) {
   const int Kr = (D + 15) / 16 * 16;
   const int tiles_d = DP / 64;
+#ifdef WN_DIAG
   static const int narrow_env = getenv("WN_GEMM_NJ") ? atoi(getenv("WN_GEMM_NJ")) : 0;  // diagnostic override
+#else
+  const int narrow_env = 0;
+#endif
   // nj = 4: the caller runs several sub-batches side by side and wants one workgroup per CU from each (wn_capi.hip, run_split_dense)
   const bool narrow = (nj == 2 || nj == 4) ? nj == 2 : narrow_env ? narrow_env == 2 : (tiles_d * (Cpad / 64) < 256);
   if (nj == 42) {  // 64 x 64 tiles, k split over two workgroups

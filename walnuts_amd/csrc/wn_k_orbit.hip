@@ -850,19 +850,19 @@ int orbit_wide_ne(const KernelChoice& kc) { return orbit_diag_geom(kc) ? 2 : orb
 size_t orbit_wide_work_doubles(int NE, int C, int M) { return (size_t)C * orbit::wide_doubles(NE, M); }
 // Which plain sampling runs of that geometry take the wide mode: fixedLeapFrog (mainSW.py:56-62: a leaf is ONE evaluation, the one-stream
 // engine spends 40 % of it on bookkeeping).  A macro step of the adaptive integrators is 8+ evaluations (minC = 3): its bookkeeping is a
-// twentieth of it in either kernel, and the one-stream engine's is the cheaper one (no ring, no batch draws); WN_ORBIT_WIDE_ADAPT=1 sends
+// twentieth of it in either kernel, and the one-stream engine's is the cheaper one (no ring, no batch draws); WN_ROUTE_ORBIT_WIDE_ADAPT sends
 // them here all the same (tests/test_gpu_orbit.py: the generic kernel against that engine, bit for bit).
 bool orbit_wide_run(const KernelChoice& kc, int integrator) {
-  if (!orbit_wide_geom(kc) || getenv("WN_ORBIT_LEGACY") || getenv("WN_ORBIT_NOWIDE")) return false;
+  if (!orbit_wide_geom(kc) || (kc.route & (WN_ROUTE_ORBIT_LEGACY | WN_ROUTE_ORBIT_NOWIDE))) return false;
   // the dense Gaussian is here for its adaptive runs (wn_k_wavelds.hip): a macro step is an evaluation or two, batches of 16 leaves pay
   if (orbit_dense_geom(kc)) return integrator == I_ADAPT_D || integrator == I_ADAPT_R2P;
   // std / diagonal Gaussian, 17 <= D <= 128: the same argument with a trivial gradient (the cooperative layout's tick machine is what costs)
-  if (orbit_diag_geom(kc)) return (integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && !getenv("WN_DIAG_COOP");
+  if (orbit_diag_geom(kc)) return (integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && !(kc.route & WN_ROUTE_DIAG_COOP);
   // fixedLeapFrog on 129 .. 256 dimensions (3.7e8 -> 5.9e8 steps/s at D = 256; up to 112 dimensions the role-split kernels are faster, beyond 256 the
   // wave layout's engine as fast: tools/fixed_diag8_ab.py)
-  if (orbit_diag64_geom(kc)) return integrator == I_FIXED && !getenv("WN_DIAG_COOP");
-  if (orbit_diag8_geom(kc)) return (integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && !getenv("WN_DIAG_COOP");
-  return integrator == I_FIXED || ((integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && getenv("WN_ORBIT_WIDE_ADAPT"));
+  if (orbit_diag64_geom(kc)) return integrator == I_FIXED && !(kc.route & WN_ROUTE_DIAG_COOP);
+  if (orbit_diag8_geom(kc)) return (integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && !(kc.route & WN_ROUTE_DIAG_COOP);
+  return integrator == I_FIXED || ((integrator == I_ADAPT_D || integrator == I_ADAPT_R2P) && (kc.route & WN_ROUTE_ORBIT_WIDE_ADAPT));
 }
 
 bool orbit_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm) {
@@ -877,7 +877,7 @@ bool orbit_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& 
   if (prm.integrator != I_FIXED && prm.integrator != I_ADAPT_D && prm.integrator != I_ADAPT_R2P) return false;
   if (prm.M < 1 || prm.M > MAX_M || (!wide && prm.D > 16) || prm.maxC > 12 || prm.minC < 0 || prm.minC > prm.maxC) return false;
   if (prm.generated != G_IDENTITY && prm.generated != G_FIRSTK && prm.generated != G_Q0_SUMSQ) return false;
-  if (getenv("WN_ORBIT_LEGACY")) return false;
+  if (kc.route & WN_ROUTE_ORBIT_LEGACY) return false;
   if (wide) return orbit_wide_run(kc, prm.integrator) && (!orbit_diag_geom(kc) || prm.D <= 128) && (!orbit_diag64_geom(kc) || (prm.D > 128 && prm.D <= 256)) && (!orbit_diag8_geom(kc) || (prm.D > 128 && prm.D <= 512));
   switch (kc.p1) {
     case T_FUNNEL10: case T_CORRGAUSS: case T_SMILE: case T_FUNNEL1: case T_MODFUNNEL: return true;
@@ -889,14 +889,14 @@ template <class T_, class = void> struct has_fused_step { static constexpr bool 
 template <class T_> struct has_fused_step<T_, typename std::enable_if<T_::FUSED_STEP>::type> { static constexpr bool value = true; };
 
 template <class Tgt>
-static hipError_t go_orbit(const Params& prm, hipStream_t st) {
+static hipError_t go_orbit(const Params& prm, hipStream_t st, bool exact) {
   const size_t dyn = (size_t)orbit::lds_doubles(prm.M) * sizeof(double);
   dim3 grid(prm.C), block(64);
-  // a target with a micro step of its own (one reduction instead of two) runs it unless WN_ORBIT_EXACT=1 asks for the arithmetic of
+  // a target with a micro step of its own (one reduction instead of two) runs it unless WN_ROUTE_ORBIT_EXACT asks for the arithmetic of
   // the one-stream engine (the bit-for-bit comparisons of tests/test_gpu_orbit.py)
   const bool warm = prm.warmupIter > 0;  // (the warm-up iterations run here too: WARM instantiations, each target's default arithmetic)
   if (warm) {
-    if constexpr (has_fused_step<Tgt>::value) if (!getenv("WN_ORBIT_EXACT")) {
+    if constexpr (has_fused_step<Tgt>::value) if (!exact) {
       if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_R2P, true, 1, 1, true>), grid, block, dyn, st, prm);
       else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_D, true, 1, 1, true>), grid, block, dyn, st, prm);
       else hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_FIXED, true, 1, 1, true>), grid, block, dyn, st, prm);
@@ -907,7 +907,7 @@ static hipError_t go_orbit(const Params& prm, hipStream_t st) {
     else hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_FIXED, false, 1, 1, true>), grid, block, dyn, st, prm);
     return hipGetLastError();
   }
-  if constexpr (has_fused_step<Tgt>::value) if (!getenv("WN_ORBIT_EXACT")) {
+  if constexpr (has_fused_step<Tgt>::value) if (!exact) {
     if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_R2P, true>), grid, block, dyn, st, prm);
     else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_D, true>), grid, block, dyn, st, prm);
     else hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_FIXED, true>), grid, block, dyn, st, prm);
@@ -948,17 +948,18 @@ static hipError_t go_orbit_wide_k(const Params& prm, hipStream_t st) {
 }
 
 hipError_t launch_orbit(const KernelChoice& kc, const Params& prm, hipStream_t st) {
+  const bool exact = (kc.route & WN_ROUTE_ORBIT_EXACT) != 0;
   if (orbit_dense_geom(kc)) return go_orbit_wide_k<WTgtDenseLDS<2>, 2, 8>(prm, st);
-  if (orbit_diag_geom(kc)) return prm.D <= 16 ? go_orbit<WTgtDiagRow>(prm, st) : go_orbit_wide_k<WTgtDiag<2>, 2, 4>(prm, st);
+  if (orbit_diag_geom(kc)) return prm.D <= 16 ? go_orbit<WTgtDiagRow>(prm, st, exact) : go_orbit_wide_k<WTgtDiag<2>, 2, 4>(prm, st);
   if (orbit_diag64_geom(kc)) return go_orbit_wide_k<WTgtDiag<4>, 4, 4, true>(prm, st);
   if (orbit_diag8_geom(kc)) return prm.D <= 256 ? go_orbit_wide_k<WTgtDiag<4>, 4, 4>(prm, st) : go_orbit_wide_k<WTgtDiag<8>, 8, 4>(prm, st);
   if (orbit_wide_geom(kc)) return go_orbit_wide<WTgtStockWatson<12>, 12>(prm, st);
   switch (kc.p1) {
-    case T_FUNNEL10: return go_orbit<WTgtFunnel10>(prm, st);
-    case T_CORRGAUSS: return go_orbit<WTgtPair<TgtCorrGauss>>(prm, st);
-    case T_SMILE: return go_orbit<WTgtPair<TgtSmile>>(prm, st);
-    case T_FUNNEL1: return go_orbit<WTgtPair<TgtFunnel1>>(prm, st);
-    case T_MODFUNNEL: return go_orbit<WTgtPair<TgtModFunnel>>(prm, st);
+    case T_FUNNEL10: return go_orbit<WTgtFunnel10>(prm, st, exact);
+    case T_CORRGAUSS: return go_orbit<WTgtPair<TgtCorrGauss>>(prm, st, exact);
+    case T_SMILE: return go_orbit<WTgtPair<TgtSmile>>(prm, st, exact);
+    case T_FUNNEL1: return go_orbit<WTgtPair<TgtFunnel1>>(prm, st, exact);
+    case T_MODFUNNEL: return go_orbit<WTgtPair<TgtModFunnel>>(prm, st, exact);
   }
   return hipErrorInvalidValue;
 }

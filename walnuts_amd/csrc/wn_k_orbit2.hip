@@ -1000,10 +1000,10 @@ static int device_cus() {
   return n;
 }
 bool orbit2_run(const KernelChoice& kc, int integrator, int n_chains) {
-  if (!orbit_wide_geom(kc) || kc.p1 != T_STOCKWATSON || getenv("WN_ORBIT_LEGACY") || getenv("WN_ORBIT_NOWIDE") || getenv("WN_ORBIT_ONEWAVE")) return false;
+  if (!orbit_wide_geom(kc) || kc.p1 != T_STOCKWATSON || (kc.route & (WN_ROUTE_ORBIT_LEGACY | WN_ROUTE_ORBIT_NOWIDE | WN_ROUTE_ORBIT_ONEWAVE))) return false;
   const bool adaptive = integrator == I_ADAPT_D || integrator == I_ADAPT_R2P;
-  if (integrator != I_FIXED && !(adaptive && !getenv("WN_ORBIT2_NOADAPT"))) return false;
-  return getenv("WN_ORBIT2_ANYC") || n_chains <= device_cus() * (adaptive ? 1 : 2);
+  if (integrator != I_FIXED && !(adaptive && !(kc.route & WN_ROUTE_ORBIT2_NOADAPT))) return false;
+  return (kc.route & WN_ROUTE_ORBIT2_ANYC) || n_chains <= device_cus() * (adaptive ? 1 : 2);
 }
 bool orbit2_eligible(const KernelChoice& kc, int adapt, bool warm, const Params& prm) {
   if (!orbit2_run(kc, prm.integrator, prm.C)) return false;

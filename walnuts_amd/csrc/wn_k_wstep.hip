@@ -825,6 +825,7 @@ struct wn_wstep {
   double *tpar = nullptr, *im = nullptr;
   int* lot = nullptr;
   double* wst = nullptr;   // wave kernels of the host-driven protocol: the chains' states between launches, [B][WvChain::ST_DOUBLES]
+  uint32_t route = 0;      // WN_ROUTE_WSTEP_LEGACY or 0 (wn_wstep_set_route)
   int* stats = nullptr;    // caller-owned [B][n_transitions][4] of the next wn_wstep_run_device_rng calls (wn_wstep_set_stats), or null
   int* asub = nullptr;     // device-RNG transitions: per-chain scratch of extend_finish
   double* alse = nullptr;  // [2][B]
@@ -844,6 +845,13 @@ static std::string g_wstep_err;
 extern "C" {
 
 const char* wn_wstep_last_error(wn_wstep* h) { return h ? h->err.c_str() : g_wstep_err.c_str(); }
+
+int wn_wstep_set_route(wn_wstep* h, uint32_t route) {
+  if (!h) return WN_E_ARG;
+  if (route & ~(uint32_t)WN_ROUTE_WSTEP_LEGACY) { h->err = "wn_wstep_set_route: only WN_ROUTE_WSTEP_LEGACY (or 0) applies to this handle"; return WN_E_ARG; }
+  h->route = route;
+  return WN_OK;
+}
 
 int wn_wstep_destroy(wn_wstep* h) {
   if (!h) return WN_OK;
@@ -925,7 +933,7 @@ int wn_wstep_create(int32_t device, int32_t target_kind, const double* tpar_dev,
 }
 
 // element-wise Gaussian targets run the host-driven protocol on the wave kernels too (WN_WSTEP_LEGACY=1: the thread-per-chain kernels)
-static bool wave_path(const wn_wstep* h) { return h->wst != nullptr && !getenv("WN_WSTEP_LEGACY"); }
+static bool wave_path(const wn_wstep* h) { return h->wst != nullptr && !(h->route & WN_ROUTE_WSTEP_LEGACY); }
 
 static int wstep_launch(wn_wstep* h, int mode, const double* theta, const double* rho, const int* backward, const int* active,
                         int nmacro, int* sub_out, double* lse_ext, double* lse_old, hipStream_t st) {
@@ -1023,7 +1031,7 @@ int wn_wstep_run_device_rng(wn_wstep* h, uint64_t seed, int64_t chain_offset, in
   if (chain_offset < 0 || (uint64_t)chain_offset + (uint64_t)h->c.B > (1ull << 32)) { h->err = "chain_offset + B must stay within [0, 2^32)"; return WN_E_ARG; }
   WCHK(hipSetDevice(h->device));
   // element-wise targets: the wave-parallel kernel (lane = element); WN_WSTEP_LEGACY=1 keeps the one-lane kernel (A/B tests)
-  if ((h->c.kind == T_STDGAUSS || h->c.kind == T_DIAGGAUSS) && h->c.nmax <= 8192 && !getenv("WN_WSTEP_LEGACY")) {
+  if ((h->c.kind == T_STDGAUSS || h->c.kind == T_DIAGGAUSS) && h->c.nmax <= 8192 && !(h->route & WN_ROUTE_WSTEP_LEGACY)) {
     const size_t dyn = (size_t)h->c.nmax * sizeof(int);
     if (h->c.D <= 16) hipLaunchKernelGGL(wstep_wave_kernel<true>, dim3(h->c.B), dim3(64), dyn, (hipStream_t)stream, h->c, h->lot, seed, (uint32_t)chain_offset,
                                          (int)iter0, (int)n_transitions, h->max_depth, theta_dev, draws_dev, h->stats);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#include "../../include/walnuts_amd.h"  // WN_ROUTE_*
 #include "wn_chain.h"
 
 namespace wn {
@@ -14,11 +15,12 @@ struct KernelChoice {
   int p1;      // lane: target kind ; coop: CK_DENSE / CK_DIAG ; wave: target kind ; split: EXT_*
   int W;       // coop: waves per group
   int G;       // wave layout: workgroups per chain (cluster), 1 otherwise
+  unsigned route;  // WN_ROUTE_* bits of the engine's configuration (include/walnuts_amd.h)
   char name[96];  // owned by the engine that holds this choice (no shared static storage)
 };
 
 // returns 0 and fills `kc` if a kernel exists for (target, D)
-int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_chains, KernelChoice* kc);
+int choose_kernel(int target, int D, int waves_per_group, int integrator, int n_chains, unsigned route, KernelChoice* kc);
 size_t kernel_work_doubles(const KernelChoice& kc, int C, int M);
 hipError_t launch_lane(const KernelChoice& kc, int adapt /* 0 fixed, 1 adaptive, 2 adaptLeapFrogFlowD */, bool warm, const Params& prm, hipStream_t st);
 hipError_t launch_coop(const KernelChoice& kc, int adapt /* 0 fixed, 1 adaptive, 2 adaptLeapFrogFlowD */, bool warm, const Params& prm, hipStream_t st);

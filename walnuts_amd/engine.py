@@ -26,7 +26,11 @@ class Engine:
     def __init__(self, dim, n_chains, integrator=L.I_FIXED, H0=0.2, stepSizeRandScale=0.2,
                  delta0=0.05, M=10, minC=0, maxC=10, R2Pprob0=2.0 / 3.0, generated=L.G_IDENTITY,
                  gen_k=0, warmupIter=0, chain_offset=0, device=None, waves_per_group=0, adaptH=True,
-                 adaptHtarget=0.8, adaptDelta=True, adaptDeltaTarget=0.6, adaptDeltaQuantile=0.9):
+                 adaptHtarget=0.8, adaptDelta=True, adaptDeltaTarget=0.6, adaptDeltaQuantile=0.9, route=0, split_parts=0,
+                 split_ks=0, adaptQuantBits=0):
+        """route: 0 (the library chooses the kernel) or WN_ROUTE_* names / bits (include/walnuts_amd.h: the other implementation of
+        the same function, for A/B comparisons); adaptQuantBits: 0 = the reference's arithmetic, b = the adapted H / delta rounded
+        to b mantissa bits (opt-in; DESIGN 9, warm-up tolerance contract)."""
         torch = _torch()
         self.torch = torch
         self.lib = L.lib()
@@ -43,6 +47,8 @@ class Engine:
         cfg.adapt_h = int(bool(adaptH)); cfg.adapt_delta = int(bool(adaptDelta))
         cfg.adapt_h_target = float(adaptHtarget); cfg.adapt_delta_target = float(adaptDeltaTarget)
         cfg.adapt_delta_quantile = float(adaptDeltaQuantile)
+        cfg.route = L.route_bits(route); cfg.split_parts = int(split_parts); cfg.split_ks = int(split_ks)
+        cfg.adapt_quant_bits = int(adaptQuantBits)
         self.cfg = cfg
         self.dim, self.n_chains = int(dim), int(n_chains)
         self.dg = {L.G_IDENTITY: self.dim, L.G_Q0_SUMSQ: 2, L.G_FIRSTK: int(gen_k), L.G_SW_CONSTRAIN: 2 * self.dim + 1}[int(generated)]

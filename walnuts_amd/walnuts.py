@@ -71,6 +71,11 @@ def _hostrng_lib():
     if _HOSTRNG is None:
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwalnuts_hostrng.so")
         try:
+            # libnpyrandom's distributions are linked statically: a helper built against another numpy could drift from what the
+            # caller's Generator methods draw, so it is only used with the numpy it was built for (csrc/Makefile records the version)
+            with open(path + ".numpy_version") as f:
+                if f.read().strip() != np.__version__:
+                    raise OSError("libwalnuts_hostrng.so was built for another numpy")
             lib = C.CDLL(path)
             for name in ("wn_hr_momentum", "wn_hr_extend_draws", "wn_hr_accept_uniforms", "wn_hr_choice_uniforms"):
                 getattr(lib, name).restype = None
@@ -81,8 +86,13 @@ def _hostrng_lib():
 
 
 def _bitgen_pointers(rngs):
-    """(void*)[B] of the Generators' bitgen_t, or None when some `rng` is not a numpy Generator with a ctypes interface (stand-ins)."""
+    """(void*)[B] of the Generators' bitgen_t, or None when some `rng` is not a numpy Generator with a ctypes interface (stand-ins)
+    or when one Generator serves several chains (the C path draws all chains' accept uniforms and then all choice uniforms, the
+    per-chain Python path interleaves them per chain: the two orders are the same only for distinct Generators).  The C path reads the
+    bit generators' states directly, without Generator's lock: do not draw from these Generators on another thread during a call."""
     try:
+        if len({id(g) for g in rngs}) != len(rngs):
+            return None
         ptrs = []
         for g in rngs:
             if not isinstance(g, np.random.Generator):
@@ -101,7 +111,7 @@ def _np(a):
 class _Stepper:
     """The wn_wstep handle of B chains and its exchange buffers."""
 
-    def __init__(self, target, fns, B, D, inv_mass, macro_step, max_nuts_depth, max_error):
+    def __init__(self, target, fns, B, D, inv_mass, macro_step, max_nuts_depth, max_error, route=0):
         import torch
         if not torch.cuda.is_available():
             from .engine import WalnutsError
@@ -120,6 +130,8 @@ class _Stepper:
             msg = self.lib.wn_wstep_last_error(None).decode()
             raise NotImplementedError(msg) if rc == L.E_UNSUPPORTED else (MemoryError(msg) if rc == L.E_ALLOC else ValueError(msg))
         self.h = h
+        if route:  # WN_ROUTE_WSTEP_LEGACY: the one-lane kernels (A/B comparisons; include/walnuts_amd.h)
+            self._ck(self.lib.wn_wstep_set_route(self.h, L.route_bits(route)))
         z = lambda *s, dt=torch.float64: torch.zeros(s, dtype=dt, device=self.dev)
         self.sub, self.uturn = z(B, dt=torch.int32), z(B, dt=torch.int32)
         self.lse_ext, self.lse_old = z(B), z(B)
@@ -167,8 +179,7 @@ class _Stepper:
         L_mass = inv_mass ** -0.5
         hr = _hostrng_lib()
         if hr is not None:  # the Generators' C interface: the same draws from the same streams, no per-chain interpreter calls
-            if getattr(self, "_bg_for", None) is not rngs:
-                self._bg, self._bg_for = _bitgen_pointers(rngs), rngs
+            self._bg = _bitgen_pointers(rngs)  # rebuilt every step (B attribute reads): a Generator replaced in the caller's list is seen
             if self._bg is None:
                 hr = None
         bg = self._bg if hr is not None else None
@@ -240,12 +251,12 @@ class _Stepper:
             pass
 
 
-def _stepper(theta, logp, grad, inv_mass, macro_step, max_nuts_depth, max_error):
+def _stepper(theta, logp, grad, inv_mass, macro_step, max_nuts_depth, max_error, route=0):
     target, fns = _resolve(logp, grad)
     B, D = theta.shape
     if target is not None:
         target.check_dim(D)
-    return _Stepper(target, fns, B, D, inv_mass, macro_step, max_nuts_depth, max_error)
+    return _Stepper(target, fns, B, D, inv_mass, macro_step, max_nuts_depth, max_error, route)
 
 
 def walnuts_step_batch(rngs, theta, logp, grad, inv_mass, macro_step, max_nuts_depth, max_error):
@@ -269,7 +280,7 @@ def walnuts_step(rng, theta, logp, grad, inv_mass, macro_step, max_nuts_depth, m
     return walnuts_step_batch([rng], theta[None, :], logp, grad, inv_mass, macro_step, max_nuts_depth, max_error)[0]
 
 
-def walnuts_batch(rngs, theta_init, logp, grad, inv_mass, macro_step, max_nuts_depth, max_error, iter_warmup, iter_sample):
+def walnuts_batch(rngs, theta_init, logp, grad, inv_mass, macro_step, max_nuts_depth, max_error, iter_warmup, iter_sample, *, route=0):
     """C chains at once: theta_init (C, D), one Generator per chain -> draws (C, iter_sample, D).  Chain c consumes
     rngs[c] exactly as walnuts(rngs[c], theta_init[c], ...) would."""
     _quiet()
@@ -279,7 +290,7 @@ def walnuts_batch(rngs, theta_init, logp, grad, inv_mass, macro_step, max_nuts_d
     if len(rngs) != Cn:
         raise ValueError("one Generator per chain")
     draws = np.empty((Cn, iter_sample, D))
-    s = _stepper(theta, logp, grad, inv_mass, macro_step, max_nuts_depth, max_error)
+    s = _stepper(theta, logp, grad, inv_mass, macro_step, max_nuts_depth, max_error, route)
     try:
         for i in range(iter_warmup + iter_sample):
             theta = s.step(rngs, theta, inv_mass)
@@ -291,7 +302,7 @@ def walnuts_batch(rngs, theta_init, logp, grad, inv_mass, macro_step, max_nuts_d
 
 
 def walnuts_device(seed, theta_init, target, inv_mass, macro_step, max_nuts_depth, max_error, iter_warmup, iter_sample,
-                   chain_offset=0, transitions_per_launch=64, iter0=1, return_stats=False):
+                   chain_offset=0, transitions_per_launch=64, iter0=1, return_stats=False, route=0):
     """C chains with the DEVICE's random stream instead of numpy Generators: theta_init (C, D) -> draws (C, iter_sample, D).
     The transition kernel is walnuts_step's (walnuts.py:279-359); the randomness is the engine's Philox stream keyed by
     (seed, chain_offset + chain, transition number) -- wn_rng.h -- so a chain's draws do not depend on how chains are batched
@@ -308,7 +319,7 @@ def walnuts_device(seed, theta_init, target, inv_mass, macro_step, max_nuts_dept
     tgt, fns = _resolve(target, target)
     if tgt is None:
         raise ValueError("walnuts_device needs a device target descriptor; host callables go through walnuts_batch")
-    s = _stepper(theta, target, target, inv_mass, macro_step, max_nuts_depth, max_error)
+    s = _stepper(theta, target, target, inv_mass, macro_step, max_nuts_depth, max_error, route)
     try:
         t = s.t
         th = s.dv(theta)
