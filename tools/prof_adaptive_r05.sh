@@ -1,3 +1,4 @@
+#!/bin/bash
 # rocprofv3 kernel traces of the adaptive runs that moved to the trajectory-first kernel in round 5 (run on the GPU box through gpurun)
 export TMPDIR=/tmp
 mkdir -p gpurun_out/prof_r05_adapt_std gpurun_out/prof_r05_adapt_dense gpurun_out/prof_r05_warm

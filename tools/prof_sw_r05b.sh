@@ -1,3 +1,4 @@
+#!/bin/bash
 mkdir -p gpurun_out
 WN_PROF_SKIP_DEFAULT=1 WN_PROF_SIDE=stockwatson WN_PROF_BENCH="default stockwatson" bash tools/prof_round.sh r05b > gpurun_out/prof_round_r05b.log 2>&1
 for r in fixed R2P; do
