@@ -37,7 +37,7 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // Params::xzero): a sub-batch of half the chains then still has a workgroup for every CU (wn_capi.hip, run_split_dense).  The sum of
 // two numbers does not depend on which arrives first, so the result is as reproducible as the one-workgroup form's.
 #ifndef WN_GEMM_XD
-#define WN_GEMM_XD 2  // row-panel groups over the 8 XCDs (1 = the whole row range per XCD, 8 = the whole chain range per XCD)
+#define WN_GEMM_XD 8  // row-panel groups over the 8 XCDs (1 = the whole row range per XCD: round 1's contiguous ranges; 8 = the whole chain range per XCD).  Measured in the run, D = 1000 x 1024 chains, us per tick: 1: 51.61, 2: 51.29, 4: 51.20, 8: 51.04 (profiles/r06_gemm_xd_ab.txt)
 #endif
 template <int NJ, int KS = 1>
 __global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __restrict__ A, const double* __restrict__ xq,
@@ -49,7 +49,13 @@ __global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __rest
   // consecutive blocks go to different XCDs (blockIdx.x & 7): give each XCD a RECTANGLE of tiles, XD row-panel groups x 8/XD chain-panel
   // groups, so that its L2 (4 MB) holds what its 32 workgroups share.  D = 1000, 1024 chains (16 x 16 tiles): XD = 2 -> 8 row panels of A
   // (4 MB, each used by 4 workgroups) + 4 chain panels of xq (2 MB, each used by 8) per XCD = 6 MB fetched per XCD and launch; the
-  // contiguous range of round 1 (2 chain panels x all 16 row panels) streamed all 8 MB of A through every L2 and used each panel twice: 9 MB.
+  // contiguous range of round 1 (2 chain panels x all 16 row panels = XD 1) streamed all 8 MB of A through every L2 and used each panel
+  // twice: 9 MB; XD = 8: 2 row panels of A (1 MB, each used by 16) + all 16 chain panels (8 MB).  Measured (round 6): the tick moves by 1 %
+  // between the best and the worst dealing -- the k loop is not waiting for L2 misses.  What it IS at: a 64 x 64 tile per CU needs
+  // (64 + 64) x 8 B of operands per k for 16 clocks of its four SIMDs' MFMA time = 64 B/clk, the rate of a CU's vector-memory path
+  // (L1 / TA, MI355X_MICROARCH.md): operand delivery and the matrix pipe are balanced 1 : 1, with nothing to spare for the prologue's first
+  // loads, the epilogue or a second resident workgroup; a larger tile per CU (the only way to fewer bytes per flop) needs k split across
+  // CUs, i.e. atomic adds into xg -- measured in round 4 (KS = 2), slower.
   int ct, dt, ks = 0;
   const int xd = WN_GEMM_XD;
   if (KS == 1 && tiles_d % xd == 0 && tiles_c % (8 / xd) == 0) {
