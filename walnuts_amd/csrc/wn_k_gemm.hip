@@ -37,7 +37,7 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // Params::xzero): a sub-batch of half the chains then still has a workgroup for every CU (wn_capi.hip, run_split_dense).  The sum of
 // two numbers does not depend on which arrives first, so the result is as reproducible as the one-workgroup form's.
 #ifndef WN_GEMM_XD
-#define WN_GEMM_XD 8  // row-panel groups over the 8 XCDs (1 = the whole row range per XCD: round 1's contiguous ranges; 8 = the whole chain range per XCD).  Measured in the run, D = 1000 x 1024 chains, us per tick: 1: 51.61, 2: 51.29, 4: 51.20, 8: 51.04 (profiles/r06_gemm_xd_ab.txt)
+#define WN_GEMM_XD 2  // row-panel groups over the 8 XCDs (1 = the whole row range per XCD: round 1's contiguous ranges; 8 = the whole chain range per XCD).  Measured in the run, D = 1000 x 1024 chains, us per tick: 1: 51.61, 2: 51.29, 4: 51.20, 8: 51.04 (profiles/r06_gemm_xd_ab.txt): equal within the launch-to-launch spread; 2 fetches the fewest bytes (6 MB per XCD and launch against 9 MB for 1 and for 8: corrected FETCH_SIZE 48 MB per launch against 71 MB, profiles/r06_traffic_side.json)
 #endif
 template <int NJ, int KS = 1>
 __global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __restrict__ A, const double* __restrict__ xq,
