@@ -419,8 +419,16 @@ def timed_launches(eng, spec, dev, steps, warmup, barrier):
         last = s
     barrier()
     el = time.perf_counter() - t0
+    # tail: a T wave of the headline kernel owns four chains and lives until the longest of them is done, the launch until the last wave is;
+    # mean over the 4-chain groups of (the group's longest chain) / the longest of all = the fraction of the launch the average wave is alive
+    # for (PMC: SQ_WAVE_CYCLES x 4 / waves against GRBM_GUI_ACTIVE / 8 gave 0.946 in round 5) -- what separates the tick's cost from the
+    # end-of-launch tail in `value`
+    tf = []
+    for p_ in per:
+        g_ = p_[: (p_.numel() // 4) * 4].reshape(-1, 4).max(1).values
+        tf.append(float((g_.mean() / g_.max()).item()) if g_.numel() else 1.0)
     return dict(elapsed=el, units=float(tot.item()), kernel_ms=kms, per_launch_units=[float(p_.sum().item()) for p_ in per],
-                busiest=[float(p_.max().item()) for p_ in per], ticks=ticks, draws=last)
+                busiest=[float(p_.max().item()) for p_ in per], ticks=ticks, draws=last, tail_frac=float(np.mean(tf)) if tf else None)
 
 
 def roofline_of(spec, units_per_launch, avg_ms, kernel_name, steps_info=None):
@@ -529,7 +537,7 @@ def summary_line(out):
     f = lambda v, spec="%.3g": (spec % v) if isinstance(v, (int, float)) else "n/a"
     ex = out.get("extras", {})
     oc = ex.get("other_configs", {})
-    parts = ["cfg2@%d=%s(%s)" % (out["config"].get("chains_per_gpu", 0), f(out["value"], "%.4g"), f(g(out, "roofline", "frac")))]
+    parts = ["cfg2@%d=%s(%s,tail_frac=%s)" % (out["config"].get("chains_per_gpu", 0), f(out["value"], "%.4g"), f(g(out, "roofline", "frac")), f(out.get("tail_frac")))]
     parts.append("cfg2@1024=%s(%s,med3)" % (f(g(ex, "dense_1024_chains", "value")), f(g(ex, "dense_1024_chains", "roofline", "frac"))))
     parts.append("diag=%s" % f(g(ex, "diag_variant", "value")))
     parts.append("cfg2adaptD/R2P=%s/%s" % (f(g(ex, "dense_adaptive", "adaptLeapFrogD", "value")), f(g(ex, "dense_adaptive", "adaptLeapFrogR2P", "value"))))
@@ -685,7 +693,10 @@ def main():
             "config": {"workload": spec["workload"], "chains_per_gpu": spec["C"], "dim": spec["D"], "iters_per_step": spec["iters"],
                        "kernel": eng.kernel_name, "sharding": f"chains x{world}, no data-path collective"},
             ("leapfrog_steps_per_launch_per_gpu" if spec["bound"] == "mfma" else "gradient_evaluations_per_launch_per_gpu"): upl,
-            "kernel_ms_avg": avg_ms, "kernel_ms": m["kernel_ms"], "gather_ms": gather_ms, "gather_bytes_per_rank": gather_bytes,
+            "kernel_ms_avg": avg_ms, "kernel_ms": m["kernel_ms"],
+            # mean life of a 4-chain wave / the launch (from the per-chain step counts): value / tail_frac = the rate of a launch without its tail
+            "tail_frac": m["tail_frac"], "value_without_tail": None if not m["tail_frac"] else units_all / elapsed / m["tail_frac"],
+            "gather_ms": gather_ms, "gather_bytes_per_rank": gather_bytes,
             "collectives": (os.environ.get("WN_DIST_BACKEND", "nccl") + (" (forced with one rank)" if world == 1 else "")) if coll else None,
             **scal, "roofline": roof,
         }
