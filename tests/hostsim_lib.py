@@ -33,7 +33,7 @@ class Params(C.Structure):
         ("kxi", ip), ("kq1", dp), ("kv1", dp), ("kg1", dp), ("kdout", dp), ("kiout", ip),
         ("warmupIter", C.c_int), ("adaptH", C.c_int), ("adaptDelta", C.c_int),
         ("adaptHtarget", C.c_double), ("adaptDeltaTarget", C.c_double), ("adaptDeltaQuantile", C.c_double),
-        ("facs", dp), ("adaptQuantBits", C.c_int), ("omin", dp), ("omax", dp), ("xq", dp), ("xg", dp), ("xlp", dp), ("sp_done", C.c_void_p), ("cl_g", C.c_int), ("cl_red", dp), ("cl_cnt", C.c_void_p), ("cl_abort", C.c_void_p), ("cl_debug_drop", C.c_int), ("stamps", C.c_void_p),
+        ("facs", dp), ("adaptQuantBits", C.c_int), ("omin", dp), ("omax", dp), ("xq", dp), ("xg", dp), ("xlp", dp), ("sp_done", C.c_void_p), ("cl_g", C.c_int), ("cl_red", dp), ("cl_cnt", C.c_void_p), ("cl_abort", C.c_void_p), ("cl_debug_drop", C.c_int), ("dynq", C.c_void_p), ("stamps", C.c_void_p),
     ]
 
 

@@ -307,6 +307,36 @@ def test_dense_adaptive_runs_one_chain_per_wave_matrix_in_lds(wa, D, integ, C):
     assert (d_new[:, :, 6] + d_new[:, :, 7]).sum() > 0
 
 
+@pytest.mark.parametrize("D,integ,warm", [(40, ol.I_ADAPT_R2P, 0), (100, ol.I_ADAPT_D, 0), (24, ol.I_ADAPT_D, 3)])
+def test_dense_adaptive_chain_queue_of_the_persistent_launch(wa, D, integ, warm):
+    """Round 6: the dense Gaussian's trajectory-first launch is a persistent grid (one workgroup per CU, its matrix staged once) with a chain
+    queue -- a wave whose chain has finished takes the next chain of the launch.  More chains than the chip holds at once (8 per CU): the chains
+    beyond the first grid's are dealt through the queue, in whatever order waves come free; every chain's draws and diagnostics are the
+    one-stream engine's (one chain per wave, no queue) bit for bit, whichever wave ran it, twice in a row (the queue head is reset per launch),
+    and the oracle's for the last chain."""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    C = 8 * cus + 8 * 37 + 3  # (ragged: the last workgroup's worth of chains is incomplete)
+    A, q0 = dense_case(D, C)
+    iters = 3
+    kw = dict(integrator=integ, H0=0.8, delta0=0.2, M=4, warmupIter=warm)
+    s_new, d_new, name = run_engine(wa, ol.T_DENSEGAUSS, q0, iters, tpar=A, **kw)
+    assert "wn_orbit_kernel<dense,NE=2,K=8" in name, name
+    s_again, d_again, _ = run_engine(wa, ol.T_DENSEGAUSS, q0, iters, tpar=A, **kw)
+    assert same(s_new, s_again) and same(d_new, d_again)
+    s_eng, d_eng, name_eng = run_engine(wa, ol.T_DENSEGAUSS, q0, iters, tpar=A, legacy=True, **kw)
+    assert "wn_wavelds_kernel" in name_eng, name_eng
+    ne = lambda a, b: ~((a == b) | (np.isnan(a) & np.isnan(b)))
+    dcols = [k for k in range(24) if k != 17]  # (column 17: same_run's note -- held to 1e-12 below)
+    bad = np.flatnonzero(ne(d_new[..., dcols], d_eng[..., dcols]).any(axis=(1, 2)) | ne(s_new, s_eng).any(axis=(1, 2)))
+    assert bad.size == 0, (bad[:10], C)
+    assert same_run(s_new, d_new, s_eng, d_eng)
+    c = C - 1
+    o = ol.walnuts(ol.T_DENSEGAUSS, q0[c], integrator=integ, tpar=A.ravel(), H0=0.8, delta0=0.2, numIter=iters, M=4, seed=SEED, chain=c, warmupIter=warm)
+    np.testing.assert_array_equal(d_new[c][:, INT_COLS], o["diagnostics"][:, INT_COLS])
+    np.testing.assert_allclose(s_new[c].T, o["samples"], rtol=1e-6, atol=1e-9)
+
+
 def test_dense_adaptive_warmup_and_yoshida_on_the_lds_engine(wa):
     """What the trajectory-first kernel does not take (adaptYoshidaD; traced runs, orbit statistics) runs on wn_wavelds_kernel, the one-stream
     engine with the matrix in LDS -- and so does everything with route WN_ROUTE_ORBIT_LEGACY, e.g. warm-up adaptation: against the cooperative layout

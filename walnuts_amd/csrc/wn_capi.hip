@@ -855,6 +855,9 @@ static int launch(wn_engine* e, const Params& p, hipStream_t st, bool timed) {
     pc.cl_debug_drop = e->debug_cluster_drop;  // test hook: wn_debug_cluster_drop (tests/test_gpu_sweep.py)
     HIPCHK(e, hipMemsetAsync(e->cl_cnt, 0, ((size_t)e->cfg.n_chains + 16) * sizeof(unsigned), st));
   }
+  // chain queue of the persistent launches (wn_k_orbit.hip, staged targets): kabort[8], zeroed in stream order in front of every launch
+  pc.dynq = e->kabort + 8;
+  HIPCHK(e, hipMemsetAsync(e->kabort + 8, 0, sizeof(int), st));
   const Params& p_ = pc;
   const bool coop_legacy = (e->cfg.route & WN_ROUTE_COOP_LEGACY) != 0;  // A-B tests: one-stream kernel
   const bool fast_legacy = (e->cfg.route & WN_ROUTE_FAST_LEGACY) != 0;  // A-B tests: the seven-T-wave kernel for dense targets too

@@ -80,6 +80,7 @@ struct Params {
   unsigned* cl_cnt;
   int* cl_abort;
   int cl_debug_drop;  // test hook (WN_DEBUG_CLUSTER_DROP): slice G-1 skips its arrival at this exchange (0 = never)
+  int* dynq;  // chain queue head of a persistent launch (wn_k_orbit.hip, staged targets): zeroed before the launch; null = one chain per wave
   unsigned long long* stamps;  // diagnostic builds (-DWN_STAMPS): [block][wave][8] cycles per phase
 };
 

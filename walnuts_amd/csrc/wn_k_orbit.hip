@@ -77,8 +77,12 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
   const int lane = threadIdx.x & 63;
   const int k16 = lane & 15;
   const int row = lane >> 4;
-  const int cl = blockIdx.x * K + (int)(threadIdx.x >> 6);
-  const uint32_t cg = prm.chain0 + (uint32_t)cl;
+  // A staged target (the dense Gaussian: the matrix in LDS, ONE workgroup per CU) runs as a persistent grid with a chain queue: a wave whose
+  // chain has finished takes the next chain of the launch (one atomic add on `prm.dynq`) instead of idling until the slowest of its
+  // workgroup's K chains is done and the next workgroup can start -- the matrix is staged once per workgroup and launch.  A chain's result
+  // does not depend on which wave runs it (random stream, workspace, output rows: all keyed by the chain).  Other targets: one chain per wave.
+  constexpr bool QUEUE = tgt_staged<Tgt>::value && K > 1;
+  int cl_ = blockIdx.x * K + (int)(threadIdx.x >> 6);
   const uint32_t seedlo = (uint32_t)prm.seed, seedhi = (uint32_t)(prm.seed >> 32);
   const int D = prm.D, M = prm.M, minC = prm.minC, maxC = prm.maxC;
   Tgt tgt;
@@ -86,12 +90,15 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
     __shared__ double wn_orbit_stage[Tgt::STAGE_DOUBLES];
     Tgt::stage(prm, wn_orbit_stage, (int)threadIdx.x, 64 * K);
     __syncthreads();
-    if (cl >= prm.C) return;  // (no barrier behind this point in wide mode)
+    if (cl_ >= prm.C) return;  // (no barrier behind this point in wide mode)
     tgt.init(prm, lane, wn_orbit_stage);
   } else {
-    if (K > 1 && cl >= prm.C) return;
+    if (K > 1 && cl_ >= prm.C) return;
     tgt.init(prm, lane, nullptr);
   }
+  for (;;) {  // (QUEUE: one trip per chain this wave runs; otherwise one trip)
+  const int cl = cl_;
+  const uint32_t cg = prm.chain0 + (uint32_t)cl;
   if constexpr (!WIDE) {
     for (int k = lane; k < lds_doubles(M); k += 64) L[k] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -829,6 +836,13 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
     for (int k = 0; k < 16; ++k) o[k] = st_[k];
   }
 #endif
+  if constexpr (QUEUE) {
+    int nxt = 0;
+    if (lane == 0) nxt = atomicAdd(prm.dynq, 1);
+    cl_ = (int)gridDim.x * K + __builtin_amdgcn_readfirstlane(nxt);
+    if (cl_ >= prm.C) break;
+  } else break;
+  }  // for (;;): the wave's chains
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
@@ -933,6 +947,19 @@ static hipError_t go_orbit_wide(const Params& prm, hipStream_t st) {
 template <class Tgt, int NE, int K, bool FIXED_TOO = false>
 static hipError_t go_orbit_wide_k(const Params& prm, hipStream_t st) {
   dim3 grid((prm.C + K - 1) / K), block(64 * K);
+  if constexpr (tgt_staged<Tgt>::value) {
+    // persistent grid + chain queue (see the kernel): as many workgroups as are resident at once (the staged matrix takes most of a CU's LDS:
+    // one per CU); the first gridDim.x * K chains are dealt statically, the rest through prm.dynq (zeroed by the caller in stream order)
+    static int resident = 0;
+    if (!resident) {
+      int dev = 0, cus = 0, per = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)wn_orbit_kernel<Tgt, I_ADAPT_D, false, NE, K>, 64 * K, 0) == hipSuccess && cus > 0 && per > 0)
+        resident = cus * per;
+      else resident = 256;
+    }
+    if (prm.dynq && (int)grid.x > resident) grid.x = (unsigned)resident;
+  }
   if (prm.warmupIter > 0) {
     if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_R2P, false, NE, K, true>), grid, block, 0, st, prm);
     else if (prm.integrator == I_ADAPT_D) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_D, false, NE, K, true>), grid, block, 0, st, prm);
