@@ -311,7 +311,8 @@ def test_dense_adaptive_runs_one_chain_per_wave_matrix_in_lds(wa, D, integ, C):
 def test_dense_adaptive_chain_queue_of_the_persistent_launch(wa, D, integ, warm):
     """Round 6: the dense Gaussian's trajectory-first launch is a persistent grid (one workgroup per CU, its matrix staged once) with a chain
     queue -- a wave whose chain has finished takes the next chain of the launch.  More chains than the chip holds at once (8 per CU): the chains
-    beyond the first grid's are dealt through the queue, in whatever order waves come free; every chain's draws and diagnostics are the
+    beyond the first grid's are dealt through the queue, in whatever order waves come free (runs with warm-up keep one chain per wave: their
+    instantiations have no register to spare for the loop); every chain's draws and diagnostics are the
     one-stream engine's (one chain per wave, no queue) bit for bit, whichever wave ran it, twice in a row (the queue head is reset per launch),
     and the oracle's for the last chain."""
     import torch

@@ -92,6 +92,20 @@ def test_orbit_kernel_has_no_flat_or_scratch_instructions(tmp_path):
     for name, m in meta.items():
         if "wn_orbit_kernel" in name and one_reg(name):
             assert m["scratch"] == 0 and m["vgpr_spill"] == 0, (name, m)
+    # the tolerated instantiations have explicit ceilings (an exemption hides a future spill inside a micro-step loop):
+    # dense-LDS WARM forms (the default route of adaptive runs with warm-up on dense Gaussians up to 128-D; 256-register cap at two waves per
+    # SIMD) <= 4 spilled registers / 32 B; the wide diagonal forms <= 4 / 0 B; StockWatson's adaptive one-wave forms (not routed by default)
+    # <= 56 / 224 B; every plain dense-LDS form (the chain-queue launch of round 6) none at all
+    for name, m in meta.items():
+        if "wn_orbit_kernel" not in name or one_reg(name):
+            continue
+        if "WTgtDenseLDS" in name:
+            cap = (4, 32) if name.endswith("ELb1EEEvNS_6ParamsE") else (0, 0)
+        elif "WTgtStockWatson" in name:
+            cap = (4, 0) if "EELi0ELb0ELi12E" in name else (56, 224)
+        else:
+            cap = (4, 0)
+        assert m["vgpr_spill"] <= cap[0] and m["scratch"] <= cap[1], (name, m, cap)
 
 
 @pytest.mark.timeout(900)
@@ -108,6 +122,11 @@ def test_two_wave_orbit_kernel_hand_off_is_lds_and_scratch_free(tmp_path):
     fixed = [k for k in hot if k.endswith("ELi12ELi0EEEvNS_6ParamsEPi")]
     assert len(fixed) == 1, hot
     assert not re.search(r"\bscratch_", ks[fixed[0]])
+    # the adaptive instantiations (config 5's adaptLeapFrogD / R2P runs: four waves of 512 registers) spill: bounded, and not inside the
+    # innermost loops' bodies beyond what round 6 found there (profiles/r06_stockwatson_summary.txt: 43-54 registers, 160-208 B)
+    for name, m in meta.items():
+        if "wn_orbit2_kernel" in name and not name.endswith("ELi12ELi0EEEvNS_6ParamsEPi"):
+            assert m["vgpr_spill"] <= 60 and m["scratch"] <= 224, (name, m)
     for name, m in meta.items():
         if name.endswith("ELi12ELi0EEEvNS_6ParamsEPi"):
             assert m["scratch"] == 0, (name, m)

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
   // chain has finished takes the next chain of the launch (one atomic add on `prm.dynq`) instead of idling until the slowest of its
   // workgroup's K chains is done and the next workgroup can start -- the matrix is staged once per workgroup and launch.  A chain's result
   // does not depend on which wave runs it (random stream, workspace, output rows: all keyed by the chain).  Other targets: one chain per wave.
-  constexpr bool QUEUE = tgt_staged<Tgt>::value && K > 1;
+  constexpr bool QUEUE = tgt_staged<Tgt>::value && K > 1 && !WARM;  // (the WARM instantiations sit at the 256-register cap of two waves per SIMD: the loop's extra live state spilled 13 more registers there)
   int cl_ = blockIdx.x * K + (int)(threadIdx.x >> 6);
   const uint32_t seedlo = (uint32_t)prm.seed, seedhi = (uint32_t)(prm.seed >> 32);
   const int D = prm.D, M = prm.M, minC = prm.minC, maxC = prm.maxC;
@@ -958,7 +958,7 @@ static hipError_t go_orbit_wide_k(const Params& prm, hipStream_t st) {
         resident = cus * per;
       else resident = 256;
     }
-    if (prm.dynq && (int)grid.x > resident) grid.x = (unsigned)resident;
+    if (prm.dynq && prm.warmupIter == 0 && (int)grid.x > resident) grid.x = (unsigned)resident;  // (warm-up runs: one chain per wave, no queue)
   }
   if (prm.warmupIter > 0) {
     if (prm.integrator == I_ADAPT_R2P) hipLaunchKernelGGL((wn_orbit_kernel<Tgt, I_ADAPT_R2P, false, NE, K, true>), grid, block, 0, st, prm);

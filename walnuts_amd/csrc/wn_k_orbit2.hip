@@ -56,6 +56,20 @@ typedef __attribute__((address_space(3))) volatile unsigned long long lds_u64;
 #else
 #define WN_O2STAMP(k) do {} while (0)
 #endif
+// Every inter-wave wait is bounded by WALL-CLOCK time, not by an iteration count (2^24 spins were 1-2 s at today's clocks, and
+// a slow but healthy peer -- clock throttling, a debugger, a maxC = 12 macro step of tens of milliseconds -- would have become a hard abort):
+// s_memrealtime counts at a constant 100 MHz; the clock is read once per 1024 spins.
+#ifndef WN_O2_DEADLINE_TICKS
+#define WN_O2_DEADLINE_TICKS 3000000000ull  // 30 s
+#endif
+// (the clock is first read after 1024 spins: a wait that ends at once -- the common case -- never touches it)
+__device__ __forceinline__ bool wn_o2_expired(unsigned& spins, unsigned long long& t0, unsigned mult) {
+  if ((++spins & 0x3FFu) != 0u) return false;
+  const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+  if (t0 == 0ull) { t0 = now | 1ull; return false; }
+  return now - t0 > (unsigned long long)mult * WN_O2_DEADLINE_TICKS;
+}
+#define WN_O2_EXPIRED(spins, t0, mult) wn_o2_expired(spins, t0, mult)
 #ifndef WN_O2_SPINS
 #define WN_O2_SPINS (1u << 24)
 #endif
@@ -214,14 +228,14 @@ __global__ __launch_bounds__(INTEG == I_FIXED ? 128 : 256) void wn_orbit2_kernel
     uint32_t last = 0;
     for (;;) {
       unsigned long long w = 0;
-      unsigned spins = 0;
+      unsigned spins = 0; unsigned long long spin_t0 = 0ull;
       bool out = false;
       for (;;) {
         w = LU[L_JOB];
         const uint32_t js = (uint32_t)(w >> 32);
         if (js == 0xFFFFFFFFu || dead()) { out = true; break; }
         if (js != last) break;
-        if (++spins > 8u * WN_O2_SPINS) { out = true; break; }  // (no job for seconds: the T wave is gone)
+        if (WN_O2_EXPIRED(spins, spin_t0, 8)) { out = true; break; }  // (no job for seconds: the T wave is gone)
         __builtin_amdgcn_s_sleep(1);
       }
       if (out) break;
@@ -264,12 +278,12 @@ __global__ __launch_bounds__(INTEG == I_FIXED ? 128 : 256) void wn_orbit2_kernel
       // ---- wait for command `seq` ----
       unsigned long long w0 = 0;
       {
-        unsigned spins = 0;
+        unsigned spins = 0; unsigned long long spin_t0 = 0ull;
         for (;;) {
           w0 = LU[L_CMD];
           if ((uint32_t)(w0 >> 32) == seq) break;
           if (dead()) break;
-          if (++spins > WN_O2_SPINS) { give_up(); break; }
+          if (WN_O2_EXPIRED(spins, spin_t0, 1)) { give_up(); break; }
           __builtin_amdgcn_s_sleep(2);
         }
       }
@@ -337,10 +351,10 @@ __global__ __launch_bounds__(INTEG == I_FIXED ? 128 : 256) void wn_orbit2_kernel
         if (k0 == 0 && n >= 32) {  // the ring entries of block (n >> 4) - 2 are about to be overwritten: the R wave must be through with it
           release();
           LU[L_PROD] = ((unsigned long long)seq << 32) | (unsigned)n;
-          unsigned spins = 0;
+          unsigned spins = 0; unsigned long long spin_t0 = 0ull;
           while ((int)(uint32_t)LU[L_CONS] < n - 16) {
             if ((uint32_t)LU[L_ABORT] == seq || dead()) { stop = true; break; }
-            if (++spins > WN_O2_SPINS) { give_up(); stop = true; break; }
+            if (WN_O2_EXPIRED(spins, spin_t0, 1)) { give_up(); stop = true; break; }
             __builtin_amdgcn_s_sleep(2);
           }
           if (stop) break;
@@ -374,13 +388,13 @@ __global__ __launch_bounds__(INTEG == I_FIXED ? 128 : 256) void wn_orbit2_kernel
             return jseq;
           };
           auto wait_helper = [&](int hj, uint32_t js) -> uint32_t {  // the helper's verdict on job js: 1 accepted, 2 done, 4 abandoned, 8 not asked
-            unsigned spins = 0;
+            unsigned spins = 0; unsigned long long spin_t0 = 0ull;
             unsigned long long w;
             for (;;) {
               w = LU[L_HDONE + hj];
               if ((uint32_t)(w >> 32) == js) break;
               if (dead()) { aborted = true; return 4u; }
-              if (++spins > WN_O2_SPINS) { give_up(); aborted = true; return 4u; }
+              if (WN_O2_EXPIRED(spins, spin_t0, 1)) { give_up(); aborted = true; return 4u; }
               __builtin_amdgcn_s_sleep(1);
             }
             acquire();
@@ -428,10 +442,10 @@ __global__ __launch_bounds__(INTEG == I_FIXED ? 128 : 256) void wn_orbit2_kernel
 #pragma unroll 1
           for (int k = k0; k < k1; ++k) {
             if ((uint32_t)LU[L_SURE] != seq) {  // the R wave's verdict on the leaves in front of this one
-              unsigned spins = 0;
+              unsigned spins = 0; unsigned long long spin_t0 = 0ull;
               while ((int)(uint32_t)LU[L_CONS] < nb0 + k && (uint32_t)LU[L_SURE] != seq) {
                 if ((uint32_t)LU[L_ABORT] == seq || dead()) { aborted = true; break; }
-                if (++spins > WN_O2_SPINS) { give_up(); aborted = true; break; }
+                if (WN_O2_EXPIRED(spins, spin_t0, 1)) { give_up(); aborted = true; break; }
                 __builtin_amdgcn_s_sleep(1);
               }
               if (aborted || (uint32_t)LU[L_ABORT] == seq) { stop = true; break; }
@@ -619,10 +633,10 @@ __global__ __launch_bounds__(INTEG == I_FIXED ? 128 : 256) void wn_orbit2_kernel
     minIf = minc = 1 << 30; maxIf = maxc = -(1 << 30); nneq = nzero = nused = 0;
     minlw = INFINITY; maxlw = -INFINITY;
     {  // the T wave's momentum: Hs[I0] = -f0 + 0.5*sum(v**2)  (:256); multinomialLscale (:259)
-      unsigned spins = 0;
+      unsigned spins = 0; unsigned long long spin_t0 = 0ull;
       while ((uint32_t)LU[L_ACK] != seq) {
         if (dead()) { gone = true; break; }
-        if (++spins > WN_O2_SPINS) { give_up(); gone = true; break; }
+        if (WN_O2_EXPIRED(spins, spin_t0, 1)) { give_up(); gone = true; break; }
         __builtin_amdgcn_s_sleep(2);
       }
       if (gone) break;
@@ -659,7 +673,7 @@ __global__ __launch_bounds__(INTEG == I_FIXED ? 128 : 256) void wn_orbit2_kernel
         int k1;
         WN_O2STAMP(4);
         {  // what the T wave has published of this run
-          unsigned spins = 0;
+          unsigned spins = 0; unsigned long long spin_t0 = 0ull;
           int npub = 0;
           const int blk_end = nleaf - nb0 < 16 ? nleaf : nb0 + 16;
           constexpr int BATCH = ADAPT ? 1 : WN_O2_BATCH;  // (a macro step of the adaptive integrators is ~100 k cycles: retire it at once)
@@ -670,7 +684,7 @@ __global__ __launch_bounds__(INTEG == I_FIXED ? 128 : 256) void wn_orbit2_kernel
             npub = mine ? (int)((uint32_t)w & 0x7FFFFFFFu) : 0;
             if (npub >= want || (mine && ((uint32_t)w & 0x80000000u) && npub > n)) break;
             if (dead()) { gone = true; break; }
-            if (++spins > WN_O2_SPINS) { give_up(); gone = true; break; }
+            if (WN_O2_EXPIRED(spins, spin_t0, 1)) { give_up(); gone = true; break; }
             __builtin_amdgcn_s_sleep(1);
           }
           if (gone) break;
@@ -994,9 +1008,13 @@ size_t orbit2_work_doubles(int NE, int C, int M) { return (size_t)C * orbit2::wi
 // WN_ORBIT_ONEWAVE=1 keeps the one-wave forms (fixedLeapFrog: wn_k_orbit.hip's wide mode; the adaptive integrators: the one-stream
 // engine, or that wide mode with WN_ORBIT_WIDE_ADAPT=1), WN_ORBIT_LEGACY=1 the one-stream engine, WN_ORBIT2_NOADAPT=1 this kernel for
 // fixedLeapFrog only.
-static int device_cus() {
+static int device_cus() {  // (asked on every wn_set_target / launch: looked up once per device)
+  static int cached[16] = {0};
   int dev = 0, n = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (dev >= 0 && dev < 16 && cached[dev]) return cached[dev];
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  if (dev >= 0 && dev < 16) cached[dev] = n;
   return n;
 }
 bool orbit2_run(const KernelChoice& kc, int integrator, int n_chains) {
