@@ -13,6 +13,7 @@ from bench import make_dense_problem
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+QBITS = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # adapt_quant_bits of the warm-up runs, engine and oracle alike (round 6: 16 cuts the feedback loop through H / delta; 0 = the reference's arithmetic)
 INT = [0, 1, 4, 5, 6, 7, 8, 9, 12, 13, 19, 20, 21, 22]
 bad = 0; badl = 0; done = 0; nor = 0; nwarm = 0; kernels = {}; t0 = time.time()
 
@@ -50,7 +51,7 @@ for it in range(n):
     else:
         tpar = None
         q0 = rng.normal(size=(C, D))
-    kw = dict(integrator=ig, H0=H0, delta0=delta, M=M, minC=minC, maxC=maxC, generated=gen, gen_k=gk, warmupIter=warm)
+    kw = dict(integrator=ig, H0=H0, delta0=delta, M=M, minC=minC, maxC=maxC, generated=gen, gen_k=gk, warmupIter=warm, adaptQuantBits=QBITS if warm else 0)
     off = 1000 * it
     s, d, name = run({}, D, C, kind, tpar, q0, kw, iters, off)
     sl, dl, namel = run({"WN_DIAG_COOP": "1", "WN_DENSE_COOP": "1"}, D, C, kind, tpar, q0, kw, iters, off)
@@ -68,7 +69,7 @@ for it in range(n):
               f"ints equal {np.array_equal(d[:, :, INT], dl[:, :, INT])}", flush=True)
     for k in sorted(set([0, C - 1])):
         o = ol.walnuts(kind, q0[k], integrator=ig, tpar=None if tpar is None else np.asarray(tpar).ravel(), H0=H0, delta0=delta, numIter=iters, warmupIter=warm, M=M,
-                       minC=minC, maxC=maxC, seed=4711, chain=off + k, generated=gen, gen_k=gk)
+                       minC=minC, maxC=maxC, seed=4711, chain=off + k, generated=gen, gen_k=gk, adaptQuantBits=QBITS if warm else 0)
         nor += 1
         with np.errstate(all="ignore"):
             ok = np.array_equal(d[k][:, INT], o["diagnostics"][:, INT]) and close(s[k].T, o["samples"]) and close(d[k], o["diagnostics"])
@@ -79,5 +80,5 @@ for it in range(n):
             bad += 1
             print(f"ORACLE MISMATCH cfg {it} chain {k}: {name}: target {kind} D {D} integ {ig} M {M} H0 {H0:.4g} delta {delta} iters {iters} warm {warm}"
                   f" (previous kernel against the oracle: {'ok' if okl else 'MISMATCH too'})", flush=True)
-print(f"fuzz_gauss_orbit: {done} configurations ({nwarm} with warm-up iterations) against the previous kernels, {nor} chains against the oracle, {bad} mismatches "
+print(f"fuzz_gauss_orbit (adapt_quant_bits {QBITS}): {done} configurations ({nwarm} with warm-up iterations) against the previous kernels, {nor} chains against the oracle, {bad} mismatches "
       f"(the previous kernels against the oracle: {badl} chains), {time.time() - t0:.0f} s; kernels: {kernels}")

@@ -9,6 +9,7 @@ import walnuts_amd as wa
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+QBITS = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # adapt_quant_bits of the warm-up runs, engine and oracle alike (0 = the reference's arithmetic)
 sw = np.load(os.path.join(ROOT, "tests", "golden", "stockwatson_data.npz"))
 SWT = int(sw["T"][0]); SWP = np.concatenate([[float(SWT)], sw["y"]])
 bad = 0
@@ -46,7 +47,7 @@ for it in range(n):
     delta = float(rng.choice([0.3, 0.05, 0.01]))
     gen, gk = (ol.G_IDENTITY, 0) if rng.random() < 0.5 else ((ol.G_Q0_SUMSQ, 0) if rng.random() < 0.5 else (ol.G_FIRSTK, min(2, D)))
     try:
-        e = wa.Engine(D, C, integrator=ig, H0=H0, delta0=delta, M=M, generated=gen, gen_k=gk, chain_offset=100 * it, warmupIter=warm)
+        e = wa.Engine(D, C, integrator=ig, H0=H0, delta0=delta, M=M, generated=gen, gen_k=gk, chain_offset=100 * it, warmupIter=warm, adaptQuantBits=QBITS if warm else 0)
         e.set_target(tk, tpar)
         s, d = e.run(q0, 777, numIter)
         s = s.transpose(1, 2).cpu().numpy(); d = d.cpu().numpy(); name = e.kernel_name; e.close()
@@ -54,7 +55,7 @@ for it in range(n):
         print(it, "unsupported:", tk, D, ig, ex); continue
     for k in sorted({0, C - 1}):
         o = ol.walnuts(tk, q0[k], integrator=ig, tpar=tpar, H0=H0, delta0=delta, numIter=numIter, M=M, seed=777,
-                       chain=100 * it + k, generated=gen, gen_k=gk, warmupIter=warm)
+                       chain=100 * it + k, generated=gen, gen_k=gk, warmupIter=warm, adaptQuantBits=QBITS if warm else 0)
         ok = np.array_equal(d[k][:, [6, 7, 19, 20]], o["diagnostics"][:, [6, 7, 19, 20]])
         with np.errstate(all="ignore"):
             a, b = s[k], o["samples"]
@@ -62,7 +63,7 @@ for it in range(n):
             # happens to be near zero has no relative accuracy of its own); warm-up adaptation of H amplifies rounding
             # through the energy differences it is computed from, so those runs get 1e-4
             scale = np.nanmax(np.abs(b), axis=0, keepdims=True) if b.size else 1.0
-            tol = 1e-4 if warm else 1e-6
+            tol = (1e-4 if warm else 1e-6) if not QBITS else 1e-6  # (with the loop cut: 1e-6 with or without warm-up)
             close = ((np.isnan(a) & np.isnan(b)) | (np.abs(a - b) <= 1e-9 + tol * np.maximum(np.abs(b), scale))).all()
         if not (ok and close):
             bad += 1
