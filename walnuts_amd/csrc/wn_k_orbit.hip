@@ -837,6 +837,7 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
   }
 #endif
   if constexpr (QUEUE) {
+    if (!prm.dynq) break;  // (no queue head: the launch dealt one chain per wave)
     int nxt = 0;
     if (lane == 0) nxt = atomicAdd(prm.dynq, 1);
     cl_ = (int)gridDim.x * K + __builtin_amdgcn_readfirstlane(nxt);
