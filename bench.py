@@ -513,18 +513,26 @@ def emulate_ranks(name, R, dev, steps, warmup, args=None, sw_run="D"):
         e.close()
         shards.append({"rank": r, "chain_offset": r * sp["C"], "kernel_ms": float(np.sum(m["kernel_ms"])), "units": m["units"],
                        "busiest_chain_units": float(np.max(m["busiest"]))})
-    t = np.array([s_["kernel_ms"] for s_ in shards]); u = np.array([s_["units"] for s_ in shards])
-    n1 = u[0] / t[0]
     return {"ranks": R, "launches_per_shard": steps, "iters_per_launch": sp["iters"], "chains_per_shard": sp["C"],
-            "per_shard_kernel_ms": [float(x) for x in t], "per_shard_units": [float(x) for x in u],
+            **scaling_prediction([s_["kernel_ms"] for s_ in shards], [s_["units"] for s_ in shards]),
+            "busiest_chain_units": [s_["busiest_chain_units"] for s_ in shards], "workload": sp["workload"],
+            "what": "R shards of an R-rank job run sequentially on one GPU; eff = sum(units) / (R * max shard time) / (shard 0 rate)"}
+
+
+def scaling_prediction(shard_ms, shard_units):
+    """What an R-rank weak-scaling job would report, from its R shards' times and units measured one after another on one device (pure
+    arithmetic: tests/test_host_logic.py): the job's time is the slowest shard's, its value the units of all shards / that time, and its
+    efficiency that value / (R x the N = 1 value), the N = 1 job being shard 0 alone."""
+    t = np.asarray(shard_ms, dtype=np.float64); u = np.asarray(shard_units, dtype=np.float64)
+    R = len(t)
+    n1 = u[0] / t[0]
+    return {"per_shard_kernel_ms": [float(x) for x in t], "per_shard_units": [float(x) for x in u],
             "per_shard_rate": [float(x) for x in u / t * 1e3],
             "n1_value": float(n1 * 1e3), "predicted_value": float(u.sum() / t.max() * 1e3),
             "predicted_weak_scaling_eff": float(u.sum() / (R * t.max()) / n1),
             # the same against the MEAN shard's rate instead of shard 0's (takes out whether shard 0 happens to be a quick or a slow one)
             "predicted_weak_scaling_eff_vs_mean_shard": float(u.sum() / (R * t.max()) / np.mean(u / t)),
-            "time_max_over_mean": float(t.max() / t.mean()), "units_max_over_mean": float(u.max() / u.mean()),
-            "busiest_chain_units": [s_["busiest_chain_units"] for s_ in shards], "workload": sp["workload"],
-            "what": "R shards of an R-rank job run sequentially on one GPU; eff = sum(units) / (R * max shard time) / (shard 0 rate)"}
+            "time_max_over_mean": float(t.max() / t.mean()), "units_max_over_mean": float(u.max() / u.mean())}
 
 
 EMULATED = (("cfg2", "gauss100", "D"), ("cfg3", "funnel", "D"), ("cfg4", "dense1000", "D"), ("cfg5D", "stockwatson", "D"))

@@ -116,6 +116,20 @@ def test_bench_self_launcher_starts_ranks_and_relays_rank0():
     assert o["n1_value_same_invocation"] == 2.0 and o["weak_scaling_eff"] == 0.75
 
 
+def test_scaling_prediction_arithmetic():
+    """bench.py --emulate-ranks: the prediction is the contract's own arithmetic (value = units of all ranks / max time over ranks;
+    efficiency = value / (R x the N = 1 value)) applied to the R shards' separately measured times."""
+    from bench import scaling_prediction
+    p = scaling_prediction([100.0] * 8, [5e7] * 8)  # balanced shards: efficiency 1
+    assert p["predicted_weak_scaling_eff"] == 1.0 and p["predicted_value"] == 8 * 5e8 and p["n1_value"] == 5e8
+    p = scaling_prediction([100.0, 100.0, 100.0, 200.0], [5e7] * 4)  # one shard twice as slow: the job takes its time
+    assert p["predicted_value"] == 4 * 5e7 / 0.2 and p["predicted_weak_scaling_eff"] == 0.5
+    assert abs(p["predicted_weak_scaling_eff_vs_mean_shard"] - (1e9 / 4) / np.mean([5e8, 5e8, 5e8, 2.5e8])) < 1e-12
+    assert p["time_max_over_mean"] == 200.0 / 125.0
+    p = scaling_prediction([200.0, 100.0], [5e7, 5e7])  # shard 0 (the N = 1 job) is the slow one: the others do not make the job faster than it
+    assert p["predicted_weak_scaling_eff"] == 1.0
+
+
 def test_bench_self_launcher_eight_ranks():
     """The node's full rank count (8 GPUs): eight fresh children rendezvous over gloo, reduce, and the final gather
     lands every rank's shard at its global chain offset (`chain_offset = rank * C`) on rank 0."""
