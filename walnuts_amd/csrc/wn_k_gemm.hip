@@ -51,10 +51,11 @@ __global__ __launch_bounds__(256) void wn_dense_grad_kernel(const double* __rest
   // (4 MB, each used by 4 workgroups) + 4 chain panels of xq (2 MB, each used by 8) per XCD = 6 MB fetched per XCD and launch; the
   // contiguous range of round 1 (2 chain panels x all 16 row panels = XD 1) streamed all 8 MB of A through every L2 and used each panel
   // twice: 9 MB; XD = 8: 2 row panels of A (1 MB, each used by 16) + all 16 chain panels (8 MB).  Measured (round 6): the tick moves by 1 %
-  // between the best and the worst dealing -- the k loop is not waiting for L2 misses, and it is nowhere near a byte rate: (64 + 64) x 8 B
-  // of operands per k for 64 clocks of the four SIMDs' MFMA time = 16 B/clk per CU, a quarter of the vector-memory path's rate.  The 35 us
-  // of a launch against 27 us of MFMA time are its un-overlapped ends (first loads, the LDS reduction of the k-quarters, stores, ramp and
-  // drain) with one workgroup per CU.
+  // between the best and the worst dealing -- the k loop is not waiting for L2 misses.  In bytes it needs (64 + 64) x 8 B per k for 64 clocks of
+  // the four SIMDs' MFMA time = 16 B/clk per CU; in cache-LINE accesses (a 16-byte fragment load touches 16 lines and uses half of each) it is
+  // within 2x of what the path delivers: without the k split (a 32 x 32 quadrant per wave over the whole k, twice the loads per MFMA, no
+  // LDS reduction) the kernel takes 64-73 us alone against 44 (tools/gemm_lab.hip, round 6).  The 35 us of a launch in the run against 27 us
+  // of MFMA time are its un-overlapped ends with one workgroup per CU.
   int ct, dt, ks = 0;
   const int xd = WN_GEMM_XD;
   if (KS == 1 && tiles_d % xd == 0 && tiles_c % (8 / xd) == 0) {
