@@ -811,7 +811,7 @@ def main():
             t_ = time.perf_counter()
             for key, nm_, run_ in EMULATED:
                 try:
-                    em[key] = emulate_ranks(nm_, 8, dev, 3, 1, args if nm_ == "gauss100" else None, run_)
+                    em[key] = emulate_ranks(nm_, 8, dev, 5, 1, args if nm_ == "gauss100" else None, run_)
                 except Exception as ex:
                     em[key] = {"error": repr(ex)}
             print(f"bench.py: 8 emulated ranks x 4 configurations took {time.perf_counter() - t_:.1f} s", file=sys.stderr)
