@@ -219,6 +219,7 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
     if (inrange) emit_generated(0, qa);  // samples[:,0] = generated(q0)  (:164)
   }
   bool live = inrange && prm.numIter >= 1;
+  int evals_total = 0, prio_now = 0;  // (longest job first: see the end of the iteration)
   unsigned long long st_[16], st_last_ = 0;  // diagnostic builds (-DWN_STAMPS): cycles per phase
 #pragma unroll
   for (int k = 0; k < 16; ++k) st_[k] = 0;
@@ -824,6 +825,15 @@ __global__ __launch_bounds__(64 * K) void wn_orbit_kernel(Params prm) {
       double* const fc = prm.facs ? prm.facs + (size_t)clc * 2 * (size_t)prm.warmupIter : nullptr;
       const double err = Hnan ? NAN : (Hmax - Hmin);
       wn_adapt_update(prm, iter, err, fc, lane == 0, dlt, Hc, p2q, p2n);
+    }
+    // longest job first: a launch is as long as its busiest chain, and a chain that has needed many evaluations per iteration so far goes on
+    // needing them (a funnel-neck / long-orbit chain stays one): such a wave takes its SIMD's issue slots ahead of the wave it shares it with
+    // (BASELINE config 3, six launches: 171 / 135 / 234 / 203 / 213 / 165 ms -> 172 / 132 / 235 / 186 / 208 / 162; scheduling only: the same draws)
+    {
+      evals_total += nevalF + nevalB;
+      const int per_it = evals_total / iter;
+      const int pr = per_it > 2048 ? 3 : per_it > 512 ? 2 : per_it > 128 ? 1 : 0;
+      if (pr != prio_now) { prio_now = pr; if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     }
     iter++;
     if (iter > prm.numIter) live = false;
