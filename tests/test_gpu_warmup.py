@@ -150,3 +150,44 @@ def test_warmup_default_call_adapted_step_size_has_the_oracles_distribution(wa):
     # total leapfrog steps: the same work to 2 % (each chain's count depends on its own H)
     tg, to = (dg[..., 6] + dg[..., 7]).sum(), (do[..., 6] + do[..., 7]).sum()
     assert abs(tg - to) <= 0.02 * to, (tg, to)
+
+
+@pytest.mark.parametrize("what", ["lane_smile_R2P", "coop_dense40_FlowD", "wave_std300_D", "wavelds_dense100_Yoshida", "split_dense200_fixed", "orbit_std60_R2P",
+                                  "fast_diag112_fixed"])
+def test_adapt_quant_bits_on_every_kernel_family(wa, what):
+    """`adapt_quant_bits` lives in the one function every kernel family adapts through (wn_adapt_update, wn_chain.h): a short run with
+    warm-up on each family -- one chain per lane, the cooperative MFMA layout, one chain per wavefront, the dense-LDS engine, split mode,
+    the trajectory-first kernel, the headline kernel's diagonal form -- with 16 bits, against the oracle with the same switch: integers
+    exactly, H / delta / draws to 1e-6 over the whole run, and every adapted value rounded."""
+    from bench import make_dense_problem
+    rng = np.random.default_rng(23)
+    iters, W, bits = 24, 24, 16
+    if what == "lane_smile_R2P":
+        tk, tp, q0, kw, kern = ol.T_SMILE, None, rng.normal(size=(20000, 2)), dict(integrator=ol.I_ADAPT_R2P, H0=0.3, delta0=0.2, M=6), "wn_lane_kernel"
+    elif what == "coop_dense40_FlowD":
+        A, q0 = make_dense_problem(40, 1e2, 24, 5)
+        tk, tp, kw, kern = ol.T_DENSEGAUSS, A.ravel(), dict(integrator=ol.I_ADAPT_FLOWD, H0=0.5, delta0=0.05, M=6), "wn_coop_kernel"
+    elif what == "wave_std300_D":
+        tk, tp, q0, kw, kern = ol.T_STDGAUSS, None, rng.normal(size=(8, 300)), dict(integrator=ol.I_ADAPT_YOSHIDA, H0=0.4, delta0=0.1, M=5), "wn_wave_kernel"
+    elif what == "wavelds_dense100_Yoshida":
+        A, q0 = make_dense_problem(100, 1e2, 10, 5)
+        tk, tp, kw, kern = ol.T_DENSEGAUSS, A.ravel(), dict(integrator=ol.I_ADAPT_YOSHIDA, H0=0.8, delta0=0.1, M=5), "wn_wavelds_kernel"
+    elif what == "split_dense200_fixed":
+        A, q0 = make_dense_problem(200, 1e2, 6, 5)
+        tk, tp, kw, kern = ol.T_DENSEGAUSS, A.ravel(), dict(integrator=ol.I_FIXED, H0=0.4, delta0=0.05, M=5), "split"
+    elif what == "orbit_std60_R2P":
+        tk, tp, q0, kw, kern = ol.T_STDGAUSS, None, rng.normal(size=(18, 60)), dict(integrator=ol.I_ADAPT_R2P, H0=0.5, delta0=0.2, M=6), "wn_orbit_kernel"
+    else:
+        lam = np.logspace(0, 1.5, 112)
+        tk, tp, q0, kw, kern = ol.T_DIAGGAUSS, 1.0 / lam, rng.normal(size=(40, 112)) * np.sqrt(lam), dict(integrator=ol.I_FIXED, H0=0.3, delta0=0.05, M=6), "wn_fast4_kernel"
+    dg, sg, kname = engine_run(wa, tk, tp, q0, iters, W, kw, bits=bits)
+    assert kern in kname, kname
+    chains = sorted(set([0, q0.shape[0] // 2, q0.shape[0] - 1]))
+    for c in chains:
+        o = ol.walnuts(tk, q0[c], tpar=tp, numIter=iters, warmupIter=W, seed=SEED, chain=c, adaptQuantBits=bits, **kw)
+        np.testing.assert_array_equal(dg[c][:, INT_COLS], o["diagnostics"][:, INT_COLS], err_msg=f"{what} chain {c}")
+        np.testing.assert_allclose(dg[c][:, [15, 18]], o["diagnostics"][:, [15, 18]], rtol=1e-6, err_msg=f"{what} chain {c}")
+        np.testing.assert_allclose(sg[c], o["samples"].T, rtol=1e-6, atol=1e-9, err_msg=f"{what} chain {c}")
+    m, _ = np.frexp(dg[chains, 12:, 15])
+    assert np.all(np.ldexp(m, bits + 1) == np.round(np.ldexp(m, bits + 1)))
+    assert len(np.unique(dg[chains[0], :, 15])) > 5
